@@ -1,0 +1,251 @@
+/*
+ * vegasafterglow_amd.h -- C-ABI of the MI355X-native afterglow forward-model engine.
+ *
+ * This is the drop-in boundary for ONE path of VegasAfterglow: the forward-shock
+ * synchrotron light-curve model behind Model.flux_density_grid / Model.flux_density /
+ * Model.flux and the per-walker log-likelihood built on it.  Every entry point states
+ * the reference interface (file:line under the VegasAfterglow tree) it replaces.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the ABI: every call returns 0 on success or a negative
+ *    VAG_E_* code; vag_last_error() returns a thread-local message for the last failure.
+ *  - all physical inputs are in the reference's user units (CGS: erg, cm, s, Hz, rad);
+ *    flux densities come back in erg cm^-2 s^-1 Hz^-1, band fluxes in erg cm^-2 s^-1
+ *    (pybind/pymodel.cpp:368-371,506-508).
+ *  - the *_dev entry points take DEVICE pointers (HBM resident inputs/outputs) and run
+ *    asynchronously on the context's HIP stream; the host-pointer forms stage through
+ *    the context's buffers and synchronise before returning.
+ *  - there is no CPU fallback: without a HIP device vag_ctx_create fails with
+ *    VAG_E_NO_DEVICE.
+ */
+#ifndef VEGASAFTERGLOW_AMD_H
+#define VEGASAFTERGLOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAG_ABI_VERSION 1
+
+/* error codes */
+#define VAG_OK 0
+#define VAG_E_INVALID (-1)   /* bad argument: the reference raises ValueError (pybind/error_handling.h:31-69) */
+#define VAG_E_NO_DEVICE (-2) /* no HIP device / HIP runtime failure at context creation */
+#define VAG_E_HIP (-3)       /* a HIP call failed; message carries hipGetErrorString */
+#define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (reverse shock, SSC, ...) */
+#define VAG_E_CAPACITY (-5)  /* grid larger than the engine's static limits */
+
+/* jet profiles: src/environment/jet.h:84-259 (TophatJet, GaussianJet, PowerLawJet),
+ * math::two_component jet.h:421-437 via PyTwoComponentJet pybind/pymodel.cpp:130-146 */
+#define VAG_JET_TOPHAT 0
+#define VAG_JET_GAUSSIAN 1
+#define VAG_JET_POWERLAW 2
+#define VAG_JET_TWO_COMPONENT 3
+
+/* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
+#define VAG_MEDIUM_ISM 0
+#define VAG_MEDIUM_WIND 1
+
+/*
+ * One forward model = the arguments of
+ *   Model(jet, medium, Observer(lumi_dist, z, theta_obs), Radiation(eps_e, eps_B, p, xi_e),
+ *         resolutions=(phi, theta, t), rtol, axisymmetric=True, radiative_fireball)
+ * (pybind/pybind.cpp:384-422, pybind/pymodel.h:613-649), flattened to plain scalars.
+ * All doubles; the two tags are int32.  Layout is fixed (176 bytes) and is what the
+ * device kernels read straight from HBM.
+ */
+typedef struct vag_model_params {
+    int32_t jet_type;    /* VAG_JET_* */
+    int32_t medium_type; /* VAG_MEDIUM_* */
+    /* jet (unused fields ignored by the profile) */
+    double theta_c;  /* core half-opening angle [rad] */
+    double E_iso;    /* isotropic-equivalent energy (core) [erg] */
+    double Gamma0;   /* initial Lorentz factor (core) */
+    double k_e;      /* PowerLawJet energy index */
+    double k_g;      /* PowerLawJet Lorentz-factor index */
+    double theta_w;  /* TwoComponentJet wing angle [rad] */
+    double E_iso_w;  /* TwoComponentJet wing energy [erg] */
+    double Gamma0_w; /* TwoComponentJet wing Lorentz factor */
+    double duration; /* engine duration T0 [s] (only enters via t0 of reverse shock; kept for parity) */
+    /* medium */
+    double n_ism;  /* ISM number density [cm^-3]; Wind: ISM floor */
+    double A_star; /* Wind parameter */
+    double n0;     /* Wind inner plateau density [cm^-3]; +inf = none */
+    /* observer */
+    double lumi_dist; /* [cm] */
+    double z;
+    double theta_obs; /* [rad] */
+    /* forward-shock radiation */
+    double eps_e;
+    double eps_B;
+    double p;
+    double xi_e;
+    /* numerics */
+    double phi_resol;   /* points per degree */
+    double theta_resol; /* points per degree */
+    double t_resol;     /* points per decade */
+    double rtol;        /* ODE tolerance, (0,1) */
+    int32_t radiative_fireball; /* 1 = radiative losses feed back on dynamics (default) */
+    int32_t reserved;           /* must be 0 */
+} vag_model_params;
+
+/* Fill a params struct with the reference's defaults: Radiation xi_e = 1,
+ * resolutions (0.06, 0.15, 6) (src/config/simulation-defaults.h:58-68), rtol 1e-6,
+ * duration 1 s, n0 = +inf, radiative_fireball = 1, k_e = k_g = 2. */
+void vag_params_default(vag_model_params* p);
+
+/* Validate one params struct exactly like the reference's factories and Model ctor
+ * (pybind/pymodel.cpp:47-186, pybind/pymodel.h:205-260,613-649).  0 or VAG_E_INVALID. */
+int vag_params_validate(const vag_model_params* p);
+
+const char* vag_last_error(void);
+const char* vag_version(void);
+int vag_abi_version(void);
+
+/* Number of visible HIP devices (0 when none / runtime missing). */
+int vag_device_count(void);
+
+/* ---- engine context: one per (process, device); owns stream + workspace in HBM ---- */
+typedef struct vag_ctx vag_ctx;
+
+int vag_ctx_create(int device, vag_ctx** out);
+void vag_ctx_destroy(vag_ctx* ctx);
+/* Use an external HIP stream (hipStream_t passed as void*); NULL = context's own stream. */
+int vag_ctx_set_stream(vag_ctx* ctx, void* hip_stream);
+int vag_ctx_synchronize(vag_ctx* ctx);
+
+/* Static per-model capacity limits of the device grids (rows/time nodes). */
+typedef struct vag_limits {
+    int32_t max_theta; /* theta nodes per model */
+    int32_t max_phi;   /* phi nodes per model */
+    int32_t max_time;  /* time-lattice nodes per row */
+    int32_t max_nu;    /* frequencies per call */
+} vag_limits;
+void vag_get_limits(vag_limits* out);
+
+/*
+ * Model.flux_density_grid(t[nt] ascending, nu[nnu]) -> total[nnu][nt]
+ * (pybind/pybind.cpp:424, pybind/pymodel.cpp:498-514, src/core/observer.h:355-445),
+ * batched over nb independent models sharing (t, nu).  out is [nb][nnu][nt] row-major.
+ */
+int vag_flux_density_grid_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
+                                const double* nu, int nnu, double* out);
+
+/*
+ * Model.flux_density(t[n] ascending, nu[n]) -> total[n]
+ * (pybind/pybind.cpp:427, pybind/pymodel.cpp:373-389, src/core/observer.h:447-538),
+ * batched: out is [nb][n].
+ */
+int vag_flux_density_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, const double* nu,
+                           int n, double* out);
+
+/*
+ * Model.flux(t[nt], nu_min, nu_max, num_nu) -> band flux[nt]
+ * (pybind/pybind.cpp:430, pybind/pymodel.cpp:391-410, src/core/observer.h:555-567,
+ * Boole weights src/core/quadrature.h:153-196); out is [nb][nt].
+ */
+int vag_flux_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                   double nu_max, int num_nu, double* out);
+
+/* Device-pointer forms: params/t/nu/out are HBM addresses; asynchronous on the context stream. */
+int vag_flux_density_grid_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,
+                                    int nt, const double* d_nu, int nnu, double* d_out);
+int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,
+                               const double* d_nu, int n, double* d_out);
+
+/*
+ * Batched log-likelihood: the seam emcee's vectorized log_prob_batch calls
+ * (VegasAfterglow/fitting/samplers.py:61-91 -> fitter.py:503-533).
+ *
+ * Point data (sorted by time, weights normalised to sum N as in fitter.py:407-451):
+ *   chi2 = sum_i w_i ((ln F_obs_i - ln max(F_mod_i, 1e-300)) / (err_i / F_obs_i))^2
+ *   loglike = -0.5 chi2; non-finite chi2 -> -inf (samplers.py:61-70).
+ * The transformer (fitting/utils.py:110-135) is expressed as a slot map: free
+ * parameter d of theta writes field slot[d] (a VAG_P_* index) of a copy of `base`,
+ * as 10**theta when is_log[d] != 0.
+ */
+#define VAG_P_THETA_C 0
+#define VAG_P_E_ISO 1
+#define VAG_P_GAMMA0 2
+#define VAG_P_K_E 3
+#define VAG_P_K_G 4
+#define VAG_P_THETA_W 5
+#define VAG_P_E_ISO_W 6
+#define VAG_P_GAMMA0_W 7
+#define VAG_P_DURATION 8
+#define VAG_P_N_ISM 9
+#define VAG_P_A_STAR 10
+#define VAG_P_N0 11
+#define VAG_P_LUMI_DIST 12
+#define VAG_P_Z 13
+#define VAG_P_THETA_OBS 14
+#define VAG_P_EPS_E 15
+#define VAG_P_EPS_B 16
+#define VAG_P_P 17
+#define VAG_P_XI_E 18
+#define VAG_P_COUNT 19
+
+typedef struct vag_fit_spec {
+    vag_model_params base; /* fixed parameters + numerics */
+    int32_t ndim;          /* number of free parameters (<= 16) */
+    int32_t slot[16];      /* VAG_P_* target of each free parameter */
+    int32_t is_log[16];    /* 1: value = 10**theta */
+    int32_t n_data;        /* number of point observations */
+    int32_t pad;
+    const double* t;        /* [n_data] observer times, ascending [s] */
+    const double* nu;       /* [n_data] frequencies [Hz] */
+    const double* ln_flux;  /* [n_data] ln F_obs */
+    const double* ln_err;   /* [n_data] err/F_obs */
+    const double* weight;   /* [n_data] normalised weights */
+} vag_fit_spec;
+
+/* theta is [nb][ndim] (host); out is [nb] log-likelihoods (host).  Walkers whose
+ * transformed parameters fail validation get -inf, like eval_one's except branch. */
+int vag_loglike_batch(vag_ctx* ctx, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out);
+
+/* Same with theta/out in HBM; the data arrays of spec are host pointers copied once per call
+ * unless identical to the previous call's (cached by content hash). */
+int vag_loglike_batch_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim,
+                          double* d_out);
+
+/*
+ * Model.details(t_min, t_max) intermediates for ONE model (pybind/pymodel.cpp:315-348):
+ * grid sizes first, then arrays copied into caller buffers (any pointer may be NULL).
+ *   phi[n_phi], theta[n_theta], t_src[n_theta][n_t] (engine frame, s),
+ *   Gamma, r (cm), t_comv (s), B (G), N_p, Gamma_th : [n_theta][n_t]
+ */
+typedef struct vag_details_shape {
+    int32_t n_phi, n_theta, n_t, n_reps;
+    int32_t symmetry;     /* 0 structured, 1 phi_symmetric, 2 piecewise, 3 isotropic (src/core/mesh.h:55-60) */
+    int32_t phi_mirrored; /* src/core/mesh.h:74-79 */
+} vag_details_shape;
+
+typedef struct vag_details_out {
+    double* phi;
+    double* theta;
+    double* t_src;
+    double* Gamma;
+    double* r;
+    double* t_comv;
+    double* B;
+    double* N_p;
+    double* Gamma_th;
+} vag_details_out;
+
+int vag_details(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                const vag_details_out* out);
+
+/* Per-stage device timings (ms) of the last batch call, stage names follow the reference's
+ * profiler (pybind/pymodel.h:877-953): grid, dynamics, syn_cells, sync_flux, reduce, total. */
+typedef struct vag_stage_times {
+    float grid_ms, dynamics_ms, cells_ms, flux_ms, reduce_ms, total_ms;
+} vag_stage_times;
+int vag_last_stage_times(vag_ctx* ctx, vag_stage_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEGASAFTERGLOW_AMD_H */

@@ -1,0 +1,247 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+//
+// C-ABI shim over the *real* VegasAfterglow C++ sources, compiled in place from
+// /root/reference by oracle/Makefile into oracle/_ref/libvag_ref.so (git-ignored).
+// No reference source is copied here: this file only calls the reference's public
+// C++ API in the order pybind/pymodel.h:922-961 (PyModel::compute_emission) and
+// pybind/pymodel.h:873-920 (single_shock_emission) do for a forward-shock,
+// synchrotron-only model, and restates the unit conversions of the pybind factories
+// (pybind/pymodel.cpp:47-224,368-410,498-514).
+//
+// It pins the C restatement in oracle/vag_oracle.c (tests/test_oracle_vs_ref.py) and is the
+// "reference" CPU baseline of bench.py when present.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <variant>
+
+#include "../include/vegasafterglow_amd.h"
+#include "afterglow.h"
+
+// pybind/shock_dispatch.h:17-28 restated (that header lives beside pybind-only code)
+std::pair<Coord, Shock> solve_fwd_shock_like(JetVariant const& jet, MediumVariant const& medium, Array const& t_obs,
+                                             Real theta_w, const vag_model_params& p, RadParams const& rad) {
+    return std::visit(
+        [&](auto const& j, auto const& med) {
+            auto coord = auto_grid(j, med, t_obs, theta_w, p.theta_obs, p.z, false, p.phi_resol, p.theta_resol,
+                                   p.t_resol, true);
+            auto shock = generate_fwd_shock(coord, med, j, rad, p.rtol);
+            return std::pair{std::move(coord), std::move(shock)};
+        },
+        jet, medium);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+JetVariant make_jet(const vag_model_params& p) {
+    // pybind/pymodel.cpp:47-146
+    switch (p.jet_type) {
+        case VAG_JET_TOPHAT:
+            return TophatJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, false, p.duration * unit::sec);
+        case VAG_JET_GAUSSIAN:
+            return GaussianJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, false, p.duration * unit::sec);
+        case VAG_JET_POWERLAW:
+            return PowerLawJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, p.k_e, p.k_g, false, p.duration * unit::sec);
+        case VAG_JET_TWO_COMPONENT: {
+            // PyTwoComponentJet (pymodel.cpp:130-146) + convert_unit_jet (pymodel.cpp:188-210)
+            Ejecta jet;
+            jet.eps_k = math::two_component(p.theta_c, p.theta_w, p.E_iso, p.E_iso_w);
+            jet.Gamma0 = math::two_component_plus_one(p.theta_c, p.theta_w, p.Gamma0 - 1, p.Gamma0_w - 1);
+            jet.spreading = false;
+            jet.T0 = p.duration;
+            const auto eps_k_cgs = jet.eps_k;
+            jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
+            const auto deps_dt_cgs = jet.deps_dt;
+            jet.deps_dt = [=](Real phi, Real theta, Real t) {
+                return deps_dt_cgs(phi, theta, t / unit::sec) * (unit::erg / (4 * con::pi * unit::sec));
+            };
+            const auto dm_dt_cgs = jet.dm_dt;
+            jet.dm_dt = [=](Real phi, Real theta, Real t) {
+                return dm_dt_cgs(phi, theta, t / unit::sec) * (unit::g / (4 * con::pi * unit::sec));
+            };
+            jet.T0 *= unit::sec;
+            return jet;
+        }
+    }
+    throw std::invalid_argument("unknown jet_type");
+}
+
+MediumVariant make_medium(const vag_model_params& p) {
+    // pybind/pymodel.cpp:148-186 (k_m == 2 branch)
+    if (p.medium_type == VAG_MEDIUM_ISM) {
+        return ISM(p.n_ism / unit::cm3);
+    }
+    if (p.medium_type == VAG_MEDIUM_WIND) {
+        return Wind(p.A_star, p.n_ism / unit::cm3, p.n0 / unit::cm3);
+    }
+    throw std::invalid_argument("unknown medium_type");
+}
+
+struct Pipeline {
+    Coord coord;
+    Shock shock;
+    Observer obs;
+    SynElectronGrid elec;
+    SynPhotonGrid phot;
+};
+
+void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) {
+    RadParams rad{p.eps_e, p.eps_B, p.p, p.xi_e};
+    rad.radiative = p.radiative_fireball != 0;
+    JetVariant jet = make_jet(p);
+    MediumVariant med = make_medium(p);
+    const Real theta_w = con::pi / 2; // pymodel.h:866
+    const Real lumi_dist = p.lumi_dist * unit::cm;
+    auto [coord, shock] = solve_fwd_shock_like(jet, med, t_obs, theta_w, p, rad);
+    out.coord = std::move(coord);
+    out.shock = std::move(shock);
+    out.obs.observe(out.coord, out.shock, lumi_dist, p.z);
+    out.elec = generate_syn_electrons(out.shock, out.coord);
+    out.phot = generate_syn_photons(out.shock, out.elec, out.coord);
+}
+
+} // namespace
+
+#define VAG_REF_API extern "C" __attribute__((visibility("default")))
+
+VAG_REF_API const char* vag_ref_last_error(void) {
+    return g_err.c_str();
+}
+
+// Model.flux_density_grid: out[nnu][nt]
+VAG_REF_API int vag_ref_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                          double* out) {
+    try {
+        Array t_obs = Array::from_shape({size_t(nt)});
+        Array nu_obs = Array::from_shape({size_t(nnu)});
+        for (int i = 0; i < nt; ++i) t_obs(i) = t[i] * unit::sec;
+        for (int i = 0; i < nnu; ++i) nu_obs(i) = nu[i] * unit::Hz;
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
+        MeshGrid F = pl.obs.specific_flux(t_obs, nu_obs, pl.phot);
+        for (int l = 0; l < nnu; ++l)
+            for (int i = 0; i < nt; ++i) out[size_t(l) * nt + i] = F(l, i) / unit::flux_den_cgs;
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Model.flux_density (series): out[n]
+VAG_REF_API int vag_ref_flux_density(const vag_model_params* p, const double* t, const double* nu, int n, double* out) {
+    try {
+        Array t_obs = Array::from_shape({size_t(n)});
+        Array nu_obs = Array::from_shape({size_t(n)});
+        for (int i = 0; i < n; ++i) {
+            t_obs(i) = t[i] * unit::sec;
+            nu_obs(i) = nu[i] * unit::Hz;
+        }
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
+        Array F = pl.obs.specific_flux_series(t_obs, nu_obs, pl.phot);
+        for (int i = 0; i < n; ++i) out[i] = F(i) / unit::flux_den_cgs;
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Model.flux (band): out[nt]
+VAG_REF_API int vag_ref_flux(const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max,
+                             int num_nu, double* out) {
+    try {
+        Array t_obs = Array::from_shape({size_t(nt)});
+        for (int i = 0; i < nt; ++i) t_obs(i) = t[i] * unit::sec;
+        const Array nu_obs = xt::logspace(std::log10(nu_min * unit::Hz), std::log10(nu_max * unit::Hz), size_t(num_nu));
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
+        Array F = pl.obs.flux(t_obs, nu_obs, pl.phot);
+        for (int i = 0; i < nt; ++i) out[i] = F(i) / unit::flux_cgs;
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Model.details-like intermediates.  Two-call protocol: shape first (out == NULL), then arrays.
+// Extra arrays beyond vag_details_out are returned through `extra` (all [n_theta][n_t] unless noted):
+//   extra[0]=gamma_m extra[1]=gamma_c extra[2]=gamma_a extra[3]=gamma_M extra[4]=N_e extra[5]=column_den
+//   extra[6]=nu_m extra[7]=nu_c extra[8]=nu_a extra[9]=nu_M extra[10]=I_nu_max  (code units)
+//   extra[11]=lg2_t extra[12]=lg2_doppler extra[13]=lg2_geom : [n_phi_eff][n_theta][n_t]
+//   extra[14]=log2 I_nu at probe log2-frequencies: [n_theta][n_t][n_probe]
+VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                                const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                                const double* probe_lg2_nu, int n_probe) {
+    try {
+        Array t_obs = Array::from_shape({size_t(2)});
+        t_obs(0) = t_min * unit::sec;
+        t_obs(1) = t_max * unit::sec;
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
+        auto const& c = pl.coord;
+        const size_t nphi = c.phi.size(), nth = c.theta.size(), nt = c.t.shape()[2];
+        shape->n_phi = int(nphi);
+        shape->n_theta = int(nth);
+        shape->n_t = int(nt);
+        shape->n_reps = int(c.theta_reps.size());
+        shape->symmetry = int(c.symmetry);
+        shape->phi_mirrored = c.phi_mirrored ? 1 : 0;
+        const size_t nphi_eff = pl.obs.lg2_t.shape()[0];
+        if (n_phi_eff) *n_phi_eff = int(nphi_eff);
+        if (!out) return 0;
+        auto copy2 = [&](double* dst, auto const& src, double scale) {
+            if (!dst) return;
+            for (size_t j = 0; j < nth; ++j)
+                for (size_t k = 0; k < nt; ++k) dst[j * nt + k] = src(0, j, k) * scale;
+        };
+        if (out->phi)
+            for (size_t i = 0; i < nphi; ++i) out->phi[i] = c.phi(i);
+        if (out->theta)
+            for (size_t j = 0; j < nth; ++j) out->theta[j] = c.theta(j);
+        copy2(out->t_src, c.t, 1 / unit::sec);
+        copy2(out->Gamma, pl.shock.Gamma, 1);
+        copy2(out->r, pl.shock.r, 1 / unit::cm);
+        copy2(out->t_comv, pl.shock.t_comv, 1 / unit::sec);
+        copy2(out->B, pl.shock.B, 1 / unit::Gauss);
+        copy2(out->N_p, pl.shock.N_p, 1);
+        copy2(out->Gamma_th, pl.shock.Gamma_th, 1);
+        auto ex = [&](int idx) -> double* { return (extra && idx < n_extra) ? extra[idx] : nullptr; };
+        for (size_t j = 0; j < nth; ++j)
+            for (size_t k = 0; k < nt; ++k) {
+                auto const& e = pl.elec(0, j, k);
+                auto const& ph = pl.phot(0, j, k);
+                const size_t o = j * nt + k;
+                if (ex(0)) ex(0)[o] = e.gamma_m;
+                if (ex(1)) ex(1)[o] = e.gamma_c;
+                if (ex(2)) ex(2)[o] = e.gamma_a;
+                if (ex(3)) ex(3)[o] = e.gamma_M;
+                if (ex(4)) ex(4)[o] = e.N_e;
+                if (ex(5)) ex(5)[o] = e.column_den;
+                if (ex(6)) ex(6)[o] = ph.nu_m;
+                if (ex(7)) ex(7)[o] = ph.nu_c;
+                if (ex(8)) ex(8)[o] = ph.nu_a;
+                if (ex(9)) ex(9)[o] = ph.nu_M;
+                if (ex(10)) ex(10)[o] = ph.I_nu_max;
+                if (ex(14))
+                    for (int q = 0; q < n_probe; ++q) ex(14)[o * n_probe + q] = ph.compute_log2_I_nu(probe_lg2_nu[q]);
+            }
+        for (size_t i = 0; i < nphi_eff; ++i)
+            for (size_t j = 0; j < nth; ++j)
+                for (size_t k = 0; k < nt; ++k) {
+                    const size_t o = (i * nth + j) * nt + k;
+                    if (ex(11)) ex(11)[o] = pl.obs.lg2_t(i, j, k);
+                    if (ex(12)) ex(12)[o] = pl.obs.lg2_doppler(i, j, k);
+                    if (ex(13)) ex(13)[o] = pl.obs.lg2_geom_factor(i, j, k);
+                }
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}

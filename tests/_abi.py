@@ -1,0 +1,174 @@
+"""ctypes mirror of include/vegasafterglow_amd.h shared by the tests, bench.py and smoke().
+
+Only structure layouts and loaders live here; no arithmetic.  The oracle libraries
+(oracle/liboracle.so, oracle/_ref/libvag_ref.so) are CHECKERS: they are loaded from tests,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT = 0, 1, 2, 3
+MEDIUM_ISM, MEDIUM_WIND = 0, 1
+JET_IDS = {"TophatJet": 0, "GaussianJet": 1, "PowerLawJet": 2, "TwoComponentJet": 3}
+MEDIUM_IDS = {"ISM": 0, "Wind": 1}
+
+
+class ModelParams(C.Structure):
+    _fields_ = [
+        ("jet_type", C.c_int32), ("medium_type", C.c_int32),
+        ("theta_c", C.c_double), ("E_iso", C.c_double), ("Gamma0", C.c_double),
+        ("k_e", C.c_double), ("k_g", C.c_double), ("theta_w", C.c_double),
+        ("E_iso_w", C.c_double), ("Gamma0_w", C.c_double), ("duration", C.c_double),
+        ("n_ism", C.c_double), ("A_star", C.c_double), ("n0", C.c_double),
+        ("lumi_dist", C.c_double), ("z", C.c_double), ("theta_obs", C.c_double),
+        ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
+        ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
+        ("radiative_fireball", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+assert C.sizeof(ModelParams) == 200
+
+
+class DetailsShape(C.Structure):
+    _fields_ = [("n_phi", C.c_int32), ("n_theta", C.c_int32), ("n_t", C.c_int32), ("n_reps", C.c_int32),
+                ("symmetry", C.c_int32), ("phi_mirrored", C.c_int32)]
+
+
+class DetailsOut(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in
+                ("phi", "theta", "t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th")]
+
+
+def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
+                theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
+                n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
+                xi_e=1.0, resolutions=(0.06, 0.15, 6.0), rtol=1e-6, radiative_fireball=True):
+    """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
+    q = ModelParams()
+    q.jet_type = JET_IDS[jet] if isinstance(jet, str) else int(jet)
+    q.medium_type = MEDIUM_IDS[medium] if isinstance(medium, str) else int(medium)
+    q.theta_c, q.E_iso, q.Gamma0, q.k_e, q.k_g = theta_c, E_iso, Gamma0, k_e, k_g
+    q.theta_w, q.E_iso_w, q.Gamma0_w, q.duration = theta_w, E_iso_w, Gamma0_w, duration
+    q.n_ism, q.A_star, q.n0 = n_ism, A_star, n0
+    q.lumi_dist, q.z, q.theta_obs = lumi_dist, z, theta_obs
+    q.eps_e, q.eps_B, q.p, q.xi_e = eps_e, eps_B, p, xi_e
+    q.phi_resol, q.theta_resol, q.t_resol = resolutions
+    q.rtol = rtol
+    q.radiative_fireball = 1 if radiative_fireball else 0
+    q.reserved = 0
+    return q
+
+
+def params_from_golden_config(cfg):
+    """Map a tests/golden/*.npz `config` JSON (reference tests/python/golden/regenerate.py) to params."""
+    jet = dict(cfg["jet"])
+    med = dict(cfg["medium"])
+    kw = dict(jet=jet.pop("type"), medium=med.pop("type"))
+    kw.update(jet)
+    kw.update(med)
+    kw.update(cfg["observer"])
+    kw.update(cfg["fwd_rad"])
+    if "resolutions" in cfg:
+        kw["resolutions"] = tuple(cfg["resolutions"])
+    if "radiative_fireball" in cfg:
+        kw["radiative_fireball"] = cfg["radiative_fireball"]
+    return make_params(**kw)
+
+
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class CpuLib:
+    """Loader for a CPU checker exporting <prefix>_flux_density_grid / _flux_density / _flux / _details."""
+
+    def __init__(self, path, prefix):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        f = getattr(self.lib, prefix + "_flux_density_grid")
+        f.argtypes = [C.POINTER(ModelParams), _dp, C.c_int, _dp, C.c_int, _dp]
+        f.restype = C.c_int
+        f = getattr(self.lib, prefix + "_flux_density")
+        f.argtypes = [C.POINTER(ModelParams), _dp, _dp, C.c_int, _dp]
+        f.restype = C.c_int
+        f = getattr(self.lib, prefix + "_flux")
+        f.argtypes = [C.POINTER(ModelParams), _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]
+        f.restype = C.c_int
+        f = getattr(self.lib, prefix + "_details")
+        f.argtypes = [C.POINTER(ModelParams), C.c_double, C.c_double, C.POINTER(DetailsShape),
+                      C.POINTER(DetailsOut), C.POINTER(_dp), C.c_int, C.POINTER(C.c_int), _dp, C.c_int]
+        f.restype = C.c_int
+        e = getattr(self.lib, prefix + "_last_error")
+        e.restype = C.c_char_p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ValueError(getattr(self.lib, self.prefix + "_last_error")().decode())
+
+    def flux_density_grid(self, prm, t, nu):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        out = np.zeros((nu.size, t.size))
+        self._check(getattr(self.lib, self.prefix + "_flux_density_grid")(
+            C.byref(prm), _p(t), t.size, _p(nu), nu.size, _p(out)))
+        return out
+
+    def flux_density(self, prm, t, nu):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        out = np.zeros(t.size)
+        self._check(getattr(self.lib, self.prefix + "_flux_density")(C.byref(prm), _p(t), _p(nu), t.size, _p(out)))
+        return out
+
+    def flux(self, prm, t, nu_min, nu_max, num_nu):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        out = np.zeros(t.size)
+        self._check(getattr(self.lib, self.prefix + "_flux")(C.byref(prm), _p(t), t.size, nu_min, nu_max,
+                                                              num_nu, _p(out)))
+        return out
+
+    EXTRA_NAMES = ["gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "column_den", "nu_m", "nu_c", "nu_a",
+                   "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe"]
+
+    def details(self, prm, t_min, t_max, probe_lg2_nu=None):
+        fn = getattr(self.lib, self.prefix + "_details")
+        sh = DetailsShape()
+        nphi_eff = C.c_int(0)
+        self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), None, None, 0, C.byref(nphi_eff), None, 0))
+        nth, nt, nphi, npe = sh.n_theta, sh.n_t, sh.n_phi, nphi_eff.value
+        probe = np.ascontiguousarray(probe_lg2_nu if probe_lg2_nu is not None else [], dtype=np.float64)
+        d = {"phi": np.zeros(nphi), "theta": np.zeros(nth)}
+        for n in ("t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th"):
+            d[n] = np.zeros((nth, nt))
+        out = DetailsOut(*[_p(d[n]) for n, _ in DetailsOut._fields_])
+        ex = {}
+        for n in self.EXTRA_NAMES[:11]:
+            ex[n] = np.zeros((nth, nt))
+        for n in self.EXTRA_NAMES[11:14]:
+            ex[n] = np.zeros((npe, nth, nt))
+        ex["lg2_I_probe"] = np.zeros((nth, nt, max(probe.size, 1)))
+        arr = (_dp * 15)(*[_p(ex[n]) for n in self.EXTRA_NAMES])
+        self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), C.byref(out), arr, 15, C.byref(nphi_eff),
+                       _p(probe) if probe.size else None, probe.size))
+        d.update(ex)
+        d["shape"] = dict(n_phi=nphi, n_theta=nth, n_t=nt, n_reps=sh.n_reps, symmetry=sh.symmetry,
+                          phi_mirrored=sh.phi_mirrored, n_phi_eff=npe)
+        return d
+
+
+def load_ref():
+    path = os.path.join(ROOT, "oracle", "_ref", "libvag_ref.so")
+    return CpuLib(path, "vag_ref") if os.path.exists(path) else None
+
+
+def load_oracle(fast=False):
+    path = os.path.join(ROOT, "oracle", "liboracle_fast.so" if fast else "liboracle.so")
+    return CpuLib(path, "vag_oracle") if os.path.exists(path) else None
