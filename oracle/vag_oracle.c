@@ -1,0 +1,1896 @@
+/*
+ * vag_oracle.c -- TEST INFRASTRUCTURE: the CPU parity checker (see vag_oracle.h).
+ *
+ * A scalar, single-threaded C11 restatement of VegasAfterglow's forward-shock
+ * synchrotron light-curve path.  Every function cites the reference file:line it
+ * follows (paths relative to the VegasAfterglow tree).  Written from the algorithm,
+ * with flat arrays instead of xtensor containers; arithmetic order follows the
+ * reference so that results agree to libm/contraction noise (measured <= ~1e-8 rel.;
+ * see tests/test_oracle_vs_ref.py).  Scope: axisymmetric, non-spreading named jets
+ * (TophatJet, GaussianJet, PowerLawJet, TwoComponentJet), ISM / Wind(k=2) media,
+ * forward shock, synchrotron with self-absorption, no SSC / reverse shock.
+ */
+#include "vag_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Units and constants: src/util/macros.h:43-110 (expression order kept so the rounded
+ * values are bit-identical), cutoffs/defaults: src/config/simulation-defaults.h:38-127
+ * ---------------------------------------------------------------------------------------- */
+#define U_LEN 1.5e13
+#define U_CM (1 / U_LEN)
+#define U_SEC (3e10 / U_LEN)
+#define U_CM2 (U_CM * U_CM)
+#define U_CM3 (U_CM * U_CM * U_CM)
+#define U_G (1 / 2e33)
+#define U_GAUSS (8.66e-11 / U_SEC)
+#define U_HZ (1 / U_SEC)
+#define U_ERG (U_G * U_CM * U_CM / U_SEC / U_SEC)
+#define U_FLUX_CGS (U_ERG / U_CM2 / U_SEC)
+#define U_FLUX_DEN_CGS (U_ERG / U_CM2 / U_SEC / U_HZ)
+
+#define C_C 1.0
+#define C_C2 (C_C * C_C)
+#define C_MP (1.67e-24 * U_G)
+#define C_ME (C_MP / 1836)
+#define C_E (4.8e-10 / 4.472136e16 / 5.809475e19 / U_SEC)
+#define C_E2 (C_E * C_E)
+#define C_E3 (C_E2 * C_E)
+#define C_PI 3.14159265358979323846
+#define C_SIGMAT (6.65e-25 * U_CM * U_CM)
+#define C_GAMMA_CUT (1.0 + 1e-6)
+#define C_SIGMA_CUT 1e-6
+
+#define DEF_MIN_THETA_POINTS 36
+#define DEF_THETA_MIN 1e-6
+#define DEF_ODE_RTOL 1e-6
+#define DEF_BINARY_SEARCH_EPS 1e-9
+#define DEF_MAX_ODE_STEPS 100000
+#define DEF_THETA_SAMPLES 200
+
+#define LOG2_10 (2.302585092994045684017991454684364208 / 0.693147180559945309417232121458176568)
+#define M_LN2_ 0.693147180559945309417232121458176568
+#define M_LOG2E_ 1.442695040888963407359924681001892137
+#define M_SQRT3_ 1.732050807568877293527446341505872367
+
+static _Thread_local char g_err[256];
+
+const char* vag_oracle_last_error(void) {
+    return g_err;
+}
+
+static int fail(const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return -1;
+}
+
+static double dmin(double a, double b) {
+    return b < a ? b : a; /* std::min */
+}
+static double dmax(double a, double b) {
+    return a < b ? b : a; /* std::max */
+}
+
+/* src/util/fast-math.h:40-202 with AFTERGLOW_FAST_MATH off: exact libm */
+static double log2_softplus(double x) {
+    if (x > 20.0) return x;
+    if (x < -20.0) return 0.0;
+    return log2(1.0 + exp2(x));
+}
+static double fast_pow(double a, double b) {
+    return exp2(b * log2(a));
+}
+static double log2_broken_power_ratio(double log2_x, double log2_x_break, double s_delta_beta, double s) {
+    return -log2_softplus(s_delta_beta * (log2_x - log2_x_break)) / s;
+}
+
+/* src/core/physics.h:36-61 */
+static double gamma_to_beta(double gamma) {
+    return sqrt((gamma - 1) * (gamma + 1)) / gamma;
+}
+static double adiabatic_idx(double gamma) {
+    return 4.0 / 3.0 + 1 / (3 * gamma);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Jet and medium in code units.  src/environment/jet.h:84-259,421-441,
+ * pybind/pymodel.cpp:47-146,188-210; src/environment/medium.h:50-133
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int type;
+    double theta_c, eps_k, Gamma0; /* eps_k = E_iso/(4 pi) in code units (named jets) */
+    double k_e, k_g, norm;         /* Gaussian: norm = -1/(2 theta_c^2) */
+    double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w; /* two-component (Ejecta built in CGS) */
+    double T0;
+} jet_t;
+
+typedef struct {
+    int type;
+    double rho_ism; /* ISM: n*mp; Wind: floor */
+    double A, r02;  /* Wind */
+} medium_t;
+
+static void jet_init(jet_t* j, const vag_model_params* p) {
+    memset(j, 0, sizeof *j);
+    j->type = p->jet_type;
+    j->theta_c = p->theta_c;
+    j->eps_k = (p->E_iso * U_ERG) / (4 * C_PI);
+    j->Gamma0 = p->Gamma0;
+    j->k_e = p->k_e;
+    j->k_g = p->k_g;
+    j->norm = -1 / (2 * p->theta_c * p->theta_c);
+    j->theta_w = p->theta_w;
+    j->E_iso_cgs = p->E_iso;
+    j->E_iso_w_cgs = p->E_iso_w;
+    j->Gm1 = p->Gamma0 - 1;
+    j->Gm1_w = p->Gamma0_w - 1;
+    j->T0 = p->duration * U_SEC;
+}
+
+static double jet_eps_k(const jet_t* j, double theta) {
+    switch (j->type) {
+        case VAG_JET_TOPHAT: return theta < j->theta_c ? j->eps_k : 0;
+        case VAG_JET_GAUSSIAN: return j->eps_k * exp(theta * theta * j->norm);
+        case VAG_JET_POWERLAW: return j->eps_k / (1 + fast_pow(theta / j->theta_c, j->k_e));
+        default: { /* math::two_component (jet.h:421-433) in CGS, then convert_unit_jet */
+            double h = theta <= j->theta_c ? j->E_iso_cgs : (theta <= j->theta_w ? j->E_iso_w_cgs : 0.);
+            return h * (U_ERG / (4 * C_PI));
+        }
+    }
+}
+
+static double jet_Gamma0(const jet_t* j, double theta) {
+    switch (j->type) {
+        case VAG_JET_TOPHAT: return theta < j->theta_c ? j->Gamma0 : 1;
+        case VAG_JET_GAUSSIAN: return (j->Gamma0 - 1) * exp(theta * theta * j->norm) + 1;
+        case VAG_JET_POWERLAW: return (j->Gamma0 - 1) / (1 + fast_pow(theta / j->theta_c, j->k_g)) + 1;
+        default: {
+            double h = theta <= j->theta_c ? j->Gm1 : (theta <= j->theta_w ? j->Gm1_w : 0.);
+            return h + 1;
+        }
+    }
+}
+
+static void medium_init(medium_t* m, const vag_model_params* p) {
+    memset(m, 0, sizeof *m);
+    m->type = p->medium_type;
+    if (m->type == VAG_MEDIUM_ISM) {
+        m->rho_ism = (p->n_ism / U_CM3) * C_MP;
+    } else {
+        const double n_ism = p->n_ism / U_CM3, n0 = p->n0 / U_CM3;
+        m->A = p->A_star * 5e11 * U_G / U_CM;
+        m->rho_ism = n_ism * C_MP;
+        m->r02 = m->A / (n0 * 1.3 * C_MP);
+    }
+}
+
+static double medium_rho(const medium_t* m, double r) {
+    if (m->type == VAG_MEDIUM_ISM) return m->rho_ism;
+    return m->A / (m->r02 + r * r) + m->rho_ism;
+}
+
+static double medium_mass(const medium_t* m, double r) {
+    if (m->type == VAG_MEDIUM_ISM) return m->rho_ism * r * r * r / 3.0;
+    double mass = m->rho_ism * r * r * r / 3.0;
+    if (m->A != 0) {
+        if (m->r02 > 0) {
+            const double a = sqrt(m->r02);
+            mass += m->A * (r - a * atan(r / a));
+        } else {
+            mass += m->A * r;
+        }
+    }
+    return mass;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DOPRI5 with step-size control and dense output, boost::odeint semantics:
+ * external/boost/numeric/odeint/stepper/runge_kutta_dopri5.hpp:88-258,
+ * controlled_runge_kutta.hpp:56-156,752-782, dense_output_runge_kutta.hpp:324-361,
+ * algebra/default_operations.hpp:431-447, integrate/max_step_checker.hpp:92
+ * ---------------------------------------------------------------------------------------- */
+#define ODE_MAXN 8
+typedef void (*rhs_fn)(const double* x, double* dxdt, double t, void* ctx);
+
+typedef struct {
+    int n;
+    double eps_abs, eps_rel;
+    double x[2][ODE_MAXN], dx[2][ODE_MAXN];
+    int cur;
+    double k2[ODE_MAXN], k3[ODE_MAXN], k4[ODE_MAXN], k5[ODE_MAXN], k6[ODE_MAXN];
+    double t, t_old, dt;
+    int deriv_init;
+} dopri5_t;
+
+static void dopri5_init(dopri5_t* s, int n, double eps_abs, double eps_rel, const double* x0, double t0, double dt0) {
+    s->n = n;
+    s->eps_abs = eps_abs;
+    s->eps_rel = eps_rel;
+    s->cur = 0;
+    for (int i = 0; i < n; ++i) s->x[0][i] = x0[i];
+    s->t = t0;
+    s->dt = dt0;
+    s->deriv_init = 0;
+}
+
+/* one controlled trial; returns 1 on success */
+static int dopri5_try_step(dopri5_t* s, rhs_fn f, void* ctx) {
+    const double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    const double b21 = 1.0 / 5;
+    const double b31 = 3.0 / 40, b32 = 9.0 / 40;
+    const double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
+    const double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729;
+    const double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176,
+                 b65 = -5103.0 / 18656;
+    const double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    const double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
+                 dc5 = c5 - -92097.0 / 339200, dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+    const int n = s->n;
+    const double* in = s->x[s->cur];
+    const double* k1 = s->dx[s->cur];
+    double* out = s->x[1 - s->cur];
+    double* k7 = s->dx[1 - s->cur];
+    double xt[ODE_MAXN], xerr[ODE_MAXN];
+    const double t = s->t, dt = s->dt;
+
+    for (int i = 0; i < n; ++i) xt[i] = 1.0 * in[i] + (dt * b21) * k1[i];
+    f(xt, s->k2, t + dt * a2, ctx);
+    for (int i = 0; i < n; ++i) xt[i] = 1.0 * in[i] + (dt * b31) * k1[i] + (dt * b32) * s->k2[i];
+    f(xt, s->k3, t + dt * a3, ctx);
+    for (int i = 0; i < n; ++i) xt[i] = 1.0 * in[i] + (dt * b41) * k1[i] + (dt * b42) * s->k2[i] + (dt * b43) * s->k3[i];
+    f(xt, s->k4, t + dt * a4, ctx);
+    for (int i = 0; i < n; ++i)
+        xt[i] = 1.0 * in[i] + (dt * b51) * k1[i] + (dt * b52) * s->k2[i] + (dt * b53) * s->k3[i] + (dt * b54) * s->k4[i];
+    f(xt, s->k5, t + dt * a5, ctx);
+    for (int i = 0; i < n; ++i)
+        xt[i] = 1.0 * in[i] + (dt * b61) * k1[i] + (dt * b62) * s->k2[i] + (dt * b63) * s->k3[i] + (dt * b64) * s->k4[i] +
+                (dt * b65) * s->k5[i];
+    f(xt, s->k6, t + dt, ctx);
+    for (int i = 0; i < n; ++i)
+        out[i] = 1.0 * in[i] + (dt * c1) * k1[i] + (dt * c3) * s->k3[i] + (dt * c4) * s->k4[i] + (dt * c5) * s->k5[i] +
+                 (dt * c6) * s->k6[i];
+    f(out, k7, t + dt, ctx);
+    for (int i = 0; i < n; ++i)
+        xerr[i] = (dt * dc1) * k1[i] + (dt * dc3) * s->k3[i] + (dt * dc4) * s->k4[i] + (dt * dc5) * s->k5[i] +
+                  (dt * dc6) * s->k6[i] + (dt * dc7) * k7[i];
+
+    double err = 0;
+    for (int i = 0; i < n; ++i) {
+        const double e = fabs(xerr[i]) / (s->eps_abs + s->eps_rel * (1.0 * fabs(in[i]) + (1.0 * fabs(dt)) * fabs(k1[i])));
+        err = dmax(err, e);
+    }
+    if (err > 1.0) {
+        s->dt = dt * dmax(9.0 / 10.0 * pow(err, -1.0 / (4 - 1)), 1.0 / 5.0);
+        return 0;
+    }
+    s->t = t + dt;
+    if (err < 0.5) {
+        err = dmax(pow(5.0, -5.0), err);
+        s->dt = dt * (9.0 / 10.0 * pow(err, -1.0 / 5));
+    }
+    return 1;
+}
+
+/* dense-output do_step; returns 0 ok, -1 after 500 consecutive rejections */
+static int dopri5_do_step(dopri5_t* s, rhs_fn f, void* ctx) {
+    if (!s->deriv_init) {
+        f(s->x[s->cur], s->dx[s->cur], s->t, ctx);
+        s->deriv_init = 1;
+    }
+    s->t_old = s->t;
+    int fails = 0;
+    while (!dopri5_try_step(s, f, ctx)) {
+        if (++fails >= 500) return -1;
+    }
+    s->cur = 1 - s->cur;
+    return 0;
+}
+
+static void dopri5_calc_state(const dopri5_t* s, double t, double* x) {
+    const double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+    const double* x_old = s->x[1 - s->cur];
+    const double* k1 = s->dx[1 - s->cur];
+    const double* k7 = s->dx[s->cur];
+    const double dt = s->t - s->t_old;
+    const double theta = (t - s->t_old) / dt;
+    const double X1 = 5.0 * (2558722523.0 - 31403016.0 * theta) / 11282082432.0;
+    const double X3 = 100.0 * (882725551.0 - 15701508.0 * theta) / 32700410799.0;
+    const double X4 = 25.0 * (443332067.0 - 31403016.0 * theta) / 1880347072.0;
+    const double X5 = 32805.0 * (23143187.0 - 3489224.0 * theta) / 199316789632.0;
+    const double X6 = 55.0 * (29972135.0 - 7076736.0 * theta) / 822651844.0;
+    const double X7 = 10.0 * (7414447.0 - 829305.0 * theta) / 29380423.0;
+    const double theta_m_1 = theta - 1.0;
+    const double theta_sq = theta * theta;
+    const double A = theta_sq * (3.0 - 2.0 * theta);
+    const double B = theta_sq * theta_m_1;
+    const double C = theta_sq * theta_m_1 * theta_m_1;
+    const double D = theta * theta_m_1 * theta_m_1;
+    const double b1_theta = A * b1 - C * X1 + D;
+    const double b3_theta = A * b3 + C * X3;
+    const double b4_theta = A * b4 - C * X4;
+    const double b5_theta = A * b5 + C * X5;
+    const double b6_theta = A * b6 - C * X6;
+    const double b7_theta = B + C * X7;
+    for (int i = 0; i < s->n; ++i)
+        x[i] = 1.0 * x_old[i] + (dt * b1_theta) * k1[i] + (dt * b3_theta) * s->k3[i] + (dt * b4_theta) * s->k4[i] +
+               (dt * b5_theta) * s->k5[i] + (dt * b6_theta) * s->k6[i] + (dt * b7_theta) * k7[i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Grid container: src/core/mesh.h:66-95 (Coord), axisymmetric => one phi slice of t
+ * ---------------------------------------------------------------------------------------- */
+enum { SYM_STRUCTURED = 0, SYM_PHI_SYMMETRIC = 1, SYM_PIECEWISE = 2, SYM_ISOTROPIC = 3 };
+
+typedef struct {
+    int n_phi, n_theta, n_t, n_reps;
+    double* phi;
+    double* theta;
+    double* t; /* [n_theta][n_t] engine-frame lattice (phi slice 0) */
+    int* reps; /* representative theta indices */
+    int symmetry, phi_mirrored;
+    double theta_view;
+} coord_t;
+
+static void coord_free(coord_t* c) {
+    free(c->phi);
+    free(c->theta);
+    free(c->t);
+    free(c->reps);
+    memset(c, 0, sizeof *c);
+}
+
+/* xt::linspace / xt::logspace: external/xtensor/generators/xbuilder.hpp:231-280,460-484 */
+static void linspace(double start, double stop, int n, double* out) {
+    const double step = (stop - start) / fmax(1.0, (double)(n - 1));
+    for (int i = 0; i < n; ++i) out[i] = (n > 1 && i == n - 1) ? stop : start + step * (double)i;
+}
+static void logspace10(double start, double stop, int n, double* out) {
+    linspace(start, stop, n, out);
+    for (int i = 0; i < n; ++i) out[i] = pow(10.0, out[i]);
+}
+
+/* src/core/grid-refinement.h:33-35 */
+static double structure_weight(double Gamma) {
+    return Gamma * sqrt(dmax((Gamma - 1) * Gamma, 0.0));
+}
+
+/* src/core/grid-refinement.h:41-86 */
+static int find_jet_jumps(const jet_t* jet, double gamma_cut, double* jumps, int max_jumps) {
+    const int n_scan = 512;
+    const double eps = DEF_BINARY_SEARCH_EPS;
+    const double theta_lo = DEF_THETA_MIN;
+    const double theta_hi = C_PI / 2;
+    const double dtheta = (theta_hi - theta_lo) / (n_scan - 1);
+    if (jet_Gamma0(jet, theta_hi) >= gamma_cut) {
+        jumps[0] = theta_hi;
+        return 1;
+    }
+    int n = 0;
+    double prev_th = theta_lo;
+    double prev_G = jet_Gamma0(jet, theta_lo);
+    for (int j = 1; j < n_scan; ++j) {
+        const double cur_th = theta_lo + dtheta * (double)j;
+        const double cur_G = jet_Gamma0(jet, cur_th);
+        if (prev_G >= gamma_cut || cur_G >= gamma_cut) {
+            const double dG = fabs(cur_G - prev_G);
+            const double scale = dmax(prev_G - 1, cur_G - 1);
+            if (scale > 0 && dG > 0.5 * scale) {
+                double lo = prev_th, hi = cur_th;
+                while (hi - lo > eps) {
+                    const double mid = 0.5 * (lo + hi);
+                    const double G_mid = jet_Gamma0(jet, mid);
+                    if (fabs(G_mid - prev_G) < fabs(G_mid - cur_G)) {
+                        lo = mid;
+                    } else {
+                        hi = mid;
+                    }
+                }
+                if (n < max_jumps) jumps[n++] = prev_G > cur_G ? lo : hi;
+            }
+        }
+        prev_th = cur_th;
+        prev_G = cur_G;
+    }
+    return n;
+}
+
+/* src/core/grid-refinement.h:89-111 */
+static void find_theta_range(const jet_t* jet, double gamma_cut, double* th_min, double* th_max) {
+    const int n_scan = 512;
+    const double theta_lo = DEF_THETA_MIN;
+    const double theta_hi = C_PI / 2;
+    double theta_max = theta_hi, theta_min = theta_lo;
+    const double step = (theta_hi - theta_lo) / n_scan;
+    for (double th = theta_hi; th >= theta_lo; th -= step) {
+        if (jet_Gamma0(jet, th) >= gamma_cut) {
+            theta_max = th;
+            break;
+        }
+    }
+    for (double th = theta_lo; th <= theta_hi; th += step) {
+        if (jet_Gamma0(jet, th) >= gamma_cut) {
+            theta_min = th;
+            break;
+        }
+    }
+    *th_min = theta_min;
+    *th_max = theta_max;
+}
+
+/* src/core/grid-refinement.h:138-189.  Returns malloc'ed x_out[num]. */
+static double* inverse_cdf_sampling(rhs_fn pdf, void* ctx, double min, double max, int num, int sample_num,
+                                    int log_sample, int midpoint) {
+    const double rtol = DEF_ODE_RTOL;
+    double* x_i = malloc(sizeof(double) * sample_num);
+    double* cdf_i = calloc(sample_num, sizeof(double));
+    if (log_sample)
+        logspace10(log10(min), log10(max), sample_num, x_i);
+    else
+        linspace(min, max, sample_num, x_i);
+
+    dopri5_t st;
+    const double x0 = 0;
+    dopri5_init(&st, 1, rtol, rtol, &x0, min, (max - min) / 1e3);
+    for (int k = 1, steps = 0; st.t <= max;) {
+        if (dopri5_do_step(&st, pdf, ctx) != 0) break;
+        if (++steps > DEF_MAX_ODE_STEPS) break;
+        while (k < sample_num && st.t > x_i[k]) {
+            dopri5_calc_state(&st, x_i[k], &cdf_i[k]);
+            ++k;
+        }
+    }
+
+    double* cdf_out = malloc(sizeof(double) * (num > 0 ? num : 1));
+    const double front = cdf_i[0], back = cdf_i[sample_num - 1];
+    if (midpoint) {
+        for (int k = 0; k < num; ++k) cdf_out[k] = front + (back - front) * ((double)k + 0.5) / num;
+    } else {
+        linspace(front, back, num, cdf_out);
+    }
+    double* x_out = calloc(num > 0 ? num : 1, sizeof(double));
+    for (int k = 0; k < num; ++k) {
+        for (int j = 0; j < sample_num; ++j) {
+            if (cdf_out[k] <= cdf_i[j]) {
+                if (j == 0) {
+                    x_out[k] = x_i[j];
+                } else {
+                    const double denom = cdf_i[j] - cdf_i[j - 1];
+                    if (denom > 0) {
+                        const double slope = (x_i[j] - x_i[j - 1]) / denom;
+                        x_out[k] = x_i[j - 1] + slope * (cdf_out[k] - cdf_i[j - 1]);
+                    } else {
+                        x_out[k] = x_i[j - 1];
+                    }
+                }
+                break;
+            }
+        }
+    }
+    free(x_i);
+    free(cdf_i);
+    free(cdf_out);
+    return x_out;
+}
+
+/* src/core/grid-refinement.h:191-291 */
+typedef struct {
+    const jet_t* jet;
+    double theta_v, core_weight, view_weight, Gamma_peak_sq, Gamma_v_sq, doppler_alpha, floor_weight;
+} theta_pdf_ctx;
+
+static void theta_pdf(const double* cdf, double* pdf, double theta, void* vctx) {
+    (void)cdf;
+    const theta_pdf_ctx* c = vctx;
+    const double Gamma = jet_Gamma0(c->jet, theta);
+    const double beta = gamma_to_beta(Gamma);
+    const double doppler = (1 - beta) / (1 - beta * cos(theta - c->theta_v));
+    const double structure = structure_weight(Gamma);
+    const double dtheta = theta - c->theta_v;
+    *pdf = c->core_weight * c->Gamma_peak_sq * theta / (1.0 + c->Gamma_peak_sq * theta * theta) +
+           c->view_weight * c->Gamma_v_sq * fabs(dtheta) / (1.0 + c->Gamma_v_sq * dtheta * dtheta) +
+           (1 + c->doppler_alpha * doppler) * structure + c->floor_weight;
+}
+
+static size_t beam_pts(double log_decades, double theta_resol, double beam_coeff, double offset) {
+    return (size_t)(dmax(0.0, log_decades - offset) * theta_resol * beam_coeff);
+}
+
+static double* adaptive_theta_grid(const jet_t* jet, double theta_min, double theta_max, size_t base_pts, double theta_v,
+                                   double theta_resol, int* n_out) {
+    const double core_beam_coeff = 55.0, view_beam_coeff = 25.0, doppler_alpha0 = 12.0, floor_fraction = 0.25;
+    const int scan_pts = 100;
+    const double theta_extent = theta_max - theta_min;
+    double peak_weight = 0, Gamma_peak = 1.0, struct_sum = 0, Gamma_v = 1.0;
+    int last_bright = 0;
+    for (int i = 0; i <= scan_pts; ++i) {
+        const double theta = theta_min + theta_extent * i / scan_pts;
+        const double Gamma = jet_Gamma0(jet, theta);
+        const double w = structure_weight(Gamma);
+        struct_sum += w;
+        if (w > peak_weight) {
+            peak_weight = w;
+            Gamma_peak = Gamma;
+            last_bright = i;
+        } else if (w > 0.01 * peak_weight) {
+            last_bright = i;
+        }
+        const double dth = theta - theta_v;
+        Gamma_v = dmax(Gamma_v, Gamma / sqrt(1.0 + Gamma * Gamma * dth * dth));
+    }
+    const double floor_weight = floor_fraction * peak_weight;
+    const double CDF_est = (struct_sum / scan_pts + floor_weight) * theta_extent;
+    const double theta_bright = theta_min + theta_extent * last_bright / scan_pts;
+
+    Gamma_peak = dmax(Gamma_peak, Gamma_v);
+    const double doppler_alpha = doppler_alpha0 * sqrt(peak_weight / dmax(structure_weight(Gamma_v), 1.0));
+    const double beam_offset = 1.0;
+    const double Gamma_peak_sq = Gamma_peak * Gamma_peak;
+    const double Gamma_v_sq = Gamma_v * Gamma_v;
+    const size_t core_beam_pts =
+        beam_pts(log10(dmax(1.0, Gamma_peak * (theta_bright - theta_min))), theta_resol, core_beam_coeff, beam_offset);
+    const size_t view_beam_pts =
+        (theta_v * Gamma_peak > 3.0)
+            ? beam_pts(log10(dmax(1.0, Gamma_v * dmax(theta_v - theta_min, theta_max - theta_v))), theta_resol,
+                       view_beam_coeff, 0.0)
+            : 0;
+    const size_t total_pts = base_pts + core_beam_pts + view_beam_pts;
+
+    const double core_cdf =
+        0.5 * log((1.0 + Gamma_peak_sq * theta_max * theta_max) / (1.0 + Gamma_peak_sq * theta_min * theta_min));
+    const double core_weight =
+        (core_beam_pts > 0 && core_cdf > 0) ? (double)core_beam_pts / base_pts * CDF_est / core_cdf : 0.0;
+    const double theta_v_left = theta_v - theta_min;
+    const double theta_v_right = theta_max - theta_v;
+    const double view_cdf = 0.5 * (log(1.0 + Gamma_v_sq * theta_v_left * theta_v_left) +
+                                   log(1.0 + Gamma_v_sq * theta_v_right * theta_v_right));
+    const double view_weight =
+        (view_beam_pts > 0 && view_cdf > 0) ? (double)view_beam_pts / base_pts * CDF_est / view_cdf : 0.0;
+
+    theta_pdf_ctx ctx = {jet, theta_v, core_weight, view_weight, Gamma_peak_sq, Gamma_v_sq, doppler_alpha, floor_weight};
+    *n_out = (int)total_pts;
+    return inverse_cdf_sampling(theta_pdf, &ctx, theta_min, theta_max, (int)total_pts, DEF_THETA_SAMPLES, 1, 0);
+}
+
+static int cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+
+/* src/core/grid-refinement.cpp:136-160 */
+static int jump_refinement_grid(const double* jumps, int n_jumps, double theta_min, double theta_max, double avg_spacing,
+                                double* points) {
+    int n = 0;
+    const double tight = avg_spacing / 8;
+    for (int idx = 0; idx < n_jumps; ++idx) {
+        const double jump_theta = jumps[idx];
+        if (jump_theta >= C_PI / 2 - 0.01) continue;
+        if (jump_theta - tight >= theta_min) points[n++] = jump_theta - tight;
+        if (jump_theta + tight <= theta_max) points[n++] = jump_theta + tight;
+        if (jump_theta >= theta_min && jump_theta <= theta_max) points[n++] = jump_theta;
+    }
+    qsort(points, n, sizeof(double), cmp_double);
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (m == 0 || points[m - 1] != points[i]) points[m++] = points[i];
+    return m;
+}
+
+/* src/core/grid-refinement.h:362-393 */
+static int merge_grids(const double* a, int na, const double* b, int nb, double* out) {
+    int n = 0, i = 0, j = 0;
+#define ADD_UNIQUE(v)                          \
+    do {                                       \
+        const double v_ = (v);                 \
+        if (n == 0 || out[n - 1] != v_) out[n++] = v_; \
+    } while (0)
+    while (i < na && j < nb) {
+        if (a[i] <= b[j]) {
+            ADD_UNIQUE(a[i++]);
+            if (a[i - 1] == b[j]) j++;
+        } else {
+            ADD_UNIQUE(b[j++]);
+        }
+    }
+    while (i < na) ADD_UNIQUE(a[i++]);
+    while (j < nb) ADD_UNIQUE(b[j++]);
+#undef ADD_UNIQUE
+    return n;
+}
+
+/* src/core/grid-refinement.h:296-360 */
+typedef struct {
+    const jet_t* jet;
+    const double* theta_grid;
+    const double* dcos;
+    int n_theta;
+    double cos_tv, sin_tv, floor_weight;
+} phi_pdf_ctx;
+
+static double phi_weight(const phi_pdf_ctx* c, double phi) {
+    const double cos_phi = cos(phi);
+    double w = 0;
+    for (int it = 0; it < c->n_theta; ++it) {
+        const double theta = c->theta_grid[it];
+        const double Gamma = jet_Gamma0(c->jet, theta);
+        const double beta = gamma_to_beta(Gamma);
+        const double cos_alpha = cos(theta) * c->cos_tv + sin(theta) * c->sin_tv * cos_phi;
+        const double a = (1 - beta) / (1 - beta * cos_alpha);
+        w += a * structure_weight(Gamma) * c->dcos[it];
+    }
+    return w;
+}
+
+static void phi_pdf(const double* cdf, double* pdf, double phi, void* vctx) {
+    (void)cdf;
+    const phi_pdf_ctx* c = vctx;
+    *pdf = phi_weight(c, phi) + c->floor_weight;
+}
+
+static double* adaptive_phi_grid(const jet_t* jet, size_t phi_num, double theta_v, const double* theta_grid, int n_theta,
+                                 int is_axisymmetric, double phi_max, double self_boost_cap, int* n_out) {
+    if (theta_v == 0 && is_axisymmetric) {
+        double* out = malloc(sizeof(double) * (phi_num > 0 ? phi_num : 1));
+        linspace(0., 2 * C_PI, (int)phi_num, out);
+        *n_out = (int)phi_num;
+        return out;
+    }
+    const int half_range = phi_max < 2 * C_PI;
+    double* dcos = malloc(sizeof(double) * n_theta);
+    for (int it = 0; it < n_theta; ++it) {
+        const double left = (it == 0) ? 0.0 : 0.5 * (theta_grid[it - 1] + theta_grid[it]);
+        const double right = (it == n_theta - 1) ? theta_grid[it] : 0.5 * (theta_grid[it] + theta_grid[it + 1]);
+        dcos[it] = fabs(cos(left) - cos(right));
+    }
+    phi_pdf_ctx ctx = {jet, theta_grid, dcos, n_theta, cos(theta_v), sin(theta_v), 0.0};
+    const int scan_pts = 100;
+    double peak_weight = 0, sum_weight = 0;
+    for (int s = 0; s <= scan_pts; ++s) {
+        const double phi = phi_max * (double)s / scan_pts;
+        const double w = phi_weight(&ctx, phi);
+        peak_weight = dmax(peak_weight, w);
+        sum_weight += w;
+    }
+    const double floor_weight = 0.05 * peak_weight;
+    if (self_boost_cap > 0 && peak_weight > 0) {
+        const double mean_pdf = sum_weight / (scan_pts + 1) + floor_weight;
+        const double concentration = (peak_weight + floor_weight) / mean_pdf;
+        double boost = concentration / 5;
+        boost = boost < 1.0 ? 1.0 : (self_boost_cap < boost ? self_boost_cap : boost); /* std::clamp */
+        phi_num = (size_t)((double)phi_num * boost);
+    }
+    ctx.floor_weight = floor_weight;
+    double* out = inverse_cdf_sampling(phi_pdf, &ctx, 0, phi_max, (int)phi_num, DEF_THETA_SAMPLES, 0, half_range);
+    free(dcos);
+    *n_out = (int)phi_num;
+    return out;
+}
+
+/* src/core/grid-refinement.h:402-453 */
+static double estimate_t_dec(const jet_t* jet, const medium_t* med, double theta) {
+    const double gamma = jet_Gamma0(jet, theta);
+    const double beta = gamma_to_beta(gamma);
+    double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2);
+    if (jet->type == VAG_JET_TWO_COMPONENT) m_jet /= (1.0 + 0.0); /* Ejecta carries sigma0 == 0 */
+    const double target = m_jet / gamma;
+    const double r_min = 1e-3;
+    const double r_max = r_min * pow(10.0, 40.0);
+    if (target <= 0) return r_min * (1 - beta) / (beta * C_C);
+
+    if (med->type == VAG_MEDIUM_ISM) {
+        const double rho = medium_rho(med, r_min);
+        if (rho > 0) {
+            const double r3_dec = r_min * r_min * r_min + 3 * target / rho;
+            const double r_dec = cbrt(dmax(r3_dec, 0.0));
+            return dmin(r_dec, r_max) * (1 - beta) / (beta * C_C);
+        }
+        return r_max * (1 - beta) / (beta * C_C);
+    }
+    const int N = 256;
+    const double u_min = log(1e-3);
+    const double u_max = u_min + 40 * log(10.0);
+    const double du = (u_max - u_min) / N;
+    double mass = 0;
+    double r_prev = exp(u_min);
+    double f_prev = medium_rho(med, r_prev) * r_prev * r_prev;
+    for (int i = 1; i <= N; ++i) {
+        const double r_i = exp(u_min + i * du);
+        const double f_i = medium_rho(med, r_i) * r_i * r_i;
+        const double dr = r_i - r_prev;
+        mass += 0.5 * (f_prev + f_i) * dr;
+        if (mass >= target) {
+            const double r_dec = r_prev + (target - (mass - 0.5 * (f_prev + f_i) * dr)) / f_i;
+            return r_dec * (1 - beta) / (beta * C_C);
+        }
+        f_prev = f_i;
+        r_prev = r_i;
+    }
+    return exp(u_max) * (1 - beta) / (beta * C_C);
+}
+
+/* src/core/grid-refinement.h:533-569: grid[n] */
+static void logspace_with_band_refinement(double ts, double t_end, double b_lo, double b_hi, size_t n, double factor,
+                                          double* grid) {
+    b_lo = dmax(b_lo, ts);
+    b_hi = dmin(b_hi, t_end);
+    if (!(b_hi > b_lo) || n < 8) {
+        logspace10(log10(ts), log10(t_end), (int)n, grid);
+        return;
+    }
+    const double l0 = log10(ts), l1 = log10(b_lo), l2 = log10(b_hi), l3 = log10(t_end);
+    const double w1 = l1 - l0, w2 = factor * (l2 - l1), w3 = l3 - l2;
+    const size_t segs = n - 1;
+    size_t n1 = (size_t)round((double)segs * w1 / (w1 + w2 + w3));
+    size_t n3 = (size_t)round((double)segs * w3 / (w1 + w2 + w3));
+    if (segs - 2 < n1) n1 = segs - 2;
+    if (segs - 1 - n1 - 1 < n3) n3 = segs - 1 - n1 - 1;
+    const size_t n2 = segs - n1 - n3;
+    size_t idx = 0;
+    for (size_t k = 0; k < n1; ++k) grid[idx++] = l0 + (l1 - l0) * (double)k / (double)n1;
+    for (size_t k = 0; k < n2; ++k) grid[idx++] = l1 + (l2 - l1) * (double)k / (double)n2;
+    for (size_t k = 0; k <= n3; ++k) grid[idx++] = (n3 > 0) ? l2 + (l3 - l2) * (double)k / (double)n3 : l3;
+    for (size_t k = 0; k < n; ++k) grid[k] = pow(10.0, grid[k]);
+}
+
+/* Coord::detect_symmetry, src/core/mesh.h:121-187 (non-spreading, isotropic medium) */
+static void detect_symmetry(coord_t* c, const jet_t* jet) {
+    c->reps = malloc(sizeof(int) * c->n_theta);
+    c->n_reps = 0;
+    c->reps[c->n_reps++] = 0;
+    for (int j = 1; j < c->n_theta; ++j) {
+        const double ta = c->theta[j - 1], tb = c->theta[j];
+        if (jet_eps_k(jet, ta) != jet_eps_k(jet, tb) || jet_Gamma0(jet, ta) != jet_Gamma0(jet, tb)) {
+            c->reps[c->n_reps++] = j;
+        }
+    }
+    if (c->n_reps == 1)
+        c->symmetry = SYM_ISOTROPIC;
+    else if (c->n_reps < c->n_theta)
+        c->symmetry = SYM_PIECEWISE;
+    else
+        c->symmetry = SYM_PHI_SYMMETRIC;
+}
+
+/* build_time_grid + scan_time_bounds + compute_time_grid_size + store_time_grid,
+ * src/core/grid-refinement.h:472-528,571-636 (forward shock only, axisymmetric => phi_size 1) */
+static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_min, double t_max, double z,
+                            double t_resol) {
+    const int nth = c->n_theta;
+    const double t_end = 1.01 * t_max / (1 + z);
+    const double cos_tv = cos(c->theta_view), sin_tv = sin(c->theta_view);
+    double min_raw = t_end, min_guarded = t_end, min_cut = t_end;
+    double* t_dec = malloc(sizeof(double) * nth);
+    for (int j = 0; j < nth; ++j) {
+        const double b = gamma_to_beta(jet_Gamma0(jet, c->theta[j]));
+        const double cos_a = cos(c->theta[j]) * cos_tv + sin(c->theta[j]) * sin_tv * cos(c->phi[0]);
+        const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
+        const double td = estimate_t_dec(jet, med, c->theta[j]);
+        t_dec[j] = td;
+        const double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+        min_raw = dmin(min_raw, ts);
+        min_guarded = dmin(min_guarded, dmax(ts, cut));
+        min_cut = dmin(min_cut, cut);
+    }
+    const double min_t_early = min_raw, min_t_start = min_guarded;
+    const int has_early = min_raw < min_cut;
+    const size_t t_num_tot = (size_t)(dmax(log10(t_end / min_t_start), 1.0) * t_resol);
+    const size_t t_num = t_num_tot + (has_early ? 1 : 0);
+    c->n_t = (int)t_num;
+    c->t = calloc((size_t)nth * t_num, sizeof(double));
+    double* grid = malloc(sizeof(double) * (t_num_tot > 0 ? t_num_tot : 1));
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j_rep = c->reps[r];
+        const int j_end = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
+        logspace_with_band_refinement(min_t_start, t_end, t_dec[j_rep] / 3, 3 * t_dec[j_rep], t_num_tot, 3.0, grid);
+        for (int j = j_rep; j < j_end; ++j) {
+            double* row = c->t + (size_t)j * t_num;
+            if (has_early) {
+                row[0] = min_t_early;
+                for (size_t k = 0; k < t_num_tot; ++k) row[1 + k] = grid[k];
+            } else {
+                for (size_t k = 0; k < t_num_tot; ++k) row[k] = grid[k];
+            }
+        }
+    }
+    free(grid);
+    free(t_dec);
+}
+
+/* auto_grid, src/core/grid-refinement.h:639-706 */
+static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_obs_min, double t_obs_max,
+                     double theta_cut, double theta_view, double z, double phi_resol, double theta_resol, double t_resol) {
+    memset(c, 0, sizeof *c);
+    c->theta_view = theta_view;
+    const size_t min_theta_num = DEF_MIN_THETA_POINTS;
+    double jumps[64];
+    const int n_jumps = find_jet_jumps(jet, C_GAMMA_CUT, jumps, 64);
+    double inner_edge, outer_edge;
+    find_theta_range(jet, C_GAMMA_CUT, &inner_edge, &outer_edge);
+    for (int i = 0; i < n_jumps; ++i) outer_edge = dmax(outer_edge, jumps[i]);
+    const double theta_min = dmax(DEF_THETA_MIN, inner_edge);
+    const double theta_max = dmin(outer_edge, theta_cut);
+    const size_t theta_num = min_theta_num + (size_t)((theta_max - theta_min) * 180 / C_PI * theta_resol);
+
+    int n_base = 0;
+    double* base_theta = adaptive_theta_grid(jet, theta_min, theta_max, theta_num, theta_view, theta_resol, &n_base);
+    const double avg_spacing = (theta_max - theta_min) / n_base;
+    double feature[3 * 64];
+    const int n_feat = jump_refinement_grid(jumps, n_jumps, theta_min, theta_max, avg_spacing, feature);
+    c->theta = malloc(sizeof(double) * (n_base + n_feat + 1));
+    c->n_theta = merge_grids(base_theta, n_base, feature, n_feat, c->theta);
+    free(base_theta);
+
+    size_t phi_base = (size_t)(360 * phi_resol);
+    if (phi_base < 1) phi_base = 1;
+    const int mirror_phi = theta_view != 0 && phi_base > 4; /* is_axisymmetric == true */
+    if (mirror_phi) {
+        const size_t n_half = (phi_base + 1) / 2;
+        c->phi = adaptive_phi_grid(jet, n_half, theta_view, c->theta, c->n_theta, 1, C_PI, 5.0, &c->n_phi);
+        c->phi_mirrored = 1;
+    } else {
+        const double doppler_sharpness = jet_Gamma0(jet, theta_view) * sin(theta_view);
+        const double phi_boost = sqrt(dmax(doppler_sharpness / (2 * C_PI), 1.0));
+        size_t phi_num = (size_t)(phi_base * phi_boost);
+        if (phi_num < 1) phi_num = 1;
+        if (phi_num > phi_base * 5) phi_num = phi_base * 5;
+        if (phi_num <= 2) {
+            c->phi = malloc(sizeof(double) * phi_num);
+            linspace(0., 2 * C_PI, (int)phi_num, c->phi);
+            c->n_phi = (int)phi_num;
+        } else {
+            c->phi = adaptive_phi_grid(jet, phi_num, theta_view, c->theta, c->n_theta, 1, 2 * C_PI, 0, &c->n_phi);
+        }
+        if (phi_num >= 2) {
+            const double shift = 0.5 * (c->phi[1] - c->phi[0]);
+            for (int i = 0; i < c->n_phi; ++i) c->phi[i] += shift;
+        }
+    }
+    detect_symmetry(c, jet);
+    build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Forward-shock dynamics: src/dynamics/forward-shock.tpp:10-236, shock-physics.h:58-132,
+ * 247-288,299-371,401-469; src/dynamics/shock.cpp:93-138
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const medium_t* med;
+    double m_jet0;
+    /* RadiativeEfficiency, shock-physics.h:247-288 */
+    double gamma_m_coeff, gamma_c_coeff, eps_e_eff, p;
+    double eps_e, eps_B;
+    int radiative;
+    const jet_t* jet;
+    double theta0;
+} fwd_eqn_t;
+
+static double radiative_efficiency(const fwd_eqn_t* e, double t_comv, double Gamma_th, double e_th) {
+    if (e->eps_e_eff == 0) return 0;
+    const double gamma_m = e->gamma_m_coeff * (Gamma_th - 1) + 1;
+    const double gamma_bar = e->gamma_c_coeff / (e_th * t_comv);
+    const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
+    const double ratio = gamma_m / gamma_c;
+    if (ratio < 1 && e->p > 2) return e->eps_e_eff * fast_pow(ratio, e->p - 2);
+    return e->eps_e_eff;
+}
+
+/* state: [Gamma, m2, U2_th, r, t_comv, theta]  (forward-shock.hpp:22-47) */
+static void fwd_rhs(const double* s, double* d, double t, void* vctx) {
+    (void)t;
+    const fwd_eqn_t* e = vctx;
+    const double Gamma = s[0], m2 = s[1], U2_th = s[2], r = s[3], t_comv = s[4];
+    const double u2 = (Gamma - 1) * (Gamma + 1);
+    const double u = sqrt(u2);
+    const double dr = u * (Gamma + u) * C_C; /* compute_dr_dt(Gamma,u), shock-physics.h:130-132 */
+    d[3] = dr;
+    d[4] = Gamma + u;
+    d[5] = 0;
+    const double rho = medium_rho(e->med, r);
+    d[1] = r * r * rho * dr;
+    const double e_th = (Gamma - 1) * 4 * Gamma * rho * C_C2;
+    const double eps_rad = radiative_efficiency(e, t_comv, Gamma, e_th);
+    const double ad_idx = adiabatic_idx(Gamma);
+    /* compute_dGamma_dt, forward-shock.tpp:62-101 (non-spreading) */
+    {
+        const double dm_dt_swept = d[1];
+        const double m_swept = m2;
+        const double Gamma2 = Gamma * Gamma;
+        const double Gamma_eff = (ad_idx * (Gamma2 - 1) + 1) / Gamma;
+        const double dGamma_eff = (ad_idx * (Gamma2 + 1) - 1) / Gamma2;
+        const double dlnVdt = 3 / r * dr;
+        const double m_jet = e->m_jet0;
+        const double U = U2_th;
+        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_dt_swept;
+        const double a2 = (ad_idx - 1) * Gamma_eff * U * dlnVdt;
+        const double b1 = (m_jet + m_swept) * C_C2;
+        const double b2 = (dGamma_eff + Gamma_eff * (ad_idx - 1) / Gamma) * U;
+        d[0] = (a1 + a2) / (b1 + b2);
+    }
+    /* compute_dU_dt, forward-shock.tpp:103-118 */
+    {
+        const double dm_dt_swept = d[1];
+        const double dlnVdt = 3 / r * dr - d[0] / Gamma;
+        d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm_dt_swept - (ad_idx - 1) * dlnVdt * U2_th;
+    }
+}
+
+/* simpson_logspace / enclosed_thermal_energy, shock-physics.h:401-437 */
+static double enclosed_thermal_energy_generic(const medium_t* med, double r, double Gamma, double ad_idx, double eps_e) {
+    const double cooling_exp = 3 * (ad_idx - 1);
+    const int N = 32;
+    const double u_max = log(r);
+    const double u_min = u_max - 18;
+    const double h = (u_max - u_min) / N;
+#define F_(u_) (medium_rho(med, exp(u_)) * exp(u_) * exp(u_) * exp(u_) * pow(exp(u_) / r, cooling_exp))
+    double sum = F_(u_min) + F_(u_max);
+    for (int i = 1; i < N; i += 2) sum += 4 * F_(u_min + i * h);
+    for (int i = 2; i < N; i += 2) sum += 2 * F_(u_min + i * h);
+#undef F_
+    return (1 - eps_e) * (Gamma - 1) * C_C2 * (sum * h / 3);
+}
+
+/* enclosed_thermal_energy_medium, shock-physics.h:451-468 */
+static double enclosed_thermal_energy_medium(const medium_t* med, double r, double Gamma, double ad_idx, double eps_e) {
+    if (med->type == VAG_MEDIUM_ISM) {
+        const double rho = medium_rho(med, r);
+        const double cooling_exp = 3 * (ad_idx - 1);
+        const double pow_exp = 3 + cooling_exp;
+        const double x0 = exp(-18.0);
+        const double attenuation = 1 - pow(x0, pow_exp);
+        const double integral = rho * r * r * r * attenuation / pow_exp;
+        return (1 - eps_e) * (Gamma - 1) * C_C2 * integral;
+    }
+    return enclosed_thermal_energy_generic(med, r, Gamma, ad_idx, eps_e);
+}
+
+/* set_init_state, forward-shock.tpp:120-149 */
+static void fwd_set_init_state(const fwd_eqn_t* e, double* s, double t0) {
+    const double Gamma4 = jet_Gamma0(e->jet, e->theta0);
+    const double beta4 = gamma_to_beta(Gamma4);
+    s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
+    s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
+    s[5] = e->theta0;
+    s[1] = medium_mass(e->med, s[3]);
+    s[0] = Gamma4;
+    const double ad_idx = adiabatic_idx(s[0]);
+    s[2] = enclosed_thermal_energy_medium(e->med, s[3], s[0], ad_idx, e->radiative ? e->eps_e : 0.0);
+}
+
+/* compute_downstr_4vel (sigma = 0 branch), src/dynamics/shock.cpp:93-100 */
+static double compute_downstr_4vel0(double gamma_rel) {
+    const double ad_idx = adiabatic_idx(gamma_rel);
+    const double gamma_m_1 = gamma_rel - 1;
+    const double ad_idx_m_2 = ad_idx - 2;
+    const double ad_idx_m_1 = ad_idx - 1;
+    return sqrt(dmax(gamma_m_1 * ad_idx_m_1 * ad_idx_m_1 / (-ad_idx * ad_idx_m_2 * gamma_m_1 + 2), 0.0));
+}
+
+/* compute_compression(1, Gamma, 0): shock-physics.h:58-66,190-203,349-352 */
+static double compute_compression_fwd(double Gamma_downstr) {
+    const double gamma1 = 1;
+    const double u1u2 = sqrt(dmax((gamma1 - 1) * (gamma1 + 1) * (Gamma_downstr - 1) * (Gamma_downstr + 1), 0.0));
+    const double dd = gamma1 - Gamma_downstr;
+    const double denom = gamma1 * Gamma_downstr - 1 + u1u2;
+    const double gamma_rel = denom <= 0 ? 1 : 1 + dd * dd / denom;
+    const double u_down = compute_downstr_4vel0(gamma_rel);
+    const double u_up = sqrt((1 + u_down * u_down) * dmax((gamma_rel - 1) * (gamma_rel + 1), 0.0)) + u_down * gamma_rel;
+    double ratio_u = u_up / u_down;
+    if (u_down == 0.) ratio_u = 4 * gamma_rel;
+    return ratio_u;
+}
+
+typedef struct {
+    int n_theta, n_t;
+    double *t_comv, *r, *theta, *Gamma, *Gamma_th, *B, *N_p; /* [n_theta][n_t] */
+} shock_t;
+
+static void shock_alloc(shock_t* s, int nth, int nt) {
+    const size_t n = (size_t)nth * nt;
+    s->n_theta = nth;
+    s->n_t = nt;
+    s->t_comv = calloc(n, sizeof(double));
+    s->r = calloc(n, sizeof(double));
+    s->theta = calloc(n, sizeof(double));
+    s->Gamma = malloc(n * sizeof(double));
+    s->Gamma_th = malloc(n * sizeof(double));
+    s->B = calloc(n, sizeof(double));
+    s->N_p = calloc(n, sizeof(double));
+    for (size_t i = 0; i < n; ++i) s->Gamma[i] = s->Gamma_th[i] = 1; /* Shock ctor, shock.cpp:12-24 */
+}
+static void shock_free(shock_t* s) {
+    free(s->t_comv);
+    free(s->r);
+    free(s->theta);
+    free(s->Gamma);
+    free(s->Gamma_th);
+    free(s->B);
+    free(s->N_p);
+    memset(s, 0, sizeof *s);
+}
+
+/* save_fwd_shock_state, forward-shock.tpp:151-173 */
+static void save_fwd_shock_state(shock_t* sh, size_t o, const fwd_eqn_t* e, const double* s) {
+    const double comp_ratio = compute_compression_fwd(s[0]);
+    const double rho = medium_rho(e->med, s[3]);
+    const double U_th = s[2];
+    const double Gamma_th = (s[1] == 0) ? 1 : U_th / (s[1] * C_C2) + 1;
+    const double rho_downstr = rho * comp_ratio;
+    const double e_th = (Gamma_th - 1) * rho_downstr * C_C2;
+    const double B = sqrt(8 * C_PI * e->eps_B * e_th) + 0 * comp_ratio;
+    sh->t_comv[o] = s[4];
+    sh->r[o] = s[3];
+    sh->theta[o] = s[5];
+    sh->Gamma[o] = s[0];
+    sh->Gamma_th[o] = Gamma_th;
+    sh->B[o] = B;
+    sh->N_p[o] = s[1] / C_MP;
+}
+
+/* grid_solve_fwd_shock, forward-shock.tpp:175-208 */
+static int grid_solve_fwd_shock(int j, const double* t, int nt, shock_t* sh, const fwd_eqn_t* e, double rtol) {
+    double state[6];
+    const double t_dec = estimate_t_dec(e->jet, e->med, e->theta0);
+    const double t0 = dmin(t[0], dmin(0.1 * U_SEC, 0.1 * t_dec));
+    fwd_set_init_state(e, state, t0);
+    const size_t base = (size_t)j * nt;
+    if (state[0] <= C_GAMMA_CUT) { /* set_stopping_shock, shock-physics.h:388-397 */
+        for (int k = 0; k < nt; ++k) {
+            sh->t_comv[base + k] = state[4];
+            sh->r[base + k] = state[3];
+            sh->theta[base + k] = state[5];
+            sh->Gamma[base + k] = 1;
+            sh->Gamma_th[base + k] = 1;
+            sh->B[base + k] = 0;
+            sh->N_p[base + k] = 0;
+        }
+        return 0;
+    }
+    dopri5_t st;
+    dopri5_init(&st, 6, rtol, rtol, state, t0, 0.01 * t0);
+    for (int k = 0, steps = 0; st.t <= t[nt - 1];) {
+        if (dopri5_do_step(&st, fwd_rhs, (void*)e) != 0) return fail("forward shock ODE: step size underflow");
+        if (++steps > DEF_MAX_ODE_STEPS) {
+            fprintf(stderr, "Warning: forward shock ODE exceeded %d steps at (j=%d), giving up\n", DEF_MAX_ODE_STEPS, j);
+            return 0;
+        }
+        while (k < nt && st.t > t[k]) {
+            dopri5_calc_state(&st, t[k], state);
+            save_fwd_shock_state(sh, base + k, e, state);
+            ++k;
+        }
+    }
+    return 0;
+}
+
+/* generate_fwd_shock + Shock::broadcast_groups: forward-shock.tpp:210-236, shock.cpp:42-91 */
+static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med, const jet_t* jet,
+                              const vag_model_params* p) {
+    shock_alloc(sh, c->n_theta, c->n_t);
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j = c->reps[r];
+        fwd_eqn_t e;
+        e.med = med;
+        e.jet = jet;
+        e.theta0 = c->theta[j];
+        e.m_jet0 = jet_eps_k(jet, e.theta0) / jet_Gamma0(jet, e.theta0) / C_C2;
+        if (jet->type == VAG_JET_TWO_COMPONENT) e.m_jet0 /= 1 + 0.0;
+        e.radiative = p->radiative_fireball != 0;
+        e.eps_e = p->eps_e;
+        e.eps_B = p->eps_B;
+        e.p = p->p;
+        e.gamma_m_coeff = (p->p - 2) / (p->p - 1) * p->eps_e * C_MP / C_ME / p->xi_e;
+        e.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * p->eps_B);
+        e.eps_e_eff = e.radiative ? p->eps_e : 0;
+        if (grid_solve_fwd_shock(j, c->t + (size_t)j * c->n_t, c->n_t, sh, &e, p->rtol) != 0) return -1;
+    }
+    /* broadcast representative rows to their groups; theta(j,k) = coord.theta(j) */
+    const int nt = c->n_t;
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j0 = c->reps[r];
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        for (int j = j0 + 1; j < j1; ++j) {
+            for (int k = 0; k < nt; ++k) {
+                const size_t o = (size_t)j * nt + k, s = (size_t)j0 * nt + k;
+                sh->t_comv[o] = sh->t_comv[s];
+                sh->r[o] = sh->r[s];
+                sh->theta[o] = c->theta[j];
+                sh->Gamma[o] = sh->Gamma[s];
+                sh->Gamma_th[o] = sh->Gamma_th[s];
+                sh->B[o] = sh->B[s];
+                sh->N_p[o] = sh->N_p[s];
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Equal-arrival-time grids: Observer::observe (non-spreading, axisymmetric =>
+ * geom_pre_logged_), src/core/observer.cpp:17-37,143-205,211-235,419-454
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_phi_eff, n_theta, n_t;
+    double *lg2_t, *lg2_doppler, *lg2_geom; /* [n_phi_eff][n_theta][n_t] */
+    double one_plus_z, lumi_dist;
+} eat_t;
+
+static void eat_free(eat_t* e) {
+    free(e->lg2_t);
+    free(e->lg2_doppler);
+    free(e->lg2_geom);
+    memset(e, 0, sizeof *e);
+}
+
+static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_dist, double z) {
+    const int nth = c->n_theta, nt = c->n_t;
+    const int eff_phi = (c->theta_view == 0) ? 1 : c->n_phi; /* jet_3d == 0 */
+    o->n_phi_eff = eff_phi;
+    o->n_theta = nth;
+    o->n_t = nt;
+    o->one_plus_z = 1 + z;
+    o->lumi_dist = lumi_dist;
+    const size_t n = (size_t)eff_phi * nth * nt;
+    o->lg2_t = malloc(n * sizeof(double));
+    o->lg2_doppler = malloc(n * sizeof(double));
+    o->lg2_geom = malloc(n * sizeof(double));
+
+    const double cos_obs = cos(c->theta_view), sin_obs = sin(c->theta_view);
+    double* dphi = malloc(sizeof(double) * eff_phi);
+    if (eff_phi == 1) {
+        dphi[0] = 2 * C_PI;
+    } else if (c->phi_mirrored) {
+        const int last = eff_phi - 1;
+        for (int i = 0; i < eff_phi; ++i) {
+            const double left = (i > 0) ? 0.5 * (c->phi[i - 1] + c->phi[i]) : 0.0;
+            const double right = (i < last) ? 0.5 * (c->phi[i] + c->phi[i + 1]) : C_PI;
+            dphi[i] = 2 * (right - left);
+        }
+    } else {
+        const int last = eff_phi - 1;
+        for (int i = 0; i < eff_phi; ++i)
+            dphi[i] = 0.5 * (c->phi[i + 1 < last ? i + 1 : last] - c->phi[i > 0 ? i - 1 : 0]);
+    }
+    double* lg2_r2 = malloc(sizeof(double) * (size_t)nth * nt);
+    for (size_t q = 0; q < (size_t)nth * nt; ++q) lg2_r2[q] = 2.0 * log2(sh->r[q]);
+
+    const int last = nth - 1;
+    for (int i = 0; i < eff_phi; ++i) {
+        const double cos_phi = cos(c->phi[i] - 0.0);
+        const double dphi_i = dphi[i];
+        double cos_th_carry = 0;
+        for (int j = 0; j < nth; ++j) {
+            const double th_j = sh->theta[(size_t)j * nt];
+            const double ct = cos(th_j), st = sin(th_j);
+            const double cos_v = st * cos_phi * sin_obs + ct * cos_obs;
+            const double t_coeff = (1 - cos_v) / C_C * o->one_plus_z;
+            const double cos_th_lo = (j == 0) ? ct : cos_th_carry;
+            double cos_th_hi;
+            if (j == last) {
+                cos_th_hi = ct;
+            } else {
+                const double th_hi = 0.5 * (th_j + sh->theta[(size_t)(j + 1) * nt]);
+                cos_th_hi = cos(th_hi);
+            }
+            const double dOmega = fabs((cos_th_hi - cos_th_lo) * dphi_i);
+            cos_th_carry = cos_th_hi;
+            const double lg2_dOmega = log2(dOmega);
+            for (int k = 0; k < nt; ++k) {
+                const size_t s = (size_t)j * nt + k;
+                const size_t q = ((size_t)i * nth + j) * nt + k;
+                const double gamma_ = sh->Gamma[s];
+                const double r = sh->r[s];
+                const double dop_lin = gamma_ - sqrt((gamma_ - 1) * (gamma_ + 1)) * cos_v;
+                const double time = c->t[s] * o->one_plus_z + t_coeff * r;
+                const double geom = lg2_dOmega + lg2_r2[s];
+                /* finalize_log_grids */
+                o->lg2_doppler[q] = -log2(dop_lin);
+                o->lg2_t[q] = log2(time);
+                o->lg2_geom[q] = geom + 3.0 * o->lg2_doppler[q];
+            }
+        }
+    }
+    free(lg2_r2);
+    free(dphi);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synchrotron electrons and photons: src/radiation/synchrotron.cpp:45-254,315-408,
+ * smooth-power-law-syn.cpp:15-167
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double gamma_m, gamma_c, gamma_a, gamma_M, N_e, column_den;
+    int regime;
+} electrons_t;
+
+typedef struct {
+    double nu_m, nu_c, nu_a, nu_M, I_nu_max, p;
+    /* cached by build(), smooth-power-law-syn.cpp:94-153 */
+    double log2_I_nu_max, log2_nu_m, log2_nu_c, log2_nu_a, log2_nu_M, inv_nu_M;
+    double log2_norm, log2_thick_norm, smooth_thick, log2_x_far, s_a_blend;
+    double log2_nu_lo, log2_nu_hi, smooth_lo, smooth_hi, diff_lo, diff_hi;
+} photons_t;
+
+static int order3(double a, double b, double c) {
+    return a <= b && b <= c;
+}
+static int determine_regime(double a, double c, double m) {
+    if (order3(a, m, c)) return 1;
+    if (order3(m, a, c)) return 2;
+    if (order3(a, c, m)) return 3;
+    if (order3(c, a, m)) return 4;
+    if (order3(m, c, a)) return 5;
+    if (order3(c, m, a)) return 6;
+    return 0;
+}
+
+static double compute_syn_I_peak(double B, double column_den) {
+    const double sin_angle_ave = C_PI / 4;
+    const double Fx_max = 0.92;
+    const double P = B * (sin_angle_ave * Fx_max * M_SQRT3_ * C_E3 / (C_ME * C_C2));
+    return P * column_den / (4 * C_PI);
+}
+
+static double compute_syn_freq(double gamma, double B) {
+    if (B == 0 || !isfinite(gamma)) return 0;
+    return 3 * C_E / (4 * C_PI * C_ME * C_C) * B * gamma * gamma;
+}
+
+static double compute_syn_gamma(double nu, double B) {
+    return sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu / B));
+}
+
+static double compute_syn_gamma_M(double B, double Y) {
+    if (B == 0) return INFINITY;
+    return sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + Y)));
+}
+
+/* root_bisect, src/util/utilities.h:230-241 specialised to the p == 2 equation */
+static double gamma_m_p2_eq(double x, double gamma_M, double gamma_ave_minus_1) {
+    return x * log(gamma_M) - (x + 1) * log(x) - gamma_ave_minus_1 - log(gamma_M);
+}
+
+static double compute_syn_gamma_m(double Gamma_th, double gamma_M, double eps_e, double p, double xi) {
+    const double gamma_ave_minus_1 = eps_e * (Gamma_th - 1) * (C_MP / C_ME) / xi;
+    double gamma_m_minus_1 = 1;
+    if (p > 2) {
+        gamma_m_minus_1 = (p - 2) / (p - 1) * gamma_ave_minus_1;
+    } else if (p < 2) {
+        gamma_m_minus_1 = pow((2 - p) / (p - 1) * gamma_ave_minus_1 * pow(gamma_M, p - 2), 1 / (p - 1));
+    } else {
+        double low = 0, high = gamma_M;
+        const double eps = 1e-6;
+        for (int iter = 0; iter < 1000 && (high - low) > fabs((high + low) * 0.5) * eps; ++iter) {
+            const double mid = 0.5 * (high + low);
+            if (gamma_m_p2_eq(mid, gamma_M, gamma_ave_minus_1) * gamma_m_p2_eq(high, gamma_M, gamma_ave_minus_1) > 0)
+                high = mid;
+            else
+                low = mid;
+        }
+        gamma_m_minus_1 = 0.5 * (high + low);
+    }
+    return gamma_m_minus_1 + 1;
+}
+
+static double compute_gamma_c(double t_comv, double B, double Y) {
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + Y) * t_comv) * 1;
+    return (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+}
+
+/* compute_syn_gamma_a with Ys = InverseComptonY{} and Y_c = 0: the IC ratio is exactly 1,
+ * synchrotron.cpp:212-246 */
+static double compute_syn_gamma_a(double B, double I_syn_peak, double gamma_m, double gamma_c, double p) {
+    const double gamma_peak = dmin(gamma_m, gamma_c);
+    const double nu_peak = compute_syn_freq(gamma_peak, B);
+    const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
+    double nu_a = fast_pow(I_syn_peak * C_C2 / (cbrt(nu_peak) * 2 * kT), 0.6);
+    if (nu_a > nu_peak) {
+        if (gamma_c > gamma_m) {
+            const double nu_m = compute_syn_freq(gamma_m, B);
+            nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * fast_pow(nu_m, p / 2), 2 / (p + 4));
+            const double nu_c = compute_syn_freq(gamma_c, B);
+            if (nu_a > nu_c) {
+                nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+                const double ic = (1 + 0.0) / (1 + 0.0);
+                nu_a *= fast_pow(ic, 2 / (p + 5));
+            }
+        } else {
+            const double nu_c = compute_syn_freq(gamma_c, B);
+            nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
+            double ic = (1 + 0.0) / (1 + 0.0);
+            nu_a *= fast_pow(ic, 0.4);
+            const double nu_m = compute_syn_freq(gamma_m, B);
+            if (nu_a > nu_m) {
+                nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+                ic = (1 + 0.0) / (1 + 0.0);
+                nu_a *= fast_pow(ic, 2 / (p + 5));
+            }
+        }
+    }
+    return compute_syn_gamma(nu_a, B) + 1;
+}
+
+static double cyclotron_correction(double gamma_m, double p) {
+    double f = (gamma_m - 1) / gamma_m;
+    if (p > 3) f = fast_pow(f, (p - 1) / 2);
+    return f;
+}
+
+/* one cell of generate_syn_electrons, synchrotron.cpp:315-360 */
+static void syn_electrons_cell(electrons_t* e, double t_com, double B, double r, double Gamma_th, double N_p,
+                               const vag_model_params* rad) {
+    e->gamma_M = compute_syn_gamma_M(B, 0.);
+    e->gamma_m = compute_syn_gamma_m(Gamma_th, e->gamma_M, rad->eps_e, rad->p, rad->xi_e);
+    const double f_syn = cyclotron_correction(e->gamma_m, rad->p);
+    e->N_e = N_p * rad->xi_e * f_syn;
+    e->column_den = e->N_e / (r * r);
+    const double I_nu_peak = compute_syn_I_peak(B, e->column_den);
+    e->gamma_c = compute_gamma_c(t_com, B, 0.);
+    e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, rad->p);
+    e->regime = determine_regime(e->gamma_a, e->gamma_c, e->gamma_m);
+}
+
+static double sigmoid2(double x) {
+    return 1.0 / (1.0 + exp2(-x));
+}
+static double blend(double w, double a, double b) {
+    return w * a + (1.0 - w) * b;
+}
+
+/* smooth-power-law-syn.cpp:49-78 */
+static double log2_optical_thick_sharp(const photons_t* ph, double log2_nu) {
+    if (log2_nu < ph->log2_nu_m) return 2. * (log2_nu - ph->log2_nu_m);
+    return 2.5 * (log2_nu - ph->log2_nu_m);
+}
+static double log2_optical_thin_sharp(const photons_t* ph, double log2_nu) {
+    const double p = ph->p, lm = ph->log2_nu_m, lc = ph->log2_nu_c;
+    if (lm < lc) {
+        if (log2_nu < lm) return (log2_nu - lm) / 3.0;
+        if (log2_nu < lc) return 0.5 * (1.0 - p) * (log2_nu - lm);
+        return 0.5 * (1.0 - p) * (lc - lm) - 0.5 * p * (log2_nu - lc);
+    }
+    if (log2_nu < lc) return (log2_nu - lc) / 3.0;
+    if (log2_nu < lm) return -0.5 * (log2_nu - lc);
+    return -0.5 * (lm - lc) - 0.5 * p * (log2_nu - lm);
+}
+
+/* SmoothPowerLawSyn::build, smooth-power-law-syn.cpp:94-153 */
+static void photons_build(photons_t* ph) {
+    const double p = ph->p;
+    ph->log2_I_nu_max = log2(ph->I_nu_max);
+    ph->log2_nu_m = log2(ph->nu_m);
+    ph->log2_nu_c = log2(ph->nu_c);
+    ph->log2_nu_a = log2(ph->nu_a);
+    ph->log2_nu_M = log2(ph->nu_M);
+    ph->inv_nu_M = 1.0 / ph->nu_M;
+    ph->smooth_thick = (3.44 * p - 1.41) / M_LN2_;
+    ph->log2_x_far = 1.5 * log2(20.0 / ph->smooth_thick);
+    const double s_swap = 4.0, s_floor = 0.1;
+    const double w_slow = sigmoid2(s_swap * (ph->log2_nu_c - ph->log2_nu_m));
+    const double soft_offset = log2_softplus(-s_swap * fabs(ph->log2_nu_c - ph->log2_nu_m)) / s_swap;
+    ph->log2_nu_lo = dmin(ph->log2_nu_m, ph->log2_nu_c) - soft_offset;
+    ph->log2_nu_hi = dmax(ph->log2_nu_m, ph->log2_nu_c) + soft_offset;
+    const double s_m_slow = dmax(1.84 - 0.40 * p, s_floor);
+    const double s_c_slow = dmax(1.15 - 0.06 * p, s_floor);
+    const double s_c_fast = 0.597;
+    const double s_m_fast = dmax(3.34 - 0.82 * p, s_floor);
+    ph->smooth_lo = blend(w_slow, s_m_slow, s_c_fast);
+    ph->smooth_hi = blend(w_slow, s_c_slow, s_m_fast);
+    const double alpha_mid = blend(w_slow, -0.5 * (p - 1.0), -0.5);
+    ph->diff_lo = ph->smooth_lo * (1.0 / 3.0 - alpha_mid);
+    ph->diff_hi = ph->smooth_hi * (alpha_mid + 0.5 * p);
+    const double u = sigmoid2(s_swap * (ph->log2_nu_a - ph->log2_nu_m));
+    const double v = sigmoid2(s_swap * (ph->log2_nu_a - ph->log2_nu_c));
+    const double w_below = (1.0 - u) * (1.0 - v);
+    const double w_above = u * v;
+    const double s_a_below = 1.64;
+    const double s_a_mid = dmax(1.47 - 0.21 * p, s_floor);
+    const double s_a_above = dmax(0.94 - 0.14 * p, s_floor);
+    ph->s_a_blend = w_below * s_a_below + w_above * s_a_above + (1.0 - w_below - w_above) * s_a_mid;
+    ph->log2_norm = 1.0 / ph->smooth_lo;
+    ph->log2_thick_norm = log2_optical_thin_sharp(ph, ph->log2_nu_a) - log2_optical_thick_sharp(ph, ph->log2_nu_a);
+}
+
+/* one cell of generate_syn_photons, synchrotron.cpp:376-408 */
+static void syn_photons_cell(photons_t* ph, const electrons_t* e, double B, double p) {
+    ph->p = p;
+    ph->nu_M = compute_syn_freq(e->gamma_M, B);
+    ph->nu_m = compute_syn_freq(e->gamma_m, B);
+    ph->nu_c = compute_syn_freq(e->gamma_c, B);
+    ph->nu_a = compute_syn_freq(e->gamma_a, B);
+    ph->I_nu_max = compute_syn_I_peak(B, e->column_den);
+    photons_build(ph);
+}
+
+/* SmoothPowerLawSyn::compute_log2_I_nu with Y == 0, smooth-power-law-syn.cpp:15-46,80-92,159-167 */
+static double compute_log2_I_nu(const photons_t* ph, double log2_nu) {
+    const double thin = (log2_nu - ph->log2_nu_lo) / 3.0 +
+                        log2_broken_power_ratio(log2_nu, ph->log2_nu_lo, ph->diff_lo, ph->smooth_lo) +
+                        log2_broken_power_ratio(log2_nu, ph->log2_nu_hi, ph->diff_hi, ph->smooth_hi);
+    double thick;
+    {
+        const double log2_x = log2_nu - ph->log2_nu_m;
+        if (log2_x > ph->log2_x_far) {
+            thick = 2.5 * log2_x;
+        } else {
+            const double s = -ph->smooth_thick * exp2(2. / 3 * log2_x);
+            thick = 2.5 * log2_x + log2_softplus(-0.5 * log2_x + s);
+        }
+    }
+    const double log2_b = thick + ph->log2_thick_norm;
+    /* log2_smooth_one(a, b, s) = a - softplus(s (a - b)) / s */
+    const double smooth_one = thin - log2_softplus(ph->s_a_blend * (thin - log2_b)) / ph->s_a_blend;
+    const double spec = ph->log2_I_nu_max + (ph->log2_norm + smooth_one);
+    if (log2_nu - ph->log2_nu_M < -20) return spec;
+    return spec - M_LOG2E_ * ph->inv_nu_M * exp2(log2_nu);
+}
+
+/* generate_syn_electrons + generate_syn_photons + broadcast_symmetry (utilities.h:293-320) */
+static void generate_syn(electrons_t* el, photons_t* ph, const shock_t* sh, const coord_t* c, const vag_model_params* p) {
+    const int nt = c->n_t;
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j0 = c->reps[r];
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        for (int k = 0; k < nt; ++k) {
+            const size_t o = (size_t)j0 * nt + k;
+            syn_electrons_cell(&el[o], sh->t_comv[o], sh->B[o], sh->r[o], sh->Gamma_th[o], sh->N_p[o], p);
+            syn_photons_cell(&ph[o], &el[o], sh->B[o], p->p);
+        }
+        for (int j = j0 + 1; j < j1; ++j)
+            for (int k = 0; k < nt; ++k) {
+                el[(size_t)j * nt + k] = el[(size_t)j0 * nt + k];
+                ph[(size_t)j * nt + k] = ph[(size_t)j0 * nt + k];
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Flux integration: src/core/observer.h:309-338 (iterate_to / observed_window),
+ * 355-445 (specific_flux), 447-538 (specific_flux_series), 555-567 (flux);
+ * Boole weights src/core/quadrature.h:153-196
+ * ---------------------------------------------------------------------------------------- */
+static void iterate_to(double value, const double* arr, int n, int* it) {
+    while (*it < n && arr[*it] < value) (*it)++;
+}
+static void iterate_through(double value, const double* arr, int n, int* it) {
+    while (*it < n && arr[*it] <= value) (*it)++;
+}
+static int observed_window(const double* t_row, int t_grid, double w_lo, double w_hi, int* k_lo, int* k_hi) {
+    if (t_row[t_grid - 1] < w_lo || t_row[0] > w_hi) return 0;
+    *k_lo = 0;
+    while (*k_lo + 1 < t_grid && t_row[*k_lo + 1] < w_lo) (*k_lo)++;
+    *k_hi = *k_lo + 1;
+    while (*k_hi + 1 < t_grid && t_row[*k_hi] <= w_hi) (*k_hi)++;
+    return 1;
+}
+
+/* F[nnu][nt] in code units */
+static void specific_flux(const eat_t* o, const photons_t* ph, const double* t_obs, int nt_obs, const double* nu_obs,
+                          int nnu, double* F) {
+    const int t_grid = o->n_t;
+    double* lg2_t_obs = malloc(sizeof(double) * nt_obs);
+    double* lg2_nu_src = malloc(sizeof(double) * nnu);
+    for (int i = 0; i < nt_obs; ++i) lg2_t_obs[i] = log2(t_obs[i]);
+    for (int l = 0; l < nnu; ++l) lg2_nu_src[l] = log2(nu_obs[l]) + log2(o->one_plus_z);
+    for (size_t q = 0; q < (size_t)nnu * nt_obs; ++q) F[q] = 0;
+    double* boundary = calloc((size_t)t_grid * nnu, sizeof(double));
+    double* slope = calloc(nnu, sizeof(double));
+    double* lo = calloc(nnu, sizeof(double));
+    double* col = calloc((size_t)nnu * nt_obs, sizeof(double));
+
+    for (int i = 0; i < o->n_phi_eff; ++i) {
+        for (int j = 0; j < o->n_theta; ++j) {
+            const size_t row = ((size_t)i * o->n_theta + j) * t_grid;
+            const double* t_row = o->lg2_t + row;
+            const double* dop_row = o->lg2_doppler + row;
+            const double* geom_row = o->lg2_geom + row;
+            const photons_t* ph_row = ph + (size_t)j * t_grid; /* eff_i = 0: one phi slice */
+            int k_lo, k_hi;
+            if (!observed_window(t_row, t_grid, lg2_t_obs[0], lg2_t_obs[nt_obs - 1], &k_lo, &k_hi)) continue;
+            for (int k = k_lo; k <= k_hi; ++k)
+                for (int l = 0; l < nnu; ++l)
+                    boundary[(size_t)k * nnu + l] = compute_log2_I_nu(&ph_row[k], lg2_nu_src[l] - dop_row[k]) + geom_row[k];
+
+            int t_idx = 0;
+            iterate_to(t_row[0], lg2_t_obs, nt_obs, &t_idx);
+            const int col_first = t_idx;
+            for (int k = k_lo; k < k_hi && t_idx < nt_obs; ++k) {
+                if (t_row[k + 1] < lg2_t_obs[t_idx]) continue;
+                const int idx_start = t_idx;
+                iterate_to(t_row[k + 1], lg2_t_obs, nt_obs, &t_idx);
+                const double t_lo_val = t_row[k];
+                const double inv_t_ratio = 1.0 / (t_row[k + 1] - t_lo_val);
+                for (int l = 0; l < nnu; ++l) {
+                    const double s = (boundary[(size_t)(k + 1) * nnu + l] - boundary[(size_t)k * nnu + l]) * inv_t_ratio;
+                    const int ok = isfinite(s);
+                    slope[l] = ok ? s : 0.0;
+                    lo[l] = ok ? boundary[(size_t)k * nnu + l] : -INFINITY;
+                }
+                for (int idx = idx_start; idx < t_idx; ++idx) {
+                    const double dlg2_t = lg2_t_obs[idx] - t_lo_val;
+                    for (int l = 0; l < nnu; ++l) col[(size_t)l * nt_obs + idx] = lo[l] + dlg2_t * slope[l];
+                }
+            }
+            for (int l = 0; l < nnu; ++l)
+                for (int idx = col_first; idx < t_idx; ++idx)
+                    F[(size_t)l * nt_obs + idx] += exp2(col[(size_t)l * nt_obs + idx]);
+        }
+    }
+    const double norm = o->one_plus_z / (o->lumi_dist * o->lumi_dist);
+    for (size_t q = 0; q < (size_t)nnu * nt_obs; ++q) F[q] *= norm;
+    free(lg2_t_obs);
+    free(lg2_nu_src);
+    free(boundary);
+    free(slope);
+    free(lo);
+    free(col);
+}
+
+/* F[n] in code units */
+static void specific_flux_series(const eat_t* o, const photons_t* ph, const double* t_obs, const double* nu_obs, int n,
+                                 double* F) {
+    const int t_grid = o->n_t;
+    double* lg2_t_obs = malloc(sizeof(double) * n);
+    double* lg2_nu_src = malloc(sizeof(double) * n);
+    double* col = malloc(sizeof(double) * n);
+    for (int i = 0; i < n; ++i) {
+        lg2_t_obs[i] = log2(t_obs[i]);
+        lg2_nu_src[i] = log2(nu_obs[i]) + log2(o->one_plus_z);
+        F[i] = 0;
+        col[i] = -INFINITY;
+    }
+    for (int i = 0; i < o->n_phi_eff; ++i) {
+        for (int j = 0; j < o->n_theta; ++j) {
+            const size_t row = ((size_t)i * o->n_theta + j) * t_grid;
+            const double* t_row = o->lg2_t + row;
+            const double* dop_row = o->lg2_doppler + row;
+            const double* geom_row = o->lg2_geom + row;
+            const photons_t* ph_row = ph + (size_t)j * t_grid;
+            int idx = 0;
+            iterate_to(t_row[0], lg2_t_obs, n, &idx);
+            const int col_first = idx;
+            int carry_k = t_grid;
+            double carry_nu = 0, carry_val = 0;
+            for (int k = 0; idx < n && k < t_grid - 1; ++k) {
+                if (t_row[k + 1] < lg2_t_obs[idx]) continue;
+                const int block_first = idx;
+                iterate_through(t_row[k + 1], lg2_t_obs, n, &idx);
+                const double inv_dt = 1.0 / (t_row[k + 1] - t_row[k]);
+                double prev_nu = NAN, prev_lo = 0, prev_hi = 0;
+                for (int s = block_first; s < idx; ++s) {
+                    const double lg2_nu = lg2_nu_src[s];
+                    double lo, hi;
+                    if (lg2_nu == prev_nu) {
+                        lo = prev_lo;
+                        hi = prev_hi;
+                    } else {
+                        const int carried = (s == block_first && carry_k == k && carry_nu == lg2_nu);
+                        lo = carried ? carry_val : compute_log2_I_nu(&ph_row[k], lg2_nu - dop_row[k]) + geom_row[k];
+                        hi = compute_log2_I_nu(&ph_row[k + 1], lg2_nu - dop_row[k + 1]) + geom_row[k + 1];
+                        prev_nu = lg2_nu;
+                        prev_lo = lo;
+                        prev_hi = hi;
+                    }
+                    const double sl = (hi - lo) * inv_dt;
+                    col[s] = isfinite(sl) ? lo + (lg2_t_obs[s] - t_row[k]) * sl : -INFINITY;
+                    carry_k = k + 1;
+                    carry_nu = lg2_nu;
+                    carry_val = hi;
+                }
+            }
+            for (int s = col_first; s < idx; ++s) F[s] += exp2(col[s]);
+        }
+    }
+    const double norm = o->one_plus_z / (o->lumi_dist * o->lumi_dist);
+    for (int i = 0; i < n; ++i) F[i] *= norm;
+    free(lg2_t_obs);
+    free(lg2_nu_src);
+    free(col);
+}
+
+/* compute_boole_weights, src/core/quadrature.h:153-196 */
+static void compute_boole_weights(const double* grid, int n, double* w) {
+    for (int i = 0; i < n; ++i) w[i] = 0;
+    if (n < 2) return;
+    const double h = log(grid[1] / grid[0]);
+    const double cb = 2.0 * h / 45.0;
+    int j = 0;
+    for (; j + 4 < n; j += 4) {
+        w[j] += cb * 7;
+        w[j + 1] += cb * 32;
+        w[j + 2] += cb * 12;
+        w[j + 3] += cb * 32;
+        w[j + 4] += cb * 7;
+    }
+    const int remaining = n - 1 - j;
+    if (remaining == 3) {
+        const double c38 = 3.0 * h / 8.0;
+        w[j] += c38;
+        w[j + 1] += c38 * 3;
+        w[j + 2] += c38 * 3;
+        w[j + 3] += c38;
+    } else if (remaining == 2) {
+        const double c13 = h / 3.0;
+        w[j] += c13;
+        w[j + 1] += c13 * 4;
+        w[j + 2] += c13;
+    } else if (remaining == 1) {
+        w[j] += 0.5 * h;
+        w[j + 1] += 0.5 * h;
+    }
+    for (int i = 0; i < n; ++i) w[i] *= grid[i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Validation: pybind/error_handling.h:31-69 macros applied as in pybind/pymodel.cpp:47-186,
+ * pybind/pymodel.h:205-260,613-649
+ * ---------------------------------------------------------------------------------------- */
+static int finite_pos(double x) {
+    return isfinite(x) && x > 0;
+}
+static int range_oi(double x, double lo, double hi) { /* (lo, hi] */
+    return isfinite(x) && x > lo && x <= hi;
+}
+
+int vag_oracle_params_validate(const vag_model_params* p) {
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_TWO_COMPONENT) return fail("unknown jet_type");
+    if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return fail("unknown medium_type");
+    if (!range_oi(p->theta_c, 0.0, C_PI / 2)) return fail("theta_c must be in (0, pi/2]");
+    if (!finite_pos(p->E_iso)) return fail("E_iso must be positive and finite");
+    if (!(isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return fail("Gamma0 must be > 1");
+    if (!finite_pos(p->duration)) return fail("duration must be positive and finite");
+    if (p->jet_type == VAG_JET_POWERLAW) {
+        if (!finite_pos(p->k_e)) return fail("k_e must be positive and finite");
+        if (!finite_pos(p->k_g)) return fail("k_g must be positive and finite");
+    }
+    if (p->jet_type == VAG_JET_TWO_COMPONENT) {
+        if (!range_oi(p->theta_w, 0.0, C_PI / 2)) return fail("theta_w must be in (0, pi/2]");
+        if (!(p->theta_w > p->theta_c)) return fail("theta_w (wing angle) must be greater than theta_c (core angle)");
+        if (!finite_pos(p->E_iso_w)) return fail("E_iso_w must be positive and finite");
+        if (!(isfinite(p->Gamma0_w) && p->Gamma0_w > 1.0)) return fail("Gamma0_w must be > 1");
+    }
+    if (p->medium_type == VAG_MEDIUM_ISM) {
+        if (!(isfinite(p->n_ism) && p->n_ism >= 0)) return fail("n_ism must be non-negative and finite");
+    } else {
+        if (!finite_pos(p->A_star)) return fail("A_star must be positive and finite");
+        if (!(isfinite(p->n_ism) && p->n_ism >= 0)) return fail("n_ism must be non-negative and finite");
+        if (!(p->n0 > 0)) return fail("n0 must be > 0 (or +inf for no floor)");
+    }
+    if (!finite_pos(p->lumi_dist)) return fail("lumi_dist must be positive and finite");
+    if (!(isfinite(p->z) && p->z >= 0)) return fail("z must be non-negative and finite");
+    if (!(isfinite(p->theta_obs) && p->theta_obs >= 0 && p->theta_obs <= C_PI)) return fail("theta_obs must be in [0, pi]");
+    if (!range_oi(p->eps_e, 0.0, 1.0)) return fail("eps_e must be in (0, 1]");
+    if (!range_oi(p->eps_B, 0.0, 1.0)) return fail("eps_B must be in (0, 1]");
+    if (!range_oi(p->xi_e, 0.0, 1.0)) return fail("xi_e must be in (0, 1]");
+    if (!(isfinite(p->p) && p->p > 1.0)) return fail("p must be > 1");
+    if (!(isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return fail("rtol must be in (0, 1)");
+    if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
+        return fail("resolutions must be positive and finite");
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Orchestration: PyModel::compute_emission / single_shock_emission, pybind/pymodel.h:873-961
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    jet_t jet;
+    medium_t med;
+    coord_t coord;
+    shock_t shock;
+    eat_t eat;
+    electrons_t* el;
+    photons_t* ph;
+} pipeline_t;
+
+static void pipeline_free(pipeline_t* pl) {
+    coord_free(&pl->coord);
+    shock_free(&pl->shock);
+    eat_free(&pl->eat);
+    free(pl->el);
+    free(pl->ph);
+    pl->el = NULL;
+    pl->ph = NULL;
+}
+
+/* t_obs_min/max in code units */
+static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_min, double t_obs_max) {
+    memset(pl, 0, sizeof *pl);
+    if (vag_oracle_params_validate(p) != 0) return -1;
+    jet_init(&pl->jet, p);
+    medium_init(&pl->med, p);
+    auto_grid(&pl->coord, &pl->jet, &pl->med, t_obs_min, t_obs_max, C_PI / 2, p->theta_obs, p->z, p->phi_resol,
+              p->theta_resol, p->t_resol);
+    if (generate_fwd_shock(&pl->shock, &pl->coord, &pl->med, &pl->jet, p) != 0) {
+        pipeline_free(pl);
+        return -1;
+    }
+    observe(&pl->eat, &pl->coord, &pl->shock, p->lumi_dist * U_CM, p->z);
+    const size_t n = (size_t)pl->coord.n_theta * pl->coord.n_t;
+    pl->el = calloc(n, sizeof(electrons_t));
+    pl->ph = calloc(n, sizeof(photons_t));
+    generate_syn(pl->el, pl->ph, &pl->shock, &pl->coord, p);
+    return 0;
+}
+
+static int check_times(const double* t, int nt) {
+    if (nt <= 0) return fail("time array must be non-empty");
+    for (int i = 1; i < nt; ++i)
+        if (t[i] < t[i - 1]) return fail("time array must be in ascending order");
+    return 0;
+}
+
+static void minmax(const double* a, int n, double* lo, double* hi) {
+    *lo = a[0];
+    *hi = a[0];
+    for (int i = 1; i < n; ++i) {
+        if (a[i] < *lo) *lo = a[i];
+        if (a[i] > *hi) *hi = a[i];
+    }
+}
+
+int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                 double* out) {
+    if (check_times(t, nt) != 0) return -1;
+    if (nnu <= 0) return fail("frequency array must be non-empty");
+    double* t_obs = malloc(sizeof(double) * nt);
+    double* nu_obs = malloc(sizeof(double) * nnu);
+    for (int i = 0; i < nt; ++i) t_obs[i] = t[i] * U_SEC;
+    for (int l = 0; l < nnu; ++l) nu_obs[l] = nu[l] * U_HZ;
+    double lo, hi;
+    minmax(t_obs, nt, &lo, &hi);
+    pipeline_t pl;
+    int rc = run_pipeline(&pl, p, lo, hi);
+    if (rc == 0) {
+        specific_flux(&pl.eat, pl.ph, t_obs, nt, nu_obs, nnu, out);
+        for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] = out[q] / U_FLUX_DEN_CGS;
+        pipeline_free(&pl);
+    }
+    free(t_obs);
+    free(nu_obs);
+    return rc;
+}
+
+int vag_oracle_flux_density(const vag_model_params* p, const double* t, const double* nu, int n, double* out) {
+    if (check_times(t, n) != 0) return -1;
+    double* t_obs = malloc(sizeof(double) * n);
+    double* nu_obs = malloc(sizeof(double) * n);
+    for (int i = 0; i < n; ++i) {
+        t_obs[i] = t[i] * U_SEC;
+        nu_obs[i] = nu[i] * U_HZ;
+    }
+    double lo, hi;
+    minmax(t_obs, n, &lo, &hi);
+    pipeline_t pl;
+    int rc = run_pipeline(&pl, p, lo, hi);
+    if (rc == 0) {
+        specific_flux_series(&pl.eat, pl.ph, t_obs, nu_obs, n, out);
+        for (int i = 0; i < n; ++i) out[i] = out[i] / U_FLUX_DEN_CGS;
+        pipeline_free(&pl);
+    }
+    free(t_obs);
+    free(nu_obs);
+    return rc;
+}
+
+int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max, int num_nu,
+                    double* out) {
+    if (check_times(t, nt) != 0) return -1;
+    if (!(nu_min > 0)) return fail("nu_min must be positive");
+    if (!(nu_max > nu_min)) return fail("nu_max must be greater than nu_min");
+    if (num_nu < 2) return fail("num_nu must be at least 2");
+    double* t_obs = malloc(sizeof(double) * nt);
+    double* nu_obs = malloc(sizeof(double) * num_nu);
+    double* w = malloc(sizeof(double) * num_nu);
+    double* F = malloc(sizeof(double) * (size_t)num_nu * nt);
+    for (int i = 0; i < nt; ++i) t_obs[i] = t[i] * U_SEC;
+    logspace10(log10(nu_min * U_HZ), log10(nu_max * U_HZ), num_nu, nu_obs);
+    double lo, hi;
+    minmax(t_obs, nt, &lo, &hi);
+    pipeline_t pl;
+    int rc = run_pipeline(&pl, p, lo, hi);
+    if (rc == 0) {
+        specific_flux(&pl.eat, pl.ph, t_obs, nt, nu_obs, num_nu, F);
+        compute_boole_weights(nu_obs, num_nu, w);
+        for (int j = 0; j < nt; ++j) out[j] = 0;
+        for (int i = 0; i < num_nu; ++i)
+            for (int j = 0; j < nt; ++j) out[j] += F[(size_t)i * nt + j] * w[i];
+        for (int j = 0; j < nt; ++j) out[j] = out[j] / U_FLUX_CGS;
+        pipeline_free(&pl);
+    }
+    free(t_obs);
+    free(nu_obs);
+    free(w);
+    free(F);
+    return rc;
+}
+
+int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                       const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                       const double* probe_lg2_nu, int n_probe) {
+    pipeline_t pl;
+    if (run_pipeline(&pl, p, t_min * U_SEC, t_max * U_SEC) != 0) return -1;
+    const coord_t* c = &pl.coord;
+    const int nth = c->n_theta, nt = c->n_t;
+    shape->n_phi = c->n_phi;
+    shape->n_theta = nth;
+    shape->n_t = nt;
+    shape->n_reps = c->n_reps;
+    shape->symmetry = c->symmetry;
+    shape->phi_mirrored = c->phi_mirrored;
+    if (n_phi_eff) *n_phi_eff = pl.eat.n_phi_eff;
+    if (out) {
+        const size_t n = (size_t)nth * nt;
+        if (out->phi) memcpy(out->phi, c->phi, sizeof(double) * c->n_phi);
+        if (out->theta) memcpy(out->theta, c->theta, sizeof(double) * nth);
+#define COPY_(dst, src, scale) \
+    if (dst)                   \
+        for (size_t q = 0; q < n; ++q) (dst)[q] = (src)[q] * (scale);
+        COPY_(out->t_src, c->t, 1 / U_SEC)
+        COPY_(out->Gamma, pl.shock.Gamma, 1)
+        COPY_(out->r, pl.shock.r, 1 / U_CM)
+        COPY_(out->t_comv, pl.shock.t_comv, 1 / U_SEC)
+        COPY_(out->B, pl.shock.B, 1 / U_GAUSS)
+        COPY_(out->N_p, pl.shock.N_p, 1)
+        COPY_(out->Gamma_th, pl.shock.Gamma_th, 1)
+#undef COPY_
+#define EX_(i) ((extra && (i) < n_extra) ? extra[i] : NULL)
+        for (size_t q = 0; q < n; ++q) {
+            const electrons_t* e = &pl.el[q];
+            const photons_t* ph = &pl.ph[q];
+            if (EX_(0)) EX_(0)[q] = e->gamma_m;
+            if (EX_(1)) EX_(1)[q] = e->gamma_c;
+            if (EX_(2)) EX_(2)[q] = e->gamma_a;
+            if (EX_(3)) EX_(3)[q] = e->gamma_M;
+            if (EX_(4)) EX_(4)[q] = e->N_e;
+            if (EX_(5)) EX_(5)[q] = e->column_den;
+            if (EX_(6)) EX_(6)[q] = ph->nu_m;
+            if (EX_(7)) EX_(7)[q] = ph->nu_c;
+            if (EX_(8)) EX_(8)[q] = ph->nu_a;
+            if (EX_(9)) EX_(9)[q] = ph->nu_M;
+            if (EX_(10)) EX_(10)[q] = ph->I_nu_max;
+            if (EX_(14))
+                for (int s = 0; s < n_probe; ++s) EX_(14)[q * n_probe + s] = compute_log2_I_nu(ph, probe_lg2_nu[s]);
+        }
+        const size_t ne = (size_t)pl.eat.n_phi_eff * n;
+        if (EX_(11)) memcpy(EX_(11), pl.eat.lg2_t, sizeof(double) * ne);
+        if (EX_(12)) memcpy(EX_(12), pl.eat.lg2_doppler, sizeof(double) * ne);
+        if (EX_(13)) memcpy(EX_(13), pl.eat.lg2_geom, sizeof(double) * ne);
+#undef EX_
+    }
+    pipeline_free(&pl);
+    return 0;
+}
+
+/* Fitter._evaluate / _chi2_sum / eval_one: VegasAfterglow/fitting/fitter.py:497-533,
+ * fitting/samplers.py:61-70, transformer fitting/utils.py:110-135 */
+int vag_oracle_loglike_batch(const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {
+    if (ndim != spec->ndim || ndim > 16) return fail("ndim mismatch");
+    const int n = spec->n_data;
+    double* F = malloc(sizeof(double) * (n > 0 ? n : 1));
+    for (int b = 0; b < nb; ++b) {
+        vag_model_params p = spec->base;
+        double* fields = &p.theta_c;
+        for (int d = 0; d < ndim; ++d) {
+            const double v = theta[(size_t)b * ndim + d];
+            fields[spec->slot[d]] = spec->is_log[d] ? pow(10.0, v) : v;
+        }
+        if (vag_oracle_flux_density(&p, spec->t, spec->nu, n, F) != 0) {
+            out[b] = -INFINITY;
+            continue;
+        }
+        double chi2 = 0;
+        for (int i = 0; i < n; ++i) {
+            const double f = F[i];
+            const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300); /* np.maximum propagates NaN */
+            const double diff = spec->ln_flux[i] - log(fm);
+            const double q = diff / spec->ln_err[i];
+            chi2 += spec->weight[i] * (q * q);
+        }
+        out[b] = isfinite(chi2) ? -0.5 * chi2 : -INFINITY;
+    }
+    free(F);
+    return 0;
+}
