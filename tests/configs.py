@@ -1,0 +1,45 @@
+"""The BASELINE.json / SURVEY.md section 8(d) configurations as plain keyword dictionaries."""
+import numpy as np
+
+DAY = 86400.0
+
+C1_T = np.logspace(2, 8, 100)
+C1_NU = np.array([1e9, 4.84e14, 1e18])
+C1A = dict(jet="TophatJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, lumi_dist=1e28, z=1.0,
+           theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3, resolutions=(0.089, 0.05, 12.0))
+C1B = dict(C1A, theta_obs=0.05)
+
+C2_T = np.logspace(2, 8, 200)
+C2_NU = np.logspace(9, 18, 10)
+C2 = dict(jet="GaussianJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, lumi_dist=1e28, z=1.0,
+          theta_obs=0.3, eps_e=0.1, eps_B=0.01, p=2.3, resolutions=(0.355, 0.31, 20.5))
+
+# C4: GW170817-like mock: truth parameters, 3 bands x 20 epochs
+C4_TRUTH = dict(jet="GaussianJet", theta_c=0.07, E_iso=10 ** 52.4, Gamma0=500.0, medium="ISM", n_ism=1e-2,
+                lumi_dist=1.23e26, z=0.0098, theta_obs=0.4, eps_e=10 ** -1.5, eps_B=10 ** -3.5, p=2.15)
+C4_BANDS = np.array([3e9, 5.06e14, 2.41e17])
+C4_EPOCHS = np.geomspace(9 * DAY, 1000 * DAY, 20)
+# free parameters: (name, is_log, lower, upper)
+C4_FREE = [("E_iso", 1, 50.0, 54.0), ("Gamma0", 1, 1.5, 3.0), ("theta_c", 0, 0.02, 0.3), ("theta_v", 0, 0.0, 0.8),
+           ("n_ism", 1, -4.0, 1.0), ("p", 0, 2.05, 2.8), ("eps_e", 1, -3.0, -0.5), ("eps_B", 1, -5.0, -1.0)]
+
+EXTRA = {
+    "powerlaw_wind": (dict(jet="PowerLawJet", medium="Wind", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
+                           A_star=0.1, n_ism=0.0, theta_obs=0.2, resolutions=(0.29, 0.16, 10.0)),
+                      np.logspace(2, 8, 60), np.array([1e9, 4.84e14, 1e18])),
+    "tophat_wind_offaxis": (dict(jet="TophatJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.2),
+                            np.logspace(2, 8, 30), np.array([4.84e14])),
+    "two_component": (dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, theta_obs=0.15,
+                           resolutions=(0.2, 0.3, 8.0)), np.logspace(2, 8, 60), np.array([1e9, 4.84e14, 1e18])),
+    "gaussian_p_below_2": (dict(jet="GaussianJet", p=1.8, theta_obs=0.1), np.logspace(2, 8, 30), np.array([1e9, 1e15])),
+    "adiabatic": (dict(jet="TophatJet", radiative_fireball=False, theta_obs=0.0), np.logspace(2, 8, 30), np.array([1e9, 1e15])),
+    "narrow_window": (dict(jet="GaussianJet", theta_obs=0.3), np.geomspace(5 * DAY, 50 * DAY, 12), np.array([3e9, 5e14])),
+}
+
+
+def c4_mock_data():
+    """Mock data set of SURVEY 8(d) C4: returns sorted (t, nu, flux placeholder built by caller)."""
+    t = np.concatenate([C4_EPOCHS] * 3)
+    nu = np.concatenate([np.full(20, b) for b in C4_BANDS])
+    order = np.argsort(t, kind="stable")
+    return t[order], nu[order]

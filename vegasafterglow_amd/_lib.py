@@ -1,0 +1,129 @@
+"""ctypes binding of the C-ABI in include/vegasafterglow_amd.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+fallback of any kind: a missing library or a machine without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvegasafterglow_amd.so")
+
+JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT = 0, 1, 2, 3
+MEDIUM_ISM, MEDIUM_WIND = 0, 1
+
+VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
+
+# VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
+PARAM_SLOTS = {
+    "theta_c": 0, "E_iso": 1, "Gamma0": 2, "k_e": 3, "k_g": 4, "theta_w": 5, "E_iso_w": 6, "Gamma0_w": 7,
+    "tau": 8, "duration": 8, "n_ism": 9, "A_star": 10, "n0": 11, "lumi_dist": 12, "z": 13, "theta_v": 14,
+    "theta_obs": 14, "eps_e": 15, "eps_B": 16, "p": 17, "xi_e": 18,
+}
+
+
+class ModelParams(C.Structure):
+    _fields_ = [
+        ("jet_type", C.c_int32), ("medium_type", C.c_int32),
+        ("theta_c", C.c_double), ("E_iso", C.c_double), ("Gamma0", C.c_double),
+        ("k_e", C.c_double), ("k_g", C.c_double), ("theta_w", C.c_double),
+        ("E_iso_w", C.c_double), ("Gamma0_w", C.c_double), ("duration", C.c_double),
+        ("n_ism", C.c_double), ("A_star", C.c_double), ("n0", C.c_double),
+        ("lumi_dist", C.c_double), ("z", C.c_double), ("theta_obs", C.c_double),
+        ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
+        ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
+        ("radiative_fireball", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class FitSpec(C.Structure):
+    _fields_ = [
+        ("base", ModelParams), ("ndim", C.c_int32), ("slot", C.c_int32 * 16), ("is_log", C.c_int32 * 16),
+        ("n_data", C.c_int32), ("pad", C.c_int32),
+        ("t", C.POINTER(C.c_double)), ("nu", C.POINTER(C.c_double)), ("ln_flux", C.POINTER(C.c_double)),
+        ("ln_err", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
+    ]
+
+
+class DetailsShape(C.Structure):
+    _fields_ = [("n_phi", C.c_int32), ("n_theta", C.c_int32), ("n_t", C.c_int32), ("n_reps", C.c_int32),
+                ("symmetry", C.c_int32), ("phi_mirrored", C.c_int32)]
+
+
+class DetailsOut(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in
+                ("phi", "theta", "t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th")]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("grid_ms", "dynamics_ms", "cells_ms", "flux_ms", "reduce_ms", "total_ms")]
+
+
+class Limits(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("max_theta", "max_phi", "max_time", "max_nu")]
+
+
+EXPORTS = [
+    "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
+    "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
+    "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_batch", "vag_flux_batch",
+    "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
+    "vag_details", "vag_last_stage_times",
+]
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_pp = C.POINTER(ModelParams)
+
+
+def load():
+    """Load the HIP engine; raises ImportError (no silent CPU path) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the gfx950 engine first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(LIB_PATH)
+    v = C.c_void_p
+    lib.vag_last_error.restype = C.c_char_p
+    lib.vag_version.restype = C.c_char_p
+    lib.vag_params_default.argtypes = [_pp]
+    lib.vag_params_default.restype = None
+    lib.vag_params_validate.argtypes = [_pp]
+    lib.vag_ctx_create.argtypes = [C.c_int, C.POINTER(v)]
+    lib.vag_ctx_destroy.argtypes = [v]
+    lib.vag_ctx_destroy.restype = None
+    lib.vag_ctx_set_stream.argtypes = [v, v]
+    lib.vag_ctx_synchronize.argtypes = [v]
+    lib.vag_get_limits.argtypes = [C.POINTER(Limits)]
+    lib.vag_get_limits.restype = None
+    lib.vag_flux_density_grid_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]
+    lib.vag_flux_density_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, _dp]
+    lib.vag_flux_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]
+    lib.vag_flux_density_grid_batch_dev.argtypes = [v, v, C.c_int, v, C.c_int, v, C.c_int, v]
+    lib.vag_flux_density_batch_dev.argtypes = [v, v, C.c_int, v, v, C.c_int, v]
+    lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
+    lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
+    lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
+    lib.vag_last_stage_times.argtypes = [v, C.POINTER(StageTimes)]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().vag_last_error().decode()
+
+
+def check(rc):
+    """Map C-ABI error codes onto the reference's exception types (pybind/error_handling.h:12-27)."""
+    if rc == VAG_OK:
+        return
+    msg = last_error()
+    if rc == VAG_E_INVALID:
+        raise ValueError(msg)
+    if rc == VAG_E_NO_DEVICE:
+        raise RuntimeError("vegasafterglow_amd needs a HIP device (no CPU path): " + msg)
+    if rc == VAG_E_CAPACITY:
+        raise ValueError("engine capacity exceeded: " + msg)
+    raise RuntimeError(f"vegasafterglow_amd error {rc}: {msg}")

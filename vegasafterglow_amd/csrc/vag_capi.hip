@@ -1,0 +1,818 @@
+// vag_capi.hip -- C-ABI of the MI355X afterglow engine (include/vegasafterglow_amd.h).
+// Host orchestration only: every number the library returns is produced by the gfx950 kernels in
+// vag_grid_kernel.h / vag_kernels.h.  There is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vag_kernels.h"
+
+using namespace vag;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return set_err(VAG_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct HostBuf {  // pinned
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIPCHK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipHostMalloc(&p, bytes + bytes / 4 + 256, hipHostMallocDefault));
+        cap = bytes + bytes / 4 + 256;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+// prepares log2 arrays and the observer-time extrema on the device (single workgroup)
+__global__ void vag_prep_kernel(const double* __restrict__ t, int nt, const double* __restrict__ nu, int nnu,
+                                double* __restrict__ lg2_t, double* __restrict__ lg2_nu, double* __restrict__ tminmax) {
+    __shared__ double s_min[256], s_max[256];
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) {
+        const double v = t[i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+        lg2_t[i] = log2(v * U_SEC);  // xt::log2(t_obs), observer.h:359
+    }
+    for (int i = threadIdx.x; i < nnu; i += blockDim.x) lg2_nu[i] = log2(nu[i] * U_HZ);
+    s_min[threadIdx.x] = lo;
+    s_max[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + off]);
+            s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tminmax[0] = s_min[0];
+        tminmax[1] = s_max[0];
+    }
+}
+
+}  // namespace
+
+// ---- validation shared by host entry points; rules of pybind/pymodel.cpp:47-186, pymodel.h:205-260,613-649 ----
+static bool finite_pos(double x) { return std::isfinite(x) && x > 0; }
+static bool range_oi(double x, double lo, double hi) { return std::isfinite(x) && x > lo && x <= hi; }
+
+static const char* validate_msg(const vag_model_params* p) {
+    const double pi = 3.14159265358979323846;
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_TWO_COMPONENT) return "unknown jet_type";
+    if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return "unknown medium_type";
+    if (!range_oi(p->theta_c, 0.0, pi / 2)) return "theta_c must be in (0, pi/2]";
+    if (!finite_pos(p->E_iso)) return "E_iso must be positive and finite";
+    if (!(std::isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return "Gamma0 must be > 1";
+    if (!finite_pos(p->duration)) return "duration must be positive and finite";
+    if (p->jet_type == VAG_JET_POWERLAW) {
+        if (!finite_pos(p->k_e)) return "k_e must be positive and finite";
+        if (!finite_pos(p->k_g)) return "k_g must be positive and finite";
+    }
+    if (p->jet_type == VAG_JET_TWO_COMPONENT) {
+        if (!range_oi(p->theta_w, 0.0, pi / 2)) return "theta_w must be in (0, pi/2]";
+        if (!(p->theta_w > p->theta_c)) return "theta_w (wing angle) must be greater than theta_c (core angle)";
+        if (!finite_pos(p->E_iso_w)) return "E_iso_w must be positive and finite";
+        if (!(std::isfinite(p->Gamma0_w) && p->Gamma0_w > 1.0)) return "Gamma0_w must be > 1";
+    }
+    if (p->medium_type == VAG_MEDIUM_ISM) {
+        if (!(std::isfinite(p->n_ism) && p->n_ism >= 0)) return "n_ism must be non-negative and finite";
+    } else {
+        if (!finite_pos(p->A_star)) return "A_star must be positive and finite";
+        if (!(std::isfinite(p->n_ism) && p->n_ism >= 0)) return "n_ism must be non-negative and finite";
+        if (!(p->n0 > 0)) return "n0 must be > 0 (or +inf for no floor)";
+    }
+    if (!finite_pos(p->lumi_dist)) return "lumi_dist must be positive and finite";
+    if (!(std::isfinite(p->z) && p->z >= 0)) return "z must be non-negative and finite";
+    if (!(std::isfinite(p->theta_obs) && p->theta_obs >= 0 && p->theta_obs <= pi)) return "theta_obs must be in [0, pi]";
+    if (!range_oi(p->eps_e, 0.0, 1.0)) return "eps_e must be in (0, 1]";
+    if (!range_oi(p->eps_B, 0.0, 1.0)) return "eps_B must be in (0, 1]";
+    if (!range_oi(p->xi_e, 0.0, 1.0)) return "xi_e must be in (0, 1]";
+    if (!(std::isfinite(p->p) && p->p > 1.0)) return "p must be > 1";
+    if (!(std::isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return "rtol must be in (0, 1)";
+    if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
+        return "resolutions must be positive and finite";
+    if (p->reserved != 0) return "reserved field must be 0";
+    return nullptr;
+}
+
+struct vag_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // inputs
+    DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
+    // grid results
+    DevBuf d_meta, d_phi, d_theta, d_rep_of, d_rep_start, d_tdec;
+    HostBuf h_meta, h_off;
+    // compact per-row / per-cell storage
+    DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
+    // fit spec cache
+    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux;
+    // plan of the last grid pass
+    int nb = 0, n_rows = 0, max_k = 0, max_pairs = 0;
+    long long n_cells = 0, total_pairs = 0;
+    vag_stage_times times{};
+};
+
+extern "C" {
+
+const char* vag_last_error(void) { return g_err.c_str(); }
+const char* vag_version(void) { return "vegasafterglow_amd 0.1 (gfx950)"; }
+int vag_abi_version(void) { return VAG_ABI_VERSION; }
+
+void vag_params_default(vag_model_params* p) {
+    std::memset(p, 0, sizeof *p);
+    p->jet_type = VAG_JET_TOPHAT;
+    p->medium_type = VAG_MEDIUM_ISM;
+    p->theta_c = 0.1;
+    p->E_iso = 1e52;
+    p->Gamma0 = 300;
+    p->k_e = 2;
+    p->k_g = 2;
+    p->theta_w = 3.14159265358979323846 / 2;
+    p->E_iso_w = 1e52;
+    p->Gamma0_w = 300;
+    p->duration = 1;
+    p->n_ism = 1;
+    p->A_star = 0;
+    p->n0 = INFINITY;
+    p->lumi_dist = 1e28;
+    p->z = 0;
+    p->theta_obs = 0;
+    p->eps_e = 0.1;
+    p->eps_B = 0.01;
+    p->p = 2.3;
+    p->xi_e = 1;
+    p->phi_resol = 0.06;
+    p->theta_resol = 0.15;
+    p->t_resol = 6;
+    p->rtol = 1e-6;
+    p->radiative_fireball = 1;
+}
+
+int vag_params_validate(const vag_model_params* p) {
+    const char* msg = validate_msg(p);
+    return msg ? set_err(VAG_E_INVALID, "%s", msg) : VAG_OK;
+}
+
+int vag_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void vag_get_limits(vag_limits* out) {
+    out->max_theta = VAG_MAX_THETA;
+    out->max_phi = VAG_MAX_PHI;
+    out->max_time = VAG_MAX_TIME;
+    out->max_nu = VAG_MAX_NU;
+}
+
+int vag_ctx_create(int device, vag_ctx** out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_err(VAG_E_NO_DEVICE, "no HIP device available: the engine has no CPU path");
+    if (device < 0 || device >= n) return set_err(VAG_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    vag_ctx* c = new vag_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    // allow the flux kernels the full 160 KiB LDS of a gfx950 CU
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_series_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    *out = c;
+    return VAG_OK;
+}
+
+void vag_ctx_destroy(vag_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_row_off,
+                      &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
+                      &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
+        b->release();
+    c->h_meta.release();
+    c->h_off.release();
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int vag_ctx_set_stream(vag_ctx* c, void* s) {
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return VAG_OK;
+}
+
+int vag_ctx_synchronize(vag_ctx* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VAG_OK;
+}
+
+int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
+    *out = c->times;
+    return VAG_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// pipeline stages (host orchestration)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// Stage 1-3: adaptive grid -> blast-wave dynamics -> per-cell radiation, for nb models whose
+// parameters are already in HBM.  d_tminmax holds the observer-time extrema [s].
+int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool want_details) {
+    hipStream_t st = c->stream;
+    if (c->d_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
+    if (c->d_phi.ensure(sizeof(double) * (size_t)nb * VAG_MAX_PHI)) return VAG_E_HIP;
+    if (c->d_theta.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_rep_of.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_rep_start.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->h_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
+    if (c->h_off.ensure((sizeof(int) + sizeof(long long)) * (size_t)(nb + 1))) return VAG_E_HIP;
+    if (c->d_row_off.ensure(sizeof(int) * (size_t)(nb + 1))) return VAG_E_HIP;
+    if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
+
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
+                       c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
+                       c->d_rep_start.as<int>(), c->d_tdec.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    // grid shapes decide the compact layout and the launch geometry of everything downstream
+    VagGridMeta* hm = c->h_meta.as<VagGridMeta>();
+    HIPCHK(hipMemcpyAsync(hm, c->d_meta.p, sizeof(VagGridMeta) * nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    long long* h_cell = c->h_off.as<long long>();
+    int* h_row = reinterpret_cast<int*>(h_cell + (nb + 1));
+    long long cells = 0, pairs = 0;
+    int rows = 0, max_k = 2, max_pairs = 0;
+    for (int m = 0; m < nb; ++m) {
+        h_row[m] = rows;
+        h_cell[m] = cells;
+        if (hm[m].status == 0) {
+            rows += hm[m].n_reps;
+            cells += (long long)hm[m].n_reps * hm[m].n_t;
+            max_k = std::max(max_k, hm[m].n_t);
+            const int pr = hm[m].n_theta * hm[m].n_phi_eff;
+            max_pairs = std::max(max_pairs, pr);
+            pairs += pr;
+        }
+    }
+    h_row[nb] = rows;
+    h_cell[nb] = cells;
+    c->nb = nb;
+    c->n_rows = rows;
+    c->n_cells = cells;
+    c->max_k = max_k;
+    c->max_pairs = max_pairs;
+    c->total_pairs = pairs;
+    HIPCHK(hipMemcpyAsync(c->d_cell_off.p, h_cell, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_row_off.p, h_row, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, st));
+    if (rows == 0) {
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        return VAG_OK;
+    }
+    if (c->d_shock.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
+    if (c->d_cellpar.ensure(sizeof(double) * (size_t)cells * VAG_NPAR)) return VAG_E_HIP;
+    if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
+    if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * 11)) return VAG_E_HIP;
+    Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    hipLaunchKernelGGL(vag_dynamics_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+                       c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+                       c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
+                       c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
+                       want_details ? c->d_celldet.as<double>() : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    return VAG_OK;
+}
+
+int choose_pairs_per_block(const vag_ctx* c) {
+    // enough workgroups to fill 256 CUs several times over, but not so many that staging the photon rows
+    // and the partial grids dominate
+    long long ppb = (c->total_pairs + 16383) / 16384;
+    long long lo = 4;
+    if (c->total_pairs / 16 >= 2048) lo = 16;
+    if (c->total_pairs / 64 >= 4096) lo = 64;
+    ppb = std::max(ppb, lo);
+    ppb = std::min<long long>(ppb, std::max(1, c->max_pairs));
+    return (int)std::max<long long>(1, ppb);
+}
+
+// Stage 4-5 for a (t, nu) grid request: d_lg2t/d_lg2nu are log2 of code-unit times / frequencies.
+int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt,
+                  const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out) {
+    hipStream_t st = c->stream;
+    const int slots = nt * nnu;
+    if (slots > FLUX_THREADS * FLUX_MAX_SLOTS)
+        return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_THREADS * FLUX_MAX_SLOTS);
+    const int ppb = choose_pairs_per_block(c);
+    const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
+    if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
+    const int ks = c->max_k;
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3) * ks + (size_t)ks * nnu + nt + nnu) + sizeof(int) * nt;
+    if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
+    FluxArgs a;
+    a.params = d_params;
+    a.meta = c->d_meta.as<VagGridMeta>();
+    a.g_phi = c->d_phi.as<double>();
+    a.g_theta = c->d_theta.as<double>();
+    a.g_rep_of = c->d_rep_of.as<int>();
+    a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    a.cellpar = c->d_cellpar.as<double>();
+    a.lg2_t_obs = d_lg2t;
+    a.lg2_nu_obs = d_lg2nu;
+    a.nt = nt;
+    a.nnu = nnu;
+    a.pairs_per_block = ppb;
+    a.max_blocks = max_blocks;
+    a.k_stride = ks;
+    a.partial = c->d_partial.as<double>();
+    if (c->n_rows > 0) {
+        hipLaunchKernelGGL(vag_flux_grid_kernel, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    const int out_slots = d_bandw ? nt : slots;
+    hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
+                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    return VAG_OK;
+}
+
+__global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
+                                         const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
+                                         double* __restrict__ out) {
+    const int m = blockIdx.y;
+    const VagGridMeta M = meta[m];
+    const vag_model_params P = params[m];
+    const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block : 0;
+    const double d_L = P.lumi_dist * U_CM;
+    const double norm = (1 + P.z) / (d_L * d_L);
+    const double* src = partial + (size_t)m * max_blocks * n;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        double v = 0;
+        for (int b = 0; b < nblk; ++b) v += src[(size_t)b * n + s];
+        out[(size_t)m * n + s] = (M.status == 0) ? (v * norm) / U_FLUX_DEN_CGS : NAN;
+    }
+}
+
+int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
+                    int n, double* d_out) {
+    hipStream_t st = c->stream;
+    if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
+        return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
+    // series work per pair is small: fewer, longer workgroups
+    long long ppb = std::max<long long>(8, (c->total_pairs + 32767) / 32768);
+    ppb = std::min<long long>(ppb, std::max(1, c->max_pairs));
+    const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
+    if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
+    const int ks = c->max_k;
+    const size_t lds = sizeof(double) * (size_t)(VAG_NPAR + 3) * ks;
+    SeriesArgs a;
+    a.params = d_params;
+    a.meta = c->d_meta.as<VagGridMeta>();
+    a.g_phi = c->d_phi.as<double>();
+    a.g_theta = c->d_theta.as<double>();
+    a.g_rep_of = c->d_rep_of.as<int>();
+    a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    a.cellpar = c->d_cellpar.as<double>();
+    a.lg2_t_obs = d_lg2t;
+    a.lg2_nu_obs = d_lg2nu;
+    a.n = n;
+    a.pairs_per_block = (int)ppb;
+    a.max_blocks = max_blocks;
+    a.k_stride = ks;
+    a.partial = c->d_partial.as<double>();
+    if (c->n_rows > 0) {
+        hipLaunchKernelGGL(vag_flux_series_kernel, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, st, d_params,
+                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, (int)ppb, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    return VAG_OK;
+}
+
+int collect_times(vag_ctx* c) {
+    HIPCHK(hipEventSynchronize(c->ev[5]));
+    float v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[0], c->ev[1]));
+    c->times.grid_ms = v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[1], c->ev[2]));
+    c->times.dynamics_ms = v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[2], c->ev[3]));
+    c->times.cells_ms = v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[3], c->ev[4]));
+    c->times.flux_ms = v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[4], c->ev[5]));
+    c->times.reduce_ms = v;
+    HIPCHK(hipEventElapsedTime(&v, c->ev[0], c->ev[5]));
+    c->times.total_ms = v;
+    return VAG_OK;
+}
+
+int prep_times(vag_ctx* c, const double* d_t, int nt, const double* d_nu, int nnu) {
+    if (c->d_lg2t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
+    if (c->d_lg2nu.ensure(sizeof(double) * std::max(1, nnu))) return VAG_E_HIP;
+    if (c->d_tminmax.ensure(sizeof(double) * 2)) return VAG_E_HIP;
+    hipLaunchKernelGGL(vag_prep_kernel, dim3(1), dim3(256), 0, c->stream, d_t, nt, d_nu, nnu, c->d_lg2t.as<double>(),
+                       c->d_lg2nu.as<double>(), c->d_tminmax.as<double>());
+    HIPCHK(hipGetLastError());
+    return VAG_OK;
+}
+
+int check_host_inputs(const vag_model_params* params, int nb, const double* t, int nt) {
+    if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
+    if (nt <= 0) return set_err(VAG_E_INVALID, "time array must be non-empty");
+    for (int i = 0; i < nt; ++i)
+        if (!(t[i] > 0) || !std::isfinite(t[i])) return set_err(VAG_E_INVALID, "times must be positive and finite");
+    for (int i = 1; i < nt; ++i)
+        if (t[i] < t[i - 1]) return set_err(VAG_E_INVALID, "time array must be in ascending order");
+    for (int m = 0; m < nb; ++m) {
+        const char* msg = validate_msg(&params[m]);
+        if (msg) return set_err(VAG_E_INVALID, "model %d: %s", m, msg);
+    }
+    return VAG_OK;
+}
+
+int check_status(vag_ctx* c, int nb) {
+    const VagGridMeta* hm = c->h_meta.as<VagGridMeta>();
+    for (int m = 0; m < nb; ++m)
+        if (hm[m].status == VAG_E_CAPACITY)
+            return set_err(VAG_E_CAPACITY, "model %d: adaptive grid exceeds engine limits (theta %d, phi %d, time %d)", m,
+                           VAG_MAX_THETA, VAG_MAX_PHI, VAG_MAX_TIME);
+    return VAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt,
+                                    const double* d_nu, int nnu, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
+    if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = prep_times(c, d_t, nt, d_nu, nnu);
+    if (rc) return rc;
+    rc = run_model_stages(c, d_params, nb, false);
+    if (rc) return rc;
+    // chunk the time axis so each launch keeps its (idx, l) slots in registers
+    const int chunk = std::max(1, (FLUX_THREADS * FLUX_MAX_SLOTS) / nnu);
+    if (nt <= chunk) return run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, nullptr, d_out);
+    // chunks write [nb][nnu][chunk] blocks; assemble into [nb][nnu][nt]
+    DevBuf tmp;
+    if (tmp.ensure(sizeof(double) * (size_t)nb * nnu * chunk)) return VAG_E_HIP;
+    for (int t0 = 0; t0 < nt; t0 += chunk) {
+        const int n = std::min(chunk, nt - t0);
+        rc = run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>() + t0, n, c->d_lg2nu.as<double>(), nnu, nullptr, tmp.as<double>());
+        if (rc) break;
+        HIPCHK(hipMemcpy2DAsync(d_out + t0, sizeof(double) * nt, tmp.p, sizeof(double) * n, sizeof(double) * n,
+                                (size_t)nb * nnu, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    tmp.release();
+    return rc;
+}
+
+int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
+                               const double* d_nu, int n, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = prep_times(c, d_t, n, d_nu, n);
+    if (rc) return rc;
+    rc = run_model_stages(c, d_params, nb, false);
+    if (rc) return rc;
+    return run_flux_series(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
+}
+
+int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
+                                const double* nu, int nnu, double* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
+    int rc = check_host_inputs(params, nb, t, nt);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
+    if (c->d_nu.ensure(sizeof(double) * nnu)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nnu * nt)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * nnu, hipMemcpyHostToDevice, c->stream));
+    rc = vag_flux_density_grid_batch_dev(c, c->d_params.as<vag_model_params>(), nb, c->d_t.as<double>(), nt,
+                                         c->d_nu.as<double>(), nnu, c->d_out.as<double>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * nnu * nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
+    return check_status(c, nb);
+}
+
+int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu, int n,
+                           double* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    int rc = check_host_inputs(params, nb, t, n);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * n)) return VAG_E_HIP;
+    if (c->d_nu.ensure(sizeof(double) * n)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    rc = vag_flux_density_batch_dev(c, c->d_params.as<vag_model_params>(), nb, c->d_t.as<double>(), c->d_nu.as<double>(), n,
+                                    c->d_out.as<double>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
+    return check_status(c, nb);
+}
+
+int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                   double nu_max, int num_nu, double* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!(nu_min > 0)) return set_err(VAG_E_INVALID, "nu_min must be positive");
+    if (!(nu_max > nu_min)) return set_err(VAG_E_INVALID, "nu_max must be greater than nu_min");
+    if (num_nu < 2) return set_err(VAG_E_INVALID, "num_nu must be at least 2");
+    if (num_nu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d band frequencies", VAG_MAX_NU);
+    int rc = check_host_inputs(params, nb, t, nt);
+    if (rc) return rc;
+    if ((long long)nt * num_nu > FLUX_THREADS * FLUX_MAX_SLOTS)
+        return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_THREADS * FLUX_MAX_SLOTS);
+    // band grid and Boole weights are request metadata (src/core/quadrature.h:153-196, pymodel.cpp:398-399):
+    // nu = xt::logspace(log10(nu_min Hz), log10(nu_max Hz), num_nu) in code units
+    std::vector<double> nu_code(num_nu), nu_cgs(num_nu), w(num_nu, 0.0);
+    {
+        const double a = std::log10(nu_min * U_HZ), b = std::log10(nu_max * U_HZ);
+        const double step = (b - a) / std::fmax(1.0, (double)(num_nu - 1));
+        for (int i = 0; i < num_nu; ++i) {
+            nu_code[i] = std::pow(10.0, (i == num_nu - 1) ? b : a + step * (double)i);
+            nu_cgs[i] = nu_code[i] / U_HZ;
+        }
+        const int n = num_nu;
+        const double h = std::log(nu_code[1] / nu_code[0]);
+        const double cb = 2.0 * h / 45.0;
+        int j = 0;
+        for (; j + 4 < n; j += 4) {
+            w[j] += cb * 7;
+            w[j + 1] += cb * 32;
+            w[j + 2] += cb * 12;
+            w[j + 3] += cb * 32;
+            w[j + 4] += cb * 7;
+        }
+        const int rem = n - 1 - j;
+        if (rem == 3) {
+            const double c38 = 3.0 * h / 8.0;
+            w[j] += c38;
+            w[j + 1] += c38 * 3;
+            w[j + 2] += c38 * 3;
+            w[j + 3] += c38;
+        } else if (rem == 2) {
+            const double c13 = h / 3.0;
+            w[j] += c13;
+            w[j + 1] += c13 * 4;
+            w[j + 2] += c13;
+        } else if (rem == 1) {
+            w[j] += 0.5 * h;
+            w[j + 1] += 0.5 * h;
+        }
+        for (int i = 0; i < n; ++i) w[i] *= nu_code[i];
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
+    if (c->d_nu.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
+    if (c->d_bandw.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nu.p, nu_cgs.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_bandw.p, w.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
+    rc = prep_times(c, c->d_t.as<double>(), nt, c->d_nu.as<double>(), num_nu);
+    if (rc) return rc;
+    // the band nodes are exact code-unit values: overwrite log2(nu_cgs * Hz) with log2(nu_code) to avoid a round trip
+    std::vector<double> lg2nu(num_nu);
+    for (int i = 0; i < num_nu; ++i) lg2nu[i] = std::log2(nu_code[i]);
+    HIPCHK(hipMemcpyAsync(c->d_lg2nu.p, lg2nu.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
+    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
+    if (rc) return rc;
+    rc = run_flux_grid(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), num_nu,
+                       c->d_bandw.as<double>(), c->d_out.as<double>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
+    return check_status(c, nb);
+}
+
+static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
+    if (ndim != spec->ndim || ndim <= 0 || ndim > 16) return set_err(VAG_E_INVALID, "ndim must match spec and be in 1..16");
+    const int n = spec->n_data;
+    if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
+    for (int d = 0; d < ndim; ++d)
+        if (spec->slot[d] < 0 || spec->slot[d] >= VAG_P_COUNT) return set_err(VAG_E_INVALID, "bad parameter slot");
+    for (int i = 0; i < n; ++i)
+        if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");
+    for (int i = 1; i < n; ++i)
+        if (spec->t[i] < spec->t[i - 1]) return set_err(VAG_E_INVALID, "data times must be ascending (fitter.py:420-428)");
+    // [t | nu | ln_flux | ln_err | weight]
+    if (c->d_fit.ensure(sizeof(double) * 5 * (size_t)n)) return VAG_E_HIP;
+    if (c->d_slot.ensure(sizeof(int) * 32)) return VAG_E_HIP;
+    double* d = c->d_fit.as<double>();
+    HIPCHK(hipMemcpyAsync(d, spec->t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d + n, spec->nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d + 2 * (size_t)n, spec->ln_flux, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d + 3 * (size_t)n, spec->ln_err, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d + 4 * (size_t)n, spec->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_slot.p, spec->slot, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_slot.as<int>() + 16, spec->is_log, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
+    return VAG_OK;
+}
+
+__global__ void vag_valid_from_meta(const VagGridMeta* meta, int nb, int* valid) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nb) valid[m] = meta[m].status == 0;
+}
+
+int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = upload_fit_spec(c, spec, ndim);
+    if (rc) return rc;
+    const int n = spec->n_data;
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
+    if (c->d_valid.ensure(sizeof(int) * nb)) return VAG_E_HIP;
+    hipLaunchKernelGGL(vag_transform_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, spec->base, d_theta, nb, ndim,
+                       c->d_slot.as<int>(), c->d_slot.as<int>() + 16, c->d_params.as<vag_model_params>());
+    HIPCHK(hipGetLastError());
+    double* d = c->d_fit.as<double>();
+    rc = prep_times(c, d, n, d + n, n);
+    if (rc) return rc;
+    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
+    if (rc) return rc;
+    rc = run_flux_series(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
+                         c->d_series_flux.as<double>());
+    if (rc) return rc;
+    hipLaunchKernelGGL(vag_valid_from_meta, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb,
+                       c->d_valid.as<int>());
+    hipLaunchKernelGGL(vag_loglike_kernel, dim3(nb), dim3(64), 0, c->stream, c->d_series_flux.as<double>(), n,
+                       d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, c->d_valid.as<int>(), d_out);
+    HIPCHK(hipGetLastError());
+    return VAG_OK;
+}
+
+int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_theta_in.ensure(sizeof(double) * (size_t)nb * (ndim + 1))) return VAG_E_HIP;
+    double* d_theta = c->d_theta_in.as<double>();
+    double* d_out = d_theta + (size_t)nb * ndim;
+    HIPCHK(hipMemcpyAsync(d_theta, theta, sizeof(double) * (size_t)nb * ndim, hipMemcpyHostToDevice, c->stream));
+    int rc = vag_loglike_batch_dev(c, spec, d_theta, nb, ndim, d_out);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
+    return VAG_OK;
+}
+
+int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                const vag_details_out* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    const char* msg = validate_msg(params);
+    if (msg) return set_err(VAG_E_INVALID, "%s", msg);
+    if (!(t_min > 0) || !(t_max >= t_min)) return set_err(VAG_E_INVALID, "need 0 < t_min <= t_max");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params))) return VAG_E_HIP;
+    if (c->d_tminmax.ensure(sizeof(double) * 2)) return VAG_E_HIP;
+    const double tmm[2] = {t_min, t_max};
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_tminmax.p, tmm, sizeof tmm, hipMemcpyHostToDevice, c->stream));
+    int rc = run_model_stages(c, c->d_params.as<vag_model_params>(), 1, true);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = check_status(c, 1);
+    if (rc) return rc;
+    const VagGridMeta M = c->h_meta.as<VagGridMeta>()[0];
+    shape->n_phi = M.n_phi;
+    shape->n_theta = M.n_theta;
+    shape->n_t = M.n_t;
+    shape->n_reps = M.n_reps;
+    shape->symmetry = M.symmetry;
+    shape->phi_mirrored = M.phi_mirrored;
+    if (!out) return VAG_OK;
+    const int nth = M.n_theta, nt = M.n_t;
+    std::vector<double> theta(nth), buf((size_t)c->n_cells * VAG_NSHOCK);
+    std::vector<int> rep_of(nth);
+    HIPCHK(hipMemcpy(theta.data(), c->d_theta.p, sizeof(double) * nth, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rep_of.data(), c->d_rep_of.p, sizeof(int) * nth, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(buf.data(), c->d_shock.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    if (out->phi) HIPCHK(hipMemcpy(out->phi, c->d_phi.p, sizeof(double) * M.n_phi, hipMemcpyDeviceToHost));
+    if (out->theta) std::memcpy(out->theta, theta.data(), sizeof(double) * nth);
+    // Shock::broadcast_groups (src/dynamics/shock.cpp:42-91): every theta row shows its representative's state
+    auto expand = [&](double* dst, int which, double scale) {
+        if (!dst) return;
+        const double* src = buf.data() + (size_t)which * c->n_cells;
+        for (int j = 0; j < nth; ++j)
+            for (int k = 0; k < nt; ++k) dst[(size_t)j * nt + k] = src[(size_t)rep_of[j] * nt + k] * scale;
+    };
+    expand(out->t_src, VS_TENG, 1 / U_SEC);
+    expand(out->Gamma, VS_GAMMA, 1);
+    expand(out->r, VS_R, 1 / U_CM);
+    expand(out->t_comv, VS_TCOMV, 1 / U_SEC);
+    expand(out->B, VS_B, 1 / U_GAUSS);
+    expand(out->N_p, VS_NP, 1);
+    expand(out->Gamma_th, VS_GAMMA_TH, 1);
+    return VAG_OK;
+}
+
+}  // extern "C"

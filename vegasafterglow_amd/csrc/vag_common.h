@@ -1,0 +1,67 @@
+// vag_common.h -- layouts shared by the host C-ABI code and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/vegasafterglow_amd.h"
+
+// Static per-model capacities of the adaptive grid (src/core/grid-refinement.h:639-706 decides
+// the actual sizes at run time; these bound them).
+#define VAG_MAX_THETA 320   // theta nodes per model
+#define VAG_MAX_PHI 640     // phi nodes per model
+#define VAG_MAX_TIME 512    // time-lattice nodes per row
+#define VAG_MAX_NU 64       // frequencies per grid call
+#define VAG_MAX_JUMPS 16
+
+// symmetry levels, src/core/mesh.h:55-60
+#define VAG_SYM_STRUCTURED 0
+#define VAG_SYM_PHI_SYMMETRIC 1
+#define VAG_SYM_PIECEWISE 2
+#define VAG_SYM_ISOTROPIC 3
+
+// Per-model result of the grid kernel (Coord of src/core/mesh.h:66-95 minus the big arrays).
+struct VagGridMeta {
+    int32_t status;       // 0 ok, VAG_E_* otherwise
+    int32_t n_phi;        // |phi|
+    int32_t n_theta;      // |theta|
+    int32_t n_t;          // time nodes per row (incl. early point)
+    int32_t n_reps;       // representative theta rows actually solved
+    int32_t symmetry;     // VAG_SYM_*
+    int32_t phi_mirrored; // phi in [0, pi], weights doubled
+    int32_t n_phi_eff;    // Observer::eff_phi_grid (observer.cpp:218-222)
+    int32_t t_num_tot;    // lattice nodes without the early point
+    int32_t has_early;    // extra early node at index 0 (grid-refinement.h:583-591)
+    int32_t pad0, pad1;
+    double t_early;  // engine frame, code units
+    double t_start;  // min_t_start
+    double t_end;    // 1.01 t_max / (1+z)
+};
+
+// Per-cell parameter block the flux kernels stage in LDS: [row][VAG_NPAR][n_t].
+// 0..12: cached SmoothPowerLawSyn members read by compute_log2_I_nu
+//        (src/radiation/smooth-power-law-syn.h:20-47); 13..16: what the EAT step needs
+//        (src/core/observer.cpp:143-205).
+enum {
+    VP_LG2_I = 0,   // log2_I_nu_max
+    VP_LG2_NUM,     // log2_nu_m
+    VP_LG2_NUMAX,   // log2_nu_M
+    VP_INV_NUMAX,   // log2(e) / nu_M
+    VP_NORM,        // log2_norm_
+    VP_TNORM,       // log2_thick_norm_
+    VP_SAB,         // s_a_blend_
+    VP_INV_SAB,     // 1 / s_a_blend_
+    VP_LG2_LO,      // log2_nu_lo_
+    VP_LG2_HI,      // log2_nu_hi_
+    VP_DLO,         // diff_lo_
+    VP_DHI,         // diff_hi_
+    VP_INV_SLO,     // 1 / smooth_lo_
+    VP_INV_SHI,     // 1 / smooth_hi_
+    VP_GAMMA,       // bulk Lorentz factor
+    VP_U,           // sqrt((Gamma-1)(Gamma+1))
+    VP_R,           // radius
+    VP_LG2_R2,      // 2 log2 r
+    VP_TENG,        // engine-frame lattice time
+    VAG_NPAR
+};
+
+// Shock-state arrays written by the dynamics kernel (Shock, src/dynamics/shock.h:26-88), SoA over cells.
+enum { VS_TENG = 0, VS_TCOMV, VS_R, VS_GAMMA, VS_GAMMA_TH, VS_B, VS_NP, VAG_NSHOCK };

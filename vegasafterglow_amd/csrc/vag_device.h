@@ -1,0 +1,607 @@
+// vag_device.h -- gfx950 device-side physics of the forward-shock synchrotron path.
+// All arithmetic FP64.  Each block cites the reference code it must agree with.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vag_common.h"
+
+#define VAG_DEV __device__ __forceinline__
+
+namespace vag {
+
+// ---- units and constants: src/util/macros.h:43-110 (same expression order => same roundings) ----
+constexpr double U_LEN = 1.5e13;
+constexpr double U_CM = 1 / U_LEN;
+constexpr double U_SEC = 3e10 / U_LEN;
+constexpr double U_CM2 = U_CM * U_CM;
+constexpr double U_CM3 = U_CM * U_CM * U_CM;
+constexpr double U_G = 1 / 2e33;
+constexpr double U_GAUSS = 8.66e-11 / U_SEC;
+constexpr double U_HZ = 1 / U_SEC;
+constexpr double U_ERG = U_G * U_CM * U_CM / U_SEC / U_SEC;
+constexpr double U_FLUX_CGS = U_ERG / U_CM2 / U_SEC;
+constexpr double U_FLUX_DEN_CGS = U_ERG / U_CM2 / U_SEC / U_HZ;
+constexpr double C_C = 1.0;
+constexpr double C_C2 = C_C * C_C;
+constexpr double C_MP = 1.67e-24 * U_G;
+constexpr double C_ME = C_MP / 1836;
+constexpr double C_E = 4.8e-10 / 4.472136e16 / 5.809475e19 / U_SEC;
+constexpr double C_E2 = C_E * C_E;
+constexpr double C_E3 = C_E2 * C_E;
+constexpr double C_PI = 3.14159265358979323846;
+constexpr double C_SIGMAT = 6.65e-25 * U_CM * U_CM;
+constexpr double GAMMA_CUT = 1.0 + 1e-6;  // src/config/simulation-defaults.h:38-48
+constexpr double LN2 = 0.693147180559945309417232121458176568;
+constexpr double LOG2E = 1.442695040888963407359924681001892137;
+constexpr double SQRT3 = 1.732050807568877293527446341505872367;
+
+VAG_DEV double dmin(double a, double b) { return b < a ? b : a; }
+VAG_DEV double dmax(double a, double b) { return a < b ? b : a; }
+
+// src/util/fast-math.h:179-202 (exact-libm build)
+VAG_DEV double log2_softplus(double x) {
+    if (x > 20.0) return x;
+    if (x < -20.0) return 0.0;
+    return log2(1.0 + exp2(x));
+}
+VAG_DEV double fast_pow(double a, double b) { return exp2(b * log2(a)); }
+
+// src/core/physics.h:36-61
+VAG_DEV double gamma_to_beta(double g) { return sqrt((g - 1) * (g + 1)) / g; }
+VAG_DEV double adiabatic_idx(double g) { return 4.0 / 3.0 + 1 / (3 * g); }
+// src/core/grid-refinement.h:33-35
+VAG_DEV double structure_weight(double G) { return G * sqrt(dmax((G - 1) * G, 0.0)); }
+
+// ---- jet / medium in code units: src/environment/jet.h:84-259,421-441, medium.h:50-133,
+//      unit handling of pybind/pymodel.cpp:47-210 ----
+struct Jet {
+    int type;
+    double theta_c, eps_k, Gamma0, k_e, k_g, norm;
+    double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w, T0;
+};
+struct Medium {
+    int type;
+    double rho_ism, A, r02;
+};
+
+VAG_DEV void jet_init(Jet& j, const vag_model_params& p) {
+    j.type = p.jet_type;
+    j.theta_c = p.theta_c;
+    j.eps_k = (p.E_iso * U_ERG) / (4 * C_PI);
+    j.Gamma0 = p.Gamma0;
+    j.k_e = p.k_e;
+    j.k_g = p.k_g;
+    j.norm = -1 / (2 * p.theta_c * p.theta_c);
+    j.theta_w = p.theta_w;
+    j.E_iso_cgs = p.E_iso;
+    j.E_iso_w_cgs = p.E_iso_w;
+    j.Gm1 = p.Gamma0 - 1;
+    j.Gm1_w = p.Gamma0_w - 1;
+    j.T0 = p.duration * U_SEC;
+}
+VAG_DEV double jet_eps_k(const Jet& j, double theta) {
+    switch (j.type) {
+        case VAG_JET_TOPHAT: return theta < j.theta_c ? j.eps_k : 0;
+        case VAG_JET_GAUSSIAN: return j.eps_k * exp(theta * theta * j.norm);
+        case VAG_JET_POWERLAW: return j.eps_k / (1 + fast_pow(theta / j.theta_c, j.k_e));
+        default: {
+            const double h = theta <= j.theta_c ? j.E_iso_cgs : (theta <= j.theta_w ? j.E_iso_w_cgs : 0.);
+            return h * (U_ERG / (4 * C_PI));
+        }
+    }
+}
+VAG_DEV double jet_Gamma0(const Jet& j, double theta) {
+    switch (j.type) {
+        case VAG_JET_TOPHAT: return theta < j.theta_c ? j.Gamma0 : 1;
+        case VAG_JET_GAUSSIAN: return (j.Gamma0 - 1) * exp(theta * theta * j.norm) + 1;
+        case VAG_JET_POWERLAW: return (j.Gamma0 - 1) / (1 + fast_pow(theta / j.theta_c, j.k_g)) + 1;
+        default: {
+            const double h = theta <= j.theta_c ? j.Gm1 : (theta <= j.theta_w ? j.Gm1_w : 0.);
+            return h + 1;
+        }
+    }
+}
+VAG_DEV void medium_init(Medium& m, const vag_model_params& p) {
+    m.type = p.medium_type;
+    m.A = 0;
+    m.r02 = 0;
+    if (m.type == VAG_MEDIUM_ISM) {
+        m.rho_ism = (p.n_ism / U_CM3) * C_MP;
+    } else {
+        const double n_ism = p.n_ism / U_CM3, n0 = p.n0 / U_CM3;
+        m.A = p.A_star * 5e11 * U_G / U_CM;
+        m.rho_ism = n_ism * C_MP;
+        m.r02 = m.A / (n0 * 1.3 * C_MP);
+    }
+}
+VAG_DEV double medium_rho(const Medium& m, double r) {
+    if (m.type == VAG_MEDIUM_ISM) return m.rho_ism;
+    return m.A / (m.r02 + r * r) + m.rho_ism;
+}
+VAG_DEV double medium_mass(const Medium& m, double r) {
+    double mass = m.rho_ism * r * r * r / 3.0;
+    if (m.type != VAG_MEDIUM_ISM && m.A != 0) {
+        if (m.r02 > 0) {
+            const double a = sqrt(m.r02);
+            mass += m.A * (r - a * atan(r / a));
+        } else {
+            mass += m.A * r;
+        }
+    }
+    return mass;
+}
+
+// Parameter validation on the device: same rules as vag_params_validate
+// (pybind/pymodel.cpp:47-186, pybind/pymodel.h:205-260,613-649).
+VAG_DEV bool params_valid(const vag_model_params& p) {
+    auto fpos = [](double x) { return isfinite(x) && x > 0; };
+    auto oi = [](double x, double lo, double hi) { return isfinite(x) && x > lo && x <= hi; };
+    bool ok = p.jet_type >= 0 && p.jet_type <= VAG_JET_TWO_COMPONENT && p.medium_type >= 0 &&
+              p.medium_type <= VAG_MEDIUM_WIND;
+    ok = ok && oi(p.theta_c, 0.0, C_PI / 2) && fpos(p.E_iso) && isfinite(p.Gamma0) && p.Gamma0 > 1.0 && fpos(p.duration);
+    if (p.jet_type == VAG_JET_POWERLAW) ok = ok && fpos(p.k_e) && fpos(p.k_g);
+    if (p.jet_type == VAG_JET_TWO_COMPONENT)
+        ok = ok && oi(p.theta_w, 0.0, C_PI / 2) && p.theta_w > p.theta_c && fpos(p.E_iso_w) && isfinite(p.Gamma0_w) &&
+             p.Gamma0_w > 1.0;
+    ok = ok && isfinite(p.n_ism) && p.n_ism >= 0;
+    if (p.medium_type == VAG_MEDIUM_WIND) ok = ok && fpos(p.A_star) && p.n0 > 0;
+    ok = ok && fpos(p.lumi_dist) && isfinite(p.z) && p.z >= 0 && isfinite(p.theta_obs) && p.theta_obs >= 0 &&
+         p.theta_obs <= C_PI;
+    ok = ok && oi(p.eps_e, 0.0, 1.0) && oi(p.eps_B, 0.0, 1.0) && oi(p.xi_e, 0.0, 1.0) && isfinite(p.p) && p.p > 1.0;
+    ok = ok && isfinite(p.rtol) && p.rtol > 0 && p.rtol < 1 && fpos(p.phi_resol) && fpos(p.theta_resol) && fpos(p.t_resol);
+    return ok;
+}
+
+// ---- DOPRI5(4) with boost::odeint's controller and dense output, register resident ----
+// external/boost/numeric/odeint/stepper/runge_kutta_dopri5.hpp:88-258,
+// controlled_runge_kutta.hpp:56-156,752-782, dense_output_runge_kutta.hpp:324-361.
+template <int N>
+struct Dopri5 {
+    double x[N], dx[N];          // current state / derivative (FSAL)
+    double xo[N], dxo[N];        // previous state / derivative
+    double k3[N], k4[N], k5[N], k6[N];
+    double t, t_old, dt, eps;
+
+    template <class F>
+    VAG_DEV void init(const double* x0, double t0, double dt0, double tol, F& f) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = x0[i];
+        t = t0;
+        dt = dt0;
+        eps = tol;
+        f(x, dx, t);
+    }
+
+    // one accepted step; returns false after 500 consecutive rejections
+    template <class F>
+    VAG_DEV bool step(F& f) {
+        constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+        constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40;
+        constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
+        constexpr double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729;
+        constexpr double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176,
+                         b65 = -5103.0 / 18656;
+        constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+        constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
+                         dc5 = c5 - -92097.0 / 339200, dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+        t_old = t;
+        for (int fails = 0; fails < 500; ++fails) {
+            double xt[N], k2[N], xn[N], k7[N];
+            const double h = dt;
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b21) * dx[i];
+            f(xt, k2, t + h * a2);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b31) * dx[i] + (h * b32) * k2[i];
+            f(xt, k3, t + h * a3);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b41) * dx[i] + (h * b42) * k2[i] + (h * b43) * k3[i];
+            f(xt, k4, t + h * a4);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xt[i] = x[i] + (h * b51) * dx[i] + (h * b52) * k2[i] + (h * b53) * k3[i] + (h * b54) * k4[i];
+            f(xt, k5, t + h * a5);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xt[i] = x[i] + (h * b61) * dx[i] + (h * b62) * k2[i] + (h * b63) * k3[i] + (h * b64) * k4[i] +
+                        (h * b65) * k5[i];
+            f(xt, k6, t + h);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xn[i] = x[i] + (h * c1) * dx[i] + (h * c3) * k3[i] + (h * c4) * k4[i] + (h * c5) * k5[i] + (h * c6) * k6[i];
+            f(xn, k7, t + h);
+            double err = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double xe = (h * dc1) * dx[i] + (h * dc3) * k3[i] + (h * dc4) * k4[i] + (h * dc5) * k5[i] +
+                                  (h * dc6) * k6[i] + (h * dc7) * k7[i];
+                err = dmax(err, fabs(xe) / (eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
+            }
+            if (err > 1.0) {
+                dt = h * dmax(9.0 / 10.0 * pow(err, -1.0 / 3), 1.0 / 5.0);
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                xo[i] = x[i];
+                dxo[i] = dx[i];
+                x[i] = xn[i];
+                dx[i] = k7[i];
+            }
+            t = t + h;
+            if (err < 0.5) {
+                err = dmax(3.2e-4, err);  // 5^-5
+                dt = h * (9.0 / 10.0 * pow(err, -1.0 / 5));
+            }
+            return true;
+        }
+        return false;
+    }
+
+    // dense output at tq in (t_old, t]
+    VAG_DEV void interp(double tq, double* out) const {
+        constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+        const double h = t - t_old;
+        const double th = (tq - t_old) / h;
+        const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) / 11282082432.0;
+        const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) / 32700410799.0;
+        const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) / 1880347072.0;
+        const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) / 199316789632.0;
+        const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) / 822651844.0;
+        const double X7 = 10.0 * (7414447.0 - 829305.0 * th) / 29380423.0;
+        const double thm1 = th - 1.0, th2 = th * th;
+        const double A = th2 * (3.0 - 2.0 * th);
+        const double B = th2 * thm1;
+        const double C = th2 * thm1 * thm1;
+        const double D = th * thm1 * thm1;
+        const double w1 = h * (A * b1 - C * X1 + D), w3 = h * (A * b3 + C * X3), w4 = h * (A * b4 - C * X4),
+                     w5 = h * (A * b5 + C * X5), w6 = h * (A * b6 - C * X6), w7 = h * (B + C * X7);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            out[i] = xo[i] + w1 * dxo[i] + w3 * k3[i] + w4 * k4[i] + w5 * k5[i] + w6 * k6[i] + w7 * dx[i];
+    }
+};
+
+// ---- deceleration time estimate: src/core/grid-refinement.h:402-453 ----
+VAG_DEV double estimate_t_dec(const Jet& jet, const Medium& med, double theta) {
+    const double gamma = jet_Gamma0(jet, theta);
+    const double beta = gamma_to_beta(gamma);
+    const double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2);
+    const double target = m_jet / gamma;
+    const double r_min = 1e-3;
+    const double r_max = r_min * 1e40;
+    const double kin = (1 - beta) / (beta * C_C);
+    if (target <= 0) return r_min * kin;
+    if (med.type == VAG_MEDIUM_ISM) {
+        const double rho = med.rho_ism;
+        if (rho > 0) {
+            const double r3_dec = r_min * r_min * r_min + 3 * target / rho;
+            const double r_dec = cbrt(dmax(r3_dec, 0.0));
+            return dmin(r_dec, r_max) * kin;
+        }
+        return r_max * kin;
+    }
+    const int N = 256;
+    const double u_min = log(1e-3);
+    const double u_max = u_min + 40 * log(10.0);
+    const double du = (u_max - u_min) / N;
+    double mass = 0;
+    double r_prev = exp(u_min);
+    double f_prev = medium_rho(med, r_prev) * r_prev * r_prev;
+    for (int i = 1; i <= N; ++i) {
+        const double r_i = exp(u_min + i * du);
+        const double f_i = medium_rho(med, r_i) * r_i * r_i;
+        const double dr = r_i - r_prev;
+        mass += 0.5 * (f_prev + f_i) * dr;
+        if (mass >= target) {
+            const double r_dec = r_prev + (target - (mass - 0.5 * (f_prev + f_i) * dr)) / f_i;
+            return r_dec * kin;
+        }
+        f_prev = f_i;
+        r_prev = r_i;
+    }
+    return exp(u_max) * kin;
+}
+
+// ---- per-row log time lattice with a 3x denser band around t_dec:
+//      src/core/grid-refinement.h:533-581 (logspace_with_band_refinement, make_time_grid) ----
+struct TimeLattice {
+    int n, n1, n2, n3, plain;
+    double l0, l1, l2, l3, step;
+    VAG_DEV void init(double ts, double t_end, double t_dec, int n_nodes) {
+        n = n_nodes;
+        double b_lo = dmax(t_dec / 3, ts);
+        double b_hi = dmin(3 * t_dec, t_end);
+        l0 = log10(ts);
+        l3 = log10(t_end);
+        plain = (!(b_hi > b_lo) || n < 8);
+        if (plain) {
+            step = (l3 - l0) / fmax(1.0, (double)(n - 1));  // xt::linspace, xbuilder.hpp:460-471
+            n1 = n2 = n3 = 0;
+            l1 = l2 = 0;
+            return;
+        }
+        l1 = log10(b_lo);
+        l2 = log10(b_hi);
+        const double w1 = l1 - l0, w2 = 3.0 * (l2 - l1), w3 = l3 - l2;
+        const int segs = n - 1;
+        n1 = (int)round((double)segs * w1 / (w1 + w2 + w3));
+        n3 = (int)round((double)segs * w3 / (w1 + w2 + w3));
+        if (segs - 2 < n1) n1 = segs - 2;
+        if (segs - 1 - n1 - 1 < n3) n3 = segs - 1 - n1 - 1;
+        n2 = segs - n1 - n3;
+        step = 0;
+    }
+    // node kk in [0, n)
+    VAG_DEV double node(int kk) const {
+        double lg;
+        if (plain) {
+            lg = (n > 1 && kk == n - 1) ? l3 : l0 + step * (double)kk;
+        } else if (kk < n1) {
+            lg = l0 + (l1 - l0) * (double)kk / (double)n1;
+        } else if (kk < n1 + n2) {
+            lg = l1 + (l2 - l1) * (double)(kk - n1) / (double)n2;
+        } else {
+            const int q = kk - n1 - n2;
+            lg = (n3 > 0) ? l2 + (l3 - l2) * (double)q / (double)n3 : l3;
+        }
+        return pow(10.0, lg);
+    }
+};
+
+// ---- forward-shock blast wave: src/dynamics/forward-shock.tpp:10-173, shock-physics.h ----
+struct FwdShock {
+    Medium med;
+    double m_jet0, gamma_m_coeff, gamma_c_coeff, eps_e_eff, p, eps_B;
+
+    // state [Gamma, m2, U2_th, r, t_comv]; theta is constant for non-spreading jets and its
+    // zero derivative never contributes to the error norm, so it is not integrated.
+    VAG_DEV void operator()(const double* s, double* d, double /*t*/) const {
+        const double Gamma = s[0], m2 = s[1], U = s[2], r = s[3], t_comv = s[4];
+        const double u2 = (Gamma - 1) * (Gamma + 1);
+        const double u = sqrt(u2);
+        const double dr = u * (Gamma + u) * C_C;
+        d[3] = dr;
+        d[4] = Gamma + u;
+        const double rho = medium_rho(med, r);
+        const double dm = r * r * rho * dr;
+        d[1] = dm;
+        const double e_th = (Gamma - 1) * 4 * Gamma * rho * C_C2;
+        double eps_rad = 0;  // RadiativeEfficiency, shock-physics.h:247-288
+        if (eps_e_eff != 0) {
+            const double gamma_m = gamma_m_coeff * (Gamma - 1) + 1;
+            const double gamma_bar = gamma_c_coeff / (e_th * t_comv);
+            const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
+            const double ratio = gamma_m / gamma_c;
+            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * fast_pow(ratio, p - 2) : eps_e_eff;
+        }
+        const double ad = adiabatic_idx(Gamma);
+        const double Gamma2 = Gamma * Gamma;
+        const double Gamma_eff = (ad * (Gamma2 - 1) + 1) / Gamma;
+        const double dGamma_eff = (ad * (Gamma2 + 1) - 1) / Gamma2;
+        const double dlnV = 3 / r * dr;
+        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm;
+        const double a2 = (ad - 1) * Gamma_eff * U * dlnV;
+        const double b1 = (m_jet0 + m2) * C_C2;
+        const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) / Gamma) * U;
+        const double dG = (a1 + a2) / (b1 + b2);
+        d[0] = dG;
+        const double dlnV2 = 3 / r * dr - dG / Gamma;
+        d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm - (ad - 1) * dlnV2 * U;
+    }
+};
+
+// enclosed_thermal_energy_medium, shock-physics.h:401-468
+VAG_DEV double enclosed_thermal_energy(const Medium& med, double r, double Gamma, double ad, double eps_e) {
+    const double cooling_exp = 3 * (ad - 1);
+    if (med.type == VAG_MEDIUM_ISM) {
+        const double pow_exp = 3 + cooling_exp;
+        const double x0 = exp(-18.0);
+        const double attenuation = 1 - pow(x0, pow_exp);
+        const double integral = med.rho_ism * r * r * r * attenuation / pow_exp;
+        return (1 - eps_e) * (Gamma - 1) * C_C2 * integral;
+    }
+    const int N = 32;
+    const double u_max = log(r), u_min = u_max - 18, h = (u_max - u_min) / N;
+    auto f = [&](double u) {
+        const double ri = exp(u);
+        return medium_rho(med, ri) * ri * ri * ri * pow(ri / r, cooling_exp);
+    };
+    double sum = f(u_min) + f(u_max);
+    for (int i = 1; i < N; i += 2) sum += 4 * f(u_min + i * h);
+    for (int i = 2; i < N; i += 2) sum += 2 * f(u_min + i * h);
+    return (1 - eps_e) * (Gamma - 1) * C_C2 * (sum * h / 3);
+}
+
+// compute_compression(1, Gamma, 0): shock-physics.h:58-66,190-203,349-352; shock.cpp:93-100
+VAG_DEV double compression_fwd(double Gd) {
+    const double dd = 1 - Gd;
+    const double denom = Gd - 1;
+    const double g = denom <= 0 ? 1 : 1 + dd * dd / denom;
+    const double ad = adiabatic_idx(g);
+    const double gm1 = g - 1, adm2 = ad - 2, adm1 = ad - 1;
+    const double u_down = sqrt(dmax(gm1 * adm1 * adm1 / (-ad * adm2 * gm1 + 2), 0.0));
+    const double u_up = sqrt((1 + u_down * u_down) * dmax((g - 1) * (g + 1), 0.0)) + u_down * g;
+    return (u_down == 0.) ? 4 * g : u_up / u_down;
+}
+
+// ---- synchrotron electrons + photons for one cell: src/radiation/synchrotron.cpp:45-254,315-408,
+//      smooth-power-law-syn.cpp:49-153.  Writes the VAG_NPAR block. ----
+VAG_DEV double syn_freq(double gamma, double B) {
+    if (B == 0 || !isfinite(gamma)) return 0;
+    return 3 * C_E / (4 * C_PI * C_ME * C_C) * B * gamma * gamma;
+}
+VAG_DEV double syn_I_peak(double B, double column_den) {
+    const double P = B * ((C_PI / 4) * 0.92 * SQRT3 * C_E3 / (C_ME * C_C2));
+    return P * column_den / (4 * C_PI);
+}
+VAG_DEV double sigmoid2(double x) { return 1.0 / (1.0 + exp2(-x)); }
+VAG_DEV double blend(double w, double a, double b) { return w * a + (1.0 - w) * b; }
+
+struct CellOut {
+    double par[VAG_NPAR];
+    // for Model.details-style inspection
+    double gamma_m, gamma_c, gamma_a, gamma_M, N_e, column_den, nu_m, nu_c, nu_a, nu_M, I_nu_max;
+};
+
+VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
+                      double N_p, double eps_e, double p, double xi_e) {
+    // --- electrons (synchrotron.cpp:315-360) ---
+    const double gamma_M = (B == 0) ? INFINITY : sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + 0.)));
+    const double gamma_ave_m1 = eps_e * (Gamma_th - 1) * (C_MP / C_ME) / xi_e;
+    double gm_m1;
+    if (p > 2) {
+        gm_m1 = (p - 2) / (p - 1) * gamma_ave_m1;
+    } else if (p < 2) {
+        gm_m1 = pow((2 - p) / (p - 1) * gamma_ave_m1 * pow(gamma_M, p - 2), 1 / (p - 1));
+    } else {  // root_bisect, utilities.h:230-241
+        auto eq = [&](double x) { return x * log(gamma_M) - (x + 1) * log(x) - gamma_ave_m1 - log(gamma_M); };
+        double low = 0, high = gamma_M;
+        for (int it = 0; it < 1000 && (high - low) > fabs((high + low) * 0.5) * 1e-6; ++it) {
+            const double mid = 0.5 * (high + low);
+            if (eq(mid) * eq(high) > 0)
+                high = mid;
+            else
+                low = mid;
+        }
+        gm_m1 = 0.5 * (high + low);
+    }
+    const double gamma_m = gm_m1 + 1;
+    double f_syn = (gamma_m - 1) / gamma_m;
+    if (p > 3) f_syn = fast_pow(f_syn, (p - 1) / 2);
+    const double N_e = N_p * xi_e * f_syn;
+    const double column_den = N_e / (r * r);
+    const double I_peak = syn_I_peak(B, column_den);
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + 0.) * t_comv) * 1;
+    const double gamma_c = (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+    // compute_syn_gamma_a with no IC (ratio exactly 1), synchrotron.cpp:212-246
+    double gamma_a;
+    {
+        const double gamma_peak = dmin(gamma_m, gamma_c);
+        const double nu_peak = syn_freq(gamma_peak, B);
+        const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
+        double nu_a = fast_pow(I_peak * C_C2 / (cbrt(nu_peak) * 2 * kT), 0.6);
+        if (nu_a > nu_peak) {
+            if (gamma_c > gamma_m) {
+                const double nu_m = syn_freq(gamma_m, B);
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * fast_pow(nu_m, p / 2), 2 / (p + 4));
+                const double nu_c = syn_freq(gamma_c, B);
+                if (nu_a > nu_c)
+                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+            } else {
+                const double nu_c = syn_freq(gamma_c, B);
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
+                const double nu_m = syn_freq(gamma_m, B);
+                if (nu_a > nu_m)
+                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+            }
+        }
+        gamma_a = sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu_a / B)) + 1;
+    }
+    // --- photons (synchrotron.cpp:376-408) + build (smooth-power-law-syn.cpp:94-153) ---
+    const double nu_M = syn_freq(gamma_M, B), nu_m = syn_freq(gamma_m, B), nu_c = syn_freq(gamma_c, B),
+                 nu_a = syn_freq(gamma_a, B);
+    const double I_nu_max = syn_I_peak(B, column_den);
+    const double l_I = log2(I_nu_max), l_m = log2(nu_m), l_c = log2(nu_c), l_a = log2(nu_a), l_M = log2(nu_M);
+    const double s_swap = 4.0, s_floor = 0.1;
+    const double w_slow = sigmoid2(s_swap * (l_c - l_m));
+    const double soft_offset = log2_softplus(-s_swap * fabs(l_c - l_m)) / s_swap;
+    const double l_lo = dmin(l_m, l_c) - soft_offset;
+    const double l_hi = dmax(l_m, l_c) + soft_offset;
+    const double s_m_slow = dmax(1.84 - 0.40 * p, s_floor);
+    const double s_c_slow = dmax(1.15 - 0.06 * p, s_floor);
+    const double s_c_fast = 0.597;
+    const double s_m_fast = dmax(3.34 - 0.82 * p, s_floor);
+    const double smooth_lo = blend(w_slow, s_m_slow, s_c_fast);
+    const double smooth_hi = blend(w_slow, s_c_slow, s_m_fast);
+    const double alpha_mid = blend(w_slow, -0.5 * (p - 1.0), -0.5);
+    const double diff_lo = smooth_lo * (1.0 / 3.0 - alpha_mid);
+    const double diff_hi = smooth_hi * (alpha_mid + 0.5 * p);
+    const double uu = sigmoid2(s_swap * (l_a - l_m));
+    const double vv = sigmoid2(s_swap * (l_a - l_c));
+    const double w_below = (1.0 - uu) * (1.0 - vv);
+    const double w_above = uu * vv;
+    const double s_a_mid = dmax(1.47 - 0.21 * p, s_floor);
+    const double s_a_above = dmax(0.94 - 0.14 * p, s_floor);
+    const double s_a_blend = w_below * 1.64 + w_above * s_a_above + (1.0 - w_below - w_above) * s_a_mid;
+    // sharp thin/thick forms at nu_a (smooth-power-law-syn.cpp:49-78)
+    double thin_a, thick_a;
+    if (l_m < l_c) {
+        if (l_a < l_m)
+            thin_a = (l_a - l_m) / 3.0;
+        else if (l_a < l_c)
+            thin_a = 0.5 * (1.0 - p) * (l_a - l_m);
+        else
+            thin_a = 0.5 * (1.0 - p) * (l_c - l_m) - 0.5 * p * (l_a - l_c);
+    } else {
+        if (l_a < l_c)
+            thin_a = (l_a - l_c) / 3.0;
+        else if (l_a < l_m)
+            thin_a = -0.5 * (l_a - l_c);
+        else
+            thin_a = -0.5 * (l_m - l_c) - 0.5 * p * (l_a - l_m);
+    }
+    thick_a = (l_a < l_m) ? 2. * (l_a - l_m) : 2.5 * (l_a - l_m);
+
+    o.par[VP_LG2_I] = l_I;
+    o.par[VP_LG2_NUM] = l_m;
+    o.par[VP_LG2_NUMAX] = l_M;
+    o.par[VP_INV_NUMAX] = LOG2E * (1.0 / nu_M);
+    o.par[VP_NORM] = 1.0 / smooth_lo;
+    o.par[VP_TNORM] = thin_a - thick_a;
+    o.par[VP_SAB] = s_a_blend;
+    o.par[VP_INV_SAB] = 1.0 / s_a_blend;
+    o.par[VP_LG2_LO] = l_lo;
+    o.par[VP_LG2_HI] = l_hi;
+    o.par[VP_DLO] = diff_lo;
+    o.par[VP_DHI] = diff_hi;
+    o.par[VP_INV_SLO] = 1.0 / smooth_lo;
+    o.par[VP_INV_SHI] = 1.0 / smooth_hi;
+    o.par[VP_GAMMA] = Gamma;
+    o.par[VP_U] = sqrt((Gamma - 1) * (Gamma + 1));
+    o.par[VP_R] = r;
+    o.par[VP_LG2_R2] = 2.0 * log2(r);
+    o.par[VP_TENG] = t_eng;
+    o.gamma_m = gamma_m;
+    o.gamma_c = gamma_c;
+    o.gamma_a = gamma_a;
+    o.gamma_M = gamma_M;
+    o.N_e = N_e;
+    o.column_den = column_den;
+    o.nu_m = nu_m;
+    o.nu_c = nu_c;
+    o.nu_a = nu_a;
+    o.nu_M = nu_M;
+    o.I_nu_max = I_nu_max;
+}
+
+// Per-model constants of the optically thick branch (smooth-power-law-syn.cpp:102-107)
+struct SpecConst {
+    double smooth_thick, log2_x_far;
+    VAG_DEV void init(double p) {
+        smooth_thick = (3.44 * p - 1.41) / LN2;
+        log2_x_far = 1.5 * log2(20.0 / smooth_thick);
+    }
+};
+
+// SmoothPowerLawSyn::compute_log2_I_nu without IC (smooth-power-law-syn.cpp:15-46,80-92,159-167).
+// `c` points at the cell's parameter column with stride `st` between parameters.
+template <class PtrT>
+VAG_DEV double log2_I_nu(const PtrT c, int st, const SpecConst& sc, double lg2_nu) {
+    const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
+    const double thin = (lg2_nu - l_lo) / 3.0 - log2_softplus(c[VP_DLO * st] * (lg2_nu - l_lo)) * c[VP_INV_SLO * st] -
+                        log2_softplus(c[VP_DHI * st] * (lg2_nu - l_hi)) * c[VP_INV_SHI * st];
+    const double lx = lg2_nu - c[VP_LG2_NUM * st];
+    double thick = 2.5 * lx;
+    if (!(lx > sc.log2_x_far)) {
+        const double s = -sc.smooth_thick * exp2(2. / 3 * lx);
+        thick += log2_softplus(-0.5 * lx + s);
+    }
+    const double lb = thick + c[VP_TNORM * st];
+    const double smooth_one = thin - log2_softplus(c[VP_SAB * st] * (thin - lb)) * c[VP_INV_SAB * st];
+    const double spec = c[VP_LG2_I * st] + (c[VP_NORM * st] + smooth_one);
+    if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
+    return spec - c[VP_INV_NUMAX * st] * exp2(lg2_nu);
+}
+
+}  // namespace vag

@@ -1,0 +1,488 @@
+// vag_grid_kernel.h -- adaptive (phi, theta, t) grid on the device, one wavefront per model.
+//
+// Restates auto_grid (src/core/grid-refinement.h:639-706) for axisymmetric, non-spreading
+// named jets.  The sequential skeleton (CDF integration, merges) is executed uniformly by all
+// 64 lanes of the model's wavefront; every loop whose iterations are independent (profile scans,
+// the theta sum inside the phi weight, per-theta deceleration times, inverse-CDF lookups) is
+// spread over the lanes, with __shfl_xor butterflies for the sums/minima.
+#pragma once
+#include "vag_device.h"
+
+namespace vag {
+
+constexpr int WAVE = 64;
+constexpr int N_SCAN = 512;      // find_jet_jumps / find_theta_range scans
+constexpr int N_SAMPLES = 200;   // defaults::sampling::theta_samples
+
+VAG_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+VAG_DEV double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+VAG_DEV int wave_min_int(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+// xt::linspace element (external/xtensor/generators/xbuilder.hpp:231-280,460-471)
+VAG_DEV double linspace_at(double start, double stop, int n, int i) {
+    const double step = (stop - start) / fmax(1.0, (double)(n - 1));
+    return (n > 1 && i == n - 1) ? stop : start + step * (double)i;
+}
+
+struct GridShared {
+    double scan_th[N_SCAN + 8];  // scan abscissae (find_theta_range accumulates them sequentially)
+    double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae
+    double xs[N_SAMPLES];        // CDF sample abscissae
+    double cdf[N_SAMPLES];       // CDF at xs
+    double theta[VAG_MAX_THETA + 64];
+    double base[VAG_MAX_THETA];
+    double phi[VAG_MAX_PHI];
+    // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
+    double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA],
+        pj_st[VAG_MAX_THETA];
+    double tdec[VAG_MAX_THETA];
+    int flag[VAG_MAX_THETA];
+};
+
+// Integrate d(cdf)/dx = pdf(x) from lo to hi with boost's dense-output DOPRI5 at rtol=atol=1e-6 and
+// sample it at sh.xs[1..N_SAMPLES) (inverse_CFD_sampling, grid-refinement.h:138-161).
+// pdf(x) must be wave-uniform.
+template <class Pdf>
+VAG_DEV void integrate_cdf(GridShared& sh, Pdf& pdf, double lo, double hi) {
+    struct Rhs {
+        Pdf& pdf;
+        VAG_DEV void operator()(const double*, double* d, double x) const { d[0] = pdf(x); }
+    } rhs{pdf};
+    const int lane = threadIdx.x;
+    for (int k = lane; k < N_SAMPLES; k += WAVE) sh.cdf[k] = 0;
+    __syncthreads();
+    Dopri5<1> st;
+    const double x0 = 0;
+    st.init(&x0, lo, (hi - lo) / 1e3, 1e-6, rhs);
+    int k = 1;
+    for (int steps = 0; st.t <= hi;) {
+        if (!st.step(rhs)) break;
+        if (++steps > 100000) break;
+        while (k < N_SAMPLES && st.t > sh.xs[k]) {
+            double v;
+            st.interp(sh.xs[k], &v);
+            if (lane == 0) sh.cdf[k] = v;
+            ++k;
+        }
+    }
+    __syncthreads();
+}
+
+// x_out[k] for CDF quantiles (grid-refinement.h:163-188); lanes split k.  out may alias nothing in sh.xs/cdf.
+VAG_DEV void invert_cdf(const GridShared& sh, int num, bool midpoint, double* out) {
+    const double front = sh.cdf[0], back = sh.cdf[N_SAMPLES - 1];
+    for (int k = threadIdx.x; k < num; k += WAVE) {
+        const double target = midpoint ? front + (back - front) * ((double)k + 0.5) / num : linspace_at(front, back, num, k);
+        double x = 0;
+        for (int j = 0; j < N_SAMPLES; ++j) {
+            if (target <= sh.cdf[j]) {
+                if (j == 0) {
+                    x = sh.xs[0];
+                } else {
+                    const double denom = sh.cdf[j] - sh.cdf[j - 1];
+                    x = denom > 0 ? sh.xs[j - 1] + (sh.xs[j] - sh.xs[j - 1]) / denom * (target - sh.cdf[j - 1]) : sh.xs[j - 1];
+                }
+                break;
+            }
+        }
+        out[k] = x;
+    }
+    __syncthreads();
+}
+
+// One wavefront (blockDim.x == 64) per model.
+// tminmax[0..1]: min / max of the requested observer times [s] (device memory).
+__global__ void __launch_bounds__(WAVE)
+vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
+                VagGridMeta* __restrict__ meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
+                int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec) {
+    const int m = blockIdx.x;
+    if (m >= nb) return;
+    const int lane = threadIdx.x;
+    __shared__ GridShared sh;
+    const vag_model_params P = params[m];
+    const double t_min_s = tminmax[0], t_max_s = tminmax[1];
+    if (!params_valid(P)) {  // the reference raises ValueError; batched walkers get status != 0 (-> NaN / -inf)
+        if (lane == 0) {
+            VagGridMeta bad = {};
+            bad.status = VAG_E_INVALID;
+            meta[m] = bad;
+        }
+        return;
+    }
+    Jet jet;
+    Medium med;
+    jet_init(jet, P);
+    medium_init(med, P);
+    const double theta_v = P.theta_obs, z = P.z;
+    VagGridMeta M;
+    M.status = 0;
+    M.pad0 = M.pad1 = 0;
+
+    // ---- find_jet_jumps (grid-refinement.h:41-86): parallel profile scan, sequential jump logic ----
+    const double th_lo = 1e-6, th_hi = C_PI / 2;
+    double jumps[VAG_MAX_JUMPS];
+    int n_jumps = 0;
+    if (jet_Gamma0(jet, th_hi) >= GAMMA_CUT) {
+        jumps[n_jumps++] = th_hi;
+    } else {
+        const double dth = (th_hi - th_lo) / (N_SCAN - 1);
+        for (int s = lane; s < N_SCAN; s += WAVE) sh.scan_g[s] = jet_Gamma0(jet, th_lo + dth * (double)s);
+        __syncthreads();
+        double prev_th = th_lo, prev_G = sh.scan_g[0];
+        for (int s = 1; s < N_SCAN; ++s) {
+            const double cur_th = th_lo + dth * (double)s;
+            const double cur_G = sh.scan_g[s];
+            if (prev_G >= GAMMA_CUT || cur_G >= GAMMA_CUT) {
+                const double dG = fabs(cur_G - prev_G);
+                const double scale = dmax(prev_G - 1, cur_G - 1);
+                if (scale > 0 && dG > 0.5 * scale) {
+                    double lo = prev_th, hi = cur_th;
+                    while (hi - lo > 1e-9) {
+                        const double mid = 0.5 * (lo + hi);
+                        const double Gm = jet_Gamma0(jet, mid);
+                        if (fabs(Gm - prev_G) < fabs(Gm - cur_G))
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    if (n_jumps < VAG_MAX_JUMPS) jumps[n_jumps++] = prev_G > cur_G ? lo : hi;
+                }
+            }
+            prev_th = cur_th;
+            prev_G = cur_G;
+        }
+        __syncthreads();
+    }
+
+    // ---- find_theta_range (grid-refinement.h:89-111).  The abscissae come from a running
+    //      subtraction/addition (kept sequential, it is only adds); the profile evaluations are parallel.
+    double inner_edge = th_lo, outer_edge = th_hi;
+    {
+        const double step = (th_hi - th_lo) / N_SCAN;
+        int n = 0;
+        if (lane == 0) {
+            for (double th = th_hi; th >= th_lo && n < N_SCAN + 8; th -= step) sh.scan_th[n++] = th;
+        }
+        n = 0;
+        for (double th = th_hi; th >= th_lo && n < N_SCAN + 8; th -= step) ++n;
+        __syncthreads();
+        int first = 1 << 30;
+        for (int s = lane; s < n; s += WAVE)
+            if (jet_Gamma0(jet, sh.scan_th[s]) >= GAMMA_CUT) {
+                first = s;
+                break;
+            }
+        first = wave_min_int(first);
+        if (first < n) outer_edge = sh.scan_th[first];
+        __syncthreads();
+        // upward scan: the first abscissa almost always qualifies; stay sequential with early exit
+        for (double th = th_lo; th <= th_hi; th += step) {
+            if (jet_Gamma0(jet, th) >= GAMMA_CUT) {
+                inner_edge = th;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n_jumps; ++i) outer_edge = dmax(outer_edge, jumps[i]);
+    const double theta_min = dmax(1e-6, inner_edge);
+    const double theta_max = dmin(outer_edge, C_PI / 2);
+    const size_t base_pts = 36 + (size_t)((theta_max - theta_min) * 180 / C_PI * P.theta_resol);
+
+    // ---- adaptive_theta_grid (grid-refinement.h:200-291) ----
+    int n_base = 0;
+    {
+        constexpr int scan_pts = 100;
+        const double extent = theta_max - theta_min;
+        for (int i = lane; i <= scan_pts; i += WAVE) sh.scan_g[i] = jet_Gamma0(jet, theta_min + extent * i / scan_pts);
+        __syncthreads();
+        double peak_weight = 0, Gamma_peak = 1.0, struct_sum = 0, Gamma_v = 1.0;
+        int last_bright = 0;
+        for (int i = 0; i <= scan_pts; ++i) {
+            const double theta = theta_min + extent * i / scan_pts;
+            const double G = sh.scan_g[i];
+            const double w = structure_weight(G);
+            struct_sum += w;
+            if (w > peak_weight) {
+                peak_weight = w;
+                Gamma_peak = G;
+                last_bright = i;
+            } else if (w > 0.01 * peak_weight) {
+                last_bright = i;
+            }
+            const double d = theta - theta_v;
+            Gamma_v = dmax(Gamma_v, G / sqrt(1.0 + G * G * d * d));
+        }
+        __syncthreads();
+        const double floor_weight = 0.25 * peak_weight;
+        const double CDF_est = (struct_sum / scan_pts + floor_weight) * extent;
+        const double theta_bright = theta_min + extent * last_bright / scan_pts;
+        Gamma_peak = dmax(Gamma_peak, Gamma_v);
+        const double doppler_alpha = 12.0 * sqrt(peak_weight / dmax(structure_weight(Gamma_v), 1.0));
+        const double Gp2 = Gamma_peak * Gamma_peak, Gv2 = Gamma_v * Gamma_v;
+        auto beam_pts = [&](double log_decades, double coeff, double offset) -> size_t {
+            return (size_t)(dmax(0.0, log_decades - offset) * P.theta_resol * coeff);
+        };
+        const size_t core_pts = beam_pts(log10(dmax(1.0, Gamma_peak * (theta_bright - theta_min))), 55.0, 1.0);
+        const size_t view_pts =
+            (theta_v * Gamma_peak > 3.0)
+                ? beam_pts(log10(dmax(1.0, Gamma_v * dmax(theta_v - theta_min, theta_max - theta_v))), 25.0, 0.0)
+                : 0;
+        const size_t total_pts = base_pts + core_pts + view_pts;
+        const double core_cdf = 0.5 * log((1.0 + Gp2 * theta_max * theta_max) / (1.0 + Gp2 * theta_min * theta_min));
+        const double core_weight = (core_pts > 0 && core_cdf > 0) ? (double)core_pts / base_pts * CDF_est / core_cdf : 0.0;
+        const double tl = theta_v - theta_min, tr = theta_max - theta_v;
+        const double view_cdf = 0.5 * (log(1.0 + Gv2 * tl * tl) + log(1.0 + Gv2 * tr * tr));
+        const double view_weight = (view_pts > 0 && view_cdf > 0) ? (double)view_pts / base_pts * CDF_est / view_cdf : 0.0;
+        if (total_pts > VAG_MAX_THETA - 3 * VAG_MAX_JUMPS) {
+            M.status = VAG_E_CAPACITY;
+            if (lane == 0) meta[m] = M;
+            return;
+        }
+        n_base = (int)total_pts;
+        // sample abscissae: xt::logspace(log10(min), log10(max), 200)
+        {
+            const double a = log10(theta_min), b = log10(theta_max);
+            for (int k = lane; k < N_SAMPLES; k += WAVE) sh.xs[k] = pow(10.0, linspace_at(a, b, N_SAMPLES, k));
+        }
+        auto pdf = [&](double theta) -> double {
+            const double G = jet_Gamma0(jet, theta);
+            const double beta = gamma_to_beta(G);
+            const double doppler = (1 - beta) / (1 - beta * cos(theta - theta_v));
+            const double structure = structure_weight(G);
+            const double d = theta - theta_v;
+            return core_weight * Gp2 * theta / (1.0 + Gp2 * theta * theta) +
+                   view_weight * Gv2 * fabs(d) / (1.0 + Gv2 * d * d) + (1 + doppler_alpha * doppler) * structure +
+                   floor_weight;
+        };
+        integrate_cdf(sh, pdf, theta_min, theta_max);
+        invert_cdf(sh, n_base, false, sh.base);
+    }
+
+    // ---- jump_refinement_grid (grid-refinement.cpp:136-160) + merge_grids (grid-refinement.h:362-393) ----
+    int n_theta = 0;
+    {
+        double feat[3 * VAG_MAX_JUMPS];
+        int nf = 0;
+        const double tight = ((theta_max - theta_min) / n_base) / 8;
+        for (int q = 0; q < n_jumps; ++q) {
+            const double jt = jumps[q];
+            if (jt >= C_PI / 2 - 0.01) continue;
+            if (jt - tight >= theta_min) feat[nf++] = jt - tight;
+            if (jt + tight <= theta_max) feat[nf++] = jt + tight;
+            if (jt >= theta_min && jt <= theta_max) feat[nf++] = jt;
+        }
+        for (int a = 1; a < nf; ++a) {  // insertion sort (tiny)
+            const double v = feat[a];
+            int b = a - 1;
+            while (b >= 0 && feat[b] > v) {
+                feat[b + 1] = feat[b];
+                --b;
+            }
+            feat[b + 1] = v;
+        }
+        int nu = 0;
+        for (int a = 0; a < nf; ++a)
+            if (nu == 0 || feat[nu - 1] != feat[a]) feat[nu++] = feat[a];
+        nf = nu;
+        // sequential merge executed by lane 0 into shared memory
+        if (lane == 0) {
+            int n = 0, i = 0, j = 0;
+            auto add = [&](double v) {
+                if (n == 0 || sh.theta[n - 1] != v) sh.theta[n++] = v;
+            };
+            while (i < n_base && j < nf) {
+                if (sh.base[i] <= feat[j]) {
+                    add(sh.base[i++]);
+                    if (sh.base[i - 1] == feat[j]) j++;
+                } else {
+                    add(feat[j++]);
+                }
+            }
+            while (i < n_base) add(sh.base[i++]);
+            while (j < nf) add(feat[j++]);
+            sh.flag[0] = n;
+        }
+        __syncthreads();
+        n_theta = sh.flag[0];
+        __syncthreads();
+    }
+
+    // ---- phi grid (grid-refinement.h:664-695, adaptive_phi_grid 296-360) ----
+    int n_phi = 0, phi_mirrored = 0;
+    {
+        size_t phi_base = (size_t)(360 * P.phi_resol);
+        if (phi_base < 1) phi_base = 1;
+        const bool mirror = theta_v != 0 && phi_base > 4;
+        size_t phi_num;
+        double phi_max, boost_cap;
+        if (mirror) {
+            phi_num = (phi_base + 1) / 2;
+            phi_max = C_PI;
+            boost_cap = 5.0;
+            phi_mirrored = 1;
+        } else {
+            const double sharp = jet_Gamma0(jet, theta_v) * sin(theta_v);
+            const double boost = sqrt(dmax(sharp / (2 * C_PI), 1.0));
+            phi_num = (size_t)(phi_base * boost);
+            if (phi_num < 1) phi_num = 1;
+            if (phi_num > phi_base * 5) phi_num = phi_base * 5;
+            phi_max = 2 * C_PI;
+            boost_cap = 0;
+        }
+        const bool uniform = (!mirror && phi_num <= 2) || theta_v == 0;
+        if (uniform) {
+            if (phi_num > VAG_MAX_PHI) {
+                M.status = VAG_E_CAPACITY;
+                if (lane == 0) meta[m] = M;
+                return;
+            }
+            n_phi = (int)phi_num;
+            for (int i = lane; i < n_phi; i += WAVE) sh.phi[i] = linspace_at(0., 2 * C_PI, n_phi, i);
+            __syncthreads();
+        } else {
+            const bool half_range = phi_max < 2 * C_PI;
+            const double cos_tv = cos(theta_v), sin_tv = sin(theta_v);
+            for (int j = lane; j < n_theta; j += WAVE) {
+                const double th = sh.theta[j];
+                const double left = (j == 0) ? 0.0 : 0.5 * (sh.theta[j - 1] + th);
+                const double right = (j == n_theta - 1) ? th : 0.5 * (th + sh.theta[j + 1]);
+                const double G = jet_Gamma0(jet, th);
+                sh.pj_dcos[j] = fabs(cos(left) - cos(right));
+                sh.pj_beta[j] = gamma_to_beta(G);
+                sh.pj_sw[j] = structure_weight(G);
+                sh.pj_ct[j] = cos(th) * cos_tv;
+                sh.pj_st[j] = sin(th) * sin_tv;
+            }
+            __syncthreads();
+            auto phi_weight = [&](double phi) -> double {
+                const double cos_phi = cos(phi);
+                double w = 0;
+                for (int j = lane; j < n_theta; j += WAVE) {
+                    const double beta = sh.pj_beta[j];
+                    const double cos_alpha = sh.pj_ct[j] + sh.pj_st[j] * cos_phi;
+                    const double a = (1 - beta) / (1 - beta * cos_alpha);
+                    w += a * sh.pj_sw[j] * sh.pj_dcos[j];
+                }
+                return wave_sum(w);
+            };
+            constexpr int scan_pts = 100;
+            double peak = 0, sum = 0;
+            for (int s = 0; s <= scan_pts; ++s) {
+                const double w = phi_weight(phi_max * (double)s / scan_pts);
+                peak = dmax(peak, w);
+                sum += w;
+            }
+            const double floor_w = 0.05 * peak;
+            if (boost_cap > 0 && peak > 0) {
+                const double mean_pdf = sum / (scan_pts + 1) + floor_w;
+                const double conc = (peak + floor_w) / mean_pdf;
+                double boost = conc / 5;
+                boost = boost < 1.0 ? 1.0 : (boost_cap < boost ? boost_cap : boost);
+                phi_num = (size_t)((double)phi_num * boost);
+            }
+            if (phi_num > VAG_MAX_PHI) {
+                M.status = VAG_E_CAPACITY;
+                if (lane == 0) meta[m] = M;
+                return;
+            }
+            n_phi = (int)phi_num;
+            for (int k = lane; k < N_SAMPLES; k += WAVE) sh.xs[k] = linspace_at(0, phi_max, N_SAMPLES, k);
+            auto pdf = [&](double phi) -> double { return phi_weight(phi) + floor_w; };
+            integrate_cdf(sh, pdf, 0, phi_max);
+            invert_cdf(sh, n_phi, half_range, sh.phi);
+        }
+        if (!mirror && phi_num >= 2) {
+            const double shift = 0.5 * (sh.phi[1] - sh.phi[0]);
+            __syncthreads();
+            for (int i = lane; i < n_phi; i += WAVE) sh.phi[i] += shift;
+            __syncthreads();
+        }
+    }
+
+    // ---- Coord::detect_symmetry (src/core/mesh.h:121-187): contiguous groups of identical rows ----
+    int n_reps = 0;
+    {
+        for (int j = lane; j < n_theta; j += WAVE) {
+            int differs = 1;
+            if (j > 0) {
+                const double a = sh.theta[j - 1], b = sh.theta[j];
+                differs = (jet_eps_k(jet, a) != jet_eps_k(jet, b)) || (jet_Gamma0(jet, a) != jet_Gamma0(jet, b));
+            }
+            sh.flag[j] = differs;
+        }
+        __syncthreads();
+        int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
+        int* rep_start = g_rep_start + (size_t)m * VAG_MAX_THETA;
+        for (int j = 0; j < n_theta; ++j) {
+            if (sh.flag[j]) {
+                if (lane == 0) rep_start[n_reps] = j;
+                ++n_reps;
+            }
+            if (lane == 0) rep_of[j] = n_reps - 1;
+        }
+        __syncthreads();
+    }
+    const int symmetry = n_reps == 1 ? VAG_SYM_ISOTROPIC : (n_reps < n_theta ? VAG_SYM_PIECEWISE : VAG_SYM_PHI_SYMMETRIC);
+
+    // ---- build_time_grid scalars (grid-refinement.h:472-528,594-636), forward shock only ----
+    {
+        const double t_min = t_min_s * U_SEC, t_max = t_max_s * U_SEC;
+        const double t_end = 1.01 * t_max / (1 + z);
+        const double cos_tv = cos(theta_v), sin_tv = sin(theta_v);
+        const double cos_phi0 = cos(sh.phi[0]);
+        double min_raw = t_end, min_guarded = t_end, min_cut = t_end;
+        for (int j = lane; j < n_theta; j += WAVE) {
+            const double th = sh.theta[j];
+            const double b = gamma_to_beta(jet_Gamma0(jet, th));
+            const double cos_a = cos(th) * cos_tv + sin(th) * sin_tv * cos_phi0;
+            const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
+            const double td = estimate_t_dec(jet, med, th);
+            sh.tdec[j] = td;
+            const double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+            min_raw = dmin(min_raw, ts);
+            min_guarded = dmin(min_guarded, dmax(ts, cut));
+            min_cut = dmin(min_cut, cut);
+        }
+        min_raw = wave_min(min_raw);
+        min_guarded = wave_min(min_guarded);
+        min_cut = wave_min(min_cut);
+        const int has_early = min_raw < min_cut;
+        const size_t t_num_tot = (size_t)(dmax(log10(t_end / min_guarded), 1.0) * P.t_resol);
+        const size_t t_num = t_num_tot + (has_early ? 1 : 0);
+        if (t_num > VAG_MAX_TIME || t_num_tot < 2) M.status = VAG_E_CAPACITY;
+        M.n_t = (int)t_num;
+        M.t_num_tot = (int)t_num_tot;
+        M.has_early = has_early;
+        M.t_early = min_raw;
+        M.t_start = min_guarded;
+        M.t_end = t_end;
+    }
+    M.n_phi = n_phi;
+    M.n_theta = n_theta;
+    M.n_reps = n_reps;
+    M.symmetry = symmetry;
+    M.phi_mirrored = phi_mirrored;
+    M.n_phi_eff = (theta_v == 0) ? 1 : n_phi;  // Observer::build_time_grid, observer.cpp:218-222
+    __syncthreads();
+    for (int i = lane; i < n_phi; i += WAVE) g_phi[(size_t)m * VAG_MAX_PHI + i] = sh.phi[i];
+    for (int j = lane; j < n_theta; j += WAVE) {
+        g_theta[(size_t)m * VAG_MAX_THETA + j] = sh.theta[j];
+        g_tdec[(size_t)m * VAG_MAX_THETA + j] = sh.tdec[j];
+    }
+    if (lane == 0) meta[m] = M;
+}
+
+}  // namespace vag

@@ -1,0 +1,598 @@
+// vag_kernels.h -- dynamics, per-cell radiation and equal-arrival-time flux kernels (gfx950).
+#pragma once
+#include "vag_device.h"
+#include "vag_grid_kernel.h"
+
+namespace vag {
+
+// Compact storage: model m owns rows [row_off[m], row_off[m+1]) (its representative theta rows) and
+// cells [cell_off[m], cell_off[m+1]) = rows x n_t.
+struct Layout {
+    const int* row_off;        // [nb+1]
+    const long long* cell_off; // [nb+1]
+};
+
+VAG_DEV int find_model(const int* off, int nb, int idx) {  // largest m with off[m] <= idx
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= idx)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dynamics: one lane per representative (model, theta) row.  grid_solve_fwd_shock
+// (src/dynamics/forward-shock.tpp:175-208) with the lattice generated on the fly, state saved through
+// save_fwd_shock_state (forward-shock.tpp:151-173).  shock[VS_*] are SoA arrays over cells.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                    const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
+                    const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
+                    long long n_cells, int* __restrict__ row_status) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const int m = find_model(lay.row_off, nb, row);
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const int r = row - lay.row_off[m];
+    const int j = g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+    const vag_model_params P = params[m];
+    Jet jet;
+    jet_init(jet, P);
+    FwdShock eq;
+    medium_init(eq.med, P);
+    const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
+    const double t_dec = g_tdec[(size_t)m * VAG_MAX_THETA + j];
+    const int nt = M.n_t;
+    double* o_teng = shock + VS_TENG * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_tcomv = shock + VS_TCOMV * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_r = shock + VS_R * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_G = shock + VS_GAMMA * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_Gth = shock + VS_GAMMA_TH * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_B = shock + VS_B * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_Np = shock + VS_NP * n_cells + lay.cell_off[m] + (long long)r * nt;
+
+    TimeLattice lat;
+    lat.init(M.t_start, M.t_end, t_dec, M.t_num_tot);
+    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? M.t_early : lat.node(k - 1)) : lat.node(k); };
+
+    const double Gamma4 = jet_Gamma0(jet, theta0);
+    eq.m_jet0 = jet_eps_k(jet, theta0) / Gamma4 / C_C2;
+    eq.gamma_m_coeff = (P.p - 2) / (P.p - 1) * P.eps_e * C_MP / C_ME / P.xi_e;
+    eq.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B);
+    eq.eps_e_eff = P.radiative_fireball ? P.eps_e : 0;
+    eq.p = P.p;
+    eq.eps_B = P.eps_B;
+
+    const double t_first = node(0);
+    const double t_last = node(nt - 1);
+    const double t0 = dmin(t_first, dmin(0.1 * U_SEC, 0.1 * t_dec));
+    // set_init_state, forward-shock.tpp:120-149
+    double s[5];
+    const double beta4 = gamma_to_beta(Gamma4);
+    s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
+    s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
+    s[1] = medium_mass(eq.med, s[3]);
+    s[0] = Gamma4;
+    s[2] = enclosed_thermal_energy(eq.med, s[3], s[0], adiabatic_idx(s[0]), P.radiative_fireball ? P.eps_e : 0.0);
+
+    if (s[0] <= GAMMA_CUT) {  // set_stopping_shock, shock-physics.h:388-397
+        for (int k = 0; k < nt; ++k) {
+            o_teng[k] = node(k);
+            o_tcomv[k] = s[4];
+            o_r[k] = s[3];
+            o_G[k] = 1;
+            o_Gth[k] = 1;
+            o_B[k] = 0;
+            o_Np[k] = 0;
+        }
+        row_status[row] = 0;
+        return;
+    }
+    // Shock ctor defaults for nodes never reached (shock.cpp:12-24)
+    int k = 0;
+    double t_k = t_first;
+    Dopri5<5> st;
+    st.init(s, t0, 0.01 * t0, P.rtol, eq);
+    int status = 0;
+    for (int steps = 0; st.t <= t_last;) {
+        if (!st.step(eq)) {
+            status = 1;
+            break;
+        }
+        if (++steps > 100000) {
+            status = 2;
+            break;
+        }
+        while (k < nt && st.t > t_k) {
+            double q[5];
+            st.interp(t_k, q);
+            // save_fwd_shock_state
+            const double comp = compression_fwd(q[0]);
+            const double rho = medium_rho(eq.med, q[3]);
+            const double Gth = (q[1] == 0) ? 1 : q[2] / (q[1] * C_C2) + 1;
+            const double e_th = (Gth - 1) * (rho * comp) * C_C2;
+            o_teng[k] = t_k;
+            o_tcomv[k] = q[4];
+            o_r[k] = q[3];
+            o_G[k] = q[0];
+            o_Gth[k] = Gth;
+            o_B[k] = sqrt(8 * C_PI * P.eps_B * e_th);
+            o_Np[k] = q[1] / C_MP;
+            ++k;
+            if (k < nt) t_k = node(k);
+        }
+    }
+    for (; k < nt; ++k) {  // unreached nodes keep the Shock constructor's defaults
+        o_teng[k] = node(k);
+        o_tcomv[k] = 0;
+        o_r[k] = 0;
+        o_G[k] = 1;
+        o_Gth[k] = 1;
+        o_B[k] = 0;
+        o_Np[k] = 0;
+    }
+    row_status[row] = status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-cell radiation: generate_syn_electrons + generate_syn_photons + SmoothPowerLawSyn::build,
+// one lane per (row, k) cell.  Output: [row][VAG_NPAR][n_t] blocks in `cellpar`.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
+                 const double* __restrict__ shock, long long n_cells, double* __restrict__ cellpar,
+                 double* __restrict__ cell_details /* optional [11][n_cells] */) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    // find model by cell offset
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lay.cell_off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int m = lo;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const int nt = M.n_t;
+    const long long local = c - lay.cell_off[m];
+    const int r = (int)(local / nt), k = (int)(local % nt);
+    const vag_model_params P = params[m];
+    CellOut o;
+    syn_cell(o, shock[VS_TENG * n_cells + c], shock[VS_TCOMV * n_cells + c], shock[VS_R * n_cells + c],
+             shock[VS_GAMMA * n_cells + c], shock[VS_GAMMA_TH * n_cells + c], shock[VS_B * n_cells + c],
+             shock[VS_NP * n_cells + c], P.eps_e, P.p, P.xi_e);
+    double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
+#pragma unroll
+    for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];
+    if (cell_details) {
+        const double v[11] = {o.gamma_m, o.gamma_c, o.gamma_a, o.gamma_M, o.N_e, o.column_den,
+                              o.nu_m, o.nu_c, o.nu_a, o.nu_M, o.I_nu_max};
+#pragma unroll
+        for (int q = 0; q < 11; ++q) cell_details[q * n_cells + c] = v[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Equal-arrival-time flux integration (Observer::observe + Observer::specific_flux,
+// src/core/observer.cpp:143-205,439-454 and src/core/observer.h:355-445), fused:
+//
+// A workgroup owns a contiguous range of (theta j, phi i) "pairs" of one model (j-major).  The photon
+// parameter rows of the representative row of j are staged in LDS once per j-group.  For each pair:
+//   A0  lanes over k:        Doppler, observer time and geometry logs of the row  -> LDS
+//   A1  lanes over (k, l):   boundary log2-luminosities B[k][l] inside the observation window -> LDS
+//   B   lanes over (idx, l): log-log interpolation at the requested times, exp2, accumulate in registers
+// Each lane owns fixed (idx, l) output slots, so the (phi, theta) sum needs no cross-lane reduction; a
+// workgroup writes one partial grid, reduced deterministically by vag_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int FLUX_THREADS = 256;
+constexpr int FLUX_MAX_SLOTS = 16;  // (idx, l) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
+
+struct FluxArgs {
+    const vag_model_params* params;
+    const VagGridMeta* meta;
+    const double* g_phi;
+    const double* g_theta;
+    const int* g_rep_of;
+    Layout lay;
+    const double* cellpar;
+    const double* lg2_t_obs;  // [nt]   log2(t * unit::sec)
+    const double* lg2_nu_obs; // [nnu]  log2(nu * unit::Hz)
+    int nt, nnu;
+    int pairs_per_block;
+    int max_blocks;  // blocks per model (gridDim.x)
+    int k_stride;    // LDS row stride (>= max n_t in the batch)
+    double* partial; // [nb][max_blocks][nnu*nt]
+};
+
+__global__ void __launch_bounds__(FLUX_THREADS)
+vag_flux_grid_kernel(FluxArgs a) {
+    const int m = blockIdx.y;
+    const VagGridMeta M = a.meta[m];
+    const int slots = a.nt * a.nnu;
+    double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
+    if (M.status != 0) return;
+    const int n_pairs = M.n_theta * M.n_phi_eff;
+    const int p0 = blockIdx.x * a.pairs_per_block;
+    if (p0 >= n_pairs) return;
+    const int p1 = min(n_pairs, p0 + a.pairs_per_block);
+    const int tid = threadIdx.x;
+    const int K = M.n_t, KS = a.k_stride;
+
+    extern __shared__ double lds[];
+    double* s_par = lds;                       // [VAG_NPAR][KS]
+    double* s_t = s_par + VAG_NPAR * KS;       // [KS] lg2 t_obs of the row
+    double* s_dop = s_t + KS;                  // [KS]
+    double* s_geom = s_dop + KS;               // [KS]
+    double* s_B = s_geom + KS;                 // [KS][nnu]
+    double* s_tobs = s_B + (size_t)KS * a.nnu; // [nt]
+    double* s_nu = s_tobs + a.nt;              // [nnu]
+    int* s_kidx = (int*)(s_nu + a.nnu);        // [nt]
+
+    const vag_model_params P = a.params[m];
+    const double one_plus_z = 1 + P.z;
+    const double lg2_1pz = log2(one_plus_z);
+    for (int i = tid; i < a.nt; i += FLUX_THREADS) s_tobs[i] = a.lg2_t_obs[i];
+    for (int l = tid; l < a.nnu; l += FLUX_THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
+    SpecConst sc;
+    sc.init(P.p);
+    const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
+    const double* phi = a.g_phi + (size_t)m * VAG_MAX_PHI;
+    const double* theta = a.g_theta + (size_t)m * VAG_MAX_THETA;
+    const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int n_phi_eff = M.n_phi_eff;
+    const int last_j = M.n_theta - 1;
+
+    double acc[FLUX_MAX_SLOTS];
+    short slot_idx[FLUX_MAX_SLOTS], slot_l[FLUX_MAX_SLOTS];
+#pragma unroll
+    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
+        acc[q] = 0;
+        const int slot = tid + q * FLUX_THREADS;
+        slot_idx[q] = (short)(slot / a.nnu);
+        slot_l[q] = (short)(slot - (slot / a.nnu) * a.nnu);
+    }
+
+    int staged_rep = -1;
+    for (int pair = p0; pair < p1; ++pair) {
+        const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+        const int rep = rep_of[j];
+        __syncthreads();  // previous pair's phase B done before LDS is overwritten
+        if (rep != staged_rep) {
+            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+            for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {
+                const int par = q / K, k = q - par * K;
+                s_par[par * KS + k] = src[q];
+            }
+            staged_rep = rep;
+            __syncthreads();
+        }
+        // ---- A0: EAT quantities of row (i, j): calc_eat_non_spreading + finalize_log_grids ----
+        {
+            const double th_j = theta[j];
+            const double ct = cos(th_j), st = sin(th_j);
+            const double cos_phi = cos(phi[i]);
+            const double cos_v = st * cos_phi * sin_obs + ct * cos_obs;
+            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+            // solid angle: midpoint theta bins x dphi (compute_dphi, observer.cpp:17-37)
+            const double cos_lo = (j == 0) ? ct : cos(0.5 * (theta[j - 1] + th_j));
+            const double cos_hi = (j == last_j) ? ct : cos(0.5 * (th_j + theta[j + 1]));
+            double dphi;
+            if (n_phi_eff == 1) {
+                dphi = 2 * C_PI;
+            } else if (M.phi_mirrored) {
+                const double left = (i > 0) ? 0.5 * (phi[i - 1] + phi[i]) : 0.0;
+                const double right = (i < n_phi_eff - 1) ? 0.5 * (phi[i] + phi[i + 1]) : C_PI;
+                dphi = 2 * (right - left);
+            } else {
+                const int lastp = n_phi_eff - 1;
+                dphi = 0.5 * (phi[min(i + 1, lastp)] - phi[i > 0 ? i - 1 : 0]);
+            }
+            const double lg2_dOmega = log2(fabs((cos_hi - cos_lo) * dphi));
+            for (int k = tid; k < K; k += FLUX_THREADS) {
+                const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+                const double lg2_dop = -log2(G - u * cos_v);
+                const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
+                s_dop[k] = lg2_dop;
+                s_t[k] = log2(time);
+                s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+            }
+        }
+        __syncthreads();
+        // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,405-433)
+        //      and the observation window [k_lo, k_hi] (observed_window, observer.h:324-338) ----
+        const double row_t0 = s_t[0], row_tN = s_t[K - 1];
+        for (int idx = tid; idx < a.nt; idx += FLUX_THREADS) {
+            const double tq = s_tobs[idx];
+            int kk = -1;
+            if (tq >= row_t0 && tq < row_tN) {
+                int lo = 0, hi = K - 1;  // invariant: s_t[lo] <= tq < s_t[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_t[mid] <= tq)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                kk = lo;
+            }
+            s_kidx[idx] = kk;
+        }
+        int k_lo, k_hi;
+        {
+            const double w_lo = s_tobs[0], w_hi = s_tobs[a.nt - 1];
+            if (row_tN < w_lo || row_t0 > w_hi) continue;  // row entirely outside the window (block-uniform)
+            // k_lo = (first node >= w_lo) - 1, floored at 0; that node exists because row_tN >= w_lo
+            int lo = -1, hi = K - 1;  // invariant: s_t[lo] < w_lo <= s_t[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_t[mid] < w_lo)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            k_lo = hi > 0 ? hi - 1 : 0;
+            // k_hi = first node > w_hi at or after k_lo + 1, capped at K - 1
+            lo = k_lo;
+            hi = K - 1;  // invariant: nodes <= lo are not candidates, hi is a valid answer
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_t[mid] <= w_hi)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            k_hi = hi;
+        }
+        // ---- A1: boundary values B[k][l] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window ----
+        {
+            const int nk = k_hi - k_lo + 1;
+            const int total = nk * a.nnu;
+            for (int q = tid; q < total; q += FLUX_THREADS) {
+                const int kq = q / a.nnu, l = q - kq * a.nnu;
+                const int k = k_lo + kq;
+                s_B[k * a.nnu + l] = log2_I_nu(s_par + k, KS, sc, s_nu[l] - s_dop[k]) + s_geom[k];
+            }
+        }
+        __syncthreads();
+        // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433) ----
+#pragma unroll
+        for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
+            const int slot = tid + q * FLUX_THREADS;
+            if (slot < slots) {
+                const int idx = slot_idx[q], l = slot_l[q];
+                const int k = s_kidx[idx];
+                if (k >= 0) {
+                    const double lo = s_B[k * a.nnu + l], hi = s_B[(k + 1) * a.nnu + l];
+                    const double inv = 1.0 / (s_t[k + 1] - s_t[k]);
+                    const double sl = (hi - lo) * inv;
+                    if (isfinite(sl)) acc[q] += exp2(lo + (s_tobs[idx] - s_t[k]) * sl);
+                }
+            }
+        }
+    }
+    // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
+#pragma unroll
+    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
+        const int slot = tid + q * FLUX_THREADS;
+        if (slot < slots) {
+            const int idx = slot_idx[q], l = slot_l[q];
+            my_partial[(size_t)l * a.nt + idx] = acc[q];
+        }
+    }
+}
+
+// Deterministic sum over a model's workgroup partials + normalisation
+// F *= (1+z)/d_L^2 (observer.h:442), / unit::flux_den_cgs (pymodel.cpp:506-508); band mode applies the
+// Boole weights of Observer::flux (observer.h:555-567) and / unit::flux_cgs (pymodel.cpp:403-405).
+__global__ void __launch_bounds__(256)
+vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
+                  const double* __restrict__ partial, int max_blocks, int pairs_per_block, int nt, int nnu,
+                  const double* __restrict__ band_w /* NULL or [nnu] */, double* __restrict__ out) {
+    const int m = blockIdx.y;
+    const VagGridMeta M = meta[m];
+    const vag_model_params P = params[m];
+    const int slots = nt * nnu;
+    const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block : 0;
+    const double d_L = P.lumi_dist * U_CM;
+    const double norm = (1 + P.z) / (d_L * d_L);
+    const double* src = partial + (size_t)m * max_blocks * slots;
+    if (!band_w) {
+        for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
+            double v = 0;
+            for (int b = 0; b < nblk; ++b) v += src[(size_t)b * slots + s];
+            out[(size_t)m * slots + s] = (M.status == 0) ? (v * norm) / U_FLUX_DEN_CGS : NAN;
+        }
+    } else {
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nt; idx += gridDim.x * blockDim.x) {
+            double f = 0;
+            for (int l = 0; l < nnu; ++l) {
+                double v = 0;
+                for (int b = 0; b < nblk; ++b) v += src[(size_t)b * slots + (size_t)l * nt + idx];
+                f += (v * norm) * band_w[l];
+            }
+            out[(size_t)m * nt + idx] = (M.status == 0) ? f / U_FLUX_CGS : NAN;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Series form (Observer::specific_flux_series, observer.h:447-538): n paired (t_s, nu_s) points.
+// One workgroup (64 lanes) per (model, pair range); lanes over data points, two boundary evaluations per
+// (row, point).  Sharing of boundary values between equal-frequency runs in the reference changes cost,
+// not values.  Output partial[m][block][n].
+// ------------------------------------------------------------------------------------------------
+constexpr int SERIES_THREADS = 64;
+constexpr int SERIES_MAX_SLOTS = 8;  // data points per lane: n <= 512
+
+struct SeriesArgs {
+    const vag_model_params* params;
+    const VagGridMeta* meta;
+    const double* g_phi;
+    const double* g_theta;
+    const int* g_rep_of;
+    Layout lay;
+    const double* cellpar;
+    const double* lg2_t_obs;  // [n]
+    const double* lg2_nu_obs; // [n]
+    int n;
+    int pairs_per_block, max_blocks, k_stride;
+    double* partial; // [nb][max_blocks][n]
+};
+
+__global__ void __launch_bounds__(SERIES_THREADS)
+vag_flux_series_kernel(SeriesArgs a) {
+    const int m = blockIdx.y;
+    const VagGridMeta M = a.meta[m];
+    double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * a.n;
+    if (M.status != 0) return;
+    const int n_pairs = M.n_theta * M.n_phi_eff;
+    const int p0 = blockIdx.x * a.pairs_per_block;
+    if (p0 >= n_pairs) return;
+    const int p1 = min(n_pairs, p0 + a.pairs_per_block);
+    const int tid = threadIdx.x;
+    const int K = M.n_t, KS = a.k_stride;
+    extern __shared__ double lds[];
+    double* s_par = lds;
+    double* s_t = s_par + VAG_NPAR * KS;
+    double* s_dop = s_t + KS;
+    double* s_geom = s_dop + KS;
+
+    const vag_model_params P = a.params[m];
+    const double one_plus_z = 1 + P.z;
+    const double lg2_1pz = log2(one_plus_z);
+    SpecConst sc;
+    sc.init(P.p);
+    const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
+    const double* phi = a.g_phi + (size_t)m * VAG_MAX_PHI;
+    const double* theta = a.g_theta + (size_t)m * VAG_MAX_THETA;
+    const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int n_phi_eff = M.n_phi_eff;
+    const int last_j = M.n_theta - 1;
+
+    double acc[SERIES_MAX_SLOTS], tq[SERIES_MAX_SLOTS], nuq[SERIES_MAX_SLOTS];
+#pragma unroll
+    for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+        acc[q] = 0;
+        const int s = tid + q * SERIES_THREADS;
+        tq[q] = s < a.n ? a.lg2_t_obs[s] : 0;
+        nuq[q] = s < a.n ? a.lg2_nu_obs[s] + lg2_1pz : 0;
+    }
+    int staged_rep = -1;
+    for (int pair = p0; pair < p1; ++pair) {
+        const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+        const int rep = rep_of[j];
+        __syncthreads();
+        if (rep != staged_rep) {
+            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+            for (int q = tid; q < VAG_NPAR * K; q += SERIES_THREADS) {
+                const int par = q / K, k = q - par * K;
+                s_par[par * KS + k] = src[q];
+            }
+            staged_rep = rep;
+            __syncthreads();
+        }
+        {
+            const double th_j = theta[j];
+            const double ct = cos(th_j), st = sin(th_j);
+            const double cos_phi = cos(phi[i]);
+            const double cos_v = st * cos_phi * sin_obs + ct * cos_obs;
+            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+            const double cos_lo = (j == 0) ? ct : cos(0.5 * (theta[j - 1] + th_j));
+            const double cos_hi = (j == last_j) ? ct : cos(0.5 * (th_j + theta[j + 1]));
+            double dphi;
+            if (n_phi_eff == 1) {
+                dphi = 2 * C_PI;
+            } else if (M.phi_mirrored) {
+                const double left = (i > 0) ? 0.5 * (phi[i - 1] + phi[i]) : 0.0;
+                const double right = (i < n_phi_eff - 1) ? 0.5 * (phi[i] + phi[i + 1]) : C_PI;
+                dphi = 2 * (right - left);
+            } else {
+                const int lastp = n_phi_eff - 1;
+                dphi = 0.5 * (phi[min(i + 1, lastp)] - phi[i > 0 ? i - 1 : 0]);
+            }
+            const double lg2_dOmega = log2(fabs((cos_hi - cos_lo) * dphi));
+            for (int k = tid; k < K; k += SERIES_THREADS) {
+                const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+                const double lg2_dop = -log2(G - u * cos_v);
+                const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
+                s_dop[k] = lg2_dop;
+                s_t[k] = log2(time);
+                s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+            }
+        }
+        __syncthreads();
+        const double row_t0 = s_t[0], row_tN = s_t[K - 1];
+#pragma unroll
+        for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+            const int s = tid + q * SERIES_THREADS;
+            if (s < a.n) {
+                const double t = tq[q];
+                // iterate_through (observer.h:316-320): a point equal to a node belongs to the interval it closes
+                if (t >= row_t0 && t <= row_tN) {
+                    int lo = 0, hi = K - 1;  // find k with s_t[k] < t <= s_t[k+1]; t == row_t0 -> k = 0
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_t[mid] < t)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    const int k = lo;
+                    const double blo = log2_I_nu(s_par + k, KS, sc, nuq[q] - s_dop[k]) + s_geom[k];
+                    const double bhi = log2_I_nu(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1]) + s_geom[k + 1];
+                    const double sl = (bhi - blo) * (1.0 / (s_t[k + 1] - s_t[k]));
+                    if (isfinite(sl)) acc[q] += exp2(blo + (t - s_t[k]) * sl);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+        const int s = tid + q * SERIES_THREADS;
+        if (s < a.n) my_partial[s] = acc[q];
+    }
+}
+
+// chi^2 / log-likelihood of Fitter._evaluate (VegasAfterglow/fitting/fitter.py:497-533,
+// fitting/samplers.py:61-70): one wavefront per walker.
+__global__ void __launch_bounds__(64)
+vag_loglike_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const double* __restrict__ ln_flux,
+                   const double* __restrict__ ln_err, const double* __restrict__ weight,
+                   const int* __restrict__ valid /* [nb] */, double* __restrict__ out) {
+    const int m = blockIdx.x;
+    double chi2 = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const double f = flux[(size_t)m * n + i];
+        const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300);
+        const double q = (ln_flux[i] - log(fm)) / ln_err[i];
+        chi2 += weight[i] * (q * q);
+    }
+    chi2 = wave_sum(chi2);
+    if (threadIdx.x == 0) out[m] = (valid[m] && isfinite(chi2)) ? -0.5 * chi2 : -INFINITY;
+}
+
+// Transformer of fitting/utils.py:110-135 on the device: theta[nb][ndim] -> params[nb]
+__global__ void vag_transform_kernel(vag_model_params base, const double* __restrict__ theta, int nb, int ndim,
+                                     const int* __restrict__ slot, const int* __restrict__ is_log,
+                                     vag_model_params* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    vag_model_params p = base;
+    double* f = &p.theta_c;
+    for (int d = 0; d < ndim; ++d) {
+        const double v = theta[(size_t)b * ndim + d];
+        f[slot[d]] = is_log[d] ? pow(10.0, v) : v;
+    }
+    out[b] = p;
+}
+
+}  // namespace vag

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's ``VegasAfterglowC`` objects for the accelerated path.
+
+Same names, argument meaning, defaults and error behaviour as the pybind layer
+(``/root/reference/pybind/pybind.cpp:205-223,347-377,384-483``) for what the MI355X engine covers:
+``TophatJet / GaussianJet / PowerLawJet / TwoComponentJet``, ``ISM / Wind(k_m=2)``, ``Observer``,
+``Radiation`` (forward shock, synchrotron), ``Model.flux_density_grid / flux_density / flux``.
+Everything numerical happens in the HIP library through the C-ABI.
+"""
+import ctypes as C
+import math
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import ModelParams
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _finite_pos(name, x):
+    _req(math.isfinite(x) and x > 0, f"{name} must be positive and finite, got {x}")
+
+
+class _Jet:
+    jet_type = None
+    spreading = False
+
+    def _fill(self, p):
+        raise NotImplementedError
+
+
+class TophatJet(_Jet):
+    """TophatJet(theta_c, E_iso, Gamma0, spreading=False, duration=1, magnetar=None) -- pybind.cpp:205."""
+    jet_type = _lib.JET_TOPHAT
+
+    def __init__(self, theta_c, E_iso, Gamma0, spreading=False, duration=1.0, magnetar=None):
+        _req(math.isfinite(theta_c) and 0 < theta_c <= math.pi / 2, f"theta_c must be in (0, pi/2], got {theta_c}")
+        _finite_pos("E_iso", E_iso)
+        _req(math.isfinite(Gamma0) and Gamma0 > 1, f"Gamma0 must be > 1, got {Gamma0}")
+        _finite_pos("duration", duration)
+        if spreading or magnetar is not None:
+            raise NotImplementedError("spreading jets / magnetar injection are outside the MI355X hot path")
+        self.theta_c, self.E_iso, self.Gamma0, self.duration = float(theta_c), float(E_iso), float(Gamma0), float(duration)
+
+    def _fill(self, p):
+        p.jet_type = self.jet_type
+        p.theta_c, p.E_iso, p.Gamma0, p.duration = self.theta_c, self.E_iso, self.Gamma0, self.duration
+
+
+class GaussianJet(TophatJet):
+    """GaussianJet(theta_c, E_iso, Gamma0, ...) -- pybind.cpp:208."""
+    jet_type = _lib.JET_GAUSSIAN
+
+
+class PowerLawJet(TophatJet):
+    """PowerLawJet(theta_c, E_iso, Gamma0, k_e, k_g, ...) -- pybind.cpp:211."""
+    jet_type = _lib.JET_POWERLAW
+
+    def __init__(self, theta_c, E_iso, Gamma0, k_e, k_g, spreading=False, duration=1.0, magnetar=None):
+        super().__init__(theta_c, E_iso, Gamma0, spreading, duration, magnetar)
+        _finite_pos("k_e", k_e)
+        _finite_pos("k_g", k_g)
+        self.k_e, self.k_g = float(k_e), float(k_g)
+
+    def _fill(self, p):
+        super()._fill(p)
+        p.k_e, p.k_g = self.k_e, self.k_g
+
+
+class TwoComponentJet(TophatJet):
+    """TwoComponentJet(theta_c, E_iso, Gamma0, theta_w, E_iso_w, Gamma0_w, ...) -- pybind.cpp:214."""
+    jet_type = _lib.JET_TWO_COMPONENT
+
+    def __init__(self, theta_c, E_iso, Gamma0, theta_w, E_iso_w, Gamma0_w, spreading=False, duration=1.0,
+                 magnetar=None):
+        super().__init__(theta_c, E_iso, Gamma0, spreading, duration, magnetar)
+        _req(math.isfinite(theta_w) and 0 < theta_w <= math.pi / 2, f"theta_w must be in (0, pi/2], got {theta_w}")
+        _req(theta_w > theta_c, "theta_w (wing angle) must be greater than theta_c (core angle), "
+                                f"got theta_w={theta_w}, theta_c={theta_c}")
+        _finite_pos("E_iso_w", E_iso_w)
+        _req(math.isfinite(Gamma0_w) and Gamma0_w > 1, f"Gamma0_w must be > 1, got {Gamma0_w}")
+        self.theta_w, self.E_iso_w, self.Gamma0_w = float(theta_w), float(E_iso_w), float(Gamma0_w)
+
+    def _fill(self, p):
+        super()._fill(p)
+        p.theta_w, p.E_iso_w, p.Gamma0_w = self.theta_w, self.E_iso_w, self.Gamma0_w
+
+
+class ISM:
+    """ISM(n_ism) -- pybind.cpp:347, pymodel.cpp:148-151."""
+
+    def __init__(self, n_ism):
+        _req(math.isfinite(n_ism) and n_ism >= 0, f"n_ism must be non-negative and finite, got {n_ism}")
+        self.n_ism = float(n_ism)
+
+    def _fill(self, p):
+        p.medium_type = _lib.MEDIUM_ISM
+        p.n_ism, p.A_star, p.n0 = self.n_ism, 0.0, math.inf
+
+
+class Wind:
+    """Wind(A_star, n_ism=None, n0=None, k_m=2) -- pybind.cpp:350-355, pymodel.cpp:153-186."""
+
+    def __init__(self, A_star, n_ism=None, n0=None, k_m=2):
+        _finite_pos("A_star", A_star)
+        _finite_pos("k_m", k_m)
+        if n_ism is not None:
+            _req(math.isfinite(n_ism) and n_ism >= 0, f"n_ism must be non-negative and finite, got {n_ism}")
+        if n0 is not None:
+            _req(n0 > 0, f"n0 must be > 0 (or +inf for no floor), got {n0}")
+        if k_m != 2:
+            raise NotImplementedError("Wind with k_m != 2 is a python-callback Medium in the reference; not on the hot path")
+        self.A_star = float(A_star)
+        self.n_ism = 0.0 if n_ism is None else float(n_ism)
+        self.n0 = math.inf if n0 is None else float(n0)
+
+    def _fill(self, p):
+        p.medium_type = _lib.MEDIUM_WIND
+        p.n_ism, p.A_star, p.n0 = self.n_ism, self.A_star, self.n0
+
+
+class Observer:
+    """Observer(lumi_dist, z, theta_obs, phi_obs=0) -- pybind.cpp:358-365, pymodel.h:208-222."""
+
+    def __init__(self, lumi_dist, z, theta_obs, phi_obs=0.0):
+        _finite_pos("lumi_dist", lumi_dist)
+        _req(math.isfinite(z) and z >= 0, f"z must be non-negative and finite, got {z}")
+        _req(math.isfinite(theta_obs) and 0 <= theta_obs <= math.pi, f"theta_obs must be in [0, pi], got {theta_obs}")
+        _req(math.isfinite(phi_obs), f"phi_obs must be finite, got {phi_obs}")
+        self.lumi_dist, self.z, self.theta_obs, self.phi_obs = float(lumi_dist), float(z), float(theta_obs), float(phi_obs)
+
+
+class Radiation:
+    """Radiation(eps_e, eps_B, p, xi_e=1, ssc=False, kn=False) -- pybind.cpp:368-377, pymodel.h:241-260."""
+
+    def __init__(self, eps_e, eps_B, p, xi_e=1.0, ssc=False, kn=False):
+        for name, x in (("eps_e", eps_e), ("eps_B", eps_B), ("xi_e", xi_e)):
+            _req(math.isfinite(x) and 0 < x <= 1, f"{name} must be in (0, 1], got {x}")
+        _req(math.isfinite(p) and p > 1, f"p must be > 1, got {p}")
+        self.eps_e, self.eps_B, self.p, self.xi_e, self.ssc, self.kn = float(eps_e), float(eps_B), float(p), float(xi_e), bool(ssc), bool(kn)
+
+
+class Flux:
+    """Flux{sync, ssc} (pybind.cpp:472-477); disabled components are 0-d zeros like the reference's."""
+
+    def __init__(self, sync=None, ssc=None):
+        self.sync = np.zeros(()) if sync is None else sync
+        self.ssc = np.zeros(()) if ssc is None else ssc
+
+
+class FluxDict:
+    """FluxDict{total, fwd, rvs} (pybind.cpp:478-483, pymodel.cpp:350-364)."""
+
+    def __init__(self, fwd_sync):
+        self.fwd = Flux(sync=fwd_sync)
+        self.rvs = Flux()
+        self.total = fwd_sync.copy()
+        for a in (self.total, self.fwd.sync):
+            a.setflags(write=False)
+
+
+_ctx_lock = threading.Lock()
+_ctx = {}
+
+
+def get_context(device=0):
+    """Process-wide engine context per device (the C-ABI context serialises its own stream)."""
+    lib = _lib.load()
+    with _ctx_lock:
+        if device not in _ctx:
+            h = C.c_void_p()
+            _lib.check(lib.vag_ctx_create(device, C.byref(h)))
+            _ctx[device] = (h, threading.Lock())
+        return _ctx[device]
+
+
+def _as_f64(a, name):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    _req(a.ndim == 1, f"{name} must be one-dimensional")
+    return a
+
+
+_dp = C.POINTER(C.c_double)
+
+
+class Model:
+    """Model(jet, medium, observer, fwd_rad, rvs_rad=None, resolutions=None, rtol=1e-6, axisymmetric=True,
+    radiative_fireball=True) -- pybind.cpp:384-422, pymodel.h:613-649."""
+
+    def __init__(self, jet, medium, observer, fwd_rad, rvs_rad=None, resolutions=None, rtol=1e-6, axisymmetric=True,
+                 radiative_fireball=True, device=0):
+        if not isinstance(jet, _Jet):
+            raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, or TwoComponentJet")
+        if not isinstance(medium, (ISM, Wind)):
+            raise TypeError("medium must be ISM or Wind")
+        if rvs_rad is not None:
+            raise NotImplementedError("reverse shock is SURVEY section 8(f) rank 2: not on the accelerated path yet")
+        if fwd_rad.ssc:
+            raise NotImplementedError("SSC / inverse Compton is SURVEY section 8(f) rank 1: not on the accelerated path yet")
+        if not axisymmetric:
+            raise NotImplementedError("axisymmetric=False is SURVEY section 8(f) rank 3")
+        _req(math.isfinite(rtol) and 0 < rtol < 1, f"rtol must be in (0, 1), got {rtol}")
+        res = (0.06, 0.15, 6.0) if resolutions is None else tuple(float(x) for x in resolutions)
+        for n, x in zip(("phi_resol", "theta_resol", "t_resol"), res):
+            _finite_pos(n, x)
+        self._jet, self._medium, self.observer, self.fwd_rad, self.rvs_rad = jet, medium, observer, fwd_rad, None
+        self.resolutions, self.rtol, self.axisymmetric, self.radiative_fireball = res, float(rtol), True, bool(radiative_fireball)
+        self._device = device
+        p = ModelParams()
+        _lib.load().vag_params_default(C.byref(p))
+        jet._fill(p)
+        medium._fill(p)
+        p.lumi_dist, p.z, p.theta_obs = observer.lumi_dist, observer.z, observer.theta_obs
+        p.eps_e, p.eps_B, p.p, p.xi_e = fwd_rad.eps_e, fwd_rad.eps_B, fwd_rad.p, fwd_rad.xi_e
+        p.phi_resol, p.theta_resol, p.t_resol = res
+        p.rtol = self.rtol
+        p.radiative_fireball = 1 if radiative_fireball else 0
+        _lib.check(_lib.load().vag_params_validate(C.byref(p)))
+        self.params = p
+
+    # -- Model.flux_density_grid: pybind.cpp:424, pymodel.cpp:498-514 --
+    def flux_density_grid(self, t, nu):
+        t, nu = _as_f64(t, "t"), _as_f64(nu, "nu")
+        _req(t.size > 0, "time array must be non-empty")
+        _req(nu.size > 0, "frequency array must be non-empty")
+        out = np.empty((nu.size, t.size))
+        h, lock = get_context(self._device)
+        with lock:
+            _lib.check(_lib.load().vag_flux_density_grid_batch(
+                h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
+                out.ctypes.data_as(_dp)))
+        return FluxDict(out)
+
+    # -- Model.flux_density: pybind.cpp:427, pymodel.cpp:373-389 --
+    def flux_density(self, t, nu):
+        t, nu = _as_f64(t, "t"), _as_f64(nu, "nu")
+        _req(t.size > 0, "time array must be non-empty")
+        _req(nu.size > 0, "frequency array must be non-empty")
+        _req(t.size == nu.size, "time and frequency arrays must have the same size\nIf you intend to get grid-like "
+                                "output, use the generic `flux_density_grid` instead")
+        out = np.empty(t.size)
+        h, lock = get_context(self._device)
+        with lock:
+            _lib.check(_lib.load().vag_flux_density_batch(
+                h, C.byref(self.params), 1, t.ctypes.data_as(_dp), nu.ctypes.data_as(_dp), t.size,
+                out.ctypes.data_as(_dp)))
+        return FluxDict(out)
+
+    # -- Model.flux: pybind.cpp:430, pymodel.cpp:391-410 --
+    def flux(self, t, nu_min, nu_max, num_nu):
+        t = _as_f64(t, "t")
+        _req(t.size > 0, "time array must be non-empty")
+        out = np.empty(t.size)
+        h, lock = get_context(self._device)
+        with lock:
+            _lib.check(_lib.load().vag_flux_batch(h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size,
+                                                  float(nu_min), float(nu_max), int(num_nu), out.ctypes.data_as(_dp)))
+        return FluxDict(out)
+
+    # -- Model.details (shock part): pybind.cpp:448, pymodel.cpp:315-348 --
+    def details(self, t_min, t_max):
+        lib = _lib.load()
+        h, lock = get_context(self._device)
+        sh = _lib.DetailsShape()
+        with lock:
+            _lib.check(lib.vag_details(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), None))
+            d = {"phi": np.zeros(sh.n_phi), "theta": np.zeros(sh.n_theta)}
+            for n in ("t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th"):
+                d[n] = np.zeros((sh.n_theta, sh.n_t))
+            out = _lib.DetailsOut(*[d[n].ctypes.data_as(_dp) for n, _ in _lib.DetailsOut._fields_])
+            _lib.check(lib.vag_details(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), C.byref(out)))
+        d["shape"] = dict(n_phi=sh.n_phi, n_theta=sh.n_theta, n_t=sh.n_t, n_reps=sh.n_reps, symmetry=sh.symmetry,
+                          phi_mirrored=sh.phi_mirrored)
+        return d
+
+    def stage_times(self):
+        """Per-stage device milliseconds of the last call (names follow pybind/pymodel.h:877-953)."""
+        st = _lib.StageTimes()
+        h, _ = get_context(self._device)
+        _lib.load().vag_last_stage_times(h, C.byref(st))
+        return {"EAT_grid+grid": st.grid_ms, "dynamics": st.dynamics_ms, "syn_electrons+syn_photons": st.cells_ms,
+                "sync_flux": st.flux_ms, "reduce": st.reduce_ms, "total": st.total_ms}
+
+    def __repr__(self):
+        o, r = self.observer, self.fwd_rad
+        return (f"Model(observer=Observer(lumi_dist={o.lumi_dist:.6g}, z={o.z:.6g}, theta_obs={o.theta_obs:.6g}),\n"
+                f"      fwd_rad=Radiation(eps_e={r.eps_e:.6g}, eps_B={r.eps_B:.6g}, p={r.p:.6g}),\n"
+                f"      resolutions=({self.resolutions[0]:.6g}, {self.resolutions[1]:.6g}, {self.resolutions[2]:.6g}), "
+                f"rtol={self.rtol:.6g})")
