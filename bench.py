@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- light-curves/s of the MI355X afterglow engine on BASELINE.json's configs[1].
+
+One "step" = one pass of the hot path (adaptive grid -> blast-wave ODE -> per-cell synchrotron -> EAT flux
+integration) over one batch of synthetic models: `--batch` Gaussian-jet off-axis models of the C2
+configuration (GaussianJet(0.1, 1e52, 300) + ISM(1), theta_obs = 0.3,
+resolutions (0.355, 0.31, 20.5) -> ~(64, 64, 199) grid, 200 times x 10 bands) with +-10 % jitter on the
+physical parameters.  Inputs (parameter structs, t, nu) are resident in HBM before the timed region and the
+fluxes stay in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 launch with torch.distributed.run
+(one rank per GPU): models are block-sharded (weak scaling: --batch models per rank), and each step ends with the
+all-gather of a per-model summary (8 B/model) that a sampler would consume.
+
+Prints ONE JSON line (see README / DESIGN.md for the roofline conventions).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F_SPEC = 210.0   # FP64 flop-equivalents per spectrum evaluation
+F_INTERP = 26.0  # per log-log interpolation + exp2 + accumulate
+PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_FP64_TFLOPS = 78.6  # FP64 vector = half the 157.3 TF FP32 vector peak of MI355X_MICROARCH.md
+
+
+def c2_batch(nb, seed):
+    """C2 models with +-10 % log-uniform jitter (synthetic, seeded)."""
+    import _abi
+    import configs
+    rng = np.random.default_rng(seed)
+    arr = (_abi.ModelParams * nb)()
+    for i in range(nb):
+        kw = dict(configs.C2)
+        j = lambda: float(np.exp(rng.uniform(np.log(0.9), np.log(1.1))))
+        kw["E_iso"] *= j()
+        kw["Gamma0"] *= j()
+        kw["n_ism"] *= j()
+        kw["eps_e"] *= j()
+        kw["eps_B"] *= j()
+        kw["p"] = 2.3 + rng.uniform(-0.1, 0.1)
+        kw["theta_c"] *= j()
+        arr[i] = _abi.make_params(**kw)
+    return arr
+
+
+def cpu_baseline(arr, t, nu, budget_s=12.0):
+    """Reference CPU path timed on this box's host, one thread, on a bounded sample of the same workload."""
+    import _abi
+    lib, kind = _abi.load_ref(), "reference"
+    if lib is None:
+        lib, kind = _abi.load_oracle(fast=True), "port"
+        if lib is None:
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"])
+            lib = _abi.load_oracle(fast=True)
+    n, t0 = 0, time.perf_counter()
+    while n < len(arr) and (time.perf_counter() - t0 < budget_s or n < 2):
+        lib.flux_density_grid(arr[n], t, nu)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "light-curves/s", "cores": 1, "kind": kind,
+            "sample": f"{n} models of the timed batch (C2: 200 t x 10 nu), single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="models per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import configs
+    from vegasafterglow_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.vag_ctx_create(local_rank, C.byref(h)))
+    stream = torch.cuda.current_stream()
+    _lib.check(lib.vag_ctx_set_stream(h, C.c_void_p(stream.cuda_stream)))
+
+    nb = args.batch
+    t_np, nu_np = configs.C2_T, configs.C2_NU
+    nt, nnu = t_np.size, nu_np.size
+    arr = c2_batch(nb, seed=1234 + rank)
+    dev = torch.device("cuda", local_rank)
+    d_params = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    d_t = torch.from_numpy(t_np).to(dev)
+    d_nu = torch.from_numpy(nu_np).to(dev)
+    d_out = torch.empty((nb, nnu, nt), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * nb,), dtype=torch.float64, device=dev) if world > 1 else None
+
+    flux_ms = []
+
+    def step(record):
+        _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_params.data_ptr(), nb, d_t.data_ptr(), nt, d_nu.data_ptr(), nnu,
+                                                       d_out.data_ptr()))
+        if world > 1:
+            # what a sampler consumes per model (here: the band-summed fluence proxy), 8 B/model over RCCL
+            dist.all_gather_into_tensor(gathered, d_out.sum(dim=(1, 2)))
+        if record:
+            st = _lib.StageTimes()
+            _lib.check(lib.vag_last_stage_times(h, C.byref(st)))  # HIP events on the kernel's own stream
+            flux_ms.append((st.grid_ms, st.dynamics_ms, st.cells_ms, st.flux_ms, st.reduce_ms, st.total_ms))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    plan = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(plan))
+    if not bool(torch.isfinite(d_out).all()) or plan.n_models_ok != nb:
+        raise SystemExit("bench produced non-finite fluxes or rejected models")
+
+    if rank == 0:
+        st = np.mean(np.array(flux_ms), axis=0)
+        flux_s = st[3] * 1e-3
+        # algorithmic work of ONE flux-kernel launch (DESIGN.md "Roofline accounting")
+        alg_bytes = plan.n_cells * 19 * 8 + nb * nnu * nt * 8 + nb * (64 + 64) * 8
+        alg_flops = plan.spec_evals * F_SPEC + plan.interps * F_INTERP
+        out = {
+            "metric": "light-curves/sec (single model) and MCMC walker-steps/sec at 1/2/4/8 MI355X",
+            "value": world * nb * args.steps / elapsed,
+            "unit": "light-curves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: GaussianJet off-axis (theta_obs=0.3) + ISM, synchrotron+SSA, "
+                                   "resolutions (0.355,0.31,20.5) -> ~64x64x199 cells/model, 200 time bins x 10 bands",
+                       "models_per_gpu_per_step": nb, "global_batch": world * nb, "parallelism": f"walker-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "vag_flux_grid_kernel",
+                         "achieved": alg_bytes / flux_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / flux_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "bytes_per_launch": alg_bytes, "ms_per_launch": st[3]},
+            "roofline_fp64": {"bound": "fp64_valu", "kernel": "vag_flux_grid_kernel",
+                              "achieved": alg_flops / flux_s / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                              "frac": alg_flops / flux_s / 1e12 / PEAK_FP64_TFLOPS,
+                              "spec_evals_per_launch": plan.spec_evals, "interps_per_launch": plan.interps},
+            "stage_ms": {"grid": st[0], "dynamics": st[1], "syn_cells": st[2], "sync_flux": st[3], "reduce": st[4],
+                         "total_device": st[5]},
+            "plan": {"ode_rows": plan.n_rows, "cells": plan.n_cells, "theta_phi_rows": plan.total_pairs,
+                     "flux_workgroups": plan.flux_blocks, "rows_per_workgroup": plan.pairs_per_block},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(arr, t_np, nu_np)
+        print(json.dumps(out))
+    lib.vag_ctx_destroy(h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ extern "C" {
  *   Model(jet, medium, Observer(lumi_dist, z, theta_obs), Radiation(eps_e, eps_B, p, xi_e),
  *         resolutions=(phi, theta, t), rtol, axisymmetric=True, radiative_fireball)
  * (pybind/pybind.cpp:384-422, pybind/pymodel.h:613-649), flattened to plain scalars.
- * All doubles; the two tags are int32.  Layout is fixed (176 bytes) and is what the
+ * All doubles; the two tags are int32.  Layout is fixed (200 bytes) and is what the
  * device kernels read straight from HBM.
  */
 typedef struct vag_model_params {
@@ -244,6 +244,23 @@ typedef struct vag_stage_times {
     float grid_ms, dynamics_ms, cells_ms, flux_ms, reduce_ms, total_ms;
 } vag_stage_times;
 int vag_last_stage_times(vag_ctx* ctx, vag_stage_times* out);
+
+/* Work done by the last batch call, for roofline accounting (SURVEY.md section 8d units):
+ *   eat_cells  = sum over models of (theta x phi_eff pairs) x n_t  -- (phi, theta, k) cells of Observer::observe
+ *   spec_evals = eat_cells x nnu (grid) or 2 x pairs x n (series)  -- calls of SmoothPowerLawSyn::compute_log2_I_nu
+ *   interps    = pairs x nt x nnu (grid) or pairs x n (series)     -- log-log interpolations + exp2 */
+typedef struct vag_plan {
+    int32_t n_models_ok; /* models whose grid fit the engine limits */
+    int32_t n_rows;      /* ODE rows solved (representative theta rows) */
+    int64_t n_cells;     /* (row, k) cells = photon parameter blocks */
+    int64_t total_pairs; /* (theta, phi_eff) rows integrated by the flux kernel */
+    int64_t eat_cells;
+    int64_t spec_evals;
+    int64_t interps;
+    int32_t flux_blocks; /* workgroups of the flux kernel */
+    int32_t pairs_per_block;
+} vag_plan;
+int vag_last_plan(vag_ctx* ctx, vag_plan* out);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,12 @@ class StageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("grid_ms", "dynamics_ms", "cells_ms", "flux_ms", "reduce_ms", "total_ms")]
 
 
+class Plan(C.Structure):
+    _fields_ = [("n_models_ok", C.c_int32), ("n_rows", C.c_int32), ("n_cells", C.c_int64), ("total_pairs", C.c_int64),
+                ("eat_cells", C.c_int64), ("spec_evals", C.c_int64), ("interps", C.c_int64),
+                ("flux_blocks", C.c_int32), ("pairs_per_block", C.c_int32)]
+
+
 class Limits(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("max_theta", "max_phi", "max_time", "max_nu")]
 
@@ -68,7 +74,7 @@ EXPORTS = [
     "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_details", "vag_last_stage_times",
+    "vag_details", "vag_last_stage_times", "vag_last_plan",
 ]
 
 _lib = None
@@ -107,6 +113,7 @@ def load():
     lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_last_stage_times.argtypes = [v, C.POINTER(StageTimes)]
+    lib.vag_last_plan.argtypes = [v, C.POINTER(Plan)]
     _lib = lib
     return lib
 

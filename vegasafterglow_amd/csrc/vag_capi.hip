@@ -173,7 +173,9 @@ struct vag_ctx {
     DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux;
     // plan of the last grid pass
     int nb = 0, n_rows = 0, max_k = 0, max_pairs = 0;
-    long long n_cells = 0, total_pairs = 0;
+    long long n_cells = 0, total_pairs = 0, eat_cells = 0;
+    int n_ok = 0;
+    vag_plan plan{};
     vag_stage_times times{};
 };
 
@@ -273,14 +275,22 @@ int vag_ctx_set_stream(vag_ctx* c, void* s) {
     return VAG_OK;
 }
 
+int vag_last_plan(vag_ctx* c, vag_plan* out) {
+    *out = c->plan;
+    return VAG_OK;
+}
+
 int vag_ctx_synchronize(vag_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return VAG_OK;
 }
 
+static int collect_times_fwd(vag_ctx* c);
 int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
+    // measured with HIP events recorded on the context stream around each kernel of the last batch call
+    const int rc = collect_times_fwd(c);
     *out = c->times;
-    return VAG_OK;
+    return rc;
 }
 
 }  // extern "C"
@@ -317,8 +327,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     HIPCHK(hipStreamSynchronize(st));
     long long* h_cell = c->h_off.as<long long>();
     int* h_row = reinterpret_cast<int*>(h_cell + (nb + 1));
-    long long cells = 0, pairs = 0;
-    int rows = 0, max_k = 2, max_pairs = 0;
+    long long cells = 0, pairs = 0, eat = 0;
+    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0;
     for (int m = 0; m < nb; ++m) {
         h_row[m] = rows;
         h_cell[m] = cells;
@@ -329,6 +339,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             const int pr = hm[m].n_theta * hm[m].n_phi_eff;
             max_pairs = std::max(max_pairs, pr);
             pairs += pr;
+            eat += (long long)pr * hm[m].n_t;
+            ++n_ok;
         }
     }
     h_row[nb] = rows;
@@ -339,6 +351,14 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->max_k = max_k;
     c->max_pairs = max_pairs;
     c->total_pairs = pairs;
+    c->eat_cells = eat;
+    c->n_ok = n_ok;
+    c->plan = vag_plan{};
+    c->plan.n_models_ok = n_ok;
+    c->plan.n_rows = rows;
+    c->plan.n_cells = cells;
+    c->plan.total_pairs = pairs;
+    c->plan.eat_cells = eat;
     HIPCHK(hipMemcpyAsync(c->d_cell_off.p, h_cell, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_row_off.p, h_row, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, st));
     if (rows == 0) {
@@ -405,6 +425,10 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.max_blocks = max_blocks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
+    c->plan.spec_evals += c->eat_cells * nnu;
+    c->plan.interps += c->total_pairs * (long long)nt * nnu;
+    c->plan.flux_blocks = max_blocks * nb;
+    c->plan.pairs_per_block = ppb;
     if (c->n_rows > 0) {
         hipLaunchKernelGGL(vag_flux_grid_kernel, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         HIPCHK(hipGetLastError());
@@ -462,6 +486,10 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.max_blocks = max_blocks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
+    c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
+    c->plan.interps = c->total_pairs * (long long)n;
+    c->plan.flux_blocks = max_blocks * nb;
+    c->plan.pairs_per_block = (int)ppb;
     if (c->n_rows > 0) {
         hipLaunchKernelGGL(vag_flux_series_kernel, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
         HIPCHK(hipGetLastError());
@@ -491,6 +519,10 @@ int collect_times(vag_ctx* c) {
     c->times.total_ms = v;
     return VAG_OK;
 }
+
+}  // namespace
+static int collect_times_fwd(vag_ctx* c) { return collect_times(c); }
+namespace {
 
 int prep_times(vag_ctx* c, const double* d_t, int nt, const double* d_nu, int nnu) {
     if (c->d_lg2t.ensure(sizeof(double) * nt)) return VAG_E_HIP;

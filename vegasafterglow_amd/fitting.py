@@ -1,0 +1,175 @@
+"""Batched log-likelihood: host-side mirror of the reference's Fitter evaluation path.
+
+Mirrors ``VegasAfterglow/fitting/fitter.py:407-451`` (_consolidate_data), ``:497-533`` (_chi2_sum,
+_evaluate), ``fitting/utils.py:110-135`` (transformer), ``fitting/samplers.py:61-91`` (eval_one,
+log_prob_batch) for point flux-density data, with the per-walker ``Model`` evaluations replaced by ONE
+batched call into the HIP engine (``vag_loglike_batch``).  Sampler drivers (emcee/bilby) stay
+third-party: hand ``Fitter.log_prob_batch`` to ``emcee.EnsembleSampler(..., vectorize=True)``.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from enum import Enum
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .model import get_context
+
+JET_TYPES = {"tophat": _lib.JET_TOPHAT, "gaussian": _lib.JET_GAUSSIAN, "powerlaw": _lib.JET_POWERLAW,
+             "two_component": _lib.JET_TWO_COMPONENT}
+MEDIUM_TYPES = {"ism": _lib.MEDIUM_ISM, "wind": _lib.MEDIUM_WIND}
+
+
+class Scale(Enum):
+    linear = "linear"
+    log = "log"
+    fixed = "fixed"
+
+
+@dataclass
+class ParamDef:
+    """ParamDef(name, lower, upper, scale, initial) -- VegasAfterglow/types.py."""
+    name: str
+    lower: float
+    upper: float
+    scale: Scale = Scale.linear
+    initial: Optional[float] = None
+
+
+# ModelParams defaults, VegasAfterglow/types.py:37-77
+MODEL_PARAM_DEFAULTS = dict(theta_v=0.0, n_ism=0.0, n0=math.inf, A_star=0.0, k_m=2.0, E_iso=1e52, Gamma0=300.0,
+                            theta_c=0.1, k_e=2.0, k_g=2.0, tau=1.0, E_iso_w=1e52, Gamma0_w=300.0,
+                            theta_w=math.pi / 2, p=2.3, eps_e=0.1, eps_B=0.01, xi_e=1.0)
+
+_dp = C.POINTER(C.c_double)
+
+
+class Fitter:
+    """Fitter(z, lumi_dist, jet=..., medium=..., resolution=..., rtol=...) for point flux-density data."""
+
+    def __init__(self, z, lumi_dist, jet="tophat", medium="ism", resolution=(0.06, 0.15, 6.0), rtol=1e-6,
+                 radiative_fireball=True, device=0):
+        if jet not in JET_TYPES:
+            raise ValueError(f"Unknown jet type: {jet}")
+        if medium not in MEDIUM_TYPES:
+            raise ValueError(f"Unknown medium type: {medium}")
+        self.z, self.lumi_dist, self.jet, self.medium = float(z), float(lumi_dist), jet, medium
+        self.resolution, self.rtol, self.radiative_fireball = tuple(resolution), float(rtol), bool(radiative_fireball)
+        self.device = device
+        self._point_t, self._point_nu, self._point_flux, self._point_err, self._point_weights = [], [], [], [], []
+        self._all_t = None
+
+    # fitter.py add_flux_density
+    def add_flux_density(self, nu, t, f_nu, err, weights=None):
+        t = np.asarray(t, dtype=np.float64)
+        f_nu = np.asarray(f_nu, dtype=np.float64)
+        err = np.asarray(err, dtype=np.float64)
+        if not (t.shape == f_nu.shape == err.shape):
+            raise ValueError("t, f_nu and err must have the same shape")
+        w = np.ones_like(t) if weights is None else np.asarray(weights, dtype=np.float64)
+        self._point_t.append(t)
+        self._point_nu.append(np.full_like(t, float(nu)) if np.ndim(nu) == 0 else np.asarray(nu, dtype=np.float64))
+        self._point_flux.append(f_nu)
+        self._point_err.append(err)
+        self._point_weights.append(w)
+        self._all_t = None
+
+    # fitter.py:407-451
+    def _consolidate_data(self):
+        if self._all_t is not None:
+            return
+        if not self._point_t:
+            raise ValueError("no data: call add_flux_density first")
+        t = np.concatenate(self._point_t)
+        nu = np.concatenate(self._point_nu)
+        f = np.concatenate(self._point_flux)
+        e = np.concatenate(self._point_err)
+        w = np.concatenate(self._point_weights)
+        order = np.argsort(t)
+        t, nu, f, e, w = t[order], nu[order], f[order], e[order], w[order].copy()
+        s = w.sum()
+        if s > 0:
+            w *= len(w) / s
+        if np.any(f <= 0) or np.any(e <= 0):
+            raise ValueError("the log-flux likelihood requires strictly positive fluxes and errors")
+        self._all_t, self._all_nu = np.ascontiguousarray(t), np.ascontiguousarray(nu)
+        self._all_log_flux = np.ascontiguousarray(np.log(f))
+        self._all_log_err = np.ascontiguousarray(e / f)
+        self._all_weights = np.ascontiguousarray(w)
+
+    def _base_params(self, fixed):
+        vals = dict(MODEL_PARAM_DEFAULTS)
+        vals.update(fixed)
+        p = _lib.ModelParams()
+        _lib.load().vag_params_default(C.byref(p))
+        p.jet_type, p.medium_type = JET_TYPES[self.jet], MEDIUM_TYPES[self.medium]
+        p.theta_c, p.E_iso, p.Gamma0, p.k_e, p.k_g = vals["theta_c"], vals["E_iso"], vals["Gamma0"], vals["k_e"], vals["k_g"]
+        p.theta_w, p.E_iso_w, p.Gamma0_w, p.duration = vals["theta_w"], vals["E_iso_w"], vals["Gamma0_w"], vals["tau"]
+        p.n_ism, p.A_star, p.n0 = vals["n_ism"], vals["A_star"], vals["n0"]
+        p.lumi_dist, p.z, p.theta_obs = self.lumi_dist, self.z, vals["theta_v"]
+        p.eps_e, p.eps_B, p.p, p.xi_e = vals["eps_e"], vals["eps_B"], vals["p"], vals["xi_e"]
+        p.phi_resol, p.theta_resol, p.t_resol = self.resolution
+        p.rtol = self.rtol
+        p.radiative_fireball = 1 if self.radiative_fireball else 0
+        return p
+
+    def build_spec(self, param_defs: Sequence[ParamDef]):
+        """The transformer of fitting/utils.py:110-135 as a C-ABI slot map (vag_fit_spec)."""
+        self._consolidate_data()
+        fixed = {pd.name: (pd.initial if pd.initial is not None else pd.lower) for pd in param_defs if pd.scale is Scale.fixed}
+        free = [pd for pd in param_defs if pd.scale is not Scale.fixed]
+        if len(free) > 16:
+            raise ValueError("at most 16 free parameters")
+        spec = _lib.FitSpec()
+        spec.base = self._base_params(fixed)
+        spec.ndim = len(free)
+        for d, pd in enumerate(free):
+            if pd.name not in _lib.PARAM_SLOTS:
+                raise ValueError(f"parameter {pd.name} is not accepted by the accelerated path")
+            spec.slot[d] = _lib.PARAM_SLOTS[pd.name]
+            spec.is_log[d] = 1 if pd.scale is Scale.log else 0
+        spec.n_data = self._all_t.size
+        spec.t = self._all_t.ctypes.data_as(_dp)
+        spec.nu = self._all_nu.ctypes.data_as(_dp)
+        spec.ln_flux = self._all_log_flux.ctypes.data_as(_dp)
+        spec.ln_err = self._all_log_err.ctypes.data_as(_dp)
+        spec.weight = self._all_weights.ctypes.data_as(_dp)
+        lower = np.array([pd.lower for pd in free], dtype=np.float64)
+        upper = np.array([pd.upper for pd in free], dtype=np.float64)
+        return spec, lower, upper
+
+    def loglike_batch(self, samples, param_defs):
+        """ln L for each row of samples[nb, ndim] (one batched device call)."""
+        spec, _, _ = self.build_spec(param_defs)
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+        if samples.ndim != 2 or samples.shape[1] != spec.ndim:
+            raise ValueError("samples must be [nb, ndim]")
+        out = np.empty(samples.shape[0])
+        h, lock = get_context(self.device)
+        with lock:
+            _lib.check(_lib.load().vag_loglike_batch(h, C.byref(spec), samples.ctypes.data_as(_dp), samples.shape[0],
+                                                     spec.ndim, out.ctypes.data_as(_dp)))
+        return out
+
+    def make_log_prob_batch(self, param_defs, loglike_fn=None):
+        """log_prob_batch(samples) of fitting/samplers.py:72-91 with uniform priors:
+        out-of-bounds -> -inf; otherwise ln L + sum ln prior.  ``loglike_fn`` lets a caller substitute a
+        sharded evaluator (vegasafterglow_amd.dist.sharded_loglike)."""
+        _, lower, upper = self.build_spec(param_defs)
+        ln_prior = -np.sum(np.log(upper - lower))
+        fn = loglike_fn if loglike_fn is not None else (lambda s: self.loglike_batch(s, param_defs))
+
+        def log_prob_batch(samples):
+            samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+            in_bounds = np.all((samples >= lower) & (samples <= upper), axis=1)
+            log_probs = np.full(samples.shape[0], -np.inf)
+            idx = np.where(in_bounds)[0]
+            if idx.size:
+                ll = np.asarray(fn(samples[idx]), dtype=np.float64)
+                ll[~np.isfinite(ll)] = -np.inf
+                log_probs[idx] = ll + ln_prior
+            return log_probs
+
+        return log_prob_batch
