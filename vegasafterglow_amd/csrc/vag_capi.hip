@@ -157,15 +157,64 @@ static const char* validate_msg(const vag_model_params* p) {
     return nullptr;
 }
 
+// g(a) = log2(1 + 2^-a) interpolation table for sp_fast (vag_device.h): per interval of width 1/8 the degree-7
+// interpolant at Chebyshev nodes, converted to monomials in tau = 8a - idx - 1/2, all in long double.
+// Returns the max abs error measured on a dense check grid.
+static double build_softplus_table(std::vector<double>& tab) {
+    const int n = SP_NCOEF, NI = SP_INTERVALS, per = SP_PER_UNIT;
+    const long double PI = 3.141592653589793238462643383279502884L;
+    tab.assign((size_t)NI * n, 0.0);
+    long double T[SP_NCOEF][SP_NCOEF] = {};
+    T[0][0] = 1;
+    T[1][1] = 1;
+    for (int k = 2; k < n; ++k)
+        for (int q = 0; q < n; ++q) T[k][q] = (q > 0 ? 2 * T[k - 1][q - 1] : 0) - T[k - 2][q];
+    for (int i = 0; i < NI; ++i) {
+        const long double a0 = (long double)i / per, h = 1.0L / per;
+        long double f[SP_NCOEF], c[SP_NCOEF], mono[SP_NCOEF] = {};
+        for (int j = 0; j < n; ++j) {
+            const long double t = cosl(PI * (2 * j + 1) / (2 * n));
+            f[j] = log2l(1 + exp2l(-(a0 + h / 2 + h / 2 * t)));
+        }
+        for (int k = 0; k < n; ++k) {
+            long double s = 0;
+            for (int j = 0; j < n; ++j) s += f[j] * cosl(k * PI * (2 * j + 1) / (2 * n));
+            c[k] = 2 * s / n;
+        }
+        c[0] /= 2;
+        for (int k = 0; k < n; ++k)
+            for (int q = 0; q < n; ++q) mono[q] += c[k] * T[k][q];
+        long double sc = 1;
+        for (int q = 0; q < n; ++q) {
+            tab[(size_t)i * n + q] = (double)(mono[q] * sc);
+            sc *= 2;
+        }
+    }
+    double maxerr = 0;
+    for (int i = 0; i < NI; ++i)
+        for (int s = 0; s <= 32; ++s) {
+            double a = (i + s / 32.0) / per;
+            int idx = std::min((int)(a * per), NI - 1);
+            const double tau = (a * per - idx) - 0.5;
+            const double* c = &tab[(size_t)idx * n];
+            double p = c[n - 1];
+            for (int q = n - 2; q >= 0; --q) p = std::fma(p, tau, c[q]);
+            const long double truth = log2l(1 + exp2l(-(long double)a));
+            maxerr = std::max(maxerr, std::fabs((double)(p - truth)));
+        }
+    return maxerr;
+}
+
 struct vag_ctx {
     int device = 0;
+    DevBuf d_sptab;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
     // inputs
     DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
     // grid results
-    DevBuf d_meta, d_phi, d_theta, d_rep_of, d_rep_start, d_tdec;
+    DevBuf d_meta, d_phi, d_theta, d_rep_of, d_rep_start, d_tdec, d_geo_th, d_geo_ph;
     HostBuf h_meta, h_off;
     // compact per-row / per-cell storage
     DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
@@ -249,6 +298,13 @@ int vag_ctx_create(int device, vag_ctx** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_series_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+        std::vector<double> tab;
+        const double err = build_softplus_table(tab);
+        if (!(err < 1e-15)) return set_err(VAG_E_HIP, "softplus table accuracy check failed: %.3e", err);
+        if (c->d_sptab.ensure(sizeof(double) * tab.size())) return VAG_E_HIP;
+        HIPCHK(hipMemcpy(c->d_sptab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    }
     *out = c;
     return VAG_OK;
 }
@@ -257,8 +313,8 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
-                      &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_row_off,
+    for (DevBuf* b : {&c->d_sptab, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
         b->release();
@@ -308,6 +364,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_phi.ensure(sizeof(double) * (size_t)nb * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_theta.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_geo_th.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_rep_of.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_rep_start.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->h_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
@@ -318,7 +376,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     HIPCHK(hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                        c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
-                       c->d_rep_start.as<int>(), c->d_tdec.as<double>());
+                       c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], st));
     // grid shapes decide the compact layout and the launch geometry of everything downstream
@@ -407,15 +465,16 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3) * ks + (size_t)ks * nnu + nt + nnu) + sizeof(int) * nt;
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + nt + nnu + SP_TABLE_DOUBLES) +
+                       sizeof(int) * nt;
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     FluxArgs a;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
-    a.g_phi = c->d_phi.as<double>();
-    a.g_theta = c->d_theta.as<double>();
+    a.geo_th = c->d_geo_th.as<double>();
+    a.geo_ph = c->d_geo_ph.as<double>();
     a.g_rep_of = c->d_rep_of.as<int>();
-    a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    a.cell_off = c->d_cell_off.as<long long>();
     a.cellpar = c->d_cellpar.as<double>();
     a.lg2_t_obs = d_lg2t;
     a.lg2_nu_obs = d_lg2nu;
@@ -425,6 +484,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.max_blocks = max_blocks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
+    a.sp_table = c->d_sptab.as<double>();
     c->plan.spec_evals += c->eat_cells * nnu;
     c->plan.interps += c->total_pairs * (long long)nt * nnu;
     c->plan.flux_blocks = max_blocks * nb;
@@ -470,12 +530,12 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * (size_t)(VAG_NPAR + 3) * ks;
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3) * ks + SP_TABLE_DOUBLES);
     SeriesArgs a;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
-    a.g_phi = c->d_phi.as<double>();
-    a.g_theta = c->d_theta.as<double>();
+    a.geo_th = c->d_geo_th.as<double>();
+    a.geo_ph = c->d_geo_ph.as<double>();
     a.g_rep_of = c->d_rep_of.as<int>();
     a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
     a.cellpar = c->d_cellpar.as<double>();
@@ -486,6 +546,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.max_blocks = max_blocks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
+    a.sp_table = c->d_sptab.as<double>();
     c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
     c->plan.interps = c->total_pairs * (long long)n;
     c->plan.flux_blocks = max_blocks * nb;

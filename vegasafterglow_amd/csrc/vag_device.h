@@ -604,4 +604,71 @@ VAG_DEV double log2_I_nu(const PtrT c, int st, const SpecConst& sc, double lg2_n
     return spec - c[VP_INV_NUMAX * st] * exp2(lg2_nu);
 }
 
+// ---- fast FP64 kernels for the hot evaluator (accuracy verified at context creation / in tests) ----
+// g(a) = log2(1 + 2^-a) on [0, 20]: 160 intervals of width 1/8, degree-7 Chebyshev-node interpolants
+// (max abs error 1.1e-16); table built on the host in extended precision (vag_capi.hip: build_softplus_table).
+constexpr int SP_PER_UNIT = 8;
+constexpr int SP_INTERVALS = 20 * SP_PER_UNIT;
+constexpr int SP_NCOEF = 8;
+constexpr int SP_TABLE_DOUBLES = SP_INTERVALS * SP_NCOEF;
+
+// log2_softplus (src/util/fast-math.h:179-185) = max(z,0) + g(|z|) with the reference's +-20 shortcuts
+VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
+    const double a = fabs(z);
+    if (a > 20.0) return z > 0 ? z : 0.0;
+    int idx = (int)(a * (double)SP_PER_UNIT);
+    idx = idx > SP_INTERVALS - 1 ? SP_INTERVALS - 1 : idx;
+    const double tau = (a * (double)SP_PER_UNIT - (double)idx) - 0.5;
+    const double* c = tab + idx * SP_NCOEF;
+    double p = c[7];
+    p = fma(p, tau, c[6]);
+    p = fma(p, tau, c[5]);
+    p = fma(p, tau, c[4]);
+    p = fma(p, tau, c[3]);
+    p = fma(p, tau, c[2]);
+    p = fma(p, tau, c[1]);
+    p = fma(p, tau, c[0]);
+    return fmax(z, 0.0) + p;
+}
+
+// 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
+// 3.3e-16) + ldexp.  Large |x| saturate through v_ldexp_f64 (0 / inf) exactly like exp2.
+VAG_DEV double exp2_fast(double x) {
+    const double n = rint(x);
+    const double f = x - n;
+    double p = 2.5678435993488206e-11;
+    p = fma(p, f, 4.4455382718708116e-10);
+    p = fma(p, f, 7.054911620801123e-09);
+    p = fma(p, f, 1.01780860092397e-07);
+    p = fma(p, f, 1.321548679014431e-06);
+    p = fma(p, f, 1.5252733804059841e-05);
+    p = fma(p, f, 0.0001540353039338161);
+    p = fma(p, f, 0.0013333558146428443);
+    p = fma(p, f, 0.009618129107628477);
+    p = fma(p, f, 0.05550410866482158);
+    p = fma(p, f, 0.24022650695910072);
+    p = fma(p, f, 0.6931471805599453);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// compute_log2_I_nu (smooth-power-law-syn.cpp:15-46,80-92,159-167) on the fast kernels above.
+template <class PtrT>
+VAG_DEV double log2_I_nu_fast(const PtrT c, int st, const SpecConst& sc, double lg2_nu, const double* __restrict__ sp) {
+    const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
+    const double thin = (lg2_nu - l_lo) / 3.0 - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
+                        sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];
+    const double lx = lg2_nu - c[VP_LG2_NUM * st];
+    double thick = 2.5 * lx;
+    if (!(lx > sc.log2_x_far)) {
+        const double s = -sc.smooth_thick * exp2_fast(2. / 3 * lx);
+        thick += sp_fast(-0.5 * lx + s, sp);
+    }
+    const double lb = thick + c[VP_TNORM * st];
+    const double smooth_one = thin - sp_fast(c[VP_SAB * st] * (thin - lb), sp) * c[VP_INV_SAB * st];
+    const double spec = c[VP_LG2_I * st] + (c[VP_NORM * st] + smooth_one);
+    if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
+    return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
+}
+
 }  // namespace vag

@@ -107,7 +107,9 @@ VAG_DEV void invert_cdf(const GridShared& sh, int num, bool midpoint, double* ou
 __global__ void __launch_bounds__(WAVE)
 vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* __restrict__ meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
-                int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec) {
+                int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
+                double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
+                double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */) {
     const int m = blockIdx.x;
     if (m >= nb) return;
     const int lane = threadIdx.x;
@@ -481,6 +483,38 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     for (int j = lane; j < n_theta; j += WAVE) {
         g_theta[(size_t)m * VAG_MAX_THETA + j] = sh.theta[j];
         g_tdec[(size_t)m * VAG_MAX_THETA + j] = sh.tdec[j];
+    }
+    // Geometry factors of the equal-arrival-time step that depend on the angular grid only
+    // (calc_eat_non_spreading + compute_dphi, src/core/observer.cpp:17-37,143-188): computed once per model
+    // here instead of once per (theta, phi) row in the flux kernel.
+    {
+        double* gth = g_geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+        double* gph = g_geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+        const int last = n_theta - 1;
+        for (int j = lane; j < n_theta; j += WAVE) {
+            const double th = sh.theta[j];
+            const double ct = cos(th);
+            const double cos_lo = (j == 0) ? ct : cos(0.5 * (sh.theta[j - 1] + th));
+            const double cos_hi = (j == last) ? ct : cos(0.5 * (th + sh.theta[j + 1]));
+            gth[j] = ct;
+            gth[VAG_MAX_THETA + j] = sin(th);
+            gth[2 * VAG_MAX_THETA + j] = log2(fabs(cos_hi - cos_lo));
+        }
+        const int npe = M.n_phi_eff;
+        for (int i = lane; i < npe; i += WAVE) {
+            double dphi;
+            if (npe == 1) {
+                dphi = 2 * C_PI;
+            } else if (phi_mirrored) {
+                const double left = (i > 0) ? 0.5 * (sh.phi[i - 1] + sh.phi[i]) : 0.0;
+                const double right = (i < npe - 1) ? 0.5 * (sh.phi[i] + sh.phi[i + 1]) : C_PI;
+                dphi = 2 * (right - left);
+            } else {
+                dphi = 0.5 * (sh.phi[min(i + 1, npe - 1)] - sh.phi[i > 0 ? i - 1 : 0]);
+            }
+            gph[i] = cos(sh.phi[i]);
+            gph[VAG_MAX_PHI + i] = log2(fabs(dphi));
+        }
     }
     if (lane == 0) meta[m] = M;
 }

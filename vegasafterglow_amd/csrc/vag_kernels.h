@@ -194,72 +194,88 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
 // workgroup writes one partial grid, reduced deterministically by vag_reduce_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int FLUX_THREADS = 256;
-constexpr int FLUX_MAX_SLOTS = 16;  // (idx, l) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
+constexpr int FLUX_MAX_SLOTS = 16;  // (l, idx) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
 
 struct FluxArgs {
     const vag_model_params* params;
     const VagGridMeta* meta;
-    const double* g_phi;
-    const double* g_theta;
+    const double* geo_th;  // [nb][3][VAG_MAX_THETA]
+    const double* geo_ph;  // [nb][2][VAG_MAX_PHI]
     const int* g_rep_of;
-    Layout lay;
+    const long long* cell_off;
     const double* cellpar;
     const double* lg2_t_obs;  // [nt]   log2(t * unit::sec)
     const double* lg2_nu_obs; // [nnu]  log2(nu * unit::Hz)
+    const double* sp_table;   // [SP_TABLE_DOUBLES] softplus interpolant (vag_device.h: sp_fast)
+    double* partial;          // [nb][max_blocks][nnu*nt]
     int nt, nnu;
     int pairs_per_block;
     int max_blocks;  // blocks per model (gridDim.x)
     int k_stride;    // LDS row stride (>= max n_t in the batch)
-    double* partial; // [nb][max_blocks][nnu*nt]
 };
 
-__global__ void __launch_bounds__(FLUX_THREADS)
+// EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
+// (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.
+VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads, double cos_v,
+                     double t_coeff, double one_plus_z, double lg2_dOmega, double* __restrict__ s_t,
+                     double* __restrict__ s_dop, double* __restrict__ s_geom) {
+    for (int k = tid; k < K; k += nthreads) {
+        const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+        const double lg2_dop = -log2(G - u * cos_v);
+        const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
+        s_dop[k] = lg2_dop;
+        s_t[k] = log2(time);
+        s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+    }
+}
+
+__global__ void __launch_bounds__(FLUX_THREADS, 2)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
-    const VagGridMeta M = a.meta[m];
-    const int slots = a.nt * a.nnu;
-    double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
-    if (M.status != 0) return;
-    const int n_pairs = M.n_theta * M.n_phi_eff;
+    const VagGridMeta* Mp = a.meta + m;
+    if (Mp->status != 0) return;
+    const int n_phi_eff = Mp->n_phi_eff;
+    const int n_pairs = Mp->n_theta * n_phi_eff;
     const int p0 = blockIdx.x * a.pairs_per_block;
     if (p0 >= n_pairs) return;
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int tid = threadIdx.x;
-    const int K = M.n_t, KS = a.k_stride;
+    const int K = Mp->n_t, KS = a.k_stride;
+    const int nt = a.nt, nnu = a.nnu;
+    const int slots = nt * nnu;
 
     extern __shared__ double lds[];
-    double* s_par = lds;                       // [VAG_NPAR][KS]
-    double* s_t = s_par + VAG_NPAR * KS;       // [KS] lg2 t_obs of the row
-    double* s_dop = s_t + KS;                  // [KS]
-    double* s_geom = s_dop + KS;               // [KS]
-    double* s_B = s_geom + KS;                 // [KS][nnu]
-    double* s_tobs = s_B + (size_t)KS * a.nnu; // [nt]
-    double* s_nu = s_tobs + a.nt;              // [nnu]
-    int* s_kidx = (int*)(s_nu + a.nnu);        // [nt]
+    double* s_par = lds;                     // [VAG_NPAR][KS] photon/shock parameters of the staged row
+    double* s_t = s_par + VAG_NPAR * KS;     // [KS] log2 observer time of the row's lattice nodes
+    double* s_dop = s_t + KS;                // [KS] log2 Doppler factor
+    double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
+    double* s_idt = s_geom + KS;             // [KS] 1 / (t[k+1] - t[k])
+    double* s_B = s_idt + KS;                // [nnu][KS] boundary log2-luminosities (frequency-major)
+    double* s_tobs = s_B + (size_t)KS * nnu; // [nt]
+    double* s_nu = s_tobs + nt;              // [nnu]
+    double* s_sp = s_nu + nnu;               // [SP_TABLE_DOUBLES]
+    int* s_kidx = (int*)(s_sp + SP_TABLE_DOUBLES);  // [nt]
 
-    const vag_model_params P = a.params[m];
-    const double one_plus_z = 1 + P.z;
-    const double lg2_1pz = log2(one_plus_z);
-    for (int i = tid; i < a.nt; i += FLUX_THREADS) s_tobs[i] = a.lg2_t_obs[i];
-    for (int l = tid; l < a.nnu; l += FLUX_THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
+    const vag_model_params* Pp = a.params + m;
+    const double one_plus_z = 1 + Pp->z;
+    {
+        const double lg2_1pz = log2(one_plus_z);
+        for (int i = tid; i < nt; i += FLUX_THREADS) s_tobs[i] = a.lg2_t_obs[i];
+        for (int l = tid; l < nnu; l += FLUX_THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
+        for (int i = tid; i < SP_TABLE_DOUBLES; i += FLUX_THREADS) s_sp[i] = a.sp_table[i];
+    }
     SpecConst sc;
-    sc.init(P.p);
-    const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
-    const double* phi = a.g_phi + (size_t)m * VAG_MAX_PHI;
-    const double* theta = a.g_theta + (size_t)m * VAG_MAX_THETA;
+    sc.init(Pp->p);
+    const double cos_obs = cos(Pp->theta_obs), sin_obs = sin(Pp->theta_obs);
+    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
-    const int n_phi_eff = M.n_phi_eff;
-    const int last_j = M.n_theta - 1;
+    const double* cell_base = a.cellpar + a.cell_off[m] * VAG_NPAR;
+    const float inv_nt = 1.0f / (float)nt;
 
     double acc[FLUX_MAX_SLOTS];
-    short slot_idx[FLUX_MAX_SLOTS], slot_l[FLUX_MAX_SLOTS];
 #pragma unroll
-    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
-        acc[q] = 0;
-        const int slot = tid + q * FLUX_THREADS;
-        slot_idx[q] = (short)(slot / a.nnu);
-        slot_l[q] = (short)(slot - (slot / a.nnu) * a.nnu);
-    }
+    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) acc[q] = 0;
 
     int staged_rep = -1;
     for (int pair = p0; pair < p1; ++pair) {
@@ -267,50 +283,24 @@ vag_flux_grid_kernel(FluxArgs a) {
         const int rep = rep_of[j];
         __syncthreads();  // previous pair's phase B done before LDS is overwritten
         if (rep != staged_rep) {
-            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
-            for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {
-                const int par = q / K, k = q - par * K;
-                s_par[par * KS + k] = src[q];
-            }
+            const double* src = cell_base + (size_t)rep * K * VAG_NPAR;
+            for (int par = 0; par < VAG_NPAR; ++par)
+                for (int k = tid; k < K; k += FLUX_THREADS) s_par[par * KS + k] = src[par * K + k];
             staged_rep = rep;
             __syncthreads();
         }
-        // ---- A0: EAT quantities of row (i, j): calc_eat_non_spreading + finalize_log_grids ----
+        // ---- A0 ----
         {
-            const double th_j = theta[j];
-            const double ct = cos(th_j), st = sin(th_j);
-            const double cos_phi = cos(phi[i]);
-            const double cos_v = st * cos_phi * sin_obs + ct * cos_obs;
+            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-            // solid angle: midpoint theta bins x dphi (compute_dphi, observer.cpp:17-37)
-            const double cos_lo = (j == 0) ? ct : cos(0.5 * (theta[j - 1] + th_j));
-            const double cos_hi = (j == last_j) ? ct : cos(0.5 * (th_j + theta[j + 1]));
-            double dphi;
-            if (n_phi_eff == 1) {
-                dphi = 2 * C_PI;
-            } else if (M.phi_mirrored) {
-                const double left = (i > 0) ? 0.5 * (phi[i - 1] + phi[i]) : 0.0;
-                const double right = (i < n_phi_eff - 1) ? 0.5 * (phi[i] + phi[i + 1]) : C_PI;
-                dphi = 2 * (right - left);
-            } else {
-                const int lastp = n_phi_eff - 1;
-                dphi = 0.5 * (phi[min(i + 1, lastp)] - phi[i > 0 ? i - 1 : 0]);
-            }
-            const double lg2_dOmega = log2(fabs((cos_hi - cos_lo) * dphi));
-            for (int k = tid; k < K; k += FLUX_THREADS) {
-                const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
-                const double lg2_dop = -log2(G - u * cos_v);
-                const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
-                s_dop[k] = lg2_dop;
-                s_t[k] = log2(time);
-                s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
-            }
+            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+            eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
         }
         __syncthreads();
-        // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,405-433)
-        //      and the observation window [k_lo, k_hi] (observed_window, observer.h:324-338) ----
+        // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,
+        //      405-433), interval reciprocals, and the observation window (observed_window, observer.h:324-338)
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
-        for (int idx = tid; idx < a.nt; idx += FLUX_THREADS) {
+        for (int idx = tid; idx < nt; idx += FLUX_THREADS) {
             const double tq = s_tobs[idx];
             int kk = -1;
             if (tq >= row_t0 && tq < row_tN) {
@@ -326,11 +316,11 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
             s_kidx[idx] = kk;
         }
+        for (int k = tid; k < K - 1; k += FLUX_THREADS) s_idt[k] = 1.0 / (s_t[k + 1] - s_t[k]);
         int k_lo, k_hi;
         {
-            const double w_lo = s_tobs[0], w_hi = s_tobs[a.nt - 1];
+            const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
             if (row_tN < w_lo || row_t0 > w_hi) continue;  // row entirely outside the window (block-uniform)
-            // k_lo = (first node >= w_lo) - 1, floored at 0; that node exists because row_tN >= w_lo
             int lo = -1, hi = K - 1;  // invariant: s_t[lo] < w_lo <= s_t[hi]
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -340,9 +330,8 @@ vag_flux_grid_kernel(FluxArgs a) {
                     hi = mid;
             }
             k_lo = hi > 0 ? hi - 1 : 0;
-            // k_hi = first node > w_hi at or after k_lo + 1, capped at K - 1
             lo = k_lo;
-            hi = K - 1;  // invariant: nodes <= lo are not candidates, hi is a valid answer
+            hi = K - 1;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (s_t[mid] <= w_hi)
@@ -352,14 +341,17 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
             k_hi = hi;
         }
-        // ---- A1: boundary values B[k][l] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window ----
+        // ---- A1: boundary values B[l][k] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window.
+        //      Lanes run over k fastest: one wavefront = one frequency x 64 neighbouring cells, so the +-20
+        //      softplus shortcuts, the optically-thick cut and the nu_M cut-off branch coherently.
         {
             const int nk = k_hi - k_lo + 1;
-            const int total = nk * a.nnu;
+            const int total = nk * nnu;
+            const float inv_nk = 1.0f / (float)nk;
             for (int q = tid; q < total; q += FLUX_THREADS) {
-                const int kq = q / a.nnu, l = q - kq * a.nnu;
-                const int k = k_lo + kq;
-                s_B[k * a.nnu + l] = log2_I_nu(s_par + k, KS, sc, s_nu[l] - s_dop[k]) + s_geom[k];
+                const int l = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
+                const int k = k_lo + (q - l * nk);
+                s_B[l * KS + k] = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l] - s_dop[k], s_sp) + s_geom[k];
             }
         }
         __syncthreads();
@@ -368,25 +360,23 @@ vag_flux_grid_kernel(FluxArgs a) {
         for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
             const int slot = tid + q * FLUX_THREADS;
             if (slot < slots) {
-                const int idx = slot_idx[q], l = slot_l[q];
+                const int l = (int)(((float)slot + 0.5f) * inv_nt);
+                const int idx = slot - l * nt;
                 const int k = s_kidx[idx];
                 if (k >= 0) {
-                    const double lo = s_B[k * a.nnu + l], hi = s_B[(k + 1) * a.nnu + l];
-                    const double inv = 1.0 / (s_t[k + 1] - s_t[k]);
-                    const double sl = (hi - lo) * inv;
-                    if (isfinite(sl)) acc[q] += exp2(lo + (s_tobs[idx] - s_t[k]) * sl);
+                    const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
+                    const double sl = (hi - lo) * s_idt[k];
+                    if (isfinite(sl)) acc[q] += exp2_fast(lo + (s_tobs[idx] - s_t[k]) * sl);
                 }
             }
         }
     }
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
+    double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
 #pragma unroll
     for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
         const int slot = tid + q * FLUX_THREADS;
-        if (slot < slots) {
-            const int idx = slot_idx[q], l = slot_l[q];
-            my_partial[(size_t)l * a.nt + idx] = acc[q];
-        }
+        if (slot < slots) my_partial[slot] = acc[q];
     }
 }
 
@@ -436,8 +426,8 @@ constexpr int SERIES_MAX_SLOTS = 8;  // data points per lane: n <= 512
 struct SeriesArgs {
     const vag_model_params* params;
     const VagGridMeta* meta;
-    const double* g_phi;
-    const double* g_theta;
+    const double* geo_th;
+    const double* geo_ph;
     const int* g_rep_of;
     Layout lay;
     const double* cellpar;
@@ -446,6 +436,7 @@ struct SeriesArgs {
     int n;
     int pairs_per_block, max_blocks, k_stride;
     double* partial; // [nb][max_blocks][n]
+    const double* sp_table;
 };
 
 __global__ void __launch_bounds__(SERIES_THREADS)
@@ -465,6 +456,8 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
+    double* s_sp = s_geom + KS;
+    for (int i = tid; i < SP_TABLE_DOUBLES; i += SERIES_THREADS) s_sp[i] = a.sp_table[i];
 
     const vag_model_params P = a.params[m];
     const double one_plus_z = 1 + P.z;
@@ -472,11 +465,10 @@ vag_flux_series_kernel(SeriesArgs a) {
     SpecConst sc;
     sc.init(P.p);
     const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
-    const double* phi = a.g_phi + (size_t)m * VAG_MAX_PHI;
-    const double* theta = a.g_theta + (size_t)m * VAG_MAX_THETA;
+    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const int n_phi_eff = M.n_phi_eff;
-    const int last_j = M.n_theta - 1;
 
     double acc[SERIES_MAX_SLOTS], tq[SERIES_MAX_SLOTS], nuq[SERIES_MAX_SLOTS];
 #pragma unroll
@@ -501,33 +493,10 @@ vag_flux_series_kernel(SeriesArgs a) {
             __syncthreads();
         }
         {
-            const double th_j = theta[j];
-            const double ct = cos(th_j), st = sin(th_j);
-            const double cos_phi = cos(phi[i]);
-            const double cos_v = st * cos_phi * sin_obs + ct * cos_obs;
+            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-            const double cos_lo = (j == 0) ? ct : cos(0.5 * (theta[j - 1] + th_j));
-            const double cos_hi = (j == last_j) ? ct : cos(0.5 * (th_j + theta[j + 1]));
-            double dphi;
-            if (n_phi_eff == 1) {
-                dphi = 2 * C_PI;
-            } else if (M.phi_mirrored) {
-                const double left = (i > 0) ? 0.5 * (phi[i - 1] + phi[i]) : 0.0;
-                const double right = (i < n_phi_eff - 1) ? 0.5 * (phi[i] + phi[i + 1]) : C_PI;
-                dphi = 2 * (right - left);
-            } else {
-                const int lastp = n_phi_eff - 1;
-                dphi = 0.5 * (phi[min(i + 1, lastp)] - phi[i > 0 ? i - 1 : 0]);
-            }
-            const double lg2_dOmega = log2(fabs((cos_hi - cos_lo) * dphi));
-            for (int k = tid; k < K; k += SERIES_THREADS) {
-                const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
-                const double lg2_dop = -log2(G - u * cos_v);
-                const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
-                s_dop[k] = lg2_dop;
-                s_t[k] = log2(time);
-                s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
-            }
+            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+            eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
         }
         __syncthreads();
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
@@ -547,10 +516,10 @@ vag_flux_series_kernel(SeriesArgs a) {
                             hi = mid;
                     }
                     const int k = lo;
-                    const double blo = log2_I_nu(s_par + k, KS, sc, nuq[q] - s_dop[k]) + s_geom[k];
-                    const double bhi = log2_I_nu(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1]) + s_geom[k + 1];
+                    const double blo = log2_I_nu_fast(s_par + k, KS, sc, nuq[q] - s_dop[k], s_sp) + s_geom[k];
+                    const double bhi = log2_I_nu_fast(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp) + s_geom[k + 1];
                     const double sl = (bhi - blo) * (1.0 / (s_t[k + 1] - s_t[k]));
-                    if (isfinite(sl)) acc[q] += exp2(blo + (t - s_t[k]) * sl);
+                    if (isfinite(sl)) acc[q] += exp2_fast(blo + (t - s_t[k]) * sl);
                 }
             }
         }
