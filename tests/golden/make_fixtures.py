@@ -1,0 +1,58 @@
+"""Generate golden vectors from the REAL reference (oracle/_ref/libvag_ref.so, the reference's own C++ sources
+compiled in place with the reference's flags) for the BASELINE configs.  Run in the dev container only
+(needs /root/reference); the resulting small .npz files are committed and travel to the GPU box.
+
+    python tests/golden/make_fixtures.py
+
+The three *_ism.npz files next to this script are the reference's own golden baselines
+(tests/python/golden/*.npz of the reference tree: data files held by its test-suite), copied verbatim.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _abi  # noqa: E402
+import configs  # noqa: E402
+
+
+def main():
+    ref = _abi.load_ref()
+    if ref is None:
+        raise SystemExit("oracle/_ref/libvag_ref.so missing: run `make -C oracle ref` in the dev container")
+    out = {}
+    meta = {}
+    cases = {"C1a": (configs.C1A, configs.C1_T, configs.C1_NU), "C1b": (configs.C1B, configs.C1_T, configs.C1_NU),
+             "C2": (configs.C2, configs.C2_T, configs.C2_NU)}
+    cases.update(configs.EXTRA)
+    for name, (kw, t, nu) in cases.items():
+        prm = _abi.make_params(**kw)
+        out[f"{name}__t"] = t
+        out[f"{name}__nu"] = nu
+        out[f"{name}__grid"] = ref.flux_density_grid(prm, t, nu)
+        meta[name] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+    # C4: series + band + grid shape for the truth model
+    prm = _abi.make_params(**configs.C4_TRUTH)
+    t, nu = configs.c4_mock_data()
+    out["C4__t"], out["C4__nu"] = t, nu
+    out["C4__series"] = ref.flux_density(prm, t, nu)
+    out["C4__band_t"] = configs.C4_EPOCHS
+    out["C4__band"] = ref.flux(prm, configs.C4_EPOCHS, 1e14, 1e15, 16)
+    meta["C4"] = {k: v for k, v in configs.C4_TRUTH.items()}
+    # grid shapes + stage intermediates (Model.details) for two configs
+    for name, kw, tmin, tmax in (("C1b", configs.C1B, 1e2, 1e8), ("C4", configs.C4_TRUTH, t.min(), t.max())):
+        d = ref.details(_abi.make_params(**kw), tmin, tmax)
+        meta[name + "__shape"] = d["shape"]
+        for k in ("phi", "theta", "t_src", "Gamma", "r", "B", "N_p", "Gamma_th", "nu_m", "nu_c", "nu_a", "I_nu_max"):
+            out[f"{name}__details_{k}"] = np.asarray(d[k])
+    out["meta"] = json.dumps(meta)
+    path = os.path.join(HERE, "reference_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares
+(no compute without a GPU), struct layouts agree between C and ctypes, the host-side mirror validates like the
+reference's pybind layer, and the product never falls back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _abi
+import vegasafterglow_amd as va
+from vegasafterglow_amd import _lib, fitting
+
+HEADER = os.path.join(_abi.ROOT, "include", "vegasafterglow_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vag_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
+    assert set(_lib.EXPORTS) <= set(names)
+    assert lib.vag_abi_version() == 1
+    assert b"gfx950" in lib.vag_version()
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_lib.ModelParams) == 200 == C.sizeof(_abi.ModelParams)
+    assert _lib.ModelParams.theta_c.offset == 8 and _lib.ModelParams.rtol.offset == 184
+    # VAG_P_* slots index the doubles that follow the two int32 tags
+    names = [n for n, t in _lib.ModelParams._fields_ if t is C.c_double]
+    for key, slot in _lib.PARAM_SLOTS.items():
+        field = {"tau": "duration", "theta_v": "theta_obs"}.get(key, key)
+        assert names[slot] == field
+    assert C.sizeof(_lib.FitSpec) == 200 + 4 + 64 + 64 + 8 + 5 * 8 + 4  # base, ndim, slot, is_log, n_data+pad, 5 ptrs (+align)
+
+
+def test_defaults_and_validation_through_the_c_abi(lib):
+    p = _lib.ModelParams()
+    lib.vag_params_default(C.byref(p))
+    assert (p.phi_resol, p.theta_resol, p.t_resol, p.rtol) == (0.06, 0.15, 6.0, 1e-6)  # simulation-defaults.h:58-68
+    assert p.xi_e == 1.0 and p.radiative_fireball == 1 and p.n0 == float("inf")
+    assert lib.vag_params_validate(C.byref(p)) == 0
+    p.eps_e = 1.5
+    assert lib.vag_params_validate(C.byref(p)) == _lib.VAG_E_INVALID
+    assert b"eps_e" in lib.vag_last_error()
+
+
+def test_no_cpu_fallback_without_a_device(lib):
+    if lib.vag_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    assert lib.vag_ctx_create(0, C.byref(h)) == _lib.VAG_E_NO_DEVICE
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.flux_density_grid(np.logspace(3, 5, 4), np.array([1e9]))
+
+
+def test_product_package_never_references_the_oracle():
+    pkg = os.path.join(_abi.ROOT, "vegasafterglow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+# ---- host-side mirror of the pybind objects (pybind/pybind.cpp:205-223,347-377,384-422) ----
+def test_constructor_validation_matches_reference_error_types():
+    with pytest.raises(ValueError):
+        va.TophatJet(0.0, 1e52, 300)
+    with pytest.raises(ValueError):
+        va.TophatJet(0.1, 1e52, 1.0)
+    with pytest.raises(ValueError):
+        va.TwoComponentJet(0.1, 1e52, 300, 0.05, 1e50, 50)  # theta_w <= theta_c
+    with pytest.raises(ValueError):
+        va.ISM(-1.0)
+    with pytest.raises(ValueError):
+        va.Wind(0.0)
+    with pytest.raises(ValueError):
+        va.Observer(1e28, -0.1, 0.0)
+    with pytest.raises(ValueError):
+        va.Observer(1e28, 0.0, 4.0)
+    with pytest.raises(ValueError):
+        va.Radiation(0.1, 0.01, 1.0)
+    with pytest.raises(ValueError):
+        va.Radiation(0.0, 0.01, 2.3)
+    obs, rad = va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.3)
+    with pytest.raises(TypeError):
+        va.Model("tophat", va.ISM(1.0), obs, rad)
+    with pytest.raises(TypeError):
+        va.Model(va.TophatJet(0.1, 1e52, 300), "ism", obs, rad)
+    with pytest.raises(ValueError):
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rtol=1.0)
+    with pytest.raises(ValueError):
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, resolutions=(0.0, 0.15, 6))
+    with pytest.raises(NotImplementedError):  # out-of-scope tiers fail loudly instead of silently degrading
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3, ssc=True))
+
+
+def test_model_flattens_to_the_same_struct_as_the_test_helper():
+    m = va.Model(va.PowerLawJet(0.1, 1e52, 300, 2.0, 3.0), va.Wind(0.1, n_ism=1e-3), va.Observer(1e28, 1.0, 0.2),
+                 va.Radiation(0.1, 0.01, 2.3, xi_e=0.5), resolutions=(0.29, 0.16, 10.0), rtol=1e-5,
+                 radiative_fireball=False)
+    want = _abi.make_params(jet="PowerLawJet", medium="Wind", k_e=2.0, k_g=3.0, A_star=0.1, n_ism=1e-3, theta_obs=0.2,
+                            xi_e=0.5, resolutions=(0.29, 0.16, 10.0), rtol=1e-5, radiative_fireball=False,
+                            theta_w=np.pi / 2, E_iso_w=1e52, Gamma0_w=300.0)
+    assert bytes(m.params) == bytes(want)
+    assert m.resolutions == (0.29, 0.16, 10.0) and m.rtol == 1e-5 and m.axisymmetric and not m.radiative_fireball
+
+
+def test_argument_checks_of_flux_calls_happen_before_the_device():
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.3))
+    with pytest.raises(ValueError, match="non-empty"):
+        m.flux_density_grid([], [1e9])
+    with pytest.raises(ValueError, match="same size"):
+        m.flux_density([1e3, 1e4], [1e9])
+
+
+# ---- Fitter host logic (fitter.py:407-451, utils.py:110-135, samplers.py:72-91) ----
+def _fitter():
+    f = fitting.Fitter(z=0.0098, lumi_dist=1.23e26, jet="gaussian", medium="ism")
+    f.add_flux_density(3e9, [3e6, 1e6, 2e6], [1e-27, 2e-27, 3e-27], [1e-28, 2e-28, 3e-28], weights=[1, 2, 1])
+    f.add_flux_density(5e14, [1.5e6], [4e-29], [4e-30])
+    return f
+
+
+def test_consolidate_sorts_by_time_and_normalises_weights():
+    f = _fitter()
+    f._consolidate_data()
+    assert list(f._all_t) == [1e6, 1.5e6, 2e6, 3e6]
+    assert list(f._all_nu) == [3e9, 5e14, 3e9, 3e9]
+    np.testing.assert_allclose(f._all_weights.sum(), 4.0)
+    np.testing.assert_allclose(f._all_weights, np.array([2, 1, 1, 1]) * 4 / 5)
+    np.testing.assert_allclose(f._all_log_err, 0.1)
+    with pytest.raises(ValueError):
+        g = fitting.Fitter(z=0.1, lumi_dist=1e27)
+        g.add_flux_density(1e9, [1e5], [-1.0], [0.1])
+        g._consolidate_data()
+
+
+def test_spec_is_the_transformer_as_a_slot_map():
+    f = _fitter()
+    defs = [fitting.ParamDef("E_iso", 50, 54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8),
+            fitting.ParamDef("p", 2.05, 2.8), fitting.ParamDef("n_ism", 1e-2, 1e-2, fitting.Scale.fixed),
+            fitting.ParamDef("eps_B", 1e-3, 1e-3, fitting.Scale.fixed, initial=2e-3)]
+    spec, lo, hi = f.build_spec(defs)
+    assert spec.ndim == 3 and list(spec.slot[:3]) == [1, 14, 17] and list(spec.is_log[:3]) == [1, 0, 0]
+    assert spec.base.n_ism == 1e-2 and spec.base.eps_B == 2e-3 and spec.base.jet_type == _lib.JET_GAUSSIAN
+    assert spec.base.Gamma0 == 300.0 and spec.base.eps_e == 0.1  # ModelParams defaults, types.py:37-77
+    assert spec.base.lumi_dist == 1.23e26 and spec.base.z == 0.0098 and spec.n_data == 4
+    assert list(lo) == [50, 0.0, 2.05] and list(hi) == [54, 0.8, 2.8]
+
+
+def test_log_prob_batch_bounds_prior_and_nonfinite_handling():
+    f = _fitter()
+    defs = [fitting.ParamDef("E_iso", 50, 54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8)]
+    calls = []
+
+    def fake_loglike(s):
+        calls.append(s.copy())
+        out = -np.arange(len(s), dtype=float)
+        out[0] = np.nan
+        return out
+
+    lp = f.make_log_prob_batch(defs, loglike_fn=fake_loglike)
+    samples = np.array([[52.0, 0.1], [49.0, 0.1], [53.0, 0.2], [52.0, 0.9], [51.0, 0.3]])
+    got = lp(samples)
+    assert calls[0].shape == (3, 2)  # only in-bounds walkers are evaluated
+    ln_prior = -np.log(4.0) - np.log(0.8)
+    assert got[0] == -np.inf and got[1] == -np.inf and got[3] == -np.inf
+    np.testing.assert_allclose(got[[2, 4]], np.array([-1.0, -2.0]) + ln_prior)

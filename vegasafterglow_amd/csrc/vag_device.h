@@ -620,15 +620,13 @@ VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
     idx = idx > SP_INTERVALS - 1 ? SP_INTERVALS - 1 : idx;
     const double tau = (a * (double)SP_PER_UNIT - (double)idx) - 0.5;
     const double* c = tab + idx * SP_NCOEF;
-    double p = c[7];
-    p = fma(p, tau, c[6]);
-    p = fma(p, tau, c[5]);
-    p = fma(p, tau, c[4]);
-    p = fma(p, tau, c[3]);
-    p = fma(p, tau, c[2]);
-    p = fma(p, tau, c[1]);
-    p = fma(p, tau, c[0]);
-    return fmax(z, 0.0) + p;
+    // Estrin scheme: three dependent levels instead of seven
+    const double t2 = tau * tau, t4 = t2 * t2;
+    const double p01 = fma(c[1], tau, c[0]), p23 = fma(c[3], tau, c[2]);
+    const double p45 = fma(c[5], tau, c[4]), p67 = fma(c[7], tau, c[6]);
+    const double p03 = fma(p23, t2, p01), p47 = fma(p67, t2, p45);
+    const double p = fma(p47, t4, p03);
+    return 0.5 * (z + a) + p;  // max(z, 0) = (z + |z|) / 2, exact
 }
 
 // 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
@@ -636,19 +634,17 @@ VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
 VAG_DEV double exp2_fast(double x) {
     const double n = rint(x);
     const double f = x - n;
-    double p = 2.5678435993488206e-11;
-    p = fma(p, f, 4.4455382718708116e-10);
-    p = fma(p, f, 7.054911620801123e-09);
-    p = fma(p, f, 1.01780860092397e-07);
-    p = fma(p, f, 1.321548679014431e-06);
-    p = fma(p, f, 1.5252733804059841e-05);
-    p = fma(p, f, 0.0001540353039338161);
-    p = fma(p, f, 0.0013333558146428443);
-    p = fma(p, f, 0.009618129107628477);
-    p = fma(p, f, 0.05550410866482158);
-    p = fma(p, f, 0.24022650695910072);
-    p = fma(p, f, 0.6931471805599453);
-    p = fma(p, f, 1.0);
+    // Estrin scheme over 13 coefficients
+    const double f2 = f * f, f4 = f2 * f2, f8 = f4 * f4;
+    const double q01 = fma(0.6931471805599453, f, 1.0), q23 = fma(0.05550410866482158, f, 0.24022650695910072);
+    const double q45 = fma(0.0013333558146428443, f, 0.009618129107628477);
+    const double q67 = fma(1.5252733804059841e-05, f, 0.0001540353039338161);
+    const double q89 = fma(1.01780860092397e-07, f, 1.321548679014431e-06);
+    const double qab = fma(4.4455382718708116e-10, f, 7.054911620801123e-09);
+    const double q03 = fma(q23, f2, q01), q47 = fma(q67, f2, q45), q8b = fma(qab, f2, q89);
+    const double q07 = fma(q47, f4, q03);
+    const double q8c = fma(2.5678435993488206e-11, f4, q8b);
+    const double p = fma(q8c, f8, q07);
     return ldexp(p, (int)n);
 }
 
@@ -656,7 +652,7 @@ VAG_DEV double exp2_fast(double x) {
 template <class PtrT>
 VAG_DEV double log2_I_nu_fast(const PtrT c, int st, const SpecConst& sc, double lg2_nu, const double* __restrict__ sp) {
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
-    const double thin = (lg2_nu - l_lo) / 3.0 - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
+    const double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
                         sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];
     const double lx = lg2_nu - c[VP_LG2_NUM * st];
     double thick = 2.5 * lx;

@@ -193,8 +193,8 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
 // Each lane owns fixed (idx, l) output slots, so the (phi, theta) sum needs no cross-lane reduction; a
 // workgroup writes one partial grid, reduced deterministically by vag_reduce_kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int FLUX_THREADS = 256;
-constexpr int FLUX_MAX_SLOTS = 16;  // (l, idx) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
+constexpr int FLUX_THREADS = 512;
+constexpr int FLUX_MAX_SLOTS = 8;   // (l, idx) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
 
 struct FluxArgs {
     const vag_model_params* params;
@@ -229,7 +229,7 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
     }
 }
 
-__global__ void __launch_bounds__(FLUX_THREADS, 2)
+__global__ void __launch_bounds__(FLUX_THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
     const VagGridMeta* Mp = a.meta + m;
