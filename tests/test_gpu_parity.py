@@ -121,8 +121,14 @@ def test_series_band_and_model_api(eng, oracle):
     d = m.details(t.min(), t.max())
     od = oracle.details(prm, t.min(), t.max())
     assert {k: d["shape"][k] for k in d["shape"]} == {k: od["shape"][k] for k in d["shape"]}
-    for k in ("phi", "theta", "t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th"):
-        np.testing.assert_allclose(d[k], od[k], rtol=1e-8, err_msg=k)
+    # angular grid = quantiles of a CDF that both sides integrate adaptively to rtol = 1e-6 (same sensitivity);
+    # the time lattice follows theta through t_dec(theta)
+    for k in ("phi", "theta", "t_src"):
+        np.testing.assert_allclose(d[k], od[k], rtol=2e-6, err_msg=k)
+    # blast-wave state: both sides integrate to rtol = 1e-6 with an adaptive step sequence that last-bit
+    # differences (FMA contraction, libm vs OCML pow) can shift; agreement is bounded by the ODE tolerance
+    for k in ("Gamma", "r", "t_comv", "B", "N_p", "Gamma_th"):
+        np.testing.assert_allclose(d[k], od[k], rtol=2e-6, err_msg=k)
 
 
 def test_ragged_batch_equals_individual_calls(eng, oracle):
