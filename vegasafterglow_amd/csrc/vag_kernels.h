@@ -321,37 +321,39 @@ vag_flux_grid_kernel(FluxArgs a) {
         {
             const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
             if (row_tN < w_lo || row_t0 > w_hi) continue;  // row entirely outside the window (block-uniform)
-            int lo = -1, hi = K - 1;  // invariant: s_t[lo] < w_lo <= s_t[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_t[mid] < w_lo)
-                    lo = mid;
-                else
-                    hi = mid;
+            // sorted row => positions by counting, one ballot per 64 nodes (no dependent LDS chain):
+            //   n_lt = #{k : s_t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)   (observed_window: last k with t[k+1] < w_lo)
+            //   n_le = #{k : s_t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)  (first node > w_hi)
+            const int lane = tid & 63;
+            int n_lt = 0, n_le = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int kk = base + lane;
+                const double v = kk < K ? s_t[kk] : INFINITY;
+                n_lt += __popcll(__ballot(v < w_lo));
+                n_le += __popcll(__ballot(v <= w_hi));
             }
-            k_lo = hi > 0 ? hi - 1 : 0;
-            lo = k_lo;
-            hi = K - 1;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_t[mid] <= w_hi)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            k_hi = hi;
+            k_lo = n_lt > 0 ? n_lt - 1 : 0;
+            k_hi = min(max(n_le, k_lo + 1), K - 1);
         }
         // ---- A1: boundary values B[l][k] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window.
         //      Lanes run over k fastest: one wavefront = one frequency x 64 neighbouring cells, so the +-20
         //      softplus shortcuts, the optically-thick cut and the nu_M cut-off branch coherently.
         {
+            // work item = (cell k, pair of frequencies): the 13 spectrum constants of the cell are read from LDS once
+            // and the two independent evaluations interleave (ILP hides the table-lookup latency)
             const int nk = k_hi - k_lo + 1;
-            const int total = nk * nnu;
+            const int npair_nu = (nnu + 1) >> 1;
+            const int total = nk * npair_nu;
             const float inv_nk = 1.0f / (float)nk;
             for (int q = tid; q < total; q += FLUX_THREADS) {
-                const int l = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
-                const int k = k_lo + (q - l * nk);
-                s_B[l * KS + k] = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l] - s_dop[k], s_sp) + s_geom[k];
+                const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
+                const int k = k_lo + (q - lg * nk);
+                const int l0 = lg * 2, l1 = min(l0 + 1, nnu - 1);
+                const double dop = s_dop[k], geom = s_geom[k];
+                const double b0 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l0] - dop, s_sp);
+                const double b1 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l1] - dop, s_sp);
+                s_B[l0 * KS + k] = b0 + geom;
+                s_B[l1 * KS + k] = b1 + geom;
             }
         }
         __syncthreads();
