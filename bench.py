@@ -70,6 +70,70 @@ def cpu_baseline(arr, t, nu, budget_s=12.0):
             "sample": f"{n} models of the timed batch (C2: 200 t x 10 nu), single thread, {dt:.1f} s"}
 
 
+def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
+    """Secondary metric of BASELINE.json: MCMC walker-steps/s on the C4 problem: GW170817-like mock,
+    60 data points (3 bands x 20 epochs), 8 free parameters, default resolutions, 1024 walkers drawn uniformly
+    from the prior box, block-sharded over the ranks with one all-gather of ln L per step."""
+    import torch
+    import torch.distributed as dist
+    import configs
+    from vegasafterglow_amd import fitting
+    from vegasafterglow_amd.dist import shard_range
+    t, nu = configs.c4_mock_data()
+    kw = configs.C4_TRUTH
+    # mock data from the engine's own truth model (+5 % noise, 10 % errors), built through the C-ABI
+    truth = np.empty(t.size)
+    p = _lib.ModelParams()
+    lib.vag_params_default(C.byref(p))
+    p.jet_type = _lib.JET_GAUSSIAN
+    p.theta_c, p.E_iso, p.Gamma0, p.n_ism = kw["theta_c"], kw["E_iso"], kw["Gamma0"], kw["n_ism"]
+    p.lumi_dist, p.z, p.theta_obs, p.eps_e, p.eps_B, p.p = kw["lumi_dist"], kw["z"], kw["theta_obs"], kw["eps_e"], kw["eps_B"], kw["p"]
+    dp = C.POINTER(C.c_double)
+    _lib.check(lib.vag_flux_density_batch(h, C.byref(p), 1, t.ctypes.data_as(dp), nu.ctypes.data_as(dp), t.size,
+                                          truth.ctypes.data_as(dp)))
+    f_obs = truth * (1 + 0.05 * np.random.default_rng(42).standard_normal(t.size))
+    fit = fitting.Fitter(z=kw["z"], lumi_dist=kw["lumi_dist"], jet="gaussian", medium="ism")
+    for b in configs.C4_BANDS:
+        sel = nu == b
+        fit.add_flux_density(b, t[sel], f_obs[sel], 0.1 * f_obs[sel])
+    defs = [fitting.ParamDef(n, lo, hi, fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
+    spec, lo, hi = fit.build_spec(defs)
+    theta = lo + (hi - lo) * np.random.default_rng(0).random((nwalkers, len(defs)))
+    a, b = shard_range(nwalkers, rank, world)
+    per = (nwalkers + world - 1) // world
+    d_theta = torch.from_numpy(np.ascontiguousarray(theta[a:b])).to(dev)
+    d_ll = torch.full((per,), float("nan"), dtype=torch.float64, device=dev)
+    d_all = torch.empty((per * world,), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        _lib.check(lib.vag_loglike_batch_dev(h, C.byref(spec), d_theta.data_ptr(), b - a, spec.ndim, d_ll.data_ptr()))
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_ll)
+
+    step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dt = float(el.item())
+    st = _lib.StageTimes()
+    lib.vag_last_stage_times(h, C.byref(st))
+    finite = int(torch.isfinite(d_ll[: b - a]).sum().item())
+    return {"value": nwalkers * steps / dt, "unit": "walker-steps/s", "walkers": nwalkers, "steps": steps,
+            "ms_per_step": 1e3 * dt / steps, "scaling": "strong", "finite_on_rank0": finite, "walkers_on_rank0": b - a,
+            "rank0_stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "syn_cells": st.cells_ms,
+                               "series_flux": st.flux_ms, "reduce": st.reduce_ms}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="models per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-walkers", action="store_true", help="skip the secondary walker-steps/s measurement")
     args = ap.parse_args()
 
     import torch
@@ -149,6 +214,7 @@ def main():
     lib.vag_last_plan(h, C.byref(plan))
     if not bool(torch.isfinite(d_out).all()) or plan.n_models_ok != nb:
         raise SystemExit("bench produced non-finite fluxes or rejected models")
+    walkers = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world)
 
     if rank == 0:
         st = np.mean(np.array(flux_ms), axis=0)
@@ -180,6 +246,8 @@ def main():
             "plan": {"ode_rows": plan.n_rows, "cells": plan.n_cells, "theta_phi_rows": plan.total_pairs,
                      "flux_workgroups": plan.flux_blocks, "rows_per_workgroup": plan.pairs_per_block},
         }
+        if walkers is not None:
+            out["walker_steps"] = walkers
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, t_np, nu_np)
         print(json.dumps(out))
