@@ -459,13 +459,13 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
                   const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out) {
     hipStream_t st = c->stream;
     const int slots = nt * nnu;
-    if (slots > FLUX_THREADS * FLUX_MAX_SLOTS)
-        return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_THREADS * FLUX_MAX_SLOTS);
+    if (slots > FLUX_MAX_SLOTS)
+        return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_MAX_SLOTS);
     const int ppb = choose_pairs_per_block(c);
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + nt + nnu + SP_TABLE_DOUBLES) +
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + nt + nnu + SP_TABLE_DOUBLES + slots) +
                        sizeof(int) * nt;
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     FluxArgs a;
@@ -633,7 +633,7 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
     // chunk the time axis so each launch keeps its (idx, l) slots in registers
-    const int chunk = std::max(1, (FLUX_THREADS * FLUX_MAX_SLOTS) / nnu);
+    const int chunk = std::max(1, 4096 / nnu);  // keeps the LDS accumulator <= 32 KiB
     if (nt <= chunk) return run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, nullptr, d_out);
     // chunks write [nb][nnu][chunk] blocks; assemble into [nb][nnu][nt]
     DevBuf tmp;
@@ -716,8 +716,8 @@ int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const dou
     if (num_nu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d band frequencies", VAG_MAX_NU);
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
-    if ((long long)nt * num_nu > FLUX_THREADS * FLUX_MAX_SLOTS)
-        return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_THREADS * FLUX_MAX_SLOTS);
+    if ((long long)nt * num_nu > FLUX_MAX_SLOTS)
+        return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_MAX_SLOTS);
     // band grid and Boole weights are request metadata (src/core/quadrature.h:153-196, pymodel.cpp:398-399):
     // nu = xt::logspace(log10(nu_min Hz), log10(nu_max Hz), num_nu) in code units
     std::vector<double> nu_code(num_nu), nu_cgs(num_nu), w(num_nu, 0.0);

@@ -194,7 +194,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
 // workgroup writes one partial grid, reduced deterministically by vag_reduce_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int FLUX_THREADS = 512;
-constexpr int FLUX_MAX_SLOTS = 8;   // (l, idx) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
+constexpr int FLUX_MAX_SLOTS = 8192;  // (l, idx) output slots per launch, accumulated in LDS  // (l, idx) slots per lane: nt * nnu <= FLUX_THREADS * FLUX_MAX_SLOTS
 
 struct FluxArgs {
     const vag_model_params* params;
@@ -244,8 +244,9 @@ vag_flux_grid_kernel(FluxArgs a) {
     const int nt = a.nt, nnu = a.nnu;
     const int slots = nt * nnu;
 
-    extern __shared__ double lds[];
-    double* s_par = lds;                     // [VAG_NPAR][KS] photon/shock parameters of the staged row
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;                      // [SP_TABLE_DOUBLES] softplus table first: keeps it 16-byte aligned
+    double* s_par = s_sp + SP_TABLE_DOUBLES; // [VAG_NPAR][KS] photon/shock parameters of the staged row
     double* s_t = s_par + VAG_NPAR * KS;     // [KS] log2 observer time of the row's lattice nodes
     double* s_dop = s_t + KS;                // [KS] log2 Doppler factor
     double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
@@ -253,8 +254,8 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_B = s_idt + KS;                // [nnu][KS] boundary log2-luminosities (frequency-major)
     double* s_tobs = s_B + (size_t)KS * nnu; // [nt]
     double* s_nu = s_tobs + nt;              // [nnu]
-    double* s_sp = s_nu + nnu;               // [SP_TABLE_DOUBLES]
-    int* s_kidx = (int*)(s_sp + SP_TABLE_DOUBLES);  // [nt]
+    double* s_acc = s_nu + nnu;              // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
+    int* s_kidx = (int*)(s_acc + slots);     // [nt]
 
     const vag_model_params* Pp = a.params + m;
     const double one_plus_z = 1 + Pp->z;
@@ -273,9 +274,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     const double* cell_base = a.cellpar + a.cell_off[m] * VAG_NPAR;
     const float inv_nt = 1.0f / (float)nt;
 
-    double acc[FLUX_MAX_SLOTS];
-#pragma unroll
-    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) acc[q] = 0;
+    for (int s = tid; s < slots; s += FLUX_THREADS) s_acc[s] = 0;
 
     int staged_rep = -1;
     for (int pair = p0; pair < p1; ++pair) {
@@ -294,6 +293,9 @@ vag_flux_grid_kernel(FluxArgs a) {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+#ifdef VAG_ABLATE_A0
+            if (pair == p0)
+#endif
             eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
         }
         __syncthreads();
@@ -345,6 +347,9 @@ vag_flux_grid_kernel(FluxArgs a) {
             const int npair_nu = (nnu + 1) >> 1;
             const int total = nk * npair_nu;
             const float inv_nk = 1.0f / (float)nk;
+#ifdef VAG_ABLATE_A1
+            if (a.nt < 0)
+#endif
             for (int q = tid; q < total; q += FLUX_THREADS) {
                 const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
                 const int k = k_lo + (q - lg * nk);
@@ -357,29 +362,27 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
         }
         __syncthreads();
-        // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433) ----
-#pragma unroll
-        for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
-            const int slot = tid + q * FLUX_THREADS;
-            if (slot < slots) {
-                const int l = (int)(((float)slot + 0.5f) * inv_nt);
-                const int idx = slot - l * nt;
-                const int k = s_kidx[idx];
-                if (k >= 0) {
-                    const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
-                    const double sl = (hi - lo) * s_idt[k];
-                    if (isfinite(sl)) acc[q] += exp2_fast(lo + (s_tobs[idx] - s_t[k]) * sl);
-                }
+        // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433).  slot = l * nt + idx is
+        //      always visited by the same lane, so the LDS accumulator needs no atomics and the sum order is fixed.
+#ifdef VAG_ABLATE_B
+        if (a.nt < 0)
+#endif
+#pragma unroll 2
+        for (int slot = tid; slot < slots; slot += FLUX_THREADS) {
+            const int l = (int)(((float)slot + 0.5f) * inv_nt);
+            const int idx = slot - l * nt;
+            const int k = s_kidx[idx];
+            if (k >= 0) {
+                const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
+                const double sl = (hi - lo) * s_idt[k];
+                if (isfinite(sl)) s_acc[slot] += exp2_fast(lo + (s_tobs[idx] - s_t[k]) * sl);
             }
         }
     }
+    __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
     double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
-#pragma unroll
-    for (int q = 0; q < FLUX_MAX_SLOTS; ++q) {
-        const int slot = tid + q * FLUX_THREADS;
-        if (slot < slots) my_partial[slot] = acc[q];
-    }
+    for (int s = tid; s < slots; s += FLUX_THREADS) my_partial[s] = s_acc[s];
 }
 
 // Deterministic sum over a model's workgroup partials + normalisation
@@ -453,12 +456,12 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int tid = threadIdx.x;
     const int K = M.n_t, KS = a.k_stride;
-    extern __shared__ double lds[];
-    double* s_par = lds;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;
+    double* s_par = s_sp + SP_TABLE_DOUBLES;
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
-    double* s_sp = s_geom + KS;
     for (int i = tid; i < SP_TABLE_DOUBLES; i += SERIES_THREADS) s_sp[i] = a.sp_table[i];
 
     const vag_model_params P = a.params[m];
