@@ -220,7 +220,7 @@ def main():
         st = np.mean(np.array(flux_ms), axis=0)
         flux_s = st[3] * 1e-3
         # algorithmic work of ONE flux-kernel launch (DESIGN.md "Roofline accounting")
-        alg_bytes = plan.n_cells * 19 * 8 + nb * nnu * nt * 8 + nb * (64 + 64) * 8
+        alg_bytes = plan.n_cells * 18 * 8 + nb * nnu * nt * 8 + nb * (64 + 64) * 8
         alg_flops = plan.spec_evals * F_SPEC + plan.interps * F_INTERP
         out = {
             "metric": "light-curves/sec (single model) and MCMC walker-steps/sec at 1/2/4/8 MI355X",

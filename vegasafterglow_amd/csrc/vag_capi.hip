@@ -465,7 +465,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + nt + nnu + SP_TABLE_DOUBLES + slots) +
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 5) * ks + (size_t)ks * nnu + nt + nnu + SP_TABLE_DOUBLES + slots) +
                        sizeof(int) * nt;
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     FluxArgs a;

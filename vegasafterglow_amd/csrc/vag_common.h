@@ -45,7 +45,6 @@ enum {
     VP_LG2_NUM,     // log2_nu_m
     VP_LG2_NUMAX,   // log2_nu_M
     VP_INV_NUMAX,   // log2(e) / nu_M
-    VP_NORM,        // log2_norm_
     VP_TNORM,       // log2_thick_norm_
     VP_SAB,         // s_a_blend_
     VP_INV_SAB,     // 1 / s_a_blend_
@@ -53,7 +52,7 @@ enum {
     VP_LG2_HI,      // log2_nu_hi_
     VP_DLO,         // diff_lo_
     VP_DHI,         // diff_hi_
-    VP_INV_SLO,     // 1 / smooth_lo_
+    VP_INV_SLO,     // 1 / smooth_lo_  (== log2_norm_, smooth-power-law-syn.cpp:151)
     VP_INV_SHI,     // 1 / smooth_hi_
     VP_GAMMA,       // bulk Lorentz factor
     VP_U,           // sqrt((Gamma-1)(Gamma+1))

@@ -547,7 +547,6 @@ VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double 
     o.par[VP_LG2_NUM] = l_m;
     o.par[VP_LG2_NUMAX] = l_M;
     o.par[VP_INV_NUMAX] = LOG2E * (1.0 / nu_M);
-    o.par[VP_NORM] = 1.0 / smooth_lo;
     o.par[VP_TNORM] = thin_a - thick_a;
     o.par[VP_SAB] = s_a_blend;
     o.par[VP_INV_SAB] = 1.0 / s_a_blend;
@@ -599,7 +598,7 @@ VAG_DEV double log2_I_nu(const PtrT c, int st, const SpecConst& sc, double lg2_n
     }
     const double lb = thick + c[VP_TNORM * st];
     const double smooth_one = thin - log2_softplus(c[VP_SAB * st] * (thin - lb)) * c[VP_INV_SAB * st];
-    const double spec = c[VP_LG2_I * st] + (c[VP_NORM * st] + smooth_one);
+    const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2(lg2_nu);
 }
@@ -664,7 +663,7 @@ VAG_DEV double log2_I_nu_fast(const PtrT c, int st, const SpecConst& sc, double 
     }
     const double lb = thick + c[VP_TNORM * st];
     const double smooth_one = thin - sp_fast(c[VP_SAB * st] * (thin - lb), sp) * c[VP_INV_SAB * st];
-    const double spec = c[VP_LG2_I * st] + (c[VP_NORM * st] + smooth_one);
+    const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
 }

@@ -247,8 +247,8 @@ vag_flux_grid_kernel(FluxArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;                      // [SP_TABLE_DOUBLES] softplus table first: keeps it 16-byte aligned
     double* s_par = s_sp + SP_TABLE_DOUBLES; // [VAG_NPAR][KS] photon/shock parameters of the staged row
-    double* s_t = s_par + VAG_NPAR * KS;     // [KS] log2 observer time of the row's lattice nodes
-    double* s_dop = s_t + KS;                // [KS] log2 Doppler factor
+    double* s_t = s_par + VAG_NPAR * KS;     // [2][KS] log2 observer time of the row's lattice nodes (double buffered)
+    double* s_dop = s_t + 2 * KS;            // [KS] log2 Doppler factor
     double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
     double* s_idt = s_geom + KS;             // [KS] 1 / (t[k+1] - t[k])
     double* s_B = s_idt + KS;                // [nnu][KS] boundary log2-luminosities (frequency-major)
@@ -276,40 +276,48 @@ vag_flux_grid_kernel(FluxArgs a) {
 
     for (int s = tid; s < slots; s += FLUX_THREADS) s_acc[s] = 0;
 
-    int staged_rep = -1;
-    for (int pair = p0; pair < p1; ++pair) {
+    // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
+    //   interval 1:  bracket lookup + interval reciprocals + A1 (boundary spectra) of row p
+    //   interval 2:  B (interpolate/accumulate) of row p  ||  A0 (EAT logs) of row p+1 into the other s_t buffer
+    // A0 is latency bound (two log2 per node on < half of the lanes) and hides behind B's exp2 work.
+    auto stage_and_eat = [&](int pair, int buf) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
-        const int rep = rep_of[j];
-        __syncthreads();  // previous pair's phase B done before LDS is overwritten
+        const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+        const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+        const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+        eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
+    };
+    int staged_rep = -1;
+    auto stage_row = [&](int pair) {  // block-uniform: (re)load the photon block when the representative row changes
+        const int rep = rep_of[pair / n_phi_eff];
         if (rep != staged_rep) {
             const double* src = cell_base + (size_t)rep * K * VAG_NPAR;
             for (int par = 0; par < VAG_NPAR; ++par)
                 for (int k = tid; k < K; k += FLUX_THREADS) s_par[par * KS + k] = src[par * K + k];
             staged_rep = rep;
-            __syncthreads();
+            return true;
         }
-        // ---- A0 ----
-        {
-            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
-            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-#ifdef VAG_ABLATE_A0
-            if (pair == p0)
-#endif
-            eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
-        }
-        __syncthreads();
+        return false;
+    };
+    __syncthreads();
+    stage_row(p0);
+    __syncthreads();
+    stage_and_eat(p0, 0);
+    __syncthreads();
+    for (int pair = p0; pair < p1; ++pair) {
+        const int buf = (pair - p0) & 1;
+        const double* s_tc = s_t + buf * KS;  // log2 observer times of the current row
         // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,
         //      405-433), interval reciprocals, and the observation window (observed_window, observer.h:324-338)
-        const double row_t0 = s_t[0], row_tN = s_t[K - 1];
+        const double row_t0 = s_tc[0], row_tN = s_tc[K - 1];
         for (int idx = tid; idx < nt; idx += FLUX_THREADS) {
             const double tq = s_tobs[idx];
             int kk = -1;
             if (tq >= row_t0 && tq < row_tN) {
-                int lo = 0, hi = K - 1;  // invariant: s_t[lo] <= tq < s_t[hi]
+                int lo = 0, hi = K - 1;  // invariant: s_tc[lo] <= tq < s_tc[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (s_t[mid] <= tq)
+                    if (s_tc[mid] <= tq)
                         lo = mid;
                     else
                         hi = mid;
@@ -318,38 +326,30 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
             s_kidx[idx] = kk;
         }
-        for (int k = tid; k < K - 1; k += FLUX_THREADS) s_idt[k] = 1.0 / (s_t[k + 1] - s_t[k]);
-        int k_lo, k_hi;
-        {
-            const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
-            if (row_tN < w_lo || row_t0 > w_hi) continue;  // row entirely outside the window (block-uniform)
+        for (int k = tid; k < K - 1; k += FLUX_THREADS) s_idt[k] = 1.0 / (s_tc[k + 1] - s_tc[k]);
+        const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
+        const bool in_window = !(row_tN < w_lo || row_t0 > w_hi);  // block-uniform
+        if (in_window) {
             // sorted row => positions by counting, one ballot per 64 nodes (no dependent LDS chain):
-            //   n_lt = #{k : s_t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)   (observed_window: last k with t[k+1] < w_lo)
-            //   n_le = #{k : s_t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)  (first node > w_hi)
+            //   n_lt = #{k : t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)   (observed_window: last k with t[k+1] < w_lo)
+            //   n_le = #{k : t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)  (first node > w_hi)
             const int lane = tid & 63;
             int n_lt = 0, n_le = 0;
             for (int base = 0; base < K; base += 64) {
                 const int kk = base + lane;
-                const double v = kk < K ? s_t[kk] : INFINITY;
+                const double v = kk < K ? s_tc[kk] : INFINITY;
                 n_lt += __popcll(__ballot(v < w_lo));
                 n_le += __popcll(__ballot(v <= w_hi));
             }
-            k_lo = n_lt > 0 ? n_lt - 1 : 0;
-            k_hi = min(max(n_le, k_lo + 1), K - 1);
-        }
-        // ---- A1: boundary values B[l][k] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window.
-        //      Lanes run over k fastest: one wavefront = one frequency x 64 neighbouring cells, so the +-20
-        //      softplus shortcuts, the optically-thick cut and the nu_M cut-off branch coherently.
-        {
-            // work item = (cell k, pair of frequencies): the 13 spectrum constants of the cell are read from LDS once
-            // and the two independent evaluations interleave (ILP hides the table-lookup latency)
+            const int k_lo = n_lt > 0 ? n_lt - 1 : 0;
+            const int k_hi = min(max(n_le, k_lo + 1), K - 1);
+            // ---- A1: boundary values B[l][k] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window.
+            //      work item = (cell k, pair of frequencies); lanes run over k fastest, so a wavefront shares its
+            //      frequencies and the +-20 softplus shortcuts / optically-thick cut / nu_M cut-off branch coherently.
             const int nk = k_hi - k_lo + 1;
             const int npair_nu = (nnu + 1) >> 1;
             const int total = nk * npair_nu;
             const float inv_nk = 1.0f / (float)nk;
-#ifdef VAG_ABLATE_A1
-            if (a.nt < 0)
-#endif
             for (int q = tid; q < total; q += FLUX_THREADS) {
                 const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
                 const int k = k_lo + (q - lg * nk);
@@ -362,21 +362,32 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
         }
         __syncthreads();
+        // ---- A0 of the next row (other s_t buffer; s_dop / s_geom are free once A1 is done).  A row that needs a
+        //      different photon block is staged after B instead (block-uniform rare path).
+        const bool have_next = pair + 1 < p1;
+        const bool same_rep = have_next && rep_of[(pair + 1) / n_phi_eff] == staged_rep;
+        if (same_rep) stage_and_eat(pair + 1, buf ^ 1);
         // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433).  slot = l * nt + idx is
         //      always visited by the same lane, so the LDS accumulator needs no atomics and the sum order is fixed.
-#ifdef VAG_ABLATE_B
-        if (a.nt < 0)
-#endif
+        if (in_window) {
 #pragma unroll 2
-        for (int slot = tid; slot < slots; slot += FLUX_THREADS) {
-            const int l = (int)(((float)slot + 0.5f) * inv_nt);
-            const int idx = slot - l * nt;
-            const int k = s_kidx[idx];
-            if (k >= 0) {
-                const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
-                const double sl = (hi - lo) * s_idt[k];
-                if (isfinite(sl)) s_acc[slot] += exp2_fast(lo + (s_tobs[idx] - s_t[k]) * sl);
+            for (int slot = tid; slot < slots; slot += FLUX_THREADS) {
+                const int l = (int)(((float)slot + 0.5f) * inv_nt);
+                const int idx = slot - l * nt;
+                const int k = s_kidx[idx];
+                if (k >= 0) {
+                    const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
+                    const double sl = (hi - lo) * s_idt[k];
+                    if (isfinite(sl)) s_acc[slot] += exp2_fast(lo + (s_tobs[idx] - s_tc[k]) * sl);
+                }
             }
+        }
+        __syncthreads();
+        if (have_next && !same_rep) {
+            stage_row(pair + 1);
+            __syncthreads();
+            stage_and_eat(pair + 1, buf ^ 1);
+            __syncthreads();
         }
     }
     __syncthreads();
