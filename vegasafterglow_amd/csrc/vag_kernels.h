@@ -250,11 +250,11 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_t = s_par + VAG_NPAR * KS;     // [2][KS] log2 observer time of the row's lattice nodes (double buffered)
     double* s_dop = s_t + 2 * KS;            // [KS] log2 Doppler factor
     double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
-    double* s_idt = s_geom + KS;             // [KS] 1 / (t[k+1] - t[k])
-    double* s_B = s_idt + KS;                // [nnu][KS] boundary log2-luminosities (frequency-major)
+    double* s_B = s_geom + KS;               // [nnu][KS] boundary log2-luminosities (frequency-major)
     double* s_tobs = s_B + (size_t)KS * nnu; // [nt]
     double* s_nu = s_tobs + nt;              // [nnu]
-    double* s_acc = s_nu + nnu;              // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
+    double* s_w = s_nu + nnu;                // [nt] fractional position of each requested time inside its interval
+    double* s_acc = s_w + nt;                // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
     int* s_kidx = (int*)(s_acc + slots);     // [nt]
 
     const vag_model_params* Pp = a.params + m;
@@ -313,6 +313,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         for (int idx = tid; idx < nt; idx += FLUX_THREADS) {
             const double tq = s_tobs[idx];
             int kk = -1;
+            double w = 0;
             if (tq >= row_t0 && tq < row_tN) {
                 int lo = 0, hi = K - 1;  // invariant: s_tc[lo] <= tq < s_tc[hi]
                 while (hi - lo > 1) {
@@ -323,10 +324,12 @@ vag_flux_grid_kernel(FluxArgs a) {
                         hi = mid;
                 }
                 kk = lo;
+                const double t_lo = s_tc[lo];
+                w = (tq - t_lo) * (1.0 / (s_tc[lo + 1] - t_lo));  // position inside the interval, shared by all nu
             }
             s_kidx[idx] = kk;
+            s_w[idx] = w;
         }
-        for (int k = tid; k < K - 1; k += FLUX_THREADS) s_idt[k] = 1.0 / (s_tc[k + 1] - s_tc[k]);
         const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         const bool in_window = !(row_tN < w_lo || row_t0 > w_hi);  // block-uniform
         if (in_window) {
@@ -377,8 +380,8 @@ vag_flux_grid_kernel(FluxArgs a) {
                 const int k = s_kidx[idx];
                 if (k >= 0) {
                     const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
-                    const double sl = (hi - lo) * s_idt[k];
-                    if (isfinite(sl)) s_acc[slot] += exp2_fast(lo + (s_tobs[idx] - s_tc[k]) * sl);
+                    const double d = hi - lo;  // slope finite <=> d finite (observer.h:422-426)
+                    if (isfinite(d)) s_acc[slot] += exp2_fast(fma(d, s_w[idx], lo));
                 }
             }
         }
