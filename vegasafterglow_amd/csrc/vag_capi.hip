@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -444,6 +445,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
 }
 
 int choose_pairs_per_block(const vag_ctx* c) {
+    if (const char* e = std::getenv("VAG_PAIRS_PER_BLOCK")) {  // tuning/debug override
+        const int v = std::atoi(e);
+        if (v > 0) return std::min(v, std::max(1, c->max_pairs));
+    }
     // enough workgroups to fill 256 CUs several times over, but not so many that staging the photon rows
     // and the partial grids dominate
     long long ppb = (c->total_pairs + 16383) / 16384;

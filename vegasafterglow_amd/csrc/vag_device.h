@@ -648,6 +648,32 @@ VAG_DEV double exp2_fast(double x) {
     return ldexp(p, (int)n);
 }
 
+// log2(x) for positive, finite, normal x (the EAT step only sees such values; anything else is routed to the
+// library log2).  Exponent/mantissa split around sqrt(2), s = f/(2+f), degree-14 even polynomial in s with the
+// classic fdlibm/musl log() coefficients (Lg1..Lg7, |err| < 2^-58 on this range); result within ~1 ulp.
+VAG_DEV double log2_fast(double x) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const int eb = (int)(bits >> 52);
+    if (eb == 0 || eb >= 2047) return log2(x);  // zero, subnormal, negative, inf, nan
+    // mantissa in [1, 2); fold (sqrt2, 2) down so that m is in [sqrt(1/2), sqrt(2)]
+    double m = __longlong_as_double((long long)((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    int e = eb - 1023;
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 +
+                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double ln_m = f - (hfsq - s * (hfsq + R));  // log(1 + f)
+    return fma(ln_m, LOG2E, (double)e);
+}
+
 // compute_log2_I_nu (smooth-power-law-syn.cpp:15-46,80-92,159-167) on the fast kernels above.
 template <class PtrT>
 VAG_DEV double log2_I_nu_fast(const PtrT c, int st, const SpecConst& sc, double lg2_nu, const double* __restrict__ sp) {

@@ -221,10 +221,10 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
                      double* __restrict__ s_dop, double* __restrict__ s_geom) {
     for (int k = tid; k < K; k += nthreads) {
         const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
-        const double lg2_dop = -log2(G - u * cos_v);
+        const double lg2_dop = -log2_fast(G - u * cos_v);
         const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
         s_dop[k] = lg2_dop;
-        s_t[k] = log2(time);
+        s_t[k] = log2_fast(time);
         s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
     }
 }
