@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="models per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="models per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walkers", action="store_true", help="skip the secondary walker-steps/s measurement")
     args = ap.parse_args()
@@ -210,6 +210,11 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
+    # one extra UNTIMED pass with the kernel's work tallies on: exact spectrum-evaluation / interpolation counts
+    _lib.check(lib.vag_ctx_count_work(h, 1))
+    step(False)
+    torch.cuda.synchronize()
+    _lib.check(lib.vag_ctx_count_work(h, 0))
     plan = _lib.Plan()
     lib.vag_last_plan(h, C.byref(plan))
     if not bool(torch.isfinite(d_out).all()) or plan.n_models_ok != nb:

@@ -261,6 +261,9 @@ typedef struct vag_plan {
     int32_t pairs_per_block;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out);
+/* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with
+ * one atomic per workgroup and a host sync; leave disabled in timed runs. */
+int vag_ctx_count_work(vag_ctx* ctx, int enable);
 
 #ifdef __cplusplus
 }

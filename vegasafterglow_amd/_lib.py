@@ -74,7 +74,7 @@ EXPORTS = [
     "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_details", "vag_last_stage_times", "vag_last_plan",
+    "vag_details", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def load():
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_last_stage_times.argtypes = [v, C.POINTER(StageTimes)]
     lib.vag_last_plan.argtypes = [v, C.POINTER(Plan)]
+    lib.vag_ctx_count_work.argtypes = [v, C.c_int]
     _lib = lib
     return lib
 

@@ -209,7 +209,8 @@ static double build_softplus_table(std::vector<double>& tab) {
 
 struct vag_ctx {
     int device = 0;
-    DevBuf d_sptab;
+    DevBuf d_sptab, d_workcount;
+    bool count_work = false;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -315,7 +316,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_sptab, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+    for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -330,6 +331,11 @@ void vag_ctx_destroy(vag_ctx* c) {
 
 int vag_ctx_set_stream(vag_ctx* c, void* s) {
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return VAG_OK;
+}
+
+int vag_ctx_count_work(vag_ctx* c, int enable) {
+    c->count_work = enable != 0;
     return VAG_OK;
 }
 
@@ -491,6 +497,14 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
     a.sp_table = c->d_sptab.as<double>();
+    a.work_count = nullptr;
+    if (c->count_work) {
+        if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
+        HIPCHK(hipMemsetAsync(c->d_workcount.p, 0, 2 * sizeof(unsigned long long), st));
+        a.work_count = c->d_workcount.as<unsigned long long>();
+    }
+    // upper bounds (every lattice node inside the observation window); vag_ctx_count_work(1) replaces them by
+    // the exact tallies of the kernel
     c->plan.spec_evals += c->eat_cells * nnu;
     c->plan.interps += c->total_pairs * (long long)nt * nnu;
     c->plan.flux_blocks = max_blocks * nb;
@@ -500,6 +514,13 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
+    if (c->count_work) {
+        unsigned long long h[2];
+        HIPCHK(hipMemcpyAsync(h, c->d_workcount.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        c->plan.spec_evals += (long long)h[0] - c->eat_cells * nnu;
+        c->plan.interps += (long long)h[1] - c->total_pairs * (long long)nt * nnu;
+    }
     const int out_slots = d_bandw ? nt : slots;
     hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
                        c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out);

@@ -212,6 +212,7 @@ struct FluxArgs {
     int pairs_per_block;
     int max_blocks;  // blocks per model (gridDim.x)
     int k_stride;    // LDS row stride (>= max n_t in the batch)
+    unsigned long long* work_count;  // optional [2]: exact spectrum evaluations / interpolations done (instrumentation)
 };
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
@@ -275,6 +276,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     const float inv_nt = 1.0f / (float)nt;
 
     for (int s = tid; s < slots; s += FLUX_THREADS) s_acc[s] = 0;
+    unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies, only kept when a.work_count != nullptr
 
     // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
     //   interval 1:  bracket lookup + interval reciprocals + A1 (boundary spectra) of row p
@@ -353,6 +355,17 @@ vag_flux_grid_kernel(FluxArgs a) {
             const int npair_nu = (nnu + 1) >> 1;
             const int total = nk * npair_nu;
             const float inv_nk = 1.0f / (float)nk;
+            if (a.work_count) {  // instrumentation pass: exact unit counts for the roofline (block-uniform branch)
+                int n_lt0 = 0, n_ltN = 0;
+                for (int base = 0; base < nt; base += 64) {
+                    const int ii = base + lane;
+                    const double v = ii < nt ? s_tobs[ii] : INFINITY;
+                    n_lt0 += __popcll(__ballot(v < row_t0));
+                    n_ltN += __popcll(__ballot(v < row_tN));
+                }
+                n_evals += (unsigned long long)nk * nnu;
+                n_interps += (unsigned long long)(n_ltN - n_lt0) * nnu;
+            }
             for (int q = tid; q < total; q += FLUX_THREADS) {
                 const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
                 const int k = k_lo + (q - lg * nk);
@@ -392,6 +405,10 @@ vag_flux_grid_kernel(FluxArgs a) {
             stage_and_eat(pair + 1, buf ^ 1);
             __syncthreads();
         }
+    }
+    if (a.work_count && tid == 0) {
+        atomicAdd(a.work_count, n_evals);
+        atomicAdd(a.work_count + 1, n_interps);
     }
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
