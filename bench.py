@@ -251,6 +251,11 @@ def main():
             "plan": {"ode_rows": plan.n_rows, "cells": plan.n_cells, "theta_phi_rows": plan.total_pairs,
                      "flux_workgroups": plan.flux_blocks, "rows_per_workgroup": plan.pairs_per_block},
         }
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/run_profile.sh; FETCH_SIZE x2 per the gfx950 note, calibrated on a kernel with known bytes)
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tp) and nb == 512 and world == 1:
+            out["roofline"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
         if walkers is not None:
             out["walker_steps"] = walkers
         if not args.no_cpu_baseline and world == 1:
