@@ -297,7 +297,9 @@ int vag_ctx_create(int device, vag_ctx** out) {
     c->stream = c->own_stream;
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     // allow the flux kernels the full 160 KiB LDS of a gfx950 CU
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_series_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -510,7 +512,10 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = ppb;
     if (c->n_rows > 0) {
-        hipLaunchKernelGGL(vag_flux_grid_kernel, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        if (a.work_count)
+            hipLaunchKernelGGL(vag_flux_grid_kernel<true>, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL(vag_flux_grid_kernel<false>, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));

@@ -230,6 +230,8 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
     }
 }
 
+// COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
+template <bool COUNT>
 __global__ void __launch_bounds__(FLUX_THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
@@ -269,14 +271,11 @@ vag_flux_grid_kernel(FluxArgs a) {
     SpecConst sc;
     sc.init(Pp->p);
     const double cos_obs = cos(Pp->theta_obs), sin_obs = sin(Pp->theta_obs);
-    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
-    const double* cell_base = a.cellpar + a.cell_off[m] * VAG_NPAR;
     const float inv_nt = 1.0f / (float)nt;
 
     for (int s = tid; s < slots; s += FLUX_THREADS) s_acc[s] = 0;
-    unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies, only kept when a.work_count != nullptr
+    unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
 
     // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
     //   interval 1:  bracket lookup + interval reciprocals + A1 (boundary spectra) of row p
@@ -284,6 +283,8 @@ vag_flux_grid_kernel(FluxArgs a) {
     // A0 is latency bound (two log2 per node on < half of the lanes) and hides behind B's exp2 work.
     auto stage_and_eat = [&](int pair, int buf) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+        const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+        const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
         const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
         const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
         const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
@@ -293,9 +294,12 @@ vag_flux_grid_kernel(FluxArgs a) {
     auto stage_row = [&](int pair) {  // block-uniform: (re)load the photon block when the representative row changes
         const int rep = rep_of[pair / n_phi_eff];
         if (rep != staged_rep) {
-            const double* src = cell_base + (size_t)rep * K * VAG_NPAR;
-            for (int par = 0; par < VAG_NPAR; ++par)
-                for (int k = tid; k < K; k += FLUX_THREADS) s_par[par * KS + k] = src[par * K + k];
+            const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+#pragma unroll 1
+            for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {  // rare path: keep its register footprint small
+                const int par = (int)(((float)q + 0.5f) / (float)K);
+                s_par[par * KS + (q - par * K)] = src[q];
+            }
             staged_rep = rep;
             return true;
         }
@@ -355,7 +359,7 @@ vag_flux_grid_kernel(FluxArgs a) {
             const int npair_nu = (nnu + 1) >> 1;
             const int total = nk * npair_nu;
             const float inv_nk = 1.0f / (float)nk;
-            if (a.work_count) {  // instrumentation pass: exact unit counts for the roofline (block-uniform branch)
+            if constexpr (COUNT) {  // instrumentation pass: exact unit counts for the roofline
                 int n_lt0 = 0, n_ltN = 0;
                 for (int base = 0; base < nt; base += 64) {
                     const int ii = base + lane;
@@ -406,9 +410,11 @@ vag_flux_grid_kernel(FluxArgs a) {
             __syncthreads();
         }
     }
-    if (a.work_count && tid == 0) {
-        atomicAdd(a.work_count, n_evals);
-        atomicAdd(a.work_count + 1, n_interps);
+    if constexpr (COUNT) {
+        if (tid == 0) {
+            atomicAdd(a.work_count, n_evals);
+            atomicAdd(a.work_count + 1, n_interps);
+        }
     }
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
