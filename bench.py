@@ -70,6 +70,66 @@ def cpu_baseline(arr, t, nu, budget_s=12.0):
             "sample": f"{n} models of the timed batch (C2: 200 t x 10 nu), single thread, {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(arr, t, nu, budget_s=8.0):
+    """Same reference path on all host cores, one model per thread (the reference's own scheme:
+    ThreadPoolExecutor over walkers with the GIL released, fitting/samplers.py:59-91; ctypes drops the GIL too)."""
+    import _abi
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _abi.load_ref() or _abi.load_oracle(fast=True)
+    ncpu = os.cpu_count() or 1
+    deadline = time.perf_counter() + budget_s
+
+    def worker(w):
+        n, i = 0, w
+        while time.perf_counter() < deadline:
+            lib.flux_density_grid(arr[i % len(arr)], t, nu)
+            n += 1
+            i += ncpu
+        return n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(ncpu) as ex:
+        total = sum(ex.map(worker, range(ncpu)))
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "light-curves/s", "cores": ncpu,
+            "sample": f"{total} models, {ncpu} threads, {dt:.1f} s"}
+
+
+def tophat_sweep(lib, h, _lib, dev):
+    """BASELINE configs[0] (the >= 100x target config): top-hat + ISM, resolutions (0.089, 0.05, 12),
+    100 times x 3 bands; single-call latency and batched throughput, on-axis (C1a) and theta_obs = 0.05 (C1b)."""
+    import torch
+    import _abi
+    import configs
+    out = {}
+    t, nu = configs.C1_T, configs.C1_NU
+    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
+    for name, kw, batches in (("C1a_onaxis", configs.C1A, (1, 64, 1024, 4096)), ("C1b_theta_obs_0.05", configs.C1B, (1, 64, 1024))):
+        res = {}
+        for nb in batches:
+            rng = np.random.default_rng(1)
+            arr = (_abi.ModelParams * nb)()
+            for i in range(nb):
+                k = dict(kw)
+                for key in ("E_iso", "n_ism", "eps_B"):
+                    k[key] *= float(np.exp(rng.uniform(-0.1, 0.1)))
+                arr[i] = _abi.make_params(**k)
+            d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            d_o = torch.empty((nb, nu.size, t.size), dtype=torch.float64, device=dev)
+            call = lambda: _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), nb, d_t.data_ptr(), t.size,
+                                                                            d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+            call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                call()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            res[f"batch_{nb}"] = {"ms_per_call": 1e3 * dt, "light_curves_per_s": nb / dt}
+        out[name] = res
+    return out
+
+
 def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
     """Secondary metric of BASELINE.json: MCMC walker-steps/s on the C4 problem: GW170817-like mock,
     60 data points (3 bands x 20 epochs), 8 free parameters, default resolutions, 1024 walkers drawn uniformly
@@ -220,6 +280,8 @@ def main():
     if not bool(torch.isfinite(d_out).all()) or plan.n_models_ok != nb:
         raise SystemExit("bench produced non-finite fluxes or rejected models")
     walkers = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world)
+    walkers_half = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512)
+    tophat = tophat_sweep(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
 
     if rank == 0:
         st = np.mean(np.array(flux_ms), axis=0)
@@ -258,8 +320,12 @@ def main():
             out["roofline"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
         if walkers is not None:
             out["walker_steps"] = walkers
+            out["walker_steps_redblue_half"] = walkers_half  # emcee red-blue moves evaluate nwalkers/2 per call
+        if tophat is not None:
+            out["tophat_config0"] = tophat
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, t_np, nu_np)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(arr, t_np, nu_np)
         print(json.dumps(out))
     lib.vag_ctx_destroy(h)
     if world > 1:
