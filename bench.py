@@ -70,29 +70,39 @@ def cpu_baseline(arr, t, nu, budget_s=12.0):
             "sample": f"{n} models of the timed batch (C2: 200 t x 10 nu), single thread, {dt:.1f} s"}
 
 
-def cpu_baseline_all_cores(arr, t, nu, budget_s=8.0):
-    """Same reference path on all host cores, one model per thread (the reference's own scheme:
-    ThreadPoolExecutor over walkers with the GIL released, fitting/samplers.py:59-91; ctypes drops the GIL too)."""
+def cpu_baseline_all_cores(arr, t, nu, budget_s=4.0):
+    """Same reference path on many host cores, one model per thread (the reference's own scheme:
+    ThreadPoolExecutor over walkers with the GIL released, fitting/samplers.py:59-91; ctypes drops the GIL too).
+    The box may expose more logical CPUs than its CPU quota grants, so a few thread counts are tried and the best
+    throughput is reported with the thread count that produced it."""
     import _abi
     from concurrent.futures import ThreadPoolExecutor
     lib = _abi.load_ref() or _abi.load_oracle(fast=True)
-    ncpu = os.cpu_count() or 1
-    deadline = time.perf_counter() + budget_s
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    best = None
+    for nthreads in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        deadline = time.perf_counter() + budget_s
 
-    def worker(w):
-        n, i = 0, w
-        while time.perf_counter() < deadline:
-            lib.flux_density_grid(arr[i % len(arr)], t, nu)
-            n += 1
-            i += ncpu
-        return n
+        def worker(w):
+            n, i = 0, w
+            while time.perf_counter() < deadline:
+                lib.flux_density_grid(arr[i % len(arr)], t, nu)
+                n += 1
+                i += nthreads
+            return n
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(ncpu) as ex:
-        total = sum(ex.map(worker, range(ncpu)))
-    dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "light-curves/s", "cores": ncpu,
-            "sample": f"{total} models, {ncpu} threads, {dt:.1f} s"}
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as ex:
+            total = sum(ex.map(worker, range(nthreads)))
+        dt = time.perf_counter() - t0
+        r = {"value": total / dt, "unit": "light-curves/s", "cores": nthreads,
+             "sample": f"{total} models, {nthreads} threads, {dt:.1f} s (host exposes {ncpu} logical CPUs)"}
+        if best is None or r["value"] > best["value"]:
+            best = r
+    return best
 
 
 def tophat_sweep(lib, h, _lib, dev):
