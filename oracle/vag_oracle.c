@@ -1775,6 +1775,55 @@ int vag_oracle_flux_density(const vag_model_params* p, const double* t, const do
     return rc;
 }
 
+/* PyModel::flux_density_exposures: generate_exposure_sampling + series flux + average_exposure_flux,
+ * pybind/pymodel.cpp:412-496.  out[n]. */
+typedef struct {
+    double t;
+    int src;
+} expo_pt;
+static int cmp_expo(const void* a, const void* b) {
+    const expo_pt* x = a;
+    const expo_pt* y = b;
+    if (x->t < y->t) return -1;
+    if (x->t > y->t) return 1;
+    return (x->src > y->src) - (x->src < y->src); /* stable tie-break: original sample order */
+}
+int vag_oracle_flux_density_exposures(const vag_model_params* p, const double* t, const double* nu,
+                                      const double* expo_time, int n, int num_points, double* out) {
+    if (n <= 0) return fail("time array must be non-empty");
+    if (num_points < 2) return fail("num_points must be at least 2 to sample within each exposure time");
+    for (int i = 0; i < n; ++i)
+        if (!(isfinite(expo_time[i]) && expo_time[i] > 0)) return fail("expo_time must be finite and > 0");
+    const int total = n * num_points;
+    expo_pt* pts = malloc(sizeof(expo_pt) * total);
+    double* ts = malloc(sizeof(double) * total);
+    double* nus = malloc(sizeof(double) * total);
+    double* F = malloc(sizeof(double) * total);
+    for (int i = 0, j = 0; i < n; ++i) {
+        const double dt = expo_time[i] / (double)(num_points - 1);
+        for (int k = 0; k < num_points; ++k, ++j) {
+            pts[j].t = t[i] + k * dt;
+            pts[j].src = j;
+        }
+    }
+    qsort(pts, total, sizeof(expo_pt), cmp_expo);
+    for (int j = 0; j < total; ++j) {
+        ts[j] = pts[j].t;
+        nus[j] = nu[pts[j].src / num_points];
+    }
+    int rc = vag_oracle_flux_density(p, ts, nus, total, F);
+    if (rc == 0) {
+        for (int i = 0; i < n; ++i) out[i] = 0;
+        for (int j = 0; j < total; ++j) out[pts[j].src / num_points] += F[j];
+        for (int i = 0; i < n; ++i) out[i] /= (double)num_points;
+    }
+    free(pts);
+    free(ts);
+    free(nus);
+    free(F);
+    return rc;
+}
+
 int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max, int num_nu,
                     double* out) {
     if (check_times(t, nt) != 0) return -1;

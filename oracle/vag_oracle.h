@@ -26,6 +26,9 @@ int vag_oracle_flux_density(const vag_model_params* p, const double* t, const do
 /* Model.flux: out[nt]  (pybind/pymodel.cpp:391-410) */
 int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max, int num_nu,
                     double* out);
+/* Model.flux_density_exposures: out[n]  (pybind/pymodel.cpp:412-496) */
+int vag_oracle_flux_density_exposures(const vag_model_params* p, const double* t, const double* nu,
+                                      const double* expo_time, int n, int num_points, double* out);
 /* Model.details-like intermediates; same protocol as oracle/ref_driver.cpp:vag_ref_details. */
 int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
                        const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,

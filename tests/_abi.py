@@ -135,6 +135,15 @@ class CpuLib:
                                                               num_nu, _p(out)))
         return out
 
+    def flux_density_exposures(self, prm, t, nu, expo, num_points=10):
+        fn = getattr(self.lib, self.prefix + "_flux_density_exposures")
+        fn.argtypes = [C.POINTER(ModelParams), _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        fn.restype = C.c_int
+        t, nu, expo = (np.ascontiguousarray(a, dtype=np.float64) for a in (t, nu, expo))
+        out = np.zeros(t.size)
+        self._check(fn(C.byref(prm), _p(t), _p(nu), _p(expo), t.size, num_points, _p(out)))
+        return out
+
     EXTRA_NAMES = ["gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "column_den", "nu_m", "nu_c", "nu_a",
                    "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe"]
 

@@ -131,6 +131,25 @@ def test_series_band_and_model_api(eng, oracle):
         np.testing.assert_allclose(d[k], od[k], rtol=2e-6, err_msg=k)
 
 
+def test_exposure_averaged_flux_and_long_series(eng, oracle):
+    """Model.flux_density_exposures (pymodel.cpp:412-496): 80 exposures x 10 samples = 800 sorted series points,
+    i.e. more than one series launch holds -> chunked on the same grid."""
+    kw = configs.C4_TRUTH
+    m = va.Model(va.GaussianJet(kw["theta_c"], kw["E_iso"], kw["Gamma0"]), va.ISM(kw["n_ism"]),
+                 va.Observer(kw["lumi_dist"], kw["z"], kw["theta_obs"]), va.Radiation(kw["eps_e"], kw["eps_B"], kw["p"]))
+    rng = np.random.default_rng(3)
+    t = np.sort(10 ** rng.uniform(5.5, 8.0, 80))
+    nu = rng.choice(configs.C4_BANDS, 80)
+    expo = 10 ** rng.uniform(3, 5.5, 80)
+    got = m.flux_density_exposures(t, nu, expo, num_points=10).total
+    want = oracle.flux_density_exposures(_abi.make_params(**kw), t, nu, expo, 10)
+    assert_close(got, want)
+    with pytest.raises(ValueError):
+        m.flux_density_exposures(t, nu, expo, num_points=1)
+    with pytest.raises(ValueError):
+        m.flux_density_exposures(t, nu, -expo)
+
+
 def test_ragged_batch_equals_individual_calls(eng, oracle):
     """Models with different jets, symmetries and grid sizes in ONE batch give bit-identical results to
     one-at-a-time calls (compact ragged layout, no cross-talk), and match the oracle."""

@@ -159,3 +159,28 @@ def test_times_outside_the_evolved_window_contribute_zero(oracle):
     kw, t, nu = configs.EXTRA["narrow_window"]
     f = oracle.flux_density_grid(_abi.make_params(**kw), t, nu)
     assert np.all(np.isfinite(f)) and np.all(f > 0)
+
+
+def test_exposure_average_follows_reference_sampling(oracle):
+    """flux_density_exposures (pymodel.cpp:412-496): the oracle's C version equals sampling/sorting/averaging done in
+    numpy around the oracle's series flux, and tends to the instantaneous flux for short exposures."""
+    prm = _abi.make_params(**configs.C4_TRUTH)
+    t = np.array([1e6, 3e6, 2e6, 5e7])  # unsorted on purpose: the reference sorts the samples, not the exposures
+    nu = np.array([3e9, 5e14, 3e9, 2.4e17])
+    expo = np.array([1e5, 2e6, 5e5, 1e7])
+    got = oracle.flux_density_exposures(prm, t, nu, expo, 7)
+    k = np.arange(7)
+    ts = (t[:, None] + k[None, :] * (expo / 6)[:, None]).ravel()
+    nus = np.repeat(nu, 7)
+    order = np.argsort(ts, kind="stable")
+    series = oracle.flux_density(prm, ts[order], nus[order])
+    want = np.zeros(4)
+    np.add.at(want, np.repeat(np.arange(4), 7)[order], series)
+    np.testing.assert_allclose(got, want / 7, rtol=1e-13)
+    short = oracle.flux_density_exposures(prm, np.sort(t), nu[np.argsort(t)], np.full(4, 1.0), 2)
+    inst = oracle.flux_density(prm, np.sort(t), nu[np.argsort(t)])
+    np.testing.assert_allclose(short, inst, rtol=1e-4)
+    with pytest.raises(ValueError):
+        oracle.flux_density_exposures(prm, t, nu, expo, 1)
+    with pytest.raises(ValueError):
+        oracle.flux_density_exposures(prm, t, nu, -expo, 5)

@@ -687,11 +687,24 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
     HIPCHK(hipSetDevice(c->device));
-    int rc = prep_times(c, d_t, n, d_nu, n);
+    int rc = prep_times(c, d_t, n, d_nu, n);  // the grid sees the extrema of ALL requested times
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    return run_flux_series(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
+    const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
+    if (n <= chunk) return run_flux_series(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
+    DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
+    if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
+    for (int s0 = 0; s0 < n; s0 += chunk) {
+        const int m = std::min(chunk, n - s0);
+        rc = run_flux_series(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m, tmp.as<double>());
+        if (rc) break;
+        HIPCHK(hipMemcpy2DAsync(d_out + s0, sizeof(double) * n, tmp.p, sizeof(double) * m, sizeof(double) * m, (size_t)nb,
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    tmp.release();
+    return rc;
 }
 
 int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,

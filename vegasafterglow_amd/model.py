@@ -261,6 +261,27 @@ class Model:
                                                   float(nu_min), float(nu_max), int(num_nu), out.ctypes.data_as(_dp)))
         return FluxDict(out)
 
+    # -- Model.flux_density_exposures: pybind.cpp:433-434, pymodel.cpp:412-496 --
+    def flux_density_exposures(self, t, nu, expo_time, num_points=10):
+        """Exposure-averaged flux density: `num_points` samples across each [t_i, t_i + expo_time_i] window are
+        evaluated as one sorted (t, nu) series on the device and averaged per exposure."""
+        t, nu, expo = _as_f64(t, "t"), _as_f64(nu, "nu"), _as_f64(expo_time, "expo_time")
+        _req(t.size == nu.size == expo.size, "time, frequency, and exposure time arrays must have the same size")
+        _req(int(num_points) >= 2, "num_points must be at least 2 to sample within each exposure time")
+        for i, e in enumerate(expo):
+            _req(math.isfinite(e) and e > 0, f"expo_time[{i}] must be finite and > 0, got {e}")
+        num_points = int(num_points)
+        k = np.arange(num_points, dtype=np.float64)
+        dt = expo / float(num_points - 1)
+        t_s = (t[:, None] + k[None, :] * dt[:, None]).ravel()       # generate_exposure_sampling, pymodel.cpp:412-431
+        nu_s = np.repeat(nu, num_points)
+        idx = np.repeat(np.arange(t.size), num_points)
+        order = np.argsort(t_s, kind="stable")
+        series = self.flux_density(t_s[order], nu_s[order]).total
+        summed = np.zeros(t.size)
+        np.add.at(summed, idx[order], series)                        # average_exposure_flux, pymodel.cpp:452-470
+        return FluxDict(summed / float(num_points))
+
     # -- Model.details (shock part): pybind.cpp:448, pymodel.cpp:315-348 --
     def details(self, t_min, t_max):
         lib = _lib.load()
