@@ -35,6 +35,8 @@ constexpr double LN2 = 0.693147180559945309417232121458176568;
 constexpr double LOG2E = 1.442695040888963407359924681001892137;
 constexpr double SQRT3 = 1.732050807568877293527446341505872367;
 
+VAG_DEV double exp2_fast(double x);
+VAG_DEV double log2_fast(double x);
 VAG_DEV double dmin(double a, double b) { return b < a ? b : a; }
 VAG_DEV double dmax(double a, double b) { return a < b ? b : a; }
 
@@ -218,7 +220,7 @@ struct Dopri5 {
                 err = dmax(err, fabs(xe) / (eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
             }
             if (err > 1.0) {
-                dt = h * dmax(9.0 / 10.0 * pow(err, -1.0 / 3), 1.0 / 5.0);
+                dt = h * dmax(9.0 / 10.0 * exp2_fast(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
                 continue;
             }
 #pragma unroll
@@ -231,7 +233,7 @@ struct Dopri5 {
             t = t + h;
             if (err < 0.5) {
                 err = dmax(3.2e-4, err);  // 5^-5
-                dt = h * (9.0 / 10.0 * pow(err, -1.0 / 5));
+                dt = h * (9.0 / 10.0 * exp2_fast(log2_fast(err) * (-1.0 / 5)));
             }
             return true;
         }
@@ -373,20 +375,21 @@ struct FwdShock {
             const double gamma_bar = gamma_c_coeff / (e_th * t_comv);
             const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
             const double ratio = gamma_m / gamma_c;
-            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * fast_pow(ratio, p - 2) : eps_e_eff;
+            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_fast((p - 2) * log2_fast(ratio)) : eps_e_eff;
         }
-        const double ad = adiabatic_idx(Gamma);
+        const double inv_G = 1 / Gamma;
+        const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
         const double Gamma2 = Gamma * Gamma;
-        const double Gamma_eff = (ad * (Gamma2 - 1) + 1) / Gamma;
-        const double dGamma_eff = (ad * (Gamma2 + 1) - 1) / Gamma2;
+        const double Gamma_eff = (ad * (Gamma2 - 1) + 1) * inv_G;
+        const double dGamma_eff = (ad * (Gamma2 + 1) - 1) * (inv_G * inv_G);
         const double dlnV = 3 / r * dr;
         const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm;
         const double a2 = (ad - 1) * Gamma_eff * U * dlnV;
         const double b1 = (m_jet0 + m2) * C_C2;
-        const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) / Gamma) * U;
+        const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * U;
         const double dG = (a1 + a2) / (b1 + b2);
         d[0] = dG;
-        const double dlnV2 = 3 / r * dr - dG / Gamma;
+        const double dlnV2 = dlnV - dG * inv_G;
         d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm - (ad - 1) * dlnV2 * U;
     }
 };
