@@ -259,6 +259,8 @@ typedef struct vag_plan {
     int64_t interps;
     int32_t flux_blocks; /* workgroups of the flux kernel */
     int32_t pairs_per_block;
+    int32_t n_models_invalid;  /* parameters rejected by validation (ValueError in the reference) */
+    int32_t n_models_capacity; /* adaptive grid larger than the engine limits: NOT evaluated (NaN / -inf) */
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out);
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -62,7 +62,8 @@ class StageTimes(C.Structure):
 class Plan(C.Structure):
     _fields_ = [("n_models_ok", C.c_int32), ("n_rows", C.c_int32), ("n_cells", C.c_int64), ("total_pairs", C.c_int64),
                 ("eat_cells", C.c_int64), ("spec_evals", C.c_int64), ("interps", C.c_int64),
-                ("flux_blocks", C.c_int32), ("pairs_per_block", C.c_int32)]
+                ("flux_blocks", C.c_int32), ("pairs_per_block", C.c_int32),
+                ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32)]
 
 
 class Limits(C.Structure):

@@ -396,7 +396,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     long long* h_cell = c->h_off.as<long long>();
     int* h_row = reinterpret_cast<int*>(h_cell + (nb + 1));
     long long cells = 0, pairs = 0, eat = 0;
-    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0;
+    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_invalid = 0, n_capacity = 0;
     for (int m = 0; m < nb; ++m) {
         h_row[m] = rows;
         h_cell[m] = cells;
@@ -409,6 +409,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             pairs += pr;
             eat += (long long)pr * hm[m].n_t;
             ++n_ok;
+        } else if (hm[m].status == VAG_E_CAPACITY) {
+            ++n_capacity;
+        } else {
+            ++n_invalid;
         }
     }
     h_row[nb] = rows;
@@ -427,6 +431,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->plan.n_cells = cells;
     c->plan.total_pairs = pairs;
     c->plan.eat_cells = eat;
+    c->plan.n_models_invalid = n_invalid;
+    c->plan.n_models_capacity = n_capacity;
     HIPCHK(hipMemcpyAsync(c->d_cell_off.p, h_cell, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_row_off.p, h_row, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, st));
     if (rows == 0) {

@@ -7,6 +7,7 @@ batched call into the HIP engine (``vag_loglike_batch``).  Sampler drivers (emce
 third-party: hand ``Fitter.log_prob_batch`` to ``emcee.EnsembleSampler(..., vectorize=True)``.
 """
 import ctypes as C
+import logging
 import math
 from dataclasses import dataclass
 from enum import Enum
@@ -16,6 +17,9 @@ import numpy as np
 
 from . import _lib
 from .model import get_context
+
+logger = logging.getLogger(__name__)
+logger.addHandler(logging.NullHandler())
 
 JET_TYPES = {"tophat": _lib.JET_TOPHAT, "gaussian": _lib.JET_GAUSSIAN, "powerlaw": _lib.JET_POWERLAW,
              "two_component": _lib.JET_TWO_COMPONENT}
@@ -148,9 +152,16 @@ class Fitter:
             raise ValueError("samples must be [nb, ndim]")
         out = np.empty(samples.shape[0])
         h, lock = get_context(self.device)
+        plan = _lib.Plan()
         with lock:
             _lib.check(_lib.load().vag_loglike_batch(h, C.byref(spec), samples.ctypes.data_as(_dp), samples.shape[0],
                                                      spec.ndim, out.ctypes.data_as(_dp)))
+            _lib.load().vag_last_plan(h, C.byref(plan))
+        if plan.n_models_capacity:
+            # never silent: these walkers were NOT evaluated (their adaptive grid exceeds the engine's static limits)
+            logger.warning("%d of %d walkers exceeded the engine grid limits and were assigned -inf",
+                           plan.n_models_capacity, samples.shape[0])
+        self.last_plan = plan
         return out
 
     def make_log_prob_batch(self, param_defs, loglike_fn=None):
