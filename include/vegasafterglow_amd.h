@@ -45,6 +45,11 @@ extern "C" {
 #define VAG_JET_POWERLAW 2
 #define VAG_JET_TWO_COMPONENT 3
 
+/* Radiation flags.  Inverse-Compton cooling + SSC emission (src/radiation/inverse-compton.*) is SURVEY 8(f) rank 1:
+ * the CPU checkers implement it; the device engine returns VAG_E_UNSUPPORTED for it until its kernels land. */
+#define VAG_FLAG_SSC 1
+#define VAG_FLAG_KN 2
+
 /* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
 #define VAG_MEDIUM_ISM 0
 #define VAG_MEDIUM_WIND 1
@@ -89,7 +94,7 @@ typedef struct vag_model_params {
     double t_resol;     /* points per decade */
     double rtol;        /* ODE tolerance, (0,1) */
     int32_t radiative_fireball; /* 1 = radiative losses feed back on dynamics (default) */
-    int32_t reserved;           /* must be 0 */
+    int32_t flags;              /* VAG_FLAG_* (Radiation(ssc=, kn=), pybind/pybind.cpp:368-377); other bits must be 0 */
 } vag_model_params;
 
 /* Fill a params struct with the reference's defaults: Radiation xi_e = 1,

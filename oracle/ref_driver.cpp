@@ -86,6 +86,7 @@ struct Pipeline {
     Observer obs;
     SynElectronGrid elec;
     SynPhotonGrid phot;
+    bool ssc{false}, kn{false};
 };
 
 void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) {
@@ -101,6 +102,26 @@ void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) 
     out.obs.observe(out.coord, out.shock, lumi_dist, p.z);
     out.elec = generate_syn_electrons(out.shock, out.coord);
     out.phot = generate_syn_photons(out.shock, out.elec, out.coord);
+    out.ssc = (p.flags & VAG_FLAG_SSC) != 0;
+    out.kn = (p.flags & VAG_FLAG_KN) != 0;
+    if (out.ssc) {  // apply_ic_cooling, pybind/pymodel.h:567-577
+        if (out.kn)
+            KN_cooling(out.elec, out.phot, out.shock, out.coord);
+        else
+            Thomson_cooling(out.elec, out.phot, out.shock, out.coord);
+    }
+}
+
+// SSC photons with the per-k observation band clamp of single_shock_emission, pybind/pymodel.h:896-914
+auto make_ic_photons(Pipeline& pl, Array const& nu_obs) {
+    const Real lg2_1pz = fast_log2(pl.obs.one_plus_z);
+    const Real lg2_nu_lo = fast_log2(xt::amin(nu_obs)()) + lg2_1pz;
+    const Real lg2_nu_hi = fast_log2(xt::amax(nu_obs)()) + lg2_1pz;
+    const Array lg2_dop_min_k = xt::amin(pl.obs.lg2_doppler, {0, 1});
+    const Array lg2_dop_max_k = xt::amax(pl.obs.lg2_doppler, {0, 1});
+    const Array nu_eval_min_k = xt::exp2(lg2_nu_lo - lg2_dop_max_k);
+    const Array nu_eval_max_k = xt::exp2(lg2_nu_hi - lg2_dop_min_k);
+    return generate_IC_photons(pl.elec, pl.phot, pl.kn, pl.coord, nu_eval_min_k, nu_eval_max_k);
 }
 
 } // namespace
@@ -121,9 +142,42 @@ VAG_REF_API int vag_ref_flux_density_grid(const vag_model_params* p, const doubl
         for (int i = 0; i < nnu; ++i) nu_obs(i) = nu[i] * unit::Hz;
         Pipeline pl;
         run_pipeline(*p, t_obs, pl);
+        // each component is converted to CGS first, then summed (flux_func + PyFlux::calc_total, pymodel.cpp:350-364,506-510)
+        MeshGrid F = pl.obs.specific_flux(t_obs, nu_obs, pl.phot) / unit::flux_den_cgs;
+        if (pl.ssc) {
+            auto ic = make_ic_photons(pl, nu_obs);
+            const MeshGrid G = pl.obs.specific_flux(t_obs, nu_obs, ic) / unit::flux_den_cgs;
+            F += G;
+        }
+        for (int l = 0; l < nnu; ++l)
+            for (int i = 0; i < nt; ++i) out[size_t(l) * nt + i] = F(l, i);
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Model.flux_density_grid components: fwd.sync and fwd.ssc, each [nnu][nt] (ssc zeros when disabled)
+VAG_REF_API int vag_ref_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu,
+                                                     int nnu, double* out_sync, double* out_ssc) {
+    try {
+        Array t_obs = Array::from_shape({size_t(nt)});
+        Array nu_obs = Array::from_shape({size_t(nnu)});
+        for (int i = 0; i < nt; ++i) t_obs(i) = t[i] * unit::sec;
+        for (int i = 0; i < nnu; ++i) nu_obs(i) = nu[i] * unit::Hz;
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
         MeshGrid F = pl.obs.specific_flux(t_obs, nu_obs, pl.phot);
         for (int l = 0; l < nnu; ++l)
-            for (int i = 0; i < nt; ++i) out[size_t(l) * nt + i] = F(l, i) / unit::flux_den_cgs;
+            for (int i = 0; i < nt; ++i) out_sync[size_t(l) * nt + i] = F(l, i) / unit::flux_den_cgs;
+        for (size_t q = 0; q < size_t(nnu) * nt; ++q) out_ssc[q] = 0;
+        if (pl.ssc) {
+            auto ic = make_ic_photons(pl, nu_obs);
+            MeshGrid G = pl.obs.specific_flux(t_obs, nu_obs, ic);
+            for (int l = 0; l < nnu; ++l)
+                for (int i = 0; i < nt; ++i) out_ssc[size_t(l) * nt + i] = G(l, i) / unit::flux_den_cgs;
+        }
         return 0;
     } catch (std::exception const& e) {
         g_err = e.what();
@@ -142,8 +196,13 @@ VAG_REF_API int vag_ref_flux_density(const vag_model_params* p, const double* t,
         }
         Pipeline pl;
         run_pipeline(*p, t_obs, pl);
-        Array F = pl.obs.specific_flux_series(t_obs, nu_obs, pl.phot);
-        for (int i = 0; i < n; ++i) out[i] = F(i) / unit::flux_den_cgs;
+        Array F = pl.obs.specific_flux_series(t_obs, nu_obs, pl.phot) / unit::flux_den_cgs;
+        if (pl.ssc) {
+            auto ic = make_ic_photons(pl, nu_obs);
+            const Array G = pl.obs.specific_flux_series(t_obs, nu_obs, ic) / unit::flux_den_cgs;
+            F += G;
+        }
+        for (int i = 0; i < n; ++i) out[i] = F(i);
         return 0;
     } catch (std::exception const& e) {
         g_err = e.what();

@@ -1201,18 +1201,156 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
  * Synchrotron electrons and photons: src/radiation/synchrotron.cpp:45-254,315-408,
  * smooth-power-law-syn.cpp:15-167
  * ---------------------------------------------------------------------------------------- */
+/* BrokenPowerLaw<5>, src/util/utilities.h:21-78 */
+typedef struct {
+    int size;
+    double slope[5], log2_lower[5], log2_const[5];
+} bpl_t;
+
+static void bpl_first_segment(bpl_t* b, double norm, double lower, double slope) {
+    b->size = 0;
+    const double log2_lower = log2(lower);
+    const double log2_val = log2(norm);
+    const int s = b->size++;
+    b->slope[s] = slope;
+    b->log2_lower[s] = log2_lower;
+    b->log2_const[s] = log2_val - slope * log2_lower;
+}
+static void bpl_add_segment(bpl_t* b, double lower, double slope) {
+    const double log2_lower = log2(lower);
+    const int prev = b->size - 1;
+    const double log2_val = b->log2_const[prev] + b->slope[prev] * log2_lower;
+    const int s = b->size++;
+    b->slope[s] = slope;
+    b->log2_lower[s] = log2_lower;
+    b->log2_const[s] = log2_val - slope * log2_lower;
+}
+static double bpl_eval(const bpl_t* b, double x) {
+    const double log2_x = log2(x);
+    for (int i = b->size - 1; i > 0; --i)
+        if (log2_x >= b->log2_lower[i]) return exp2(b->log2_const[i] + b->slope[i] * log2_x);
+    return (b->size > 0) ? exp2(b->log2_const[0] + b->slope[0] * log2_x) : 0.0;
+}
+
+/* InverseComptonY, src/radiation/inverse-compton.h:28-76, inverse-compton.cpp:18-187 */
+typedef struct {
+    double gamma_m_hat, gamma_c_hat, gamma_self, gamma0, Y_T;
+    int regime;
+    double gamma_m_, B_, p_, gamma_self3;
+    bpl_t seg;
+} icy_t;
+
 typedef struct {
     double gamma_m, gamma_c, gamma_a, gamma_M, N_e, column_den;
     int regime;
+    double p, Y_c;
+    icy_t Ys;
 } electrons_t;
 
 typedef struct {
+    double Y_c;
+    icy_t Ys;
     double nu_m, nu_c, nu_a, nu_M, I_nu_max, p;
     /* cached by build(), smooth-power-law-syn.cpp:94-153 */
     double log2_I_nu_max, log2_nu_m, log2_nu_c, log2_nu_a, log2_nu_M, inv_nu_M;
     double log2_norm, log2_thick_norm, smooth_thick, log2_x_far, s_a_blend;
     double log2_nu_lo, log2_nu_hi, smooth_lo, smooth_hi, diff_lo, diff_hi;
 } photons_t;
+
+#define C_H (6.63e-27 * U_ERG * U_SEC) /* con::h, src/util/macros.h:95 */
+
+static double compute_syn_freq(double gamma, double B);
+static double compute_syn_gamma(double nu, double B);
+
+static void icy_default(icy_t* y) { /* InverseComptonY::InverseComptonY(), inverse-compton.cpp:37-43 */
+    memset(y, 0, sizeof *y);
+    y->gamma_m_hat = 1.0;
+    y->gamma_c_hat = 1.0;
+    y->gamma_self = 1;
+    y->gamma0 = 1;
+    y->Y_T = 0.0;
+    y->regime = 0;
+    y->gamma_m_ = 1;
+    y->B_ = 0;
+    y->p_ = 2.3;
+    y->gamma_self3 = 1;
+    y->seg.size = 0;
+}
+static double icy_gamma_hat(const icy_t* y, double gamma) {
+    return dmax(y->gamma_self3 / (gamma * gamma), 1.0);
+}
+static double icy_gamma_spectrum(const icy_t* y, double gamma) {
+    return bpl_eval(&y->seg, gamma);
+}
+static double icy_nu_spectrum(const icy_t* y, double nu) {
+    return icy_gamma_spectrum(y, compute_syn_gamma(nu, y->B_));
+}
+/* build_segments, inverse-compton.cpp:112-175 (regimes 3-5 are unreachable: update_cooling_breaks only sets 1 or 2) */
+static void icy_build_segments(icy_t* y) {
+    switch (y->regime) {
+        case 0:
+            bpl_first_segment(&y->seg, y->Y_T, 1.0, 0.0);
+            break;
+        case 1:
+            bpl_first_segment(&y->seg, y->Y_T, 1.0, 0.0);
+            bpl_add_segment(&y->seg, y->gamma_c_hat, 0.5 * (y->p_ - 3.0));
+            bpl_add_segment(&y->seg, y->gamma_m_hat, -4.0 / 3.0);
+            break;
+        default:
+            bpl_first_segment(&y->seg, y->Y_T, 1.0, 0.0);
+            bpl_add_segment(&y->seg, y->gamma_m_hat, -0.5);
+            bpl_add_segment(&y->seg, y->gamma_c_hat, -4.0 / 3.0);
+            break;
+    }
+}
+/* update_gamma0, inverse-compton.cpp:48-88 */
+static void icy_update_gamma0(icy_t* y, double gamma_c) {
+    if (y->Y_T < 1) {
+        y->gamma0 = 0.0;
+        return;
+    }
+    if (y->gamma_m_ < gamma_c) {
+        y->gamma0 = fast_pow(y->Y_T, 2.0 / (3.0 - y->p_)) * y->gamma_c_hat;
+        if (y->gamma0 > y->gamma_m_hat)
+            y->gamma0 = y->gamma_m_hat * fast_pow(y->Y_T, 3.0 / 4.0) * fast_pow(gamma_c / y->gamma_m_, 0.75 * (y->p_ - 3.0));
+    } else {
+        if (y->gamma_m_ < y->gamma_m_hat) {
+            y->gamma0 = y->Y_T * y->Y_T * y->gamma_m_hat;
+            if (y->gamma0 > y->gamma_c_hat) y->gamma0 = fast_pow(y->Y_T * gamma_c / y->gamma_m_, 3.0 / 4.0) * y->gamma_c_hat;
+        } else {
+            y->gamma0 = y->Y_T * y->Y_T * y->gamma_m_hat;
+            if (y->gamma0 > y->gamma_self) y->gamma0 = sqrt(y->Y_T * y->gamma_m_ * y->gamma_m_hat);
+        }
+    }
+}
+/* update_cooling_breaks, inverse-compton.cpp:90-110 */
+static void icy_update_cooling_breaks(icy_t* y, double gamma_c, double Y_T) {
+    y->gamma_c_hat = icy_gamma_hat(y, gamma_c);
+    y->Y_T = Y_T;
+    icy_update_gamma0(y, gamma_c);
+    y->regime = (y->gamma_m_ < gamma_c) ? 1 : 2;
+    icy_build_segments(y);
+}
+/* InverseComptonY(gamma_m, gamma_c, p, B, Y_T, is_KN), inverse-compton.cpp:18-35 */
+static void icy_init(icy_t* y, double gamma_m, double gamma_c, double p, double B, double Y_T, int is_KN) {
+    icy_default(y);
+    y->gamma_c_hat = 1;
+    const double nu_m = compute_syn_freq(gamma_m, B);
+    y->gamma_m_hat = dmax(C_ME * C_C2 / C_H / nu_m, 1.0);
+    y->gamma_self = fast_pow(y->gamma_m_hat * gamma_m * gamma_m, 1.0 / 3.0);
+    y->gamma_self3 = y->gamma_self * y->gamma_self * y->gamma_self;
+    y->B_ = B;
+    y->gamma_m_ = gamma_m;
+    y->p_ = p;
+    if (is_KN) {
+        icy_update_cooling_breaks(y, gamma_c, Y_T);
+    } else {
+        y->gamma_c_hat = icy_gamma_hat(y, gamma_c);
+        y->Y_T = Y_T;
+        y->regime = 0;
+        icy_build_segments(y);
+    }
+}
 
 static int order3(double a, double b, double c) {
     return a <= b && b <= c;
@@ -1280,9 +1418,9 @@ static double compute_gamma_c(double t_comv, double B, double Y) {
     return (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
 }
 
-/* compute_syn_gamma_a with Ys = InverseComptonY{} and Y_c = 0: the IC ratio is exactly 1,
- * synchrotron.cpp:212-246 */
-static double compute_syn_gamma_a(double B, double I_syn_peak, double gamma_m, double gamma_c, double p) {
+/* compute_syn_gamma_a, synchrotron.cpp:212-246 (Ys default-constructed + Y_c = 0 in the first pass) */
+static double compute_syn_gamma_a(double B, double I_syn_peak, double gamma_m, double gamma_c, double p, const icy_t* Ys,
+                                  double Y_c) {
     const double gamma_peak = dmin(gamma_m, gamma_c);
     const double nu_peak = compute_syn_freq(gamma_peak, B);
     const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
@@ -1294,18 +1432,18 @@ static double compute_syn_gamma_a(double B, double I_syn_peak, double gamma_m, d
             const double nu_c = compute_syn_freq(gamma_c, B);
             if (nu_a > nu_c) {
                 nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
-                const double ic = (1 + 0.0) / (1 + 0.0);
+                const double ic = (1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a));
                 nu_a *= fast_pow(ic, 2 / (p + 5));
             }
         } else {
             const double nu_c = compute_syn_freq(gamma_c, B);
             nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
-            double ic = (1 + 0.0) / (1 + 0.0);
+            double ic = (1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a));
             nu_a *= fast_pow(ic, 0.4);
             const double nu_m = compute_syn_freq(gamma_m, B);
             if (nu_a > nu_m) {
                 nu_a = fast_pow(I_syn_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
-                ic = (1 + 0.0) / (1 + 0.0);
+                ic = (1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a));
                 nu_a *= fast_pow(ic, 2 / (p + 5));
             }
         }
@@ -1329,8 +1467,11 @@ static void syn_electrons_cell(electrons_t* e, double t_com, double B, double r,
     e->column_den = e->N_e / (r * r);
     const double I_nu_peak = compute_syn_I_peak(B, e->column_den);
     e->gamma_c = compute_gamma_c(t_com, B, 0.);
-    e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, rad->p);
+    icy_default(&e->Ys);
+    e->Y_c = 0;
+    e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, rad->p, &e->Ys, 0.0);
     e->regime = determine_regime(e->gamma_a, e->gamma_c, e->gamma_m);
+    e->p = rad->p;
 }
 
 static double sigmoid2(double x) {
@@ -1397,6 +1538,8 @@ static void photons_build(photons_t* ph) {
 /* one cell of generate_syn_photons, synchrotron.cpp:376-408 */
 static void syn_photons_cell(photons_t* ph, const electrons_t* e, double B, double p) {
     ph->p = p;
+    ph->Ys = e->Ys;
+    ph->Y_c = e->Y_c;
     ph->nu_M = compute_syn_freq(e->gamma_M, B);
     ph->nu_m = compute_syn_freq(e->gamma_m, B);
     ph->nu_c = compute_syn_freq(e->gamma_c, B);
@@ -1410,6 +1553,12 @@ static double compute_log2_I_nu(const photons_t* ph, double log2_nu) {
     const double thin = (log2_nu - ph->log2_nu_lo) / 3.0 +
                         log2_broken_power_ratio(log2_nu, ph->log2_nu_lo, ph->diff_lo, ph->smooth_lo) +
                         log2_broken_power_ratio(log2_nu, ph->log2_nu_hi, ph->diff_hi, ph->smooth_hi);
+    double thin_ic = thin;
+    /* IC steepening above nu_c on the thin branch only (smooth-power-law-syn.cpp:83-90, inverse-compton.h:781-792) */
+    if (log2_nu > ph->log2_nu_c && (ph->Y_c > 0 || ph->Ys.Y_T > 0)) {
+        const double nu = exp2(log2_nu);
+        thin_ic += log2((1. + ph->Y_c) / (1 + icy_nu_spectrum(&ph->Ys, nu)));
+    }
     double thick;
     {
         const double log2_x = log2_nu - ph->log2_nu_m;
@@ -1422,15 +1571,19 @@ static double compute_log2_I_nu(const photons_t* ph, double log2_nu) {
     }
     const double log2_b = thick + ph->log2_thick_norm;
     /* log2_smooth_one(a, b, s) = a - softplus(s (a - b)) / s */
-    const double smooth_one = thin - log2_softplus(ph->s_a_blend * (thin - log2_b)) / ph->s_a_blend;
+    const double smooth_one = thin_ic - log2_softplus(ph->s_a_blend * (thin_ic - log2_b)) / ph->s_a_blend;
     const double spec = ph->log2_I_nu_max + (ph->log2_norm + smooth_one);
     if (log2_nu - ph->log2_nu_M < -20) return spec;
     return spec - M_LOG2E_ * ph->inv_nu_M * exp2(log2_nu);
 }
 
-/* generate_syn_electrons + generate_syn_photons + broadcast_symmetry (utilities.h:293-320) */
+/* generate_syn_electrons + generate_syn_photons (+ apply_ic_cooling, pybind/pymodel.h:567-577) + broadcast_symmetry
+ * (utilities.h:293-320) */
+static void ic_cooling_row(electrons_t* el, const shock_t* sh, size_t row0, int nt, const vag_model_params* rad, int kn);
+
 static void generate_syn(electrons_t* el, photons_t* ph, const shock_t* sh, const coord_t* c, const vag_model_params* p) {
     const int nt = c->n_t;
+    const int ssc = (p->flags & VAG_FLAG_SSC) != 0, kn = (p->flags & VAG_FLAG_KN) != 0;
     for (int r = 0; r < c->n_reps; ++r) {
         const int j0 = c->reps[r];
         const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
@@ -1439,12 +1592,431 @@ static void generate_syn(electrons_t* el, photons_t* ph, const shock_t* sh, cons
             syn_electrons_cell(&el[o], sh->t_comv[o], sh->B[o], sh->r[o], sh->Gamma_th[o], sh->N_p[o], p);
             syn_photons_cell(&ph[o], &el[o], sh->B[o], p->p);
         }
+        if (ssc) { /* Thomson_cooling / KN_cooling: electrons updated in place, photons regenerated */
+            ic_cooling_row(el, sh, (size_t)j0 * nt, nt, p, kn);
+            for (int k = 0; k < nt; ++k) {
+                const size_t o = (size_t)j0 * nt + k;
+                syn_photons_cell(&ph[o], &el[o], sh->B[o], el[o].p);
+            }
+        }
         for (int j = j0 + 1; j < j1; ++j)
             for (int k = 0; k < nt; ++k) {
                 el[(size_t)j * nt + k] = el[(size_t)j0 * nt + k];
                 ph[(size_t)j * nt + k] = ph[(size_t)j0 * nt + k];
             }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Inverse-Compton cooling and SSC photons: src/radiation/inverse-compton.h:270-776,
+ * src/radiation/inverse-compton.cpp:192-378
+ * ---------------------------------------------------------------------------------------- */
+static double compute_Thomson_Y(const vag_model_params* rad, double gamma_m, double gamma_c) {
+    const double eta_e = (gamma_c < gamma_m) ? 1 : fast_pow(gamma_c / gamma_m, 2 - rad->p); /* eta_rad_Thomson */
+    const double b = eta_e * rad->eps_e / rad->eps_B;
+    return 0.5 * (sqrt(1. + 4. * b) - 1.);
+}
+
+/* update_gamma_c_Thomson, inverse-compton.cpp:192-204 */
+static void update_gamma_c_Thomson(double* gamma_c, icy_t* Ys, const vag_model_params* rad, double B, double t_com,
+                                   double gamma_m, double gamma_c_last) {
+    double Y_T = compute_Thomson_Y(rad, gamma_m, *gamma_c);
+    double gamma_c_new = gamma_c_last;
+    while (fabs((gamma_c_new - *gamma_c) / *gamma_c) > 1e-3) {
+        *gamma_c = gamma_c_new;
+        Y_T = compute_Thomson_Y(rad, gamma_m, *gamma_c);
+        gamma_c_new = compute_gamma_c(t_com, B, Y_T);
+    }
+    *gamma_c = gamma_c_new;
+    icy_init(Ys, gamma_m, *gamma_c, rad->p, B, Y_T, 0);
+}
+
+/* update_gamma_c_KN, inverse-compton.cpp:206-235 */
+static void update_gamma_c_KN(double* gamma_c, icy_t* Ys, const vag_model_params* rad, double B, double t_com,
+                              double gamma_m, double gamma_c_last) {
+    double gamma_c_new = gamma_c_last;
+    double Y_T = compute_Thomson_Y(rad, gamma_m, gamma_c_new);
+    icy_init(Ys, gamma_m, gamma_c_new, rad->p, B, Y_T, 1);
+    const int max_iter = 100;
+    int iter = 0;
+    do {
+        *gamma_c = gamma_c_new;
+        Y_T = compute_Thomson_Y(rad, gamma_m, *gamma_c);
+        icy_update_cooling_breaks(Ys, *gamma_c, Y_T);
+        const double Y_c = icy_gamma_spectrum(Ys, *gamma_c);
+        gamma_c_new = compute_gamma_c(t_com, B, Y_c);
+        iter++;
+    } while (fabs((gamma_c_new - *gamma_c) / *gamma_c) > 1e-3 && iter < max_iter);
+    *gamma_c = gamma_c_new;
+}
+
+/* update_gamma_M, inverse-compton.cpp:237-251 */
+static void update_gamma_M(double* gamma_M, const icy_t* Ys, double B) {
+    if (B == 0) {
+        *gamma_M = INFINITY;
+        return;
+    }
+    double Y_M = icy_gamma_spectrum(Ys, *gamma_M);
+    double gamma_M_new = compute_syn_gamma_M(B, Y_M);
+    while (fabs((*gamma_M - gamma_M_new) / gamma_M_new) > 1e-3) {
+        *gamma_M = gamma_M_new;
+        Y_M = icy_gamma_spectrum(Ys, *gamma_M);
+        gamma_M_new = compute_syn_gamma_M(B, Y_M);
+    }
+}
+
+/* IC_cooling for one representative row (sequential in k: gamma_c_last), inverse-compton.h:729-768 */
+static void ic_cooling_row(electrons_t* el, const shock_t* sh, size_t row0, int nt, const vag_model_params* rad, int kn) {
+    for (int k = 0; k < nt; ++k) {
+        const size_t o = row0 + k;
+        electrons_t* e = &el[o];
+        const double t_com = sh->t_comv[o], B = sh->B[o];
+        const double gamma_c_last = el[row0 + (k > 0 ? k - 1 : 0)].gamma_c;
+        if (kn)
+            update_gamma_c_KN(&e->gamma_c, &e->Ys, rad, B, t_com, e->gamma_m, gamma_c_last);
+        else
+            update_gamma_c_Thomson(&e->gamma_c, &e->Ys, rad, B, t_com, e->gamma_m, gamma_c_last);
+        update_gamma_M(&e->gamma_M, &e->Ys, B);
+        const double I_nu_peak = compute_syn_I_peak(B, e->column_den);
+        e->Y_c = icy_gamma_spectrum(&e->Ys, e->gamma_c);
+        e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, e->p, &e->Ys, e->Y_c);
+        e->regime = determine_regime(e->gamma_a, e->gamma_c, e->gamma_m);
+    }
+}
+
+/* SynElectrons::compute_spectrum / compute_column_den, synchrotron.cpp:261-309 */
+static double electrons_column_den(const electrons_t* e, double gamma) {
+    double spec;
+    switch (e->regime) {
+        case 1:
+        case 2:
+        case 5:
+            spec = (e->p - 1) / e->gamma_m * exp(-gamma / e->gamma_M - e->gamma_m / gamma) *
+                   fast_pow(gamma / e->gamma_m, -e->p) * e->gamma_c / (gamma + e->gamma_c);
+            break;
+        case 3:
+        case 4:
+        case 6:
+            spec = exp(-gamma / e->gamma_M - e->gamma_c / gamma) * e->gamma_c / (gamma * gamma) /
+                   (1.0 + fast_pow(gamma / e->gamma_m, e->p - 1));
+            break;
+        default:
+            spec = 0;
+    }
+    if (gamma <= e->gamma_c) return e->column_den * spec;
+    return e->column_den * spec * (1 + e->Y_c) / (1 + icy_gamma_spectrum(&e->Ys, gamma));
+}
+
+/* Klein-Nishina cross-section ratio and its LUT, inverse-compton.cpp:257-378 */
+static double compton_ratio_from_x(double x) {
+    if (x < 1e-2) return 1 - 2 * x;
+    if (x > 1e2) return 3. / 8 * (log(2 * x) + 0.5) / x;
+    const double l = log1p(2.0 * x);
+    const double invx = 1.0 / x, invx2 = invx * invx;
+    const double term1 = 1.0 + 2.0 * x, invt1 = 1.0 / term1, invt1_2 = invt1 * invt1;
+    const double a = (1.0 + x) * invx2 * invx;
+    const double b = 2.0 * x * (1.0 + x) * invt1 - l;
+    const double c = 0.5 * l * invx;
+    const double d = (1.0 + 3.0 * x) * invt1_2;
+    return 0.75 * (a * b + c - d);
+}
+#define KN_LUT_N 128
+static double kn_ratio[KN_LUT_N], kn_lg2_ratio[KN_LUT_N], kn_inv_step;
+static int kn_ready = 0;
+static const double KN_LG2_XMIN = -6.6438561897747247, KN_LG2_XMAX = 6.6438561897747247;
+static void kn_lut_init(void) {
+    const double step = (KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1);
+    kn_inv_step = 1.0 / step;
+    for (int i = 0; i < KN_LUT_N; ++i) {
+        const double lg2_x = KN_LG2_XMIN + step * (double)i;
+        kn_ratio[i] = compton_ratio_from_x(exp2(lg2_x));
+        kn_lg2_ratio[i] = log2(kn_ratio[i]);
+    }
+    kn_ready = 1;
+}
+static void compton_correction_pair(double nu, double* corr, double* lg2_corr) {
+    const double x = C_H / (C_ME * C_C2) * nu;
+    if (!(x > 0)) {
+        *corr = 0;
+        *lg2_corr = -INFINITY;
+        return;
+    }
+    if (x <= 1e-2) {
+        *corr = 1 - 2 * x;
+        *lg2_corr = -(2 * x + 2 * x * x) * 1.4426950408889634;
+        return;
+    }
+    if (x >= 1e2) {
+        *corr = compton_ratio_from_x(x);
+        *lg2_corr = log2(*corr);
+        return;
+    }
+    if (!kn_ready) kn_lut_init();
+    const double pos = (log2(x) - KN_LG2_XMIN) * kn_inv_step;
+    if (pos <= 0) {
+        *corr = kn_ratio[0];
+        *lg2_corr = kn_lg2_ratio[0];
+        return;
+    }
+    if (pos >= (double)(KN_LUT_N - 1)) {
+        *corr = kn_ratio[KN_LUT_N - 1];
+        *lg2_corr = kn_lg2_ratio[KN_LUT_N - 1];
+        return;
+    }
+    const size_t idx = (size_t)pos;
+    const double frac = pos - (double)idx;
+    *corr = kn_ratio[idx] + (kn_ratio[idx + 1] - kn_ratio[idx]) * frac;
+    *lg2_corr = kn_lg2_ratio[idx] + (kn_lg2_ratio[idx + 1] - kn_lg2_ratio[idx]) * frac;
+}
+
+/* ICPhoton, inverse-compton.h:86-607 */
+typedef struct {
+    electrons_t electrons;
+    photons_t photons;
+    int KN, generated, n_ic;
+    double nu_eval_min, nu_eval_max;
+    double log2_nu_theory_max, log2_nu_theory_min;
+    long ic_idx0;
+    double *log2_nu_IC, *log2_I_nu_IC, *interp_slope;
+} icphoton_t;
+
+#define IC_Q (3.321928094887362 / 8) /* lattice_quantum */
+#define IC_GAMMA_MULT 2
+#define IC_NU_MULT 2
+#define IC_IC_MULT 2
+#define IC_X0 0.47140452079103166
+
+static double compute_log2_I_nu(const photons_t* ph, double log2_nu);
+
+static void icphoton_free(icphoton_t* ic) {
+    free(ic->log2_nu_IC);
+    free(ic->log2_I_nu_IC);
+    free(ic->interp_slope);
+    ic->log2_nu_IC = ic->log2_I_nu_IC = ic->interp_slope = NULL;
+    ic->n_ic = 0;
+}
+
+static void icphoton_copy(icphoton_t* dst, const icphoton_t* src) { /* broadcast_symmetry deep copy */
+    *dst = *src;
+    if (src->n_ic > 0) {
+        dst->log2_nu_IC = malloc(sizeof(double) * src->n_ic);
+        dst->log2_I_nu_IC = malloc(sizeof(double) * src->n_ic);
+        dst->interp_slope = malloc(sizeof(double) * src->n_ic);
+        memcpy(dst->log2_nu_IC, src->log2_nu_IC, sizeof(double) * src->n_ic);
+        memcpy(dst->log2_I_nu_IC, src->log2_I_nu_IC, sizeof(double) * src->n_ic);
+        memcpy(dst->interp_slope, src->interp_slope, sizeof(double) * (src->n_ic - 1));
+    }
+}
+
+static double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, double nu_hi, double lg2f_lo, double lg2f_hi,
+                                     double lg2r, double inv_lg2r, double trap) {
+    if (!(f_lo > 0) || !(f_hi > 0)) return trap;
+    const double s1 = 1 + (lg2f_hi - lg2f_lo) * inv_lg2r;
+    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) / s1;
+    return f_lo * nu_lo * lg2r * 0.6931471805599453;
+}
+
+static int build_lattice(double lg2_lo, double lg2_hi, double step, double** grid, double** lg2_grid) {
+    size_t n = (size_t)ceil((lg2_hi - lg2_lo) / step) + 1;
+    if (n < 2) n = 2;
+    *grid = malloc(sizeof(double) * n);
+    *lg2_grid = malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; ++i) {
+        (*lg2_grid)[i] = lg2_lo + step * (double)i;
+        (*grid)[i] = exp2((*lg2_grid)[i]);
+    }
+    return (int)n;
+}
+
+/* generate_spectrum: compute_grid_params + initialize_grids + sample_distributions + compute_IC_spectrum */
+static void icphoton_generate(icphoton_t* ic) {
+    icphoton_free(ic);
+    const electrons_t* el = &ic->electrons;
+    const photons_t* ph = &ic->photons;
+    /* compute_grid_params, inverse-compton.h:297-338 */
+    const double tail_factor = dmax(-log(1e-2), 5.0);
+    const double gamma_min = dmin(el->gamma_m, el->gamma_c) / 30;
+    const double gamma_max = dmax(el->gamma_M * tail_factor, gamma_min);
+    const double nu_min = dmin(ph->nu_a, ph->nu_m) / 10;
+    const double nu_max = dmax(ph->nu_M * tail_factor, nu_min);
+    double nu_IC_min = 4 * IC_X0 * nu_min * gamma_min * gamma_min;
+    const double nu_ic_base = 4 * IC_X0 * ph->nu_M * el->gamma_M * el->gamma_M;
+    const double nu_ic_single_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
+    double nu_IC_max = nu_ic_single_cut * 2.0;
+    ic->log2_nu_theory_max = log2(nu_IC_max);
+    ic->log2_nu_theory_min = log2(nu_IC_min);
+    nu_IC_min = dmax(nu_IC_min, dmin(ic->nu_eval_min / 4.0, nu_IC_max / 16.0));
+    nu_IC_max = dmin(nu_IC_max, dmax(ic->nu_eval_max * 4.0, nu_IC_min * 16.0));
+#define POSFIN_(x) (isfinite(x) && (x) > 0)
+    if (!(POSFIN_(gamma_min) && POSFIN_(gamma_max) && POSFIN_(nu_min) && POSFIN_(nu_max) && POSFIN_(nu_IC_min) &&
+          POSFIN_(nu_IC_max))) {
+        ic->generated = 1;
+        return;
+    }
+#undef POSFIN_
+    /* initialize_grids, inverse-compton.h:340-369 */
+    double *nu_seed, *lg2_nu_seed, *gamma, *lg2_gamma;
+    const int nu_size = build_lattice(log2(nu_min), log2(nu_max), IC_NU_MULT * IC_Q, &nu_seed, &lg2_nu_seed);
+    double* dnu_seed = malloc(sizeof(double) * nu_size);
+    for (int j = 0; j + 1 < nu_size; ++j) dnu_seed[j] = nu_seed[j + 1] - nu_seed[j];
+    const int g_size = build_lattice(log2(gamma_min), log2(gamma_max), IC_GAMMA_MULT * IC_Q, &gamma, &lg2_gamma);
+    const double q = IC_Q;
+    const double phase = lg2_nu_seed[0] + 2 * lg2_gamma[0] + log2(4 * IC_X0);
+    const long n_lo = (long)floor((log2(nu_IC_min) - phase) / (q * IC_IC_MULT));
+    const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / (q * IC_IC_MULT));
+    const long span = n_hi - n_lo;
+    const int n_ic = (int)(span > 1 ? span : 1) + 1;
+    ic->ic_idx0 = n_lo * IC_IC_MULT;
+    ic->n_ic = n_ic;
+    ic->log2_nu_IC = malloc(sizeof(double) * n_ic);
+    ic->log2_I_nu_IC = malloc(sizeof(double) * n_ic);
+    ic->interp_slope = calloc(n_ic, sizeof(double));
+    for (int k = 0; k < n_ic; ++k) ic->log2_nu_IC[k] = phase + q * (double)(ic->ic_idx0 + (long)(IC_IC_MULT * k));
+    /* sample_distributions, inverse-compton.h:371-399 */
+    double* dN_e_boost = malloc(sizeof(double) * g_size);
+    for (int i = 0; i < g_size; ++i) {
+        const double gi = gamma[i];
+        const double dgi = 0.5 * ((i + 1 < g_size ? gamma[i + 1] : gamma[i]) - (i > 0 ? gamma[i - 1] : gamma[i]));
+        dN_e_boost[i] = electrons_column_den(el, gi) / (gi * gi) * dgi;
+    }
+    double* I_nu_seed = malloc(sizeof(double) * nu_size);
+    for (int j = 0; j < nu_size; ++j) I_nu_seed[j] = exp2(compute_log2_I_nu(ph, lg2_nu_seed[j]));
+    /* compute_IC_spectrum, inverse-compton.h:529-607 */
+    const int nu_last = nu_size - 1;
+    double* I_buf = calloc(n_ic, sizeof(double));
+    double* cdf_buf = calloc(nu_size, sizeof(double));
+    double* fv_buf = calloc(nu_size, sizeof(double));
+    double* ratio_buf = calloc(nu_size, sizeof(double));
+    double* fv_th = malloc(sizeof(double) * nu_size);
+    double* lg2fv_th = malloc(sizeof(double) * nu_size);
+    double* lg2r = calloc(nu_size, sizeof(double));
+    double* inv_lg2r = calloc(nu_size, sizeof(double));
+    double* cdf_th = calloc(nu_size, sizeof(double));
+    double* ratio_th = calloc(nu_size, sizeof(double));
+    for (int j = 0; j < nu_size; ++j) {
+        const double f = I_nu_seed[j] / (nu_seed[j] * nu_seed[j]);
+        fv_th[j] = f;
+        lg2fv_th[j] = (f > 0) ? log2(f) : -INFINITY;
+        if (j + 1 < nu_size) {
+            lg2r[j] = lg2_nu_seed[j + 1] - lg2_nu_seed[j];
+            inv_lg2r[j] = (lg2r[j] != 0) ? 1 / lg2r[j] : 0;
+        }
+    }
+    /* build_cdf_thomson, inverse-compton.h:415-430 */
+#define BUILD_CDF_TH_(cdf, ratio)                                                                                      \
+    do {                                                                                                               \
+        (cdf)[nu_last] = 0;                                                                                            \
+        for (int j = nu_last - 1; j >= 0; --j) {                                                                       \
+            const double trap = 0.5 * (fv_th[j] + fv_th[j + 1]) * dnu_seed[j];                                         \
+            const double exact = power_law_bin_integral(fv_th[j], fv_th[j + 1], nu_seed[j], nu_seed[j + 1], lg2fv_th[j], \
+                                                        lg2fv_th[j + 1], lg2r[j], inv_lg2r[j], trap);                  \
+            (cdf)[j] = (cdf)[j + 1] + exact;                                                                           \
+            (ratio)[j] = (trap > 0) ? exact / trap : 1;                                                                \
+        }                                                                                                              \
+    } while (0)
+    /* accumulate_IC, inverse-compton.h:483-527 */
+    const double expq[2] = {exp2(IC_Q * 0.0), exp2(IC_Q * 1.0)};
+#define ACCUMULATE_IC_(dNe, n_off_, fv)                                                                   \
+    do {                                                                                                  \
+        const long ns_top = ((long)nu_size - 1) * (long)IC_NU_MULT;                                       \
+        if (cdf_buf[0] <= 0) break;                                                                       \
+        const double plateau = (dNe)*cdf_buf[0];                                                          \
+        int kk = 0;                                                                                       \
+        long nn = (n_off_);                                                                               \
+        for (; kk < n_ic && nn < 0; ++kk, nn += IC_IC_MULT) I_buf[kk] += plateau;                         \
+        for (; kk < n_ic && nn < ns_top; ++kk, nn += IC_IC_MULT) {                                        \
+            const size_t j = (size_t)nn / IC_NU_MULT;                                                     \
+            const size_t fi = (size_t)nn % IC_NU_MULT;                                                    \
+            const double nu_lo = nu_seed[j], dnu = dnu_seed[j];                                           \
+            const double f_lo = (fv)[j], f_hi = (fv)[j + 1];                                              \
+            const double frac = (nu_lo * expq[fi] - nu_lo) / dnu;                                         \
+            const double rem = 1.0 - frac;                                                                \
+            const double f_seed = f_lo * rem + f_hi * frac;                                               \
+            I_buf[kk] += (dNe) * (cdf_buf[j + 1] + 0.5 * (f_seed + f_hi) * rem * dnu * ratio_buf[j]);     \
+        }                                                                                                 \
+    } while (0)
+    if (ic->KN) {
+        BUILD_CDF_TH_(cdf_th, ratio_th);
+        const size_t n_lat = IC_GAMMA_MULT * ((size_t)g_size - 1) + IC_NU_MULT * ((size_t)nu_size - 1) + 1;
+        double* corr_lat = malloc(sizeof(double) * n_lat);
+        double* lg2corr_lat = malloc(sizeof(double) * n_lat);
+        const double lg2_base = log2(gamma[0]) + lg2_nu_seed[0];
+        for (size_t k = 0; k < n_lat; ++k)
+            compton_correction_pair(exp2(lg2_base + IC_Q * (double)k), &corr_lat[k], &lg2corr_lat[k]);
+        for (int i = 0; i < g_size; ++i) {
+            if (dN_e_boost[i] <= 0) continue;
+            /* build_cdf_KN, inverse-compton.h:432-481 */
+            const size_t i_gamma = IC_GAMMA_MULT * (size_t)i;
+            const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / gamma[i];
+            int j_split = 0;
+            while (j_split < nu_last && nu_seed[j_split] < nu_split) ++j_split;
+            double corr = corr_lat[i_gamma + IC_NU_MULT * (size_t)nu_last];
+            double lg2_corr = lg2corr_lat[i_gamma + IC_NU_MULT * (size_t)nu_last];
+            fv_buf[nu_last] = fv_th[nu_last] * corr;
+            double lg2f_hi = lg2fv_th[nu_last] + lg2_corr;
+            cdf_buf[nu_last] = 0;
+            for (int j = nu_last - 1; j >= j_split; --j) {
+                corr = corr_lat[i_gamma + IC_NU_MULT * (size_t)j];
+                lg2_corr = lg2corr_lat[i_gamma + IC_NU_MULT * (size_t)j];
+                fv_buf[j] = fv_th[j] * corr;
+                const double lg2f_lo = lg2fv_th[j] + lg2_corr;
+                const double trap = 0.5 * (fv_buf[j] + fv_buf[j + 1]) * dnu_seed[j];
+                const double exact = power_law_bin_integral(fv_buf[j], fv_buf[j + 1], nu_seed[j], nu_seed[j + 1], lg2f_lo,
+                                                            lg2f_hi, lg2r[j], inv_lg2r[j], trap);
+                cdf_buf[j] = cdf_buf[j + 1] + exact;
+                ratio_buf[j] = (trap > 0) ? exact / trap : 1;
+                lg2f_hi = lg2f_lo;
+            }
+            if (j_split > 0) {
+                const double delta = cdf_buf[j_split] - cdf_th[j_split];
+                for (int j = j_split - 1; j >= 0; --j) {
+                    fv_buf[j] = fv_th[j];
+                    ratio_buf[j] = ratio_th[j];
+                    cdf_buf[j] = cdf_th[j] + delta;
+                }
+            }
+            ACCUMULATE_IC_(dN_e_boost[i], ic->ic_idx0 - 2 * (long)IC_GAMMA_MULT * i, fv_buf);
+        }
+        free(corr_lat);
+        free(lg2corr_lat);
+    } else {
+        BUILD_CDF_TH_(cdf_buf, ratio_buf);
+        for (int i = 0; i < g_size; ++i) {
+            if (dN_e_boost[i] <= 0) continue;
+            ACCUMULATE_IC_(dN_e_boost[i], ic->ic_idx0 - 2 * (long)IC_GAMMA_MULT * i, fv_th);
+        }
+    }
+#undef BUILD_CDF_TH_
+#undef ACCUMULATE_IC_
+    const double log2_scale = log2(0.25 * C_SIGMAT);
+    for (int i = 0; i < n_ic; ++i) {
+        ic->log2_I_nu_IC[i] = log2(I_buf[i]) + ic->log2_nu_IC[i] + log2_scale;
+        if (i > 0) {
+            const double dl = ic->log2_nu_IC[i] - ic->log2_nu_IC[i - 1];
+            ic->interp_slope[i - 1] = (dl != 0) ? (ic->log2_I_nu_IC[i] - ic->log2_I_nu_IC[i - 1]) / dl : 0;
+        }
+    }
+    free(nu_seed); free(lg2_nu_seed); free(dnu_seed); free(gamma); free(lg2_gamma); free(dN_e_boost); free(I_nu_seed);
+    free(I_buf); free(cdf_buf); free(fv_buf); free(ratio_buf); free(fv_th); free(lg2fv_th); free(lg2r); free(inv_lg2r);
+    free(cdf_th); free(ratio_th);
+    ic->generated = 1;
+}
+
+/* ICPhoton::compute_log2_I_nu, inverse-compton.h:614-652 (band-contract rebuild included) */
+static double icphoton_log2_I_nu(icphoton_t* ic, double log2_nu) {
+    if (!ic->generated) icphoton_generate(ic);
+    int n = ic->n_ic;
+    if (n >= 2 && ((log2_nu > ic->log2_nu_IC[n - 1] && log2_nu < ic->log2_nu_theory_max) ||
+                   (log2_nu < ic->log2_nu_IC[0] && log2_nu > ic->log2_nu_theory_min))) {
+        ic->nu_eval_min = 0;
+        ic->nu_eval_max = INFINITY;
+        icphoton_generate(ic);
+        n = ic->n_ic;
+    }
+    if (n < 2 || log2_nu > ic->log2_nu_IC[n - 1]) return -INFINITY;
+    int idx = 0;
+    while (idx + 2 < n && ic->log2_nu_IC[idx + 1] <= log2_nu) ++idx;
+    return ic->log2_I_nu_IC[idx] + (log2_nu - ic->log2_nu_IC[idx]) * ic->interp_slope[idx];
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1467,8 +2039,17 @@ static int observed_window(const double* t_row, int t_grid, double w_lo, double 
     return 1;
 }
 
+/* photon-grid evaluator: log2 I_nu'(cell (j,k), log2 nu') -- synchrotron cells or SSC tables */
+typedef double (*cell_eval_fn)(void* grid, int j, int k, int t_grid, double log2_nu);
+static double eval_syn_cell(void* grid, int j, int k, int t_grid, double log2_nu) {
+    return compute_log2_I_nu((const photons_t*)grid + (size_t)j * t_grid + k, log2_nu);
+}
+static double eval_ic_cell(void* grid, int j, int k, int t_grid, double log2_nu) {
+    return icphoton_log2_I_nu((icphoton_t*)grid + (size_t)j * t_grid + k, log2_nu);
+}
+
 /* F[nnu][nt] in code units */
-static void specific_flux(const eat_t* o, const photons_t* ph, const double* t_obs, int nt_obs, const double* nu_obs,
+static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const double* t_obs, int nt_obs, const double* nu_obs,
                           int nnu, double* F) {
     const int t_grid = o->n_t;
     double* lg2_t_obs = malloc(sizeof(double) * nt_obs);
@@ -1487,12 +2068,11 @@ static void specific_flux(const eat_t* o, const photons_t* ph, const double* t_o
             const double* t_row = o->lg2_t + row;
             const double* dop_row = o->lg2_doppler + row;
             const double* geom_row = o->lg2_geom + row;
-            const photons_t* ph_row = ph + (size_t)j * t_grid; /* eff_i = 0: one phi slice */
-            int k_lo, k_hi;
+            int k_lo, k_hi; /* photons: eff_i = 0, one phi slice */
             if (!observed_window(t_row, t_grid, lg2_t_obs[0], lg2_t_obs[nt_obs - 1], &k_lo, &k_hi)) continue;
             for (int k = k_lo; k <= k_hi; ++k)
                 for (int l = 0; l < nnu; ++l)
-                    boundary[(size_t)k * nnu + l] = compute_log2_I_nu(&ph_row[k], lg2_nu_src[l] - dop_row[k]) + geom_row[k];
+                    boundary[(size_t)k * nnu + l] = eval(grid, j, k, t_grid, lg2_nu_src[l] - dop_row[k]) + geom_row[k];
 
             int t_idx = 0;
             iterate_to(t_row[0], lg2_t_obs, nt_obs, &t_idx);
@@ -1530,8 +2110,8 @@ static void specific_flux(const eat_t* o, const photons_t* ph, const double* t_o
 }
 
 /* F[n] in code units */
-static void specific_flux_series(const eat_t* o, const photons_t* ph, const double* t_obs, const double* nu_obs, int n,
-                                 double* F) {
+static void specific_flux_series(const eat_t* o, cell_eval_fn eval, void* grid, const double* t_obs, const double* nu_obs,
+                                 int n, double* F) {
     const int t_grid = o->n_t;
     double* lg2_t_obs = malloc(sizeof(double) * n);
     double* lg2_nu_src = malloc(sizeof(double) * n);
@@ -1548,7 +2128,6 @@ static void specific_flux_series(const eat_t* o, const photons_t* ph, const doub
             const double* t_row = o->lg2_t + row;
             const double* dop_row = o->lg2_doppler + row;
             const double* geom_row = o->lg2_geom + row;
-            const photons_t* ph_row = ph + (size_t)j * t_grid;
             int idx = 0;
             iterate_to(t_row[0], lg2_t_obs, n, &idx);
             const int col_first = idx;
@@ -1568,8 +2147,8 @@ static void specific_flux_series(const eat_t* o, const photons_t* ph, const doub
                         hi = prev_hi;
                     } else {
                         const int carried = (s == block_first && carry_k == k && carry_nu == lg2_nu);
-                        lo = carried ? carry_val : compute_log2_I_nu(&ph_row[k], lg2_nu - dop_row[k]) + geom_row[k];
-                        hi = compute_log2_I_nu(&ph_row[k + 1], lg2_nu - dop_row[k + 1]) + geom_row[k + 1];
+                        lo = carried ? carry_val : eval(grid, j, k, t_grid, lg2_nu - dop_row[k]) + geom_row[k];
+                        hi = eval(grid, j, k + 1, t_grid, lg2_nu - dop_row[k + 1]) + geom_row[k + 1];
                         prev_nu = lg2_nu;
                         prev_lo = lo;
                         prev_hi = hi;
@@ -1715,6 +2294,53 @@ static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_
     return 0;
 }
 
+/* generate_IC_photons with the per-k observation-band clamp of single_shock_emission
+ * (pybind/pymodel.h:896-914, inverse-compton.h:656-690): one ICPhoton per (theta, k), deep-copied across each
+ * symmetry group like broadcast_symmetry does. */
+static icphoton_t* make_ic_photons(pipeline_t* pl, const vag_model_params* p, const double* nu_obs, int nnu) {
+    const coord_t* c = &pl->coord;
+    const eat_t* o = &pl->eat;
+    const int nth = c->n_theta, nt = c->n_t;
+    const int kn = (p->flags & VAG_FLAG_KN) != 0;
+    double nu_lo = nu_obs[0], nu_hi = nu_obs[0];
+    for (int l = 1; l < nnu; ++l) {
+        if (nu_obs[l] < nu_lo) nu_lo = nu_obs[l];
+        if (nu_obs[l] > nu_hi) nu_hi = nu_obs[l];
+    }
+    const double lg2_1pz = log2(o->one_plus_z);
+    const double lg2_nu_lo = log2(nu_lo) + lg2_1pz, lg2_nu_hi = log2(nu_hi) + lg2_1pz;
+    icphoton_t* ic = calloc((size_t)nth * nt, sizeof(icphoton_t));
+    for (int k = 0; k < nt; ++k) {
+        double dmin_k = INFINITY, dmax_k = -INFINITY;
+        for (int i = 0; i < o->n_phi_eff; ++i)
+            for (int j = 0; j < nth; ++j) {
+                const double d = o->lg2_doppler[((size_t)i * nth + j) * nt + k];
+                if (d < dmin_k) dmin_k = d;
+                if (d > dmax_k) dmax_k = d;
+            }
+        const double nu_eval_min = exp2(lg2_nu_lo - dmax_k), nu_eval_max = exp2(lg2_nu_hi - dmin_k);
+        for (int r = 0; r < c->n_reps; ++r) {
+            const int j0 = c->reps[r];
+            const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
+            icphoton_t* q = &ic[(size_t)j0 * nt + k];
+            q->electrons = pl->el[(size_t)j0 * nt + k];
+            q->photons = pl->ph[(size_t)j0 * nt + k];
+            q->KN = kn;
+            q->nu_eval_min = nu_eval_min;
+            q->nu_eval_max = nu_eval_max;
+            q->log2_nu_theory_max = INFINITY;
+            q->log2_nu_theory_min = -INFINITY;
+            icphoton_generate(q); /* precompute = true: symmetry != structured */
+            for (int j = j0 + 1; j < j1; ++j) icphoton_copy(&ic[(size_t)j * nt + k], q);
+        }
+    }
+    return ic;
+}
+static void free_ic_photons(icphoton_t* ic, size_t n) {
+    for (size_t q = 0; q < n; ++q) icphoton_free(&ic[q]);
+    free(ic);
+}
+
 static int check_times(const double* t, int nt) {
     if (nt <= 0) return fail("time array must be non-empty");
     for (int i = 1; i < nt; ++i)
@@ -1731,8 +2357,9 @@ static void minmax(const double* a, int n, double* lo, double* hi) {
     }
 }
 
-int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
-                                 double* out) {
+/* fwd.sync -> out_sync, fwd.ssc -> out_ssc (may be NULL), each [nnu][nt] */
+int vag_oracle_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                            double* out, double* out_ssc) {
     if (check_times(t, nt) != 0) return -1;
     if (nnu <= 0) return fail("frequency array must be non-empty");
     double* t_obs = malloc(sizeof(double) * nt);
@@ -1744,12 +2371,34 @@ int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux(&pl.eat, pl.ph, t_obs, nt, nu_obs, nnu, out);
+        specific_flux(&pl.eat, eval_syn_cell, pl.ph, t_obs, nt, nu_obs, nnu, out);
         for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] = out[q] / U_FLUX_DEN_CGS;
+        if (out_ssc) {
+            for (size_t q = 0; q < (size_t)nnu * nt; ++q) out_ssc[q] = 0;
+            if (p->flags & VAG_FLAG_SSC) {
+                const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+                icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, nnu);
+                specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, nnu, out_ssc);
+                for (size_t q = 0; q < (size_t)nnu * nt; ++q) out_ssc[q] = out_ssc[q] / U_FLUX_DEN_CGS;
+                free_ic_photons(ic, ncell);
+            }
+        }
         pipeline_free(&pl);
     }
     free(t_obs);
     free(nu_obs);
+    return rc;
+}
+
+/* Model.flux_density_grid: total = fwd.sync + fwd.ssc (PyFlux::calc_total, pymodel.cpp:350-364) */
+int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                 double* out) {
+    if (!(p->flags & VAG_FLAG_SSC)) return vag_oracle_flux_density_grid_components(p, t, nt, nu, nnu, out, NULL);
+    double* ssc = malloc(sizeof(double) * (size_t)(nnu > 0 ? nnu : 1) * (nt > 0 ? nt : 1));
+    const int rc = vag_oracle_flux_density_grid_components(p, t, nt, nu, nnu, out, ssc);
+    if (rc == 0)
+        for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] += ssc[q];
+    free(ssc);
     return rc;
 }
 
@@ -1766,8 +2415,17 @@ int vag_oracle_flux_density(const vag_model_params* p, const double* t, const do
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux_series(&pl.eat, pl.ph, t_obs, nu_obs, n, out);
+        specific_flux_series(&pl.eat, eval_syn_cell, pl.ph, t_obs, nu_obs, n, out);
         for (int i = 0; i < n; ++i) out[i] = out[i] / U_FLUX_DEN_CGS;
+        if (p->flags & VAG_FLAG_SSC) {
+            const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+            double* ssc = malloc(sizeof(double) * n);
+            icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, n);
+            specific_flux_series(&pl.eat, eval_ic_cell, ic, t_obs, nu_obs, n, ssc);
+            for (int i = 0; i < n; ++i) out[i] += ssc[i] / U_FLUX_DEN_CGS;
+            free_ic_photons(ic, ncell);
+            free(ssc);
+        }
         pipeline_free(&pl);
     }
     free(t_obs);
@@ -1841,12 +2499,23 @@ int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double n
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux(&pl.eat, pl.ph, t_obs, nt, nu_obs, num_nu, F);
+        specific_flux(&pl.eat, eval_syn_cell, pl.ph, t_obs, nt, nu_obs, num_nu, F);
         compute_boole_weights(nu_obs, num_nu, w);
         for (int j = 0; j < nt; ++j) out[j] = 0;
         for (int i = 0; i < num_nu; ++i)
             for (int j = 0; j < nt; ++j) out[j] += F[(size_t)i * nt + j] * w[i];
         for (int j = 0; j < nt; ++j) out[j] = out[j] / U_FLUX_CGS;
+        if (p->flags & VAG_FLAG_SSC) {
+            const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+            icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, num_nu);
+            specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, num_nu, F);
+            double* band = calloc(nt, sizeof(double));
+            for (int i = 0; i < num_nu; ++i)
+                for (int j = 0; j < nt; ++j) band[j] += F[(size_t)i * nt + j] * w[i];
+            for (int j = 0; j < nt; ++j) out[j] += band[j] / U_FLUX_CGS;
+            free(band);
+            free_ic_photons(ic, ncell);
+        }
         pipeline_free(&pl);
     }
     free(t_obs);

@@ -21,6 +21,9 @@ const char* vag_oracle_last_error(void);
 /* Model.flux_density_grid: out[nnu][nt]  (pybind/pymodel.cpp:498-514) */
 int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
                                  double* out);
+/* fwd.sync and fwd.ssc components of the grid (out_ssc may be NULL), each [nnu][nt] */
+int vag_oracle_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                            double* out_sync, double* out_ssc);
 /* Model.flux_density: out[n]  (pybind/pymodel.cpp:373-389) */
 int vag_oracle_flux_density(const vag_model_params* p, const double* t, const double* nu, int n, double* out);
 /* Model.flux: out[nt]  (pybind/pymodel.cpp:391-410) */

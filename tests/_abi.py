@@ -27,7 +27,7 @@ class ModelParams(C.Structure):
         ("lumi_dist", C.c_double), ("z", C.c_double), ("theta_obs", C.c_double),
         ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
-        ("radiative_fireball", C.c_int32), ("reserved", C.c_int32),
+        ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -47,7 +47,7 @@ class DetailsOut(C.Structure):
 def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
-                xi_e=1.0, resolutions=(0.06, 0.15, 6.0), rtol=1e-6, radiative_fireball=True):
+                xi_e=1.0, resolutions=(0.06, 0.15, 6.0), rtol=1e-6, radiative_fireball=True, ssc=False, kn=False):
     """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
     q = ModelParams()
     q.jet_type = JET_IDS[jet] if isinstance(jet, str) else int(jet)
@@ -60,7 +60,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
     q.phi_resol, q.theta_resol, q.t_resol = resolutions
     q.rtol = rtol
     q.radiative_fireball = 1 if radiative_fireball else 0
-    q.reserved = 0
+    q.flags = (1 if ssc else 0) | (2 if kn else 0)
     return q
 
 
@@ -69,10 +69,12 @@ def params_from_golden_config(cfg):
     jet = dict(cfg["jet"])
     med = dict(cfg["medium"])
     kw = dict(jet=jet.pop("type"), medium=med.pop("type"))
+    if kw["medium"] == "Wind":
+        kw["n_ism"] = 0.0  # Wind(A_star, n_ism=None, n0=None): pybind/pymodel.cpp:153-166
     kw.update(jet)
     kw.update(med)
     kw.update(cfg["observer"])
-    kw.update(cfg["fwd_rad"])
+    kw.update(cfg["fwd_rad"])  # includes ssc / kn
     if "resolutions" in cfg:
         kw["resolutions"] = tuple(cfg["resolutions"])
     if "radiative_fireball" in cfg:
@@ -134,6 +136,17 @@ class CpuLib:
         self._check(getattr(self.lib, self.prefix + "_flux")(C.byref(prm), _p(t), t.size, nu_min, nu_max,
                                                               num_nu, _p(out)))
         return out
+
+    def flux_components(self, prm, t, nu):
+        """(fwd_sync, fwd_ssc) grids [nnu][nt]; fwd_ssc is zeros when Radiation.ssc is off."""
+        fn = getattr(self.lib, self.prefix + "_flux_density_grid_components")
+        fn.argtypes = [C.POINTER(ModelParams), _dp, C.c_int, _dp, C.c_int, _dp, _dp]
+        fn.restype = C.c_int
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        sync, ssc = np.zeros((nu.size, t.size)), np.zeros((nu.size, t.size))
+        self._check(fn(C.byref(prm), _p(t), t.size, _p(nu), nu.size, _p(sync), _p(ssc)))
+        return sync, ssc
 
     def flux_density_exposures(self, prm, t, nu, expo, num_points=10):
         fn = getattr(self.lib, self.prefix + "_flux_density_exposures")

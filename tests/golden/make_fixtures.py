@@ -48,6 +48,22 @@ def main():
         meta[name + "__shape"] = d["shape"]
         for k in ("phi", "theta", "t_src", "Gamma", "r", "B", "N_p", "Gamma_th", "nu_m", "nu_c", "nu_a", "I_nu_max"):
             out[f"{name}__details_{k}"] = np.asarray(d[k])
+    # SSC tier: components of a C5-like two-component SSC model and a KN Gaussian model
+    import numpy as _np
+    ssc_cases = {
+        "C5_central": (dict(jet="TwoComponentJet", theta_c=0.065, E_iso=1e52, Gamma0=300.0, theta_w=0.35, E_iso_w=1e50,
+                            Gamma0_w=60.0, medium="ISM", n_ism=1.0, lumi_dist=1e28, z=1.0, theta_obs=0.15, eps_e=0.1,
+                            eps_B=0.01, p=2.3, ssc=True, kn=False, resolutions=(0.59, 0.98, 12.0)),
+                       _np.logspace(2, 8, 100), _np.array([1e9, 4.84e14, 1e18, 2.4e26])),
+        "ssc_kn_gaussian": (dict(jet="GaussianJet", theta_obs=0.2, eps_B=1e-4, ssc=True, kn=True),
+                            _np.logspace(2, 8, 40), _np.array([1e9, 1e14, 1e18, 1e22, 2.4e26])),
+    }
+    for name, (kw, t, nu) in ssc_cases.items():
+        prm = _abi.make_params(**kw)
+        sync, ssc = ref.flux_components(prm, t, nu)
+        out[f"{name}__t"], out[f"{name}__nu"] = t, nu
+        out[f"{name}__sync"], out[f"{name}__ssc"] = sync, ssc
+        meta[name] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
     out["meta"] = json.dumps(meta)
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)

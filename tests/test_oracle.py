@@ -38,6 +38,22 @@ def test_oracle_matches_reference_goldens(oracle, name):
     assert g["fwd_ssc"].shape == () and g["rvs_sync"].shape == () and float(g["fwd_ssc"]) == 0.0
 
 
+@pytest.mark.parametrize("name", ["gauss_wind_ssc", "dense_ism_ssa_ssc", "ism_absorbed_slow_ssc"])
+def test_oracle_ssc_matches_reference_goldens(oracle, name):
+    """SSC + Klein-Nishina goldens of the reference (all orderings of nu_a / nu_m / nu_c in the seed spectrum):
+    synchrotron with IC cooling, the SSC component and their total."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    prm = _abi.params_from_golden_config(json.loads(str(g["config"])))
+    assert prm.flags == 3
+    sync, ssc = oracle.flux_components(prm, g["t"], g["nus"])
+    total = oracle.flux_density_grid(prm, g["t"], g["nus"])
+    for got, comp in ((sync, "fwd_sync"), (ssc, "fwd_ssc"), (total, "total")):
+        want = g[comp]
+        assert np.all(np.abs(got - want) <= RTOL * np.abs(want) + ATOL_PEAK * np.abs(want).max())
+        assert rel_bright(got, want, 1e-2) < 2e-6
+    np.testing.assert_allclose(total, sync + ssc, rtol=1e-15)
+
+
 @pytest.fixture(scope="module")
 def vectors():
     return np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
@@ -52,6 +68,17 @@ def test_oracle_matches_committed_reference_vectors(oracle, vectors, name):
     prm = _abi.make_params(**meta)
     got = oracle.flux_density_grid(prm, vectors[f"{name}__t"], vectors[f"{name}__nu"])
     assert rel_bright(got, vectors[f"{name}__grid"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["C5_central", "ssc_kn_gaussian"])
+def test_oracle_ssc_matches_committed_reference_vectors(oracle, vectors, name):
+    meta = json.loads(str(vectors["meta"]))[name]
+    if "resolutions" in meta:
+        meta["resolutions"] = tuple(meta["resolutions"])
+    prm = _abi.make_params(**meta)
+    sync, ssc = oracle.flux_components(prm, vectors[f"{name}__t"], vectors[f"{name}__nu"])
+    assert rel_bright(sync, vectors[f"{name}__sync"]) < 2e-6
+    assert rel_bright(ssc, vectors[f"{name}__ssc"], 1e-9) < 2e-5  # SSC grids are coarse: contraction noise is larger
 
 
 def test_oracle_series_band_and_details_vs_reference_vectors(oracle, vectors):
@@ -101,6 +128,27 @@ def test_oracle_series_and_band_bit_identical_to_strict_reference_build(oracle, 
     assert np.array_equal(oracle.flux_density(prm, t, nu), ref_strict.flux_density(prm, t, nu))
     assert np.array_equal(oracle.flux(prm, configs.C4_EPOCHS, 1e14, 1e15, 16),
                           ref_strict.flux(prm, configs.C4_EPOCHS, 1e14, 1e15, 16))
+
+
+SSC_LIVE = {
+    "thomson_only": dict(jet="TophatJet", theta_obs=0.0, eps_B=1e-3, ssc=True, kn=False),
+    "kn_gaussian_offaxis": dict(jet="GaussianJet", theta_obs=0.2, eps_B=1e-4, ssc=True, kn=True),
+    "kn_two_component": dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, theta_obs=0.15,
+                             ssc=True, kn=True, resolutions=(0.1, 0.2, 6.0)),
+    "kn_wind_fast_cooling": dict(jet="TophatJet", medium="Wind", A_star=1.0, n_ism=0.0, eps_B=0.1, eps_e=0.3, ssc=True, kn=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SSC_LIVE))
+def test_oracle_ssc_bit_identical_to_strict_reference_build(oracle, ref_strict, name):
+    prm = _abi.make_params(**SSC_LIVE[name])
+    t, nu = np.logspace(2, 8, 24), np.array([1e9, 1e14, 1e18, 1e22, 2.4e26])
+    s, c = oracle.flux_components(prm, t, nu)
+    s2, c2 = ref_strict.flux_components(prm, t, nu)
+    assert np.array_equal(s, s2) and np.array_equal(c, c2) and c.max() > 0
+    assert np.array_equal(oracle.flux_density_grid(prm, t, nu), ref_strict.flux_density_grid(prm, t, nu))
+    ts, nus = np.repeat(t, 2), np.tile(nu[[1, 3]], t.size)
+    assert np.array_equal(oracle.flux_density(prm, ts, nus), ref_strict.flux_density(prm, ts, nus))
 
 
 @pytest.mark.parametrize("name,kw,t,nu", LIVE, ids=[c[0] for c in LIVE])

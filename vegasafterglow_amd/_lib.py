@@ -32,7 +32,7 @@ class ModelParams(C.Structure):
         ("lumi_dist", C.c_double), ("z", C.c_double), ("theta_obs", C.c_double),
         ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
-        ("radiative_fireball", C.c_int32), ("reserved", C.c_int32),
+        ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
     ]
 
 

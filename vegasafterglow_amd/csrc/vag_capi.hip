@@ -154,7 +154,7 @@ static const char* validate_msg(const vag_model_params* p) {
     if (!(std::isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return "rtol must be in (0, 1)";
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
         return "resolutions must be positive and finite";
-    if (p->reserved != 0) return "reserved field must be 0";
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN)) return "unknown bits set in flags";
     return nullptr;
 }
 

@@ -219,6 +219,7 @@ class Model:
         p.phi_resol, p.theta_resol, p.t_resol = res
         p.rtol = self.rtol
         p.radiative_fireball = 1 if radiative_fireball else 0
+        p.flags = 0
         _lib.check(_lib.load().vag_params_validate(C.byref(p)))
         self.params = p
 
