@@ -46,7 +46,8 @@ extern "C" {
 #define VAG_JET_TWO_COMPONENT 3
 
 /* Radiation flags.  Inverse-Compton cooling + SSC emission (src/radiation/inverse-compton.*) is SURVEY 8(f) rank 1:
- * the CPU checkers implement it; the device engine returns VAG_E_UNSUPPORTED for it until its kernels land. */
+ * on the device for flux_density_grid / flux (grid and band forms); the series form and the batched log-likelihood
+ * still return VAG_E_UNSUPPORTED with these flags. */
 #define VAG_FLAG_SSC 1
 #define VAG_FLAG_KN 2
 
@@ -139,6 +140,11 @@ void vag_get_limits(vag_limits* out);
 int vag_flux_density_grid_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
                                 const double* nu, int nnu, double* out);
 
+/* Same request with the components kept apart: out_sync = FluxDict.fwd.sync, out_ssc = FluxDict.fwd.ssc (zeros when
+ * Radiation.ssc is off), each [nb][nnu][nt] (pybind/pybind.cpp:472-483).  nt * nnu <= 4096. */
+int vag_flux_density_grid_components_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
+                                           const double* nu, int nnu, double* out_sync, double* out_ssc);
+
 /*
  * Model.flux_density(t[n] ascending, nu[n]) -> total[n]
  * (pybind/pybind.cpp:427, pybind/pymodel.cpp:373-389, src/core/observer.h:447-538),
@@ -154,6 +160,9 @@ int vag_flux_density_batch(vag_ctx* ctx, const vag_model_params* params, int nb,
  */
 int vag_flux_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                    double nu_max, int num_nu, double* out);
+/* Same with the components apart: out_sync = fwd.sync, out_ssc = fwd.ssc, each [nb][nt]. */
+int vag_flux_components_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
+                              double nu_min, double nu_max, int num_nu, double* out_sync, double* out_ssc);
 
 /* Device-pointer forms: params/t/nu/out are HBM addresses; asynchronous on the context stream. */
 int vag_flux_density_grid_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,

@@ -110,7 +110,9 @@ def test_constructor_validation_matches_reference_error_types():
     with pytest.raises(ValueError):
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, resolutions=(0.0, 0.15, 6))
     with pytest.raises(NotImplementedError):  # out-of-scope tiers fail loudly instead of silently degrading
-        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3, ssc=True))
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=va.Radiation(0.1, 0.01, 2.3))
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3, ssc=True, kn=True))
+    assert m.params.flags == 3  # VAG_FLAG_SSC | VAG_FLAG_KN
 
 
 def test_model_flattens_to_the_same_struct_as_the_test_helper():

@@ -267,3 +267,102 @@ def test_capacity_and_argument_errors_are_loud(eng):
     with pytest.raises(ValueError):
         gpu_grid(eng, _abi.make_params(theta_c=-1.0), configs.C1_T, configs.C1_NU)
     assert prm.phi_resol == 5.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SSC / inverse-Compton tier: Radiation(ssc=True[, kn=True])
+# ---------------------------------------------------------------------------------------------------------------
+def gpu_components(eng, prms, t, nu):
+    lib, h = eng
+    prms = prms if isinstance(prms, (list, tuple)) else [prms]
+    arr = (_lib.ModelParams * len(prms))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    sync, ssc = np.empty((len(prms), nu.size, t.size)), np.empty((len(prms), nu.size, t.size))
+    _lib.check(lib.vag_flux_density_grid_components_batch(h, arr, len(prms), t.ctypes.data_as(dp), t.size,
+                                                          nu.ctypes.data_as(dp), nu.size, sync.ctypes.data_as(dp),
+                                                          ssc.ctypes.data_as(dp)))
+    return sync, ssc
+
+
+SSC_T = np.logspace(2, 7, 24)
+SSC_NU = np.array([1e9, 1e14, 1e17, 1e20, 1e23])
+SSC_CASES = {
+    "gauss_thomson": dict(jet="GaussianJet", theta_obs=0.2, ssc=True),
+    "gauss_kn": dict(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True),
+    "tophat_kn_weakB": dict(E_iso=1e53, n_ism=0.1, eps_B=1e-4, ssc=True, kn=True),
+    "powerlaw_wind_kn": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, k_e=2.0, k_g=2.0, theta_obs=0.3,
+                             eps_B=1e-3, ssc=True, kn=True),
+    "two_component_thomson": dict(jet="TwoComponentJet", theta_c=0.065, theta_w=0.35, E_iso_w=1e50, Gamma0_w=60.0,
+                                  theta_obs=0.15, ssc=True, resolutions=(0.59, 0.98, 12.0)),
+    "kn_flag_without_ssc": dict(jet="GaussianJet", theta_obs=0.2, kn=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SSC_CASES))
+def test_ssc_components_match_oracle(eng, oracle, name):
+    prm = _abi.make_params(**SSC_CASES[name])
+    want_sync, want_ssc = oracle.flux_components(prm, SSC_T, SSC_NU)
+    sync, ssc = gpu_components(eng, prm, SSC_T, SSC_NU)
+    assert_close(sync[0], want_sync)
+    if want_ssc.max() > 0:
+        assert_close(ssc[0], want_ssc)
+    else:
+        assert np.all(ssc[0] == 0)
+    total = gpu_grid(eng, prm, SSC_T, SSC_NU)[0]
+    assert_close(total, want_sync + want_ssc)
+
+
+@pytest.mark.parametrize("name", ["gauss_wind_ssc", "dense_ism_ssa_ssc", "ism_absorbed_slow_ssc"])
+def test_ssc_reference_golden_contract(eng, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    prm = _abi.params_from_golden_config(json.loads(str(g["config"])))
+    sync, ssc = gpu_components(eng, prm, g["t"], g["nus"])
+    for got, want in ((sync[0], g["fwd_sync"]), (ssc[0], g["fwd_ssc"]), (sync[0] + ssc[0], g["total"])):
+        assert np.all(np.abs(got - want) <= 2e-3 * np.abs(want) + 1e-2 * np.abs(want).max())
+        assert_close(got, want, rtol=2e-6, floor=1e-2)
+
+
+def test_ssc_committed_reference_vectors(eng):
+    v = np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
+    meta = json.loads(str(v["meta"]))
+    for name in ("C5_central", "ssc_kn_gaussian"):
+        kw = dict(meta[name])
+        if "resolutions" in kw:
+            kw["resolutions"] = tuple(kw["resolutions"])
+        t, nu = v[f"{name}__t"], v[f"{name}__nu"]
+        sync, ssc = gpu_components(eng, _abi.make_params(**kw), t, nu)
+        assert_close(sync[0], v[f"{name}__sync"])
+        assert_close(ssc[0], v[f"{name}__ssc"], floor=1e-9)
+
+
+def test_ssc_batch_band_model_api_and_loud_limits(eng, oracle):
+    lib, h = eng
+    names = ["gauss_kn", "tophat_kn_weakB", "two_component_thomson"]
+    prms = [_abi.make_params(**{**SSC_CASES[n], "ssc": True, "kn": True}) for n in names]
+    sync, ssc = gpu_components(eng, prms, SSC_T, SSC_NU)
+    for i in range(3):
+        s1, c1 = gpu_components(eng, prms[i], SSC_T, SSC_NU)
+        assert np.array_equal(sync[i], s1[0]) and np.array_equal(ssc[i], c1[0])  # ragged batch == single calls, bitwise
+    # Model.flux (band integral) with SSC: total and components
+    t = np.logspace(3, 6, 12)
+    m = va.Model(va.GaussianJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2),
+                 va.Radiation(0.1, 0.01, 2.3, ssc=True, kn=True))
+    prm = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True)
+    band = m.flux(t, 1e17, 1e19, 9)
+    assert_close(band.total, oracle.flux(prm, t, 1e17, 1e19, 9))
+    assert np.all(band.fwd.ssc > 0) and np.allclose(band.total, band.fwd.sync + band.fwd.ssc, rtol=1e-15)
+    fd = m.flux_density_grid(SSC_T, SSC_NU)
+    o_sync, o_ssc = oracle.flux_components(prm, SSC_T, SSC_NU)
+    assert_close(fd.fwd.sync, o_sync)
+    assert_close(fd.fwd.ssc, o_ssc)
+    assert_close(fd.total, o_sync + o_ssc)
+    # limits fail loudly: mixed Radiation flags in one batch, SSC in the series / log-likelihood forms
+    mixed = (_lib.ModelParams * 2)(_lib.ModelParams.from_buffer_copy(bytes(prm)),
+                                   _lib.ModelParams.from_buffer_copy(bytes(_abi.make_params(jet="GaussianJet"))))
+    out = np.empty((2, SSC_NU.size, SSC_T.size))
+    rc = lib.vag_flux_density_grid_batch(h, mixed, 2, SSC_T.ctypes.data_as(dp), SSC_T.size, SSC_NU.ctypes.data_as(dp),
+                                         SSC_NU.size, out.ctypes.data_as(dp))
+    assert rc == _lib.VAG_E_UNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        m.flux_density(t, np.full(t.size, 1e17))

@@ -13,6 +13,7 @@ JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT = 0, 1, 2, 3
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
+FLAG_SSC, FLAG_KN = 1, 2  # VAG_FLAG_* of include/vegasafterglow_amd.h
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
 PARAM_SLOTS = {
@@ -73,7 +74,7 @@ class Limits(C.Structure):
 EXPORTS = [
     "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
     "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
-    "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_batch", "vag_flux_batch",
+    "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
     "vag_details", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
@@ -106,8 +107,10 @@ def load():
     lib.vag_get_limits.argtypes = [C.POINTER(Limits)]
     lib.vag_get_limits.restype = None
     lib.vag_flux_density_grid_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]
+    lib.vag_flux_density_grid_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
     lib.vag_flux_density_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, _dp]
     lib.vag_flux_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]
+    lib.vag_flux_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]
     lib.vag_flux_density_grid_batch_dev.argtypes = [v, v, C.c_int, v, C.c_int, v, C.c_int, v]
     lib.vag_flux_density_batch_dev.argtypes = [v, v, C.c_int, v, v, C.c_int, v]
     lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
@@ -135,4 +138,6 @@ def check(rc):
         raise RuntimeError("vegasafterglow_amd needs a HIP device (no CPU path): " + msg)
     if rc == VAG_E_CAPACITY:
         raise ValueError("engine capacity exceeded: " + msg)
+    if rc == VAG_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
     raise RuntimeError(f"vegasafterglow_amd error {rc}: {msg}")

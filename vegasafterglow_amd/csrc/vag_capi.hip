@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "vag_ic_kernels.h"
 #include "vag_kernels.h"
 
 using namespace vag;
@@ -209,8 +210,9 @@ static double build_softplus_table(std::vector<double>& tab) {
 
 struct vag_ctx {
     int device = 0;
-    DevBuf d_sptab, d_workcount;
+    DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_ssc;
     bool count_work = false;
+    int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -297,10 +299,33 @@ int vag_ctx_create(int device, vag_ctx** out) {
     c->stream = c->own_stream;
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     // allow the flux kernels the full 160 KiB LDS of a gfx950 CU
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_grid_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (const void* fn : {reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<true, FLUX_SYN>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC>)})
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {   // Klein-Nishina cross-section table (ComptonSigmaLUT, src/radiation/inverse-compton.cpp:285-300): request-independent
+        std::vector<double> lut(2 * KN_LUT_N);
+        const double step = (KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1);
+        for (int i = 0; i < KN_LUT_N; ++i) {
+            const double x = std::exp2(KN_LG2_XMIN + step * (double)i);
+            double ratio;
+            if (x < 1e-2) {
+                ratio = 1 - 2 * x;
+            } else if (x > 1e2) {
+                ratio = 3. / 8 * (std::log(2 * x) + 0.5) / x;
+            } else {
+                const double l = std::log1p(2.0 * x), invx = 1.0 / x, invx2 = invx * invx;
+                const double invt1 = 1.0 / (1.0 + 2.0 * x), invt1_2 = invt1 * invt1;
+                ratio = 0.75 * ((1.0 + x) * invx2 * invx * (2.0 * x * (1.0 + x) * invt1 - l) + 0.5 * l * invx -
+                                (1.0 + 3.0 * x) * invt1_2);
+            }
+            lut[i] = ratio;
+            lut[KN_LUT_N + i] = std::log2(ratio);
+        }
+        if (c->d_knlut.ensure(sizeof(double) * lut.size())) return VAG_E_HIP;
+        HIPCHK(hipMemcpy(c->d_knlut.p, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_series_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
@@ -318,7 +343,8 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+    for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
+                      &c->d_icstatus, &c->d_ssc, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -417,6 +443,16 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     }
     h_row[nb] = rows;
     h_cell[nb] = cells;
+    {
+        int flags = -1;
+        for (int m = 0; m < nb; ++m)
+            if (hm[m].status == 0) {
+                if (flags < 0) flags = hm[m].flags;
+                if (hm[m].flags != flags)
+                    return set_err(VAG_E_UNSUPPORTED, "models with different Radiation(ssc, kn) flags in one batch");
+            }
+        c->batch_flags = flags < 0 ? 0 : flags;
+    }
     c->nb = nb;
     c->n_rows = rows;
     c->n_cells = cells;
@@ -443,7 +479,9 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_shock.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
     if (c->d_cellpar.ensure(sizeof(double) * (size_t)cells * VAG_NPAR)) return VAG_E_HIP;
     if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
-    if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * 11)) return VAG_E_HIP;
+    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+    if (ssc) want_details = true;  // the cooling pass works on the electron arrays
+    if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * VAG_NDET)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
     hipLaunchKernelGGL(vag_dynamics_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
                        c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
@@ -454,6 +492,18 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                        c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
                        want_details ? c->d_celldet.as<double>() : nullptr);
     HIPCHK(hipGetLastError());
+    if (ssc) {  // apply_ic_cooling (pybind/pymodel.h:567-577): cool the electrons row by row, then rebuild the photons
+        if (c->d_icy.ensure(sizeof(double) * (size_t)cells * VAG_NICY)) return VAG_E_HIP;
+        if (c->d_cellq.ensure(sizeof(double) * (size_t)cells * VAG_NQ)) return VAG_E_HIP;
+        hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                           c->d_icy.as<double>());
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                           c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev[3], st));
     return VAG_OK;
 }
@@ -476,7 +526,7 @@ int choose_pairs_per_block(const vag_ctx* c) {
 
 // Stage 4-5 for a (t, nu) grid request: d_lg2t/d_lg2nu are log2 of code-unit times / frequencies.
 int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt,
-                  const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out) {
+                  const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN) {
     hipStream_t st = c->stream;
     const int slots = nt * nnu;
     if (slots > FLUX_MAX_SLOTS)
@@ -485,7 +535,8 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + 2 * nt + nnu + SP_TABLE_DOUBLES + slots) +
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4 + (mode == FLUX_SYN_IC ? VAG_NQ : 0)) * ks + (size_t)ks * nnu +
+                                         2 * nt + nnu + SP_TABLE_DOUBLES + slots) +
                        sizeof(int) * nt;
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     FluxArgs a;
@@ -506,7 +557,10 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.partial = c->d_partial.as<double>();
     a.sp_table = c->d_sptab.as<double>();
     a.work_count = nullptr;
-    if (c->count_work) {
+    a.cellq = c->d_cellq.as<double>();
+    a.ictab = c->d_ictab.as<double>();
+    a.ic_status = c->d_icstatus.as<int>();
+    if (c->count_work && mode == FLUX_SYN) {
         if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
         HIPCHK(hipMemsetAsync(c->d_workcount.p, 0, 2 * sizeof(unsigned long long), st));
         a.work_count = c->d_workcount.as<unsigned long long>();
@@ -518,14 +572,18 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = ppb;
     if (c->n_rows > 0) {
-        if (a.work_count)
-            hipLaunchKernelGGL(vag_flux_grid_kernel<true>, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        if (mode == FLUX_SYN_IC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (mode == FLUX_SSC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (a.work_count)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<true, FLUX_SYN>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         else
-            hipLaunchKernelGGL(vag_flux_grid_kernel<false>, dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
-    if (c->count_work) {
+    if (a.work_count) {
         unsigned long long h[2];
         HIPCHK(hipMemcpyAsync(h, c->d_workcount.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -537,6 +595,71 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
                        c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
+    return VAG_OK;
+}
+
+__global__ void vag_add_kernel(double* __restrict__ out, const double* __restrict__ add, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] += add[i];
+}
+
+// SSC emission of the whole batch on a (t, nu) grid (single_shock_emission, pybind/pymodel.h:896-919):
+// observation band per k -> SSC table per representative cell -> EAT flux integration over the tables.
+int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
+                 int nnu, const double* d_bandw, double* d_ssc) {
+    hipStream_t st = c->stream;
+    if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
+    if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
+    if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
+    HIPCHK(hipMemsetAsync(c->d_icstatus.p, 0, sizeof(int) * (size_t)nb, st));
+    if (c->n_rows > 0) {
+        Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+        hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
+                           c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
+                           c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>());
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
+                           c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_band.as<double>(), c->d_sptab.as<double>(),
+                           c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>());
+        HIPCHK(hipGetLastError());
+    }
+    int rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
+    if (rc) return rc;
+    std::vector<int> h(nb);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_icstatus.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int m = 0; m < nb; ++m) {
+        if (h[m] & 1) return set_err(VAG_E_CAPACITY, "model %d: SSC lattices exceed the engine limits", m);
+        if (h[m] & 2)
+            return set_err(VAG_E_UNSUPPORTED, "model %d: SSC query left the clamped band (the reference would rebuild the cell)", m);
+    }
+    return VAG_OK;
+}
+
+// Grid request for a batch: fwd.sync -> d_sync, fwd.ssc -> d_ssc (zeros without SSC), or their sum into d_sync when
+// d_ssc == nullptr.  (t, nu) prepared; model stages already run.
+int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw, double* d_sync,
+                 double* d_ssc) {
+    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+    const size_t n_out = (size_t)nb * (d_bandw ? nt : (size_t)nt * nnu);
+    int rc = run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, d_sync,
+                           ssc ? FLUX_SYN_IC : FLUX_SYN);
+    if (rc) return rc;
+    if (!ssc) {
+        if (d_ssc) HIPCHK(hipMemsetAsync(d_ssc, 0, sizeof(double) * n_out, c->stream));
+        return VAG_OK;
+    }
+    double* tmp = d_ssc;
+    if (!tmp) {
+        if (c->d_ssc.ensure(sizeof(double) * n_out)) return VAG_E_HIP;
+        tmp = c->d_ssc.as<double>();
+    }
+    rc = run_flux_ssc(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, tmp);
+    if (rc) return rc;
+    if (!d_ssc) {  // PyFlux::calc_total (pymodel.cpp:350-364): total = fwd.sync + fwd.ssc
+        hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_sync, tmp, n_out);
+        HIPCHK(hipGetLastError());
+    }
     return VAG_OK;
 }
 
@@ -672,7 +795,8 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     if (rc) return rc;
     // chunk the time axis so each launch keeps its (idx, l) slots in registers
     const int chunk = std::max(1, 4096 / nnu);  // keeps the LDS accumulator <= 32 KiB
-    if (nt <= chunk) return run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, nullptr, d_out);
+    if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
+    if (c->batch_flags & VAG_FLAG_SSC) return set_err(VAG_E_CAPACITY, "SSC requests need nt * nnu <= 4096 per call");
     // chunks write [nb][nnu][chunk] blocks; assemble into [nb][nnu][nt]
     DevBuf tmp;
     if (tmp.ensure(sizeof(double) * (size_t)nb * nnu * chunk)) return VAG_E_HIP;
@@ -697,6 +821,8 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
+    if (c->batch_flags & VAG_FLAG_SSC)
+        return set_err(VAG_E_UNSUPPORTED, "SSC for the (t, nu) series form is not on the device yet; use flux_density_grid");
     const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
     if (n <= chunk) return run_flux_series(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
     DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
@@ -736,6 +862,36 @@ int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int 
     return check_status(c, nb);
 }
 
+int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
+                                           const double* nu, int nnu, double* out_sync, double* out_ssc) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
+    if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
+    int rc = check_host_inputs(params, nb, t, nt);
+    if (rc) return rc;
+    if ((long long)nt * nnu > 4096) return set_err(VAG_E_CAPACITY, "component requests need nt * nnu <= 4096 per call");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n_out = (size_t)nb * nnu * nt;
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
+    if (c->d_nu.ensure(sizeof(double) * nnu)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * 2 * n_out)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * nnu, hipMemcpyHostToDevice, c->stream));
+    rc = prep_times(c, c->d_t.as<double>(), nt, c->d_nu.as<double>(), nnu);
+    if (rc) return rc;
+    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
+    if (rc) return rc;
+    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, nnu, nullptr, c->d_out.as<double>(),
+                      c->d_out.as<double>() + n_out);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_sync, c->d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out_ssc, c->d_out.as<double>() + n_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return check_status(c, nb);
+}
+
 int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu, int n,
                            double* out) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
@@ -758,8 +914,9 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     return check_status(c, nb);
 }
 
-int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
-                   double nu_max, int num_nu, double* out) {
+// Model.flux for a batch; out_ssc == nullptr -> out receives the total, otherwise (fwd.sync, fwd.ssc) apart.
+static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                          double nu_max, int num_nu, double* out, double* out_ssc) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (!(nu_min > 0)) return set_err(VAG_E_INVALID, "nu_min must be positive");
     if (!(nu_max > nu_min)) return set_err(VAG_E_INVALID, "nu_max must be greater than nu_min");
@@ -813,7 +970,7 @@ int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const dou
     if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
     if (c->d_nu.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
     if (c->d_bandw.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
-    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt * 2)) return VAG_E_HIP;
     HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nu.p, nu_cgs.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
@@ -826,13 +983,26 @@ int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const dou
     HIPCHK(hipMemcpyAsync(c->d_lg2nu.p, lg2nu.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
-    rc = run_flux_grid(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), num_nu,
-                       c->d_bandw.as<double>(), c->d_out.as<double>());
+    double* d_ssc = out_ssc ? c->d_out.as<double>() + (size_t)nb * nt : nullptr;
+    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, num_nu, c->d_bandw.as<double>(), c->d_out.as<double>(),
+                      d_ssc);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * nt, hipMemcpyDeviceToHost, c->stream));
+    if (out_ssc) HIPCHK(hipMemcpyAsync(out_ssc, d_ssc, sizeof(double) * (size_t)nb * nt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)collect_times(c);
     return check_status(c, nb);
+}
+
+int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                   double nu_max, int num_nu, double* out) {
+    return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, out, nullptr);
+}
+
+int vag_flux_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                              double nu_max, int num_nu, double* out_sync, double* out_ssc) {
+    if (!out_ssc) return set_err(VAG_E_INVALID, "out_ssc must not be null");
+    return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, out_sync, out_ssc);
 }
 
 static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
@@ -882,6 +1052,8 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     if (rc) return rc;
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
+    if (c->batch_flags & VAG_FLAG_SSC)
+        return set_err(VAG_E_UNSUPPORTED, "SSC in the batched log-likelihood is not on the device yet");
     rc = run_flux_series(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
                          c->d_series_flux.as<double>());
     if (rc) return rc;

@@ -30,7 +30,8 @@ struct VagGridMeta {
     int32_t n_phi_eff;    // Observer::eff_phi_grid (observer.cpp:218-222)
     int32_t t_num_tot;    // lattice nodes without the early point
     int32_t has_early;    // extra early node at index 0 (grid-refinement.h:583-591)
-    int32_t pad0, pad1;
+    int32_t flags;        // VAG_FLAG_* of the model (the host checks they are uniform over a batch)
+    int32_t pad1;
     double t_early;  // engine frame, code units
     double t_start;  // min_t_start
     double t_end;    // 1.01 t_max / (1+z)

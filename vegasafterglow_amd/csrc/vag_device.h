@@ -447,61 +447,9 @@ struct CellOut {
     double gamma_m, gamma_c, gamma_a, gamma_M, N_e, column_den, nu_m, nu_c, nu_a, nu_M, I_nu_max;
 };
 
-VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
-                      double N_p, double eps_e, double p, double xi_e) {
-    // --- electrons (synchrotron.cpp:315-360) ---
-    const double gamma_M = (B == 0) ? INFINITY : sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + 0.)));
-    const double gamma_ave_m1 = eps_e * (Gamma_th - 1) * (C_MP / C_ME) / xi_e;
-    double gm_m1;
-    if (p > 2) {
-        gm_m1 = (p - 2) / (p - 1) * gamma_ave_m1;
-    } else if (p < 2) {
-        gm_m1 = pow((2 - p) / (p - 1) * gamma_ave_m1 * pow(gamma_M, p - 2), 1 / (p - 1));
-    } else {  // root_bisect, utilities.h:230-241
-        auto eq = [&](double x) { return x * log(gamma_M) - (x + 1) * log(x) - gamma_ave_m1 - log(gamma_M); };
-        double low = 0, high = gamma_M;
-        for (int it = 0; it < 1000 && (high - low) > fabs((high + low) * 0.5) * 1e-6; ++it) {
-            const double mid = 0.5 * (high + low);
-            if (eq(mid) * eq(high) > 0)
-                high = mid;
-            else
-                low = mid;
-        }
-        gm_m1 = 0.5 * (high + low);
-    }
-    const double gamma_m = gm_m1 + 1;
-    double f_syn = (gamma_m - 1) / gamma_m;
-    if (p > 3) f_syn = fast_pow(f_syn, (p - 1) / 2);
-    const double N_e = N_p * xi_e * f_syn;
-    const double column_den = N_e / (r * r);
-    const double I_peak = syn_I_peak(B, column_den);
-    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + 0.) * t_comv) * 1;
-    const double gamma_c = (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
-    // compute_syn_gamma_a with no IC (ratio exactly 1), synchrotron.cpp:212-246
-    double gamma_a;
-    {
-        const double gamma_peak = dmin(gamma_m, gamma_c);
-        const double nu_peak = syn_freq(gamma_peak, B);
-        const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
-        double nu_a = fast_pow(I_peak * C_C2 / (cbrt(nu_peak) * 2 * kT), 0.6);
-        if (nu_a > nu_peak) {
-            if (gamma_c > gamma_m) {
-                const double nu_m = syn_freq(gamma_m, B);
-                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * fast_pow(nu_m, p / 2), 2 / (p + 4));
-                const double nu_c = syn_freq(gamma_c, B);
-                if (nu_a > nu_c)
-                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
-            } else {
-                const double nu_c = syn_freq(gamma_c, B);
-                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
-                const double nu_m = syn_freq(gamma_m, B);
-                if (nu_a > nu_m)
-                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
-            }
-        }
-        gamma_a = sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu_a / B)) + 1;
-    }
-    // --- photons (synchrotron.cpp:376-408) + build (smooth-power-law-syn.cpp:94-153) ---
+// generate_syn_photons for one cell (synchrotron.cpp:376-408) + SmoothPowerLawSyn::build (smooth-power-law-syn.cpp:94-153)
+VAG_DEV void syn_photons_build(CellOut& o, double gamma_m, double gamma_c, double gamma_a, double gamma_M, double column_den,
+                               double N_e, double B, double p, double Gamma, double r, double t_eng) {
     const double nu_M = syn_freq(gamma_M, B), nu_m = syn_freq(gamma_m, B), nu_c = syn_freq(gamma_c, B),
                  nu_a = syn_freq(gamma_a, B);
     const double I_nu_max = syn_I_peak(B, column_den);
@@ -575,6 +523,64 @@ VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double 
     o.nu_a = nu_a;
     o.nu_M = nu_M;
     o.I_nu_max = I_nu_max;
+}
+
+
+VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
+                      double N_p, double eps_e, double p, double xi_e) {
+    // --- electrons (synchrotron.cpp:315-360) ---
+    const double gamma_M = (B == 0) ? INFINITY : sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + 0.)));
+    const double gamma_ave_m1 = eps_e * (Gamma_th - 1) * (C_MP / C_ME) / xi_e;
+    double gm_m1;
+    if (p > 2) {
+        gm_m1 = (p - 2) / (p - 1) * gamma_ave_m1;
+    } else if (p < 2) {
+        gm_m1 = pow((2 - p) / (p - 1) * gamma_ave_m1 * pow(gamma_M, p - 2), 1 / (p - 1));
+    } else {  // root_bisect, utilities.h:230-241
+        auto eq = [&](double x) { return x * log(gamma_M) - (x + 1) * log(x) - gamma_ave_m1 - log(gamma_M); };
+        double low = 0, high = gamma_M;
+        for (int it = 0; it < 1000 && (high - low) > fabs((high + low) * 0.5) * 1e-6; ++it) {
+            const double mid = 0.5 * (high + low);
+            if (eq(mid) * eq(high) > 0)
+                high = mid;
+            else
+                low = mid;
+        }
+        gm_m1 = 0.5 * (high + low);
+    }
+    const double gamma_m = gm_m1 + 1;
+    double f_syn = (gamma_m - 1) / gamma_m;
+    if (p > 3) f_syn = fast_pow(f_syn, (p - 1) / 2);
+    const double N_e = N_p * xi_e * f_syn;
+    const double column_den = N_e / (r * r);
+    const double I_peak = syn_I_peak(B, column_den);
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + 0.) * t_comv) * 1;
+    const double gamma_c = (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+    // compute_syn_gamma_a with no IC (ratio exactly 1), synchrotron.cpp:212-246
+    double gamma_a;
+    {
+        const double gamma_peak = dmin(gamma_m, gamma_c);
+        const double nu_peak = syn_freq(gamma_peak, B);
+        const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
+        double nu_a = fast_pow(I_peak * C_C2 / (cbrt(nu_peak) * 2 * kT), 0.6);
+        if (nu_a > nu_peak) {
+            if (gamma_c > gamma_m) {
+                const double nu_m = syn_freq(gamma_m, B);
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * fast_pow(nu_m, p / 2), 2 / (p + 4));
+                const double nu_c = syn_freq(gamma_c, B);
+                if (nu_a > nu_c)
+                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+            } else {
+                const double nu_c = syn_freq(gamma_c, B);
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
+                const double nu_m = syn_freq(gamma_m, B);
+                if (nu_a > nu_m)
+                    nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+            }
+        }
+        gamma_a = sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu_a / B)) + 1;
+    }
+    syn_photons_build(o, gamma_m, gamma_c, gamma_a, gamma_M, column_den, N_e, B, p, Gamma, r, t_eng);
 }
 
 // Per-model constants of the optically thick branch (smooth-power-law-syn.cpp:102-107)

@@ -131,7 +131,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     const double theta_v = P.theta_obs, z = P.z;
     VagGridMeta M;
     M.status = 0;
-    M.pad0 = M.pad1 = 0;
+    M.flags = P.flags;
+    M.pad1 = 0;
 
     // ---- find_jet_jumps (grid-refinement.h:41-86): parallel profile scan, sequential jump logic ----
     const double th_lo = 1e-6, th_hi = C_PI / 2;

@@ -1,0 +1,272 @@
+// vag_ic.h -- inverse-Compton cooling and SSC photon spectra on the device.
+// Reference: src/radiation/inverse-compton.h:270-776, src/radiation/inverse-compton.cpp:18-378.
+#pragma once
+#include "vag_device.h"
+#include "vag_grid_kernel.h"
+
+namespace vag {
+
+constexpr double C_H = 6.63e-27 * U_ERG * U_SEC;  // con::h, src/util/macros.h:95
+
+// ---- BrokenPowerLaw<5> restricted to the three segments build_segments() can create for regimes 0-2
+//      (src/util/utilities.h:21-78, inverse-compton.cpp:112-131) ----
+struct Bpl {
+    int size;
+    double slope[3], lg2_lower[3], lg2_const[3];
+    VAG_DEV void first(double norm, double lower, double sl) {
+        size = 1;
+        const double ll = log2(lower);
+        slope[0] = sl;
+        lg2_lower[0] = ll;
+        lg2_const[0] = log2(norm) - sl * ll;
+    }
+    VAG_DEV void add(double lower, double sl) {
+        const double ll = log2(lower);
+        const int p = size - 1;
+        const double val = lg2_const[p] + slope[p] * ll;
+        slope[size] = sl;
+        lg2_lower[size] = ll;
+        lg2_const[size] = val - sl * ll;
+        ++size;
+    }
+    VAG_DEV double eval(double x) const {
+        const double lx = log2(x);
+        for (int i = size - 1; i > 0; --i)
+            if (lx >= lg2_lower[i]) return exp2(lg2_const[i] + slope[i] * lx);
+        return size > 0 ? exp2(lg2_const[0] + slope[0] * lx) : 0.0;
+    }
+};
+
+// ---- InverseComptonY (inverse-compton.h:28-76, inverse-compton.cpp:18-187) ----
+struct IcY {
+    double gamma_m_hat, gamma_c_hat, gamma_self, gamma0, Y_T;
+    int regime;
+    double gamma_m_, B_, p_, gamma_self3;
+    Bpl seg;
+
+    VAG_DEV void set_default() {
+        gamma_m_hat = 1.0;
+        gamma_c_hat = 1.0;
+        gamma_self = 1;
+        gamma0 = 1;
+        Y_T = 0.0;
+        regime = 0;
+        gamma_m_ = 1;
+        B_ = 0;
+        p_ = 2.3;
+        gamma_self3 = 1;
+        seg.size = 0;
+    }
+    VAG_DEV double gamma_hat(double g) const { return dmax(gamma_self3 / (g * g), 1.0); }
+    VAG_DEV double gamma_spectrum(double g) const { return seg.eval(g); }
+    VAG_DEV void build_segments() {
+        seg.first(Y_T, 1.0, 0.0);
+        if (regime == 1) {
+            seg.add(gamma_c_hat, 0.5 * (p_ - 3.0));
+            seg.add(gamma_m_hat, -4.0 / 3.0);
+        } else if (regime == 2) {
+            seg.add(gamma_m_hat, -0.5);
+            seg.add(gamma_c_hat, -4.0 / 3.0);
+        }
+    }
+    VAG_DEV void update_gamma0(double gamma_c) {
+        if (Y_T < 1) {
+            gamma0 = 0.0;
+            return;
+        }
+        if (gamma_m_ < gamma_c) {
+            gamma0 = fast_pow(Y_T, 2.0 / (3.0 - p_)) * gamma_c_hat;
+            if (gamma0 > gamma_m_hat)
+                gamma0 = gamma_m_hat * fast_pow(Y_T, 3.0 / 4.0) * fast_pow(gamma_c / gamma_m_, 0.75 * (p_ - 3.0));
+        } else {
+            gamma0 = Y_T * Y_T * gamma_m_hat;
+            if (gamma_m_ < gamma_m_hat) {
+                if (gamma0 > gamma_c_hat) gamma0 = fast_pow(Y_T * gamma_c / gamma_m_, 3.0 / 4.0) * gamma_c_hat;
+            } else {
+                if (gamma0 > gamma_self) gamma0 = sqrt(Y_T * gamma_m_ * gamma_m_hat);
+            }
+        }
+    }
+    VAG_DEV void update_cooling_breaks(double gamma_c, double YT) {
+        gamma_c_hat = gamma_hat(gamma_c);
+        Y_T = YT;
+        update_gamma0(gamma_c);
+        regime = (gamma_m_ < gamma_c) ? 1 : 2;
+        build_segments();
+    }
+    VAG_DEV void init(double gamma_m, double gamma_c, double p, double B, double YT, bool is_KN) {
+        set_default();
+        const double nu_m = syn_freq(gamma_m, B);
+        gamma_m_hat = dmax(C_ME * C_C2 / C_H / nu_m, 1.0);
+        gamma_self = fast_pow(gamma_m_hat * gamma_m * gamma_m, 1.0 / 3.0);
+        gamma_self3 = gamma_self * gamma_self * gamma_self;
+        B_ = B;
+        gamma_m_ = gamma_m;
+        p_ = p;
+        if (is_KN) {
+            update_cooling_breaks(gamma_c, YT);
+        } else {
+            gamma_c_hat = gamma_hat(gamma_c);
+            Y_T = YT;
+            regime = 0;
+            build_segments();
+        }
+    }
+};
+
+VAG_DEV double syn_gamma(double nu, double B) { return sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu / B)); }
+VAG_DEV double icy_nu_spectrum(const IcY& y, double nu) { return y.gamma_spectrum(syn_gamma(nu, y.B_)); }
+
+VAG_DEV double thomson_Y(double eps_e, double eps_B, double p, double gamma_m, double gamma_c) {
+    const double eta_e = (gamma_c < gamma_m) ? 1 : fast_pow(gamma_c / gamma_m, 2 - p);
+    const double b = eta_e * eps_e / eps_B;
+    return 0.5 * (sqrt(1. + 4. * b) - 1.);
+}
+VAG_DEV double gamma_c_of(double t_comv, double B, double Y) {
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + Y) * t_comv) * 1;
+    return (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+}
+VAG_DEV double gamma_M_of(double B, double Y) {
+    if (B == 0) return INFINITY;
+    return sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + Y)));
+}
+
+// compute_syn_gamma_a with IC terms (synchrotron.cpp:212-246)
+VAG_DEV double syn_gamma_a_ic(double B, double I_peak, double gamma_m, double gamma_c, double p, const IcY& Ys, double Y_c) {
+    const double gamma_peak = dmin(gamma_m, gamma_c);
+    const double nu_peak = syn_freq(gamma_peak, B);
+    const double kT = (gamma_peak - 1) * (C_ME * C_C2) / 3;
+    double nu_a = fast_pow(I_peak * C_C2 / (cbrt(nu_peak) * 2 * kT), 0.6);
+    if (nu_a > nu_peak) {
+        if (gamma_c > gamma_m) {
+            const double nu_m = syn_freq(gamma_m, B);
+            nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * fast_pow(nu_m, p / 2), 2 / (p + 4));
+            const double nu_c = syn_freq(gamma_c, B);
+            if (nu_a > nu_c) {
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+                nu_a *= fast_pow((1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a)), 2 / (p + 5));
+            }
+        } else {
+            const double nu_c = syn_freq(gamma_c, B);
+            nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c), 0.4);
+            nu_a *= fast_pow((1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a)), 0.4);
+            const double nu_m = syn_freq(gamma_m, B);
+            if (nu_a > nu_m) {
+                nu_a = fast_pow(I_peak * C_C2 / (2 * kT) * sqrt(nu_c) * fast_pow(nu_m, p / 2), 2 / (p + 5));
+                nu_a *= fast_pow((1 + Y_c) / (1 + icy_nu_spectrum(Ys, nu_a)), 2 / (p + 5));
+            }
+        }
+    }
+    return syn_gamma(nu_a, B) + 1;
+}
+
+VAG_DEV int determine_regime(double a, double c, double m) {
+    if (a <= m && m <= c) return 1;
+    if (m <= a && a <= c) return 2;
+    if (a <= c && c <= m) return 3;
+    if (c <= a && a <= m) return 4;
+    if (m <= c && c <= a) return 5;
+    if (c <= m && m <= a) return 6;
+    return 0;
+}
+
+// Electron state of one cell kept between the radiation kernels of the SSC path (SynElectrons,
+// src/radiation/synchrotron.h:20-43), SoA over cells.
+enum { VE_GAMMA_M = 0, VE_GAMMA_C, VE_GAMMA_A, VE_GAMMA_M_MAX, VE_COLUMN_DEN, VE_YC, VE_REGIME, VAG_NELEC };
+// InverseComptonY of one cell, SoA over cells
+enum {
+    VY_GAMMA_M_HAT = 0, VY_GAMMA_C_HAT, VY_YT, VY_B, VY_NSEG,
+    VY_S0, VY_L0, VY_C0, VY_S1, VY_L1, VY_C1, VY_S2, VY_L2, VY_C2,
+    VAG_NICY
+};
+
+VAG_DEV void icy_store(const IcY& y, double* base, long long n_cells, long long c) {
+    base[VY_GAMMA_M_HAT * n_cells + c] = y.gamma_m_hat;
+    base[VY_GAMMA_C_HAT * n_cells + c] = y.gamma_c_hat;
+    base[VY_YT * n_cells + c] = y.Y_T;
+    base[VY_B * n_cells + c] = y.B_;
+    base[VY_NSEG * n_cells + c] = (double)y.seg.size;
+    for (int s = 0; s < 3; ++s) {
+        base[(VY_S0 + 3 * s) * n_cells + c] = s < y.seg.size ? y.seg.slope[s] : 0;
+        base[(VY_L0 + 3 * s) * n_cells + c] = s < y.seg.size ? y.seg.lg2_lower[s] : INFINITY;
+        base[(VY_C0 + 3 * s) * n_cells + c] = s < y.seg.size ? y.seg.lg2_const[s] : 0;
+    }
+}
+// Y(gamma) from the stored segments: log2 Y = const_i + slope_i log2(gamma)
+VAG_DEV double icy_lg2_Y(const double* base, long long n_cells, long long c, double lg2_gamma) {
+    const int n = (int)base[VY_NSEG * n_cells + c];
+    if (n == 0) return -INFINITY;
+    for (int i = n - 1; i > 0; --i)
+        if (lg2_gamma >= base[(VY_L0 + 3 * i) * n_cells + c])
+            return base[(VY_C0 + 3 * i) * n_cells + c] + base[(VY_S0 + 3 * i) * n_cells + c] * lg2_gamma;
+    return base[VY_C0 * n_cells + c] + base[VY_S0 * n_cells + c] * lg2_gamma;
+}
+
+// SynElectrons::compute_column_den (synchrotron.cpp:261-309)
+VAG_DEV double electron_column_den(double gamma, double gamma_m, double gamma_c, double gamma_M, double p, int regime,
+                                   double column_den, double Y_c, double Y_at_gamma) {
+    double spec;
+    if (regime == 1 || regime == 2 || regime == 5) {
+        spec = (p - 1) / gamma_m * exp(-gamma / gamma_M - gamma_m / gamma) * fast_pow(gamma / gamma_m, -p) * gamma_c /
+               (gamma + gamma_c);
+    } else if (regime == 3 || regime == 4 || regime == 6) {
+        spec = exp(-gamma / gamma_M - gamma_c / gamma) * gamma_c / (gamma * gamma) / (1.0 + fast_pow(gamma / gamma_m, p - 1));
+    } else {
+        spec = 0;
+    }
+    if (gamma <= gamma_c) return column_den * spec;
+    return column_den * spec * (1 + Y_c) / (1 + Y_at_gamma);
+}
+
+// Klein-Nishina cross-section ratio sigma/sigma_T (inverse-compton.cpp:257-283)
+VAG_DEV double compton_ratio_from_x(double x) {
+    if (x < 1e-2) return 1 - 2 * x;
+    if (x > 1e2) return 3. / 8 * (log(2 * x) + 0.5) / x;
+    const double l = log1p(2.0 * x);
+    const double invx = 1.0 / x, invx2 = invx * invx;
+    const double term1 = 1.0 + 2.0 * x, invt1 = 1.0 / term1, invt1_2 = invt1 * invt1;
+    const double a = (1.0 + x) * invx2 * invx;
+    const double b = 2.0 * x * (1.0 + x) * invt1 - l;
+    const double c = 0.5 * l * invx;
+    const double d = (1.0 + 3.0 * x) * invt1_2;
+    return 0.75 * (a * b + c - d);
+}
+constexpr int KN_LUT_N = 128;
+constexpr double KN_LG2_XMIN = -6.6438561897747247, KN_LG2_XMAX = 6.6438561897747247;
+// lut: [2][KN_LUT_N] = ratio, log2 ratio (ComptonSigmaLUT, inverse-compton.cpp:285-343), built on the host
+VAG_DEV void compton_correction_pair(double nu, const double* __restrict__ lut, double& corr, double& lg2_corr) {
+    const double x = C_H / (C_ME * C_C2) * nu;
+    if (!(x > 0)) {
+        corr = 0;
+        lg2_corr = -INFINITY;
+        return;
+    }
+    if (x <= 1e-2) {
+        corr = 1 - 2 * x;
+        lg2_corr = -(2 * x + 2 * x * x) * 1.4426950408889634;
+        return;
+    }
+    if (x >= 1e2) {
+        corr = compton_ratio_from_x(x);
+        lg2_corr = log2(corr);
+        return;
+    }
+    constexpr double inv_step = 1.0 / ((KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1));
+    const double pos = (log2(x) - KN_LG2_XMIN) * inv_step;
+    if (pos <= 0) {
+        corr = lut[0];
+        lg2_corr = lut[KN_LUT_N];
+        return;
+    }
+    if (pos >= (double)(KN_LUT_N - 1)) {
+        corr = lut[KN_LUT_N - 1];
+        lg2_corr = lut[2 * KN_LUT_N - 1];
+        return;
+    }
+    const int idx = (int)pos;
+    const double frac = pos - (double)idx;
+    corr = lut[idx] + (lut[idx + 1] - lut[idx]) * frac;
+    lg2_corr = lut[KN_LUT_N + idx] + (lut[KN_LUT_N + idx + 1] - lut[KN_LUT_N + idx]) * frac;
+}
+
+}  // namespace vag

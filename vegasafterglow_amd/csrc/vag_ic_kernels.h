@@ -1,0 +1,514 @@
+// vag_ic_kernels.h -- kernels of the SSC / inverse-Compton tier.
+#pragma once
+#include "vag_ic.h"
+#include "vag_kernels.h"
+
+namespace vag {
+
+// Rows of the per-cell electron/photon detail arrays (SoA over cells); 0..10 are also what Model.details exposes
+// (pybind/pymodel.h:490-535).
+enum {
+    VD_GAMMA_M = 0, VD_GAMMA_C, VD_GAMMA_A, VD_GAMMA_MAX, VD_N_E, VD_COLUMN_DEN, VD_NU_M, VD_NU_C, VD_NU_A, VD_NU_MAX,
+    VD_I_NU_MAX, VD_YC, VD_REGIME, VAG_NDET
+};
+
+// Extra per-cell parameters of the IC-corrected synchrotron spectrum: [row][VAG_NQ][n_t]
+enum {
+    VQ_LG2_NUC = 0, VQ_L1PYC, VQ_HASIC, VQ_LG2_KB, VQ_NSEG,
+    VQ_S0, VQ_L0, VQ_C0, VQ_S1, VQ_L1, VQ_C1, VQ_S2, VQ_L2, VQ_C2,
+    VAG_NQ
+};
+
+// SSC table of one cell: header + log2 I on the phase-locked output lattice (inverse-compton.h:354-369,595-606)
+constexpr int IC_MAX_OUT = 160;
+constexpr int IC_HDR = 6;  // n_ic, phase, idx0, log2 theory min, log2 theory max, spare
+constexpr int IC_STRIDE = IC_HDR + IC_MAX_OUT;
+constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = 2 * (IC_MAX_G - 1) + 2 * (IC_MAX_NU - 1) + 1;
+static_assert(VAG_NQ == FLUX_NQ && IC_STRIDE == FLUX_IC_STRIDE, "keep vag_kernels.h forward constants in sync");
+constexpr double IC_Q = 3.321928094887362 / 8;  // lattice_quantum
+constexpr double IC_X0 = 0.47140452079103166;
+
+// ------------------------------------------------------------------------------------------------
+// IC cooling: one lane per representative row, sequential in k because each cell's iteration starts from the
+// previous cell's cooled gamma_c (IC_cooling, inverse-compton.h:729-768; update_gamma_c_Thomson/_KN and
+// update_gamma_M, inverse-compton.cpp:192-251).  Updates the electron detail arrays in place and stores
+// InverseComptonY per cell.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                      Layout lay, int n_rows, const double* __restrict__ shock, long long n_cells,
+                      double* __restrict__ det, double* __restrict__ icy) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const int m = find_model(lay.row_off, nb, row);
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const vag_model_params P = params[m];
+    const bool kn = (P.flags & VAG_FLAG_KN) != 0;
+    const int nt = M.n_t;
+    const long long c0 = lay.cell_off[m] + (long long)(row - lay.row_off[m]) * nt;
+    double gamma_c_last = det[VD_GAMMA_C * n_cells + c0];
+    for (int k = 0; k < nt; ++k) {
+        const long long c = c0 + k;
+        const double t_com = shock[VS_TCOMV * n_cells + c], B = shock[VS_B * n_cells + c];
+        const double gm = det[VD_GAMMA_M * n_cells + c];
+        double gc = det[VD_GAMMA_C * n_cells + c];
+        double gM = det[VD_GAMMA_MAX * n_cells + c];
+        const double cd = det[VD_COLUMN_DEN * n_cells + c];
+        IcY Ys;
+        if (kn) {
+            double gc_new = gamma_c_last;
+            double Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc_new);
+            Ys.init(gm, gc_new, P.p, B, Y_T, true);
+            int iter = 0;
+            do {
+                gc = gc_new;
+                Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+                Ys.update_cooling_breaks(gc, Y_T);
+                gc_new = gamma_c_of(t_com, B, Ys.gamma_spectrum(gc));
+                iter++;
+            } while (fabs((gc_new - gc) / gc) > 1e-3 && iter < 100);
+            gc = gc_new;
+        } else {
+            double Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+            double gc_new = gamma_c_last;
+            for (int guard = 0; fabs((gc_new - gc) / gc) > 1e-3 && guard < 10000; ++guard) {
+                gc = gc_new;
+                Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+                gc_new = gamma_c_of(t_com, B, Y_T);
+            }
+            gc = gc_new;
+            Ys.init(gm, gc, P.p, B, Y_T, false);
+        }
+        if (B == 0) {
+            gM = INFINITY;
+        } else {
+            double gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
+            for (int guard = 0; fabs((gM - gM_new) / gM_new) > 1e-3 && guard < 10000; ++guard) {
+                gM = gM_new;
+                gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
+            }
+        }
+        const double Y_c = Ys.gamma_spectrum(gc);
+        const double ga = syn_gamma_a_ic(B, syn_I_peak(B, cd), gm, gc, P.p, Ys, Y_c);
+        det[VD_GAMMA_C * n_cells + c] = gc;
+        det[VD_GAMMA_MAX * n_cells + c] = gM;
+        det[VD_GAMMA_A * n_cells + c] = ga;
+        det[VD_YC * n_cells + c] = Y_c;
+        det[VD_REGIME * n_cells + c] = (double)determine_regime(ga, gc, gm);
+        icy_store(Ys, icy, n_cells, c);
+        gamma_c_last = gc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Photons from the (cooled) electrons, one lane per cell: generate_syn_photons + build, plus the constants of
+// the IC correction of the thin branch (inverse_compton_correction, inverse-compton.h:781-792).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                      Layout lay, const double* __restrict__ shock, long long n_cells, double* __restrict__ det,
+                      const double* __restrict__ icy, double* __restrict__ cellpar, double* __restrict__ cellq) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lay.cell_off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int m = lo;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const int nt = M.n_t;
+    const long long local = c - lay.cell_off[m];
+    const int r = (int)(local / nt), k = (int)(local % nt);
+    const vag_model_params P = params[m];
+    const double B = shock[VS_B * n_cells + c];
+    CellOut o;
+    syn_photons_build(o, det[VD_GAMMA_M * n_cells + c], det[VD_GAMMA_C * n_cells + c], det[VD_GAMMA_A * n_cells + c],
+                      det[VD_GAMMA_MAX * n_cells + c], det[VD_COLUMN_DEN * n_cells + c], det[VD_N_E * n_cells + c], B, P.p,
+                      shock[VS_GAMMA * n_cells + c], shock[VS_R * n_cells + c], shock[VS_TENG * n_cells + c]);
+    double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
+#pragma unroll
+    for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];
+    det[VD_NU_M * n_cells + c] = o.nu_m;
+    det[VD_NU_C * n_cells + c] = o.nu_c;
+    det[VD_NU_A * n_cells + c] = o.nu_a;
+    det[VD_NU_MAX * n_cells + c] = o.nu_M;
+    det[VD_I_NU_MAX * n_cells + c] = o.I_nu_max;
+    const double Y_c = det[VD_YC * n_cells + c], Y_T = icy[VY_YT * n_cells + c];
+    double* q = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
+    q[(long long)VQ_LG2_NUC * nt] = log2(o.nu_c);
+    q[(long long)VQ_L1PYC * nt] = log2(1. + Y_c);
+    q[(long long)VQ_HASIC * nt] = (Y_c > 0 || Y_T > 0) ? 1.0 : 0.0;
+    q[(long long)VQ_LG2_KB * nt] = log2(4 * C_PI * C_ME * C_C / (3 * C_E)) - log2(B);
+    q[(long long)VQ_NSEG * nt] = icy[VY_NSEG * n_cells + c];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) q[(long long)(VQ_S0 + s) * nt] = icy[(VY_S0 + s) * n_cells + c];
+}
+
+// IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92).  `c`/`st` address the
+// 18-parameter block, `qv`/`qst` the IC extras of the same cell.  log2((1+Y_c)/(1+Y(nu))) = log2(1+Y_c) - sp(log2 Y).
+template <class P1, class P2>
+VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu,
+                            const double* __restrict__ sp) {
+    const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
+    double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
+                  sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];
+    if (lg2_nu > qv[VQ_LG2_NUC * qst] && qv[VQ_HASIC * qst] != 0.0) {
+        const double lg = 0.5 * (lg2_nu + qv[VQ_LG2_KB * qst]);  // log2 gamma of the electrons radiating at nu
+        const int n = (int)qv[VQ_NSEG * qst];
+        double z = qv[VQ_C0 * qst] + qv[VQ_S0 * qst] * lg;
+        if (n > 2 && lg >= qv[VQ_L2 * qst])
+            z = qv[VQ_C2 * qst] + qv[VQ_S2 * qst] * lg;
+        else if (n > 1 && lg >= qv[VQ_L1 * qst])
+            z = qv[VQ_C1 * qst] + qv[VQ_S1 * qst] * lg;
+        // log2(1 + 2^z) without the reference's +-20 softplus shortcut (this term is an exact log2 there)
+        const double a = fabs(z);
+        const double g = a > 20.0 ? exp2_fast(-a) * LOG2E : (sp_fast(-a, sp));
+        thin += qv[VQ_L1PYC * qst] - (0.5 * (z + a) + g);
+    }
+    const double lx = lg2_nu - c[VP_LG2_NUM * st];
+    double thick = 2.5 * lx;
+    if (!(lx > sc.log2_x_far)) {
+        const double s = -sc.smooth_thick * exp2_fast(2. / 3 * lx);
+        thick += sp_fast(-0.5 * lx + s, sp);
+    }
+    const double lb = thick + c[VP_TNORM * st];
+    const double smooth_one = thin - sp_fast(c[VP_SAB * st] * (thin - lb), sp) * c[VP_INV_SAB * st];
+    const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
+    if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
+    return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-k comoving band the observer will sample (single_shock_emission, pybind/pymodel.h:896-909): extrema of the
+// Doppler factor over all (phi, theta) rows.  D^-1 = Gamma - u cos_v is monotone in cos_v, so the extrema over phi
+// come from the extrema of cos_v per theta row.  One wavefront per model.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
+                   const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ g_rep_of,
+                   const long long* __restrict__ cell_off, const double* __restrict__ cellpar,
+                   const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][VAG_MAX_TIME] */) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
+    const vag_model_params P = params[m];
+    const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
+    const double* gth = geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    for (int j = lane; j < M.n_theta; j += 64) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < M.n_phi_eff; ++i) {
+            const double cv = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            lo = fmin(lo, cv);
+            hi = fmax(hi, cv);
+        }
+        s_cvmin[j] = lo;
+        s_cvmax[j] = hi;
+    }
+    __syncthreads();
+    double nu_lo = INFINITY, nu_hi = -INFINITY;
+    for (int l = 0; l < nnu; ++l) {
+        nu_lo = fmin(nu_lo, lg2_nu_obs[l]);
+        nu_hi = fmax(nu_hi, lg2_nu_obs[l]);
+    }
+    const double lg2_1pz = log2(1 + P.z);
+    const int nt = M.n_t;
+    const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
+    for (int k = lane; k < nt; k += 64) {
+        double dmin_k = INFINITY, dmax_k = -INFINITY;
+        for (int j = 0; j < M.n_theta; ++j) {
+            const double* par = cellpar + (cell_off[m] + (long long)rep_of[j] * nt) * VAG_NPAR;
+            const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];
+            dmax_k = fmax(dmax_k, -log2(G - u * s_cvmax[j]));
+            dmin_k = fmin(dmin_k, -log2(G - u * s_cvmin[j]));
+        }
+        band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
+        band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = exp2((nu_hi + lg2_1pz) - dmin_k);  // nu_eval_max_k
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SSC spectrum of one cell (ICPhoton::generate_spectrum, inverse-compton.h:270-607): one wavefront per
+// representative cell.  Seed and electron lattices live in LDS; per electron energy the scattering CDF over the
+// seed lattice is a suffix scan done with wave shuffles (two seed bins per lane), the accumulation onto the
+// phase-locked output lattice is integer-indexed with one output node per lane (registers).
+// ------------------------------------------------------------------------------------------------
+struct IcShared {
+    double sp[SP_TABLE_DOUBLES];
+    double nu[IC_MAX_NU], lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU],
+        inv_lg2r[IC_MAX_NU], cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU], cdf[IC_MAX_NU], fv[IC_MAX_NU], ratio[IC_MAX_NU],
+        ex[IC_MAX_NU];
+    double gam[IC_MAX_G], dNe[IC_MAX_G];
+    double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
+};
+
+VAG_DEV double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, double nu_hi, double lg2f_lo, double lg2f_hi,
+                                      double lg2r, double inv_lg2r, double trap) {
+    if (!(f_lo > 0) || !(f_hi > 0)) return trap;
+    const double s1 = 1 + (lg2f_hi - lg2f_lo) * inv_lg2r;
+    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) / s1;
+    return f_lo * nu_lo * lg2r * 0.6931471805599453;
+}
+
+// cdf[j] = sum_{m >= j} ex[m] for j < n (ex beyond n treated as 0), cdf[n] = 0.  Two elements per lane + shuffles.
+VAG_DEV void suffix_scan(const double* __restrict__ ex, double* __restrict__ cdf, int n, int lane) {
+    const int j0 = 2 * lane, j1 = j0 + 1;
+    const double a = j0 < n ? ex[j0] : 0.0, b = j1 < n ? ex[j1] : 0.0;
+    double S = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_down(S, off, 64);
+        if (lane + off < 64) S += t;
+    }
+    double S_next = __shfl_down(S, 1, 64);
+    if (lane == 63) S_next = 0;
+    const double c1 = S_next + b;
+    if (j1 <= n) cdf[j1] = j1 < n ? c1 : 0.0;
+    if (j0 <= n) cdf[j0] = j0 < n ? c1 + a : 0.0;
+}
+
+__global__ void __launch_bounds__(64)
+vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
+                     long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
+                     const double* __restrict__ cellpar, const double* __restrict__ cellq, const double* __restrict__ band,
+                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* __restrict__ ictab,
+                     int* __restrict__ ic_status) {
+    const long long c = blockIdx.x;
+    if (c >= n_cells) return;
+    const int lane = threadIdx.x;
+    __shared__ IcShared sh;
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lay.cell_off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int m = lo;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const int nt = M.n_t;
+    const long long local = c - lay.cell_off[m];
+    const int r = (int)(local / nt), k = (int)(local % nt);
+    const vag_model_params P = params[m];
+    const bool KN = (P.flags & VAG_FLAG_KN) != 0;
+    double* tab = ictab + (size_t)c * IC_STRIDE;
+    for (int i = lane; i < SP_TABLE_DOUBLES; i += 64) sh.sp[i] = sp_table[i];
+
+    const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
+    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c], column_den = det[VD_COLUMN_DEN * n_cells + c];
+    const double Y_c = det[VD_YC * n_cells + c];
+    const int regime = (int)det[VD_REGIME * n_cells + c];
+    const double nu_m = det[VD_NU_M * n_cells + c], nu_a = det[VD_NU_A * n_cells + c], nu_M = det[VD_NU_MAX * n_cells + c];
+    const double nu_eval_min = band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k];
+    const double nu_eval_max = band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k];
+    // compute_grid_params, inverse-compton.h:297-338
+    const double tail_factor = dmax(-log(1e-2), 5.0);
+    const double gamma_min = dmin(gamma_m, gamma_c) / 30;
+    const double gamma_max = dmax(gamma_M * tail_factor, gamma_min);
+    const double nu_min = dmin(nu_a, nu_m) / 10;
+    const double nu_max = dmax(nu_M * tail_factor, nu_min);
+    double nu_IC_min = 4 * IC_X0 * nu_min * gamma_min * gamma_min;
+    const double nu_ic_base = 4 * IC_X0 * nu_M * gamma_M * gamma_M;
+    const double nu_ic_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
+    double nu_IC_max = nu_ic_cut * 2.0;
+    const double theory_max = log2(nu_IC_max), theory_min = log2(nu_IC_min);
+    nu_IC_min = dmax(nu_IC_min, dmin(nu_eval_min / 4.0, nu_IC_max / 16.0));
+    nu_IC_max = dmin(nu_IC_max, dmax(nu_eval_max * 4.0, nu_IC_min * 16.0));
+    auto posfin = [](double x) { return isfinite(x) && x > 0; };
+    if (!(posfin(gamma_min) && posfin(gamma_max) && posfin(nu_min) && posfin(nu_max) && posfin(nu_IC_min) &&
+          posfin(nu_IC_max))) {
+        if (lane == 0) {
+            tab[0] = 0;
+            tab[3] = theory_min;
+            tab[4] = theory_max;
+        }
+        return;
+    }
+    // initialize_grids, inverse-compton.h:340-369
+    const double step = 2 * IC_Q;
+    const double lg2_nu0 = log2(nu_min), lg2_g0 = log2(gamma_min);
+    int nu_size = (int)ceil((log2(nu_max) - lg2_nu0) / step) + 1;
+    int g_size = (int)ceil((log2(gamma_max) - lg2_g0) / step) + 1;
+    if (nu_size < 2) nu_size = 2;
+    if (g_size < 2) g_size = 2;
+    const double phase = lg2_nu0 + 2 * lg2_g0 + log2(4 * IC_X0);
+    const long n_lo = (long)floor((log2(nu_IC_min) - phase) / step);
+    const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
+    const long span = n_hi - n_lo;
+    const int n_ic = (int)(span > 1 ? span : 1) + 1;
+    const long idx0 = n_lo * 2;
+    if (nu_size > IC_MAX_NU || g_size > IC_MAX_G || n_ic > IC_MAX_OUT) {
+        if (lane == 0) {
+            tab[0] = 0;
+            tab[3] = theory_min;
+            tab[4] = theory_max;
+            atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
+        }
+        return;
+    }
+    __syncthreads();
+    for (int j = lane; j < nu_size; j += 64) {
+        sh.lg2nu[j] = lg2_nu0 + step * (double)j;
+        sh.nu[j] = exp2(sh.lg2nu[j]);
+    }
+    for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2(lg2_g0 + step * (double)i);
+    __syncthreads();
+    // sample_distributions, inverse-compton.h:371-399
+    const double* par = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
+    const double* qv = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
+    SpecConst sc;
+    sc.init(P.p);
+    for (int i = lane; i < g_size; i += 64) {
+        const double gi = sh.gam[i];
+        const double dgi = 0.5 * ((i + 1 < g_size ? sh.gam[i + 1] : gi) - (i > 0 ? sh.gam[i - 1] : gi));
+        const double Yg = exp2(icy_lg2_Y(icy, n_cells, c, log2(gi)));
+        sh.dNe[i] = electron_column_den(gi, gamma_m, gamma_c, gamma_M, P.p, regime, column_den, Y_c, Yg) / (gi * gi) * dgi;
+    }
+    for (int j = lane; j < nu_size; j += 64) {
+        const double I_seed = exp2(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sh.sp));
+        const double f = I_seed / (sh.nu[j] * sh.nu[j]);
+        sh.fv_th[j] = f;
+        sh.lg2fv[j] = f > 0 ? log2(f) : -INFINITY;
+    }
+    __syncthreads();
+    const int nu_last = nu_size - 1;
+    for (int j = lane; j < nu_last; j += 64) {
+        sh.dnu[j] = sh.nu[j + 1] - sh.nu[j];
+        sh.lg2r[j] = sh.lg2nu[j + 1] - sh.lg2nu[j];
+        sh.inv_lg2r[j] = sh.lg2r[j] != 0 ? 1 / sh.lg2r[j] : 0;
+    }
+    __syncthreads();
+    // build_cdf_thomson, inverse-compton.h:415-430
+    for (int j = lane; j < nu_last; j += 64) {
+        const double trap = 0.5 * (sh.fv_th[j] + sh.fv_th[j + 1]) * sh.dnu[j];
+        const double exact = power_law_bin_integral(sh.fv_th[j], sh.fv_th[j + 1], sh.nu[j], sh.nu[j + 1], sh.lg2fv[j],
+                                                    sh.lg2fv[j + 1], sh.lg2r[j], sh.inv_lg2r[j], trap);
+        sh.ex[j] = exact;
+        sh.ratio_th[j] = trap > 0 ? exact / trap : 1;
+    }
+    __syncthreads();
+    suffix_scan(sh.ex, sh.cdf_th, nu_last, lane);
+    __syncthreads();
+    if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
+        const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
+        const double lg2_base = log2(sh.gam[0]) + sh.lg2nu[0];
+        for (int q = lane; q < n_lat; q += 64)
+            compton_correction_pair(exp2(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+        __syncthreads();
+    }
+    // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527)
+    double I_acc[3] = {0, 0, 0};
+    const double expq1 = exp2(IC_Q * 1.0);
+    const long ns_top = (long)nu_last * 2;
+    for (int i = 0; i < g_size; ++i) {
+        const double dNe = sh.dNe[i];
+        if (!(dNe > 0)) continue;  // uniform
+        const double* fvp = sh.fv_th;
+        const double* cdfp = sh.cdf_th;
+        const double* ratp = sh.ratio_th;
+        if (KN) {  // build_cdf_KN, inverse-compton.h:432-481
+            const int i_gamma = 2 * i;
+            const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / sh.gam[i];
+            int j_split = 0;
+            while (j_split < nu_last && sh.nu[j_split] < nu_split) ++j_split;
+            __syncthreads();
+            for (int j = lane; j <= nu_last; j += 64)
+                sh.fv[j] = j >= j_split ? sh.fv_th[j] * sh.corr[i_gamma + 2 * j] : sh.fv_th[j];
+            __syncthreads();
+            for (int j = lane; j < nu_last; j += 64) {
+                if (j >= j_split) {
+                    const double lg2f_lo = sh.lg2fv[j] + sh.lg2corr[i_gamma + 2 * j];
+                    const double lg2f_hi = sh.lg2fv[j + 1] + sh.lg2corr[i_gamma + 2 * (j + 1)];
+                    const double trap = 0.5 * (sh.fv[j] + sh.fv[j + 1]) * sh.dnu[j];
+                    const double exact = power_law_bin_integral(sh.fv[j], sh.fv[j + 1], sh.nu[j], sh.nu[j + 1], lg2f_lo, lg2f_hi,
+                                                                sh.lg2r[j], sh.inv_lg2r[j], trap);
+                    sh.ex[j] = exact;
+                    sh.ratio[j] = trap > 0 ? exact / trap : 1;
+                } else {
+                    sh.ex[j] = 0;
+                    sh.ratio[j] = sh.ratio_th[j];
+                }
+            }
+            __syncthreads();
+            suffix_scan(sh.ex, sh.cdf, nu_last, lane);
+            __syncthreads();
+            if (j_split > 0) {
+                const double delta = sh.cdf[j_split] - sh.cdf_th[j_split];
+                __syncthreads();
+                for (int j = lane; j < j_split; j += 64) sh.cdf[j] = sh.cdf_th[j] + delta;
+            }
+            __syncthreads();
+            fvp = sh.fv;
+            cdfp = sh.cdf;
+            ratp = sh.ratio;
+        }
+        const double cdf0 = cdfp[0];
+        if (cdf0 <= 0) continue;  // uniform
+        const long n_off = idx0 - 4L * i;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int kk = lane + 64 * s;
+            if (kk < n_ic) {
+                const long n = n_off + 2L * kk;
+                if (n < 0) {
+                    I_acc[s] += dNe * cdf0;
+                } else if (n < ns_top) {
+                    const int j = (int)(n >> 1);
+                    const int fi = (int)(n & 1);
+                    const double nu_l = sh.nu[j], dn = sh.dnu[j];
+                    const double f_lo = fvp[j], f_hi = fvp[j + 1];
+                    const double frac = fi ? (nu_l * expq1 - nu_l) / dn : (nu_l * 1.0 - nu_l) / dn;
+                    const double rem = 1.0 - frac;
+                    const double f_seed = f_lo * rem + f_hi * frac;
+                    I_acc[s] += dNe * (cdfp[j + 1] + 0.5 * (f_seed + f_hi) * rem * dn * ratp[j]);
+                }
+            }
+        }
+    }
+    // log2 table on the output lattice, inverse-compton.h:595-606
+    const double lg2_scale = log2(0.25 * C_SIGMAT);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int kk = lane + 64 * s;
+        if (kk < n_ic) tab[IC_HDR + kk] = log2(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
+    }
+    if (lane == 0) {
+        tab[0] = (double)n_ic;
+        tab[1] = phase;
+        tab[2] = (double)idx0;
+        tab[3] = theory_min;
+        tab[4] = theory_max;
+    }
+}
+
+// ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table.  A query outside the clamped band but
+// inside the theoretical range would make the reference rebuild the cell's spectrum; here it raises `*breach`.
+VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach) {
+    const int n = (int)tab[0];
+    if (n < 2) return -INFINITY;
+    const double phase = tab[1];
+    const long idx0 = (long)tab[2];
+    auto node = [&](int q) { return phase + IC_Q * (double)(idx0 + 2L * q); };
+    const double first = node(0), last = node(n - 1);
+    if ((x > last && x < tab[4]) || (x < first && x > tab[3])) *breach = 1;
+    if (x > last) return -INFINITY;
+    int idx = (int)floor((x - first) / (2 * IC_Q));
+    idx = idx < 0 ? 0 : (idx > n - 2 ? n - 2 : idx);
+    while (idx + 2 < n && node(idx + 1) <= x) ++idx;  // settle exactly like the reference's forward scan
+    while (idx > 0 && node(idx) > x) --idx;
+    const double Ilo = tab[IC_HDR + idx], Ihi = tab[IC_HDR + idx + 1];
+    const double dl = node(idx + 1) - node(idx);
+    const double slope = dl != 0 ? (Ihi - Ilo) / dl : 0;
+    return Ilo + (x - node(idx)) * slope;
+}
+
+}  // namespace vag

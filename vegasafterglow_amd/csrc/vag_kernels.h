@@ -213,7 +213,23 @@ struct FluxArgs {
     int max_blocks;  // blocks per model (gridDim.x)
     int k_stride;    // LDS row stride (>= max n_t in the batch)
     unsigned long long* work_count;  // optional [2]: exact spectrum evaluations / interpolations done (instrumentation)
+    // SSC tier (vag_ic_kernels.h)
+    const double* cellq;   // [rows][VAG_NQ][n_t] IC-correction constants of the synchrotron spectrum (MODE 1)
+    const double* ictab;   // [cells][IC_STRIDE] SSC tables (MODE 2)
+    int* ic_status;        // [nb] bit 2: band-contract breach seen by the SSC flux pass
 };
+
+// photon source of the flux kernels
+constexpr int FLUX_SYN = 0;     // synchrotron, no inverse-Compton cooling
+constexpr int FLUX_SYN_IC = 1;  // synchrotron with the IC correction above nu_c
+constexpr int FLUX_SSC = 2;     // SSC tables
+
+template <class P1, class P2>
+VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu,
+                            const double* __restrict__ sp);
+VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
+constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
+constexpr int FLUX_IC_STRIDE = 166;  // == IC_STRIDE
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
 // (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.
@@ -231,8 +247,9 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
 }
 
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
-template <bool COUNT>
-__global__ void __launch_bounds__(FLUX_THREADS, 4)
+// MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
+template <bool COUNT, int MODE>
+__global__ void __launch_bounds__(FLUX_THREADS, MODE == FLUX_SYN ? 4 : 2)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
     const VagGridMeta* Mp = a.meta + m;
@@ -258,7 +275,9 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_nu = s_tobs + nt;              // [nnu]
     double* s_w = s_nu + nnu;                // [nt] fractional position of each requested time inside its interval
     double* s_acc = s_w + nt;                // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
-    int* s_kidx = (int*)(s_acc + slots);     // [nt]
+    double* s_q = s_acc + slots;             // [FLUX_NQ][KS] IC-correction constants (FLUX_SYN_IC only)
+    int* s_kidx = (int*)(s_q + (MODE == FLUX_SYN_IC ? FLUX_NQ * KS : 0));  // [nt]
+    int breach = 0;
 
     const vag_model_params* Pp = a.params + m;
     const double one_plus_z = 1 + Pp->z;
@@ -299,6 +318,14 @@ vag_flux_grid_kernel(FluxArgs a) {
             for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {  // rare path: keep its register footprint small
                 const int par = (int)(((float)q + 0.5f) / (float)K);
                 s_par[par * KS + (q - par * K)] = src[q];
+            }
+            if constexpr (MODE == FLUX_SYN_IC) {
+                const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K) * FLUX_NQ;
+#pragma unroll 1
+                for (int q = tid; q < FLUX_NQ * K; q += FLUX_THREADS) {
+                    const int par = (int)(((float)q + 0.5f) / (float)K);
+                    s_q[par * KS + (q - par * K)] = srcq[q];
+                }
             }
             staged_rep = rep;
             return true;
@@ -375,8 +402,18 @@ vag_flux_grid_kernel(FluxArgs a) {
                 const int k = k_lo + (q - lg * nk);
                 const int l0 = lg * 2, l1 = min(l0 + 1, nnu - 1);
                 const double dop = s_dop[k], geom = s_geom[k];
-                const double b0 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l0] - dop, s_sp);
-                const double b1 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l1] - dop, s_sp);
+                double b0, b1;
+                if constexpr (MODE == FLUX_SYN) {
+                    b0 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l0] - dop, s_sp);
+                    b1 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l1] - dop, s_sp);
+                } else if constexpr (MODE == FLUX_SYN_IC) {
+                    b0 = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, s_nu[l0] - dop, s_sp);
+                    b1 = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, s_nu[l1] - dop, s_sp);
+                } else {
+                    const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
+                    b0 = ic_table_eval(tab, s_nu[l0] - dop, &breach);
+                    b1 = ic_table_eval(tab, s_nu[l1] - dop, &breach);
+                }
                 s_B[l0 * KS + k] = b0 + geom;
                 s_B[l1 * KS + k] = b1 + geom;
             }
@@ -415,6 +452,9 @@ vag_flux_grid_kernel(FluxArgs a) {
             atomicAdd(a.work_count, n_evals);
             atomicAdd(a.work_count + 1, n_interps);
         }
+    }
+    if constexpr (MODE == FLUX_SSC) {
+        if (breach) atomicOr(a.ic_status + m, 2);
     }
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)

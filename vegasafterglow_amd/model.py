@@ -155,11 +155,11 @@ class Flux:
 class FluxDict:
     """FluxDict{total, fwd, rvs} (pybind.cpp:478-483, pymodel.cpp:350-364)."""
 
-    def __init__(self, fwd_sync):
-        self.fwd = Flux(sync=fwd_sync)
+    def __init__(self, fwd_sync, fwd_ssc=None):
+        self.fwd = Flux(sync=fwd_sync, ssc=fwd_ssc)
         self.rvs = Flux()
-        self.total = fwd_sync.copy()
-        for a in (self.total, self.fwd.sync):
+        self.total = fwd_sync.copy() if fwd_ssc is None else fwd_sync + fwd_ssc
+        for a in (self.total, self.fwd.sync, self.fwd.ssc):
             a.setflags(write=False)
 
 
@@ -199,8 +199,8 @@ class Model:
             raise TypeError("medium must be ISM or Wind")
         if rvs_rad is not None:
             raise NotImplementedError("reverse shock is SURVEY section 8(f) rank 2: not on the accelerated path yet")
-        if fwd_rad.ssc:
-            raise NotImplementedError("SSC / inverse Compton is SURVEY section 8(f) rank 1: not on the accelerated path yet")
+        if fwd_rad.kn and not fwd_rad.ssc:
+            pass  # Klein-Nishina corrections only act through the IC cooling enabled by ssc (pymodel.h:567-577)
         if not axisymmetric:
             raise NotImplementedError("axisymmetric=False is SURVEY section 8(f) rank 3")
         _req(math.isfinite(rtol) and 0 < rtol < 1, f"rtol must be in (0, 1), got {rtol}")
@@ -219,7 +219,7 @@ class Model:
         p.phi_resol, p.theta_resol, p.t_resol = res
         p.rtol = self.rtol
         p.radiative_fireball = 1 if radiative_fireball else 0
-        p.flags = 0
+        p.flags = (_lib.FLAG_SSC if fwd_rad.ssc else 0) | (_lib.FLAG_KN if fwd_rad.kn else 0)
         _lib.check(_lib.load().vag_params_validate(C.byref(p)))
         self.params = p
 
@@ -230,6 +230,13 @@ class Model:
         _req(nu.size > 0, "frequency array must be non-empty")
         out = np.empty((nu.size, t.size))
         h, lock = get_context(self._device)
+        if self.fwd_rad.ssc:
+            ssc = np.empty((nu.size, t.size))
+            with lock:
+                _lib.check(_lib.load().vag_flux_density_grid_components_batch(
+                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
+                    out.ctypes.data_as(_dp), ssc.ctypes.data_as(_dp)))
+            return FluxDict(out, ssc)
         with lock:
             _lib.check(_lib.load().vag_flux_density_grid_batch(
                 h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
@@ -257,6 +264,13 @@ class Model:
         _req(t.size > 0, "time array must be non-empty")
         out = np.empty(t.size)
         h, lock = get_context(self._device)
+        if self.fwd_rad.ssc:
+            ssc = np.empty(t.size)
+            with lock:
+                _lib.check(_lib.load().vag_flux_components_batch(
+                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, float(nu_min), float(nu_max), int(num_nu),
+                    out.ctypes.data_as(_dp), ssc.ctypes.data_as(_dp)))
+            return FluxDict(out, ssc)
         with lock:
             _lib.check(_lib.load().vag_flux_batch(h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size,
                                                   float(nu_min), float(nu_max), int(num_nu), out.ctypes.data_as(_dp)))
