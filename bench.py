@@ -166,7 +166,8 @@ def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
     for b in configs.C4_BANDS:
         sel = nu == b
         fit.add_flux_density(b, t[sel], f_obs[sel], 0.1 * f_obs[sel])
-    defs = [fitting.ParamDef(n, lo, hi, fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
+    defs = [fitting.ParamDef(n, 10.0 ** lo if lg else lo, 10.0 ** hi if lg else hi,
+                             fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
     spec, lo, hi = fit.build_spec(defs)
     theta = lo + (hi - lo) * np.random.default_rng(0).random((nwalkers, len(defs)))
     a, b = shard_range(nwalkers, rank, world)

@@ -158,7 +158,7 @@ def test_consolidate_sorts_by_time_and_normalises_weights():
 
 def test_spec_is_the_transformer_as_a_slot_map():
     f = _fitter()
-    defs = [fitting.ParamDef("E_iso", 50, 54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8),
+    defs = [fitting.ParamDef("E_iso", 1e50, 1e54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8),
             fitting.ParamDef("p", 2.05, 2.8), fitting.ParamDef("n_ism", 1e-2, 1e-2, fitting.Scale.fixed),
             fitting.ParamDef("eps_B", 1e-3, 1e-3, fitting.Scale.fixed, initial=2e-3)]
     spec, lo, hi = f.build_spec(defs)
@@ -171,7 +171,7 @@ def test_spec_is_the_transformer_as_a_slot_map():
 
 def test_log_prob_batch_bounds_prior_and_nonfinite_handling():
     f = _fitter()
-    defs = [fitting.ParamDef("E_iso", 50, 54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8)]
+    defs = [fitting.ParamDef("E_iso", 1e50, 1e54, fitting.Scale.log), fitting.ParamDef("theta_v", 0.0, 0.8)]
     calls = []
 
     def fake_loglike(s):

@@ -178,7 +178,8 @@ def _c4_fitter(oracle):
     for b in configs.C4_BANDS:
         sel = nu == b
         f.add_flux_density(b, t[sel], f_obs[sel], 0.1 * f_obs[sel])
-    defs = [fitting.ParamDef(n, lo, hi, fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
+    defs = [fitting.ParamDef(n, 10.0 ** lo if lg else lo, 10.0 ** hi if lg else hi,
+                             fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
     return f, defs
 
 
@@ -187,8 +188,7 @@ def test_loglike_batch_matches_fitter_formula_on_oracle_fluxes(eng, oracle):
     oracle's Model.flux_density (fitter.py:497-533); invalid / out-of-domain walkers -> -inf."""
     f, defs = _c4_fitter(oracle)
     rng = np.random.default_rng(0)
-    lo = np.array([d.lower for d in defs])
-    hi = np.array([d.upper for d in defs])
+    _, lo, hi = f.build_spec(defs)  # sampler-space bounds (log10 for LOG-scale parameters)
     samples = lo + (hi - lo) * rng.random((64, len(defs)))
     samples[5, 2] = -0.5  # theta_c < 0: Model construction raises in the reference -> eval_one returns -inf
     got = f.loglike_batch(samples, defs)
@@ -364,5 +364,35 @@ def test_ssc_batch_band_model_api_and_loud_limits(eng, oracle):
     rc = lib.vag_flux_density_grid_batch(h, mixed, 2, SSC_T.ctypes.data_as(dp), SSC_T.size, SSC_NU.ctypes.data_as(dp),
                                          SSC_NU.size, out.ctypes.data_as(dp))
     assert rc == _lib.VAG_E_UNSUPPORTED
-    with pytest.raises(NotImplementedError):
-        m.flux_density(t, np.full(t.size, 1e17))
+
+
+def test_ssc_series_and_loglike(eng, oracle):
+    """Model.flux_density and the Fitter log-likelihood with Radiation(ssc=True, kn=True)."""
+    rng = np.random.default_rng(5)
+    t = np.sort(10 ** rng.uniform(2.5, 6.5, 90))
+    nu = 10 ** rng.choice([9.0, 14.7, 17.5, 22.0, 25.0], size=t.size)
+    prms = [_abi.make_params(**SSC_CASES[n]) for n in ("gauss_kn", "tophat_kn_weakB", "powerlaw_wind_kn")]
+    got = gpu_series(eng, prms, t, nu)
+    for i, prm in enumerate(prms):
+        assert_close(got[i], oracle.flux_density(prm, t, nu))
+    # Fitter(fwd_ssc=True, kn=True): ln L from the device == the fitter formula on the checker's fluxes
+    f = fitting.Fitter(z=1.0, lumi_dist=1e28, jet="gaussian", medium="ism", fwd_ssc=True, kn=True)
+    truth = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True)
+    f_obs = oracle.flux_density(truth, t, nu) * (1 + 0.05 * rng.standard_normal(t.size))
+    f.add_flux_density(nu, t, f_obs, 0.05 * f_obs)
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e51, 1e53, S.log), P("Gamma0", 100, 500, S.log), P("theta_c", 0.05, 0.2, S.linear),
+            P("theta_v", 0.0, 0.4, S.linear), P("n_ism", 0.1, 10, S.log), P("p", 2.1, 2.6, S.linear),
+            P("eps_e", 0.03, 0.3, S.log), P("eps_B", 1e-3, 1e-1, S.log), P("xi_e", 1.0, 1.0, S.fixed, 1.0)]
+    lo = np.array([np.log10(d.lower) if d.scale is S.log else d.lower for d in defs[:8]])
+    hi = np.array([np.log10(d.upper) if d.scale is S.log else d.upper for d in defs[:8]])
+    theta = lo + (hi - lo) * rng.random((6, 8))
+    ll = f.loglike_batch(theta, defs)
+    f._consolidate_data()
+    for w in range(theta.shape[0]):
+        v = [10 ** x if d.scale is S.log else x for x, d in zip(theta[w], defs[:8])]
+        prm = _abi.make_params(jet="GaussianJet", E_iso=v[0], Gamma0=v[1], theta_c=v[2], theta_obs=v[3], n_ism=v[4], p=v[5],
+                               eps_e=v[6], eps_B=v[7], ssc=True, kn=True)
+        model = oracle.flux_density(prm, f._all_t, f._all_nu)
+        chi2 = np.sum(f._all_weights * ((np.log(model) - f._all_log_flux) / f._all_log_err) ** 2)
+        assert abs(ll[w] - (-0.5 * chi2)) <= 1e-5 * max(1.0, abs(chi2)), (w, ll[w], -0.5 * chi2)

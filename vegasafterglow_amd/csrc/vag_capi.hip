@@ -326,8 +326,10 @@ int vag_ctx_create(int device, vag_ctx** out) {
         if (c->d_knlut.ensure(sizeof(double) * lut.size())) return VAG_E_HIP;
         HIPCHK(hipMemcpy(c->d_knlut.p, lut.data(), sizeof(double) * lut.size(), hipMemcpyHostToDevice));
     }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(vag_flux_series_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (const void* fn : {reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC>)})
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
         std::vector<double> tab;
         const double err = build_softplus_table(tab);
@@ -604,8 +606,7 @@ __global__ void vag_add_kernel(double* __restrict__ out, const double* __restric
 
 // SSC emission of the whole batch on a (t, nu) grid (single_shock_emission, pybind/pymodel.h:896-919):
 // observation band per k -> SSC table per representative cell -> EAT flux integration over the tables.
-int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
-                 int nnu, const double* d_bandw, double* d_ssc) {
+int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2nu, int nnu) {
     hipStream_t st = c->stream;
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
     if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
@@ -623,8 +624,11 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
                            c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>());
         HIPCHK(hipGetLastError());
     }
-    int rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
-    if (rc) return rc;
+    return VAG_OK;
+}
+
+int check_ic_status(vag_ctx* c, int nb) {
+    hipStream_t st = c->stream;
     std::vector<int> h(nb);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_icstatus.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -634,6 +638,15 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
             return set_err(VAG_E_UNSUPPORTED, "model %d: SSC query left the clamped band (the reference would rebuild the cell)", m);
     }
     return VAG_OK;
+}
+
+int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
+                 int nnu, const double* d_bandw, double* d_ssc) {
+    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu, nnu);
+    if (rc) return rc;
+    rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
+    if (rc) return rc;
+    return check_ic_status(c, nb);
 }
 
 // Grid request for a batch: fwd.sync -> d_sync, fwd.ssc -> d_ssc (zeros without SSC), or their sum into d_sync when
@@ -681,7 +694,7 @@ __global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ pa
 }
 
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
-                    int n, double* d_out) {
+                    int n, double* d_out, int mode = FLUX_SYN) {
     hipStream_t st = c->stream;
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
@@ -691,8 +704,11 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3) * ks + SP_TABLE_DOUBLES);
+    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3 + (mode == FLUX_SYN_IC ? VAG_NQ : 0)) * ks + SP_TABLE_DOUBLES);
     SeriesArgs a;
+    a.cellq = c->d_cellq.as<double>();
+    a.ictab = c->d_ictab.as<double>();
+    a.ic_status = c->d_icstatus.as<int>();
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
     a.geo_th = c->d_geo_th.as<double>();
@@ -713,7 +729,12 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = (int)ppb;
     if (c->n_rows > 0) {
-        hipLaunchKernelGGL(vag_flux_series_kernel, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        if (mode == FLUX_SYN_IC)
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN_IC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        else if (mode == FLUX_SSC)
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SSC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
@@ -721,6 +742,20 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
                        c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, (int)ppb, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
+    return VAG_OK;
+}
+
+// One chunk of a (t, nu) series for the batch: fwd.sync (+ fwd.ssc from the prepared tables) -> d_out[nb][n].
+int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
+                 double* d_out) {
+    if (!(c->batch_flags & VAG_FLAG_SSC)) return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, d_out);
+    int rc = run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, d_out, FLUX_SYN_IC);
+    if (rc) return rc;
+    if (c->d_ssc.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
+    rc = run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, c->d_ssc.as<double>(), FLUX_SSC);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_out, c->d_ssc.as<double>(), (size_t)nb * n);
+    HIPCHK(hipGetLastError());
     return VAG_OK;
 }
 
@@ -821,21 +856,29 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    if (c->batch_flags & VAG_FLAG_SSC)
-        return set_err(VAG_E_UNSUPPORTED, "SSC for the (t, nu) series form is not on the device yet; use flux_density_grid");
+    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+    if (ssc) {  // the comoving band spans all requested frequencies (pymodel.h:896-909)
+        rc = build_ssc_tables(c, d_params, nb, c->d_lg2nu.as<double>(), n);
+        if (rc) return rc;
+    }
     const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
-    if (n <= chunk) return run_flux_series(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
+    if (n <= chunk) {
+        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
+        if (rc) return rc;
+        return ssc ? check_ic_status(c, nb) : VAG_OK;
+    }
     DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
     if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
     for (int s0 = 0; s0 < n; s0 += chunk) {
         const int m = std::min(chunk, n - s0);
-        rc = run_flux_series(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m, tmp.as<double>());
+        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m, tmp.as<double>());
         if (rc) break;
         HIPCHK(hipMemcpy2DAsync(d_out + s0, sizeof(double) * n, tmp.p, sizeof(double) * m, sizeof(double) * m, (size_t)nb,
                                 hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     tmp.release();
+    if (rc == VAG_OK && ssc) rc = check_ic_status(c, nb);
     return rc;
 }
 
@@ -1052,16 +1095,19 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     if (rc) return rc;
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
-    if (c->batch_flags & VAG_FLAG_SSC)
-        return set_err(VAG_E_UNSUPPORTED, "SSC in the batched log-likelihood is not on the device yet");
-    rc = run_flux_series(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
-                         c->d_series_flux.as<double>());
+    if (c->batch_flags & VAG_FLAG_SSC) {
+        rc = build_ssc_tables(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2nu.as<double>(), n);
+        if (rc) return rc;
+    }
+    rc = series_chunk(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
+                      c->d_series_flux.as<double>());
     if (rc) return rc;
     hipLaunchKernelGGL(vag_valid_from_meta, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb,
                        c->d_valid.as<int>());
     hipLaunchKernelGGL(vag_loglike_kernel, dim3(nb), dim3(64), 0, c->stream, c->d_series_flux.as<double>(), n,
                        d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, c->d_valid.as<int>(), d_out);
     HIPCHK(hipGetLastError());
+    if (c->batch_flags & VAG_FLAG_SSC) return check_ic_status(c, nb);
     return VAG_OK;
 }
 

@@ -519,8 +519,12 @@ struct SeriesArgs {
     int pairs_per_block, max_blocks, k_stride;
     double* partial; // [nb][max_blocks][n]
     const double* sp_table;
+    const double* cellq;  // FLUX_SYN_IC: [cells][FLUX_NQ]
+    const double* ictab;  // FLUX_SSC: [cells][FLUX_IC_STRIDE]
+    int* ic_status;       // FLUX_SSC: per-model breach flag
 };
 
+template <int MODE>
 __global__ void __launch_bounds__(SERIES_THREADS)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -539,7 +543,9 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
+    double* s_q = s_geom + KS;  // [FLUX_NQ][KS], FLUX_SYN_IC only
     for (int i = tid; i < SP_TABLE_DOUBLES; i += SERIES_THREADS) s_sp[i] = a.sp_table[i];
+    int breach = 0;
 
     const vag_model_params P = a.params[m];
     const double one_plus_z = 1 + P.z;
@@ -571,6 +577,13 @@ vag_flux_series_kernel(SeriesArgs a) {
                 const int par = q / K, k = q - par * K;
                 s_par[par * KS + k] = src[q];
             }
+            if (MODE == FLUX_SYN_IC) {
+                const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K) * FLUX_NQ;
+                for (int q = tid; q < FLUX_NQ * K; q += SERIES_THREADS) {
+                    const int par = q / K, k = q - par * K;
+                    s_q[par * KS + k] = srcq[q];
+                }
+            }
             staged_rep = rep;
             __syncthreads();
         }
@@ -598,8 +611,20 @@ vag_flux_series_kernel(SeriesArgs a) {
                             hi = mid;
                     }
                     const int k = lo;
-                    const double blo = log2_I_nu_fast(s_par + k, KS, sc, nuq[q] - s_dop[k], s_sp) + s_geom[k];
-                    const double bhi = log2_I_nu_fast(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp) + s_geom[k + 1];
+                    double blo, bhi;
+                    if (MODE == FLUX_SYN) {
+                        blo = log2_I_nu_fast(s_par + k, KS, sc, nuq[q] - s_dop[k], s_sp);
+                        bhi = log2_I_nu_fast(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp);
+                    } else if (MODE == FLUX_SYN_IC) {
+                        blo = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, nuq[q] - s_dop[k], s_sp);
+                        bhi = log2_I_nu_ic(s_par + k + 1, KS, s_q + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp);
+                    } else {
+                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + k) * FLUX_IC_STRIDE;
+                        blo = ic_table_eval(tab, nuq[q] - s_dop[k], &breach);
+                        bhi = ic_table_eval(tab + FLUX_IC_STRIDE, nuq[q] - s_dop[k + 1], &breach);
+                    }
+                    blo += s_geom[k];
+                    bhi += s_geom[k + 1];
                     const double sl = (bhi - blo) * (1.0 / (s_t[k + 1] - s_t[k]));
                     if (isfinite(sl)) acc[q] += exp2_fast(blo + (t - s_t[k]) * sl);
                 }
@@ -611,6 +636,7 @@ vag_flux_series_kernel(SeriesArgs a) {
         const int s = tid + q * SERIES_THREADS;
         if (s < a.n) my_partial[s] = acc[q];
     }
+    if (MODE == FLUX_SSC && breach) atomicOr(a.ic_status + m, 2);
 }
 
 // chi^2 / log-likelihood of Fitter._evaluate (VegasAfterglow/fitting/fitter.py:497-533,

@@ -54,7 +54,11 @@ class Fitter:
     """Fitter(z, lumi_dist, jet=..., medium=..., resolution=..., rtol=...) for point flux-density data."""
 
     def __init__(self, z, lumi_dist, jet="tophat", medium="ism", resolution=(0.06, 0.15, 6.0), rtol=1e-6,
-                 radiative_fireball=True, device=0):
+                 radiative_fireball=True, device=0, fwd_ssc=False, kn=False, rvs_shock=False, rvs_ssc=False,
+                 magnetar=False):
+        if rvs_shock or rvs_ssc or magnetar:
+            raise NotImplementedError("reverse shock / magnetar injection are not on the accelerated path")
+        self.fwd_ssc, self.kn = bool(fwd_ssc), bool(kn)
         if jet not in JET_TYPES:
             raise ValueError(f"Unknown jet type: {jet}")
         if medium not in MEDIUM_TYPES:
@@ -117,6 +121,7 @@ class Fitter:
         p.phi_resol, p.theta_resol, p.t_resol = self.resolution
         p.rtol = self.rtol
         p.radiative_fireball = 1 if self.radiative_fireball else 0
+        p.flags = (_lib.FLAG_SSC if self.fwd_ssc else 0) | (_lib.FLAG_KN if self.kn else 0)  # fitter.py:466-473
         return p
 
     def build_spec(self, param_defs: Sequence[ParamDef]):
@@ -140,8 +145,9 @@ class Fitter:
         spec.ln_flux = self._all_log_flux.ctypes.data_as(_dp)
         spec.ln_err = self._all_log_err.ctypes.data_as(_dp)
         spec.weight = self._all_weights.ctypes.data_as(_dp)
-        lower = np.array([pd.lower for pd in free], dtype=np.float64)
-        upper = np.array([pd.upper for pd in free], dtype=np.float64)
+        # sampler-space bounds: log10 of the ParamDef bounds for LOG-scale parameters (fitting/params.py:196-201)
+        lower = np.array([np.log10(pd.lower) if pd.scale is Scale.log else pd.lower for pd in free], dtype=np.float64)
+        upper = np.array([np.log10(pd.upper) if pd.scale is Scale.log else pd.upper for pd in free], dtype=np.float64)
         return spec, lower, upper
 
     def loglike_batch(self, samples, param_defs):
