@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 1
+#define VAG_ABI_VERSION 2
 
 /* error codes */
 #define VAG_OK 0
@@ -45,11 +45,14 @@ extern "C" {
 #define VAG_JET_POWERLAW 2
 #define VAG_JET_TWO_COMPONENT 3
 
-/* Radiation flags.  Inverse-Compton cooling + SSC emission (src/radiation/inverse-compton.*) is SURVEY 8(f) rank 1:
- * on the device for flux_density_grid / flux (grid and band forms); the series form and the batched log-likelihood
- * still return VAG_E_UNSUPPORTED with these flags. */
+/* Radiation flags.  VAG_FLAG_SSC / VAG_FLAG_KN = fwd_rad Radiation(ssc=, kn=): inverse-Compton cooling + SSC emission
+ * (src/radiation/inverse-compton.*).  VAG_FLAG_RVS = Model(rvs_rad=Radiation(...)) i.e. the coupled forward+reverse
+ * shock solve (src/dynamics/reverse-shock.tpp); VAG_FLAG_RVS_SSC / VAG_FLAG_RVS_KN = rvs_rad's ssc / kn. */
 #define VAG_FLAG_SSC 1
 #define VAG_FLAG_KN 2
+#define VAG_FLAG_RVS 4
+#define VAG_FLAG_RVS_SSC 8
+#define VAG_FLAG_RVS_KN 16
 
 /* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
 #define VAG_MEDIUM_ISM 0
@@ -60,7 +63,7 @@ extern "C" {
  *   Model(jet, medium, Observer(lumi_dist, z, theta_obs), Radiation(eps_e, eps_B, p, xi_e),
  *         resolutions=(phi, theta, t), rtol, axisymmetric=True, radiative_fireball)
  * (pybind/pybind.cpp:384-422, pybind/pymodel.h:613-649), flattened to plain scalars.
- * All doubles; the two tags are int32.  Layout is fixed (200 bytes) and is what the
+ * All doubles; the two tags are int32.  Layout is fixed (232 bytes) and is what the
  * device kernels read straight from HBM.
  */
 typedef struct vag_model_params {
@@ -75,7 +78,7 @@ typedef struct vag_model_params {
     double theta_w;  /* TwoComponentJet wing angle [rad] */
     double E_iso_w;  /* TwoComponentJet wing energy [erg] */
     double Gamma0_w; /* TwoComponentJet wing Lorentz factor */
-    double duration; /* engine duration T0 [s] (only enters via t0 of reverse shock; kept for parity) */
+    double duration; /* engine duration T0 [s] (shapes the reverse shock and its time lattice) */
     /* medium */
     double n_ism;  /* ISM number density [cm^-3]; Wind: ISM floor */
     double A_star; /* Wind parameter */
@@ -96,6 +99,11 @@ typedef struct vag_model_params {
     double rtol;        /* ODE tolerance, (0,1) */
     int32_t radiative_fireball; /* 1 = radiative losses feed back on dynamics (default) */
     int32_t flags;              /* VAG_FLAG_* (Radiation(ssc=, kn=), pybind/pybind.cpp:368-377); other bits must be 0 */
+    /* reverse-shock radiation (Model(rvs_rad=...), pybind/pymodel.h:613-629); read only when VAG_FLAG_RVS is set */
+    double rvs_eps_e;
+    double rvs_eps_B;
+    double rvs_p;
+    double rvs_xi_e;
 } vag_model_params;
 
 /* Fill a params struct with the reference's defaults: Radiation xi_e = 1,

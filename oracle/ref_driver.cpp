@@ -32,6 +32,20 @@ std::pair<Coord, Shock> solve_fwd_shock_like(JetVariant const& jet, MediumVarian
         jet, medium);
 }
 
+// pybind/shock_dispatch.h:29-43 restated
+std::tuple<Coord, Shock, Shock> solve_shock_pair_like(JetVariant const& jet, MediumVariant const& medium, Array const& t_obs,
+                                                      Real theta_w, const vag_model_params& p, RadParams const& fwd_rad,
+                                                      RadParams const& rvs_rad) {
+    return std::visit(
+        [&](auto const& j, auto const& med) {
+            auto coord = auto_grid(j, med, t_obs, theta_w, p.theta_obs, p.z, true, p.phi_resol, p.theta_resol, p.t_resol,
+                                   true);
+            auto [fwd, rvs] = generate_shock_pair(coord, med, j, fwd_rad, rvs_rad, p.rtol);
+            return std::tuple{std::move(coord), std::move(fwd), std::move(rvs)};
+        },
+        jet, medium);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -87,6 +101,11 @@ struct Pipeline {
     SynElectronGrid elec;
     SynPhotonGrid phot;
     bool ssc{false}, kn{false};
+    // reverse shock (Model(rvs_rad=...)): same EAT grids, own electrons / photons (pymodel.h:940-958)
+    bool rvs{false}, rvs_ssc{false}, rvs_kn{false};
+    Shock rvs_shock;
+    SynElectronGrid rvs_elec;
+    SynPhotonGrid rvs_phot;
 };
 
 void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) {
@@ -96,9 +115,19 @@ void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) 
     MediumVariant med = make_medium(p);
     const Real theta_w = con::pi / 2; // pymodel.h:866
     const Real lumi_dist = p.lumi_dist * unit::cm;
-    auto [coord, shock] = solve_fwd_shock_like(jet, med, t_obs, theta_w, p, rad);
-    out.coord = std::move(coord);
-    out.shock = std::move(shock);
+    out.rvs = (p.flags & VAG_FLAG_RVS) != 0;
+    if (out.rvs) {
+        RadParams rrad{p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e};
+        rrad.radiative = rad.radiative;
+        auto [coord, shock, rshock] = solve_shock_pair_like(jet, med, t_obs, theta_w, p, rad, rrad);
+        out.coord = std::move(coord);
+        out.shock = std::move(shock);
+        out.rvs_shock = std::move(rshock);
+    } else {
+        auto [coord, shock] = solve_fwd_shock_like(jet, med, t_obs, theta_w, p, rad);
+        out.coord = std::move(coord);
+        out.shock = std::move(shock);
+    }
     out.obs.observe(out.coord, out.shock, lumi_dist, p.z);
     out.elec = generate_syn_electrons(out.shock, out.coord);
     out.phot = generate_syn_photons(out.shock, out.elec, out.coord);
@@ -110,10 +139,22 @@ void run_pipeline(const vag_model_params& p, Array const& t_obs, Pipeline& out) 
         else
             Thomson_cooling(out.elec, out.phot, out.shock, out.coord);
     }
+    if (out.rvs) {
+        out.rvs_elec = generate_syn_electrons(out.rvs_shock, out.coord);
+        out.rvs_phot = generate_syn_photons(out.rvs_shock, out.rvs_elec, out.coord);
+        out.rvs_ssc = (p.flags & VAG_FLAG_RVS_SSC) != 0;
+        out.rvs_kn = (p.flags & VAG_FLAG_RVS_KN) != 0;
+        if (out.rvs_ssc) {
+            if (out.rvs_kn)
+                KN_cooling(out.rvs_elec, out.rvs_phot, out.rvs_shock, out.coord);
+            else
+                Thomson_cooling(out.rvs_elec, out.rvs_phot, out.rvs_shock, out.coord);
+        }
+    }
 }
 
 // SSC photons with the per-k observation band clamp of single_shock_emission, pybind/pymodel.h:896-914
-auto make_ic_photons(Pipeline& pl, Array const& nu_obs) {
+auto make_ic_photons(Pipeline& pl, Array const& nu_obs, bool rvs = false) {
     const Real lg2_1pz = fast_log2(pl.obs.one_plus_z);
     const Real lg2_nu_lo = fast_log2(xt::amin(nu_obs)()) + lg2_1pz;
     const Real lg2_nu_hi = fast_log2(xt::amax(nu_obs)()) + lg2_1pz;
@@ -121,6 +162,7 @@ auto make_ic_photons(Pipeline& pl, Array const& nu_obs) {
     const Array lg2_dop_max_k = xt::amax(pl.obs.lg2_doppler, {0, 1});
     const Array nu_eval_min_k = xt::exp2(lg2_nu_lo - lg2_dop_max_k);
     const Array nu_eval_max_k = xt::exp2(lg2_nu_hi - lg2_dop_min_k);
+    if (rvs) return generate_IC_photons(pl.rvs_elec, pl.rvs_phot, pl.rvs_kn, pl.coord, nu_eval_min_k, nu_eval_max_k);
     return generate_IC_photons(pl.elec, pl.phot, pl.kn, pl.coord, nu_eval_min_k, nu_eval_max_k);
 }
 
@@ -148,6 +190,15 @@ VAG_REF_API int vag_ref_flux_density_grid(const vag_model_params* p, const doubl
             auto ic = make_ic_photons(pl, nu_obs);
             const MeshGrid G = pl.obs.specific_flux(t_obs, nu_obs, ic) / unit::flux_den_cgs;
             F += G;
+        }
+        if (pl.rvs) {
+            const MeshGrid R = pl.obs.specific_flux(t_obs, nu_obs, pl.rvs_phot) / unit::flux_den_cgs;
+            F += R;
+            if (pl.rvs_ssc) {
+                auto ic = make_ic_photons(pl, nu_obs, true);
+                const MeshGrid G = pl.obs.specific_flux(t_obs, nu_obs, ic) / unit::flux_den_cgs;
+                F += G;
+            }
         }
         for (int l = 0; l < nnu; ++l)
             for (int i = 0; i < nt; ++i) out[size_t(l) * nt + i] = F(l, i);
@@ -185,6 +236,41 @@ VAG_REF_API int vag_ref_flux_density_grid_components(const vag_model_params* p, 
     }
 }
 
+// All four FluxDict components of the grid: out4 = {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc}, each [nnu][nt] (zeros when off)
+VAG_REF_API int vag_ref_flux_density_grid_components4(const vag_model_params* p, const double* t, int nt, const double* nu,
+                                                      int nnu, double* const* out4) {
+    try {
+        Array t_obs = Array::from_shape({size_t(nt)});
+        Array nu_obs = Array::from_shape({size_t(nnu)});
+        for (int i = 0; i < nt; ++i) t_obs(i) = t[i] * unit::sec;
+        for (int i = 0; i < nnu; ++i) nu_obs(i) = nu[i] * unit::Hz;
+        Pipeline pl;
+        run_pipeline(*p, t_obs, pl);
+        auto store = [&](double* dst, MeshGrid const& F) {
+            for (int l = 0; l < nnu; ++l)
+                for (int i = 0; i < nt; ++i) dst[size_t(l) * nt + i] = F(l, i) / unit::flux_den_cgs;
+        };
+        for (int c = 0; c < 4; ++c)
+            for (size_t q = 0; q < size_t(nnu) * nt; ++q) out4[c][q] = 0;
+        store(out4[0], pl.obs.specific_flux(t_obs, nu_obs, pl.phot));
+        if (pl.ssc) {
+            auto ic = make_ic_photons(pl, nu_obs);
+            store(out4[1], pl.obs.specific_flux(t_obs, nu_obs, ic));
+        }
+        if (pl.rvs) {
+            store(out4[2], pl.obs.specific_flux(t_obs, nu_obs, pl.rvs_phot));
+            if (pl.rvs_ssc) {
+                auto ic = make_ic_photons(pl, nu_obs, true);
+                store(out4[3], pl.obs.specific_flux(t_obs, nu_obs, ic));
+            }
+        }
+        return 0;
+    } catch (std::exception const& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Model.flux_density (series): out[n]
 VAG_REF_API int vag_ref_flux_density(const vag_model_params* p, const double* t, const double* nu, int n, double* out) {
     try {
@@ -201,6 +287,15 @@ VAG_REF_API int vag_ref_flux_density(const vag_model_params* p, const double* t,
             auto ic = make_ic_photons(pl, nu_obs);
             const Array G = pl.obs.specific_flux_series(t_obs, nu_obs, ic) / unit::flux_den_cgs;
             F += G;
+        }
+        if (pl.rvs) {
+            const Array R = pl.obs.specific_flux_series(t_obs, nu_obs, pl.rvs_phot) / unit::flux_den_cgs;
+            F += R;
+            if (pl.rvs_ssc) {
+                auto ic = make_ic_photons(pl, nu_obs, true);
+                const Array G = pl.obs.specific_flux_series(t_obs, nu_obs, ic) / unit::flux_den_cgs;
+                F += G;
+            }
         }
         for (int i = 0; i < n; ++i) out[i] = F(i);
         return 0;
@@ -219,8 +314,23 @@ VAG_REF_API int vag_ref_flux(const vag_model_params* p, const double* t, int nt,
         const Array nu_obs = xt::logspace(std::log10(nu_min * unit::Hz), std::log10(nu_max * unit::Hz), size_t(num_nu));
         Pipeline pl;
         run_pipeline(*p, t_obs, pl);
-        Array F = pl.obs.flux(t_obs, nu_obs, pl.phot);
-        for (int i = 0; i < nt; ++i) out[i] = F(i) / unit::flux_cgs;
+        // each enabled component is integrated and converted on its own, then summed (pymodel.cpp:350-364,391-410)
+        Array F = pl.obs.flux(t_obs, nu_obs, pl.phot) / unit::flux_cgs;
+        if (pl.ssc) {
+            auto ic = make_ic_photons(pl, nu_obs);
+            const Array G = pl.obs.flux(t_obs, nu_obs, ic) / unit::flux_cgs;
+            F += G;
+        }
+        if (pl.rvs) {
+            const Array R = pl.obs.flux(t_obs, nu_obs, pl.rvs_phot) / unit::flux_cgs;
+            F += R;
+            if (pl.rvs_ssc) {
+                auto ic = make_ic_photons(pl, nu_obs, true);
+                const Array G = pl.obs.flux(t_obs, nu_obs, ic) / unit::flux_cgs;
+                F += G;
+            }
+        }
+        for (int i = 0; i < nt; ++i) out[i] = F(i);
         return 0;
     } catch (std::exception const& e) {
         g_err = e.what();
@@ -234,15 +344,19 @@ VAG_REF_API int vag_ref_flux(const vag_model_params* p, const double* t, int nt,
 //   extra[6]=nu_m extra[7]=nu_c extra[8]=nu_a extra[9]=nu_M extra[10]=I_nu_max  (code units)
 //   extra[11]=lg2_t extra[12]=lg2_doppler extra[13]=lg2_geom : [n_phi_eff][n_theta][n_t]
 //   extra[14]=log2 I_nu at probe log2-frequencies: [n_theta][n_t][n_probe]
-VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
-                                const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
-                                const double* probe_lg2_nu, int n_probe) {
+static int details_impl(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                        const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff, const double* probe_lg2_nu,
+                        int n_probe, bool want_rvs) {
     try {
         Array t_obs = Array::from_shape({size_t(2)});
         t_obs(0) = t_min * unit::sec;
         t_obs(1) = t_max * unit::sec;
         Pipeline pl;
         run_pipeline(*p, t_obs, pl);
+        if (want_rvs && !pl.rvs) throw std::invalid_argument("model has no reverse shock");
+        Shock const& shock = want_rvs ? pl.rvs_shock : pl.shock;
+        SynElectronGrid const& elec = want_rvs ? pl.rvs_elec : pl.elec;
+        SynPhotonGrid const& phot = want_rvs ? pl.rvs_phot : pl.phot;
         auto const& c = pl.coord;
         const size_t nphi = c.phi.size(), nth = c.theta.size(), nt = c.t.shape()[2];
         shape->n_phi = int(nphi);
@@ -264,17 +378,17 @@ VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double 
         if (out->theta)
             for (size_t j = 0; j < nth; ++j) out->theta[j] = c.theta(j);
         copy2(out->t_src, c.t, 1 / unit::sec);
-        copy2(out->Gamma, pl.shock.Gamma, 1);
-        copy2(out->r, pl.shock.r, 1 / unit::cm);
-        copy2(out->t_comv, pl.shock.t_comv, 1 / unit::sec);
-        copy2(out->B, pl.shock.B, 1 / unit::Gauss);
-        copy2(out->N_p, pl.shock.N_p, 1);
-        copy2(out->Gamma_th, pl.shock.Gamma_th, 1);
+        copy2(out->Gamma, shock.Gamma, 1);
+        copy2(out->r, shock.r, 1 / unit::cm);
+        copy2(out->t_comv, shock.t_comv, 1 / unit::sec);
+        copy2(out->B, shock.B, 1 / unit::Gauss);
+        copy2(out->N_p, shock.N_p, 1);
+        copy2(out->Gamma_th, shock.Gamma_th, 1);
         auto ex = [&](int idx) -> double* { return (extra && idx < n_extra) ? extra[idx] : nullptr; };
         for (size_t j = 0; j < nth; ++j)
             for (size_t k = 0; k < nt; ++k) {
-                auto const& e = pl.elec(0, j, k);
-                auto const& ph = pl.phot(0, j, k);
+                auto const& e = elec(0, j, k);
+                auto const& ph = phot(0, j, k);
                 const size_t o = j * nt + k;
                 if (ex(0)) ex(0)[o] = e.gamma_m;
                 if (ex(1)) ex(1)[o] = e.gamma_c;
@@ -289,6 +403,7 @@ VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double 
                 if (ex(10)) ex(10)[o] = ph.I_nu_max;
                 if (ex(14))
                     for (int q = 0; q < n_probe; ++q) ex(14)[o * n_probe + q] = ph.compute_log2_I_nu(probe_lg2_nu[q]);
+                if (ex(15)) ex(15)[o] = double(shock.injection_idx(0, j));
             }
         for (size_t i = 0; i < nphi_eff; ++i)
             for (size_t j = 0; j < nth; ++j)
@@ -303,4 +418,17 @@ VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double 
         g_err = e.what();
         return -1;
     }
+}
+
+VAG_REF_API int vag_ref_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                                const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                                const double* probe_lg2_nu, int n_probe) {
+    return details_impl(p, t_min, t_max, shape, out, extra, n_extra, n_phi_eff, probe_lg2_nu, n_probe, false);
+}
+
+// Same protocol for the reverse shock's arrays; extra[15] = injection_idx per cell [n_theta][n_t].
+VAG_REF_API int vag_ref_details_rvs(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                                    const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                                    const double* probe_lg2_nu, int n_probe) {
+    return details_impl(p, t_min, t_max, shape, out, extra, n_extra, n_phi_eff, probe_lg2_nu, n_probe, true);
 }

@@ -193,7 +193,7 @@ static double medium_mass(const medium_t* m, double r) {
  * controlled_runge_kutta.hpp:56-156,752-782, dense_output_runge_kutta.hpp:324-361,
  * algebra/default_operations.hpp:431-447, integrate/max_step_checker.hpp:92
  * ---------------------------------------------------------------------------------------- */
-#define ODE_MAXN 8
+#define ODE_MAXN 12
 typedef void (*rhs_fn)(const double* x, double* dxdt, double t, void* ctx);
 
 typedef struct {
@@ -754,14 +754,38 @@ static void detect_symmetry(coord_t* c, const jet_t* jet) {
         c->symmetry = SYM_PHI_SYMMETRIC;
 }
 
-/* build_time_grid + scan_time_bounds + compute_time_grid_size + store_time_grid,
- * src/core/grid-refinement.h:472-528,571-636 (forward shock only, axisymmetric => phi_size 1) */
+/* logspace_with_cross_refinement, src/core/grid-refinement.cpp:166-197: result[t_num] */
+static void logspace_with_cross_refinement(double t_start, double t_end, double t_refine, size_t t_num, size_t base_t_num,
+                                           double* result) {
+    t_refine = dmin(dmax(t_refine, t_start), t_end); /* std::clamp */
+    if (t_refine <= t_start || t_refine >= t_end) {
+        logspace10(log10(t_start), log10(t_end), (int)t_num, result);
+        return;
+    }
+    const double log_total = log10(t_end / t_start);
+    const double log_after = log10(t_end / t_refine);
+    size_t n_post = (size_t)(base_t_num * log_after / log_total);
+    if (n_post < 2) n_post = 2;
+    if (n_post >= t_num) n_post = t_num / 2;
+    const size_t n_pre = t_num + 1 - n_post;
+    double* seg = malloc(sizeof(double) * ((n_pre > n_post ? n_pre : n_post) + 1));
+    size_t idx = 0;
+    for (size_t k = 0; k < t_num; ++k) result[k] = 0;
+    logspace10(log10(t_start), log10(t_refine), (int)n_pre, seg);
+    for (size_t k = 0; k < n_pre; ++k) result[idx++] = seg[k];
+    logspace10(log10(t_refine), log10(t_end), (int)n_post, seg);
+    for (size_t k = 1; k < n_post && idx < t_num; ++k) result[idx++] = seg[k];
+    free(seg);
+}
+
+/* build_time_grid + scan_time_bounds + compute_time_grid_size + make_time_grid + store_time_grid,
+ * src/core/grid-refinement.h:472-528,571-636 (axisymmetric => phi_size 1) */
 static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_min, double t_max, double z,
-                            double t_resol) {
+                            double t_resol, int is_rvs) {
     const int nth = c->n_theta;
     const double t_end = 1.01 * t_max / (1 + z);
     const double cos_tv = cos(c->theta_view), sin_tv = sin(c->theta_view);
-    double min_raw = t_end, min_guarded = t_end, min_cut = t_end;
+    double min_raw = t_end, min_guarded = t_end, min_cut = t_end, max_ref = 0;
     double* t_dec = malloc(sizeof(double) * nth);
     for (int j = 0; j < nth; ++j) {
         const double b = gamma_to_beta(jet_Gamma0(jet, c->theta[j]));
@@ -769,14 +793,24 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
         const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
         const double td = estimate_t_dec(jet, med, c->theta[j]);
         t_dec[j] = td;
-        const double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+        double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+        if (is_rvs) {
+            cut = dmin(cut, 0.01 * jet->T0);
+            max_ref = dmax(max_ref, 10.0 * dmax(td, jet->T0));
+        }
         min_raw = dmin(min_raw, ts);
         min_guarded = dmin(min_guarded, dmax(ts, cut));
         min_cut = dmin(min_cut, cut);
     }
     const double min_t_early = min_raw, min_t_start = min_guarded;
     const int has_early = min_raw < min_cut;
-    const size_t t_num_tot = (size_t)(dmax(log10(t_end / min_t_start), 1.0) * t_resol);
+    const size_t t_num_base = (size_t)(dmax(log10(t_end / min_t_start), 1.0) * t_resol);
+    size_t t_num_rvs_extra = 0; /* compute_time_grid_size: rvs_refinement_ratio = 2 */
+    if (is_rvs && max_ref > min_t_start) {
+        const double log_pre_span = log10(dmin(max_ref, t_end) / min_t_start);
+        t_num_rvs_extra = (size_t)((2.0 - 1.0) * log_pre_span * t_resol);
+    }
+    const size_t t_num_tot = t_num_base + t_num_rvs_extra;
     const size_t t_num = t_num_tot + (has_early ? 1 : 0);
     c->n_t = (int)t_num;
     c->t = calloc((size_t)nth * t_num, sizeof(double));
@@ -784,7 +818,12 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     for (int r = 0; r < c->n_reps; ++r) {
         const int j_rep = c->reps[r];
         const int j_end = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
-        logspace_with_band_refinement(min_t_start, t_end, t_dec[j_rep] / 3, 3 * t_dec[j_rep], t_num_tot, 3.0, grid);
+        if (is_rvs) { /* make_time_grid, grid-refinement.h:571-581 */
+            const double t_cross_limit = dmax(t_dec[j_rep], jet->T0);
+            logspace_with_cross_refinement(min_t_start, t_end, 10 * t_cross_limit, t_num_tot, t_num_base, grid);
+        } else {
+            logspace_with_band_refinement(min_t_start, t_end, t_dec[j_rep] / 3, 3 * t_dec[j_rep], t_num_tot, 3.0, grid);
+        }
         for (int j = j_rep; j < j_end; ++j) {
             double* row = c->t + (size_t)j * t_num;
             if (has_early) {
@@ -801,7 +840,8 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
 
 /* auto_grid, src/core/grid-refinement.h:639-706 */
 static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_obs_min, double t_obs_max,
-                     double theta_cut, double theta_view, double z, double phi_resol, double theta_resol, double t_resol) {
+                     double theta_cut, double theta_view, double z, double phi_resol, double theta_resol, double t_resol,
+                     int is_rvs) {
     memset(c, 0, sizeof *c);
     c->theta_view = theta_view;
     const size_t min_theta_num = DEF_MIN_THETA_POINTS;
@@ -849,7 +889,7 @@ static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t
         }
     }
     detect_symmetry(c, jet);
-    build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol);
+    build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol, is_rvs);
     return 0;
 }
 
@@ -986,6 +1026,7 @@ static double compute_compression_fwd(double Gamma_downstr) {
 typedef struct {
     int n_theta, n_t;
     double *t_comv, *r, *theta, *Gamma, *Gamma_th, *B, *N_p; /* [n_theta][n_t] */
+    int* injection_idx;                                      /* [n_theta]; n_t = always injecting (shock.h:50-56) */
 } shock_t;
 
 static void shock_alloc(shock_t* s, int nth, int nt) {
@@ -1000,6 +1041,8 @@ static void shock_alloc(shock_t* s, int nth, int nt) {
     s->B = calloc(n, sizeof(double));
     s->N_p = calloc(n, sizeof(double));
     for (size_t i = 0; i < n; ++i) s->Gamma[i] = s->Gamma_th[i] = 1; /* Shock ctor, shock.cpp:12-24 */
+    s->injection_idx = malloc(sizeof(int) * nth);
+    for (int j = 0; j < nth; ++j) s->injection_idx[j] = nt;
 }
 static void shock_free(shock_t* s) {
     free(s->t_comv);
@@ -1009,6 +1052,7 @@ static void shock_free(shock_t* s) {
     free(s->Gamma_th);
     free(s->B);
     free(s->N_p);
+    free(s->injection_idx);
     memset(s, 0, sizeof *s);
 }
 
@@ -1105,6 +1149,510 @@ static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med
             }
         }
     }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Coupled forward + reverse shock: src/dynamics/reverse-shock.hpp:22-60, reverse-shock.tpp:11-614,
+ * shock-physics.h:40-245,401-437, src/dynamics/shock.cpp:93-137
+ * state: [Gamma, x4, x3, m2, m3, U2_th, U3_th, r, t_comv, theta, eps4, m4]
+ * ---------------------------------------------------------------------------------------- */
+enum { RS_GAMMA = 0, RS_X4, RS_X3, RS_M2, RS_M3, RS_U2, RS_U3, RS_R, RS_TCOMV, RS_THETA, RS_EPS4, RS_M4, RS_N };
+#define C_SIGMA_CUT 1e-6
+
+typedef struct {
+    const medium_t* med;
+    const jet_t* jet;
+    double theta0, Gamma4, deps0_dt, dm0_dt, u4, T0;
+    fwd_eqn_t rad_fwd;          /* RadiativeEfficiency(rad_fwd) + eps_e / eps_B / radiative of the forward shock */
+    double eps_B_rvs;
+    double u_x, r_x, B3_ordered_x, V3_comv_x, rho3_x; /* save_cross_state */
+} rvs_eqn_t;
+
+static double smoothstep(double edge0, double edge1, double x) {
+    double t = (x - edge0) / (edge1 - edge0);
+    if (t < 0.0)
+        t = 0.0;
+    else if (t > 1.0)
+        t = 1.0;
+    return t * t * (3.0 - 2.0 * t);
+}
+
+/* compute_downstr_4vel, src/dynamics/shock.cpp:93-137 */
+static double compute_downstr_4vel(double gamma_rel, double sigma) {
+    const double ad_idx = adiabatic_idx(gamma_rel);
+    const double gamma_m_1 = gamma_rel - 1;
+    const double ad_idx_m_2 = ad_idx - 2;
+    const double ad_idx_m_1 = ad_idx - 1;
+    if (sigma <= C_SIGMA_CUT)
+        return sqrt(dmax(gamma_m_1 * ad_idx_m_1 * ad_idx_m_1 / (-ad_idx * ad_idx_m_2 * gamma_m_1 + 2), 0.0));
+    const double gamma_sq = gamma_rel * gamma_rel;
+    const double gamma_p_1 = gamma_rel + 1;
+    const double term1 = -ad_idx * ad_idx_m_2;
+    const double term2 = gamma_sq - 1;
+    const double A = term1 * gamma_m_1 + 2;
+    const double B = -gamma_p_1 * (-ad_idx_m_2 * (ad_idx * gamma_sq + 1) + ad_idx * ad_idx_m_1 * gamma_rel) * sigma -
+                     gamma_m_1 * (term1 * (gamma_sq - 2) + 2 * gamma_rel + 3);
+    const double Cc = gamma_p_1 * (ad_idx * (1 - ad_idx / 4) * term2 + 1) * sigma * sigma +
+                      term2 * (2 * gamma_rel + ad_idx_m_2 * (ad_idx * gamma_rel - 1)) * sigma +
+                      gamma_p_1 * gamma_m_1 * gamma_m_1 * ad_idx_m_1 * ad_idx_m_1;
+    const double D = -gamma_m_1 * gamma_p_1 * gamma_p_1 * ad_idx_m_2 * ad_idx_m_2 * sigma * sigma / 4;
+    const double b = B / A, c = Cc / A, d = D / A;
+    const double P = c - b * b / 3;
+    const double Q = 2 * b * b * b / 27 - b * c / 3 + d;
+    const double u = sqrt(dmax(-P, 0.0) / 3);
+    const double denom = 2 * P * u;
+    const double v = (denom != 0) ? dmin(dmax(3 * Q / denom, -1.0), 1.0) : 0.0;
+    const double x_max = 2 * u * cos(acos(v) / 3) - b / 3;
+    if (x_max <= 0) return 0;
+    const double prod = -d / x_max;
+    const double sum = (c - prod) / x_max;
+    const double uds = (sum + sqrt(dmax(sum * sum - 4 * prod, 0.0))) / 2;
+    return sqrt(dmax(uds, 0.0));
+}
+
+/* compute_4vel_jump, shock-physics.h:58-66 */
+static double compute_4vel_jump(double gamma_rel, double sigma_upstr) {
+    const double u_down = compute_downstr_4vel(gamma_rel, sigma_upstr);
+    const double u_up = sqrt((1 + u_down * u_down) * dmax((gamma_rel - 1) * (gamma_rel + 1), 0.0)) + u_down * gamma_rel;
+    double ratio_u = u_up / u_down;
+    if (u_down == 0.) ratio_u = 4 * gamma_rel;
+    return ratio_u;
+}
+
+/* compute_rel_Gamma, shock-physics.h:190-198 */
+static double compute_rel_Gamma(double gamma1, double gamma2) {
+    const double u1u2 = sqrt(dmax((gamma1 - 1) * (gamma1 + 1) * (gamma2 - 1) * (gamma2 + 1), 0.0));
+    const double d = gamma1 - gamma2;
+    const double denom = gamma1 * gamma2 - 1 + u1u2;
+    if (denom <= 0) return 1;
+    return 1 + d * d / denom;
+}
+
+static double compute_compression(double Gamma_upstr, double Gamma_downstr, double sigma_upstr) {
+    return compute_4vel_jump(compute_rel_Gamma(Gamma_upstr, Gamma_downstr), sigma_upstr);
+}
+
+/* compute_sound_speed, shock-physics.h:77-80 */
+static double compute_sound_speed(double Gamma_rel) {
+    const double ad_idx = adiabatic_idx(Gamma_rel);
+    return sqrt(dmax(ad_idx * (ad_idx - 1) * (Gamma_rel - 1) / (1 + (Gamma_rel - 1) * ad_idx), 0.0)) * C_C;
+}
+
+static double compute_upstr_B(double rho_up, double sigma) {
+    return sqrt((4 * C_PI * C_C2) * sigma * rho_up);
+}
+
+/* compute_downstr_B, shock-physics.h:354-360 */
+static double compute_downstr_B(double eps_B, double rho_upstr, double B_upstr, double Gamma_th, double comp_ratio) {
+    const double rho_downstr = rho_upstr * comp_ratio;
+    const double e_th = (Gamma_th - 1) * rho_downstr * C_C2;
+    return sqrt(8 * C_PI * eps_B * e_th) + B_upstr * comp_ratio;
+}
+
+/* compute_Gamma_therm, shock-physics.h:290-301 */
+static double compute_Gamma_therm(double U_th, double mass, int limiter) {
+    if (mass == 0) return 1;
+    const double Gamma_th = U_th / (mass * C_C2) + 1;
+    if (limiter && Gamma_th < C_GAMMA_CUT) return 1; /* con::gamma_therm_cut == 1 + 1e-6 */
+    return Gamma_th;
+}
+
+static double rvs_shell_sigma(const rvs_eqn_t* e, const double* s) {
+    const double sigma = s[RS_EPS4] / (e->Gamma4 * s[RS_M4] * C_C2) - 1;
+    return (sigma > C_SIGMA_CUT) ? sigma : 0;
+}
+
+static double rvs_injection_efficiency(const rvs_eqn_t* e, const double* d) {
+    if (e->dm0_dt > 0 && d[RS_M4] > 0) return dmin(d[RS_M4] / e->dm0_dt, 1.0);
+    return 0.0;
+}
+
+/* FRShockEqn::crossing_complete, reverse-shock.tpp:46-58 (named jets: no mass injection) */
+static int rvs_crossing_complete(const rvs_eqn_t* e, const double* s, double t) {
+    if (s[RS_M3] < 0.999 * s[RS_M4]) return 0;
+    if (smoothstep(e->T0 * 1.5, e->T0 * 0.5, t) > 1e-6) return 0;
+    return 1;
+}
+
+/* FRShockEqn::operator(), reverse-shock.tpp:251-293 with the compute_* members of :60-249 */
+static void rvs_rhs(const double* raw, double* d, double t, void* vctx) {
+    const rvs_eqn_t* e = vctx;
+    double s[RS_N];
+    for (int i = 0; i < RS_N; ++i) s[i] = raw[i];
+    s[RS_GAMMA] = dmin(dmax(s[RS_GAMMA], 1.0), e->Gamma4);
+    s[RS_M3] = dmin(dmax(s[RS_M3], 0.0), dmax(s[RS_M4], 0.0));
+    s[RS_X3] = dmax(s[RS_X3], 0.0);
+    s[RS_U3] = dmax(s[RS_U3], 0.0);
+    const double Gamma = s[RS_GAMMA], Gamma4 = e->Gamma4;
+    const double u3 = sqrt((Gamma - 1) * (Gamma + 1));
+    d[RS_R] = u3 * (Gamma + u3) * C_C;
+    d[RS_TCOMV] = Gamma + u3;
+    const double rho = medium_rho(e->med, s[RS_R]);
+    d[RS_M2] = s[RS_R] * s[RS_R] * rho * d[RS_R];
+    const double inject_w = smoothstep(e->T0 * 1.5, e->T0 * 0.5, t);
+    d[RS_EPS4] = (inject_w > 1e-6) ? inject_w * e->deps0_dt : 0;
+    d[RS_M4] = (inject_w > 1e-6) ? inject_w * e->dm0_dt : 0;
+    if (e->jet->type == VAG_JET_TWO_COMPONENT) { /* python-level Ejecta: deps_dt / dm_dt are the zero functions */
+        d[RS_EPS4] += 0.0;
+        d[RS_M4] += 0.0;
+    }
+    const double Gamma34 = compute_rel_Gamma(Gamma4, Gamma);
+    const double sigma = rvs_shell_sigma(e, s);
+    const double comp_ratio = compute_4vel_jump(Gamma34, sigma);
+    const double f = rvs_injection_efficiency(e, d);
+    { /* compute_dx4_dt */
+        const double sound_expansion = compute_sound_speed(Gamma4) * d[RS_TCOMV];
+        d[RS_X4] = (f > 1e-6) ? f * e->u4 + (1 - f) * sound_expansion : sound_expansion;
+    }
+    { /* compute_dx3_dt */
+        const double sound_expansion = compute_sound_speed(Gamma34) * d[RS_TCOMV];
+        double dx3 = sound_expansion;
+        if (!(s[RS_M4] <= 0)) {
+            const double remaining = dmax(s[RS_M4] - s[RS_M3], 0.0);
+            const double crossing_w = f + (1.0 - f) * remaining / s[RS_M4];
+            const double penetration = Gamma * comp_ratio / Gamma4 - 1;
+            if (!(crossing_w < 1e-6) && !(penetration <= 0)) {
+                const double beta3 = gamma_to_beta(Gamma);
+                const double beta4 = gamma_to_beta(Gamma4);
+                const double dx3dt = (Gamma4 - Gamma) * (Gamma4 + Gamma) * (1 + beta3) * C_C /
+                                     (Gamma4 * Gamma4 * (beta3 + beta4) * penetration);
+                double crossing = fabs(dx3dt * Gamma);
+                if (penetration < 1) {
+                    const double cs = compute_sound_speed(Gamma34);
+                    const double va2 = sigma / (1 + sigma);
+                    const double cs2 = cs * cs / (C_C * C_C);
+                    const double v_ms = sqrt(va2 + cs2 * (1 - va2)) * C_C;
+                    crossing = dmin(crossing, v_ms * d[RS_TCOMV]);
+                }
+                dx3 = crossing_w * crossing + (1.0 - crossing_w) * sound_expansion;
+            }
+        }
+        d[RS_X3] = dx3;
+    }
+    { /* compute_dm3_dt */
+        double dm3 = 0.;
+        if (!(s[RS_M4] <= 0)) {
+            const double remaining = dmax(s[RS_M4] - s[RS_M3], 0.0);
+            if (!(remaining <= 0 && f < 1e-6)) {
+                const double eff_mass = f * s[RS_M4] + (1.0 - f) * remaining;
+                const double column_den3 = eff_mass * comp_ratio / s[RS_X4];
+                const double dm3dt = column_den3 * d[RS_X3];
+                if (f > 1e-6) {
+                    const double ratio = s[RS_M3] / s[RS_M4];
+                    const double cap_w = smoothstep(0, 1.0, ratio);
+                    const double capped_rate = dmin(dm3dt, d[RS_M4]);
+                    dm3 = (1.0 - cap_w) * dm3dt + cap_w * capped_rate;
+                } else {
+                    dm3 = dm3dt;
+                }
+            }
+        }
+        d[RS_M3] = dm3;
+    }
+    { /* compute_dU2_dt */
+        const double e_th = (Gamma - 1) * 4 * Gamma * rho * C_C2;
+        const double eps_rad = radiative_efficiency(&e->rad_fwd, s[RS_TCOMV], Gamma, e_th);
+        const double ad_idx = adiabatic_idx(Gamma);
+        const double shock_heating = d[RS_M2] * (Gamma - 1) * C_C2;
+        double dlnvdt = 2 * d[RS_R] / s[RS_R];
+        if (s[RS_X4] > 0) dlnvdt += d[RS_X4] / s[RS_X4];
+        const double adiabatic_cooling = -(ad_idx - 1) * dlnvdt * s[RS_U2];
+        d[RS_U2] = (1 - eps_rad) * shock_heating + adiabatic_cooling;
+    }
+    { /* compute_dU3_dt */
+        const double ad_idx = adiabatic_idx(Gamma34);
+        double dlnvdt = 2 * d[RS_R] / s[RS_R];
+        if (s[RS_X3] > 0) dlnvdt += d[RS_X3] / s[RS_X3];
+        const double adiabatic_cooling = -(ad_idx - 1) * dlnvdt * s[RS_U3];
+        const double shock_heating = d[RS_M3] * (Gamma34 - 1) * C_C2;
+        d[RS_U3] = shock_heating + adiabatic_cooling;
+    }
+    { /* compute_dGamma_dt */
+        const double ad_idx2 = adiabatic_idx(Gamma);
+        const double ad_idx3 = adiabatic_idx(Gamma34);
+        const double Gamma_eff2 = (ad_idx2 * Gamma * Gamma - ad_idx2 + 1) / Gamma;
+        const double Gamma_eff3 = (ad_idx3 * Gamma * Gamma - ad_idx3 + 1) / Gamma;
+        const double Gamma2 = Gamma * Gamma;
+        const double dGamma_eff2_dGamma = (ad_idx2 * Gamma2 + ad_idx2 - 1) / Gamma2;
+        const double dGamma_eff3_dGamma = (ad_idx3 * Gamma2 + ad_idx3 - 1) / Gamma2;
+        double deps_dt = 0;
+        if (e->jet->type == VAG_JET_TWO_COMPONENT) deps_dt = 0.0; /* Ejecta::deps_dt == zero function */
+        const double a = (Gamma - 1) * C_C2 * d[RS_M2] + (Gamma - Gamma4) * C_C2 * d[RS_M3] + Gamma_eff2 * d[RS_U2] +
+                         Gamma_eff3 * d[RS_U3] - deps_dt;
+        const double b = (s[RS_M2] + s[RS_M3]) * C_C2 + dGamma_eff2_dGamma * s[RS_U2] + dGamma_eff3_dGamma * s[RS_U3];
+        if (b == 0 || isnan(-a / b) || isinf(-a / b))
+            d[RS_GAMMA] = 0;
+        else
+            d[RS_GAMMA] = -a / b;
+    }
+    d[RS_THETA] = 0;
+}
+
+/* simpson_logspace / enclosed_mass, shock-physics.h:401-425 */
+static double enclosed_mass_generic(const medium_t* med, double r) {
+    const int N = 32;
+    const double u_max = log(r);
+    const double u_min = u_max - 18;
+    const double h = (u_max - u_min) / N;
+#define F_(u_) (medium_rho(med, exp(u_)) * exp(u_) * exp(u_) * exp(u_))
+    double sum = F_(u_min) + F_(u_max);
+    for (int i = 1; i < N; i += 2) sum += 4 * F_(u_min + i * h);
+    for (int i = 2; i < N; i += 2) sum += 2 * F_(u_min + i * h);
+#undef F_
+    return sum * h / 3;
+}
+
+/* compute_init_comv_shell_width, reverse-shock.tpp:367-376 */
+static double compute_init_comv_shell_width(double Gamma4, double t0, double T) {
+    const double beta4 = gamma_to_beta(Gamma4);
+    if (t0 < T) return Gamma4 * t0 * beta4 * C_C;
+    const double cs = compute_sound_speed(Gamma4);
+    return Gamma4 * T * beta4 * C_C + cs * (t0 - T) * Gamma4;
+}
+
+/* FRShockEqn::set_init_state, reverse-shock.tpp:312-354 */
+static void rvs_set_init_state(const rvs_eqn_t* e, double* s, double t0) {
+    const double Gamma4 = e->Gamma4;
+    const double beta4 = gamma_to_beta(Gamma4);
+    s[RS_R] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
+    s[RS_TCOMV] = s[RS_R] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
+    s[RS_THETA] = e->theta0;
+    const double dt = dmin(t0, e->T0);
+    s[RS_EPS4] = e->deps0_dt * dt;
+    s[RS_M4] = e->dm0_dt * dt;
+    s[RS_X4] = compute_init_comv_shell_width(Gamma4, t0, e->T0);
+    s[RS_M2] = enclosed_mass_generic(e->med, s[RS_R]);
+    const double m_jet_total = e->dm0_dt * e->T0;
+    if (m_jet_total > 0 && s[RS_M2] > 0)
+        s[RS_GAMMA] = Gamma4 / (1 + s[RS_M2] / m_jet_total);
+    else
+        s[RS_GAMMA] = Gamma4;
+    const double ad_idx = adiabatic_idx(s[RS_GAMMA]);
+    s[RS_U2] = enclosed_thermal_energy_generic(e->med, s[RS_R], s[RS_GAMMA], ad_idx,
+                                               e->rad_fwd.radiative ? e->rad_fwd.eps_e : 0.0);
+    const double Gamma34 = compute_rel_Gamma(Gamma4, s[RS_GAMMA]);
+    if (Gamma34 > 1 && s[RS_M4] > 0 && s[RS_X4] > 0) {
+        const double seed_frac = 1e-8;
+        const double sigma = rvs_shell_sigma(e, s);
+        const double comp_ratio = compute_4vel_jump(Gamma34, sigma);
+        s[RS_X3] = s[RS_X4] * seed_frac;
+        s[RS_M3] = s[RS_M4] * comp_ratio * s[RS_X3] / s[RS_X4];
+        s[RS_U3] = (Gamma34 - 1) * s[RS_M3] * C_C2;
+    } else {
+        s[RS_M3] = 0;
+        s[RS_U3] = 0;
+        s[RS_X3] = 0;
+    }
+}
+
+/* FRShockEqn::save_cross_state, reverse-shock.tpp:297-310 */
+static void rvs_save_cross_state(rvs_eqn_t* e, const double* s) {
+    e->r_x = s[RS_R];
+    e->u_x = sqrt((s[RS_GAMMA] - 1) * (s[RS_GAMMA] + 1));
+    e->V3_comv_x = e->r_x * e->r_x * s[RS_X3];
+    const double sigma4 = rvs_shell_sigma(e, s);
+    const double comp_ratio34 = compute_compression(e->Gamma4, s[RS_GAMMA], sigma4);
+    const double rho4 = s[RS_M4] / (s[RS_R] * s[RS_R] * s[RS_X4]);
+    e->rho3_x = rho4 * comp_ratio34;
+    const double B4 = compute_upstr_B(rho4, sigma4);
+    e->B3_ordered_x = B4 * comp_ratio34;
+}
+
+static void write_shock_state(shock_t* sh, size_t o, double t_comv, double r, double theta, double Gamma, double Gamma_th,
+                              double B, double mass) {
+    sh->t_comv[o] = t_comv;
+    sh->r[o] = r;
+    sh->theta[o] = theta;
+    sh->Gamma[o] = Gamma;
+    sh->Gamma_th[o] = Gamma_th;
+    sh->B[o] = B;
+    sh->N_p[o] = mass / C_MP;
+}
+
+/* save_fwd_shock_state (forward-shock.tpp:151-173) on the pair state: region 2 */
+static void save_fwd_state_of_pair(shock_t* sh, size_t o, const rvs_eqn_t* e, const double* s) {
+    const double comp_ratio = compute_compression(1, s[RS_GAMMA], 0);
+    const double rho = medium_rho(e->med, s[RS_R]);
+    const double Gamma_th = compute_Gamma_therm(s[RS_U2], s[RS_M2], 0);
+    const double B = compute_downstr_B(e->rad_fwd.eps_B, rho, 0, Gamma_th, comp_ratio);
+    write_shock_state(sh, o, s[RS_TCOMV], s[RS_R], s[RS_THETA], s[RS_GAMMA], Gamma_th, B, s[RS_M2]);
+}
+
+/* save_rvs_shock_state, reverse-shock.tpp:393-426 */
+static void save_rvs_shock_state(shock_t* sh, int j, int k, const rvs_eqn_t* e, const double* s) {
+    const size_t o = (size_t)j * sh->n_t + k;
+    if (k <= sh->injection_idx[j]) {
+        const double sigma4 = rvs_shell_sigma(e, s);
+        const double comp_ratio34 = compute_compression(e->Gamma4, s[RS_GAMMA], sigma4);
+        const double rho4 = s[RS_M4] / (s[RS_R] * s[RS_R] * s[RS_X4]);
+        const double Gamma3_th = compute_Gamma_therm(s[RS_U3], s[RS_M3], 1);
+        const double B4 = compute_upstr_B(rho4, sigma4);
+        const double B3 = compute_downstr_B(e->eps_B_rvs, rho4, B4, Gamma3_th, comp_ratio34);
+        write_shock_state(sh, o, s[RS_TCOMV], s[RS_R], s[RS_THETA], s[RS_GAMMA], Gamma3_th, B3, s[RS_M3]);
+    } else {
+        const double V3_comv = s[RS_R] * s[RS_R] * s[RS_X3];
+        const double comp_ratio = e->V3_comv_x / V3_comv;
+        const double Gamma3_th = compute_Gamma_therm(s[RS_U3], s[RS_M3], 0);
+        const double B3 = compute_downstr_B(e->eps_B_rvs, e->rho3_x, e->B3_ordered_x, Gamma3_th, comp_ratio);
+        write_shock_state(sh, o, s[RS_TCOMV], s[RS_R], s[RS_THETA], s[RS_GAMMA], Gamma3_th, B3, s[RS_M3]);
+    }
+}
+
+/* reverse_shock_early_extrap, reverse-shock.tpp:428-469 */
+static void reverse_shock_early_extrap(shock_t* sh, int j) {
+    const int nt = sh->n_t;
+    const size_t b = (size_t)j * nt;
+    int idx_cut = 0;
+    for (; idx_cut < nt; ++idx_cut)
+        if (sh->Gamma_th[b + idx_cut] > C_GAMMA_CUT) break;
+    const int offset = 2;
+    if (idx_cut == 0 || idx_cut >= nt - offset || idx_cut >= sh->injection_idx[j]) return;
+    const double log2_r = log2(sh->r[b + idx_cut]);
+    const double log2_Gamma_th = log2(sh->Gamma_th[b + idx_cut] - 1);
+    const double log2_B = log2(sh->B[b + idx_cut]);
+    const double log2_N_p = log2(sh->N_p[b + idx_cut]);
+    const double gamma_slope =
+        (log2(sh->Gamma_th[b + idx_cut + offset] - 1) - log2_Gamma_th) / (log2(sh->r[b + idx_cut + offset]) - log2_r);
+    const double B_slope = (log2(sh->B[b + idx_cut + offset]) - log2_B) / (log2(sh->r[b + idx_cut + offset]) - log2_r);
+    const double N_p_slope =
+        (log2(sh->N_p[b + idx_cut + offset]) - log2_N_p) / (log2(sh->r[b + idx_cut + offset]) - log2_r);
+    for (int k = 0; k < idx_cut; k++) {
+        const double dlog2_r = log2(sh->r[b + k]) - log2_r;
+        sh->Gamma_th[b + k] = 1 + exp2(log2_Gamma_th + gamma_slope * dlog2_r);
+        sh->B[b + k] = exp2(log2_B + B_slope * dlog2_r);
+        sh->N_p[b + k] = exp2(log2_N_p + N_p_slope * dlog2_r);
+    }
+}
+
+/* grid_solve_shock_pair + locate_crossing_time, reverse-shock.tpp:470-590 */
+static int grid_solve_shock_pair(int j, const double* t, int nt, shock_t* fwd, shock_t* rvs, rvs_eqn_t* e, double rtol) {
+    double state[RS_N];
+    const double t_dec = estimate_t_dec(e->jet, e->med, e->theta0);
+    const double t0 = dmin(t[0], dmin(0.01 * U_SEC, 0.1 * t_dec));
+    rvs_set_init_state(e, state, t0);
+    const size_t base = (size_t)j * nt;
+    if (state[RS_GAMMA] <= 1.03) { /* RS_Gamma_limit; set_stopping_shock for both shocks */
+        for (int k = 0; k < nt; ++k) {
+            shock_t* both[2] = {fwd, rvs};
+            for (int q = 0; q < 2; ++q) {
+                both[q]->t_comv[base + k] = state[RS_TCOMV];
+                both[q]->r[base + k] = state[RS_R];
+                both[q]->theta[base + k] = state[RS_THETA];
+                both[q]->Gamma[base + k] = 1;
+                both[q]->Gamma_th[base + k] = 1;
+                both[q]->B[base + k] = 0;
+                both[q]->N_p[base + k] = 0;
+            }
+        }
+        return 0;
+    }
+    if (rvs_shell_sigma(e, state) > 0) rtol *= 0.1; /* defaults::solver::magnetized_rtol_factor */
+    dopri5_t st;
+    dopri5_init(&st, RS_N, rtol, rtol, state, t0, 1e-9 * t0);
+    int k = 0;
+    for (; t[k] < t0; k++) {
+        rvs_set_init_state(e, state, t[k]);
+        save_fwd_state_of_pair(fwd, base + k, e, state);
+        save_rvs_shock_state(rvs, j, k, e, state);
+    }
+    int reverse_shock_crossing = 1, injection_idx_pending = 0;
+    double t_cross = 0, t_step_start = t0;
+    for (int steps = 0; st.t <= t[nt - 1];) {
+        if (dopri5_do_step(&st, rvs_rhs, e) != 0) return fail("reverse shock ODE: step size underflow");
+        if (++steps > DEF_MAX_ODE_STEPS) {
+            fprintf(stderr, "Warning: reverse shock ODE exceeded %d steps at (j=%d), giving up\n", DEF_MAX_ODE_STEPS, j);
+            break;
+        }
+        if (st.t + st.dt == st.t) {
+            fprintf(stderr, "Warning: reverse shock ODE stalled (dt below time ulp) at (j=%d), giving up\n", j);
+            break;
+        }
+        if (reverse_shock_crossing && rvs_crossing_complete(e, st.x[st.cur], st.t)) {
+            double t_lo = t_step_start, t_hi = st.t;
+            for (int iter = 0; iter < 100 && (t_hi - t_lo) > 1e-12 * t_hi; ++iter) {
+                const double t_mid = 0.5 * (t_lo + t_hi);
+                dopri5_calc_state(&st, t_mid, state);
+                if (rvs_crossing_complete(e, state, t_mid))
+                    t_hi = t_mid;
+                else
+                    t_lo = t_mid;
+            }
+            dopri5_calc_state(&st, t_hi, state);
+            t_cross = t_hi;
+            rvs_save_cross_state(e, state);
+            reverse_shock_crossing = 0;
+            injection_idx_pending = 1;
+        }
+        t_step_start = st.t;
+        while (k < nt && st.t > t[k]) {
+            dopri5_calc_state(&st, t[k], state);
+            if (injection_idx_pending && t[k] >= t_cross) {
+                rvs->injection_idx[j] = k > 0 ? k : 1;
+                injection_idx_pending = 0;
+            }
+            save_fwd_state_of_pair(fwd, base + k, e, state);
+            save_rvs_shock_state(rvs, j, k, e, state);
+            ++k;
+        }
+    }
+    reverse_shock_early_extrap(rvs, j);
+    return 0;
+}
+
+static void broadcast_shock_groups(shock_t* sh, const coord_t* c) { /* Shock::broadcast_groups, shock.cpp:42-91 */
+    const int nt = c->n_t;
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j0 = c->reps[r];
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        for (int j = j0 + 1; j < j1; ++j) {
+            sh->injection_idx[j] = sh->injection_idx[j0];
+            for (int k = 0; k < nt; ++k) {
+                const size_t o = (size_t)j * nt + k, s = (size_t)j0 * nt + k;
+                sh->t_comv[o] = sh->t_comv[s];
+                sh->r[o] = sh->r[s];
+                sh->theta[o] = c->theta[j];
+                sh->Gamma[o] = sh->Gamma[s];
+                sh->Gamma_th[o] = sh->Gamma_th[s];
+                sh->B[o] = sh->B[s];
+                sh->N_p[o] = sh->N_p[s];
+            }
+        }
+    }
+}
+
+/* generate_shock_pair, reverse-shock.tpp:592-614 */
+static int generate_shock_pair(shock_t* fwd, shock_t* rvs, const coord_t* c, const medium_t* med, const jet_t* jet,
+                               const vag_model_params* p) {
+    shock_alloc(fwd, c->n_theta, c->n_t);
+    shock_alloc(rvs, c->n_theta, c->n_t);
+    for (int r = 0; r < c->n_reps; ++r) {
+        const int j = c->reps[r];
+        rvs_eqn_t e;
+        memset(&e, 0, sizeof e);
+        e.med = med;
+        e.jet = jet;
+        e.theta0 = c->theta[j];
+        e.T0 = jet->T0;
+        e.Gamma4 = jet_Gamma0(jet, e.theta0);
+        e.deps0_dt = jet_eps_k(jet, e.theta0) / jet->T0;
+        e.dm0_dt = e.deps0_dt / (e.Gamma4 * C_C2);
+        e.u4 = sqrt(e.Gamma4 * e.Gamma4 - 1) * C_C;
+        if (jet->type == VAG_JET_TWO_COMPONENT) e.dm0_dt /= 1 + 0.0; /* HasSigma<Ejecta>, sigma0 == zero function */
+        e.rad_fwd.med = med;
+        e.rad_fwd.jet = jet;
+        e.rad_fwd.radiative = p->radiative_fireball != 0;
+        e.rad_fwd.eps_e = p->eps_e;
+        e.rad_fwd.eps_B = p->eps_B;
+        e.rad_fwd.p = p->p;
+        e.rad_fwd.gamma_m_coeff = (p->p - 2) / (p->p - 1) * p->eps_e * C_MP / C_ME / p->xi_e;
+        e.rad_fwd.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * p->eps_B);
+        e.rad_fwd.eps_e_eff = e.rad_fwd.radiative ? p->eps_e : 0;
+        e.eps_B_rvs = p->rvs_eps_B;
+        if (grid_solve_shock_pair(j, c->t + (size_t)j * c->n_t, c->n_t, fwd, rvs, &e, p->rtol) != 0) return -1;
+    }
+    broadcast_shock_groups(fwd, c);
+    broadcast_shock_groups(rvs, c);
     return 0;
 }
 
@@ -1458,15 +2006,29 @@ static double cyclotron_correction(double gamma_m, double p) {
 }
 
 /* one cell of generate_syn_electrons, synchrotron.cpp:315-360 */
+/* cool_after_crossing, synchrotron.cpp:190-195 */
+static double cool_after_crossing(double gamma_x, double gamma_m_x, double gamma_m) {
+    const double gamma_syn = gamma_x;
+    const double f_ad = (gamma_m - 1) / (gamma_m_x - 1);
+    return (gamma_syn - 1) * f_ad + 1;
+}
+
+/* one cell of generate_syn_electrons (synchrotron.cpp:315-361); `inj` = the electrons frozen at the crossing cell
+ * (injection_idx - 1) when this cell is a relic one (cool_relic_electrons, synchrotron.h:187-201), else NULL */
 static void syn_electrons_cell(electrons_t* e, double t_com, double B, double r, double Gamma_th, double N_p,
-                               const vag_model_params* rad) {
+                               const vag_model_params* rad, const electrons_t* inj) {
     e->gamma_M = compute_syn_gamma_M(B, 0.);
     e->gamma_m = compute_syn_gamma_m(Gamma_th, e->gamma_M, rad->eps_e, rad->p, rad->xi_e);
     const double f_syn = cyclotron_correction(e->gamma_m, rad->p);
     e->N_e = N_p * rad->xi_e * f_syn;
     e->column_den = e->N_e / (r * r);
     const double I_nu_peak = compute_syn_I_peak(B, e->column_den);
-    e->gamma_c = compute_gamma_c(t_com, B, 0.);
+    if (inj) {
+        e->gamma_c = cool_after_crossing(inj->gamma_c, inj->gamma_m, e->gamma_m);
+        e->gamma_M = cool_after_crossing(inj->gamma_M, inj->gamma_m, e->gamma_m);
+    } else {
+        e->gamma_c = compute_gamma_c(t_com, B, 0.);
+    }
     icy_default(&e->Ys);
     e->Y_c = 0;
     e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, rad->p, &e->Ys, 0.0);
@@ -1589,7 +2151,9 @@ static void generate_syn(electrons_t* el, photons_t* ph, const shock_t* sh, cons
         const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
         for (int k = 0; k < nt; ++k) {
             const size_t o = (size_t)j0 * nt + k;
-            syn_electrons_cell(&el[o], sh->t_comv[o], sh->B[o], sh->r[o], sh->Gamma_th[o], sh->N_p[o], p);
+            const int k_inj = sh->injection_idx[j0];
+            syn_electrons_cell(&el[o], sh->t_comv[o], sh->B[o], sh->r[o], sh->Gamma_th[o], sh->N_p[o], p,
+                               k >= k_inj ? &el[(size_t)j0 * nt + k_inj - 1] : NULL);
             syn_photons_cell(&ph[o], &el[o], sh->B[o], p->p);
         }
         if (ssc) { /* Thomson_cooling / KN_cooling: electrons updated in place, photons regenerated */
@@ -1677,6 +2241,14 @@ static void ic_cooling_row(electrons_t* el, const shock_t* sh, size_t row0, int 
         else
             update_gamma_c_Thomson(&e->gamma_c, &e->Ys, rad, B, t_com, e->gamma_m, gamma_c_last);
         update_gamma_M(&e->gamma_M, &e->Ys, B);
+        {   /* cool_relic_electrons, inverse-compton.h:752 */
+            const int k_inj = sh->injection_idx[row0 / nt];
+            if (k >= k_inj) {
+                const electrons_t* inj = &el[row0 + k_inj - 1];
+                e->gamma_c = cool_after_crossing(inj->gamma_c, inj->gamma_m, e->gamma_m);
+                e->gamma_M = cool_after_crossing(inj->gamma_M, inj->gamma_m, e->gamma_m);
+            }
+        }
         const double I_nu_peak = compute_syn_I_peak(B, e->column_den);
         e->Y_c = icy_gamma_spectrum(&e->Ys, e->gamma_c);
         e->gamma_a = compute_syn_gamma_a(B, I_nu_peak, e->gamma_m, e->gamma_c, e->p, &e->Ys, e->Y_c);
@@ -2245,6 +2817,15 @@ int vag_oracle_params_validate(const vag_model_params* p) {
     if (!range_oi(p->eps_B, 0.0, 1.0)) return fail("eps_B must be in (0, 1]");
     if (!range_oi(p->xi_e, 0.0, 1.0)) return fail("xi_e must be in (0, 1]");
     if (!(isfinite(p->p) && p->p > 1.0)) return fail("p must be > 1");
+    if (p->flags & VAG_FLAG_RVS) { /* rvs_rad is a Radiation too: same checks (pymodel.h:241-260) */
+        if (!range_oi(p->rvs_eps_e, 0.0, 1.0)) return fail("rvs eps_e must be in (0, 1]");
+        if (!range_oi(p->rvs_eps_B, 0.0, 1.0)) return fail("rvs eps_B must be in (0, 1]");
+        if (!range_oi(p->rvs_xi_e, 0.0, 1.0)) return fail("rvs xi_e must be in (0, 1]");
+        if (!(isfinite(p->rvs_p) && p->rvs_p > 1.0)) return fail("rvs p must be > 1");
+        if (!finite_pos(p->duration)) return fail("duration must be positive and finite");
+    }
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN))
+        return fail("unknown bits set in flags");
     if (!(isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return fail("rtol must be in (0, 1)");
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
         return fail("resolutions must be positive and finite");
@@ -2262,16 +2843,46 @@ typedef struct {
     eat_t eat;
     electrons_t* el;
     photons_t* ph;
+    /* reverse shock (Model(rvs_rad=...), pymodel.h:940-958): shares coord and the EAT grids */
+    int has_rvs;
+    shock_t rvs_shock;
+    electrons_t* rvs_el;
+    photons_t* rvs_ph;
 } pipeline_t;
+
+/* one emitting region: forward (0) or reverse (1) shock */
+typedef struct {
+    electrons_t* el;
+    photons_t* ph;
+    int ssc, kn;
+} emitter_t;
+
+static int pipeline_emitters(const pipeline_t* pl, const vag_model_params* p, emitter_t em[2]) {
+    em[0].el = pl->el;
+    em[0].ph = pl->ph;
+    em[0].ssc = (p->flags & VAG_FLAG_SSC) != 0;
+    em[0].kn = (p->flags & VAG_FLAG_KN) != 0;
+    if (!pl->has_rvs) return 1;
+    em[1].el = pl->rvs_el;
+    em[1].ph = pl->rvs_ph;
+    em[1].ssc = (p->flags & VAG_FLAG_RVS_SSC) != 0;
+    em[1].kn = (p->flags & VAG_FLAG_RVS_KN) != 0;
+    return 2;
+}
 
 static void pipeline_free(pipeline_t* pl) {
     coord_free(&pl->coord);
     shock_free(&pl->shock);
+    if (pl->has_rvs) shock_free(&pl->rvs_shock);
     eat_free(&pl->eat);
     free(pl->el);
     free(pl->ph);
+    free(pl->rvs_el);
+    free(pl->rvs_ph);
     pl->el = NULL;
     pl->ph = NULL;
+    pl->rvs_el = NULL;
+    pl->rvs_ph = NULL;
 }
 
 /* t_obs_min/max in code units */
@@ -2280,9 +2891,12 @@ static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_
     if (vag_oracle_params_validate(p) != 0) return -1;
     jet_init(&pl->jet, p);
     medium_init(&pl->med, p);
+    pl->has_rvs = (p->flags & VAG_FLAG_RVS) != 0;
     auto_grid(&pl->coord, &pl->jet, &pl->med, t_obs_min, t_obs_max, C_PI / 2, p->theta_obs, p->z, p->phi_resol,
-              p->theta_resol, p->t_resol);
-    if (generate_fwd_shock(&pl->shock, &pl->coord, &pl->med, &pl->jet, p) != 0) {
+              p->theta_resol, p->t_resol, pl->has_rvs);
+    const int rc = pl->has_rvs ? generate_shock_pair(&pl->shock, &pl->rvs_shock, &pl->coord, &pl->med, &pl->jet, p)
+                               : generate_fwd_shock(&pl->shock, &pl->coord, &pl->med, &pl->jet, p);
+    if (rc != 0) {
         pipeline_free(pl);
         return -1;
     }
@@ -2291,17 +2905,28 @@ static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_
     pl->el = calloc(n, sizeof(electrons_t));
     pl->ph = calloc(n, sizeof(photons_t));
     generate_syn(pl->el, pl->ph, &pl->shock, &pl->coord, p);
+    if (pl->has_rvs) { /* same passes with rvs_rad on the reverse shock's arrays */
+        vag_model_params rp = *p;
+        rp.eps_e = p->rvs_eps_e;
+        rp.eps_B = p->rvs_eps_B;
+        rp.p = p->rvs_p;
+        rp.xi_e = p->rvs_xi_e;
+        rp.flags = ((p->flags & VAG_FLAG_RVS_SSC) ? VAG_FLAG_SSC : 0) | ((p->flags & VAG_FLAG_RVS_KN) ? VAG_FLAG_KN : 0);
+        pl->rvs_el = calloc(n, sizeof(electrons_t));
+        pl->rvs_ph = calloc(n, sizeof(photons_t));
+        generate_syn(pl->rvs_el, pl->rvs_ph, &pl->rvs_shock, &pl->coord, &rp);
+    }
     return 0;
 }
 
 /* generate_IC_photons with the per-k observation-band clamp of single_shock_emission
  * (pybind/pymodel.h:896-914, inverse-compton.h:656-690): one ICPhoton per (theta, k), deep-copied across each
  * symmetry group like broadcast_symmetry does. */
-static icphoton_t* make_ic_photons(pipeline_t* pl, const vag_model_params* p, const double* nu_obs, int nnu) {
+static icphoton_t* make_ic_photons(pipeline_t* pl, const emitter_t* em, const double* nu_obs, int nnu) {
     const coord_t* c = &pl->coord;
     const eat_t* o = &pl->eat;
     const int nth = c->n_theta, nt = c->n_t;
-    const int kn = (p->flags & VAG_FLAG_KN) != 0;
+    const int kn = em->kn;
     double nu_lo = nu_obs[0], nu_hi = nu_obs[0];
     for (int l = 1; l < nnu; ++l) {
         if (nu_obs[l] < nu_lo) nu_lo = nu_obs[l];
@@ -2323,8 +2948,8 @@ static icphoton_t* make_ic_photons(pipeline_t* pl, const vag_model_params* p, co
             const int j0 = c->reps[r];
             const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
             icphoton_t* q = &ic[(size_t)j0 * nt + k];
-            q->electrons = pl->el[(size_t)j0 * nt + k];
-            q->photons = pl->ph[(size_t)j0 * nt + k];
+            q->electrons = em->el[(size_t)j0 * nt + k];
+            q->photons = em->ph[(size_t)j0 * nt + k];
             q->KN = kn;
             q->nu_eval_min = nu_eval_min;
             q->nu_eval_max = nu_eval_max;
@@ -2358,8 +2983,10 @@ static void minmax(const double* a, int n, double* lo, double* hi) {
 }
 
 /* fwd.sync -> out_sync, fwd.ssc -> out_ssc (may be NULL), each [nnu][nt] */
-int vag_oracle_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
-                                            double* out, double* out_ssc) {
+/* All four FluxDict components of the grid (pybind/pybind.cpp:472-483): out4 = {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc},
+ * each [nnu][nt]; NULL entries are skipped, disabled components are zeros. */
+int vag_oracle_flux_density_grid_components4(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                             double* const* out4) {
     if (check_times(t, nt) != 0) return -1;
     if (nnu <= 0) return fail("frequency array must be non-empty");
     double* t_obs = malloc(sizeof(double) * nt);
@@ -2371,15 +2998,24 @@ int vag_oracle_flux_density_grid_components(const vag_model_params* p, const dou
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux(&pl.eat, eval_syn_cell, pl.ph, t_obs, nt, nu_obs, nnu, out);
-        for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] = out[q] / U_FLUX_DEN_CGS;
-        if (out_ssc) {
-            for (size_t q = 0; q < (size_t)nnu * nt; ++q) out_ssc[q] = 0;
-            if (p->flags & VAG_FLAG_SSC) {
+        const size_t nout = (size_t)nnu * nt;
+        for (int c = 0; c < 4; ++c)
+            if (out4[c])
+                for (size_t q = 0; q < nout; ++q) out4[c][q] = 0;
+        emitter_t em[2];
+        const int n_em = pipeline_emitters(&pl, p, em);
+        for (int e = 0; e < n_em; ++e) {
+            double* sync = out4[2 * e];
+            double* ssc = out4[2 * e + 1];
+            if (sync) {
+                specific_flux(&pl.eat, eval_syn_cell, em[e].ph, t_obs, nt, nu_obs, nnu, sync);
+                for (size_t q = 0; q < nout; ++q) sync[q] = sync[q] / U_FLUX_DEN_CGS;
+            }
+            if (ssc && em[e].ssc) {
                 const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
-                icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, nnu);
-                specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, nnu, out_ssc);
-                for (size_t q = 0; q < (size_t)nnu * nt; ++q) out_ssc[q] = out_ssc[q] / U_FLUX_DEN_CGS;
+                icphoton_t* ic = make_ic_photons(&pl, &em[e], nu_obs, nnu);
+                specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, nnu, ssc);
+                for (size_t q = 0; q < nout; ++q) ssc[q] = ssc[q] / U_FLUX_DEN_CGS;
                 free_ic_photons(ic, ncell);
             }
         }
@@ -2390,15 +3026,27 @@ int vag_oracle_flux_density_grid_components(const vag_model_params* p, const dou
     return rc;
 }
 
+int vag_oracle_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                            double* out, double* out_ssc) {
+    double* out4[4] = {out, out_ssc, NULL, NULL};
+    return vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, out4);
+}
+
 /* Model.flux_density_grid: total = fwd.sync + fwd.ssc (PyFlux::calc_total, pymodel.cpp:350-364) */
 int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
                                  double* out) {
-    if (!(p->flags & VAG_FLAG_SSC)) return vag_oracle_flux_density_grid_components(p, t, nt, nu, nnu, out, NULL);
-    double* ssc = malloc(sizeof(double) * (size_t)(nnu > 0 ? nnu : 1) * (nt > 0 ? nt : 1));
-    const int rc = vag_oracle_flux_density_grid_components(p, t, nt, nu, nnu, out, ssc);
-    if (rc == 0)
-        for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] += ssc[q];
-    free(ssc);
+    const size_t n = (size_t)(nnu > 0 ? nnu : 1) * (nt > 0 ? nt : 1);
+    const int want[4] = {1, (p->flags & VAG_FLAG_SSC) != 0, (p->flags & VAG_FLAG_RVS) != 0,
+                         (p->flags & VAG_FLAG_RVS) && (p->flags & VAG_FLAG_RVS_SSC)};
+    double* comp[4] = {out, NULL, NULL, NULL};
+    for (int c = 1; c < 4; ++c)
+        if (want[c]) comp[c] = malloc(sizeof(double) * n);
+    const int rc = vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, comp);
+    for (int c = 1; c < 4; ++c) {
+        if (rc == 0 && comp[c])
+            for (size_t q = 0; q < (size_t)nnu * nt; ++q) out[q] += comp[c][q];
+        free(comp[c]);
+    }
     return rc;
 }
 
@@ -2415,17 +3063,24 @@ int vag_oracle_flux_density(const vag_model_params* p, const double* t, const do
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux_series(&pl.eat, eval_syn_cell, pl.ph, t_obs, nu_obs, n, out);
-        for (int i = 0; i < n; ++i) out[i] = out[i] / U_FLUX_DEN_CGS;
-        if (p->flags & VAG_FLAG_SSC) {
-            const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
-            double* ssc = malloc(sizeof(double) * n);
-            icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, n);
-            specific_flux_series(&pl.eat, eval_ic_cell, ic, t_obs, nu_obs, n, ssc);
-            for (int i = 0; i < n; ++i) out[i] += ssc[i] / U_FLUX_DEN_CGS;
-            free_ic_photons(ic, ncell);
-            free(ssc);
+        emitter_t em[2];
+        const int n_em = pipeline_emitters(&pl, p, em);
+        double* tmp = malloc(sizeof(double) * n);
+        for (int e = 0; e < n_em; ++e) {
+            specific_flux_series(&pl.eat, eval_syn_cell, em[e].ph, t_obs, nu_obs, n, e == 0 ? out : tmp);
+            if (e == 0)
+                for (int i = 0; i < n; ++i) out[i] = out[i] / U_FLUX_DEN_CGS;
+            else
+                for (int i = 0; i < n; ++i) out[i] += tmp[i] / U_FLUX_DEN_CGS;
+            if (em[e].ssc) {
+                const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+                icphoton_t* ic = make_ic_photons(&pl, &em[e], nu_obs, n);
+                specific_flux_series(&pl.eat, eval_ic_cell, ic, t_obs, nu_obs, n, tmp);
+                for (int i = 0; i < n; ++i) out[i] += tmp[i] / U_FLUX_DEN_CGS;
+                free_ic_photons(ic, ncell);
+            }
         }
+        free(tmp);
         pipeline_free(&pl);
     }
     free(t_obs);
@@ -2499,23 +3154,32 @@ int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double n
     pipeline_t pl;
     int rc = run_pipeline(&pl, p, lo, hi);
     if (rc == 0) {
-        specific_flux(&pl.eat, eval_syn_cell, pl.ph, t_obs, nt, nu_obs, num_nu, F);
         compute_boole_weights(nu_obs, num_nu, w);
+        emitter_t em[2];
+        const int n_em = pipeline_emitters(&pl, p, em);
+        double* band = malloc(sizeof(double) * nt);
         for (int j = 0; j < nt; ++j) out[j] = 0;
-        for (int i = 0; i < num_nu; ++i)
-            for (int j = 0; j < nt; ++j) out[j] += F[(size_t)i * nt + j] * w[i];
-        for (int j = 0; j < nt; ++j) out[j] = out[j] / U_FLUX_CGS;
-        if (p->flags & VAG_FLAG_SSC) {
-            const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
-            icphoton_t* ic = make_ic_photons(&pl, p, nu_obs, num_nu);
-            specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, num_nu, F);
-            double* band = calloc(nt, sizeof(double));
-            for (int i = 0; i < num_nu; ++i)
-                for (int j = 0; j < nt; ++j) band[j] += F[(size_t)i * nt + j] * w[i];
-            for (int j = 0; j < nt; ++j) out[j] += band[j] / U_FLUX_CGS;
-            free(band);
-            free_ic_photons(ic, ncell);
+        for (int e = 0; e < n_em; ++e) {
+            for (int pass = 0; pass < 2; ++pass) { /* Observer::flux per component, then PyFlux::calc_total */
+                icphoton_t* ic = NULL;
+                if (pass == 1) {
+                    if (!em[e].ssc) continue;
+                    ic = make_ic_photons(&pl, &em[e], nu_obs, num_nu);
+                    specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, num_nu, F);
+                } else {
+                    specific_flux(&pl.eat, eval_syn_cell, em[e].ph, t_obs, nt, nu_obs, num_nu, F);
+                }
+                for (int j = 0; j < nt; ++j) band[j] = 0;
+                for (int i = 0; i < num_nu; ++i)
+                    for (int j = 0; j < nt; ++j) band[j] += F[(size_t)i * nt + j] * w[i];
+                if (e == 0 && pass == 0)
+                    for (int j = 0; j < nt; ++j) out[j] = band[j] / U_FLUX_CGS;
+                else
+                    for (int j = 0; j < nt; ++j) out[j] += band[j] / U_FLUX_CGS;
+                if (ic) free_ic_photons(ic, (size_t)pl.coord.n_theta * pl.coord.n_t);
+            }
         }
+        free(band);
         pipeline_free(&pl);
     }
     free(t_obs);
@@ -2525,11 +3189,18 @@ int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double n
     return rc;
 }
 
-int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
-                       const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
-                       const double* probe_lg2_nu, int n_probe) {
+static int details_impl(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                        const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff, const double* probe_lg2_nu,
+                        int n_probe, int want_rvs) {
     pipeline_t pl;
     if (run_pipeline(&pl, p, t_min * U_SEC, t_max * U_SEC) != 0) return -1;
+    if (want_rvs && !pl.has_rvs) {
+        pipeline_free(&pl);
+        return fail("model has no reverse shock");
+    }
+    const shock_t* shock = want_rvs ? &pl.rvs_shock : &pl.shock;
+    const electrons_t* els = want_rvs ? pl.rvs_el : pl.el;
+    const photons_t* phs = want_rvs ? pl.rvs_ph : pl.ph;
     const coord_t* c = &pl.coord;
     const int nth = c->n_theta, nt = c->n_t;
     shape->n_phi = c->n_phi;
@@ -2547,17 +3218,17 @@ int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, va
     if (dst)                   \
         for (size_t q = 0; q < n; ++q) (dst)[q] = (src)[q] * (scale);
         COPY_(out->t_src, c->t, 1 / U_SEC)
-        COPY_(out->Gamma, pl.shock.Gamma, 1)
-        COPY_(out->r, pl.shock.r, 1 / U_CM)
-        COPY_(out->t_comv, pl.shock.t_comv, 1 / U_SEC)
-        COPY_(out->B, pl.shock.B, 1 / U_GAUSS)
-        COPY_(out->N_p, pl.shock.N_p, 1)
-        COPY_(out->Gamma_th, pl.shock.Gamma_th, 1)
+        COPY_(out->Gamma, shock->Gamma, 1)
+        COPY_(out->r, shock->r, 1 / U_CM)
+        COPY_(out->t_comv, shock->t_comv, 1 / U_SEC)
+        COPY_(out->B, shock->B, 1 / U_GAUSS)
+        COPY_(out->N_p, shock->N_p, 1)
+        COPY_(out->Gamma_th, shock->Gamma_th, 1)
 #undef COPY_
 #define EX_(i) ((extra && (i) < n_extra) ? extra[i] : NULL)
         for (size_t q = 0; q < n; ++q) {
-            const electrons_t* e = &pl.el[q];
-            const photons_t* ph = &pl.ph[q];
+            const electrons_t* e = &els[q];
+            const photons_t* ph = &phs[q];
             if (EX_(0)) EX_(0)[q] = e->gamma_m;
             if (EX_(1)) EX_(1)[q] = e->gamma_c;
             if (EX_(2)) EX_(2)[q] = e->gamma_a;
@@ -2571,6 +3242,7 @@ int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, va
             if (EX_(10)) EX_(10)[q] = ph->I_nu_max;
             if (EX_(14))
                 for (int s = 0; s < n_probe; ++s) EX_(14)[q * n_probe + s] = compute_log2_I_nu(ph, probe_lg2_nu[s]);
+            if (EX_(15)) EX_(15)[q] = (double)shock->injection_idx[q / nt];
         }
         const size_t ne = (size_t)pl.eat.n_phi_eff * n;
         if (EX_(11)) memcpy(EX_(11), pl.eat.lg2_t, sizeof(double) * ne);
@@ -2580,6 +3252,18 @@ int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, va
     }
     pipeline_free(&pl);
     return 0;
+}
+
+int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                       const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                       const double* probe_lg2_nu, int n_probe) {
+    return details_impl(p, t_min, t_max, shape, out, extra, n_extra, n_phi_eff, probe_lg2_nu, n_probe, 0);
+}
+
+int vag_oracle_details_rvs(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                           const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                           const double* probe_lg2_nu, int n_probe) {
+    return details_impl(p, t_min, t_max, shape, out, extra, n_extra, n_phi_eff, probe_lg2_nu, n_probe, 1);
 }
 
 /* Fitter._evaluate / _chi2_sum / eval_one: VegasAfterglow/fitting/fitter.py:497-533,

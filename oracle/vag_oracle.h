@@ -24,6 +24,9 @@ int vag_oracle_flux_density_grid(const vag_model_params* p, const double* t, int
 /* fwd.sync and fwd.ssc components of the grid (out_ssc may be NULL), each [nnu][nt] */
 int vag_oracle_flux_density_grid_components(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
                                             double* out_sync, double* out_ssc);
+/* all four components {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc}, each [nnu][nt]; NULL entries are skipped */
+int vag_oracle_flux_density_grid_components4(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                             double* const* out4);
 /* Model.flux_density: out[n]  (pybind/pymodel.cpp:373-389) */
 int vag_oracle_flux_density(const vag_model_params* p, const double* t, const double* nu, int n, double* out);
 /* Model.flux: out[nt]  (pybind/pymodel.cpp:391-410) */
@@ -36,6 +39,10 @@ int vag_oracle_flux_density_exposures(const vag_model_params* p, const double* t
 int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
                        const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
                        const double* probe_lg2_nu, int n_probe);
+/* same for the reverse shock of a Model(rvs_rad=...); extra[15] = injection_idx per cell */
+int vag_oracle_details_rvs(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
+                           const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
+                           const double* probe_lg2_nu, int n_probe);
 /* Fitter log-likelihood for nb walkers (fitter.py:497-533, samplers.py:61-70): out[nb]. */
 int vag_oracle_loglike_batch(const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out);
 /* Same validation rules as the product's vag_params_validate (pybind/pymodel.cpp:47-186). */

@@ -28,10 +28,11 @@ class ModelParams(C.Structure):
         ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
+        ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
     ]
 
 
-assert C.sizeof(ModelParams) == 200
+assert C.sizeof(ModelParams) == 232
 
 
 class DetailsShape(C.Structure):
@@ -47,7 +48,9 @@ class DetailsOut(C.Structure):
 def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
-                xi_e=1.0, resolutions=(0.06, 0.15, 6.0), rtol=1e-6, radiative_fireball=True, ssc=False, kn=False):
+                xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None):
+    # rvs = dict(eps_e, eps_B, p[, xi_e, ssc, kn]) mirrors Model(rvs_rad=Radiation(...)); the default resolutions are
+    # mode-aware like the reference's Model ctor (pybind/pymodel.h:630-637)
     """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
     q = ModelParams()
     q.jet_type = JET_IDS[jet] if isinstance(jet, str) else int(jet)
@@ -57,10 +60,15 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
     q.n_ism, q.A_star, q.n0 = n_ism, A_star, n0
     q.lumi_dist, q.z, q.theta_obs = lumi_dist, z, theta_obs
     q.eps_e, q.eps_B, q.p, q.xi_e = eps_e, eps_B, p, xi_e
+    if resolutions is None:
+        resolutions = (0.06, 0.2, 10.0) if rvs else (0.06, 0.15, 6.0)
     q.phi_resol, q.theta_resol, q.t_resol = resolutions
     q.rtol = rtol
     q.radiative_fireball = 1 if radiative_fireball else 0
     q.flags = (1 if ssc else 0) | (2 if kn else 0)
+    if rvs:
+        q.flags |= 4 | (8 if rvs.get("ssc") else 0) | (16 if rvs.get("kn") else 0)
+        q.rvs_eps_e, q.rvs_eps_B, q.rvs_p, q.rvs_xi_e = rvs["eps_e"], rvs["eps_B"], rvs["p"], rvs.get("xi_e", 1.0)
     return q
 
 
@@ -75,6 +83,8 @@ def params_from_golden_config(cfg):
     kw.update(med)
     kw.update(cfg["observer"])
     kw.update(cfg["fwd_rad"])  # includes ssc / kn
+    if "rvs_rad" in cfg:
+        kw["rvs"] = dict(cfg["rvs_rad"])
     if "resolutions" in cfg:
         kw["resolutions"] = tuple(cfg["resolutions"])
     if "radiative_fireball" in cfg:
@@ -148,6 +158,18 @@ class CpuLib:
         self._check(fn(C.byref(prm), _p(t), t.size, _p(nu), nu.size, _p(sync), _p(ssc)))
         return sync, ssc
 
+    def flux_components4(self, prm, t, nu):
+        """(fwd_sync, fwd_ssc, rvs_sync, rvs_ssc) grids [nnu][nt]; disabled components are zeros."""
+        fn = getattr(self.lib, self.prefix + "_flux_density_grid_components4")
+        fn.argtypes = [C.POINTER(ModelParams), _dp, C.c_int, _dp, C.c_int, C.POINTER(_dp)]
+        fn.restype = C.c_int
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        nu = np.ascontiguousarray(nu, dtype=np.float64)
+        comps = [np.zeros((nu.size, t.size)) for _ in range(4)]
+        arr = (_dp * 4)(*[_p(a) for a in comps])
+        self._check(fn(C.byref(prm), _p(t), t.size, _p(nu), nu.size, arr))
+        return tuple(comps)
+
     def flux_density_exposures(self, prm, t, nu, expo, num_points=10):
         fn = getattr(self.lib, self.prefix + "_flux_density_exposures")
         fn.argtypes = [C.POINTER(ModelParams), _dp, _dp, _dp, C.c_int, C.c_int, _dp]
@@ -158,10 +180,14 @@ class CpuLib:
         return out
 
     EXTRA_NAMES = ["gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "column_den", "nu_m", "nu_c", "nu_a",
-                   "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe"]
+                   "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe", "injection_idx"]
 
-    def details(self, prm, t_min, t_max, probe_lg2_nu=None):
-        fn = getattr(self.lib, self.prefix + "_details")
+    def details(self, prm, t_min, t_max, probe_lg2_nu=None, rvs=False):
+        """Intermediates of the forward shock (or, rvs=True, of the reverse shock of a Model(rvs_rad=...))."""
+        fn = getattr(self.lib, self.prefix + ("_details_rvs" if rvs else "_details"))
+        fn.argtypes = [C.POINTER(ModelParams), C.c_double, C.c_double, C.POINTER(DetailsShape),
+                       C.POINTER(DetailsOut), C.POINTER(_dp), C.c_int, C.POINTER(C.c_int), _dp, C.c_int]
+        fn.restype = C.c_int
         sh = DetailsShape()
         nphi_eff = C.c_int(0)
         self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), None, None, 0, C.byref(nphi_eff), None, 0))
@@ -177,8 +203,9 @@ class CpuLib:
         for n in self.EXTRA_NAMES[11:14]:
             ex[n] = np.zeros((npe, nth, nt))
         ex["lg2_I_probe"] = np.zeros((nth, nt, max(probe.size, 1)))
-        arr = (_dp * 15)(*[_p(ex[n]) for n in self.EXTRA_NAMES])
-        self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), C.byref(out), arr, 15, C.byref(nphi_eff),
+        ex["injection_idx"] = np.zeros((nth, nt))
+        arr = (_dp * 16)(*[_p(ex[n]) for n in self.EXTRA_NAMES])
+        self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), C.byref(out), arr, 16, C.byref(nphi_eff),
                        _p(probe) if probe.size else None, probe.size))
         d.update(ex)
         d["shape"] = dict(n_phi=nphi, n_theta=nth, n_t=nt, n_reps=sh.n_reps, symmetry=sh.symmetry,

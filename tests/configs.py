@@ -43,3 +43,29 @@ def c4_mock_data():
     nu = np.concatenate([np.full(20, b) for b in C4_BANDS])
     order = np.argsort(t, kind="stable")
     return t[order], nu[order]
+
+
+# BASELINE configs[2] as pinned by SURVEY section 8(d): forward + reverse shock, both with SSC + Klein-Nishina
+C3 = dict(jet="PowerLawJet", medium="Wind", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0, duration=1.0,
+          A_star=0.1, n_ism=0.0, lumi_dist=1e28, z=1.0, theta_obs=0.2, eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True,
+          rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True), resolutions=(0.29, 0.16, 10.0))
+C3_T = np.logspace(2, 8, 100)
+C3_NU = np.array([1e9, 4.84e14, 1e18, 2.4e26])
+
+# reverse-shock cases for live/fixture comparisons (thin and thick shells, structured jets, RS with its own SSC)
+RS_CASES = {
+    "rs_thin_tophat": (dict(jet="TophatJet", theta_obs=0.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+                       np.logspace(0, 7, 48), np.array([1e9, 4.84e14, 1e18])),
+    "rs_thick_offaxis": (dict(jet="TophatJet", E_iso=1e53, Gamma0=100.0, duration=1000.0, theta_obs=0.15, z=0.5,
+                              lumi_dist=3e28, eps_B=1e-3, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.5)),
+                         np.logspace(1, 7, 40), np.array([1e9, 4.84e14, 1e18])),
+    "rs_two_component": (dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0,
+                              theta_obs=0.15, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+                         np.logspace(1, 7, 40), np.array([1e9, 1e14, 1e17])),
+    "rs_gaussian_adiabatic": (dict(jet="GaussianJet", theta_obs=0.2, radiative_fireball=False, duration=10.0,
+                                   rvs=dict(eps_e=0.05, eps_B=0.1, p=2.2, xi_e=0.5), resolutions=(0.1, 0.3, 8.0)),
+                              np.logspace(1, 7, 40), np.array([1e9, 1e14, 1e17])),
+    "rs_tophat_both_ssc_kn": (dict(jet="TophatJet", duration=100.0, ssc=True, kn=True,
+                                   rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True)),
+                              np.logspace(1, 7, 40), np.array([1e9, 1e14, 1e17, 1e23])),
+}

@@ -19,6 +19,36 @@ import _abi  # noqa: E402
 import configs  # noqa: E402
 
 
+def main_rs(ref):
+    """Reverse-shock tier: all four FluxDict components of C3 and five RS cases, a (t, nu) series and
+    a band integral, plus the reverse shock's own arrays (Model.details().rvs) for one case."""
+    out, meta = {}, {}
+    cases = {"C3": (configs.C3, configs.C3_T, configs.C3_NU)}
+    cases.update(configs.RS_CASES)
+    for name, (kw, t, nu) in cases.items():
+        prm = _abi.make_params(**kw)
+        comps = ref.flux_components4(prm, t, nu)
+        out[f"{name}__t"], out[f"{name}__nu"] = t, nu
+        for cname, a in zip(("fwd_sync", "fwd_ssc", "rvs_sync", "rvs_ssc"), comps):
+            out[f"{name}__{cname}"] = a
+        out[f"{name}__total"] = ref.flux_density_grid(prm, t, nu)
+        meta[name] = json.loads(json.dumps(kw, default=list))
+    kw, t, nu = configs.RS_CASES["rs_thick_offaxis"]
+    prm = _abi.make_params(**kw)
+    ts, nus = np.repeat(t, 2), np.tile(nu[[0, 2]], t.size)
+    out["series__t"], out["series__nu"] = ts, nus
+    out["series__flux"] = ref.flux_density(prm, ts, nus)
+    out["band__flux"] = ref.flux(prm, t, 1e17, 1e19, 9)
+    d = ref.details(prm, t.min(), t.max(), rvs=True)
+    meta["rs_thick_offaxis__shape"] = d["shape"]
+    for k in ("t_src", "Gamma", "r", "B", "N_p", "Gamma_th", "gamma_c", "gamma_M", "injection_idx"):
+        out[f"rs_thick_offaxis__rvs_{k}"] = np.asarray(d[k])
+    out["meta"] = json.dumps(meta)
+    path = os.path.join(HERE, "reference_vectors_rs.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref = _abi.load_ref()
     if ref is None:
@@ -68,6 +98,7 @@ def main():
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    main_rs(ref)
 
 
 if __name__ == "__main__":

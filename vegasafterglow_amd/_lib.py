@@ -34,6 +34,7 @@ class ModelParams(C.Structure):
         ("eps_e", C.c_double), ("eps_B", C.c_double), ("p", C.c_double), ("xi_e", C.c_double),
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
+        ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
     ]
 
 
