@@ -153,6 +153,11 @@ int vag_flux_density_grid_batch(vag_ctx* ctx, const vag_model_params* params, in
 int vag_flux_density_grid_components_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
                                            const double* nu, int nnu, double* out_sync, double* out_ssc);
 
+/* All four FluxDict components {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} (pybind/pybind.cpp:472-483), each [nb][nnu][nt];
+ * NULL entries of out4 are skipped, disabled components come back as zeros.  nt * nnu <= 4096. */
+int vag_flux_density_grid_components4_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
+                                            const double* nu, int nnu, double* const* out4);
+
 /*
  * Model.flux_density(t[n] ascending, nu[n]) -> total[n]
  * (pybind/pybind.cpp:427, pybind/pymodel.cpp:373-389, src/core/observer.h:447-538),
@@ -171,6 +176,9 @@ int vag_flux_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const d
 /* Same with the components apart: out_sync = fwd.sync, out_ssc = fwd.ssc, each [nb][nt]. */
 int vag_flux_components_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
                               double nu_min, double nu_max, int num_nu, double* out_sync, double* out_ssc);
+/* ... and all four components, each [nb][nt] (NULL entries skipped). */
+int vag_flux_components4_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
+                               double nu_min, double nu_max, int num_nu, double* const* out4);
 
 /* Device-pointer forms: params/t/nu/out are HBM addresses; asynchronous on the context stream. */
 int vag_flux_density_grid_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,
@@ -208,7 +216,11 @@ int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, i
 #define VAG_P_EPS_B 16
 #define VAG_P_P 17
 #define VAG_P_XI_E 18
-#define VAG_P_COUNT 19
+#define VAG_P_COUNT 19 /* slots 0..18 are contiguous; the reverse-shock radiation parameters follow the numerics block */
+#define VAG_P_RVS_EPS_E 24
+#define VAG_P_RVS_EPS_B 25
+#define VAG_P_RVS_P 26
+#define VAG_P_RVS_XI_E 27
 
 typedef struct vag_fit_spec {
     vag_model_params base; /* fixed parameters + numerics */
@@ -259,6 +271,9 @@ typedef struct vag_details_out {
 
 int vag_details(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                 const vag_details_out* out);
+/* Same protocol for the reverse shock of a Model(rvs_rad=...) (Model.details().rvs, pybind/pymodel.cpp:315-348). */
+int vag_details_rvs(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                    const vag_details_out* out);
 
 /* Per-stage device timings (ms) of the last batch call, stage names follow the reference's
  * profiler (pybind/pymodel.h:877-953): grid, dynamics, syn_cells, sync_flux, reduce, total. */

@@ -43,10 +43,10 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.ModelParams) == 232 == C.sizeof(_abi.ModelParams)
     assert _lib.ModelParams.theta_c.offset == 8 and _lib.ModelParams.rtol.offset == 184
     # VAG_P_* slots index the doubles that follow the two int32 tags
-    names = [n for n, t in _lib.ModelParams._fields_ if t is C.c_double]
     for key, slot in _lib.PARAM_SLOTS.items():
-        field = {"tau": "duration", "theta_v": "theta_obs"}.get(key, key)
-        assert names[slot] == field
+        field = {"tau": "duration", "theta_v": "theta_obs", "eps_e_r": "rvs_eps_e", "eps_B_r": "rvs_eps_B", "p_r": "rvs_p",
+                 "xi_e_r": "rvs_xi_e"}.get(key, key)
+        assert getattr(_lib.ModelParams, field).offset == 8 + 8 * slot, key
     assert C.sizeof(_lib.FitSpec) == 232 + 4 + 64 + 64 + 8 + 5 * 8 + 4  # base, ndim, slot, is_log, n_data+pad, 5 ptrs (+align)
 
 
@@ -110,7 +110,12 @@ def test_constructor_validation_matches_reference_error_types():
     with pytest.raises(ValueError):
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, resolutions=(0.0, 0.15, 6))
     with pytest.raises(NotImplementedError):  # out-of-scope tiers fail loudly instead of silently degrading
-        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=va.Radiation(0.1, 0.01, 2.3))
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, axisymmetric=False)
+    with pytest.raises(TypeError):
+        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=(0.1, 0.01, 2.3))
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=va.Radiation(0.2, 0.02, 2.6, ssc=True))
+    assert m.params.flags == 4 | 8 and (m.params.rvs_eps_e, m.params.rvs_eps_B, m.params.rvs_p) == (0.2, 0.02, 2.6)
+    assert m.resolutions == (0.06, 0.2, 10.0)  # reverse-shock runs default to the denser grid (pymodel.h:630-637)
     m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3, ssc=True, kn=True))
     assert m.params.flags == 3  # VAG_FLAG_SSC | VAG_FLAG_KN
 

@@ -13,13 +13,14 @@ JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT = 0, 1, 2, 3
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
-FLAG_SSC, FLAG_KN = 1, 2  # VAG_FLAG_* of include/vegasafterglow_amd.h
+FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN = 1, 2, 4, 8, 16  # VAG_FLAG_* of include/vegasafterglow_amd.h
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
 PARAM_SLOTS = {
     "theta_c": 0, "E_iso": 1, "Gamma0": 2, "k_e": 3, "k_g": 4, "theta_w": 5, "E_iso_w": 6, "Gamma0_w": 7,
     "tau": 8, "duration": 8, "n_ism": 9, "A_star": 10, "n0": 11, "lumi_dist": 12, "z": 13, "theta_v": 14,
     "theta_obs": 14, "eps_e": 15, "eps_B": 16, "p": 17, "xi_e": 18,
+    "eps_e_r": 24, "eps_B_r": 25, "p_r": 26, "xi_e_r": 27,  # VAG_P_RVS_*: rvs_rad of Fitter(rvs_shock=True)
 }
 
 
@@ -75,9 +76,10 @@ class Limits(C.Structure):
 EXPORTS = [
     "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
     "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
-    "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch", "vag_flux_density_batch", "vag_flux_batch",
+    "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
+    "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_details", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_details", "vag_details_rvs", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
 _lib = None
@@ -109,6 +111,8 @@ def load():
     lib.vag_get_limits.restype = None
     lib.vag_flux_density_grid_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]
     lib.vag_flux_density_grid_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
+    lib.vag_flux_density_grid_components4_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.POINTER(_dp)]
+    lib.vag_flux_components4_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]
     lib.vag_flux_density_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, _dp]
     lib.vag_flux_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]
     lib.vag_flux_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]
@@ -117,6 +121,7 @@ def load():
     lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
     lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
+    lib.vag_details_rvs.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_last_stage_times.argtypes = [v, C.POINTER(StageTimes)]
     lib.vag_last_plan.argtypes = [v, C.POINTER(Plan)]
     lib.vag_ctx_count_work.argtypes = [v, C.c_int]

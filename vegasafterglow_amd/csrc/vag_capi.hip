@@ -14,6 +14,7 @@
 
 #include "vag_ic_kernels.h"
 #include "vag_kernels.h"
+#include "vag_rs_kernels.h"
 
 using namespace vag;
 
@@ -155,7 +156,14 @@ static const char* validate_msg(const vag_model_params* p) {
     if (!(std::isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return "rtol must be in (0, 1)";
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
         return "resolutions must be positive and finite";
-    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN)) return "unknown bits set in flags";
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN))
+        return "unknown bits set in flags";
+    if (p->flags & VAG_FLAG_RVS) {  // rvs_rad is a Radiation too (pymodel.h:241-260)
+        if (!range_oi(p->rvs_eps_e, 0.0, 1.0)) return "rvs eps_e must be in (0, 1]";
+        if (!range_oi(p->rvs_eps_B, 0.0, 1.0)) return "rvs eps_B must be in (0, 1]";
+        if (!range_oi(p->rvs_xi_e, 0.0, 1.0)) return "rvs xi_e must be in (0, 1]";
+        if (!(std::isfinite(p->rvs_p) && p->rvs_p > 1.0)) return "rvs p must be > 1";
+    }
     return nullptr;
 }
 
@@ -213,6 +221,12 @@ struct vag_ctx {
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_ssc;
     bool count_work = false;
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
+    // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
+    // flux passes always read d_shock, d_cellpar, ...; select_emitter() swaps the reverse shock's buffers in and out.
+    DevBuf d_shock_r, d_cellpar_r, d_celldet_r, d_icy_r, d_cellq_r, d_params_rvs, d_inj, d_comp;
+    int cur_emitter = 0;                            // 0 forward, 1 reverse
+    bool cur_ssc = false;                           // SSC switch of the selected emitter
+    const vag_model_params* cur_params = nullptr;   // parameters its radiation / flux kernels read
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -346,7 +360,8 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
-                      &c->d_icstatus, &c->d_ssc, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -393,6 +408,56 @@ int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
 // pipeline stages (host orchestration)
 // ------------------------------------------------------------------------------------------------
 namespace {
+
+// Swap the reverse shock's arrays into (e = 1) or out of (e = 0) the slots every radiation / flux pass reads, and
+// point the passes at the matching radiation parameters (single_shock_emission is the same code for both shocks,
+// pybind/pymodel.h:877-920).
+void select_emitter(vag_ctx* c, int e, const vag_model_params* d_params) {
+    if (e != c->cur_emitter) {
+        std::swap(c->d_shock, c->d_shock_r);
+        std::swap(c->d_cellpar, c->d_cellpar_r);
+        std::swap(c->d_celldet, c->d_celldet_r);
+        std::swap(c->d_icy, c->d_icy_r);
+        std::swap(c->d_cellq, c->d_cellq_r);
+        c->cur_emitter = e;
+    }
+    if (e == 0) {
+        c->cur_params = d_params;
+        c->cur_ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+    } else {
+        c->cur_params = c->d_params_rvs.as<vag_model_params>();
+        c->cur_ssc = (c->batch_flags & VAG_FLAG_RVS_SSC) != 0;
+    }
+}
+
+// Stage 3 for the selected emitter: electrons + photons per cell (generate_syn_electrons / generate_syn_photons),
+// then apply_ic_cooling (pybind/pymodel.h:567-577) when its Radiation has ssc.
+int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, const int* d_inj, bool ssc, bool want_details) {
+    hipStream_t st = c->stream;
+    const long long cells = c->n_cells;
+    const int rows = c->n_rows;
+    if (c->d_cellpar.ensure(sizeof(double) * (size_t)cells * VAG_NPAR)) return VAG_E_HIP;
+    if (ssc) want_details = true;  // the cooling pass works on the electron arrays
+    if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * VAG_NDET)) return VAG_E_HIP;
+    Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
+                       c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
+                       want_details ? c->d_celldet.as<double>() : nullptr, d_inj);
+    HIPCHK(hipGetLastError());
+    if (ssc) {  // cool the electrons row by row, then rebuild the photons
+        if (c->d_icy.ensure(sizeof(double) * (size_t)cells * VAG_NICY)) return VAG_E_HIP;
+        if (c->d_cellq.ensure(sizeof(double) * (size_t)cells * VAG_NQ)) return VAG_E_HIP;
+        hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_rad_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                           c->d_icy.as<double>(), d_inj);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                           c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
+        HIPCHK(hipGetLastError());
+    }
+    return VAG_OK;
+}
 
 // Stage 1-3: adaptive grid -> blast-wave dynamics -> per-cell radiation, for nb models whose
 // parameters are already in HBM.  d_tminmax holds the observer-time extrema [s].
@@ -478,33 +543,37 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         HIPCHK(hipEventRecord(c->ev[3], st));
         return VAG_OK;
     }
+    const bool rvs = (c->batch_flags & VAG_FLAG_RVS) != 0;
     if (c->d_shock.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
-    if (c->d_cellpar.ensure(sizeof(double) * (size_t)cells * VAG_NPAR)) return VAG_E_HIP;
     if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
-    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
-    if (ssc) want_details = true;  // the cooling pass works on the electron arrays
-    if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * VAG_NDET)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
-    hipLaunchKernelGGL(vag_dynamics_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
-                       c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
-                       c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
+    if (rvs) {  // generate_shock_pair (reverse-shock.tpp:592-614): both shocks from one ODE state per row
+        if (c->d_shock_r.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
+        if (c->d_inj.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
+        if (c->d_params_rvs.ensure(sizeof(vag_model_params) * (size_t)nb)) return VAG_E_HIP;
+        hipLaunchKernelGGL(vag_rvs_params_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, d_params, nb,
+                           c->d_params_rvs.as<vag_model_params>());
+        hipLaunchKernelGGL(vag_dynamics_pair_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
+                           c->d_inj.as<int>(), c->d_row_status.as<int>());
+    } else {
+        hipLaunchKernelGGL(vag_dynamics_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
-                       c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
-                       want_details ? c->d_celldet.as<double>() : nullptr);
-    HIPCHK(hipGetLastError());
-    if (ssc) {  // apply_ic_cooling (pybind/pymodel.h:567-577): cool the electrons row by row, then rebuild the photons
-        if (c->d_icy.ensure(sizeof(double) * (size_t)cells * VAG_NICY)) return VAG_E_HIP;
-        if (c->d_cellq.ensure(sizeof(double) * (size_t)cells * VAG_NQ)) return VAG_E_HIP;
-        hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                           c->d_icy.as<double>());
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                           c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
-        HIPCHK(hipGetLastError());
+    c->cur_emitter = 0;
+    c->cur_params = d_params;
+    c->cur_ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+    int rc = run_radiation(c, d_params, nb, nullptr, c->cur_ssc, want_details);
+    if (rc) return rc;
+    if (rvs) {
+        select_emitter(c, 1, d_params);
+        rc = run_radiation(c, c->cur_params, nb, c->d_inj.as<int>(), c->cur_ssc, want_details);
+        select_emitter(c, 0, d_params);
+        if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c->ev[3], st));
     return VAG_OK;
@@ -649,31 +718,61 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
     return check_ic_status(c, nb);
 }
 
-// Grid request for a batch: fwd.sync -> d_sync, fwd.ssc -> d_ssc (zeros without SSC), or their sum into d_sync when
-// d_ssc == nullptr.  (t, nu) prepared; model stages already run.
-int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw, double* d_sync,
-                 double* d_ssc) {
-    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
+__global__ void vag_copy_kernel(double* __restrict__ out, const double* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = src[i];
+}
+
+// One request on a (t, nu) grid (or a band when d_bandw != nullptr) for the whole batch; model stages already run.
+// Components in FluxDict order {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} (pybind/pybind.cpp:472-483):
+// d_comp (optional) -> d_comp[i] != nullptr receives component i, zeros when that component is disabled;
+// d_total (optional) receives the sum of the enabled components in PyFlux::calc_total order (pymodel.cpp:350-364).
+int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw, double* d_total,
+                 double* const* d_comp) {
     const size_t n_out = (size_t)nb * (d_bandw ? nt : (size_t)nt * nnu);
-    int rc = run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, d_sync,
-                           ssc ? FLUX_SYN_IC : FLUX_SYN);
-    if (rc) return rc;
-    if (!ssc) {
-        if (d_ssc) HIPCHK(hipMemsetAsync(d_ssc, 0, sizeof(double) * n_out, c->stream));
-        return VAG_OK;
+    const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
+    bool first = true;
+    int rc = VAG_OK;
+    for (int e = 0; e < 2 && rc == VAG_OK; ++e) {
+        if (e < n_em) select_emitter(c, e, d_params);
+        for (int pass = 0; pass < 2 && rc == VAG_OK; ++pass) {
+            double* dst_comp = d_comp ? d_comp[2 * e + pass] : nullptr;
+            const bool enabled = e < n_em && (pass == 0 || c->cur_ssc);
+            if (!enabled) {
+                if (dst_comp && hipMemsetAsync(dst_comp, 0, sizeof(double) * n_out, c->stream) != hipSuccess) rc = VAG_E_HIP;
+                continue;
+            }
+            double* dst = dst_comp;
+            if (!dst) {
+                if (!d_total) continue;  // nobody wants this component
+                if (first) {
+                    dst = d_total;
+                } else {
+                    if (c->d_ssc.ensure(sizeof(double) * n_out)) {
+                        rc = VAG_E_HIP;
+                        break;
+                    }
+                    dst = c->d_ssc.as<double>();
+                }
+            }
+            if (pass == 0)
+                rc = run_flux_grid(c, c->cur_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst,
+                                   c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+            else
+                rc = run_flux_ssc(c, c->cur_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst);
+            if (rc) break;
+            if (d_total) {
+                if (first) {
+                    if (dst != d_total) hipLaunchKernelGGL(vag_copy_kernel, dim3(256), dim3(256), 0, c->stream, d_total, dst, n_out);
+                    first = false;
+                } else {
+                    hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_total, dst, n_out);
+                }
+                if (hipGetLastError() != hipSuccess) rc = VAG_E_HIP;
+            }
+        }
     }
-    double* tmp = d_ssc;
-    if (!tmp) {
-        if (c->d_ssc.ensure(sizeof(double) * n_out)) return VAG_E_HIP;
-        tmp = c->d_ssc.as<double>();
-    }
-    rc = run_flux_ssc(c, d_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, tmp);
-    if (rc) return rc;
-    if (!d_ssc) {  // PyFlux::calc_total (pymodel.cpp:350-364): total = fwd.sync + fwd.ssc
-        hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_sync, tmp, n_out);
-        HIPCHK(hipGetLastError());
-    }
-    return VAG_OK;
+    select_emitter(c, 0, d_params);
+    return rc;
 }
 
 __global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
@@ -745,18 +844,42 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     return VAG_OK;
 }
 
-// One chunk of a (t, nu) series for the batch: fwd.sync (+ fwd.ssc from the prepared tables) -> d_out[nb][n].
+// One chunk of a (t, nu) series for the batch: the sum of every enabled component -> d_out[nb][n].  The comoving band
+// of an SSC table spans ALL requested frequencies (d_lg2nu_all[n_all], pymodel.h:896-909), not only this chunk's.
 int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
-                 double* d_out) {
-    if (!(c->batch_flags & VAG_FLAG_SSC)) return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, d_out);
-    int rc = run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, d_out, FLUX_SYN_IC);
-    if (rc) return rc;
-    if (c->d_ssc.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
-    rc = run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, n, c->d_ssc.as<double>(), FLUX_SSC);
-    if (rc) return rc;
-    hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_out, c->d_ssc.as<double>(), (size_t)nb * n);
-    HIPCHK(hipGetLastError());
-    return VAG_OK;
+                 const double* d_lg2nu_all, int n_all, double* d_out) {
+    const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
+    int rc = VAG_OK;
+    bool first = true;
+    for (int e = 0; e < n_em && rc == VAG_OK; ++e) {
+        select_emitter(c, e, d_params);
+        for (int pass = 0; pass < 2 && rc == VAG_OK; ++pass) {
+            if (pass == 1 && !c->cur_ssc) continue;
+            double* dst = d_out;
+            if (!first) {
+                if (c->d_ssc.ensure(sizeof(double) * (size_t)nb * n)) {
+                    rc = VAG_E_HIP;
+                    break;
+                }
+                dst = c->d_ssc.as<double>();
+            }
+            if (pass == 0) {
+                rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+            } else {
+                rc = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all);
+                if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC);
+                if (rc == VAG_OK) rc = check_ic_status(c, nb);
+            }
+            if (rc) break;
+            if (!first) {
+                hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_out, dst, (size_t)nb * n);
+                if (hipGetLastError() != hipSuccess) rc = VAG_E_HIP;
+            }
+            first = false;
+        }
+    }
+    select_emitter(c, 0, d_params);
+    return rc;
 }
 
 int collect_times(vag_ctx* c) {
@@ -831,7 +954,8 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     // chunk the time axis so each launch keeps its (idx, l) slots in registers
     const int chunk = std::max(1, 4096 / nnu);  // keeps the LDS accumulator <= 32 KiB
     if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
-    if (c->batch_flags & VAG_FLAG_SSC) return set_err(VAG_E_CAPACITY, "SSC requests need nt * nnu <= 4096 per call");
+    if (c->batch_flags & (VAG_FLAG_SSC | VAG_FLAG_RVS))
+        return set_err(VAG_E_CAPACITY, "SSC / reverse-shock requests need nt * nnu <= 4096 per call");
     // chunks write [nb][nnu][chunk] blocks; assemble into [nb][nnu][nt]
     DevBuf tmp;
     if (tmp.ensure(sizeof(double) * (size_t)nb * nnu * chunk)) return VAG_E_HIP;
@@ -856,29 +980,22 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    const bool ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
-    if (ssc) {  // the comoving band spans all requested frequencies (pymodel.h:896-909)
-        rc = build_ssc_tables(c, d_params, nb, c->d_lg2nu.as<double>(), n);
-        if (rc) return rc;
-    }
     const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
-    if (n <= chunk) {
-        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, d_out);
-        if (rc) return rc;
-        return ssc ? check_ic_status(c, nb) : VAG_OK;
-    }
+    if (n <= chunk)
+        return series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
+                            d_out);
     DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
     if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
     for (int s0 = 0; s0 < n; s0 += chunk) {
         const int m = std::min(chunk, n - s0);
-        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m, tmp.as<double>());
+        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m,
+                          c->d_lg2nu.as<double>(), n, tmp.as<double>());
         if (rc) break;
         HIPCHK(hipMemcpy2DAsync(d_out + s0, sizeof(double) * n, tmp.p, sizeof(double) * m, sizeof(double) * m, (size_t)nb,
                                 hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     tmp.release();
-    if (rc == VAG_OK && ssc) rc = check_ic_status(c, nb);
     return rc;
 }
 
@@ -905,8 +1022,9 @@ int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int 
     return check_status(c, nb);
 }
 
-int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
-                                           const double* nu, int nnu, double* out_sync, double* out_ssc) {
+// out4 = {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc}; NULL entries are skipped
+static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, const double* nu,
+                                int nnu, double* const* out4) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
     if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
@@ -918,7 +1036,7 @@ int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* p
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
     if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
     if (c->d_nu.ensure(sizeof(double) * nnu)) return VAG_E_HIP;
-    if (c->d_out.ensure(sizeof(double) * 2 * n_out)) return VAG_E_HIP;
+    if (c->d_comp.ensure(sizeof(double) * 4 * n_out)) return VAG_E_HIP;
     HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * nnu, hipMemcpyHostToDevice, c->stream));
@@ -926,13 +1044,27 @@ int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* p
     if (rc) return rc;
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
-    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, nnu, nullptr, c->d_out.as<double>(),
-                      c->d_out.as<double>() + n_out);
+    double* d4[4];
+    for (int q = 0; q < 4; ++q) d4[q] = out4[q] ? c->d_comp.as<double>() + q * n_out : nullptr;
+    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, nnu, nullptr, nullptr, d4);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out_sync, c->d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(out_ssc, c->d_out.as<double>() + n_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+    for (int q = 0; q < 4; ++q)
+        if (out4[q]) HIPCHK(hipMemcpyAsync(out4[q], d4[q], sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
     return check_status(c, nb);
+}
+
+int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
+                                           const double* nu, int nnu, double* out_sync, double* out_ssc) {
+    double* out4[4] = {out_sync, out_ssc, nullptr, nullptr};
+    return grid_components_impl(c, params, nb, t, nt, nu, nnu, out4);
+}
+
+int vag_flux_density_grid_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
+                                            const double* nu, int nnu, double* const* out4) {
+    if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
+    return grid_components_impl(c, params, nb, t, nt, nu, nnu, out4);
 }
 
 int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu, int n,
@@ -957,9 +1089,10 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     return check_status(c, nb);
 }
 
-// Model.flux for a batch; out_ssc == nullptr -> out receives the total, otherwise (fwd.sync, fwd.ssc) apart.
+// Model.flux for a batch: out_total (optional) receives the sum of the enabled components, out4 (optional) the
+// components {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} apart (NULL entries skipped).
 static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
-                          double nu_max, int num_nu, double* out, double* out_ssc) {
+                          double nu_max, int num_nu, double* out_total, double* const* out4) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (!(nu_min > 0)) return set_err(VAG_E_INVALID, "nu_min must be positive");
     if (!(nu_max > nu_min)) return set_err(VAG_E_INVALID, "nu_max must be greater than nu_min");
@@ -1013,7 +1146,8 @@ static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, co
     if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
     if (c->d_nu.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
     if (c->d_bandw.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
-    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt * 2)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt)) return VAG_E_HIP;
+    if (c->d_comp.ensure(sizeof(double) * (size_t)nb * nt * 4)) return VAG_E_HIP;
     HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nu.p, nu_cgs.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
@@ -1026,12 +1160,16 @@ static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, co
     HIPCHK(hipMemcpyAsync(c->d_lg2nu.p, lg2nu.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
-    double* d_ssc = out_ssc ? c->d_out.as<double>() + (size_t)nb * nt : nullptr;
-    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, num_nu, c->d_bandw.as<double>(), c->d_out.as<double>(),
-                      d_ssc);
+    const size_t n_out = (size_t)nb * nt;
+    double* d4[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (out4)
+        for (int q = 0; q < 4; ++q) d4[q] = out4[q] ? c->d_comp.as<double>() + q * n_out : nullptr;
+    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, num_nu, c->d_bandw.as<double>(),
+                      out_total ? c->d_out.as<double>() : nullptr, out4 ? d4 : nullptr);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * nt, hipMemcpyDeviceToHost, c->stream));
-    if (out_ssc) HIPCHK(hipMemcpyAsync(out_ssc, d_ssc, sizeof(double) * (size_t)nb * nt, hipMemcpyDeviceToHost, c->stream));
+    if (out_total) HIPCHK(hipMemcpyAsync(out_total, c->d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+    for (int q = 0; q < 4; ++q)
+        if (d4[q]) HIPCHK(hipMemcpyAsync(out4[q], d4[q], sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)collect_times(c);
     return check_status(c, nb);
@@ -1044,8 +1182,14 @@ int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const dou
 
 int vag_flux_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                               double nu_max, int num_nu, double* out_sync, double* out_ssc) {
-    if (!out_ssc) return set_err(VAG_E_INVALID, "out_ssc must not be null");
-    return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, out_sync, out_ssc);
+    double* out4[4] = {out_sync, out_ssc, nullptr, nullptr};
+    return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, nullptr, out4);
+}
+
+int vag_flux_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                               double nu_max, int num_nu, double* const* out4) {
+    if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
+    return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, nullptr, out4);
 }
 
 static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
@@ -1053,7 +1197,8 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     const int n = spec->n_data;
     if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
     for (int d = 0; d < ndim; ++d)
-        if (spec->slot[d] < 0 || spec->slot[d] >= VAG_P_COUNT) return set_err(VAG_E_INVALID, "bad parameter slot");
+        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_RVS_XI_E)))
+            return set_err(VAG_E_INVALID, "bad parameter slot");
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");
     for (int i = 1; i < n; ++i)
@@ -1095,19 +1240,14 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     if (rc) return rc;
     rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
     if (rc) return rc;
-    if (c->batch_flags & VAG_FLAG_SSC) {
-        rc = build_ssc_tables(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2nu.as<double>(), n);
-        if (rc) return rc;
-    }
     rc = series_chunk(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
-                      c->d_series_flux.as<double>());
+                      c->d_lg2nu.as<double>(), n, c->d_series_flux.as<double>());
     if (rc) return rc;
     hipLaunchKernelGGL(vag_valid_from_meta, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb,
                        c->d_valid.as<int>());
     hipLaunchKernelGGL(vag_loglike_kernel, dim3(nb), dim3(64), 0, c->stream, c->d_series_flux.as<double>(), n,
                        d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, c->d_valid.as<int>(), d_out);
     HIPCHK(hipGetLastError());
-    if (c->batch_flags & VAG_FLAG_SSC) return check_ic_status(c, nb);
     return VAG_OK;
 }
 
@@ -1127,9 +1267,10 @@ int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta,
     return VAG_OK;
 }
 
-int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
-                const vag_details_out* out) {
+static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                        const vag_details_out* out, bool want_rvs) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (want_rvs && !(params->flags & VAG_FLAG_RVS)) return set_err(VAG_E_INVALID, "model has no reverse shock");
     const char* msg = validate_msg(params);
     if (msg) return set_err(VAG_E_INVALID, "%s", msg);
     if (!(t_min > 0) || !(t_max >= t_min)) return set_err(VAG_E_INVALID, "need 0 < t_min <= t_max");
@@ -1153,11 +1294,17 @@ int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double
     shape->phi_mirrored = M.phi_mirrored;
     if (!out) return VAG_OK;
     const int nth = M.n_theta, nt = M.n_t;
+    if (std::getenv("VAG_DEBUG_ROWS")) {  // developer aid: ODE status (and injection cutoff) per representative row
+        std::vector<int> st(c->n_rows), inj(c->n_rows, -1);
+        HIPCHK(hipMemcpy(st.data(), c->d_row_status.p, sizeof(int) * c->n_rows, hipMemcpyDeviceToHost));
+        if (params->flags & VAG_FLAG_RVS) HIPCHK(hipMemcpy(inj.data(), c->d_inj.p, sizeof(int) * c->n_rows, hipMemcpyDeviceToHost));
+        for (int r = 0; r < c->n_rows; ++r) std::fprintf(stderr, "row %d status %d inj %d\n", r, st[r], inj[r]);
+    }
     std::vector<double> theta(nth), buf((size_t)c->n_cells * VAG_NSHOCK);
     std::vector<int> rep_of(nth);
     HIPCHK(hipMemcpy(theta.data(), c->d_theta.p, sizeof(double) * nth, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rep_of.data(), c->d_rep_of.p, sizeof(int) * nth, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(buf.data(), c->d_shock.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(buf.data(), want_rvs ? c->d_shock_r.p : c->d_shock.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
     if (out->phi) HIPCHK(hipMemcpy(out->phi, c->d_phi.p, sizeof(double) * M.n_phi, hipMemcpyDeviceToHost));
     if (out->theta) std::memcpy(out->theta, theta.data(), sizeof(double) * nth);
     // Shock::broadcast_groups (src/dynamics/shock.cpp:42-91): every theta row shows its representative's state
@@ -1175,6 +1322,16 @@ int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double
     expand(out->N_p, VS_NP, 1);
     expand(out->Gamma_th, VS_GAMMA_TH, 1);
     return VAG_OK;
+}
+
+int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                const vag_details_out* out) {
+    return details_impl(c, params, t_min, t_max, shape, out, false);
+}
+
+int vag_details_rvs(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
+                    const vag_details_out* out) {
+    return details_impl(c, params, t_min, t_max, shape, out, true);
 }
 
 }  // extern "C"

@@ -5,7 +5,11 @@
 
 #include "vag_common.h"
 
+#ifdef VAG_HOST_DEBUG  // developer aid: lets a host program step through the device physics
+#define VAG_DEV __host__ __device__ inline
+#else
 #define VAG_DEV __device__ __forceinline__
+#endif
 
 namespace vag {
 
@@ -151,6 +155,9 @@ VAG_DEV bool params_valid(const vag_model_params& p) {
          p.theta_obs <= C_PI;
     ok = ok && oi(p.eps_e, 0.0, 1.0) && oi(p.eps_B, 0.0, 1.0) && oi(p.xi_e, 0.0, 1.0) && isfinite(p.p) && p.p > 1.0;
     ok = ok && isfinite(p.rtol) && p.rtol > 0 && p.rtol < 1 && fpos(p.phi_resol) && fpos(p.theta_resol) && fpos(p.t_resol);
+    if (p.flags & VAG_FLAG_RVS)
+        ok = ok && oi(p.rvs_eps_e, 0.0, 1.0) && oi(p.rvs_eps_B, 0.0, 1.0) && oi(p.rvs_xi_e, 0.0, 1.0) && isfinite(p.rvs_p) &&
+             p.rvs_p > 1.0;
     return ok;
 }
 
@@ -526,9 +533,12 @@ VAG_DEV void syn_photons_build(CellOut& o, double gamma_m, double gamma_c, doubl
 }
 
 
-VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
-                      double N_p, double eps_e, double p, double xi_e) {
-    // --- electrons (synchrotron.cpp:315-360) ---
+// gamma_M, gamma_m and the synchrotron-only gamma_c of one cell (synchrotron.cpp:45-110,334-347)
+struct ElecBasic {
+    double gamma_M, gamma_m, gamma_c;
+};
+VAG_DEV ElecBasic syn_elec_basic(double t_comv, double Gamma_th, double B, double eps_e, double p, double xi_e) {
+    ElecBasic e;
     const double gamma_M = (B == 0) ? INFINITY : sqrt(6 * C_PI * C_E / C_SIGMAT / (B * (1 + 0.)));
     const double gamma_ave_m1 = eps_e * (Gamma_th - 1) * (C_MP / C_ME) / xi_e;
     double gm_m1;
@@ -548,14 +558,36 @@ VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double 
         }
         gm_m1 = 0.5 * (high + low);
     }
-    const double gamma_m = gm_m1 + 1;
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + 0.) * t_comv) * 1;
+    e.gamma_M = gamma_M;
+    e.gamma_m = gm_m1 + 1;
+    e.gamma_c = (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+    return e;
+}
+
+// cool_after_crossing, synchrotron.cpp:190-195
+VAG_DEV double cool_after_crossing(double gamma_x, double gamma_m_x, double gamma_m) {
+    return (gamma_x - 1) * ((gamma_m - 1) / (gamma_m_x - 1)) + 1;
+}
+
+// `inj` = electrons frozen at the crossing cell for a relic cell of a reverse shock (cool_relic_electrons,
+// synchrotron.h:187-201), nullptr otherwise.
+VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
+                      double N_p, double eps_e, double p, double xi_e, const ElecBasic* inj = nullptr) {
+    // --- electrons (synchrotron.cpp:315-360) ---
+    const ElecBasic eb = syn_elec_basic(t_comv, Gamma_th, B, eps_e, p, xi_e);
+    double gamma_M = eb.gamma_M;
+    const double gamma_m = eb.gamma_m;
     double f_syn = (gamma_m - 1) / gamma_m;
     if (p > 3) f_syn = fast_pow(f_syn, (p - 1) / 2);
     const double N_e = N_p * xi_e * f_syn;
     const double column_den = N_e / (r * r);
     const double I_peak = syn_I_peak(B, column_den);
-    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + 0.) * t_comv) * 1;
-    const double gamma_c = (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+    double gamma_c = eb.gamma_c;
+    if (inj) {
+        gamma_c = cool_after_crossing(inj->gamma_c, inj->gamma_m, gamma_m);
+        gamma_M = cool_after_crossing(inj->gamma_M, inj->gamma_m, gamma_m);
+    }
     // compute_syn_gamma_a with no IC (ratio exactly 1), synchrotron.cpp:212-246
     double gamma_a;
     {
@@ -639,8 +671,9 @@ VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
 }
 
 // 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
-// 3.3e-16) + ldexp.  Large |x| saturate through v_ldexp_f64 (0 / inf) exactly like exp2.
+// 3.3e-16) + ldexp.  Large |x| (and +-inf) saturate through v_ldexp_f64 (0 / inf) exactly like exp2.
 VAG_DEV double exp2_fast(double x) {
+    x = dmin(dmax(x, -1100.0), 1100.0);  // +-inf must saturate (0 / inf) instead of producing inf - inf; NaN passes through
     const double n = rint(x);
     const double f = x - n;
     // Estrin scheme over 13 coefficients

@@ -132,7 +132,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     VagGridMeta M;
     M.status = 0;
     M.flags = P.flags;
-    M.pad1 = 0;
+    M.t_num_base = 0;
 
     // ---- find_jet_jumps (grid-refinement.h:41-86): parallel profile scan, sequential jump logic ----
     const double th_lo = 1e-6, th_hi = C_PI / 2;
@@ -440,8 +440,11 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     }
     const int symmetry = n_reps == 1 ? VAG_SYM_ISOTROPIC : (n_reps < n_theta ? VAG_SYM_PIECEWISE : VAG_SYM_PHI_SYMMETRIC);
 
-    // ---- build_time_grid scalars (grid-refinement.h:472-528,594-636), forward shock only ----
+    // ---- build_time_grid scalars (grid-refinement.h:472-528,594-636); is_rvs = Model(rvs_rad=...) ----
     {
+        const bool is_rvs = (P.flags & VAG_FLAG_RVS) != 0;
+        const double T0 = P.duration * U_SEC;
+        double max_ref = 0;
         const double t_min = t_min_s * U_SEC, t_max = t_max_s * U_SEC;
         const double t_end = 1.01 * t_max / (1 + z);
         const double cos_tv = cos(theta_v), sin_tv = sin(theta_v);
@@ -454,7 +457,11 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
             const double td = estimate_t_dec(jet, med, th);
             sh.tdec[j] = td;
-            const double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+            double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+            if (is_rvs) {
+                cut = dmin(cut, 0.01 * T0);
+                max_ref = dmax(max_ref, 10.0 * dmax(td, T0));
+            }
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, dmax(ts, cut));
             min_cut = dmin(min_cut, cut);
@@ -462,12 +469,18 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         min_raw = wave_min(min_raw);
         min_guarded = wave_min(min_guarded);
         min_cut = wave_min(min_cut);
+        max_ref = -wave_min(-max_ref);
         const int has_early = min_raw < min_cut;
-        const size_t t_num_tot = (size_t)(dmax(log10(t_end / min_guarded), 1.0) * P.t_resol);
+        const size_t t_num_base = (size_t)(dmax(log10(t_end / min_guarded), 1.0) * P.t_resol);
+        size_t t_num_extra = 0;  // compute_time_grid_size: pre-crossing lattice twice as dense
+        if (is_rvs && max_ref > min_guarded)
+            t_num_extra = (size_t)((2.0 - 1.0) * log10(dmin(max_ref, t_end) / min_guarded) * P.t_resol);
+        const size_t t_num_tot = t_num_base + t_num_extra;
         const size_t t_num = t_num_tot + (has_early ? 1 : 0);
         if (t_num > VAG_MAX_TIME || t_num_tot < 2) M.status = VAG_E_CAPACITY;
         M.n_t = (int)t_num;
         M.t_num_tot = (int)t_num_tot;
+        M.t_num_base = (int)t_num_base;
         M.has_early = has_early;
         M.t_early = min_raw;
         M.t_start = min_guarded;

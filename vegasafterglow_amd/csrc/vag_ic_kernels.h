@@ -37,7 +37,8 @@ constexpr double IC_X0 = 0.47140452079103166;
 __global__ void __launch_bounds__(64)
 vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                       Layout lay, int n_rows, const double* __restrict__ shock, long long n_cells,
-                      double* __restrict__ det, double* __restrict__ icy) {
+                      double* __restrict__ det, double* __restrict__ icy,
+                      const int* __restrict__ inj_idx /* optional: reverse shock's injection cutoff per row */) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const int m = find_model(lay.row_off, nb, row);
@@ -48,6 +49,8 @@ vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const
     const int nt = M.n_t;
     const long long c0 = lay.cell_off[m] + (long long)(row - lay.row_off[m]) * nt;
     double gamma_c_last = det[VD_GAMMA_C * n_cells + c0];
+    const int k_inj = inj_idx ? inj_idx[row] : nt;
+    double inj_gc = 0, inj_gm = 1, inj_gM = 0;  // cooled electrons of the crossing cell k_inj - 1
     for (int k = 0; k < nt; ++k) {
         const long long c = c0 + k;
         const double t_com = shock[VS_TCOMV * n_cells + c], B = shock[VS_B * n_cells + c];
@@ -88,6 +91,15 @@ vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const
                 gM = gM_new;
                 gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
             }
+        }
+        if (k >= k_inj) {  // cool_relic_electrons inside IC_cooling, inverse-compton.h:752
+            gc = cool_after_crossing(inj_gc, inj_gm, gm);
+            gM = cool_after_crossing(inj_gM, inj_gm, gm);
+        }
+        if (k == k_inj - 1) {
+            inj_gc = gc;
+            inj_gm = gm;
+            inj_gM = gM;
         }
         const double Y_c = Ys.gamma_spectrum(gc);
         const double ga = syn_gamma_a_ic(B, syn_I_peak(B, cd), gm, gc, P.p, Ys, Y_c);

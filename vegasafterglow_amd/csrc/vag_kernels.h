@@ -147,7 +147,8 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
 __global__ void __launch_bounds__(256)
 vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                  const double* __restrict__ shock, long long n_cells, double* __restrict__ cellpar,
-                 double* __restrict__ cell_details /* optional [11][n_cells] */) {
+                 double* __restrict__ cell_details /* optional [11][n_cells] */,
+                 const int* __restrict__ inj_idx /* optional, per row: reverse shock's injection cutoff */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     // find model by cell offset
@@ -167,9 +168,20 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
     const int r = (int)(local / nt), k = (int)(local % nt);
     const vag_model_params P = params[m];
     CellOut o;
+    ElecBasic inj;
+    bool relic = false;
+    if (inj_idx) {  // Shock::is_relic, shock.h:56
+        const int k_inj = inj_idx[lay.row_off[m] + r];
+        if (k >= k_inj) {
+            const long long ci = c - k + (k_inj - 1);
+            inj = syn_elec_basic(shock[VS_TCOMV * n_cells + ci], shock[VS_GAMMA_TH * n_cells + ci], shock[VS_B * n_cells + ci],
+                                 P.eps_e, P.p, P.xi_e);
+            relic = true;
+        }
+    }
     syn_cell(o, shock[VS_TENG * n_cells + c], shock[VS_TCOMV * n_cells + c], shock[VS_R * n_cells + c],
              shock[VS_GAMMA * n_cells + c], shock[VS_GAMMA_TH * n_cells + c], shock[VS_B * n_cells + c],
-             shock[VS_NP * n_cells + c], P.eps_e, P.p, P.xi_e);
+             shock[VS_NP * n_cells + c], P.eps_e, P.p, P.xi_e, relic ? &inj : nullptr);
     double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
 #pragma unroll
     for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];

@@ -155,11 +155,15 @@ class Flux:
 class FluxDict:
     """FluxDict{total, fwd, rvs} (pybind.cpp:478-483, pymodel.cpp:350-364)."""
 
-    def __init__(self, fwd_sync, fwd_ssc=None):
+    def __init__(self, fwd_sync, fwd_ssc=None, rvs_sync=None, rvs_ssc=None):
         self.fwd = Flux(sync=fwd_sync, ssc=fwd_ssc)
-        self.rvs = Flux()
-        self.total = fwd_sync.copy() if fwd_ssc is None else fwd_sync + fwd_ssc
-        for a in (self.total, self.fwd.sync, self.fwd.ssc):
+        self.rvs = Flux(sync=rvs_sync, ssc=rvs_ssc)
+        total = fwd_sync.copy()  # PyFlux::calc_total order, pymodel.cpp:350-364
+        for extra in (fwd_ssc, rvs_sync, rvs_ssc):
+            if extra is not None:
+                total = total + extra
+        self.total = total
+        for a in (self.total, self.fwd.sync, self.fwd.ssc, self.rvs.sync, self.rvs.ssc):
             a.setflags(write=False)
 
 
@@ -197,17 +201,19 @@ class Model:
             raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, or TwoComponentJet")
         if not isinstance(medium, (ISM, Wind)):
             raise TypeError("medium must be ISM or Wind")
-        if rvs_rad is not None:
-            raise NotImplementedError("reverse shock is SURVEY section 8(f) rank 2: not on the accelerated path yet")
+        if rvs_rad is not None and not isinstance(rvs_rad, Radiation):
+            raise TypeError("rvs_rad must be a Radiation")
         if fwd_rad.kn and not fwd_rad.ssc:
             pass  # Klein-Nishina corrections only act through the IC cooling enabled by ssc (pymodel.h:567-577)
         if not axisymmetric:
             raise NotImplementedError("axisymmetric=False is SURVEY section 8(f) rank 3")
         _req(math.isfinite(rtol) and 0 < rtol < 1, f"rtol must be in (0, 1), got {rtol}")
-        res = (0.06, 0.15, 6.0) if resolutions is None else tuple(float(x) for x in resolutions)
+        # forward-only runs default to the coarser calibrated grid, reverse-shock runs to the denser one (pymodel.h:630-637)
+        default_res = (0.06, 0.2, 10.0) if rvs_rad is not None else (0.06, 0.15, 6.0)
+        res = default_res if resolutions is None else tuple(float(x) for x in resolutions)
         for n, x in zip(("phi_resol", "theta_resol", "t_resol"), res):
             _finite_pos(n, x)
-        self._jet, self._medium, self.observer, self.fwd_rad, self.rvs_rad = jet, medium, observer, fwd_rad, None
+        self._jet, self._medium, self.observer, self.fwd_rad, self.rvs_rad = jet, medium, observer, fwd_rad, rvs_rad
         self.resolutions, self.rtol, self.axisymmetric, self.radiative_fireball = res, float(rtol), True, bool(radiative_fireball)
         self._device = device
         p = ModelParams()
@@ -220,8 +226,21 @@ class Model:
         p.rtol = self.rtol
         p.radiative_fireball = 1 if radiative_fireball else 0
         p.flags = (_lib.FLAG_SSC if fwd_rad.ssc else 0) | (_lib.FLAG_KN if fwd_rad.kn else 0)
+        if rvs_rad is not None:
+            p.flags |= _lib.FLAG_RVS | (_lib.FLAG_RVS_SSC if rvs_rad.ssc else 0) | (_lib.FLAG_RVS_KN if rvs_rad.kn else 0)
+            p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e = rvs_rad.eps_e, rvs_rad.eps_B, rvs_rad.p, rvs_rad.xi_e
         _lib.check(_lib.load().vag_params_validate(C.byref(p)))
         self.params = p
+
+    def _has_components(self):
+        return self.fwd_rad.ssc or self.rvs_rad is not None
+
+    def _component_buffers(self, shape):
+        """Output arrays for the enabled FluxDict components (None = disabled) and the matching double*[4]."""
+        want = (True, self.fwd_rad.ssc, self.rvs_rad is not None, self.rvs_rad is not None and self.rvs_rad.ssc)
+        comps = [np.empty(shape) if w else None for w in want]
+        arr = (_dp * 4)(*[a.ctypes.data_as(_dp) if a is not None else None for a in comps])
+        return comps, arr
 
     # -- Model.flux_density_grid: pybind.cpp:424, pymodel.cpp:498-514 --
     def flux_density_grid(self, t, nu):
@@ -230,13 +249,12 @@ class Model:
         _req(nu.size > 0, "frequency array must be non-empty")
         out = np.empty((nu.size, t.size))
         h, lock = get_context(self._device)
-        if self.fwd_rad.ssc:
-            ssc = np.empty((nu.size, t.size))
+        if self._has_components():
+            comps, arr = self._component_buffers((nu.size, t.size))
             with lock:
-                _lib.check(_lib.load().vag_flux_density_grid_components_batch(
-                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
-                    out.ctypes.data_as(_dp), ssc.ctypes.data_as(_dp)))
-            return FluxDict(out, ssc)
+                _lib.check(_lib.load().vag_flux_density_grid_components4_batch(
+                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size, arr))
+            return FluxDict(*comps)
         with lock:
             _lib.check(_lib.load().vag_flux_density_grid_batch(
                 h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
@@ -264,13 +282,12 @@ class Model:
         _req(t.size > 0, "time array must be non-empty")
         out = np.empty(t.size)
         h, lock = get_context(self._device)
-        if self.fwd_rad.ssc:
-            ssc = np.empty(t.size)
+        if self._has_components():
+            comps, arr = self._component_buffers((t.size,))
             with lock:
-                _lib.check(_lib.load().vag_flux_components_batch(
-                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, float(nu_min), float(nu_max), int(num_nu),
-                    out.ctypes.data_as(_dp), ssc.ctypes.data_as(_dp)))
-            return FluxDict(out, ssc)
+                _lib.check(_lib.load().vag_flux_components4_batch(
+                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size, float(nu_min), float(nu_max), int(num_nu), arr))
+            return FluxDict(*comps)
         with lock:
             _lib.check(_lib.load().vag_flux_batch(h, C.byref(self.params), 1, t.ctypes.data_as(_dp), t.size,
                                                   float(nu_min), float(nu_max), int(num_nu), out.ctypes.data_as(_dp)))
@@ -298,17 +315,19 @@ class Model:
         return FluxDict(summed / float(num_points))
 
     # -- Model.details (shock part): pybind.cpp:448, pymodel.cpp:315-348 --
-    def details(self, t_min, t_max):
+    def details(self, t_min, t_max, rvs=False):
+        """Shock arrays of the forward shock, or with rvs=True of the reverse shock (Model.details().rvs)."""
         lib = _lib.load()
         h, lock = get_context(self._device)
         sh = _lib.DetailsShape()
+        fn = lib.vag_details_rvs if rvs else lib.vag_details
         with lock:
-            _lib.check(lib.vag_details(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), None))
+            _lib.check(fn(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), None))
             d = {"phi": np.zeros(sh.n_phi), "theta": np.zeros(sh.n_theta)}
             for n in ("t_src", "Gamma", "r", "t_comv", "B", "N_p", "Gamma_th"):
                 d[n] = np.zeros((sh.n_theta, sh.n_t))
             out = _lib.DetailsOut(*[d[n].ctypes.data_as(_dp) for n, _ in _lib.DetailsOut._fields_])
-            _lib.check(lib.vag_details(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), C.byref(out)))
+            _lib.check(fn(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), C.byref(out)))
         d["shape"] = dict(n_phi=sh.n_phi, n_theta=sh.n_theta, n_t=sh.n_t, n_reps=sh.n_reps, symmetry=sh.symmetry,
                           phi_mirrored=sh.phi_mirrored)
         return d
