@@ -1,5 +1,7 @@
-"""C5 workload probe: ensemble of two-component SSC models, timed through the C-ABI.
-usage: python3 profiles/ssc_ensemble.py [nb] [reps]"""
+"""C5 / C3 workload probes, timed through the C-ABI.
+  C5 (default): ensemble of two-component SSC models;  C3 (env ENSEMBLE=c3): power-law jet in a wind, forward +
+  reverse shock, SSC + Klein-Nishina on both, with +-10 % jitter on the jet and microphysics parameters.
+usage: python3 profiles/ssc_ensemble.py [nb] [reps] [check]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,11 +24,26 @@ def c5_batch(nb, seed=1):
     return out
 
 
+def c3_batch(nb, seed=3):
+    import configs
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nb):
+        kw = dict(configs.C3)
+        j = lambda: float(np.exp(rng.uniform(np.log(0.9), np.log(1.1))))
+        kw.update(theta_c=kw["theta_c"] * j(), E_iso=kw["E_iso"] * j(), Gamma0=kw["Gamma0"] * j(), A_star=kw["A_star"] * j(),
+                  eps_e=kw["eps_e"] * j(), eps_B=kw["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
+        kw["rvs"] = dict(kw["rvs"], eps_B=kw["rvs"]["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
+        out.append(_abi.make_params(**kw))
+    return out
+
+
 if __name__ == "__main__":
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     lib = _lib.load(); h, _ = get_context(0); dp = C.POINTER(C.c_double)
-    prms = c5_batch(nb)
+    which = os.environ.get("ENSEMBLE", "c5")
+    prms = c3_batch(nb) if which == "c3" else c5_batch(nb)
     if os.environ.get("C5_NOSSC"):
         for q in prms: q.flags = 0
     arr = (_lib.ModelParams * nb)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
@@ -45,7 +62,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 3:  # parity of a few members against the CPU checker
         orc = _abi.load_oracle()
         for i in range(0, nb, max(1, nb // 4)):
-            s, c = orc.flux_components(prms[i], t, nu)
-            w = s + c
+            w = orc.flux_density_grid(prms[i], t, nu)
             m = w > 1e-12 * w.max()
             print(f" member {i}: rel {np.abs(out[i] - w)[m].max() if False else (np.abs(out[i]-w)/np.where(m,w,1))[m].max():.3e}")

@@ -253,7 +253,6 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
 // phase-locked output lattice is integer-indexed with one output node per lane (registers).
 // ------------------------------------------------------------------------------------------------
 struct IcShared {
-    double sp[SP_TABLE_DOUBLES];
     double nu[IC_MAX_NU], lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU],
         inv_lg2r[IC_MAX_NU], cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU], cdf[IC_MAX_NU], fv[IC_MAX_NU], ratio[IC_MAX_NU],
         ex[IC_MAX_NU];
@@ -313,7 +312,6 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const vag_model_params P = params[m];
     const bool KN = (P.flags & VAG_FLAG_KN) != 0;
     double* tab = ictab + (size_t)c * IC_STRIDE;
-    for (int i = lane; i < SP_TABLE_DOUBLES; i += 64) sh.sp[i] = sp_table[i];
 
     const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
     const double gamma_M = det[VD_GAMMA_MAX * n_cells + c], column_den = det[VD_COLUMN_DEN * n_cells + c];
@@ -370,9 +368,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     for (int j = lane; j < nu_size; j += 64) {
         sh.lg2nu[j] = lg2_nu0 + step * (double)j;
-        sh.nu[j] = exp2(sh.lg2nu[j]);
+        sh.nu[j] = exp2_fast(sh.lg2nu[j]);
     }
-    for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2(lg2_g0 + step * (double)i);
+    for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_fast(lg2_g0 + step * (double)i);
     __syncthreads();
     // sample_distributions, inverse-compton.h:371-399
     const double* par = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
@@ -382,14 +380,14 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     for (int i = lane; i < g_size; i += 64) {
         const double gi = sh.gam[i];
         const double dgi = 0.5 * ((i + 1 < g_size ? sh.gam[i + 1] : gi) - (i > 0 ? sh.gam[i - 1] : gi));
-        const double Yg = exp2(icy_lg2_Y(icy, n_cells, c, log2(gi)));
+        const double Yg = exp2_fast(icy_lg2_Y(icy, n_cells, c, log2_fast(gi)));
         sh.dNe[i] = electron_column_den(gi, gamma_m, gamma_c, gamma_M, P.p, regime, column_den, Y_c, Yg) / (gi * gi) * dgi;
     }
     for (int j = lane; j < nu_size; j += 64) {
-        const double I_seed = exp2(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sh.sp));
+        const double I_seed = exp2_fast(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table));
         const double f = I_seed / (sh.nu[j] * sh.nu[j]);
         sh.fv_th[j] = f;
-        sh.lg2fv[j] = f > 0 ? log2(f) : -INFINITY;
+        sh.lg2fv[j] = f > 0 ? log2_fast(f) : -INFINITY;
     }
     __syncthreads();
     const int nu_last = nu_size - 1;
@@ -414,12 +412,13 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
         const double lg2_base = log2(sh.gam[0]) + sh.lg2nu[0];
         for (int q = lane; q < n_lat; q += 64)
-            compton_correction_pair(exp2(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+            compton_correction_pair(exp2_fast(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
         __syncthreads();
     }
     // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527)
     double I_acc[3] = {0, 0, 0};
     const double expq1 = exp2(IC_Q * 1.0);
+    const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;  // log2(nu_split) of electron node 0
     const long ns_top = (long)nu_last * 2;
     for (int i = 0; i < g_size; ++i) {
         const double dNe = sh.dNe[i];
@@ -430,7 +429,10 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         if (KN) {  // build_cdf_KN, inverse-compton.h:432-481
             const int i_gamma = 2 * i;
             const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / sh.gam[i];
-            int j_split = 0;
+            // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
+            int j_split = (int)ceil((lg2_split0 - step * (double)i - lg2_nu0) / step);
+            j_split = j_split < 0 ? 0 : (j_split > nu_last ? nu_last : j_split);
+            while (j_split > 0 && sh.nu[j_split - 1] >= nu_split) --j_split;
             while (j_split < nu_last && sh.nu[j_split] < nu_split) ++j_split;
             __syncthreads();
             for (int j = lane; j <= nu_last; j += 64)
@@ -491,7 +493,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int kk = lane + 64 * s;
-        if (kk < n_ic) tab[IC_HDR + kk] = log2(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
+        if (kk < n_ic) tab[IC_HDR + kk] = log2_fast(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
     }
     if (lane == 0) {
         tab[0] = (double)n_ic;
