@@ -140,6 +140,39 @@ def tophat_sweep(lib, h, _lib, dev):
     return out
 
 
+def ensemble_bench(lib, h, _lib, dev):
+    """BASELINE configs[2] and [4] as batched ensembles on one GPU: C3 = power-law jet in a wind,
+    forward + reverse shock with SSC + Klein-Nishina on both (jittered parameters); C5 = prior-predictive sweep of
+    two-component SSC jets.  100 times x 4 bands (incl. 2.4e26 Hz), device-resident inputs."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from ssc_ensemble import c3_batch, c5_batch
+    t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
+    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
+    out = {}
+    for name, prms, ref_ms in (("C3_fs_rs_ssc_kn", c3_batch(128), 1197.0), ("C5_two_component_ssc", c5_batch(256), 1120.0)):
+        nb = len(prms)
+        import _abi
+        arr = (_abi.ModelParams * nb)(*prms)
+        d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        d_o = torch.empty((nb, nu.size, t.size), dtype=torch.float64, device=dev)
+        call = lambda: _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), nb, d_t.data_ptr(), t.size,
+                                                                        d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        plan = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(plan))
+        out[name] = {"batch": nb, "ms_per_batch": 1e3 * dt, "light_curves_per_s": nb / dt, "finite": bool(torch.isfinite(d_o).all()),
+                     "ode_rows": plan.n_rows, "cells": plan.n_cells,
+                     "reference_cpu_ms_per_model_survey": ref_ms}
+    return out
+
+
 def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
     """Secondary metric of BASELINE.json: MCMC walker-steps/s on the C4 problem: GW170817-like mock,
     60 data points (3 bands x 20 epochs), 8 free parameters, default resolutions, 1024 walkers drawn uniformly
@@ -293,6 +326,7 @@ def main():
     walkers = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world)
     walkers_half = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512)
     tophat = tophat_sweep(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
+    ensembles = ensemble_bench(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
 
     if rank == 0:
         st = np.mean(np.array(flux_ms), axis=0)
@@ -334,6 +368,8 @@ def main():
             out["walker_steps_redblue_half"] = walkers_half  # emcee red-blue moves evaluate nwalkers/2 per call
         if tophat is not None:
             out["tophat_config0"] = tophat
+        if ensembles:
+            out["ensembles_config2_config4"] = ensembles
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, t_np, nu_np)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(arr, t_np, nu_np)

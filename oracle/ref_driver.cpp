@@ -79,6 +79,27 @@ JetVariant make_jet(const vag_model_params& p) {
             jet.T0 *= unit::sec;
             return jet;
         }
+        case VAG_JET_MAGNETIZED_TOPHAT: {
+            // tests/python/golden/regenerate.py:141-149 (_magnetized_tophat) through the Ejecta factory of
+            // pybind/pybind.cpp:224-272 and convert_unit_jet (pymodel.cpp:188-210)
+            const Real theta_c = p.theta_c, E_iso = p.E_iso, Gamma0 = p.Gamma0, sigma0 = p.sigma0;
+            Ejecta jet(BinaryFunc([=](Real, Real theta) { return theta <= theta_c ? E_iso : 0.0; }),
+                       BinaryFunc([=](Real, Real theta) { return theta <= theta_c ? Gamma0 : 1.0; }),
+                       BinaryFunc([=](Real, Real) { return sigma0; }), TernaryFunc(func::zero_3d), TernaryFunc(func::zero_3d),
+                       false, p.duration);
+            const auto eps_k_cgs = jet.eps_k;
+            jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
+            const auto deps_dt_cgs = jet.deps_dt;
+            jet.deps_dt = [=](Real phi, Real theta, Real t) {
+                return deps_dt_cgs(phi, theta, t / unit::sec) * (unit::erg / (4 * con::pi * unit::sec));
+            };
+            const auto dm_dt_cgs = jet.dm_dt;
+            jet.dm_dt = [=](Real phi, Real theta, Real t) {
+                return dm_dt_cgs(phi, theta, t / unit::sec) * (unit::g / (4 * con::pi * unit::sec));
+            };
+            jet.T0 *= unit::sec;
+            return jet;
+        }
     }
     throw std::invalid_argument("unknown jet_type");
 }

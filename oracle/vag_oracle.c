@@ -106,6 +106,7 @@ typedef struct {
     double k_e, k_g, norm;         /* Gaussian: norm = -1/(2 theta_c^2) */
     double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w; /* two-component (Ejecta built in CGS) */
     double T0;
+    double sigma0; /* constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise */
 } jet_t;
 
 typedef struct {
@@ -129,6 +130,7 @@ static void jet_init(jet_t* j, const vag_model_params* p) {
     j->Gm1 = p->Gamma0 - 1;
     j->Gm1_w = p->Gamma0_w - 1;
     j->T0 = p->duration * U_SEC;
+    j->sigma0 = (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT) ? p->sigma0 : 0.0;
 }
 
 static double jet_eps_k(const jet_t* j, double theta) {
@@ -136,6 +138,8 @@ static double jet_eps_k(const jet_t* j, double theta) {
         case VAG_JET_TOPHAT: return theta < j->theta_c ? j->eps_k : 0;
         case VAG_JET_GAUSSIAN: return j->eps_k * exp(theta * theta * j->norm);
         case VAG_JET_POWERLAW: return j->eps_k / (1 + fast_pow(theta / j->theta_c, j->k_e));
+        case VAG_JET_MAGNETIZED_TOPHAT: /* Ejecta(E_iso = E if theta <= theta_c else 0) in CGS, then convert_unit_jet */
+            return (theta <= j->theta_c ? j->E_iso_cgs : 0.0) * (U_ERG / (4 * C_PI));
         default: { /* math::two_component (jet.h:421-433) in CGS, then convert_unit_jet */
             double h = theta <= j->theta_c ? j->E_iso_cgs : (theta <= j->theta_w ? j->E_iso_w_cgs : 0.);
             return h * (U_ERG / (4 * C_PI));
@@ -148,6 +152,7 @@ static double jet_Gamma0(const jet_t* j, double theta) {
         case VAG_JET_TOPHAT: return theta < j->theta_c ? j->Gamma0 : 1;
         case VAG_JET_GAUSSIAN: return (j->Gamma0 - 1) * exp(theta * theta * j->norm) + 1;
         case VAG_JET_POWERLAW: return (j->Gamma0 - 1) / (1 + fast_pow(theta / j->theta_c, j->k_g)) + 1;
+        case VAG_JET_MAGNETIZED_TOPHAT: return theta <= j->theta_c ? j->Gamma0 : 1.0;
         default: {
             double h = theta <= j->theta_c ? j->Gm1 : (theta <= j->theta_w ? j->Gm1_w : 0.);
             return h + 1;
@@ -674,7 +679,7 @@ static double estimate_t_dec(const jet_t* jet, const medium_t* med, double theta
     const double gamma = jet_Gamma0(jet, theta);
     const double beta = gamma_to_beta(gamma);
     double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2);
-    if (jet->type == VAG_JET_TWO_COMPONENT) m_jet /= (1.0 + 0.0); /* Ejecta carries sigma0 == 0 */
+    if (jet->type >= VAG_JET_TWO_COMPONENT) m_jet /= (1.0 + jet->sigma0); /* HasSigma<Ejecta> */
     const double target = m_jet / gamma;
     const double r_min = 1e-3;
     const double r_max = r_min * pow(10.0, 40.0);
@@ -1121,7 +1126,7 @@ static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med
         e.jet = jet;
         e.theta0 = c->theta[j];
         e.m_jet0 = jet_eps_k(jet, e.theta0) / jet_Gamma0(jet, e.theta0) / C_C2;
-        if (jet->type == VAG_JET_TWO_COMPONENT) e.m_jet0 /= 1 + 0.0;
+        if (jet->type >= VAG_JET_TWO_COMPONENT) e.m_jet0 /= 1 + jet->sigma0;
         e.radiative = p->radiative_fireball != 0;
         e.eps_e = p->eps_e;
         e.eps_B = p->eps_B;
@@ -1293,7 +1298,7 @@ static void rvs_rhs(const double* raw, double* d, double t, void* vctx) {
     const double inject_w = smoothstep(e->T0 * 1.5, e->T0 * 0.5, t);
     d[RS_EPS4] = (inject_w > 1e-6) ? inject_w * e->deps0_dt : 0;
     d[RS_M4] = (inject_w > 1e-6) ? inject_w * e->dm0_dt : 0;
-    if (e->jet->type == VAG_JET_TWO_COMPONENT) { /* python-level Ejecta: deps_dt / dm_dt are the zero functions */
+    if (e->jet->type >= VAG_JET_TWO_COMPONENT) { /* python-level Ejecta: deps_dt / dm_dt are the zero functions */
         d[RS_EPS4] += 0.0;
         d[RS_M4] += 0.0;
     }
@@ -1377,7 +1382,7 @@ static void rvs_rhs(const double* raw, double* d, double t, void* vctx) {
         const double dGamma_eff2_dGamma = (ad_idx2 * Gamma2 + ad_idx2 - 1) / Gamma2;
         const double dGamma_eff3_dGamma = (ad_idx3 * Gamma2 + ad_idx3 - 1) / Gamma2;
         double deps_dt = 0;
-        if (e->jet->type == VAG_JET_TWO_COMPONENT) deps_dt = 0.0; /* Ejecta::deps_dt == zero function */
+        if (e->jet->type >= VAG_JET_TWO_COMPONENT) deps_dt = 0.0; /* Ejecta::deps_dt == zero function */
         const double a = (Gamma - 1) * C_C2 * d[RS_M2] + (Gamma - Gamma4) * C_C2 * d[RS_M3] + Gamma_eff2 * d[RS_U2] +
                          Gamma_eff3 * d[RS_U3] - deps_dt;
         const double b = (s[RS_M2] + s[RS_M3]) * C_C2 + dGamma_eff2_dGamma * s[RS_U2] + dGamma_eff3_dGamma * s[RS_U3];
@@ -1638,7 +1643,7 @@ static int generate_shock_pair(shock_t* fwd, shock_t* rvs, const coord_t* c, con
         e.deps0_dt = jet_eps_k(jet, e.theta0) / jet->T0;
         e.dm0_dt = e.deps0_dt / (e.Gamma4 * C_C2);
         e.u4 = sqrt(e.Gamma4 * e.Gamma4 - 1) * C_C;
-        if (jet->type == VAG_JET_TWO_COMPONENT) e.dm0_dt /= 1 + 0.0; /* HasSigma<Ejecta>, sigma0 == zero function */
+        if (jet->type >= VAG_JET_TWO_COMPONENT) e.dm0_dt /= 1 + jet->sigma0; /* HasSigma<Ejecta> */
         e.rad_fwd.med = med;
         e.rad_fwd.jet = jet;
         e.rad_fwd.radiative = p->radiative_fireball != 0;
@@ -2787,7 +2792,9 @@ static int range_oi(double x, double lo, double hi) { /* (lo, hi] */
 }
 
 int vag_oracle_params_validate(const vag_model_params* p) {
-    if (p->jet_type < 0 || p->jet_type > VAG_JET_TWO_COMPONENT) return fail("unknown jet_type");
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_MAGNETIZED_TOPHAT) return fail("unknown jet_type");
+    if (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT && !(isfinite(p->sigma0) && p->sigma0 >= 0))
+        return fail("sigma0 must be finite and non-negative");
     if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return fail("unknown medium_type");
     if (!range_oi(p->theta_c, 0.0, C_PI / 2)) return fail("theta_c must be in (0, pi/2]");
     if (!finite_pos(p->E_iso)) return fail("E_iso must be positive and finite");

@@ -11,9 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT = 0, 1, 2, 3
+JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT = 0, 1, 2, 3, 4
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
-JET_IDS = {"TophatJet": 0, "GaussianJet": 1, "PowerLawJet": 2, "TwoComponentJet": 3}
+JET_IDS = {"TophatJet": 0, "GaussianJet": 1, "PowerLawJet": 2, "TwoComponentJet": 3, "MagnetizedTophat": 4}
 MEDIUM_IDS = {"ISM": 0, "Wind": 1}
 
 
@@ -29,10 +29,11 @@ class ModelParams(C.Structure):
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
         ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
+        ("sigma0", C.c_double),
     ]
 
 
-assert C.sizeof(ModelParams) == 232
+assert C.sizeof(ModelParams) == 240
 
 
 class DetailsShape(C.Structure):
@@ -48,7 +49,7 @@ class DetailsOut(C.Structure):
 def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
-                xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None):
+                xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None, sigma0=0.0):
     # rvs = dict(eps_e, eps_B, p[, xi_e, ssc, kn]) mirrors Model(rvs_rad=Radiation(...)); the default resolutions are
     # mode-aware like the reference's Model ctor (pybind/pymodel.h:630-637)
     """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
@@ -64,6 +65,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
         resolutions = (0.06, 0.2, 10.0) if rvs else (0.06, 0.15, 6.0)
     q.phi_resol, q.theta_resol, q.t_resol = resolutions
     q.rtol = rtol
+    q.sigma0 = sigma0
     q.radiative_fireball = 1 if radiative_fireball else 0
     q.flags = (1 if ssc else 0) | (2 if kn else 0)
     if rvs:
@@ -79,7 +81,7 @@ def params_from_golden_config(cfg):
     kw = dict(jet=jet.pop("type"), medium=med.pop("type"))
     if kw["medium"] == "Wind":
         kw["n_ism"] = 0.0  # Wind(A_star, n_ism=None, n0=None): pybind/pymodel.cpp:153-166
-    kw.update(jet)
+    kw.update(jet)  # MagnetizedTophat carries sigma0
     kw.update(med)
     kw.update(cfg["observer"])
     kw.update(cfg["fwd_rad"])  # includes ssc / kn

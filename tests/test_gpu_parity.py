@@ -450,7 +450,8 @@ def test_rs_components_match_oracle(eng, oracle, name):
         assert_close(total, w_total)
 
 
-@pytest.mark.parametrize("name", ["rs_thick", "gauss_ism_rs", "powerlaw_wind_rs"])
+@pytest.mark.parametrize("name", ["rs_thick", "gauss_ism_rs", "powerlaw_wind_rs", "tophat_sigma_rs", "tophat_sigma1_rs",
+                                  "tophat_sigma10_rs"])
 def test_rs_reference_golden_contract(eng, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     prm = _abi.params_from_golden_config(json.loads(str(g["config"])))
@@ -461,6 +462,21 @@ def test_rs_reference_golden_contract(eng, name):
             assert_close(got[comp], g[comp], rtol=2e-6, floor=1e-2)
     assert within_contract(gpu_grid(eng, prm, g["t"], g["nus"])[0], g["total"])
     assert np.all(got["fwd_ssc"] == 0) and np.all(got["rvs_ssc"] == 0)
+
+
+@pytest.mark.parametrize("sigma0", [0.1, 1.0, 10.0])
+def test_magnetized_tophat_matches_oracle(eng, oracle, sigma0):
+    """sigma > 0: cubic jump condition, magnetosonic crossing cap, 10x tighter ODE tolerance (reverse-shock.tpp:529-537)."""
+    prm = _abi.make_params(jet="MagnetizedTophat", sigma0=sigma0, theta_obs=0.05, z=0.5, lumi_dist=3e28, eps_B=1e-3,
+                           rvs=dict(eps_e=0.1, eps_B=0.01, p=2.5))
+    t, nu = np.logspace(0, 7, 36), np.array([1e9, 4.84e14, 1e18])
+    want = oracle.flux_components4(prm, t, nu)
+    got = gpu_components4(eng, prm, t, nu)
+    assert_close(got[0][0], want[0])
+    assert_close(got[2][0], want[2], rtol=2e-5)  # the magnetised solve is the reference's tolerance-sensitive case
+    m = va.Model(va.MagnetizedTophatJet(0.1, 1e52, 300.0, sigma0), va.ISM(1.0), va.Observer(3e28, 0.5, 0.05),
+                 va.Radiation(0.1, 1e-3, 2.3), rvs_rad=va.Radiation(0.1, 0.01, 2.5))
+    assert_close(m.flux_density_grid(t, nu).rvs.sync, want[2], rtol=2e-5)
 
 
 def test_rs_committed_reference_vectors(eng):

@@ -240,14 +240,19 @@ def test_exposure_average_follows_reference_sampling(oracle):
 COMPONENTS = ("fwd_sync", "fwd_ssc", "rvs_sync", "rvs_ssc")
 
 
-@pytest.mark.parametrize("name", ["rs_thick", "gauss_ism_rs", "powerlaw_wind_rs"])
+RS_GOLDENS = ["rs_thick", "gauss_ism_rs", "powerlaw_wind_rs", "tophat_sigma_rs", "tophat_sigma1_rs", "tophat_sigma10_rs"]
+
+
+@pytest.mark.parametrize("name", RS_GOLDENS)
 def test_oracle_rs_matches_reference_goldens(oracle, name):
-    """The reference's reverse-shock goldens on the four built-in jets (thick shell, structured jets, wind):
-    forward and reverse components and their total under the reference's acceptance contract.  (Its three
-    tophat_sigma*_rs goldens need a python-callback magnetised Ejecta: out of scope.)"""
+    """All six reverse-shock goldens of the reference (thick shell, structured jets, wind, and the three magnetised
+    top-hat ejecta with sigma0 = 0.1 / 1 / 10 that exercise the cubic jump condition): forward and reverse components
+    and their total under the reference's acceptance contract."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     prm = _abi.params_from_golden_config(json.loads(str(g["config"])))
     assert prm.flags == 4
+    if "sigma" in name:
+        assert prm.jet_type == _abi.JET_MAGNETIZED_TOPHAT and prm.sigma0 in (0.1, 1.0, 10.0)
     comps = dict(zip(COMPONENTS, oracle.flux_components4(prm, g["t"], g["nus"])))
     total = oracle.flux_density_grid(prm, g["t"], g["nus"])
     for got, comp in ((comps["fwd_sync"], "fwd_sync"), (comps["rvs_sync"], "rvs_sync"), (total, "total")):
@@ -322,6 +327,17 @@ def test_oracle_rs_bit_identical_to_strict_reference_build(oracle, ref_strict, n
     for k in ("t_src", "Gamma", "r", "B", "N_p", "Gamma_th", "gamma_m", "gamma_c", "gamma_a", "gamma_M", "nu_c", "I_nu_max",
               "injection_idx"):
         assert np.array_equal(da[k], db[k], equal_nan=True), k  # cells without shocked ejecta carry NaN in both
+
+
+@pytest.mark.parametrize("sigma0", [0.0, 0.1, 1.0, 10.0])
+def test_oracle_magnetized_tophat_bit_identical_to_strict_reference_build(oracle, ref_strict, sigma0):
+    prm = _abi.make_params(jet="MagnetizedTophat", sigma0=sigma0, theta_obs=0.05, z=0.5, lumi_dist=3e28, eps_B=1e-3,
+                           rvs=dict(eps_e=0.1, eps_B=0.01, p=2.5))
+    t, nu = np.logspace(0, 7, 36), np.array([1e9, 4.84e14, 1e18])
+    for a, b in zip(oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)):
+        assert np.array_equal(a, b)
+    fwd_only = _abi.make_params(jet="MagnetizedTophat", sigma0=sigma0, theta_obs=0.05)
+    assert np.array_equal(oracle.flux_density_grid(fwd_only, t, nu), ref_strict.flux_density_grid(fwd_only, t, nu))
 
 
 def test_oracle_rs_validation_and_zero_rs_limit(oracle):

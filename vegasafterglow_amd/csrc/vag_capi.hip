@@ -123,7 +123,9 @@ static bool range_oi(double x, double lo, double hi) { return std::isfinite(x) &
 
 static const char* validate_msg(const vag_model_params* p) {
     const double pi = 3.14159265358979323846;
-    if (p->jet_type < 0 || p->jet_type > VAG_JET_TWO_COMPONENT) return "unknown jet_type";
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_MAGNETIZED_TOPHAT) return "unknown jet_type";
+    if (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT && !(std::isfinite(p->sigma0) && p->sigma0 >= 0))
+        return "sigma0 must be finite and non-negative";
     if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return "unknown medium_type";
     if (!range_oi(p->theta_c, 0.0, pi / 2)) return "theta_c must be in (0, pi/2]";
     if (!finite_pos(p->E_iso)) return "E_iso must be positive and finite";
@@ -1197,7 +1199,7 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     const int n = spec->n_data;
     if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
     for (int d = 0; d < ndim; ++d)
-        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_RVS_XI_E)))
+        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_SIGMA0)))
             return set_err(VAG_E_INVALID, "bad parameter slot");
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");

@@ -64,6 +64,7 @@ struct Jet {
     int type;
     double theta_c, eps_k, Gamma0, k_e, k_g, norm;
     double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w, T0;
+    double sigma0;  // constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise
 };
 struct Medium {
     int type;
@@ -84,12 +85,14 @@ VAG_DEV void jet_init(Jet& j, const vag_model_params& p) {
     j.Gm1 = p.Gamma0 - 1;
     j.Gm1_w = p.Gamma0_w - 1;
     j.T0 = p.duration * U_SEC;
+    j.sigma0 = (p.jet_type == VAG_JET_MAGNETIZED_TOPHAT) ? p.sigma0 : 0.0;
 }
 VAG_DEV double jet_eps_k(const Jet& j, double theta) {
     switch (j.type) {
         case VAG_JET_TOPHAT: return theta < j.theta_c ? j.eps_k : 0;
         case VAG_JET_GAUSSIAN: return j.eps_k * exp(theta * theta * j.norm);
         case VAG_JET_POWERLAW: return j.eps_k / (1 + fast_pow(theta / j.theta_c, j.k_e));
+        case VAG_JET_MAGNETIZED_TOPHAT: return (theta <= j.theta_c ? j.E_iso_cgs : 0.0) * (U_ERG / (4 * C_PI));
         default: {
             const double h = theta <= j.theta_c ? j.E_iso_cgs : (theta <= j.theta_w ? j.E_iso_w_cgs : 0.);
             return h * (U_ERG / (4 * C_PI));
@@ -101,6 +104,7 @@ VAG_DEV double jet_Gamma0(const Jet& j, double theta) {
         case VAG_JET_TOPHAT: return theta < j.theta_c ? j.Gamma0 : 1;
         case VAG_JET_GAUSSIAN: return (j.Gamma0 - 1) * exp(theta * theta * j.norm) + 1;
         case VAG_JET_POWERLAW: return (j.Gamma0 - 1) / (1 + fast_pow(theta / j.theta_c, j.k_g)) + 1;
+        case VAG_JET_MAGNETIZED_TOPHAT: return theta <= j.theta_c ? j.Gamma0 : 1.0;
         default: {
             const double h = theta <= j.theta_c ? j.Gm1 : (theta <= j.theta_w ? j.Gm1_w : 0.);
             return h + 1;
@@ -142,7 +146,7 @@ VAG_DEV double medium_mass(const Medium& m, double r) {
 VAG_DEV bool params_valid(const vag_model_params& p) {
     auto fpos = [](double x) { return isfinite(x) && x > 0; };
     auto oi = [](double x, double lo, double hi) { return isfinite(x) && x > lo && x <= hi; };
-    bool ok = p.jet_type >= 0 && p.jet_type <= VAG_JET_TWO_COMPONENT && p.medium_type >= 0 &&
+    bool ok = p.jet_type >= 0 && p.jet_type <= VAG_JET_MAGNETIZED_TOPHAT && p.medium_type >= 0 &&
               p.medium_type <= VAG_MEDIUM_WIND;
     ok = ok && oi(p.theta_c, 0.0, C_PI / 2) && fpos(p.E_iso) && isfinite(p.Gamma0) && p.Gamma0 > 1.0 && fpos(p.duration);
     if (p.jet_type == VAG_JET_POWERLAW) ok = ok && fpos(p.k_e) && fpos(p.k_g);
@@ -155,6 +159,7 @@ VAG_DEV bool params_valid(const vag_model_params& p) {
          p.theta_obs <= C_PI;
     ok = ok && oi(p.eps_e, 0.0, 1.0) && oi(p.eps_B, 0.0, 1.0) && oi(p.xi_e, 0.0, 1.0) && isfinite(p.p) && p.p > 1.0;
     ok = ok && isfinite(p.rtol) && p.rtol > 0 && p.rtol < 1 && fpos(p.phi_resol) && fpos(p.theta_resol) && fpos(p.t_resol);
+    if (p.jet_type == VAG_JET_MAGNETIZED_TOPHAT) ok = ok && isfinite(p.sigma0) && p.sigma0 >= 0;
     if (p.flags & VAG_FLAG_RVS)
         ok = ok && oi(p.rvs_eps_e, 0.0, 1.0) && oi(p.rvs_eps_B, 0.0, 1.0) && oi(p.rvs_xi_e, 0.0, 1.0) && isfinite(p.rvs_p) &&
              p.rvs_p > 1.0;
@@ -275,7 +280,7 @@ struct Dopri5 {
 VAG_DEV double estimate_t_dec(const Jet& jet, const Medium& med, double theta) {
     const double gamma = jet_Gamma0(jet, theta);
     const double beta = gamma_to_beta(gamma);
-    const double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2);
+    const double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2) / (1.0 + jet.sigma0);  // HasSigma<Ejecta>: x / 1.0 is exact
     const double target = m_jet / gamma;
     const double r_min = 1e-3;
     const double r_max = r_min * 1e40;

@@ -62,7 +62,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? M.t_early : lat.node(k - 1)) : lat.node(k); };
 
     const double Gamma4 = jet_Gamma0(jet, theta0);
-    eq.m_jet0 = jet_eps_k(jet, theta0) / Gamma4 / C_C2;
+    eq.m_jet0 = jet_eps_k(jet, theta0) / Gamma4 / C_C2 / (1 + jet.sigma0);
     eq.gamma_m_coeff = (P.p - 2) / (P.p - 1) * P.eps_e * C_MP / C_ME / P.xi_e;
     eq.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B);
     eq.eps_e_eff = P.radiative_fireball ? P.eps_e : 0;

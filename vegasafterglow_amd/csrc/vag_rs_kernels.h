@@ -68,7 +68,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     eq.Gamma4 = jet_Gamma0(jet, theta0);
     eq.T0 = T0;
     eq.deps0_dt = jet_eps_k(jet, theta0) / T0;
-    eq.dm0_dt = eq.deps0_dt / (eq.Gamma4 * C_C2);
+    eq.dm0_dt = eq.deps0_dt / (eq.Gamma4 * C_C2) / (1 + jet.sigma0);
     eq.u4 = sqrt(eq.Gamma4 * eq.Gamma4 - 1) * C_C;
     eq.gamma_m_coeff = (P.p - 2) / (P.p - 1) * P.eps_e * C_MP / C_ME / P.xi_e;
     eq.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B);

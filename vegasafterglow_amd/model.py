@@ -90,6 +90,22 @@ class TwoComponentJet(TophatJet):
         p.theta_w, p.E_iso_w, p.Gamma0_w = self.theta_w, self.E_iso_w, self.Gamma0_w
 
 
+class MagnetizedTophatJet(TophatJet):
+    """Top-hat profile on the generic Ejecta with a constant magnetisation sigma0 -- what the reference's test-suite
+    builds as Ejecta(E_iso=lambda phi, theta: E_iso if theta <= theta_c else 0, Gamma0=..., sigma0=lambda ...: sigma0)
+    (tests/python/golden/regenerate.py:141-149).  Arbitrary python-callback Ejecta profiles are not on the device."""
+    jet_type = _lib.JET_MAGNETIZED_TOPHAT
+
+    def __init__(self, theta_c, E_iso, Gamma0, sigma0, duration=1.0):
+        super().__init__(theta_c, E_iso, Gamma0, duration=duration)
+        _req(math.isfinite(sigma0) and sigma0 >= 0, f"sigma0 must be finite and non-negative, got {sigma0}")
+        self.sigma0 = float(sigma0)
+
+    def _fill(self, p):
+        super()._fill(p)
+        p.sigma0 = self.sigma0
+
+
 class ISM:
     """ISM(n_ism) -- pybind.cpp:347, pymodel.cpp:148-151."""
 
@@ -198,7 +214,7 @@ class Model:
     def __init__(self, jet, medium, observer, fwd_rad, rvs_rad=None, resolutions=None, rtol=1e-6, axisymmetric=True,
                  radiative_fireball=True, device=0):
         if not isinstance(jet, _Jet):
-            raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, or TwoComponentJet")
+            raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, TwoComponentJet or MagnetizedTophatJet")
         if not isinstance(medium, (ISM, Wind)):
             raise TypeError("medium must be ISM or Wind")
         if rvs_rad is not None and not isinstance(rvs_rad, Radiation):
