@@ -252,7 +252,7 @@ VAG_DEV void compton_correction_pair(double nu, const double* __restrict__ lut, 
         return;
     }
     constexpr double inv_step = 1.0 / ((KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1));
-    const double pos = (log2(x) - KN_LG2_XMIN) * inv_step;
+    const double pos = (log2_fast(x) - KN_LG2_XMIN) * inv_step;
     if (pos <= 0) {
         corr = lut[0];
         lg2_corr = lut[KN_LUT_N];

@@ -254,8 +254,8 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
 // ------------------------------------------------------------------------------------------------
 struct IcShared {
     double nu[IC_MAX_NU], lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU],
-        inv_lg2r[IC_MAX_NU], cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU], cdf[IC_MAX_NU], fv[IC_MAX_NU], ratio[IC_MAX_NU],
-        ex[IC_MAX_NU];
+        inv_lg2r[IC_MAX_NU], cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU], ex[IC_MAX_NU];
+    double T[4][IC_MAX_NU];  // per-bin terms of four electron energies (exchange rows of the accumulation loop)
     double gam[IC_MAX_G], dNe[IC_MAX_G];
     double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
 };
@@ -283,6 +283,28 @@ VAG_DEV void suffix_scan(const double* __restrict__ ex, double* __restrict__ cdf
     const double c1 = S_next + b;
     if (j1 <= n) cdf[j1] = j1 < n ? c1 : 0.0;
     if (j0 <= n) cdf[j0] = j0 < n ? c1 + a : 0.0;
+}
+
+// ---- cross-lane helpers on the DPP path (no LDS round trip): gfx9 row_shr / row_bcast / wave_shr controls ----
+template <int CTRL, int ROW_MASK>
+VAG_DEV double dpp_zero(double v) {  // value of the DPP source lane; 0 where the source is invalid or the row is masked off
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+VAG_DEV double wave_prefix_sum(double x) {  // inclusive sum over lanes 0..lane (Kogge-Stone in rows of 16, then row totals)
+    x += dpp_zero<0x111, 0xf>(x);  // row_shr:1
+    x += dpp_zero<0x112, 0xf>(x);  // row_shr:2
+    x += dpp_zero<0x114, 0xf>(x);  // row_shr:4
+    x += dpp_zero<0x118, 0xf>(x);  // row_shr:8
+    x += dpp_zero<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3 add the total of the row before
+    x += dpp_zero<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3 add the total of rows 0-1
+    return x;
+}
+VAG_DEV double from_lane_below(double v) { return dpp_zero<0x138, 0xf>(v); }  // wave_shr:1: lane - 1's value, 0 into lane 0
+VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
+    const int l = __builtin_amdgcn_readfirstlane(src);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
 __global__ void __launch_bounds__(64)
@@ -408,6 +430,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     suffix_scan(sh.ex, sh.cdf_th, nu_last, lane);
     __syncthreads();
+#ifdef VAG_IC_ABLATE
+    if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
+#endif
     if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
         const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
         const double lg2_base = log2(sh.gam[0]) + sh.lg2nu[0];
@@ -415,75 +440,121 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             compton_correction_pair(exp2_fast(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
         __syncthreads();
     }
-    // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527)
+    // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527).
+    // Register-resident form: every lane keeps two seed nodes, in REVERSED lane order (j0 = 2 (63 - lane), j1 = j0 + 1),
+    // so the suffix sums of the scattering CDF are a prefix sum over lanes and the value at node j + 1 is the lane's own
+    // second node or the first node of lane - 1 (one wave_shr DPP move); the per-gamma KN CDF (build_cdf_KN, :432-481)
+    // never touches LDS.  Output node kk samples seed bin j = n_lo - 2 i + kk exactly at its lower edge (all lattice offsets are
+    // even), so its term is cdf[j+1] + 0.5 (f_j + f_j+1) dnu_j ratio_j, a per-bin quantity exchanged through one LDS row.
     double I_acc[3] = {0, 0, 0};
-    const double expq1 = exp2(IC_Q * 1.0);
-    const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;  // log2(nu_split) of electron node 0
-    const long ns_top = (long)nu_last * 2;
-    for (int i = 0; i < g_size; ++i) {
-        const double dNe = sh.dNe[i];
-        if (!(dNe > 0)) continue;  // uniform
-        const double* fvp = sh.fv_th;
-        const double* cdfp = sh.cdf_th;
-        const double* ratp = sh.ratio_th;
-        if (KN) {  // build_cdf_KN, inverse-compton.h:432-481
-            const int i_gamma = 2 * i;
-            const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / sh.gam[i];
-            // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
-            int j_split = (int)ceil((lg2_split0 - step * (double)i - lg2_nu0) / step);
-            j_split = j_split < 0 ? 0 : (j_split > nu_last ? nu_last : j_split);
-            while (j_split > 0 && sh.nu[j_split - 1] >= nu_split) --j_split;
-            while (j_split < nu_last && sh.nu[j_split] < nu_split) ++j_split;
-            __syncthreads();
-            for (int j = lane; j <= nu_last; j += 64)
-                sh.fv[j] = j >= j_split ? sh.fv_th[j] * sh.corr[i_gamma + 2 * j] : sh.fv_th[j];
-            __syncthreads();
-            for (int j = lane; j < nu_last; j += 64) {
-                if (j >= j_split) {
-                    const double lg2f_lo = sh.lg2fv[j] + sh.lg2corr[i_gamma + 2 * j];
-                    const double lg2f_hi = sh.lg2fv[j + 1] + sh.lg2corr[i_gamma + 2 * (j + 1)];
-                    const double trap = 0.5 * (sh.fv[j] + sh.fv[j + 1]) * sh.dnu[j];
-                    const double exact = power_law_bin_integral(sh.fv[j], sh.fv[j + 1], sh.nu[j], sh.nu[j + 1], lg2f_lo, lg2f_hi,
-                                                                sh.lg2r[j], sh.inv_lg2r[j], trap);
-                    sh.ex[j] = exact;
-                    sh.ratio[j] = trap > 0 ? exact / trap : 1;
-                } else {
-                    sh.ex[j] = 0;
-                    sh.ratio[j] = sh.ratio_th[j];
-                }
-            }
-            __syncthreads();
-            suffix_scan(sh.ex, sh.cdf, nu_last, lane);
-            __syncthreads();
-            if (j_split > 0) {
-                const double delta = sh.cdf[j_split] - sh.cdf_th[j_split];
-                __syncthreads();
-                for (int j = lane; j < j_split; j += 64) sh.cdf[j] = sh.cdf_th[j] + delta;
-            }
-            __syncthreads();
-            fvp = sh.fv;
-            cdfp = sh.cdf;
-            ratp = sh.ratio;
+    const int j0 = 2 * (63 - lane), j1 = j0 + 1;
+    auto ld = [&](const double* a, int jj) { return jj <= nu_last ? a[jj] : 0.0; };
+    const double nu0 = ld(sh.nu, j0), nu1 = ld(sh.nu, j1);
+    const double fth0 = ld(sh.fv_th, j0), fth1 = ld(sh.fv_th, j1);
+    const double lth0 = ld(sh.lg2fv, j0), lth1 = ld(sh.lg2fv, j1);
+    const bool bin0 = j0 < nu_last, bin1 = j1 < nu_last;  // bins [j, j+1]
+    const double dnu0 = bin0 ? sh.dnu[j0] : 0.0, dnu1 = bin1 ? sh.dnu[j1] : 0.0;
+    const double lgr0 = bin0 ? sh.lg2r[j0] : 0.0, lgr1 = bin1 ? sh.lg2r[j1] : 0.0;
+    const double ilr0 = bin0 ? sh.inv_lg2r[j0] : 0.0, ilr1 = bin1 ? sh.inv_lg2r[j1] : 0.0;
+    const double cth0 = ld(sh.cdf_th, j0), cth1 = ld(sh.cdf_th, j1);
+    const double nuN0 = nu1;
+    const double nuN1 = from_lane_below(nu0);
+    const double rth0 = bin0 ? sh.ratio_th[j0] : 1.0, rth1 = bin1 ? sh.ratio_th[j1] : 1.0;
+    if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
+        const double fN0 = fth1, fN1 = from_lane_below(fth0);
+        const double cN0 = cth1, cN1 = from_lane_below(cth0);
+        __syncthreads();
+        if (bin0) sh.ex[j0] = cN0 + 0.5 * (fth0 + fN0) * dnu0 * rth0;  // sh.ex doubles as the exchange row T[j]
+        if (bin1) sh.ex[j1] = cN1 + 0.5 * (fth1 + fN1) * dnu1 * rth1;
+        __syncthreads();
+    }
+    const double cdf0_th = sh.cdf_th[0];
+    const int n_lo_i = (int)n_lo;
+    // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): dNe and the KN split index
+    const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
+    int my_split = 0;
+    if (KN && lane < g_size) {
+        const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / sh.gam[lane];
+        // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
+        const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
+        int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) / step);
+        js = js < 0 ? 0 : (js > nu_last ? nu_last : js);
+        while (js > 0 && sh.nu[js - 1] >= nu_split) --js;
+        while (js < nu_last && sh.nu[js] < nu_split) ++js;
+        my_split = js;
+    }
+    // one electron energy: per-bin terms T_a = cdf[j_a + 1] + trap_a ratio_a of this lane's two bins, and cdf[0]
+    auto kn_terms = [&](int i, double& T0, double& T1, double& cdf0) {  // build_cdf_KN, inverse-compton.h:432-481
+        const int i_gamma = 2 * i;
+        const int j_split = __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i));
+        const bool kn0 = j0 >= j_split && j0 <= nu_last, kn1 = j1 >= j_split && j1 <= nu_last;
+        const double f0 = kn0 ? fth0 * sh.corr[i_gamma + 2 * j0] : fth0;
+        const double f1 = kn1 ? fth1 * sh.corr[i_gamma + 2 * j1] : fth1;
+        const double lf0 = kn0 ? lth0 + sh.lg2corr[i_gamma + 2 * j0] : 0.0;
+        const double lf1 = kn1 ? lth1 + sh.lg2corr[i_gamma + 2 * j1] : 0.0;
+        const double fN0 = f1, fN1 = from_lane_below(f0);
+        const double lfN0 = lf1, lfN1 = from_lane_below(lf0);
+        // bins below the split keep the Thomson ratio (but see the corrected f at their upper edge j_split)
+        const double trap0 = 0.5 * (f0 + fN0) * dnu0, trap1 = 0.5 * (f1 + fN1) * dnu1;
+        double ex0 = 0, ex1 = 0, term0 = trap0 * rth0, term1 = trap1 * rth1;
+        if (bin0 && j0 >= j_split) {
+            ex0 = power_law_bin_integral(f0, fN0, nu0, nuN0, lf0, lfN0, lgr0, ilr0, trap0);
+            term0 = ex0;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
         }
-        const double cdf0 = cdfp[0];
-        if (cdf0 <= 0) continue;  // uniform
-        const long n_off = idx0 - 4L * i;
+        if (bin1 && j1 >= j_split) {
+            ex1 = power_law_bin_integral(f1, fN1, nu1, nuN1, lf1, lfN1, lgr1, ilr1, trap1);
+            term1 = ex1;
+        }
+        // suffix sums over the bins, c_a = sum_{m >= j_a} ex[m]: a prefix sum over the reversed lanes
+        const double S = wave_prefix_sum(ex0 + ex1);  // bins of this lane and of every lane below (= higher j)
+        double c1 = from_lane_below(S) + ex1;
+        double c0 = c1 + ex0;
+        if (j_split > 0) {  // below the split the Thomson CDF applies, shifted to join continuously
+            const double dsel = (j_split & 1) ? (c1 - cth1) : (c0 - cth0);
+            const double delta = read_lane(dsel, 63 - (j_split >> 1));
+            if (j0 < j_split) c0 = cth0 + delta;
+            if (j1 < j_split) c1 = cth1 + delta;
+        }
+        cdf0 = read_lane(c0, 63);
+        T0 = c1 + term0;
+        T1 = from_lane_below(c0) + term1;
+    };
+#ifdef VAG_IC_ABLATE
+    if (VAG_IC_ABLATE >= 1) g_size = 0;
+#endif
+    constexpr int U = 4;  // electron energies per exchange round: four independent dependency chains in flight
+    for (int ib = 0; ib < g_size; ib += U) {
+        double dNe_u[U], cdf0_u[U];
+        bool live[U];
+        if (KN) __syncthreads();  // the rows below are still being read by the previous round
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int kk = lane + 64 * s;
-            if (kk < n_ic) {
-                const long n = n_off + 2L * kk;
-                if (n < 0) {
-                    I_acc[s] += dNe * cdf0;
-                } else if (n < ns_top) {
-                    const int j = (int)(n >> 1);
-                    const int fi = (int)(n & 1);
-                    const double nu_l = sh.nu[j], dn = sh.dnu[j];
-                    const double f_lo = fvp[j], f_hi = fvp[j + 1];
-                    const double frac = fi ? (nu_l * expq1 - nu_l) / dn : (nu_l * 1.0 - nu_l) / dn;
-                    const double rem = 1.0 - frac;
-                    const double f_seed = f_lo * rem + f_hi * frac;
-                    I_acc[s] += dNe * (cdfp[j + 1] + 0.5 * (f_seed + f_hi) * rem * dn * ratp[j]);
+        for (int u = 0; u < U; ++u) {
+            const int i = ib + u;
+            dNe_u[u] = i < g_size ? read_lane(my_dNe, i) : 0.0;
+            live[u] = dNe_u[u] > 0;  // uniform
+            cdf0_u[u] = cdf0_th;
+            if (KN && live[u]) {
+                double T0, T1;
+                kn_terms(i, T0, T1, cdf0_u[u]);
+                if (bin0) sh.T[u][j0] = T0;
+                if (bin1) sh.T[u][j1] = T1;
+            }
+        }
+        if (KN) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u] || cdf0_u[u] <= 0) continue;  // uniform
+            const double* Trow = KN ? sh.T[u] : sh.ex;
+            const int jb = n_lo_i - 2 * (ib + u) + lane;
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int kk = lane + 64 * s3;
+                const int jo = jb + 64 * s3;
+                if (kk < n_ic) {
+                    if (jo < 0)
+                        I_acc[s3] += dNe_u[u] * cdf0_u[u];
+                    else if (jo < nu_last)
+                        I_acc[s3] += dNe_u[u] * Trow[jo];
                 }
             }
         }
