@@ -549,3 +549,19 @@ def test_rs_series_band_loglike_model_api_and_batch(eng, oracle):
         model = oracle.flux_density(q, f._all_t, f._all_nu)
         chi2 = np.sum(f._all_weights * ((np.log(model) - f._all_log_flux) / f._all_log_err) ** 2)
         assert abs(ll[w] - (-0.5 * chi2)) <= 1e-5 * max(1.0, abs(chi2)), (w, ll[w], -0.5 * chi2)
+
+
+def test_end_to_end_mcmc_on_the_device_likelihood(eng, oracle):
+    """Affine-invariant MCMC (vegasafterglow_amd/sampling.py) on the C4 mock problem: every half-step is one
+    vag_loglike_batch call; the chain must climb to the truth's likelihood level and stay inside the prior box."""
+    from vegasafterglow_amd import sampling
+    f, defs = _c4_fitter(oracle)
+    _, lo, hi = f.build_spec(defs)
+    truth = np.array([np.log10(configs.C4_TRUTH[{"theta_v": "theta_obs"}.get(n, n)]) if lg
+                      else configs.C4_TRUTH[{"theta_v": "theta_obs"}.get(n, n)] for n, lg, _, _ in configs.C4_FREE])
+    ll_truth = f.loglike_batch(truth[None, :], defs)[0]
+    res = sampling.fit(f, defs, nwalkers=32, nsteps=40, nburn=20, seed=1, center=truth + 0.05 * (hi - lo), spread=0.02)
+    assert res["samples"].shape == (20 * 32, len(defs)) and np.all(np.isfinite(res["log_prob"]))
+    assert np.all(res["samples"] >= lo) and np.all(res["samples"] <= hi)
+    assert res["log_prob"].max() > ll_truth - 40  # started ~5 % of the box away; walked back toward the truth
+    assert res["chain"][-1].std(axis=0).min() > 0 and 0.05 < res["acceptance"].mean() < 0.95
