@@ -40,6 +40,7 @@ constexpr double LOG2E = 1.442695040888963407359924681001892137;
 constexpr double SQRT3 = 1.732050807568877293527446341505872367;
 
 VAG_DEV double exp2_fast(double x);
+VAG_DEV double exp2_sat(double x);
 VAG_DEV double log2_fast(double x);
 VAG_DEV double dmin(double a, double b) { return b < a ? b : a; }
 VAG_DEV double dmax(double a, double b) { return a < b ? b : a; }
@@ -232,7 +233,7 @@ struct Dopri5 {
                 err = dmax(err, fabs(xe) / (eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
             }
             if (err > 1.0) {
-                dt = h * dmax(9.0 / 10.0 * exp2_fast(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
+                dt = h * dmax(9.0 / 10.0 * exp2_sat(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
                 continue;
             }
 #pragma unroll
@@ -387,7 +388,7 @@ struct FwdShock {
             const double gamma_bar = gamma_c_coeff / (e_th * t_comv);
             const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
             const double ratio = gamma_m / gamma_c;
-            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_fast((p - 2) * log2_fast(ratio)) : eps_e_eff;
+            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
         }
         const double inv_G = 1 / Gamma;
         const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
@@ -677,8 +678,7 @@ VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
 
 // 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
 // 3.3e-16) + ldexp.  Large |x| (and +-inf) saturate through v_ldexp_f64 (0 / inf) exactly like exp2.
-VAG_DEV double exp2_fast(double x) {
-    x = dmin(dmax(x, -1100.0), 1100.0);  // +-inf must saturate (0 / inf) instead of producing inf - inf; NaN passes through
+VAG_DEV double exp2_fast(double x) {  // finite x only: +-inf would give inf - inf in the range reduction (see exp2_sat)
     const double n = rint(x);
     const double f = x - n;
     // Estrin scheme over 13 coefficients
@@ -694,6 +694,10 @@ VAG_DEV double exp2_fast(double x) {
     const double p = fma(q8c, f8, q07);
     return ldexp(p, (int)n);
 }
+
+// exp2_fast for arguments that may be +-inf (log2 of 0 / overflowed ratios in the ODE right-hand sides and the IC
+// corrections): saturates to 0 / inf like exp2; NaN passes through.
+VAG_DEV double exp2_sat(double x) { return exp2_fast(dmin(dmax(x, -1100.0), 1100.0)); }
 
 // log2(x) for positive, finite, normal x (the EAT step only sees such values; anything else is routed to the
 // library log2).  Exponent/mantissa split around sqrt(2), s = f/(2+f), degree-14 even polynomial in s with the

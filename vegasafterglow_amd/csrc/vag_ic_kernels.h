@@ -180,7 +180,7 @@ VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const Spec
             z = qv[VQ_C1 * qst] + qv[VQ_S1 * qst] * lg;
         // log2(1 + 2^z) without the reference's +-20 softplus shortcut (this term is an exact log2 there)
         const double a = fabs(z);
-        const double g = a > 20.0 ? exp2_fast(-a) * LOG2E : (sp_fast(-a, sp));
+        const double g = a > 20.0 ? exp2_sat(-a) * LOG2E : (sp_fast(-a, sp));
         thin += qv[VQ_L1PYC * qst] - (0.5 * (z + a) + g);
     }
     const double lx = lg2_nu - c[VP_LG2_NUM * st];
@@ -390,9 +390,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     for (int j = lane; j < nu_size; j += 64) {
         sh.lg2nu[j] = lg2_nu0 + step * (double)j;
-        sh.nu[j] = exp2_fast(sh.lg2nu[j]);
+        sh.nu[j] = exp2_sat(sh.lg2nu[j]);
     }
-    for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_fast(lg2_g0 + step * (double)i);
+    for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_sat(lg2_g0 + step * (double)i);
     __syncthreads();
     // sample_distributions, inverse-compton.h:371-399
     const double* par = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
@@ -402,11 +402,11 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     for (int i = lane; i < g_size; i += 64) {
         const double gi = sh.gam[i];
         const double dgi = 0.5 * ((i + 1 < g_size ? sh.gam[i + 1] : gi) - (i > 0 ? sh.gam[i - 1] : gi));
-        const double Yg = exp2_fast(icy_lg2_Y(icy, n_cells, c, log2_fast(gi)));
+        const double Yg = exp2_sat(icy_lg2_Y(icy, n_cells, c, log2_fast(gi)));
         sh.dNe[i] = electron_column_den(gi, gamma_m, gamma_c, gamma_M, P.p, regime, column_den, Y_c, Yg) / (gi * gi) * dgi;
     }
     for (int j = lane; j < nu_size; j += 64) {
-        const double I_seed = exp2_fast(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table));
+        const double I_seed = exp2_sat(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table));
         const double f = I_seed / (sh.nu[j] * sh.nu[j]);
         sh.fv_th[j] = f;
         sh.lg2fv[j] = f > 0 ? log2_fast(f) : -INFINITY;
@@ -437,7 +437,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
         const double lg2_base = log2(sh.gam[0]) + sh.lg2nu[0];
         for (int q = lane; q < n_lat; q += 64)
-            compton_correction_pair(exp2_fast(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+            compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
         __syncthreads();
     }
     // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527).

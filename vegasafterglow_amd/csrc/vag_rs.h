@@ -239,7 +239,7 @@ struct PairShock {
                 const double gamma_bar = gamma_c_coeff / (e_th * t_comv);
                 const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
                 const double ratio = gamma_m / gamma_c;
-                eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_fast((p - 2) * log2_fast(ratio)) : eps_e_eff;
+                eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
             }
             double dlnv = 2 * dr / r;
             if (x4 > 0) dlnv += d[RS_X4] / x4;
