@@ -56,6 +56,9 @@ extern "C" {
 #define VAG_FLAG_RVS 4
 #define VAG_FLAG_RVS_SSC 8
 #define VAG_FLAG_RVS_KN 16
+/* jet(..., spreading=True): lateral expansion of the forward shock (forward-shock.tpp:36-40,78-84,110-116), per-row time
+ * lattices and per-cell solid angles (observer.cpp:51-141). */
+#define VAG_FLAG_SPREADING 32
 
 /* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
 #define VAG_MEDIUM_ISM 0

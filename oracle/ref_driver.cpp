@@ -52,19 +52,20 @@ thread_local std::string g_err;
 
 JetVariant make_jet(const vag_model_params& p) {
     // pybind/pymodel.cpp:47-146
+    const bool spreading = (p.flags & VAG_FLAG_SPREADING) != 0;
     switch (p.jet_type) {
         case VAG_JET_TOPHAT:
-            return TophatJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, false, p.duration * unit::sec);
+            return TophatJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, spreading, p.duration * unit::sec);
         case VAG_JET_GAUSSIAN:
-            return GaussianJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, false, p.duration * unit::sec);
+            return GaussianJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, spreading, p.duration * unit::sec);
         case VAG_JET_POWERLAW:
-            return PowerLawJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, p.k_e, p.k_g, false, p.duration * unit::sec);
+            return PowerLawJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, p.k_e, p.k_g, spreading, p.duration * unit::sec);
         case VAG_JET_TWO_COMPONENT: {
             // PyTwoComponentJet (pymodel.cpp:130-146) + convert_unit_jet (pymodel.cpp:188-210)
             Ejecta jet;
             jet.eps_k = math::two_component(p.theta_c, p.theta_w, p.E_iso, p.E_iso_w);
             jet.Gamma0 = math::two_component_plus_one(p.theta_c, p.theta_w, p.Gamma0 - 1, p.Gamma0_w - 1);
-            jet.spreading = false;
+            jet.spreading = spreading;
             jet.T0 = p.duration;
             const auto eps_k_cgs = jet.eps_k;
             jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
@@ -86,7 +87,7 @@ JetVariant make_jet(const vag_model_params& p) {
             Ejecta jet(BinaryFunc([=](Real, Real theta) { return theta <= theta_c ? E_iso : 0.0; }),
                        BinaryFunc([=](Real, Real theta) { return theta <= theta_c ? Gamma0 : 1.0; }),
                        BinaryFunc([=](Real, Real) { return sigma0; }), TernaryFunc(func::zero_3d), TernaryFunc(func::zero_3d),
-                       false, p.duration);
+                       spreading, p.duration);
             const auto eps_k_cgs = jet.eps_k;
             jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
             const auto deps_dt_cgs = jet.deps_dt;

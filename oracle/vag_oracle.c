@@ -107,6 +107,7 @@ typedef struct {
     double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w; /* two-component (Ejecta built in CGS) */
     double T0;
     double sigma0; /* constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise */
+    int spreading; /* jet(..., spreading=True) */
 } jet_t;
 
 typedef struct {
@@ -131,6 +132,7 @@ static void jet_init(jet_t* j, const vag_model_params* p) {
     j->Gm1_w = p->Gamma0_w - 1;
     j->T0 = p->duration * U_SEC;
     j->sigma0 = (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT) ? p->sigma0 : 0.0;
+    j->spreading = (p->flags & VAG_FLAG_SPREADING) != 0;
 }
 
 static double jet_eps_k(const jet_t* j, double theta) {
@@ -337,6 +339,7 @@ typedef struct {
     double* t; /* [n_theta][n_t] engine-frame lattice (phi slice 0) */
     int* reps; /* representative theta indices */
     int symmetry, phi_mirrored;
+    int spreading; /* Coord::spreading, mesh.h:92 */
     double theta_view;
 } coord_t;
 
@@ -740,10 +743,16 @@ static void logspace_with_band_refinement(double ts, double t_end, double b_lo, 
     for (size_t k = 0; k < n; ++k) grid[k] = pow(10.0, grid[k]);
 }
 
-/* Coord::detect_symmetry, src/core/mesh.h:121-187 (non-spreading, isotropic medium) */
+/* Coord::detect_symmetry, src/core/mesh.h:121-187 (isotropic medium) */
 static void detect_symmetry(coord_t* c, const jet_t* jet) {
     c->reps = malloc(sizeof(int) * c->n_theta);
     c->n_reps = 0;
+    c->spreading = jet->spreading;
+    if (jet->spreading) { /* every row evolves on its own: Symmetry::structured */
+        for (int j = 0; j < c->n_theta; ++j) c->reps[c->n_reps++] = j;
+        c->symmetry = SYM_STRUCTURED;
+        return;
+    }
     c->reps[c->n_reps++] = 0;
     for (int j = 1; j < c->n_theta; ++j) {
         const double ta = c->theta[j - 1], tb = c->theta[j];
@@ -792,6 +801,8 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     const double cos_tv = cos(c->theta_view), sin_tv = sin(c->theta_view);
     double min_raw = t_end, min_guarded = t_end, min_cut = t_end, max_ref = 0;
     double* t_dec = malloc(sizeof(double) * nth);
+    double* t_start_row = malloc(sizeof(double) * nth); /* TimeScanResult::t_start / early_t, grid-refinement.h:462-469 */
+    double* early_t_row = malloc(sizeof(double) * nth);
     for (int j = 0; j < nth; ++j) {
         const double b = gamma_to_beta(jet_Gamma0(jet, c->theta[j]));
         const double cos_a = cos(c->theta[j]) * cos_tv + sin(c->theta[j]) * sin_tv * cos(c->phi[0]);
@@ -803,6 +814,8 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
             cut = dmin(cut, 0.01 * jet->T0);
             max_ref = dmax(max_ref, 10.0 * dmax(td, jet->T0));
         }
+        t_start_row[j] = dmax(ts, cut);
+        early_t_row[j] = 0.99 * dmin(ts, cut);
         min_raw = dmin(min_raw, ts);
         min_guarded = dmin(min_guarded, dmax(ts, cut));
         min_cut = dmin(min_cut, cut);
@@ -823,6 +836,23 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     for (int r = 0; r < c->n_reps; ++r) {
         const int j_rep = c->reps[r];
         const int j_end = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
+        if (c->symmetry < SYM_PHI_SYMMETRIC) { /* structured: every row has its own start and early point (:619-625) */
+            const int j = j_rep;
+            if (is_rvs) {
+                const double t_cross_limit = dmax(t_dec[j], jet->T0);
+                logspace_with_cross_refinement(t_start_row[j], t_end, 10 * t_cross_limit, t_num_tot, t_num_base, grid);
+            } else {
+                logspace_with_band_refinement(t_start_row[j], t_end, t_dec[j] / 3, 3 * t_dec[j], t_num_tot, 3.0, grid);
+            }
+            double* row = c->t + (size_t)j * t_num;
+            if (has_early) {
+                row[0] = early_t_row[j];
+                for (size_t k = 0; k < t_num_tot; ++k) row[1 + k] = grid[k];
+            } else {
+                for (size_t k = 0; k < t_num_tot; ++k) row[k] = grid[k];
+            }
+            continue;
+        }
         if (is_rvs) { /* make_time_grid, grid-refinement.h:571-581 */
             const double t_cross_limit = dmax(t_dec[j_rep], jet->T0);
             logspace_with_cross_refinement(min_t_start, t_end, 10 * t_cross_limit, t_num_tot, t_num_base, grid);
@@ -841,6 +871,8 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     }
     free(grid);
     free(t_dec);
+    free(t_start_row);
+    free(early_t_row);
 }
 
 /* auto_grid, src/core/grid-refinement.h:639-706 */
@@ -911,6 +943,7 @@ typedef struct {
     int radiative;
     const jet_t* jet;
     double theta0;
+    double theta_s; /* jet_spreading_edge, grid-refinement.h:113-135 */
 } fwd_eqn_t;
 
 static double radiative_efficiency(const fwd_eqn_t* e, double t_comv, double Gamma_th, double e_th) {
@@ -933,22 +966,42 @@ static void fwd_rhs(const double* s, double* d, double t, void* vctx) {
     const double dr = u * (Gamma + u) * C_C; /* compute_dr_dt(Gamma,u), shock-physics.h:130-132 */
     d[3] = dr;
     d[4] = Gamma + u;
-    d[5] = 0;
+    const int spreading = e->jet->spreading;
+    if (spreading && s[5] < 0.5 * C_PI) { /* compute_dtheta_dt, shock-physics.h:141-145 */
+        const double Q = 7;
+        const double f = 1 / (1 + u * e->theta_s * Q);
+        d[5] = dr / (2 * Gamma * r) * sqrt((2 * u2 + 3) / (4 * u2 + 3)) * f;
+    } else {
+        d[5] = 0;
+    }
+    double sin_theta = 0, cos_theta = 1;
+    if (spreading) {
+        sin_theta = sin(s[5]);
+        cos_theta = cos(s[5]);
+    }
     const double rho = medium_rho(e->med, r);
     d[1] = r * r * rho * dr;
     const double e_th = (Gamma - 1) * 4 * Gamma * rho * C_C2;
     const double eps_rad = radiative_efficiency(e, t_comv, Gamma, e_th);
     const double ad_idx = adiabatic_idx(Gamma);
-    /* compute_dGamma_dt, forward-shock.tpp:62-101 (non-spreading) */
+    /* compute_dGamma_dt, forward-shock.tpp:62-101 */
     {
-        const double dm_dt_swept = d[1];
-        const double m_swept = m2;
+        double dm_dt_swept = d[1];
+        double m_swept = m2;
         const double Gamma2 = Gamma * Gamma;
         const double Gamma_eff = (ad_idx * (Gamma2 - 1) + 1) / Gamma;
         const double dGamma_eff = (ad_idx * (Gamma2 + 1) - 1) / Gamma2;
-        const double dlnVdt = 3 / r * dr;
+        double dlnVdt = 3 / r * dr;
         const double m_jet = e->m_jet0;
-        const double U = U2_th;
+        double U = U2_th;
+        if (spreading) {
+            const double dOmega0 = 1 - cos(e->theta0);
+            const double f_spread = (1 - cos_theta) / dOmega0;
+            dm_dt_swept = dm_dt_swept * f_spread + m_swept / dOmega0 * sin_theta * d[5];
+            m_swept *= f_spread;
+            dlnVdt += sin_theta / (1 - cos_theta) * d[5];
+            U *= f_spread;
+        }
         const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_dt_swept;
         const double a2 = (ad_idx - 1) * Gamma_eff * U * dlnVdt;
         const double b1 = (m_jet + m_swept) * C_C2;
@@ -957,8 +1010,14 @@ static void fwd_rhs(const double* s, double* d, double t, void* vctx) {
     }
     /* compute_dU_dt, forward-shock.tpp:103-118 */
     {
-        const double dm_dt_swept = d[1];
-        const double dlnVdt = 3 / r * dr - d[0] / Gamma;
+        double dm_dt_swept = d[1];
+        double dlnVdt = 3 / r * dr - d[0] / Gamma;
+        if (spreading) {
+            const double factor = sin_theta / (1 - cos_theta) * d[5];
+            dm_dt_swept = dm_dt_swept + m2 * factor;
+            dlnVdt += factor;
+            dlnVdt += factor / (ad_idx - 1);
+        }
         d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm_dt_swept - (ad_idx - 1) * dlnVdt * U2_th;
     }
 }
@@ -1116,15 +1175,35 @@ static int grid_solve_fwd_shock(int j, const double* t, int nt, shock_t* sh, con
 }
 
 /* generate_fwd_shock + Shock::broadcast_groups: forward-shock.tpp:210-236, shock.cpp:42-91 */
+/* jet_spreading_edge, grid-refinement.h:113-135 */
+static double jet_spreading_edge(const jet_t* jet, double theta_min, double theta_max) {
+    const double step = (theta_max - theta_min) / 256;
+    double theta_s = theta_min;
+    double dp_min = 0;
+    for (double theta = theta_min; theta <= theta_max; theta += step) {
+        const double th_lo = dmax(theta - step, theta_min);
+        const double th_hi = dmin(theta + step, theta_max);
+        const double dp = (jet_Gamma0(jet, th_hi) - jet_Gamma0(jet, th_lo)) / (th_hi - th_lo);
+        if (dp < dp_min) {
+            dp_min = dp;
+            theta_s = theta;
+        }
+    }
+    if (dp_min == 0) theta_s = theta_max;
+    return theta_s;
+}
+
 static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med, const jet_t* jet,
                               const vag_model_params* p) {
     shock_alloc(sh, c->n_theta, c->n_t);
+    const double theta_s = jet->spreading ? jet_spreading_edge(jet, c->theta[0], c->theta[c->n_theta - 1]) : 0;
     for (int r = 0; r < c->n_reps; ++r) {
         const int j = c->reps[r];
         fwd_eqn_t e;
         e.med = med;
         e.jet = jet;
         e.theta0 = c->theta[j];
+        e.theta_s = theta_s;
         e.m_jet0 = jet_eps_k(jet, e.theta0) / jet_Gamma0(jet, e.theta0) / C_C2;
         if (jet->type >= VAG_JET_TWO_COMPONENT) e.m_jet0 /= 1 + jet->sigma0;
         e.radiative = p->radiative_fireball != 0;
@@ -1706,6 +1785,66 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
         const int last = eff_phi - 1;
         for (int i = 0; i < eff_phi; ++i)
             dphi[i] = 0.5 * (c->phi[i + 1 < last ? i + 1 : last] - c->phi[i > 0 ? i - 1 : 0]);
+    }
+    if (c->spreading) { /* calc_t_obs + calc_solid_angle + finalize_log_grids (geometry not pre-logged), observer.cpp:51-141,439-454 */
+        const int last = nth - 1;
+        double* dcos = malloc(sizeof(double) * (size_t)nth * nt);
+        for (int j = 0; j < nth; ++j) {
+            const int j_p1 = (j == last) ? last : j + 1;
+            int k_hint_lo = 0, k_hint_hi = 0;
+            for (int k = 0; k < nt; ++k) {
+                const double t_target = c->t[(size_t)j * nt + k];
+                double th_lo, th_hi;
+#define INTERP_THETA_(j_nb, hint, out)                                                                          \
+    do {                                                                                                        \
+        const double* tn = c->t + (size_t)(j_nb) * nt;                                                          \
+        const double* thn = sh->theta + (size_t)(j_nb) * nt;                                                    \
+        while ((hint) + 1 < nt && tn[(hint) + 1] < t_target) (hint)++;                                          \
+        if ((hint) + 1 >= nt) {                                                                                 \
+            (out) = thn[nt - 1];                                                                                \
+        } else {                                                                                                \
+            const double w = (t_target - tn[hint]) / (tn[(hint) + 1] - tn[hint]);                               \
+            (out) = thn[hint] + w * (thn[(hint) + 1] - thn[hint]);                                              \
+        }                                                                                                       \
+    } while (0)
+                const double th_jk = sh->theta[(size_t)j * nt + k];
+                if (j == 0) {
+                    th_lo = th_jk;
+                } else {
+                    double nb;
+                    INTERP_THETA_(j - 1, k_hint_lo, nb);
+                    th_lo = 0.5 * (th_jk + nb);
+                }
+                if (j == last) {
+                    th_hi = th_jk;
+                } else {
+                    double nb;
+                    INTERP_THETA_(j_p1, k_hint_hi, nb);
+                    th_hi = 0.5 * (th_jk + nb);
+                }
+#undef INTERP_THETA_
+                dcos[(size_t)j * nt + k] = cos(th_hi) - cos(th_lo);
+            }
+        }
+        for (int i = 0; i < eff_phi; ++i) {
+            const double cos_phi = cos(c->phi[i] - 0.0);
+            for (int j = 0; j < nth; ++j)
+                for (int k = 0; k < nt; ++k) {
+                    const size_t s = (size_t)j * nt + k;
+                    const size_t q = ((size_t)i * nth + j) * nt + k;
+                    const double gamma_ = sh->Gamma[s], r = sh->r[s];
+                    const double cos_v = sin(sh->theta[s]) * cos_phi * sin_obs + cos(sh->theta[s]) * cos_obs;
+                    const double dop_lin = gamma_ - sqrt((gamma_ - 1) * (gamma_ + 1)) * cos_v;
+                    const double time = (c->t[s] + (1 - cos_v) * r / C_C) * o->one_plus_z;
+                    const double dOmega = fabs(dcos[s] * dphi[i]);
+                    o->lg2_doppler[q] = -log2(dop_lin);
+                    o->lg2_t[q] = log2(time);
+                    o->lg2_geom[q] = log2(dOmega * r * r) + 3.0 * o->lg2_doppler[q];
+                }
+        }
+        free(dcos);
+        free(dphi);
+        return;
     }
     double* lg2_r2 = malloc(sizeof(double) * (size_t)nth * nt);
     for (size_t q = 0; q < (size_t)nth * nt; ++q) lg2_r2[q] = 2.0 * log2(sh->r[q]);
@@ -2831,7 +2970,7 @@ int vag_oracle_params_validate(const vag_model_params* p) {
         if (!(isfinite(p->rvs_p) && p->rvs_p > 1.0)) return fail("rvs p must be > 1");
         if (!finite_pos(p->duration)) return fail("duration must be positive and finite");
     }
-    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN))
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING))
         return fail("unknown bits set in flags");
     if (!(isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return fail("rtol must be in (0, 1)");
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))

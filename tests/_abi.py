@@ -49,7 +49,8 @@ class DetailsOut(C.Structure):
 def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=300.0, k_e=2.0, k_g=2.0,
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
-                xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None, sigma0=0.0):
+                xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None, sigma0=0.0,
+                spreading=False):
     # rvs = dict(eps_e, eps_B, p[, xi_e, ssc, kn]) mirrors Model(rvs_rad=Radiation(...)); the default resolutions are
     # mode-aware like the reference's Model ctor (pybind/pymodel.h:630-637)
     """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
@@ -67,7 +68,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
     q.rtol = rtol
     q.sigma0 = sigma0
     q.radiative_fireball = 1 if radiative_fireball else 0
-    q.flags = (1 if ssc else 0) | (2 if kn else 0)
+    q.flags = (1 if ssc else 0) | (2 if kn else 0) | (32 if spreading else 0)
     if rvs:
         q.flags |= 4 | (8 if rvs.get("ssc") else 0) | (16 if rvs.get("kn") else 0)
         q.rvs_eps_e, q.rvs_eps_B, q.rvs_p, q.rvs_xi_e = rvs["eps_e"], rvs["eps_B"], rvs["p"], rvs.get("xi_e", 1.0)

@@ -69,3 +69,18 @@ RS_CASES = {
                                    rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True)),
                               np.logspace(1, 7, 40), np.array([1e9, 1e14, 1e17, 1e23])),
 }
+
+
+# spreading jets (jet(..., spreading=True)): Symmetry::structured grids, lateral expansion, per-cell solid angles
+SPREAD_CASES = {
+    "tophat_spread_onaxis": dict(spreading=True),
+    "tophat_spread_offaxis": dict(spreading=True, theta_obs=0.2),
+    "gauss_spread": dict(jet="GaussianJet", spreading=True, theta_obs=0.15),
+    "powerlaw_wind_spread": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, spreading=True, theta_obs=0.3),
+    "two_comp_spread": dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, theta_obs=0.15,
+                            spreading=True),
+    "tophat_spread_rs": dict(spreading=True, theta_obs=0.1, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+    "gauss_spread_ssc": dict(jet="GaussianJet", spreading=True, theta_obs=0.15, ssc=True, kn=True),
+}
+SPREAD_T = np.logspace(2, 8, 40)
+SPREAD_NU = np.array([1e9, 4.84e14, 1e18])

@@ -33,6 +33,9 @@ def main_rs(ref):
             out[f"{name}__{cname}"] = a
         out[f"{name}__total"] = ref.flux_density_grid(prm, t, nu)
         meta[name] = json.loads(json.dumps(kw, default=list))
+    for name in ("tophat_spread_offaxis", "gauss_spread"):  # spreading jets
+        prm = _abi.make_params(**configs.SPREAD_CASES[name])
+        out[f"{name}__total"] = ref.flux_density_grid(prm, configs.SPREAD_T, configs.SPREAD_NU)
     kw, t, nu = configs.RS_CASES["rs_thick_offaxis"]
     prm = _abi.make_params(**kw)
     ts, nus = np.repeat(t, 2), np.tile(nu[[0, 2]], t.size)

@@ -565,3 +565,40 @@ def test_end_to_end_mcmc_on_the_device_likelihood(eng, oracle):
     assert np.all(res["samples"] >= lo) and np.all(res["samples"] <= hi)
     assert res["log_prob"].max() > ll_truth - 40  # started ~5 % of the box away; walked back toward the truth
     assert res["chain"][-1].std(axis=0).min() > 0 and 0.05 < res["acceptance"].mean() < 0.95
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Spreading jets: jet(..., spreading=True)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(configs.SPREAD_CASES))
+def test_spreading_components_match_oracle(eng, oracle, name):
+    prm = _abi.make_params(**configs.SPREAD_CASES[name])
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    want = oracle.flux_components4(prm, t, nu)
+    got = gpu_components4(eng, prm, t, nu)
+    for g, w, comp in zip(got, want, COMPONENTS):
+        if w.max() == 0:
+            assert np.all(g[0] == 0), comp
+        else:
+            assert_close(g[0], w, rtol=5e-6)
+    ts, nus = np.repeat(t, 2), np.tile(nu[[0, 2]], t.size)
+    assert_close(gpu_series(eng, prm, ts, nus)[0], oracle.flux_density(prm, ts, nus), rtol=5e-6)
+
+
+def test_spreading_model_api_batch_and_vectors(eng, oracle):
+    v = np.load(os.path.join(GOLDEN, "reference_vectors_rs.npz"))
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    m = va.Model(va.GaussianJet(0.1, 1e52, 300.0, spreading=True), va.ISM(1.0), va.Observer(1e28, 1.0, 0.15),
+                 va.Radiation(0.1, 0.01, 2.3))
+    assert m.params.flags == 32
+    got = m.flux_density_grid(t, nu).total
+    assert within_contract(got, v["gauss_spread__total"])
+    assert_close(got, v["gauss_spread__total"], rtol=1e-4, floor=1e-3)
+    d = m.details(t.min(), t.max())
+    assert d["shape"]["symmetry"] == 0 and d["shape"]["n_reps"] == d["shape"]["n_theta"]
+    names = ["tophat_spread_onaxis", "tophat_spread_offaxis", "two_comp_spread"]
+    prms = [_abi.make_params(**configs.SPREAD_CASES[n]) for n in names]
+    batch = gpu_grid(eng, prms, t, nu)
+    for i, p in enumerate(prms):
+        assert np.array_equal(batch[i], gpu_grid(eng, p, t, nu)[0])
+        assert_close(batch[i], oracle.flux_density_grid(p, t, nu), rtol=5e-6)

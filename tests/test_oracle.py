@@ -349,3 +349,38 @@ def test_oracle_rs_validation_and_zero_rs_limit(oracle):
     assert (prm.phi_resol, prm.theta_resol, prm.t_resol) == (0.06, 0.2, 10.0)
     with pytest.raises(ValueError):
         oracle.details(_abi.make_params(), 1e2, 1e6, rvs=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Spreading jets: jet(..., spreading=True)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(configs.SPREAD_CASES))
+def test_oracle_spreading_bit_identical_to_strict_reference_build(oracle, ref_strict, name):
+    prm = _abi.make_params(**configs.SPREAD_CASES[name])
+    assert prm.flags & 32
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    for a, b in zip(oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)):
+        assert np.array_equal(a, b)
+    ts, nus = np.repeat(t, 2), np.tile(nu[[0, 2]], t.size)
+    assert np.array_equal(oracle.flux_density(prm, ts, nus), ref_strict.flux_density(prm, ts, nus))
+    da, db = oracle.details(prm, t.min(), t.max()), ref_strict.details(prm, t.min(), t.max())
+    assert da["shape"]["symmetry"] == 0 and da["shape"]["n_reps"] == da["shape"]["n_theta"]  # Symmetry::structured
+    for k in ("theta", "t_src", "Gamma", "r", "B", "N_p"):
+        assert np.array_equal(da[k], db[k], equal_nan=True), k
+    for k in ("lg2_t", "lg2_doppler", "lg2_geom"):  # a handful of cells differ in the last bit (sin / cos of the evolved theta)
+        np.testing.assert_allclose(da[k], db[k], rtol=0, atol=1e-10, err_msg=k)
+
+
+def test_oracle_spreading_physics_and_committed_vectors(oracle, rs_vectors):
+    """Lateral expansion steepens the post-jet-break decay and leaves the early light curve alone."""
+    t, nu = np.logspace(2, 8, 13), np.array([4.84e14])
+    spread = oracle.flux_density_grid(_abi.make_params(spreading=True), t, nu)[0]
+    plain = oracle.flux_density_grid(_abi.make_params(), t, nu)[0]
+    ratio = spread / plain
+    assert 0.9 < ratio[0] < 1.05 and ratio[-1] < 0.2 and np.all(np.diff(ratio[4:]) < 0)
+    for name in ("tophat_spread_offaxis", "gauss_spread"):
+        prm = _abi.make_params(**configs.SPREAD_CASES[name])
+        got = oracle.flux_density_grid(prm, configs.SPREAD_T, configs.SPREAD_NU)
+        want = rs_vectors[f"{name}__total"]
+        assert np.all(np.abs(got - want) <= RTOL * np.abs(want) + ATOL_PEAK * np.abs(want).max())
+        assert rel_bright(got, want, 1e-3) < 1e-4

@@ -13,7 +13,7 @@ JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
-FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN = 1, 2, 4, 8, 16  # VAG_FLAG_* of include/vegasafterglow_amd.h
+FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING = 1, 2, 4, 8, 16, 32  # VAG_FLAG_* of include/vegasafterglow_amd.h
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
 PARAM_SLOTS = {

@@ -158,7 +158,7 @@ static const char* validate_msg(const vag_model_params* p) {
     if (!(std::isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return "rtol must be in (0, 1)";
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
         return "resolutions must be positive and finite";
-    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN))
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING))
         return "unknown bits set in flags";
     if (p->flags & VAG_FLAG_RVS) {  // rvs_rad is a Radiation too (pymodel.h:241-260)
         if (!range_oi(p->rvs_eps_e, 0.0, 1.0)) return "rvs eps_e must be in (0, 1]";
@@ -226,6 +226,7 @@ struct vag_ctx {
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
     // flux passes always read d_shock, d_cellpar, ...; select_emitter() swaps the reverse shock's buffers in and out.
     DevBuf d_shock_r, d_cellpar_r, d_celldet_r, d_icy_r, d_cellq_r, d_params_rvs, d_inj, d_comp;
+    DevBuf d_cellgeo;  // spreading jets (VAG_FLAG_SPREADING): per-cell cos/sin(theta), log2|dcos|, shared by both shocks
     int cur_emitter = 0;                            // 0 forward, 1 reverse
     bool cur_ssc = false;                           // SSC switch of the selected emitter
     const vag_model_params* cur_params = nullptr;   // parameters its radiation / flux kernels read
@@ -318,7 +319,13 @@ int vag_ctx_create(int device, vag_ctx** out) {
     for (const void* fn : {reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<true, FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC>),
-                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC>)})
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN, true>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC, true>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC, true>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, true>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, true>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, true>)})
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {   // Klein-Nishina cross-section table (ComptonSigmaLUT, src/radiation/inverse-compton.cpp:285-300): request-independent
         std::vector<double> lut(2 * KN_LUT_N);
@@ -363,7 +370,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
-                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -468,7 +475,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
     if (c->d_phi.ensure(sizeof(double) * (size_t)nb * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_theta.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_geo_th.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_rep_of.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
@@ -546,6 +553,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         return VAG_OK;
     }
     const bool rvs = (c->batch_flags & VAG_FLAG_RVS) != 0;
+    const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
     if (c->d_shock.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
     if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
@@ -559,12 +567,22 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
                            c->d_inj.as<int>(), c->d_row_status.as<int>());
+    } else if (spreading) {
+        hipLaunchKernelGGL(vag_dynamics_kernel<true>, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
     } else {
-        hipLaunchKernelGGL(vag_dynamics_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+        hipLaunchKernelGGL(vag_dynamics_kernel<false>, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
     }
     HIPCHK(hipGetLastError());
+    if (spreading) {  // per-cell viewing geometry from the evolved theta (both shocks ride the same contact discontinuity)
+        if (c->d_cellgeo.ensure(sizeof(double) * (size_t)cells * 3)) return VAG_E_HIP;
+        hipLaunchKernelGGL(vag_spread_geo_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellgeo.as<double>());
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev[2], st));
     c->cur_emitter = 0;
     c->cur_params = d_params;
@@ -633,7 +651,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();
     a.ic_status = c->d_icstatus.as<int>();
-    if (c->count_work && mode == FLUX_SYN) {
+    a.cellgeo = c->d_cellgeo.as<double>();
+    const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
+    if (c->count_work && mode == FLUX_SYN && !spreading) {
         if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
         HIPCHK(hipMemsetAsync(c->d_workcount.p, 0, 2 * sizeof(unsigned long long), st));
         a.work_count = c->d_workcount.as<unsigned long long>();
@@ -645,7 +665,13 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = ppb;
     if (c->n_rows > 0) {
-        if (mode == FLUX_SYN_IC)
+        if (spreading && mode == FLUX_SYN_IC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (spreading && mode == FLUX_SSC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (spreading)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (mode == FLUX_SYN_IC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         else if (mode == FLUX_SSC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
@@ -687,7 +713,8 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
         hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
                            c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
-                           c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>());
+                           c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
+                           (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
@@ -810,6 +837,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();
     a.ic_status = c->d_icstatus.as<int>();
+    a.cellgeo = c->d_cellgeo.as<double>();
+    const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
     a.geo_th = c->d_geo_th.as<double>();
@@ -830,7 +859,13 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = (int)ppb;
     if (c->n_rows > 0) {
-        if (mode == FLUX_SYN_IC)
+        if (spreading && mode == FLUX_SYN_IC)
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN_IC, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        else if (spreading && mode == FLUX_SSC)
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SSC, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        else if (spreading)
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+        else if (mode == FLUX_SYN_IC)
             hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN_IC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
         else if (mode == FLUX_SSC)
             hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SSC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);

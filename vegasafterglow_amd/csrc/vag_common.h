@@ -64,4 +64,4 @@ enum {
 };
 
 // Shock-state arrays written by the dynamics kernel (Shock, src/dynamics/shock.h:26-88), SoA over cells.
-enum { VS_TENG = 0, VS_TCOMV, VS_R, VS_GAMMA, VS_GAMMA_TH, VS_B, VS_NP, VAG_NSHOCK };
+enum { VS_TENG = 0, VS_TCOMV, VS_R, VS_GAMMA, VS_GAMMA_TH, VS_B, VS_NP, VS_THETA /* spreading jets only */, VAG_NSHOCK };

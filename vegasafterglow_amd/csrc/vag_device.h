@@ -365,12 +365,14 @@ struct TimeLattice {
 };
 
 // ---- forward-shock blast wave: src/dynamics/forward-shock.tpp:10-173, shock-physics.h ----
+template <bool SPREAD = false>
 struct FwdShock {
     Medium med;
     double m_jet0, gamma_m_coeff, gamma_c_coeff, eps_e_eff, p, eps_B;
+    double theta_s, dOmega0;  // SPREAD: jet_spreading_edge (grid-refinement.h:113-135), 1 - cos(theta0)
 
-    // state [Gamma, m2, U2_th, r, t_comv]; theta is constant for non-spreading jets and its
-    // zero derivative never contributes to the error norm, so it is not integrated.
+    // state [Gamma, m2, U2_th, r, t_comv (, theta)]; theta is constant for non-spreading jets and its zero derivative
+    // never contributes to the error norm, so it is only integrated when the jet spreads (forward-shock.tpp:36-40).
     VAG_DEV void operator()(const double* s, double* d, double /*t*/) const {
         const double Gamma = s[0], m2 = s[1], U = s[2], r = s[3], t_comv = s[4];
         const double u2 = (Gamma - 1) * (Gamma + 1);
@@ -378,6 +380,16 @@ struct FwdShock {
         const double dr = u * (Gamma + u) * C_C;
         d[3] = dr;
         d[4] = Gamma + u;
+        const double inv_G = 1 / Gamma;
+        double dth = 0, sin_th = 0, cos_th = 1;
+        if constexpr (SPREAD) {
+            const double theta = s[5];
+            if (theta < 0.5 * C_PI)  // compute_dtheta_dt, shock-physics.h:141-145
+                dth = dr / (2 * Gamma * r) * sqrt((2 * u2 + 3) / (4 * u2 + 3)) * (1 / (1 + u * theta_s * 7));
+            d[5] = dth;
+            sin_th = sin(theta);
+            cos_th = cos(theta);
+        }
         const double rho = medium_rho(med, r);
         const double dm = r * r * rho * dr;
         d[1] = dm;
@@ -390,20 +402,34 @@ struct FwdShock {
             const double ratio = gamma_m / gamma_c;
             eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
         }
-        const double inv_G = 1 / Gamma;
         const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
         const double Gamma2 = Gamma * Gamma;
         const double Gamma_eff = (ad * (Gamma2 - 1) + 1) * inv_G;
         const double dGamma_eff = (ad * (Gamma2 + 1) - 1) * (inv_G * inv_G);
-        const double dlnV = 3 / r * dr;
-        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm;
-        const double a2 = (ad - 1) * Gamma_eff * U * dlnV;
-        const double b1 = (m_jet0 + m2) * C_C2;
-        const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * U;
+        double dlnV = 3 / r * dr;
+        double dm_swept = dm, m_swept = m2, Ueff = U;
+        if constexpr (SPREAD) {  // compute_dGamma_dt, forward-shock.tpp:77-84
+            const double f_spread = (1 - cos_th) / dOmega0;
+            dm_swept = dm * f_spread + m2 / dOmega0 * sin_th * dth;
+            m_swept = m2 * f_spread;
+            dlnV += sin_th / (1 - cos_th) * dth;
+            Ueff = U * f_spread;
+        }
+        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_swept;
+        const double a2 = (ad - 1) * Gamma_eff * Ueff * dlnV;
+        const double b1 = (m_jet0 + m_swept) * C_C2;
+        const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * Ueff;
         const double dG = (a1 + a2) / (b1 + b2);
         d[0] = dG;
-        const double dlnV2 = dlnV - dG * inv_G;
-        d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm - (ad - 1) * dlnV2 * U;
+        double dlnV2 = 3 / r * dr - dG * inv_G;
+        double dm_u = dm;
+        if constexpr (SPREAD) {  // compute_dU_dt, forward-shock.tpp:109-115
+            const double factor = sin_th / (1 - cos_th) * dth;
+            dm_u = dm + m2 * factor;
+            dlnV2 += factor;
+            dlnV2 += factor / (ad - 1);
+        }
+        d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm_u - (ad - 1) * dlnV2 * U;
     }
 };
 

@@ -47,7 +47,7 @@ struct GridShared {
     // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
     double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA],
         pj_st[VAG_MAX_THETA];
-    double tdec[VAG_MAX_THETA];
+    double tdec[VAG_MAX_THETA], tstart[VAG_MAX_THETA], tearly[VAG_MAX_THETA];
     int flag[VAG_MAX_THETA];
 };
 
@@ -415,12 +415,14 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         }
     }
 
-    // ---- Coord::detect_symmetry (src/core/mesh.h:121-187): contiguous groups of identical rows ----
+    // ---- Coord::detect_symmetry (src/core/mesh.h:121-187): contiguous groups of identical rows; a spreading jet
+    //      evolves every row on its own (Symmetry::structured) ----
+    const bool spreading = (P.flags & VAG_FLAG_SPREADING) != 0;
     int n_reps = 0;
     {
         for (int j = lane; j < n_theta; j += WAVE) {
             int differs = 1;
-            if (j > 0) {
+            if (j > 0 && !spreading) {
                 const double a = sh.theta[j - 1], b = sh.theta[j];
                 differs = (jet_eps_k(jet, a) != jet_eps_k(jet, b)) || (jet_Gamma0(jet, a) != jet_Gamma0(jet, b));
             }
@@ -438,7 +440,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         }
         __syncthreads();
     }
-    const int symmetry = n_reps == 1 ? VAG_SYM_ISOTROPIC : (n_reps < n_theta ? VAG_SYM_PIECEWISE : VAG_SYM_PHI_SYMMETRIC);
+    const int symmetry = spreading ? VAG_SYM_STRUCTURED
+                                   : (n_reps == 1 ? VAG_SYM_ISOTROPIC : (n_reps < n_theta ? VAG_SYM_PIECEWISE : VAG_SYM_PHI_SYMMETRIC));
 
     // ---- build_time_grid scalars (grid-refinement.h:472-528,594-636); is_rvs = Model(rvs_rad=...) ----
     {
@@ -462,6 +465,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 cut = dmin(cut, 0.01 * T0);
                 max_ref = dmax(max_ref, 10.0 * dmax(td, T0));
             }
+            sh.tstart[j] = dmax(ts, cut);          // TimeScanResult::t_start / early_t (grid-refinement.h:462-469,497-498):
+            sh.tearly[j] = 0.99 * dmin(ts, cut);   // used per row by structured (spreading) grids
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, dmax(ts, cut));
             min_cut = dmin(min_cut, cut);
@@ -496,7 +501,11 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     for (int i = lane; i < n_phi; i += WAVE) g_phi[(size_t)m * VAG_MAX_PHI + i] = sh.phi[i];
     for (int j = lane; j < n_theta; j += WAVE) {
         g_theta[(size_t)m * VAG_MAX_THETA + j] = sh.theta[j];
-        g_tdec[(size_t)m * VAG_MAX_THETA + j] = sh.tdec[j];
+        // lattice scalars per row: [0] t_dec, [1] first regular node, [2] early node.  Symmetric grids share the global
+        // start / early point (build_time_grid, grid-refinement.h:609-626)
+        g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j] = sh.tdec[j];
+        g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = spreading ? sh.tstart[j] : M.t_start;
+        g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = spreading ? sh.tearly[j] : M.t_early;
     }
     // Geometry factors of the equal-arrival-time step that depend on the angular grid only
     // (calc_eat_non_spreading + compute_dphi, src/core/observer.cpp:17-37,143-188): computed once per model

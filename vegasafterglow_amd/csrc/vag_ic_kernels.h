@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(64)
 vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                    const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ g_rep_of,
                    const long long* __restrict__ cell_off, const double* __restrict__ cellpar,
-                   const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][VAG_MAX_TIME] */) {
+                   const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][VAG_MAX_TIME] */,
+                   const double* __restrict__ cellgeo /* spreading jets: [rows][3][n_t], else nullptr */) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -233,13 +234,25 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
     const double lg2_1pz = log2(1 + P.z);
     const int nt = M.n_t;
     const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
+    double cphi_max = -INFINITY, cphi_min = INFINITY;
+    for (int ii = 0; ii < M.n_phi_eff; ++ii) {
+        cphi_max = fmax(cphi_max, gph[ii]);
+        cphi_min = fmin(cphi_min, gph[ii]);
+    }
     for (int k = lane; k < nt; k += 64) {
         double dmin_k = INFINITY, dmax_k = -INFINITY;
         for (int j = 0; j < M.n_theta; ++j) {
             const double* par = cellpar + (cell_off[m] + (long long)rep_of[j] * nt) * VAG_NPAR;
             const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];
-            dmax_k = fmax(dmax_k, -log2(G - u * s_cvmax[j]));
-            dmin_k = fmin(dmin_k, -log2(G - u * s_cvmin[j]));
+            double cvmax = s_cvmax[j], cvmin = s_cvmin[j];
+            if (cellgeo) {  // theta evolves: the extrema over phi of cos_v = sin th cos phi sin_obs + cos th cos_obs per cell
+                const double* geo = cellgeo + (cell_off[m] + (long long)rep_of[j] * nt) * 3;
+                const double ct = geo[k], st = geo[nt + k];
+                cvmax = st * cphi_max * sin_obs + ct * cos_obs;
+                cvmin = st * cphi_min * sin_obs + ct * cos_obs;
+            }
+            dmax_k = fmax(dmax_k, -log2(G - u * cvmax));
+            dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
         }
         band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
         band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = exp2((nu_hi + lg2_1pz) - dmin_k);  // nu_eval_max_k

@@ -29,6 +29,7 @@ VAG_DEV int find_model(const int* off, int nb, int idx) {  // largest m with off
 // (src/dynamics/forward-shock.tpp:175-208) with the lattice generated on the fly, state saved through
 // save_fwd_shock_state (forward-shock.tpp:151-173).  shock[VS_*] are SoA arrays over cells.
 // ------------------------------------------------------------------------------------------------
+template <bool SPREAD>
 __global__ void __launch_bounds__(64)
 vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
@@ -44,10 +45,12 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
-    FwdShock eq;
+    FwdShock<SPREAD> eq;
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
-    const double t_dec = g_tdec[(size_t)m * VAG_MAX_THETA + j];
+    const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
+    const double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
+    const double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
     const int nt = M.n_t;
     double* o_teng = shock + VS_TENG * n_cells + lay.cell_off[m] + (long long)r * nt;
     double* o_tcomv = shock + VS_TCOMV * n_cells + lay.cell_off[m] + (long long)r * nt;
@@ -56,10 +59,11 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     double* o_Gth = shock + VS_GAMMA_TH * n_cells + lay.cell_off[m] + (long long)r * nt;
     double* o_B = shock + VS_B * n_cells + lay.cell_off[m] + (long long)r * nt;
     double* o_Np = shock + VS_NP * n_cells + lay.cell_off[m] + (long long)r * nt;
+    double* o_th = shock + VS_THETA * n_cells + lay.cell_off[m] + (long long)r * nt;  // written for spreading jets only
 
     TimeLattice lat;
-    lat.init(M.t_start, M.t_end, t_dec, M.t_num_tot);
-    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? M.t_early : lat.node(k - 1)) : lat.node(k); };
+    lat.init(t_start_row, M.t_end, t_dec, M.t_num_tot);
+    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? t_early_row : lat.node(k - 1)) : lat.node(k); };
 
     const double Gamma4 = jet_Gamma0(jet, theta0);
     eq.m_jet0 = jet_eps_k(jet, theta0) / Gamma4 / C_C2 / (1 + jet.sigma0);
@@ -68,12 +72,30 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     eq.eps_e_eff = P.radiative_fireball ? P.eps_e : 0;
     eq.p = P.p;
     eq.eps_B = P.eps_B;
+    eq.theta_s = 0;
+    eq.dOmega0 = 1 - cos(theta0);
+    constexpr int NS = SPREAD ? 6 : 5;
+    if constexpr (SPREAD) {  // jet_spreading_edge over [theta.front(), theta.back()], grid-refinement.h:113-135
+        const double th_min = g_theta[(size_t)m * VAG_MAX_THETA], th_max = g_theta[(size_t)m * VAG_MAX_THETA + M.n_theta - 1];
+        const double step = (th_max - th_min) / 256;
+        double theta_s = th_min, dp_min = 0;
+        for (double th = th_min; th <= th_max; th += step) {
+            const double lo = dmax(th - step, th_min), hi = dmin(th + step, th_max);
+            const double dp = (jet_Gamma0(jet, hi) - jet_Gamma0(jet, lo)) / (hi - lo);
+            if (dp < dp_min) {
+                dp_min = dp;
+                theta_s = th;
+            }
+        }
+        eq.theta_s = (dp_min == 0) ? th_max : theta_s;
+    }
 
     const double t_first = node(0);
     const double t_last = node(nt - 1);
     const double t0 = dmin(t_first, dmin(0.1 * U_SEC, 0.1 * t_dec));
     // set_init_state, forward-shock.tpp:120-149
-    double s[5];
+    double s[NS];
+    if constexpr (SPREAD) s[5] = theta0;
     const double beta4 = gamma_to_beta(Gamma4);
     s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
     s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
@@ -90,6 +112,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
             o_Gth[k] = 1;
             o_B[k] = 0;
             o_Np[k] = 0;
+            if constexpr (SPREAD) o_th[k] = theta0;
         }
         row_status[row] = 0;
         return;
@@ -97,7 +120,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     // Shock ctor defaults for nodes never reached (shock.cpp:12-24)
     int k = 0;
     double t_k = t_first;
-    Dopri5<5> st;
+    Dopri5<NS> st;
     st.init(s, t0, 0.01 * t0, P.rtol, eq);
     int status = 0;
     for (int steps = 0; st.t <= t_last;) {
@@ -110,8 +133,9 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
             break;
         }
         while (k < nt && st.t > t_k) {
-            double q[5];
+            double q[NS];
             st.interp(t_k, q);
+            if constexpr (SPREAD) o_th[k] = q[5];
             // save_fwd_shock_state
             const double comp = compression_fwd(q[0]);
             const double rho = medium_rho(eq.med, q[3]);
@@ -136,8 +160,65 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
         o_Gth[k] = 1;
         o_B[k] = 0;
         o_Np[k] = 0;
+        if constexpr (SPREAD) o_th[k] = 0;
     }
     row_status[row] = status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spreading jets: per-cell polar geometry of the equal-arrival-time step (Observer::calc_t_obs +
+// calc_solid_angle, src/core/observer.cpp:51-141): cos / sin of the evolved theta and log2 |cos th_hi - cos th_lo|,
+// where the bin edges are midpoints to the neighbouring rows' theta interpolated at the same engine time.
+// One lane per (row, k) cell; cellgeo is [row][3][n_t].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, const double* __restrict__ shock,
+                      long long n_cells, double* __restrict__ cellgeo) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lay.cell_off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int m = lo;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    const int nt = M.n_t;
+    const long long local = c - lay.cell_off[m];
+    const int j = (int)(local / nt), k = (int)(local % nt);  // structured symmetry: row index == theta index
+    const int last = M.n_theta - 1;
+    const double* teng = shock + VS_TENG * n_cells + lay.cell_off[m];
+    const double* theta = shock + VS_THETA * n_cells + lay.cell_off[m];
+    const double th = theta[(long long)j * nt + k];
+    const double t_target = teng[(long long)j * nt + k];
+    auto interp_theta = [&](int j_nb) {  // theta of row j_nb at engine time t_target (the reference walks a hint forward)
+        const double* tn = teng + (long long)j_nb * nt;
+        const double* thn = theta + (long long)j_nb * nt;
+        // largest h with h == 0 or tn[h] < t_target, capped so that h + 1 exists
+        int a = 0, b = nt - 1;
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (tn[mid] < t_target)
+                a = mid;
+            else
+                b = mid;
+        }
+        int h = a;
+        if (h + 1 < nt && tn[h + 1] < t_target) h = h + 1;
+        if (h + 1 >= nt) return thn[nt - 1];
+        const double w = (t_target - tn[h]) / (tn[h + 1] - tn[h]);
+        return thn[h] + w * (thn[h + 1] - thn[h]);
+    };
+    const double th_lo = (j == 0) ? th : 0.5 * (th + interp_theta(j - 1));
+    const double th_hi = (j == last) ? th : 0.5 * (th + interp_theta(j + 1));
+    double* dst = cellgeo + (lay.cell_off[m] + (long long)j * nt) * 3 + k;
+    dst[0] = cos(th);
+    dst[(long long)nt] = sin(th);
+    dst[2LL * nt] = log2(fabs(cos(th_hi) - cos(th_lo)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,6 +310,7 @@ struct FluxArgs {
     const double* cellq;   // [rows][VAG_NQ][n_t] IC-correction constants of the synchrotron spectrum (MODE 1)
     const double* ictab;   // [cells][IC_STRIDE] SSC tables (MODE 2)
     int* ic_status;        // [nb] bit 2: band-contract breach seen by the SSC flux pass
+    const double* cellgeo; // [rows][3][n_t] per-cell cos(theta), sin(theta), log2|dcos| of a spreading jet (SPREAD kernels)
 };
 
 // photon source of the flux kernels
@@ -258,9 +340,26 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
     }
 }
 
+// Same for a spreading jet (calc_t_obs + calc_solid_angle, observer.cpp:51-141): theta evolves along k, so the viewing
+// cosine and the solid angle are per cell; `geo` = this row's [3][K] block (cos theta, sin theta, log2|dcos|) in L2.
+VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads,
+                            const double* __restrict__ geo, double cos_phi, double sin_obs, double cos_obs, double lg2_dphi,
+                            double one_plus_z, double* __restrict__ s_t, double* __restrict__ s_dop,
+                            double* __restrict__ s_geom) {
+    for (int k = tid; k < K; k += nthreads) {
+        const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+        const double cos_v = geo[K + k] * cos_phi * sin_obs + geo[k] * cos_obs;
+        const double lg2_dop = -log2_fast(G - u * cos_v);
+        const double time = (s_par[VP_TENG * KS + k] + (1 - cos_v) * r / C_C) * one_plus_z;
+        s_dop[k] = lg2_dop;
+        s_t[k] = log2_fast(time);
+        s_geom[k] = ((geo[2 * K + k] + lg2_dphi) + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+    }
+}
+
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
 // MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
-template <bool COUNT, int MODE>
+template <bool COUNT, int MODE, bool SPREAD = false>
 __global__ void __launch_bounds__(FLUX_THREADS, MODE == FLUX_SYN ? 4 : 2)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
@@ -316,10 +415,16 @@ vag_flux_grid_kernel(FluxArgs a) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
         const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
         const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-        const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
-        const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-        const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-        eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
+        if constexpr (SPREAD) {
+            const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K) * 3;
+            eat_row_spread(s_par, KS, K, tid, FLUX_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
+                           s_t + buf * KS, s_dop, s_geom);
+        } else {
+            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+            eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
+        }
     };
     int staged_rep = -1;
     auto stage_row = [&](int pair) {  // block-uniform: (re)load the photon block when the representative row changes
@@ -534,9 +639,10 @@ struct SeriesArgs {
     const double* cellq;  // FLUX_SYN_IC: [cells][FLUX_NQ]
     const double* ictab;  // FLUX_SSC: [cells][FLUX_IC_STRIDE]
     int* ic_status;       // FLUX_SSC: per-model breach flag
+    const double* cellgeo; // SPREAD: [rows][3][n_t] per-cell polar geometry
 };
 
-template <int MODE>
+template <int MODE, bool SPREAD = false>
 __global__ void __launch_bounds__(SERIES_THREADS)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -599,7 +705,11 @@ vag_flux_series_kernel(SeriesArgs a) {
             staged_rep = rep;
             __syncthreads();
         }
-        {
+        if constexpr (SPREAD) {
+            const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
+            eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z, s_t,
+                           s_dop, s_geom);
+        } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];

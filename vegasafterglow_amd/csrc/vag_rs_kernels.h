@@ -45,7 +45,9 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     PairShock eq;
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
-    const double t_dec = g_tdec[(size_t)m * VAG_MAX_THETA + j];
+    const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
+    const double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
+    const double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
     const int nt = M.n_t;
     const long long c0 = lay.cell_off[m] + (long long)r * nt;
     double* F = shock_fwd + c0;
@@ -58,12 +60,13 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
         base[VS_GAMMA_TH * n_cells + k] = Gth;
         base[VS_B * n_cells + k] = B;
         base[VS_NP * n_cells + k] = Np;
+        base[VS_THETA * n_cells + k] = (tcomv == 0 && rr == 0) ? 0.0 : theta0;  // the pair solver never spreads (diff.theta = 0)
     };
 
     const double T0 = P.duration * U_SEC;
     CrossLattice lat;
-    lat.init(M.t_start, M.t_end, t_dec, T0, M.t_num_tot, M.t_num_base);
-    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? M.t_early : lat.node(k - 1)) : lat.node(k); };
+    lat.init(t_start_row, M.t_end, t_dec, T0, M.t_num_tot, M.t_num_base);
+    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? t_early_row : lat.node(k - 1)) : lat.node(k); };
 
     eq.Gamma4 = jet_Gamma0(jet, theta0);
     eq.T0 = T0;

@@ -42,9 +42,10 @@ class TophatJet(_Jet):
         _finite_pos("E_iso", E_iso)
         _req(math.isfinite(Gamma0) and Gamma0 > 1, f"Gamma0 must be > 1, got {Gamma0}")
         _finite_pos("duration", duration)
-        if spreading or magnetar is not None:
-            raise NotImplementedError("spreading jets / magnetar injection are outside the MI355X hot path")
+        if magnetar is not None:
+            raise NotImplementedError("magnetar injection is outside the MI355X hot path")
         self.theta_c, self.E_iso, self.Gamma0, self.duration = float(theta_c), float(E_iso), float(Gamma0), float(duration)
+        self.spreading = bool(spreading)
 
     def _fill(self, p):
         p.jet_type = self.jet_type
@@ -242,6 +243,8 @@ class Model:
         p.rtol = self.rtol
         p.radiative_fireball = 1 if radiative_fireball else 0
         p.flags = (_lib.FLAG_SSC if fwd_rad.ssc else 0) | (_lib.FLAG_KN if fwd_rad.kn else 0)
+        if getattr(jet, "spreading", False):
+            p.flags |= _lib.FLAG_SPREADING
         if rvs_rad is not None:
             p.flags |= _lib.FLAG_RVS | (_lib.FLAG_RVS_SSC if rvs_rad.ssc else 0) | (_lib.FLAG_RVS_KN if rvs_rad.kn else 0)
             p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e = rvs_rad.eps_e, rvs_rad.eps_B, rvs_rad.p, rvs_rad.xi_e
