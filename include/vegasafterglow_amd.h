@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 3
+#define VAG_ABI_VERSION 4
 
 /* error codes */
 #define VAG_OK 0
@@ -47,6 +47,10 @@ extern "C" {
 /* Top-hat profile on the generic Ejecta with a constant magnetisation sigma0 (eps = E_iso, Gamma0 for theta <= theta_c):
  * the jet of the reference's tophat_sigma*_rs goldens (tests/python/golden/regenerate.py:141-149). */
 #define VAG_JET_MAGNETIZED_TOPHAT 4
+/* StepPowerLawJet(theta_c, E_iso, Gamma0, E_iso_w, Gamma0_w, k_e, k_g) and PowerLawWing(theta_c, E_iso_w, Gamma0_w, k_e, k_g):
+ * pybind/pymodel.cpp:90-125, src/environment/jet.h:403-429 */
+#define VAG_JET_STEP_POWERLAW 5
+#define VAG_JET_POWERLAW_WING 6
 
 /* Radiation flags.  VAG_FLAG_SSC / VAG_FLAG_KN = fwd_rad Radiation(ssc=, kn=): inverse-Compton cooling + SSC emission
  * (src/radiation/inverse-compton.*).  VAG_FLAG_RVS = Model(rvs_rad=Radiation(...)) i.e. the coupled forward+reverse
@@ -69,7 +73,7 @@ extern "C" {
  *   Model(jet, medium, Observer(lumi_dist, z, theta_obs), Radiation(eps_e, eps_B, p, xi_e),
  *         resolutions=(phi, theta, t), rtol, axisymmetric=True, radiative_fireball)
  * (pybind/pybind.cpp:384-422, pybind/pymodel.h:613-649), flattened to plain scalars.
- * All doubles; the two tags are int32.  Layout is fixed (240 bytes) and is what the
+ * All doubles; the two tags are int32.  Layout is fixed (248 bytes) and is what the
  * device kernels read straight from HBM.
  */
 typedef struct vag_model_params {
@@ -111,6 +115,7 @@ typedef struct vag_model_params {
     double rvs_p;
     double rvs_xi_e;
     double sigma0; /* ejecta magnetisation, VAG_JET_MAGNETIZED_TOPHAT only (Ejecta(sigma0=...), pybind/pybind.cpp:224-272) */
+    double k_m;    /* Wind density slope rho ~ r^-k_m (pybind/pymodel.cpp:153-186); 2 = the analytic Wind class */
 } vag_model_params;
 
 /* Fill a params struct with the reference's defaults: Radiation xi_e = 1,
@@ -229,6 +234,7 @@ int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, i
 #define VAG_P_RVS_P 26
 #define VAG_P_RVS_XI_E 27
 #define VAG_P_SIGMA0 28
+#define VAG_P_K_M 29
 
 typedef struct vag_fit_spec {
     vag_model_params base; /* fixed parameters + numerics */

@@ -80,6 +80,32 @@ JetVariant make_jet(const vag_model_params& p) {
             jet.T0 *= unit::sec;
             return jet;
         }
+        case VAG_JET_STEP_POWERLAW:
+        case VAG_JET_POWERLAW_WING: {
+            // PyStepPowerLawJet / PyPowerLawWing (pymodel.cpp:90-125) + convert_unit_jet (pymodel.cpp:188-210)
+            Ejecta jet;
+            if (p.jet_type == VAG_JET_STEP_POWERLAW) {
+                jet.eps_k = math::step_powerlaw(p.theta_c, p.E_iso, p.E_iso_w, p.k_e);
+                jet.Gamma0 = math::step_powerlaw_plus_one(p.theta_c, p.Gamma0 - 1, p.Gamma0_w - 1, p.k_g);
+            } else {
+                jet.eps_k = math::powerlaw_wing(p.theta_c, p.E_iso_w, p.k_e);
+                jet.Gamma0 = math::powerlaw_wing_plus_one(p.theta_c, p.Gamma0_w - 1, p.k_g);
+            }
+            jet.spreading = spreading;
+            jet.T0 = p.duration;
+            const auto eps_k_cgs = jet.eps_k;
+            jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
+            const auto deps_dt_cgs = jet.deps_dt;
+            jet.deps_dt = [=](Real phi, Real theta, Real t) {
+                return deps_dt_cgs(phi, theta, t / unit::sec) * (unit::erg / (4 * con::pi * unit::sec));
+            };
+            const auto dm_dt_cgs = jet.dm_dt;
+            jet.dm_dt = [=](Real phi, Real theta, Real t) {
+                return dm_dt_cgs(phi, theta, t / unit::sec) * (unit::g / (4 * con::pi * unit::sec));
+            };
+            jet.T0 *= unit::sec;
+            return jet;
+        }
         case VAG_JET_MAGNETIZED_TOPHAT: {
             // tests/python/golden/regenerate.py:141-149 (_magnetized_tophat) through the Ejecta factory of
             // pybind/pybind.cpp:224-272 and convert_unit_jet (pymodel.cpp:188-210)
@@ -111,7 +137,20 @@ MediumVariant make_medium(const vag_model_params& p) {
         return ISM(p.n_ism / unit::cm3);
     }
     if (p.medium_type == VAG_MEDIUM_WIND) {
-        return Wind(p.A_star, p.n_ism / unit::cm3, p.n0 / unit::cm3);
+        if (p.k_m == 2) return Wind(p.A_star, p.n_ism / unit::cm3, p.n0 / unit::cm3);
+        // general k_m: PyWind's CGS closure (pymodel.cpp:167-185) wrapped by convert_unit_medium (pymodel.cpp:212-224)
+        const Real k_m = p.k_m, n_ism = p.n_ism, n0 = p.n0;
+        constexpr Real r0_cgs = 1e17;
+        const Real mp_cgs = con::mp / unit::g;
+        const Real A_cgs = p.A_star * 5e11 * std::pow(r0_cgs, k_m - 2);
+        const Real rho_ism_cgs = n_ism * mp_cgs;
+        const Real r0k_cgs = A_cgs / (n0 * 1.3 * mp_cgs);
+        Medium medium;
+        medium.rho = [=](Real, Real, Real r) noexcept {
+            return (A_cgs / (r0k_cgs + std::pow(r / unit::cm, k_m)) + rho_ism_cgs) * (unit::g / unit::cm3);
+        };
+        medium.isotropic = true;
+        return medium;
     }
     throw std::invalid_argument("unknown medium_type");
 }

@@ -114,6 +114,8 @@ typedef struct {
     int type;
     double rho_ism; /* ISM: n*mp; Wind: floor */
     double A, r02;  /* Wind */
+    int generic;    /* Wind with k_m != 2: python-level Medium built from a CGS closed form (pymodel.cpp:167-185) */
+    double k_m, A_cgs, r0k_cgs, rho_ism_cgs;
 } medium_t;
 
 static void jet_init(jet_t* j, const vag_model_params* p) {
@@ -142,6 +144,11 @@ static double jet_eps_k(const jet_t* j, double theta) {
         case VAG_JET_POWERLAW: return j->eps_k / (1 + fast_pow(theta / j->theta_c, j->k_e));
         case VAG_JET_MAGNETIZED_TOPHAT: /* Ejecta(E_iso = E if theta <= theta_c else 0) in CGS, then convert_unit_jet */
             return (theta <= j->theta_c ? j->E_iso_cgs : 0.0) * (U_ERG / (4 * C_PI));
+        case VAG_JET_STEP_POWERLAW: /* math::step_powerlaw, jet.h:418-426 */
+            return (theta <= j->theta_c ? j->E_iso_cgs : j->E_iso_w_cgs * fast_pow(theta / j->theta_c, -j->k_e)) *
+                   (U_ERG / (4 * C_PI));
+        case VAG_JET_POWERLAW_WING: /* math::powerlaw_wing, jet.h:403-411 */
+            return (theta <= j->theta_c ? 0. : j->E_iso_w_cgs * fast_pow(theta / j->theta_c, -j->k_e)) * (U_ERG / (4 * C_PI));
         default: { /* math::two_component (jet.h:421-433) in CGS, then convert_unit_jet */
             double h = theta <= j->theta_c ? j->E_iso_cgs : (theta <= j->theta_w ? j->E_iso_w_cgs : 0.);
             return h * (U_ERG / (4 * C_PI));
@@ -155,6 +162,8 @@ static double jet_Gamma0(const jet_t* j, double theta) {
         case VAG_JET_GAUSSIAN: return (j->Gamma0 - 1) * exp(theta * theta * j->norm) + 1;
         case VAG_JET_POWERLAW: return (j->Gamma0 - 1) / (1 + fast_pow(theta / j->theta_c, j->k_g)) + 1;
         case VAG_JET_MAGNETIZED_TOPHAT: return theta <= j->theta_c ? j->Gamma0 : 1.0;
+        case VAG_JET_STEP_POWERLAW: return (theta <= j->theta_c ? j->Gm1 : j->Gm1_w * fast_pow(theta / j->theta_c, -j->k_g)) + 1;
+        case VAG_JET_POWERLAW_WING: return (theta <= j->theta_c ? 0. : j->Gm1_w * fast_pow(theta / j->theta_c, -j->k_g)) + 1;
         default: {
             double h = theta <= j->theta_c ? j->Gm1 : (theta <= j->theta_w ? j->Gm1_w : 0.);
             return h + 1;
@@ -172,16 +181,28 @@ static void medium_init(medium_t* m, const vag_model_params* p) {
         m->A = p->A_star * 5e11 * U_G / U_CM;
         m->rho_ism = n_ism * C_MP;
         m->r02 = m->A / (n0 * 1.3 * C_MP);
+        m->generic = (p->k_m != 2);
+        if (m->generic) { /* CGS closure of PyWind, evaluated through convert_unit_medium (pymodel.cpp:212-224) */
+            const double r0_cgs = 1e17;
+            const double mp_cgs = C_MP / U_G;
+            m->k_m = p->k_m;
+            m->A_cgs = p->A_star * 5e11 * pow(r0_cgs, p->k_m - 2);
+            m->rho_ism_cgs = p->n_ism * mp_cgs;
+            m->r0k_cgs = m->A_cgs / (p->n0 * 1.3 * mp_cgs);
+        }
     }
 }
 
 static double medium_rho(const medium_t* m, double r) {
     if (m->type == VAG_MEDIUM_ISM) return m->rho_ism;
+    if (m->generic) return (m->A_cgs / (m->r0k_cgs + pow(r / U_CM, m->k_m)) + m->rho_ism_cgs) * (U_G / U_CM3);
     return m->A / (m->r02 + r * r) + m->rho_ism;
 }
 
-static double medium_mass(const medium_t* m, double r) {
+static double enclosed_mass_generic(const medium_t* med, double r);
+static double medium_mass(const medium_t* m, double r) { /* enclosed_mass_medium, shock-physics.h:439-446 */
     if (m->type == VAG_MEDIUM_ISM) return m->rho_ism * r * r * r / 3.0;
+    if (m->generic) return enclosed_mass_generic(m, r); /* python-level Medium has no mass(): Simpson in log radius */
     double mass = m->rho_ism * r * r * r / 3.0;
     if (m->A != 0) {
         if (m->r02 > 0) {
@@ -2931,15 +2952,21 @@ static int range_oi(double x, double lo, double hi) { /* (lo, hi] */
 }
 
 int vag_oracle_params_validate(const vag_model_params* p) {
-    if (p->jet_type < 0 || p->jet_type > VAG_JET_MAGNETIZED_TOPHAT) return fail("unknown jet_type");
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_POWERLAW_WING) return fail("unknown jet_type");
     if (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT && !(isfinite(p->sigma0) && p->sigma0 >= 0))
         return fail("sigma0 must be finite and non-negative");
     if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return fail("unknown medium_type");
     if (!range_oi(p->theta_c, 0.0, C_PI / 2)) return fail("theta_c must be in (0, pi/2]");
-    if (!finite_pos(p->E_iso)) return fail("E_iso must be positive and finite");
-    if (!(isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return fail("Gamma0 must be > 1");
+    if (p->jet_type != VAG_JET_POWERLAW_WING) { /* PowerLawWing has no core (pymodel.cpp:90-110) */
+        if (!finite_pos(p->E_iso)) return fail("E_iso must be positive and finite");
+        if (!(isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return fail("Gamma0 must be > 1");
+    }
     if (!finite_pos(p->duration)) return fail("duration must be positive and finite");
-    if (p->jet_type == VAG_JET_POWERLAW) {
+    if (p->jet_type == VAG_JET_STEP_POWERLAW || p->jet_type == VAG_JET_POWERLAW_WING) {
+        if (!finite_pos(p->E_iso_w)) return fail("E_iso_w must be positive and finite");
+        if (!(isfinite(p->Gamma0_w) && p->Gamma0_w > 1.0)) return fail("Gamma0_w must be > 1");
+    }
+    if (p->jet_type == VAG_JET_POWERLAW || p->jet_type == VAG_JET_STEP_POWERLAW || p->jet_type == VAG_JET_POWERLAW_WING) {
         if (!finite_pos(p->k_e)) return fail("k_e must be positive and finite");
         if (!finite_pos(p->k_g)) return fail("k_g must be positive and finite");
     }
@@ -2955,6 +2982,7 @@ int vag_oracle_params_validate(const vag_model_params* p) {
         if (!finite_pos(p->A_star)) return fail("A_star must be positive and finite");
         if (!(isfinite(p->n_ism) && p->n_ism >= 0)) return fail("n_ism must be non-negative and finite");
         if (!(p->n0 > 0)) return fail("n0 must be > 0 (or +inf for no floor)");
+        if (!finite_pos(p->k_m)) return fail("k_m must be positive and finite");
     }
     if (!finite_pos(p->lumi_dist)) return fail("lumi_dist must be positive and finite");
     if (!(isfinite(p->z) && p->z >= 0)) return fail("z must be non-negative and finite");

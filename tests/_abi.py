@@ -12,8 +12,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT = 0, 1, 2, 3, 4
+JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
-JET_IDS = {"TophatJet": 0, "GaussianJet": 1, "PowerLawJet": 2, "TwoComponentJet": 3, "MagnetizedTophat": 4}
+JET_IDS = {"TophatJet": 0, "GaussianJet": 1, "PowerLawJet": 2, "TwoComponentJet": 3, "MagnetizedTophat": 4,
+           "StepPowerLawJet": 5, "PowerLawWing": 6}
 MEDIUM_IDS = {"ISM": 0, "Wind": 1}
 
 
@@ -29,11 +31,11 @@ class ModelParams(C.Structure):
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
         ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
-        ("sigma0", C.c_double),
+        ("sigma0", C.c_double), ("k_m", C.c_double),
     ]
 
 
-assert C.sizeof(ModelParams) == 240
+assert C.sizeof(ModelParams) == 248
 
 
 class DetailsShape(C.Structure):
@@ -50,7 +52,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
                 xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None, sigma0=0.0,
-                spreading=False):
+                spreading=False, k_m=2.0):
     # rvs = dict(eps_e, eps_B, p[, xi_e, ssc, kn]) mirrors Model(rvs_rad=Radiation(...)); the default resolutions are
     # mode-aware like the reference's Model ctor (pybind/pymodel.h:630-637)
     """Flatten Model(jet, medium, Observer, Radiation, resolutions, rtol) keyword arguments."""
@@ -67,6 +69,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
     q.phi_resol, q.theta_resol, q.t_resol = resolutions
     q.rtol = rtol
     q.sigma0 = sigma0
+    q.k_m = k_m
     q.radiative_fireball = 1 if radiative_fireball else 0
     q.flags = (1 if ssc else 0) | (2 if kn else 0) | (32 if spreading else 0)
     if rvs:

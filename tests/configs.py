@@ -84,3 +84,16 @@ SPREAD_CASES = {
 }
 SPREAD_T = np.logspace(2, 8, 40)
 SPREAD_NU = np.array([1e9, 4.84e14, 1e18])
+
+
+# the remaining closed-form profiles of the reference's registry (fitting/config.py:99-137): step power law, power-law wing,
+# and a wind with a general density slope k_m (a generic Medium in the reference)
+PROFILE_CASES = {
+    "step_powerlaw": dict(jet="StepPowerLawJet", theta_c=0.05, E_iso_w=3e51, Gamma0_w=100.0, k_e=3.0, k_g=2.0, theta_obs=0.2),
+    "powerlaw_wing": dict(jet="PowerLawWing", theta_c=0.05, E_iso_w=3e51, Gamma0_w=100.0, k_e=3.0, k_g=2.0, theta_obs=0.2),
+    "step_powerlaw_rs_spread": dict(jet="StepPowerLawJet", theta_c=0.05, E_iso_w=3e51, Gamma0_w=100.0, k_e=3.0, k_g=2.0,
+                                    theta_obs=0.1, spreading=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+    "wind_k1.5": dict(medium="Wind", A_star=0.3, n_ism=0.0, k_m=1.5, theta_obs=0.1),
+    "wind_k2.5_floor": dict(jet="GaussianJet", medium="Wind", A_star=0.1, n_ism=1e-3, n0=1e3, k_m=2.5, theta_obs=0.2),
+    "wind_k1_rs_ssc": dict(medium="Wind", A_star=0.1, n_ism=0.0, k_m=1.0, ssc=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+}

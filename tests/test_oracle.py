@@ -384,3 +384,12 @@ def test_oracle_spreading_physics_and_committed_vectors(oracle, rs_vectors):
         want = rs_vectors[f"{name}__total"]
         assert np.all(np.abs(got - want) <= RTOL * np.abs(want) + ATOL_PEAK * np.abs(want).max())
         assert rel_bright(got, want, 1e-3) < 1e-4
+
+
+@pytest.mark.parametrize("name", list(configs.PROFILE_CASES))
+def test_oracle_remaining_profiles_bit_identical_to_strict_reference_build(oracle, ref_strict, name):
+    """StepPowerLawJet, PowerLawWing and Wind(k_m != 2): closed forms the reference builds on its generic Ejecta / Medium."""
+    prm = _abi.make_params(**configs.PROFILE_CASES[name])
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    a, b = oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].max() > 0

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvegasafterglow_amd.so")
 
 JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT = 0, 1, 2, 3, 4
+JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -21,7 +22,7 @@ PARAM_SLOTS = {
     "tau": 8, "duration": 8, "n_ism": 9, "A_star": 10, "n0": 11, "lumi_dist": 12, "z": 13, "theta_v": 14,
     "theta_obs": 14, "eps_e": 15, "eps_B": 16, "p": 17, "xi_e": 18,
     "eps_e_r": 24, "eps_B_r": 25, "p_r": 26, "xi_e_r": 27,  # VAG_P_RVS_*: rvs_rad of Fitter(rvs_shock=True)
-    "sigma0": 28,
+    "sigma0": 28, "k_m": 29,
 }
 
 
@@ -37,7 +38,7 @@ class ModelParams(C.Structure):
         ("phi_resol", C.c_double), ("theta_resol", C.c_double), ("t_resol", C.c_double), ("rtol", C.c_double),
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
         ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
-        ("sigma0", C.c_double),
+        ("sigma0", C.c_double), ("k_m", C.c_double),
     ]
 
 

@@ -123,15 +123,21 @@ static bool range_oi(double x, double lo, double hi) { return std::isfinite(x) &
 
 static const char* validate_msg(const vag_model_params* p) {
     const double pi = 3.14159265358979323846;
-    if (p->jet_type < 0 || p->jet_type > VAG_JET_MAGNETIZED_TOPHAT) return "unknown jet_type";
+    if (p->jet_type < 0 || p->jet_type > VAG_JET_POWERLAW_WING) return "unknown jet_type";
     if (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT && !(std::isfinite(p->sigma0) && p->sigma0 >= 0))
         return "sigma0 must be finite and non-negative";
     if (p->medium_type < 0 || p->medium_type > VAG_MEDIUM_WIND) return "unknown medium_type";
     if (!range_oi(p->theta_c, 0.0, pi / 2)) return "theta_c must be in (0, pi/2]";
-    if (!finite_pos(p->E_iso)) return "E_iso must be positive and finite";
-    if (!(std::isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return "Gamma0 must be > 1";
+    if (p->jet_type != VAG_JET_POWERLAW_WING) {  // PowerLawWing has no core (pymodel.cpp:90-110)
+        if (!finite_pos(p->E_iso)) return "E_iso must be positive and finite";
+        if (!(std::isfinite(p->Gamma0) && p->Gamma0 > 1.0)) return "Gamma0 must be > 1";
+    }
     if (!finite_pos(p->duration)) return "duration must be positive and finite";
-    if (p->jet_type == VAG_JET_POWERLAW) {
+    if (p->jet_type == VAG_JET_STEP_POWERLAW || p->jet_type == VAG_JET_POWERLAW_WING) {
+        if (!finite_pos(p->E_iso_w)) return "E_iso_w must be positive and finite";
+        if (!(std::isfinite(p->Gamma0_w) && p->Gamma0_w > 1.0)) return "Gamma0_w must be > 1";
+    }
+    if (p->jet_type == VAG_JET_POWERLAW || p->jet_type == VAG_JET_STEP_POWERLAW || p->jet_type == VAG_JET_POWERLAW_WING) {
         if (!finite_pos(p->k_e)) return "k_e must be positive and finite";
         if (!finite_pos(p->k_g)) return "k_g must be positive and finite";
     }
@@ -147,6 +153,7 @@ static const char* validate_msg(const vag_model_params* p) {
         if (!finite_pos(p->A_star)) return "A_star must be positive and finite";
         if (!(std::isfinite(p->n_ism) && p->n_ism >= 0)) return "n_ism must be non-negative and finite";
         if (!(p->n0 > 0)) return "n0 must be > 0 (or +inf for no floor)";
+        if (!finite_pos(p->k_m)) return "k_m must be positive and finite";
     }
     if (!finite_pos(p->lumi_dist)) return "lumi_dist must be positive and finite";
     if (!(std::isfinite(p->z) && p->z >= 0)) return "z must be non-negative and finite";
@@ -272,6 +279,7 @@ void vag_params_default(vag_model_params* p) {
     p->n_ism = 1;
     p->A_star = 0;
     p->n0 = INFINITY;
+    p->k_m = 2;
     p->lumi_dist = 1e28;
     p->z = 0;
     p->theta_obs = 0;
@@ -1234,7 +1242,7 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     const int n = spec->n_data;
     if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
     for (int d = 0; d < ndim; ++d)
-        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_SIGMA0)))
+        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_K_M)))
             return set_err(VAG_E_INVALID, "bad parameter slot");
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");

@@ -70,6 +70,8 @@ struct Jet {
 struct Medium {
     int type;
     double rho_ism, A, r02;
+    int generic;  // Wind with k_m != 2: the python-level Medium built from PyWind's CGS closed form (pymodel.cpp:167-185)
+    double k_m, A_cgs, r0k_cgs, rho_ism_cgs;
 };
 
 VAG_DEV void jet_init(Jet& j, const vag_model_params& p) {
@@ -94,6 +96,10 @@ VAG_DEV double jet_eps_k(const Jet& j, double theta) {
         case VAG_JET_GAUSSIAN: return j.eps_k * exp(theta * theta * j.norm);
         case VAG_JET_POWERLAW: return j.eps_k / (1 + fast_pow(theta / j.theta_c, j.k_e));
         case VAG_JET_MAGNETIZED_TOPHAT: return (theta <= j.theta_c ? j.E_iso_cgs : 0.0) * (U_ERG / (4 * C_PI));
+        case VAG_JET_STEP_POWERLAW:  // math::step_powerlaw, jet.h:418-426
+            return (theta <= j.theta_c ? j.E_iso_cgs : j.E_iso_w_cgs * fast_pow(theta / j.theta_c, -j.k_e)) * (U_ERG / (4 * C_PI));
+        case VAG_JET_POWERLAW_WING:  // math::powerlaw_wing, jet.h:403-411
+            return (theta <= j.theta_c ? 0. : j.E_iso_w_cgs * fast_pow(theta / j.theta_c, -j.k_e)) * (U_ERG / (4 * C_PI));
         default: {
             const double h = theta <= j.theta_c ? j.E_iso_cgs : (theta <= j.theta_w ? j.E_iso_w_cgs : 0.);
             return h * (U_ERG / (4 * C_PI));
@@ -106,6 +112,8 @@ VAG_DEV double jet_Gamma0(const Jet& j, double theta) {
         case VAG_JET_GAUSSIAN: return (j.Gamma0 - 1) * exp(theta * theta * j.norm) + 1;
         case VAG_JET_POWERLAW: return (j.Gamma0 - 1) / (1 + fast_pow(theta / j.theta_c, j.k_g)) + 1;
         case VAG_JET_MAGNETIZED_TOPHAT: return theta <= j.theta_c ? j.Gamma0 : 1.0;
+        case VAG_JET_STEP_POWERLAW: return (theta <= j.theta_c ? j.Gm1 : j.Gm1_w * fast_pow(theta / j.theta_c, -j.k_g)) + 1;
+        case VAG_JET_POWERLAW_WING: return (theta <= j.theta_c ? 0. : j.Gm1_w * fast_pow(theta / j.theta_c, -j.k_g)) + 1;
         default: {
             const double h = theta <= j.theta_c ? j.Gm1 : (theta <= j.theta_w ? j.Gm1_w : 0.);
             return h + 1;
@@ -116,6 +124,9 @@ VAG_DEV void medium_init(Medium& m, const vag_model_params& p) {
     m.type = p.medium_type;
     m.A = 0;
     m.r02 = 0;
+    m.generic = 0;
+    m.k_m = 2;
+    m.A_cgs = m.r0k_cgs = m.rho_ism_cgs = 0;
     if (m.type == VAG_MEDIUM_ISM) {
         m.rho_ism = (p.n_ism / U_CM3) * C_MP;
     } else {
@@ -123,13 +134,36 @@ VAG_DEV void medium_init(Medium& m, const vag_model_params& p) {
         m.A = p.A_star * 5e11 * U_G / U_CM;
         m.rho_ism = n_ism * C_MP;
         m.r02 = m.A / (n0 * 1.3 * C_MP);
+        m.generic = (p.k_m != 2);
+        if (m.generic) {
+            const double mp_cgs = C_MP / U_G;
+            m.k_m = p.k_m;
+            m.A_cgs = p.A_star * 5e11 * pow(1e17, p.k_m - 2);
+            m.rho_ism_cgs = p.n_ism * mp_cgs;
+            m.r0k_cgs = m.A_cgs / (p.n0 * 1.3 * mp_cgs);
+        }
     }
 }
 VAG_DEV double medium_rho(const Medium& m, double r) {
     if (m.type == VAG_MEDIUM_ISM) return m.rho_ism;
+    if (m.generic) return (m.A_cgs / (m.r0k_cgs + pow(r / U_CM, m.k_m)) + m.rho_ism_cgs) * (U_G / U_CM3);
     return m.A / (m.r02 + r * r) + m.rho_ism;
 }
-VAG_DEV double medium_mass(const Medium& m, double r) {
+// simpson_logspace of rho r^3 d(ln r): enclosed_mass, shock-physics.h:401-425
+VAG_DEV double enclosed_mass_generic(const Medium& med, double r) {
+    const int N = 32;
+    const double u_max = log(r), u_min = u_max - 18, h = (u_max - u_min) / N;
+    auto f = [&](double u) {
+        const double ri = exp(u);
+        return medium_rho(med, ri) * ri * ri * ri;
+    };
+    double sum = f(u_min) + f(u_max);
+    for (int i = 1; i < N; i += 2) sum += 4 * f(u_min + i * h);
+    for (int i = 2; i < N; i += 2) sum += 2 * f(u_min + i * h);
+    return sum * h / 3;
+}
+VAG_DEV double medium_mass(const Medium& m, double r) {  // enclosed_mass_medium, shock-physics.h:439-446
+    if (m.type != VAG_MEDIUM_ISM && m.generic) return enclosed_mass_generic(m, r);
     double mass = m.rho_ism * r * r * r / 3.0;
     if (m.type != VAG_MEDIUM_ISM && m.A != 0) {
         if (m.r02 > 0) {
@@ -147,15 +181,19 @@ VAG_DEV double medium_mass(const Medium& m, double r) {
 VAG_DEV bool params_valid(const vag_model_params& p) {
     auto fpos = [](double x) { return isfinite(x) && x > 0; };
     auto oi = [](double x, double lo, double hi) { return isfinite(x) && x > lo && x <= hi; };
-    bool ok = p.jet_type >= 0 && p.jet_type <= VAG_JET_MAGNETIZED_TOPHAT && p.medium_type >= 0 &&
+    bool ok = p.jet_type >= 0 && p.jet_type <= VAG_JET_POWERLAW_WING && p.medium_type >= 0 &&
               p.medium_type <= VAG_MEDIUM_WIND;
-    ok = ok && oi(p.theta_c, 0.0, C_PI / 2) && fpos(p.E_iso) && isfinite(p.Gamma0) && p.Gamma0 > 1.0 && fpos(p.duration);
-    if (p.jet_type == VAG_JET_POWERLAW) ok = ok && fpos(p.k_e) && fpos(p.k_g);
+    ok = ok && oi(p.theta_c, 0.0, C_PI / 2) && fpos(p.duration);
+    if (p.jet_type != VAG_JET_POWERLAW_WING) ok = ok && fpos(p.E_iso) && isfinite(p.Gamma0) && p.Gamma0 > 1.0;
+    if (p.jet_type == VAG_JET_STEP_POWERLAW || p.jet_type == VAG_JET_POWERLAW_WING)
+        ok = ok && fpos(p.E_iso_w) && isfinite(p.Gamma0_w) && p.Gamma0_w > 1.0;
+    if (p.jet_type == VAG_JET_POWERLAW || p.jet_type == VAG_JET_STEP_POWERLAW || p.jet_type == VAG_JET_POWERLAW_WING)
+        ok = ok && fpos(p.k_e) && fpos(p.k_g);
     if (p.jet_type == VAG_JET_TWO_COMPONENT)
         ok = ok && oi(p.theta_w, 0.0, C_PI / 2) && p.theta_w > p.theta_c && fpos(p.E_iso_w) && isfinite(p.Gamma0_w) &&
              p.Gamma0_w > 1.0;
     ok = ok && isfinite(p.n_ism) && p.n_ism >= 0;
-    if (p.medium_type == VAG_MEDIUM_WIND) ok = ok && fpos(p.A_star) && p.n0 > 0;
+    if (p.medium_type == VAG_MEDIUM_WIND) ok = ok && fpos(p.A_star) && p.n0 > 0 && fpos(p.k_m);
     ok = ok && fpos(p.lumi_dist) && isfinite(p.z) && p.z >= 0 && isfinite(p.theta_obs) && p.theta_obs >= 0 &&
          p.theta_obs <= C_PI;
     ok = ok && oi(p.eps_e, 0.0, 1.0) && oi(p.eps_B, 0.0, 1.0) && oi(p.xi_e, 0.0, 1.0) && isfinite(p.p) && p.p > 1.0;

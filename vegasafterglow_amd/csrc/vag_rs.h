@@ -117,20 +117,6 @@ VAG_DEV double Gamma_therm(double U_th, double mass, bool limiter) {  // shock-p
     return (limiter && G < GAMMA_CUT) ? 1 : G;
 }
 
-// simpson_logspace of rho r^3 d(ln r): enclosed_mass, shock-physics.h:401-425
-VAG_DEV double enclosed_mass_generic(const Medium& med, double r) {
-    const int N = 32;
-    const double u_max = log(r), u_min = u_max - 18, h = (u_max - u_min) / N;
-    auto f = [&](double u) {
-        const double ri = exp(u);
-        return medium_rho(med, ri) * ri * ri * ri;
-    };
-    double sum = f(u_min) + f(u_max);
-    for (int i = 1; i < N; i += 2) sum += 4 * f(u_min + i * h);
-    for (int i = 2; i < N; i += 2) sum += 2 * f(u_min + i * h);
-    return sum * h / 3;
-}
-
 // enclosed_thermal_energy (generic Simpson form for every medium), shock-physics.h:427-437
 VAG_DEV double enclosed_thermal_energy_generic(const Medium& med, double r, double Gamma, double ad, double eps_e) {
     const double cooling_exp = 3 * (ad - 1);

@@ -21,8 +21,10 @@ from .model import get_context
 logger = logging.getLogger(__name__)
 logger.addHandler(logging.NullHandler())
 
+# the registry of VegasAfterglow/fitting/config.py:99-121 ("uniform" = TophatJet with theta_c fixed to pi/2)
 JET_TYPES = {"tophat": _lib.JET_TOPHAT, "gaussian": _lib.JET_GAUSSIAN, "powerlaw": _lib.JET_POWERLAW,
-             "two_component": _lib.JET_TWO_COMPONENT}
+             "two_component": _lib.JET_TWO_COMPONENT, "step_powerlaw": _lib.JET_STEP_POWERLAW,
+             "powerlaw_wing": _lib.JET_POWERLAW_WING, "uniform": _lib.JET_TOPHAT}
 MEDIUM_TYPES = {"ism": _lib.MEDIUM_ISM, "wind": _lib.MEDIUM_WIND}
 
 
@@ -121,7 +123,9 @@ class Fitter:
         p.jet_type, p.medium_type = JET_TYPES[self.jet], MEDIUM_TYPES[self.medium]
         p.theta_c, p.E_iso, p.Gamma0, p.k_e, p.k_g = vals["theta_c"], vals["E_iso"], vals["Gamma0"], vals["k_e"], vals["k_g"]
         p.theta_w, p.E_iso_w, p.Gamma0_w, p.duration = vals["theta_w"], vals["E_iso_w"], vals["Gamma0_w"], vals["tau"]
-        p.n_ism, p.A_star, p.n0 = vals["n_ism"], vals["A_star"], vals["n0"]
+        p.n_ism, p.A_star, p.n0, p.k_m = vals["n_ism"], vals["A_star"], vals["n0"], vals["k_m"]
+        if self.jet == "uniform":
+            p.theta_c = math.pi / 2
         p.lumi_dist, p.z, p.theta_obs = self.lumi_dist, self.z, vals["theta_v"]
         p.eps_e, p.eps_B, p.p, p.xi_e = vals["eps_e"], vals["eps_B"], vals["p"], vals["xi_e"]
         p.phi_resol, p.theta_resol, p.t_resol = self.resolution

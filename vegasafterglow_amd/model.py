@@ -91,6 +91,45 @@ class TwoComponentJet(TophatJet):
         p.theta_w, p.E_iso_w, p.Gamma0_w = self.theta_w, self.E_iso_w, self.Gamma0_w
 
 
+class StepPowerLawJet(TophatJet):
+    """StepPowerLawJet(theta_c, E_iso, Gamma0, E_iso_w, Gamma0_w, k_e, k_g, spreading=False, duration=1, magnetar=None)
+    -- pybind.cpp:221, pymodel.cpp:112-128."""
+    jet_type = _lib.JET_STEP_POWERLAW
+
+    def __init__(self, theta_c, E_iso, Gamma0, E_iso_w, Gamma0_w, k_e, k_g, spreading=False, duration=1.0, magnetar=None):
+        super().__init__(theta_c, E_iso, Gamma0, spreading, duration, magnetar)
+        _finite_pos("E_iso_w", E_iso_w)
+        _req(math.isfinite(Gamma0_w) and Gamma0_w > 1, f"Gamma0_w must be > 1, got {Gamma0_w}")
+        _finite_pos("k_e", k_e)
+        _finite_pos("k_g", k_g)
+        self.E_iso_w, self.Gamma0_w, self.k_e, self.k_g = float(E_iso_w), float(Gamma0_w), float(k_e), float(k_g)
+
+    def _fill(self, p):
+        super()._fill(p)
+        p.E_iso_w, p.Gamma0_w, p.k_e, p.k_g = self.E_iso_w, self.Gamma0_w, self.k_e, self.k_g
+
+
+class PowerLawWing(_Jet):
+    """PowerLawWing(theta_c, E_iso_w, Gamma0_w, k_e, k_g, spreading=False, duration=1) -- pybind.cpp:214,
+    pymodel.cpp:90-110: a hollow-core wing, eps ~ (theta / theta_c)^-k_e outside theta_c."""
+    jet_type = _lib.JET_POWERLAW_WING
+
+    def __init__(self, theta_c, E_iso_w, Gamma0_w, k_e, k_g, spreading=False, duration=1.0):
+        _req(math.isfinite(theta_c) and 0 < theta_c <= math.pi / 2, f"theta_c must be in (0, pi/2], got {theta_c}")
+        _finite_pos("E_iso_w", E_iso_w)
+        _req(math.isfinite(Gamma0_w) and Gamma0_w > 1, f"Gamma0_w must be > 1, got {Gamma0_w}")
+        _finite_pos("k_e", k_e)
+        _finite_pos("k_g", k_g)
+        _finite_pos("duration", duration)
+        self.theta_c, self.E_iso_w, self.Gamma0_w = float(theta_c), float(E_iso_w), float(Gamma0_w)
+        self.k_e, self.k_g, self.duration, self.spreading = float(k_e), float(k_g), float(duration), bool(spreading)
+
+    def _fill(self, p):
+        p.jet_type = self.jet_type
+        p.theta_c, p.E_iso_w, p.Gamma0_w, p.k_e, p.k_g, p.duration = (self.theta_c, self.E_iso_w, self.Gamma0_w, self.k_e,
+                                                                        self.k_g, self.duration)
+
+
 class MagnetizedTophatJet(TophatJet):
     """Top-hat profile on the generic Ejecta with a constant magnetisation sigma0 -- what the reference's test-suite
     builds as Ejecta(E_iso=lambda phi, theta: E_iso if theta <= theta_c else 0, Gamma0=..., sigma0=lambda ...: sigma0)
@@ -129,15 +168,14 @@ class Wind:
             _req(math.isfinite(n_ism) and n_ism >= 0, f"n_ism must be non-negative and finite, got {n_ism}")
         if n0 is not None:
             _req(n0 > 0, f"n0 must be > 0 (or +inf for no floor), got {n0}")
-        if k_m != 2:
-            raise NotImplementedError("Wind with k_m != 2 is a python-callback Medium in the reference; not on the hot path")
+        self.k_m = float(k_m)  # k_m != 2 is the closed-form generic Medium of pymodel.cpp:167-185
         self.A_star = float(A_star)
         self.n_ism = 0.0 if n_ism is None else float(n_ism)
         self.n0 = math.inf if n0 is None else float(n0)
 
     def _fill(self, p):
         p.medium_type = _lib.MEDIUM_WIND
-        p.n_ism, p.A_star, p.n0 = self.n_ism, self.A_star, self.n0
+        p.n_ism, p.A_star, p.n0, p.k_m = self.n_ism, self.A_star, self.n0, self.k_m
 
 
 class Observer:
@@ -215,7 +253,8 @@ class Model:
     def __init__(self, jet, medium, observer, fwd_rad, rvs_rad=None, resolutions=None, rtol=1e-6, axisymmetric=True,
                  radiative_fireball=True, device=0):
         if not isinstance(jet, _Jet):
-            raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, TwoComponentJet or MagnetizedTophatJet")
+            raise TypeError("jet must be TophatJet, GaussianJet, PowerLawJet, TwoComponentJet, StepPowerLawJet, PowerLawWing "
+                            "or MagnetizedTophatJet")
         if not isinstance(medium, (ISM, Wind)):
             raise TypeError("medium must be ISM or Wind")
         if rvs_rad is not None and not isinstance(rvs_rad, Radiation):
