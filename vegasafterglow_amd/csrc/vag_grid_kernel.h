@@ -47,7 +47,7 @@ struct GridShared {
     // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
     double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA],
         pj_st[VAG_MAX_THETA];
-    double tdec[VAG_MAX_THETA], tstart[VAG_MAX_THETA], tearly[VAG_MAX_THETA];
+    double tdec[VAG_MAX_THETA];
     int flag[VAG_MAX_THETA];
 };
 
@@ -465,8 +465,10 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 cut = dmin(cut, 0.01 * T0);
                 max_ref = dmax(max_ref, 10.0 * dmax(td, T0));
             }
-            sh.tstart[j] = dmax(ts, cut);          // TimeScanResult::t_start / early_t (grid-refinement.h:462-469,497-498):
-            sh.tearly[j] = 0.99 * dmin(ts, cut);   // used per row by structured (spreading) grids
+            // TimeScanResult::t_start / early_t (grid-refinement.h:462-469,497-498), used per row by structured (spreading)
+            // grids; symmetric grids overwrite them below with the shared start / early node
+            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = dmax(ts, cut);
+            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = 0.99 * dmin(ts, cut);
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, dmax(ts, cut));
             min_cut = dmin(min_cut, cut);
@@ -504,8 +506,10 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         // lattice scalars per row: [0] t_dec, [1] first regular node, [2] early node.  Symmetric grids share the global
         // start / early point (build_time_grid, grid-refinement.h:609-626)
         g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j] = sh.tdec[j];
-        g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = spreading ? sh.tstart[j] : M.t_start;
-        g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = spreading ? sh.tearly[j] : M.t_early;
+        if (!spreading) {
+            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = M.t_start;
+            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = M.t_early;
+        }
     }
     // Geometry factors of the equal-arrival-time step that depend on the angular grid only
     // (calc_eat_non_spreading + compute_dphi, src/core/observer.cpp:17-37,143-188): computed once per model
