@@ -590,16 +590,22 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 
 // ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table.  A query outside the clamped band but
 // inside the theoretical range would make the reference rebuild the cell's spectrum; here it raises `*breach`.
+VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
+                                 double th_max, double x, int* breach);
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach) {
-    const int n = (int)tab[0];
+    return ic_table_eval_hdr(tab, tab[0], tab[1], tab[2], tab[3], tab[4], x, breach);
+}
+// the same with the five header words already at hand (the grid flux kernel keeps them in its LDS-staged row)
+VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
+                                 double th_max, double x, int* breach) {
+    const int n = (int)h_n;
     if (n < 2) return -INFINITY;
-    const double phase = tab[1];
-    const long idx0 = (long)tab[2];
+    const long idx0 = (long)h_idx0;
     auto node = [&](int q) { return phase + IC_Q * (double)(idx0 + 2L * q); };
     const double first = node(0), last = node(n - 1);
-    if ((x > last && x < tab[4]) || (x < first && x > tab[3])) *breach = 1;
+    if ((x > last && x < th_max) || (x < first && x > th_min)) *breach = 1;
     if (x > last) return -INFINITY;
-    int idx = (int)floor((x - first) / (2 * IC_Q));
+    int idx = (int)floor((x - first) * (1.0 / (2 * IC_Q)));
     idx = idx < 0 ? 0 : (idx > n - 2 ? n - 2 : idx);
     while (idx + 2 < n && node(idx + 1) <= x) ++idx;  // settle exactly like the reference's forward scan
     while (idx > 0 && node(idx) > x) --idx;

@@ -322,6 +322,8 @@ template <class P1, class P2>
 VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu,
                             const double* __restrict__ sp);
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
+VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
+                                 double th_max, double x, int* breach);
 constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
 constexpr int FLUX_IC_STRIDE = 166;  // == IC_STRIDE
 
@@ -360,7 +362,7 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
 // MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
 template <bool COUNT, int MODE, bool SPREAD = false>
-__global__ void __launch_bounds__(FLUX_THREADS, MODE == FLUX_SYN ? 4 : 2)
+__global__ void __launch_bounds__(FLUX_THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
     const VagGridMeta* Mp = a.meta + m;
@@ -435,6 +437,17 @@ vag_flux_grid_kernel(FluxArgs a) {
             for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {  // rare path: keep its register footprint small
                 const int par = (int)(((float)q + 0.5f) / (float)K);
                 s_par[par * KS + (q - par * K)] = src[q];
+            }
+            if constexpr (MODE == FLUX_SSC) {
+                // the SSC pass never evaluates the synchrotron block: its first five rows carry the table headers
+                // (n, phase, idx0, theory_min, theory_max) instead, saving a dependent global round trip per evaluation
+                __syncthreads();
+                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K) * FLUX_IC_STRIDE;
+#pragma unroll 1
+                for (int q = tid; q < 5 * K; q += FLUX_THREADS) {
+                    const int kk = q / 5, w = q - kk * 5;
+                    s_par[w * KS + kk] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
+                }
             }
             if constexpr (MODE == FLUX_SYN_IC) {
                 const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K) * FLUX_NQ;
@@ -528,8 +541,10 @@ vag_flux_grid_kernel(FluxArgs a) {
                     b1 = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, s_nu[l1] - dop, s_sp);
                 } else {
                     const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
-                    b0 = ic_table_eval(tab, s_nu[l0] - dop, &breach);
-                    b1 = ic_table_eval(tab, s_nu[l1] - dop, &breach);
+                    const double h0 = s_par[k], h1 = s_par[KS + k], h2 = s_par[2 * KS + k], h3 = s_par[3 * KS + k],
+                                 h4 = s_par[4 * KS + k];
+                    b0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
+                    b1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
                 }
                 s_B[l0 * KS + k] = b0 + geom;
                 s_B[l1 * KS + k] = b1 + geom;
