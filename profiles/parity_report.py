@@ -46,10 +46,44 @@ for name, (kw, t, nu) in cases.items():
     O, G = orc.flux_density_grid(prm, t, nu), gpu_grid(prm, t, nu)
     s = orc.details(prm, t.min(), t.max())["shape"]
     print(f"{name:22s} {str((s['n_phi'], s['n_theta'], s['n_t'])):>20s} {rel(G, O, 1e-2):24.3e} {rel(G, O, 1e-12):26.3e}")
-print("\nreference golden baselines (contract: |d| <= 2e-3 |ref| + 1e-2 max|ref|)")
-for name in ("tophat_ism", "tophat_ism_adiabatic", "two_component_ism"):
-    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+def gpu_comp4(prm, t, nu):
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    comps = [np.zeros((nu.size, t.size)) for _ in range(4)]
+    arr = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+    q = _lib.ModelParams.from_buffer_copy(bytes(prm))
+    _lib.check(lib.vag_flux_density_grid_components4_batch(h, C.byref(q), 1, t.ctypes.data_as(dp), t.size,
+                                                           nu.ctypes.data_as(dp), nu.size, arr))
+    return comps
+
+
+print("\nper-component parity of the widened tiers (max rel err over bins > 1e-12 of the component's peak; '-' = component off)")
+print(f"{'config':28s} {'fwd.sync':>10s} {'fwd.ssc':>10s} {'rvs.sync':>10s} {'rvs.ssc':>10s}")
+tiers = {"C3 (FS+RS, SSC+KN)": (configs.C3, configs.C3_T, configs.C3_NU)}
+tiers.update({k: v for k, v in configs.RS_CASES.items()})
+tiers.update({k: (kw, configs.SPREAD_T, configs.SPREAD_NU) for k, kw in configs.SPREAD_CASES.items()})
+tiers.update({k: (kw, configs.SPREAD_T, configs.SPREAD_NU) for k, kw in configs.PROFILE_CASES.items()})
+for name, (kw, t, nu) in tiers.items():
+    prm = _abi.make_params(**kw)
+    O, G = orc.flux_components4(prm, t, nu), gpu_comp4(prm, t, nu)
+    print(f"{name:28s} " + " ".join(f"{rel(g, o, 1e-12):10.2e}" if o.max() > 0 else f"{'-':>10s}" for g, o in zip(G, O)))
+
+print("\nall 13 golden baselines of the reference test-suite (contract: |d| <= 2e-3 |ref| + 1e-2 max|ref| per component)")
+import glob
+for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))):
+    name = os.path.basename(path)[:-4]
+    if name.startswith("reference_vectors"):
+        continue
+    g = np.load(path)
     prm = _abi.params_from_golden_config(json.loads(str(g["config"])))
-    G, T = gpu_grid(prm, g["t"], g["nus"]), g["total"]
-    ok = bool(np.all(np.abs(G - T) <= 2e-3 * np.abs(T) + 1e-2 * np.abs(T).max()))
-    print(f"{name:24s} contract={'PASS' if ok else 'FAIL'}  max rel err >1e-2 peak = {rel(G, T, 1e-2):.3e}")
+    G = dict(zip(("fwd_sync", "fwd_ssc", "rvs_sync", "rvs_ssc"), gpu_comp4(prm, g["t"], g["nus"])))
+    line = []
+    for comp in ("fwd_sync", "fwd_ssc", "rvs_sync", "rvs_ssc"):
+        T = g[comp]
+        if T.ndim == 0:
+            continue
+        ok = bool(np.all(np.abs(G[comp] - T) <= 2e-3 * np.abs(T) + 1e-2 * np.abs(T).max()))
+        line.append(f"{comp} contract={ok} rel(>1e-2 peak)={rel(G[comp], T, 1e-2):.1e}")
+    print(f"{name:24s} " + "; ".join(line))
