@@ -37,6 +37,7 @@ extern "C" {
 #define VAG_E_HIP (-3)       /* a HIP call failed; message carries hipGetErrorString */
 #define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (reverse shock, SSC, ...) */
 #define VAG_E_CAPACITY (-5)  /* grid larger than the engine's static limits */
+#define VAG_E_NUMERIC (-6)   /* an ODE row could not find a step size (the reference throws odeint's step_adjustment_error) */
 
 /* jet profiles: src/environment/jet.h:84-259 (TophatJet, GaussianJet, PowerLawJet),
  * math::two_component jet.h:421-437 via PyTwoComponentJet pybind/pymodel.cpp:130-146 */
@@ -312,8 +313,10 @@ typedef struct vag_plan {
     int32_t pairs_per_block;
     int32_t n_models_invalid;  /* parameters rejected by validation (ValueError in the reference) */
     int32_t n_models_capacity; /* adaptive grid larger than the engine limits: NOT evaluated (NaN / -inf) */
+    int32_t n_rows_failed;     /* ODE rows without an acceptable step after 500 rejections (error in the reference) */
+    int32_t n_rows_gave_up;    /* ODE rows that hit the 100000-step cap or stalled (warning in the reference; row kept) */
 } vag_plan;
-int vag_last_plan(vag_ctx* ctx, vag_plan* out);
+int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with
  * one atomic per workgroup and a host sync; leave disabled in timed runs. */
 int vag_ctx_count_work(vag_ctx* ctx, int enable);

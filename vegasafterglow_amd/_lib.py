@@ -13,7 +13,7 @@ JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT
 JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
-VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY = 0, -1, -2, -3, -4, -5
+VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY, VAG_E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
 FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING = 1, 2, 4, 8, 16, 32  # VAG_FLAG_* of include/vegasafterglow_amd.h
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
@@ -69,7 +69,8 @@ class Plan(C.Structure):
     _fields_ = [("n_models_ok", C.c_int32), ("n_rows", C.c_int32), ("n_cells", C.c_int64), ("total_pairs", C.c_int64),
                 ("eat_cells", C.c_int64), ("spec_evals", C.c_int64), ("interps", C.c_int64),
                 ("flux_blocks", C.c_int32), ("pairs_per_block", C.c_int32),
-                ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32)]
+                ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32),
+                ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32)]
 
 
 class Limits(C.Structure):
@@ -149,4 +150,6 @@ def check(rc):
         raise ValueError("engine capacity exceeded: " + msg)
     if rc == VAG_E_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == VAG_E_NUMERIC:
+        raise RuntimeError("ODE integration failed: " + msg)  # odeint's step_adjustment_error surfaces as RuntimeError
     raise RuntimeError(f"vegasafterglow_amd error {rc}: {msg}")

@@ -233,6 +233,7 @@ struct vag_ctx {
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
     // flux passes always read d_shock, d_cellpar, ...; select_emitter() swaps the reverse shock's buffers in and out.
     DevBuf d_shock_r, d_cellpar_r, d_celldet_r, d_icy_r, d_cellq_r, d_params_rvs, d_inj, d_comp;
+    DevBuf d_fail;     // int[4]: ODE rows per status (1 step underflow, 2 step cap, 3 stalled), reset per batch
     DevBuf d_cellgeo;  // spreading jets (VAG_FLAG_SPREADING): per-cell cos/sin(theta), log2|dcos|, shared by both shocks
     int cur_emitter = 0;                            // 0 forward, 1 reverse
     bool cur_ssc = false;                           // SSC switch of the selected emitter
@@ -378,7 +379,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
-                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -401,9 +402,21 @@ int vag_ctx_count_work(vag_ctx* c, int enable) {
     return VAG_OK;
 }
 
-int vag_last_plan(vag_ctx* c, vag_plan* out) {
-    *out = c->plan;
+static int read_row_failures(vag_ctx* c) {
+    int f[4] = {0, 0, 0, 0};
+    if (c->d_fail.p && c->n_rows > 0) {
+        HIPCHK(hipMemcpyAsync(f, c->d_fail.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    c->plan.n_rows_failed = f[1];
+    c->plan.n_rows_gave_up = f[2] + f[3];
     return VAG_OK;
+}
+
+int vag_last_plan(vag_ctx* c, vag_plan* out) {
+    const int rc = read_row_failures(c);
+    *out = c->plan;
+    return rc;
 }
 
 int vag_ctx_synchronize(vag_ctx* c) {
@@ -584,6 +597,11 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
     }
+    HIPCHK(hipGetLastError());
+    if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
+    HIPCHK(hipMemsetAsync(c->d_fail.p, 0, sizeof(int) * 4, st));
+    hipLaunchKernelGGL(vag_count_row_status, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_status.as<int>(), rows,
+                       c->d_fail.as<int>());
     HIPCHK(hipGetLastError());
     if (spreading) {  // per-cell viewing geometry from the evolved theta (both shocks ride the same contact discontinuity)
         if (c->d_cellgeo.ensure(sizeof(double) * (size_t)cells * 3)) return VAG_E_HIP;
@@ -974,6 +992,10 @@ int check_host_inputs(const vag_model_params* params, int nb, const double* t, i
 }
 
 int check_status(vag_ctx* c, int nb) {
+    const int rf = read_row_failures(c);
+    if (rf) return rf;
+    if (c->plan.n_rows_failed > 0)
+        return set_err(VAG_E_NUMERIC, "%d ODE row(s): no acceptable step size after 500 rejections", c->plan.n_rows_failed);
     const VagGridMeta* hm = c->h_meta.as<VagGridMeta>();
     for (int m = 0; m < nb; ++m)
         if (hm[m].status == VAG_E_CAPACITY)
@@ -1267,6 +1289,13 @@ __global__ void vag_valid_from_meta(const VagGridMeta* meta, int nb, int* valid)
     if (m < nb) valid[m] = meta[m].status == 0;
 }
 
+// a walker whose ODE threw in the reference (no acceptable step) is caught by eval_one and scored -inf (samplers.py:61-70)
+__global__ void vag_invalidate_failed_rows(const int* __restrict__ row_status, const int* __restrict__ row_off, int nb,
+                                           int n_rows, int* __restrict__ valid) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows && row_status[r] == 1) valid[vag::find_model(row_off, nb, r)] = 0;
+}
+
 int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
@@ -1290,6 +1319,9 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     if (rc) return rc;
     hipLaunchKernelGGL(vag_valid_from_meta, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb,
                        c->d_valid.as<int>());
+    if (c->n_rows > 0)
+        hipLaunchKernelGGL(vag_invalidate_failed_rows, dim3((c->n_rows + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_row_status.as<int>(), c->d_row_off.as<int>(), nb, c->n_rows, c->d_valid.as<int>());
     hipLaunchKernelGGL(vag_loglike_kernel, dim3(nb), dim3(64), 0, c->stream, c->d_series_flux.as<double>(), n,
                        d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, c->d_valid.as<int>(), d_out);
     HIPCHK(hipGetLastError());

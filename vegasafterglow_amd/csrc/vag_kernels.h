@@ -165,6 +165,15 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     row_status[row] = status;
 }
 
+// ODE rows per outcome (row_status written by the dynamics kernels): fail[s] += 1 for s in {1, 2, 3}.
+__global__ void vag_count_row_status(const int* __restrict__ row_status, int n_rows, int* __restrict__ fail) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) {
+        const int s = row_status[r];
+        if (s > 0 && s < 4) atomicAdd(fail + s, 1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Spreading jets: per-cell polar geometry of the equal-arrival-time step (Observer::calc_t_obs +
 // calc_solid_angle, src/core/observer.cpp:51-141): cos / sin of the evolved theta and log2 |cos th_hi - cos th_lo|,
