@@ -53,6 +53,25 @@ VAG_DEV double log2_softplus(double x) {
 }
 VAG_DEV double fast_pow(double a, double b) { return exp2(b * log2(a)); }
 
+// 1/x and sqrt(x) for the ODE right-hand sides: hardware estimate + two Newton steps (<= 2 ulp) instead of the ~35- and
+// ~25-instruction IEEE sequences.  One lane integrates one row, so a dynamics wavefront is VALU-issue bound and its
+// instruction count IS its latency.  x must be finite, non-zero (rcp) / positive (sqrt) and normal.
+VAG_DEV double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+VAG_DEV double sqrt_fast(double x) {
+    if (!(x > 0)) return sqrt(x);  // 0, negative, NaN: library semantics
+    double y = __builtin_amdgcn_rsq(x);               // ~ 1/sqrt(x)
+    y = y * fma(-0.5 * x * y, y, 1.5);                // Newton on 1/sqrt
+    double s = x * y;                                 // ~ sqrt(x)
+    s = fma(fma(-s, s, x), 0.5 * y, s);               // Newton on sqrt with the residual in fma
+    s = fma(fma(-s, s, x), 0.5 * y, s);
+    return s;
+}
+
 // src/core/physics.h:36-61
 VAG_DEV double gamma_to_beta(double g) { return sqrt((g - 1) * (g + 1)) / g; }
 VAG_DEV double adiabatic_idx(double g) { return 4.0 / 3.0 + 1 / (3 * g); }
@@ -268,7 +287,7 @@ struct Dopri5 {
             for (int i = 0; i < N; ++i) {
                 const double xe = (h * dc1) * dx[i] + (h * dc3) * k3[i] + (h * dc4) * k4[i] + (h * dc5) * k5[i] +
                                   (h * dc6) * k6[i] + (h * dc7) * k7[i];
-                err = dmax(err, fabs(xe) / (eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
+                err = dmax(err, fabs(xe) * rcp_fast(eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
             }
             if (err > 1.0) {
                 dt = h * dmax(9.0 / 10.0 * exp2_sat(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
@@ -361,6 +380,7 @@ VAG_DEV double estimate_t_dec(const Jet& jet, const Medium& med, double theta) {
 struct TimeLattice {
     int n, n1, n2, n3, plain;
     double l0, l1, l2, l3, step;
+    double s1, s2, s3;  // per-segment log10 steps (the reference divides per node; one rounding apart)
     VAG_DEV void init(double ts, double t_end, double t_dec, int n_nodes) {
         n = n_nodes;
         double b_lo = dmax(t_dec / 3, ts);
@@ -368,6 +388,7 @@ struct TimeLattice {
         l0 = log10(ts);
         l3 = log10(t_end);
         plain = (!(b_hi > b_lo) || n < 8);
+        s1 = s2 = s3 = 0;
         if (plain) {
             step = (l3 - l0) / fmax(1.0, (double)(n - 1));  // xt::linspace, xbuilder.hpp:460-471
             n1 = n2 = n3 = 0;
@@ -384,21 +405,24 @@ struct TimeLattice {
         if (segs - 1 - n1 - 1 < n3) n3 = segs - 1 - n1 - 1;
         n2 = segs - n1 - n3;
         step = 0;
+        s1 = n1 > 0 ? (l1 - l0) / (double)n1 : 0;
+        s2 = n2 > 0 ? (l2 - l1) / (double)n2 : 0;
+        s3 = n3 > 0 ? (l3 - l2) / (double)n3 : 0;
     }
-    // node kk in [0, n)
+    // node kk in [0, n): 10^lg through the fast exp2 (3.3e-16), not the library pow
     VAG_DEV double node(int kk) const {
         double lg;
         if (plain) {
             lg = (n > 1 && kk == n - 1) ? l3 : l0 + step * (double)kk;
         } else if (kk < n1) {
-            lg = l0 + (l1 - l0) * (double)kk / (double)n1;
+            lg = l0 + s1 * (double)kk;
         } else if (kk < n1 + n2) {
-            lg = l1 + (l2 - l1) * (double)(kk - n1) / (double)n2;
+            lg = l1 + s2 * (double)(kk - n1);
         } else {
             const int q = kk - n1 - n2;
-            lg = (n3 > 0) ? l2 + (l3 - l2) * (double)q / (double)n3 : l3;
+            lg = (n3 > 0 && q < n3) ? l2 + s3 * (double)q : l3;
         }
-        return pow(10.0, lg);
+        return exp2_fast(lg * 3.321928094887362347870319429489390175865);
     }
 };
 
@@ -414,16 +438,16 @@ struct FwdShock {
     VAG_DEV void operator()(const double* s, double* d, double /*t*/) const {
         const double Gamma = s[0], m2 = s[1], U = s[2], r = s[3], t_comv = s[4];
         const double u2 = (Gamma - 1) * (Gamma + 1);
-        const double u = sqrt(u2);
+        const double u = sqrt_fast(u2);
         const double dr = u * (Gamma + u) * C_C;
         d[3] = dr;
         d[4] = Gamma + u;
-        const double inv_G = 1 / Gamma;
+        const double inv_G = rcp_fast(Gamma);
         double dth = 0, sin_th = 0, cos_th = 1;
         if constexpr (SPREAD) {
             const double theta = s[5];
             if (theta < 0.5 * C_PI)  // compute_dtheta_dt, shock-physics.h:141-145
-                dth = dr / (2 * Gamma * r) * sqrt((2 * u2 + 3) / (4 * u2 + 3)) * (1 / (1 + u * theta_s * 7));
+                dth = dr * rcp_fast(2 * Gamma * r) * sqrt_fast((2 * u2 + 3) * rcp_fast(4 * u2 + 3)) * rcp_fast(1 + u * theta_s * 7);
             d[5] = dth;
             sin_th = sin(theta);
             cos_th = cos(theta);
@@ -435,37 +459,39 @@ struct FwdShock {
         double eps_rad = 0;  // RadiativeEfficiency, shock-physics.h:247-288
         if (eps_e_eff != 0) {
             const double gamma_m = gamma_m_coeff * (Gamma - 1) + 1;
-            const double gamma_bar = gamma_c_coeff / (e_th * t_comv);
-            const double gamma_c = 0.5 * (gamma_bar + sqrt(gamma_bar * gamma_bar + 4));
-            const double ratio = gamma_m / gamma_c;
+            const double gamma_bar = gamma_c_coeff * rcp_fast(e_th * t_comv);
+            const double gamma_c = 0.5 * (gamma_bar + sqrt_fast(gamma_bar * gamma_bar + 4));
+            const double ratio = gamma_m * rcp_fast(gamma_c);
             eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
         }
         const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
         const double Gamma2 = Gamma * Gamma;
         const double Gamma_eff = (ad * (Gamma2 - 1) + 1) * inv_G;
         const double dGamma_eff = (ad * (Gamma2 + 1) - 1) * (inv_G * inv_G);
-        double dlnV = 3 / r * dr;
+        const double inv_r = rcp_fast(r);
+        double dlnV = 3 * inv_r * dr;
         double dm_swept = dm, m_swept = m2, Ueff = U;
         if constexpr (SPREAD) {  // compute_dGamma_dt, forward-shock.tpp:77-84
-            const double f_spread = (1 - cos_th) / dOmega0;
-            dm_swept = dm * f_spread + m2 / dOmega0 * sin_th * dth;
+            const double inv_dO = rcp_fast(dOmega0);
+            const double f_spread = (1 - cos_th) * inv_dO;
+            dm_swept = dm * f_spread + m2 * inv_dO * sin_th * dth;
             m_swept = m2 * f_spread;
-            dlnV += sin_th / (1 - cos_th) * dth;
+            dlnV += sin_th * rcp_fast(1 - cos_th) * dth;
             Ueff = U * f_spread;
         }
         const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_swept;
         const double a2 = (ad - 1) * Gamma_eff * Ueff * dlnV;
         const double b1 = (m_jet0 + m_swept) * C_C2;
         const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * Ueff;
-        const double dG = (a1 + a2) / (b1 + b2);
+        const double dG = (a1 + a2) * rcp_fast(b1 + b2);
         d[0] = dG;
-        double dlnV2 = 3 / r * dr - dG * inv_G;
+        double dlnV2 = 3 * inv_r * dr - dG * inv_G;
         double dm_u = dm;
         if constexpr (SPREAD) {  // compute_dU_dt, forward-shock.tpp:109-115
-            const double factor = sin_th / (1 - cos_th) * dth;
+            const double factor = sin_th * rcp_fast(1 - cos_th) * dth;
             dm_u = dm + m2 * factor;
             dlnV2 += factor;
-            dlnV2 += factor / (ad - 1);
+            dlnV2 += factor * rcp_fast(ad - 1);
         }
         d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm_u - (ad - 1) * dlnV2 * U;
     }
@@ -497,12 +523,12 @@ VAG_DEV double enclosed_thermal_energy(const Medium& med, double r, double Gamma
 VAG_DEV double compression_fwd(double Gd) {
     const double dd = 1 - Gd;
     const double denom = Gd - 1;
-    const double g = denom <= 0 ? 1 : 1 + dd * dd / denom;
-    const double ad = adiabatic_idx(g);
+    const double g = denom <= 0 ? 1 : 1 + dd * dd * rcp_fast(denom);
+    const double ad = 4.0 / 3.0 + rcp_fast(3 * g);
     const double gm1 = g - 1, adm2 = ad - 2, adm1 = ad - 1;
-    const double u_down = sqrt(dmax(gm1 * adm1 * adm1 / (-ad * adm2 * gm1 + 2), 0.0));
-    const double u_up = sqrt((1 + u_down * u_down) * dmax((g - 1) * (g + 1), 0.0)) + u_down * g;
-    return (u_down == 0.) ? 4 * g : u_up / u_down;
+    const double u_down = sqrt_fast(dmax(gm1 * adm1 * adm1 * rcp_fast(-ad * adm2 * gm1 + 2), 0.0));
+    const double u_up = sqrt_fast((1 + u_down * u_down) * dmax((g - 1) * (g + 1), 0.0)) + u_down * g;
+    return (u_down == 0.) ? 4 * g : u_up * rcp_fast(u_down);
 }
 
 // ---- synchrotron electrons + photons for one cell: src/radiation/synchrotron.cpp:45-254,315-408,

@@ -139,14 +139,14 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
             // save_fwd_shock_state
             const double comp = compression_fwd(q[0]);
             const double rho = medium_rho(eq.med, q[3]);
-            const double Gth = (q[1] == 0) ? 1 : q[2] / (q[1] * C_C2) + 1;
+            const double Gth = (q[1] == 0) ? 1 : q[2] * rcp_fast(q[1] * C_C2) + 1;
             const double e_th = (Gth - 1) * (rho * comp) * C_C2;
             o_teng[k] = t_k;
             o_tcomv[k] = q[4];
             o_r[k] = q[3];
             o_G[k] = q[0];
             o_Gth[k] = Gth;
-            o_B[k] = sqrt(8 * C_PI * P.eps_B * e_th);
+            o_B[k] = sqrt_fast(8 * C_PI * P.eps_B * e_th);
             o_Np[k] = q[1] / C_MP;
             ++k;
             if (k < nt) t_k = node(k);
