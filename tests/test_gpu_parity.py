@@ -632,3 +632,10 @@ def test_remaining_profiles_python_mirror(eng, oracle):
     assert_close(m.flux_density_grid(t, nu).total, oracle.flux_density_grid(_abi.make_params(**configs.PROFILE_CASES["wind_k1.5"]), t, nu))
     f = fitting.Fitter(z=1.0, lumi_dist=1e28, jet="uniform", medium="wind")
     assert f._base_params({"A_star": 0.1, "k_m": 1.5}).theta_c == np.pi / 2 and f._base_params({"k_m": 1.5}).k_m == 1.5
+
+
+def test_long_time_axis_is_chunked_for_every_tier(eng, oracle):
+    """nt * nnu > 4096 with SSC and a reverse shock: the time axis is processed in chunks on the same grid."""
+    prm = _abi.make_params(theta_obs=0.1, duration=100.0, ssc=True, kn=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True))
+    t, nu = np.logspace(1, 7, 1500), np.array([1e9, 1e14, 1e17, 1e22])
+    assert_close(gpu_grid(eng, prm, t, nu)[0], oracle.flux_density_grid(prm, t, nu))

@@ -782,7 +782,7 @@ __global__ void vag_copy_kernel(double* __restrict__ out, const double* __restri
 // d_comp (optional) -> d_comp[i] != nullptr receives component i, zeros when that component is disabled;
 // d_total (optional) receives the sum of the enabled components in PyFlux::calc_total order (pymodel.cpp:350-364).
 int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw, double* d_total,
-                 double* const* d_comp) {
+                 double* const* d_comp, int t_off = 0) {  // t_off: first requested time of this call (time-axis chunking)
     const size_t n_out = (size_t)nb * (d_bandw ? nt : (size_t)nt * nnu);
     const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
     bool first = true;
@@ -810,10 +810,11 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
                 }
             }
             if (pass == 0)
-                rc = run_flux_grid(c, c->cur_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst,
-                                   c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+                rc = run_flux_grid(c, c->cur_params, nb, c->d_lg2t.as<double>() + t_off, nt, c->d_lg2nu.as<double>(), nnu, d_bandw,
+                                   dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
             else
-                rc = run_flux_ssc(c, c->cur_params, nb, c->d_lg2t.as<double>(), nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst);
+                rc = run_flux_ssc(c, c->cur_params, nb, c->d_lg2t.as<double>() + t_off, nt, c->d_lg2nu.as<double>(), nnu, d_bandw,
+                                  dst);
             if (rc) break;
             if (d_total) {
                 if (first) {
@@ -1021,14 +1022,12 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     // chunk the time axis so each launch keeps its (idx, l) slots in registers
     const int chunk = std::max(1, 4096 / nnu);  // keeps the LDS accumulator <= 32 KiB
     if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
-    if (c->batch_flags & (VAG_FLAG_SSC | VAG_FLAG_RVS))
-        return set_err(VAG_E_CAPACITY, "SSC / reverse-shock requests need nt * nnu <= 4096 per call");
-    // chunks write [nb][nnu][chunk] blocks; assemble into [nb][nnu][nt]
+    // chunks write [nb][nnu][chunk] blocks (every enabled component summed); assemble into [nb][nnu][nt]
     DevBuf tmp;
     if (tmp.ensure(sizeof(double) * (size_t)nb * nnu * chunk)) return VAG_E_HIP;
     for (int t0 = 0; t0 < nt; t0 += chunk) {
         const int n = std::min(chunk, nt - t0);
-        rc = run_flux_grid(c, d_params, nb, c->d_lg2t.as<double>() + t0, n, c->d_lg2nu.as<double>(), nnu, nullptr, tmp.as<double>());
+        rc = grid_request(c, d_params, nb, n, nnu, nullptr, tmp.as<double>(), nullptr, t0);
         if (rc) break;
         HIPCHK(hipMemcpy2DAsync(d_out + t0, sizeof(double) * nt, tmp.p, sizeof(double) * n, sizeof(double) * n,
                                 (size_t)nb * nnu, hipMemcpyDeviceToDevice, c->stream));
