@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 4
+#define VAG_ABI_VERSION 5
 
 /* error codes */
 #define VAG_OK 0
@@ -64,6 +64,9 @@ extern "C" {
 /* jet(..., spreading=True): lateral expansion of the forward shock (forward-shock.tpp:36-40,78-84,110-116), per-row time
  * lattices and per-cell solid angles (observer.cpp:51-141). */
 #define VAG_FLAG_SPREADING 32
+/* jet(..., magnetar=Magnetar(L0, t0, q)): energy injection L0 (1 + t/t0)^-q inside theta_c (src/environment/jet.h:518-527,
+ * pybind/pymodel.cpp:38-45); the jet then runs on the generic Ejecta profile forms of the reference. */
+#define VAG_FLAG_MAGNETAR 64
 
 /* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
 #define VAG_MEDIUM_ISM 0
@@ -74,7 +77,7 @@ extern "C" {
  *   Model(jet, medium, Observer(lumi_dist, z, theta_obs), Radiation(eps_e, eps_B, p, xi_e),
  *         resolutions=(phi, theta, t), rtol, axisymmetric=True, radiative_fireball)
  * (pybind/pybind.cpp:384-422, pybind/pymodel.h:613-649), flattened to plain scalars.
- * All doubles; the two tags are int32.  Layout is fixed (248 bytes) and is what the
+ * All doubles; the two tags are int32.  Layout is fixed (272 bytes) and is what the
  * device kernels read straight from HBM.
  */
 typedef struct vag_model_params {
@@ -117,6 +120,10 @@ typedef struct vag_model_params {
     double rvs_xi_e;
     double sigma0; /* ejecta magnetisation, VAG_JET_MAGNETIZED_TOPHAT only (Ejecta(sigma0=...), pybind/pybind.cpp:224-272) */
     double k_m;    /* Wind density slope rho ~ r^-k_m (pybind/pymodel.cpp:153-186); 2 = the analytic Wind class */
+    /* Magnetar(L0 [erg/s], t0 [s], q), read only with VAG_FLAG_MAGNETAR (pybind/pymodel.h:34-54) */
+    double mag_L0;
+    double mag_t0;
+    double mag_q;
 } vag_model_params;
 
 /* Fill a params struct with the reference's defaults: Radiation xi_e = 1,
@@ -236,6 +243,9 @@ int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, i
 #define VAG_P_RVS_XI_E 27
 #define VAG_P_SIGMA0 28
 #define VAG_P_K_M 29
+#define VAG_P_MAG_L0 30
+#define VAG_P_MAG_T0 31
+#define VAG_P_MAG_Q 32
 
 typedef struct vag_fit_spec {
     vag_model_params base; /* fixed parameters + numerics */

@@ -53,6 +53,53 @@ thread_local std::string g_err;
 JetVariant make_jet(const vag_model_params& p) {
     // pybind/pymodel.cpp:47-146
     const bool spreading = (p.flags & VAG_FLAG_SPREADING) != 0;
+    const bool magnetar = (p.flags & VAG_FLAG_MAGNETAR) != 0;
+    // convert_unit_jet for an Ejecta (pymodel.cpp:188-210)
+    auto convert = [](Ejecta jet) {
+        const auto eps_k_cgs = jet.eps_k;
+        jet.eps_k = [=](Real phi, Real theta) { return eps_k_cgs(phi, theta) * (unit::erg / (4 * con::pi)); };
+        const auto deps_dt_cgs = jet.deps_dt;
+        jet.deps_dt = [=](Real phi, Real theta, Real t) {
+            return deps_dt_cgs(phi, theta, t / unit::sec) * (unit::erg / (4 * con::pi * unit::sec));
+        };
+        const auto dm_dt_cgs = jet.dm_dt;
+        jet.dm_dt = [=](Real phi, Real theta, Real t) {
+            return dm_dt_cgs(phi, theta, t / unit::sec) * (unit::g / (4 * con::pi * unit::sec));
+        };
+        jet.T0 *= unit::sec;
+        return jet;
+    };
+    if (magnetar) {  // the named factories switch to the generic Ejecta when a magnetar is attached (pymodel.cpp:47-128)
+        Ejecta jet;
+        switch (p.jet_type) {
+            case VAG_JET_TOPHAT:
+                jet.eps_k = math::tophat(p.theta_c, p.E_iso);
+                jet.Gamma0 = math::tophat_plus_one(p.theta_c, p.Gamma0 - 1);
+                break;
+            case VAG_JET_GAUSSIAN:
+                jet.eps_k = math::gaussian(p.theta_c, p.E_iso);
+                jet.Gamma0 = math::gaussian_plus_one(p.theta_c, p.Gamma0 - 1);
+                break;
+            case VAG_JET_POWERLAW:
+                jet.eps_k = math::powerlaw(p.theta_c, p.E_iso, p.k_e);
+                jet.Gamma0 = math::powerlaw_plus_one(p.theta_c, p.Gamma0 - 1, p.k_g);
+                break;
+            case VAG_JET_TWO_COMPONENT:
+                jet.eps_k = math::two_component(p.theta_c, p.theta_w, p.E_iso, p.E_iso_w);
+                jet.Gamma0 = math::two_component_plus_one(p.theta_c, p.theta_w, p.Gamma0 - 1, p.Gamma0_w - 1);
+                break;
+            case VAG_JET_STEP_POWERLAW:
+                jet.eps_k = math::step_powerlaw(p.theta_c, p.E_iso, p.E_iso_w, p.k_e);
+                jet.Gamma0 = math::step_powerlaw_plus_one(p.theta_c, p.Gamma0 - 1, p.Gamma0_w - 1, p.k_g);
+                break;
+            default:
+                throw std::invalid_argument("this jet type takes no magnetar");
+        }
+        jet.spreading = spreading;
+        jet.T0 = p.duration;
+        jet.deps_dt = math::magnetar_injection(p.mag_t0, p.mag_q, p.mag_L0, p.theta_c);
+        return convert(jet);
+    }
     switch (p.jet_type) {
         case VAG_JET_TOPHAT:
             return TophatJet(p.theta_c, p.E_iso * unit::erg, p.Gamma0, spreading, p.duration * unit::sec);

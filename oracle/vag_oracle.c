@@ -108,6 +108,8 @@ typedef struct {
     double T0;
     double sigma0; /* constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise */
     int spreading; /* jet(..., spreading=True) */
+    int magnetar;  /* jet(..., magnetar=Magnetar(L0, t0, q)): the jet is built on the generic Ejecta (pymodel.cpp:47-128) */
+    double mag_L0, mag_t0, mag_q;
 } jet_t;
 
 typedef struct {
@@ -135,9 +137,39 @@ static void jet_init(jet_t* j, const vag_model_params* p) {
     j->T0 = p->duration * U_SEC;
     j->sigma0 = (p->jet_type == VAG_JET_MAGNETIZED_TOPHAT) ? p->sigma0 : 0.0;
     j->spreading = (p->flags & VAG_FLAG_SPREADING) != 0;
+    j->magnetar = (p->flags & VAG_FLAG_MAGNETAR) != 0;
+    j->mag_L0 = p->mag_L0;
+    j->mag_t0 = p->mag_t0;
+    j->mag_q = p->mag_q;
+}
+
+/* is the jet an `Ejecta` object in the reference (python-level profile forms, HasSigma / HasDedt / HasDmdt)? */
+static int jet_is_ejecta(const jet_t* j) {
+    return j->type >= VAG_JET_TWO_COMPONENT || j->magnetar;
+}
+
+/* Ejecta::deps_dt of math::magnetar_injection (jet.h:518-527) through convert_unit_jet (pymodel.cpp:196-199) */
+static double jet_deps_dt(const jet_t* j, double theta, double t) {
+    if (!j->magnetar) return 0.0;
+    double v = 0.;
+    if (theta <= j->theta_c) {
+        const double tt = 1 + (t / U_SEC) / j->mag_t0;
+        v = j->mag_L0 * fast_pow(tt, -j->mag_q);
+    }
+    return v * (U_ERG / (4 * C_PI * U_SEC));
 }
 
 static double jet_eps_k(const jet_t* j, double theta) {
+    if (j->magnetar && j->type <= VAG_JET_POWERLAW) { /* math::tophat / gaussian / powerlaw in CGS, then convert_unit_jet */
+        double h;
+        if (j->type == VAG_JET_TOPHAT)
+            h = theta < j->theta_c ? j->E_iso_cgs : 0;
+        else if (j->type == VAG_JET_GAUSSIAN)
+            h = j->E_iso_cgs * exp(theta * theta / (-2 * j->theta_c * j->theta_c));
+        else
+            h = j->E_iso_cgs / (1 + fast_pow(theta / j->theta_c, j->k_e));
+        return h * (U_ERG / (4 * C_PI));
+    }
     switch (j->type) {
         case VAG_JET_TOPHAT: return theta < j->theta_c ? j->eps_k : 0;
         case VAG_JET_GAUSSIAN: return j->eps_k * exp(theta * theta * j->norm);
@@ -157,6 +189,16 @@ static double jet_eps_k(const jet_t* j, double theta) {
 }
 
 static double jet_Gamma0(const jet_t* j, double theta) {
+    if (j->magnetar && j->type <= VAG_JET_POWERLAW) { /* math::*_plus_one(theta_c, Gamma0 - 1, ...) */
+        double h;
+        if (j->type == VAG_JET_TOPHAT)
+            h = theta < j->theta_c ? j->Gm1 : 0;
+        else if (j->type == VAG_JET_GAUSSIAN)
+            h = j->Gm1 * exp(theta * theta / (-2 * j->theta_c * j->theta_c));
+        else
+            h = j->Gm1 / (1 + fast_pow(theta / j->theta_c, j->k_g));
+        return h + 1;
+    }
     switch (j->type) {
         case VAG_JET_TOPHAT: return theta < j->theta_c ? j->Gamma0 : 1;
         case VAG_JET_GAUSSIAN: return (j->Gamma0 - 1) * exp(theta * theta * j->norm) + 1;
@@ -703,7 +745,7 @@ static double estimate_t_dec(const jet_t* jet, const medium_t* med, double theta
     const double gamma = jet_Gamma0(jet, theta);
     const double beta = gamma_to_beta(gamma);
     double m_jet = jet_eps_k(jet, theta) / (gamma * C_C2);
-    if (jet->type >= VAG_JET_TWO_COMPONENT) m_jet /= (1.0 + jet->sigma0); /* HasSigma<Ejecta> */
+    if (jet_is_ejecta(jet)) m_jet /= (1.0 + jet->sigma0); /* HasSigma<Ejecta> */
     const double target = m_jet / gamma;
     const double r_min = 1e-3;
     const double r_max = r_min * pow(10.0, 40.0);
@@ -979,8 +1021,11 @@ static double radiative_efficiency(const fwd_eqn_t* e, double t_comv, double Gam
 
 /* state: [Gamma, m2, U2_th, r, t_comv, theta]  (forward-shock.hpp:22-47) */
 static void fwd_rhs(const double* s, double* d, double t, void* vctx) {
-    (void)t;
     const fwd_eqn_t* e = vctx;
+    /* state[6] = eps_jet (ForwardState::energy_inject, forward-shock.hpp:36-44): only its derivative enters the
+     * dynamics, but the variable takes part in the step-size control */
+    const double deps_jet = jet_is_ejecta(e->jet) ? jet_deps_dt(e->jet, e->theta0, t) : 0.0;
+    d[6] = deps_jet;
     const double Gamma = s[0], m2 = s[1], U2_th = s[2], r = s[3], t_comv = s[4];
     const double u2 = (Gamma - 1) * (Gamma + 1);
     const double u = sqrt(u2);
@@ -1023,8 +1068,9 @@ static void fwd_rhs(const double* s, double* d, double t, void* vctx) {
             dlnVdt += sin_theta / (1 - cos_theta) * d[5];
             U *= f_spread;
         }
-        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_dt_swept;
+        double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_dt_swept;
         const double a2 = (ad_idx - 1) * Gamma_eff * U * dlnVdt;
+        if (jet_is_ejecta(e->jet)) a1 += deps_jet; /* energy_inject, forward-shock.tpp:89-91 */
         const double b1 = (m_jet + m_swept) * C_C2;
         const double b2 = (dGamma_eff + Gamma_eff * (ad_idx - 1) / Gamma) * U;
         d[0] = (a1 + a2) / (b1 + b2);
@@ -1079,6 +1125,7 @@ static void fwd_set_init_state(const fwd_eqn_t* e, double* s, double t0) {
     s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
     s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
     s[5] = e->theta0;
+    s[6] = jet_eps_k(e->jet, e->theta0); /* state.eps_jet, forward-shock.tpp:137-139 */
     s[1] = medium_mass(e->med, s[3]);
     s[0] = Gamma4;
     const double ad_idx = adiabatic_idx(s[0]);
@@ -1161,7 +1208,7 @@ static void save_fwd_shock_state(shock_t* sh, size_t o, const fwd_eqn_t* e, cons
 
 /* grid_solve_fwd_shock, forward-shock.tpp:175-208 */
 static int grid_solve_fwd_shock(int j, const double* t, int nt, shock_t* sh, const fwd_eqn_t* e, double rtol) {
-    double state[6];
+    double state[7];
     const double t_dec = estimate_t_dec(e->jet, e->med, e->theta0);
     const double t0 = dmin(t[0], dmin(0.1 * U_SEC, 0.1 * t_dec));
     fwd_set_init_state(e, state, t0);
@@ -1179,7 +1226,7 @@ static int grid_solve_fwd_shock(int j, const double* t, int nt, shock_t* sh, con
         return 0;
     }
     dopri5_t st;
-    dopri5_init(&st, 6, rtol, rtol, state, t0, 0.01 * t0);
+    dopri5_init(&st, 7, rtol, rtol, state, t0, 0.01 * t0);
     for (int k = 0, steps = 0; st.t <= t[nt - 1];) {
         if (dopri5_do_step(&st, fwd_rhs, (void*)e) != 0) return fail("forward shock ODE: step size underflow");
         if (++steps > DEF_MAX_ODE_STEPS) {
@@ -1226,7 +1273,7 @@ static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med
         e.theta0 = c->theta[j];
         e.theta_s = theta_s;
         e.m_jet0 = jet_eps_k(jet, e.theta0) / jet_Gamma0(jet, e.theta0) / C_C2;
-        if (jet->type >= VAG_JET_TWO_COMPONENT) e.m_jet0 /= 1 + jet->sigma0;
+        if (jet_is_ejecta(jet)) e.m_jet0 /= 1 + jet->sigma0;
         e.radiative = p->radiative_fireball != 0;
         e.eps_e = p->eps_e;
         e.eps_B = p->eps_B;
@@ -1398,8 +1445,8 @@ static void rvs_rhs(const double* raw, double* d, double t, void* vctx) {
     const double inject_w = smoothstep(e->T0 * 1.5, e->T0 * 0.5, t);
     d[RS_EPS4] = (inject_w > 1e-6) ? inject_w * e->deps0_dt : 0;
     d[RS_M4] = (inject_w > 1e-6) ? inject_w * e->dm0_dt : 0;
-    if (e->jet->type >= VAG_JET_TWO_COMPONENT) { /* python-level Ejecta: deps_dt / dm_dt are the zero functions */
-        d[RS_EPS4] += 0.0;
+    if (jet_is_ejecta(e->jet)) { /* python-level Ejecta: deps_dt = magnetar injection or zero, dm_dt the zero function */
+        d[RS_EPS4] += jet_deps_dt(e->jet, e->theta0, t);
         d[RS_M4] += 0.0;
     }
     const double Gamma34 = compute_rel_Gamma(Gamma4, Gamma);
@@ -1482,7 +1529,7 @@ static void rvs_rhs(const double* raw, double* d, double t, void* vctx) {
         const double dGamma_eff2_dGamma = (ad_idx2 * Gamma2 + ad_idx2 - 1) / Gamma2;
         const double dGamma_eff3_dGamma = (ad_idx3 * Gamma2 + ad_idx3 - 1) / Gamma2;
         double deps_dt = 0;
-        if (e->jet->type >= VAG_JET_TWO_COMPONENT) deps_dt = 0.0; /* Ejecta::deps_dt == zero function */
+        if (jet_is_ejecta(e->jet)) deps_dt = jet_deps_dt(e->jet, s[RS_THETA], t);
         const double a = (Gamma - 1) * C_C2 * d[RS_M2] + (Gamma - Gamma4) * C_C2 * d[RS_M3] + Gamma_eff2 * d[RS_U2] +
                          Gamma_eff3 * d[RS_U3] - deps_dt;
         const double b = (s[RS_M2] + s[RS_M3]) * C_C2 + dGamma_eff2_dGamma * s[RS_U2] + dGamma_eff3_dGamma * s[RS_U3];
@@ -1743,7 +1790,7 @@ static int generate_shock_pair(shock_t* fwd, shock_t* rvs, const coord_t* c, con
         e.deps0_dt = jet_eps_k(jet, e.theta0) / jet->T0;
         e.dm0_dt = e.deps0_dt / (e.Gamma4 * C_C2);
         e.u4 = sqrt(e.Gamma4 * e.Gamma4 - 1) * C_C;
-        if (jet->type >= VAG_JET_TWO_COMPONENT) e.dm0_dt /= 1 + jet->sigma0; /* HasSigma<Ejecta> */
+        if (jet_is_ejecta(jet)) e.dm0_dt /= 1 + jet->sigma0; /* HasSigma<Ejecta> */
         e.rad_fwd.med = med;
         e.rad_fwd.jet = jet;
         e.rad_fwd.radiative = p->radiative_fireball != 0;
@@ -2998,7 +3045,13 @@ int vag_oracle_params_validate(const vag_model_params* p) {
         if (!(isfinite(p->rvs_p) && p->rvs_p > 1.0)) return fail("rvs p must be > 1");
         if (!finite_pos(p->duration)) return fail("duration must be positive and finite");
     }
-    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING))
+    if (p->flags & VAG_FLAG_MAGNETAR) { /* PyMagnetar ctor, pymodel.h:45-49; PowerLawWing takes no magnetar */
+        if (!finite_pos(p->mag_L0) || !finite_pos(p->mag_t0) || !finite_pos(p->mag_q)) return fail("magnetar L0, t0, q must be positive and finite");
+        if (p->jet_type == VAG_JET_POWERLAW_WING || p->jet_type == VAG_JET_MAGNETIZED_TOPHAT)
+            return fail("this jet type takes no magnetar");
+    }
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING |
+                     VAG_FLAG_MAGNETAR))
         return fail("unknown bits set in flags");
     if (!(isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return fail("rtol must be in (0, 1)");
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))

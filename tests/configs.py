@@ -97,3 +97,15 @@ PROFILE_CASES = {
     "wind_k2.5_floor": dict(jet="GaussianJet", medium="Wind", A_star=0.1, n_ism=1e-3, n0=1e3, k_m=2.5, theta_obs=0.2),
     "wind_k1_rs_ssc": dict(medium="Wind", A_star=0.1, n_ism=0.0, k_m=1.0, ssc=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
 }
+
+MAG = (1e47, 1e4, 2.0)
+MAGNETAR_CASES = {
+    "tophat_mag": dict(magnetar=MAG),
+    "gauss_mag_offaxis": dict(jet="GaussianJet", theta_obs=0.2, magnetar=MAG),
+    "powerlaw_mag_wind": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.2, magnetar=(3e46, 3e3, 1.5)),
+    "two_comp_mag": dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, theta_obs=0.15, magnetar=MAG),
+    "step_mag_spread": dict(jet="StepPowerLawJet", theta_c=0.05, E_iso_w=3e51, Gamma0_w=100.0, k_e=3.0, k_g=2.0, theta_obs=0.1,
+                            spreading=True, magnetar=MAG),
+    "tophat_mag_rs": dict(magnetar=MAG, duration=100.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+    "tophat_mag_ssc": dict(magnetar=MAG, ssc=True, kn=True),
+}

@@ -35,19 +35,19 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert lib.vag_abi_version() == 4
+    assert lib.vag_abi_version() == 5
     assert b"gfx950" in lib.vag_version()
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(_lib.ModelParams) == 248 == C.sizeof(_abi.ModelParams)
+    assert C.sizeof(_lib.ModelParams) == 272 == C.sizeof(_abi.ModelParams)
     assert _lib.ModelParams.theta_c.offset == 8 and _lib.ModelParams.rtol.offset == 184
     # VAG_P_* slots index the doubles that follow the two int32 tags
     for key, slot in _lib.PARAM_SLOTS.items():
         field = {"tau": "duration", "theta_v": "theta_obs", "eps_e_r": "rvs_eps_e", "eps_B_r": "rvs_eps_B", "p_r": "rvs_p",
-                 "xi_e_r": "rvs_xi_e"}.get(key, key)
+                 "xi_e_r": "rvs_xi_e", "L0": "mag_L0", "t0": "mag_t0", "q": "mag_q"}.get(key, key)
         assert getattr(_lib.ModelParams, field).offset == 8 + 8 * slot, key
-    assert C.sizeof(_lib.FitSpec) == 248 + 4 + 64 + 64 + 8 + 5 * 8 + 4  # base, ndim, slot, is_log, n_data+pad, 5 ptrs (+align)
+    assert C.sizeof(_lib.FitSpec) == 272 + 4 + 64 + 64 + 8 + 5 * 8 + 4  # base, ndim, slot, is_log, n_data+pad, 5 ptrs (+align)
 
 
 def test_defaults_and_validation_through_the_c_abi(lib):

@@ -639,3 +639,20 @@ def test_long_time_axis_is_chunked_for_every_tier(eng, oracle):
     prm = _abi.make_params(theta_obs=0.1, duration=100.0, ssc=True, kn=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True))
     t, nu = np.logspace(1, 7, 1500), np.array([1e9, 1e14, 1e17, 1e22])
     assert_close(gpu_grid(eng, prm, t, nu)[0], oracle.flux_density_grid(prm, t, nu))
+
+
+@pytest.mark.parametrize("name", list(configs.MAGNETAR_CASES))
+def test_magnetar_matches_oracle(eng, oracle, name):
+    prm = _abi.make_params(**configs.MAGNETAR_CASES[name])
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    want = oracle.flux_components4(prm, t, nu)
+    got = gpu_components4(eng, prm, t, nu)
+    for g_, w, comp in zip(got, want, COMPONENTS):
+        if w.max() == 0:
+            assert np.all(g_[0] == 0), comp
+        else:
+            assert_close(g_[0], w, rtol=5e-6)
+    if name == "gauss_mag_offaxis":
+        m = va.Model(va.GaussianJet(0.1, 1e52, 300.0, magnetar=va.Magnetar(*configs.MAG)), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2),
+                     va.Radiation(0.1, 0.01, 2.3))
+        assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)

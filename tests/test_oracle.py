@@ -393,3 +393,15 @@ def test_oracle_remaining_profiles_bit_identical_to_strict_reference_build(oracl
     t, nu = configs.SPREAD_T, configs.SPREAD_NU
     a, b = oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].max() > 0
+
+
+@pytest.mark.parametrize("name", list(configs.MAGNETAR_CASES))
+def test_oracle_magnetar_bit_identical_to_strict_reference_build(oracle, ref_strict, name):
+    """jet(..., magnetar=Magnetar(L0, t0, q)): generic-Ejecta profile forms + energy injection in both ODE systems."""
+    prm = _abi.make_params(**configs.MAGNETAR_CASES[name])
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    a, b = oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    if name == "tophat_mag":  # the injection re-brightens the late light curve
+        plain = oracle.flux_density_grid(_abi.make_params(), t, nu)
+        assert 1.1 < (a[0] / plain)[1, 20] < 1.3

@@ -4,9 +4,9 @@ Drop-in names for the accelerated path of the reference's Python API
 (``Model.flux_density_grid / flux_density / flux`` and the batched log-likelihood).
 """
 from . import _lib
-from .model import (ISM, Flux, FluxDict, GaussianJet, MagnetizedTophatJet, Model, Observer, PowerLawJet, PowerLawWing,
+from .model import (ISM, Flux, FluxDict, GaussianJet, Magnetar, MagnetizedTophatJet, Model, Observer, PowerLawJet, PowerLawWing,
                     Radiation, StepPowerLawJet, TophatJet, TwoComponentJet, Wind, get_context)
 
-__all__ = ["ISM", "Wind", "TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing", "MagnetizedTophatJet", "Observer", "Radiation",
+__all__ = ["ISM", "Wind", "TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing", "MagnetizedTophatJet", "Magnetar", "Observer", "Radiation",
            "Model", "Flux", "FluxDict", "get_context"]
 __version__ = "0.1.0"

@@ -14,7 +14,7 @@ JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY, VAG_E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
-FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING = 1, 2, 4, 8, 16, 32  # VAG_FLAG_* of include/vegasafterglow_amd.h
+FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING, FLAG_MAGNETAR = 1, 2, 4, 8, 16, 32, 64  # VAG_FLAG_* of include/vegasafterglow_amd.h
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
 PARAM_SLOTS = {
@@ -22,7 +22,7 @@ PARAM_SLOTS = {
     "tau": 8, "duration": 8, "n_ism": 9, "A_star": 10, "n0": 11, "lumi_dist": 12, "z": 13, "theta_v": 14,
     "theta_obs": 14, "eps_e": 15, "eps_B": 16, "p": 17, "xi_e": 18,
     "eps_e_r": 24, "eps_B_r": 25, "p_r": 26, "xi_e_r": 27,  # VAG_P_RVS_*: rvs_rad of Fitter(rvs_shock=True)
-    "sigma0": 28, "k_m": 29,
+    "sigma0": 28, "k_m": 29, "L0": 30, "t0": 31, "q": 32,
 }
 
 
@@ -39,6 +39,7 @@ class ModelParams(C.Structure):
         ("radiative_fireball", C.c_int32), ("flags", C.c_int32),
         ("rvs_eps_e", C.c_double), ("rvs_eps_B", C.c_double), ("rvs_p", C.c_double), ("rvs_xi_e", C.c_double),
         ("sigma0", C.c_double), ("k_m", C.c_double),
+        ("mag_L0", C.c_double), ("mag_t0", C.c_double), ("mag_q", C.c_double),
     ]
 
 

@@ -165,7 +165,12 @@ static const char* validate_msg(const vag_model_params* p) {
     if (!(std::isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return "rtol must be in (0, 1)";
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
         return "resolutions must be positive and finite";
-    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING))
+    if (p->flags & VAG_FLAG_MAGNETAR) {  // PyMagnetar ctor, pymodel.h:45-49
+        if (!finite_pos(p->mag_L0) || !finite_pos(p->mag_t0) || !finite_pos(p->mag_q)) return "magnetar L0, t0, q must be positive and finite";
+        if (p->jet_type == VAG_JET_POWERLAW_WING || p->jet_type == VAG_JET_MAGNETIZED_TOPHAT) return "this jet type takes no magnetar";
+    }
+    if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING |
+                     VAG_FLAG_MAGNETAR))
         return "unknown bits set in flags";
     if (p->flags & VAG_FLAG_RVS) {  // rvs_rad is a Radiation too (pymodel.h:241-260)
         if (!range_oi(p->rvs_eps_e, 0.0, 1.0)) return "rvs eps_e must be in (0, 1]";
@@ -588,14 +593,13 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
                            c->d_inj.as<int>(), c->d_row_status.as<int>());
-    } else if (spreading) {
-        hipLaunchKernelGGL(vag_dynamics_kernel<true>, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
-                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
     } else {
-        hipLaunchKernelGGL(vag_dynamics_kernel<false>, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
-                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
+        const bool inject = (c->batch_flags & VAG_FLAG_MAGNETAR) != 0;
+        auto kern = spreading ? (inject ? vag_dynamics_kernel<true, true> : vag_dynamics_kernel<true, false>)
+                              : (inject ? vag_dynamics_kernel<false, true> : vag_dynamics_kernel<false, false>);
+        hipLaunchKernelGGL(kern, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
+                           c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
+                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
     }
     HIPCHK(hipGetLastError());
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
@@ -1263,7 +1267,7 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     const int n = spec->n_data;
     if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
     for (int d = 0; d < ndim; ++d)
-        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_K_M)))
+        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_MAG_Q)))
             return set_err(VAG_E_INVALID, "bad parameter slot");
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");

@@ -85,6 +85,8 @@ struct Jet {
     double theta_c, eps_k, Gamma0, k_e, k_g, norm;
     double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w, T0;
     double sigma0;  // constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise
+    int magnetar;   // jet(..., magnetar=Magnetar(L0, t0, q)): generic-Ejecta profile forms + energy injection
+    double mag_L0, mag_t0, mag_q;
 };
 struct Medium {
     int type;
@@ -108,8 +110,28 @@ VAG_DEV void jet_init(Jet& j, const vag_model_params& p) {
     j.Gm1_w = p.Gamma0_w - 1;
     j.T0 = p.duration * U_SEC;
     j.sigma0 = (p.jet_type == VAG_JET_MAGNETIZED_TOPHAT) ? p.sigma0 : 0.0;
+    j.magnetar = (p.flags & VAG_FLAG_MAGNETAR) != 0;
+    j.mag_L0 = p.mag_L0;
+    j.mag_t0 = p.mag_t0;
+    j.mag_q = p.mag_q;
+}
+// Ejecta::deps_dt of math::magnetar_injection (jet.h:518-527) through convert_unit_jet (pymodel.cpp:196-199)
+VAG_DEV double jet_deps_dt(const Jet& j, double theta, double t) {
+    if (!j.magnetar || !(theta <= j.theta_c)) return 0.0;
+    const double tt = 1 + (t / U_SEC) / j.mag_t0;
+    return j.mag_L0 * exp2_sat(-j.mag_q * log2_fast(tt)) * (U_ERG / (4 * C_PI * U_SEC));
 }
 VAG_DEV double jet_eps_k(const Jet& j, double theta) {
+    if (j.magnetar && j.type <= VAG_JET_POWERLAW) {  // math::tophat / gaussian / powerlaw in CGS, then convert_unit_jet
+        double h;
+        if (j.type == VAG_JET_TOPHAT)
+            h = theta < j.theta_c ? j.E_iso_cgs : 0;
+        else if (j.type == VAG_JET_GAUSSIAN)
+            h = j.E_iso_cgs * exp(theta * theta / (-2 * j.theta_c * j.theta_c));
+        else
+            h = j.E_iso_cgs / (1 + fast_pow(theta / j.theta_c, j.k_e));
+        return h * (U_ERG / (4 * C_PI));
+    }
     switch (j.type) {
         case VAG_JET_TOPHAT: return theta < j.theta_c ? j.eps_k : 0;
         case VAG_JET_GAUSSIAN: return j.eps_k * exp(theta * theta * j.norm);
@@ -126,6 +148,16 @@ VAG_DEV double jet_eps_k(const Jet& j, double theta) {
     }
 }
 VAG_DEV double jet_Gamma0(const Jet& j, double theta) {
+    if (j.magnetar && j.type <= VAG_JET_POWERLAW) {  // math::*_plus_one(theta_c, Gamma0 - 1, ...)
+        double h;
+        if (j.type == VAG_JET_TOPHAT)
+            h = theta < j.theta_c ? j.Gm1 : 0;
+        else if (j.type == VAG_JET_GAUSSIAN)
+            h = j.Gm1 * exp(theta * theta / (-2 * j.theta_c * j.theta_c));
+        else
+            h = j.Gm1 / (1 + fast_pow(theta / j.theta_c, j.k_g));
+        return h + 1;
+    }
     switch (j.type) {
         case VAG_JET_TOPHAT: return theta < j.theta_c ? j.Gamma0 : 1;
         case VAG_JET_GAUSSIAN: return (j.Gamma0 - 1) * exp(theta * theta * j.norm) + 1;
@@ -218,6 +250,9 @@ VAG_DEV bool params_valid(const vag_model_params& p) {
     ok = ok && oi(p.eps_e, 0.0, 1.0) && oi(p.eps_B, 0.0, 1.0) && oi(p.xi_e, 0.0, 1.0) && isfinite(p.p) && p.p > 1.0;
     ok = ok && isfinite(p.rtol) && p.rtol > 0 && p.rtol < 1 && fpos(p.phi_resol) && fpos(p.theta_resol) && fpos(p.t_resol);
     if (p.jet_type == VAG_JET_MAGNETIZED_TOPHAT) ok = ok && isfinite(p.sigma0) && p.sigma0 >= 0;
+    if (p.flags & VAG_FLAG_MAGNETAR)
+        ok = ok && fpos(p.mag_L0) && fpos(p.mag_t0) && fpos(p.mag_q) && p.jet_type != VAG_JET_POWERLAW_WING &&
+             p.jet_type != VAG_JET_MAGNETIZED_TOPHAT;
     if (p.flags & VAG_FLAG_RVS)
         ok = ok && oi(p.rvs_eps_e, 0.0, 1.0) && oi(p.rvs_eps_B, 0.0, 1.0) && oi(p.rvs_xi_e, 0.0, 1.0) && isfinite(p.rvs_p) &&
              p.rvs_p > 1.0;
@@ -427,16 +462,23 @@ struct TimeLattice {
 };
 
 // ---- forward-shock blast wave: src/dynamics/forward-shock.tpp:10-173, shock-physics.h ----
-template <bool SPREAD = false>
+template <bool SPREAD = false, bool INJECT = false>
 struct FwdShock {
     Medium med;
     double m_jet0, gamma_m_coeff, gamma_c_coeff, eps_e_eff, p, eps_B;
     double theta_s, dOmega0;  // SPREAD: jet_spreading_edge (grid-refinement.h:113-135), 1 - cos(theta0)
+    double inj_L, inj_t0, inj_q;  // INJECT: magnetar luminosity per solid angle in code units (0 outside theta_c), t0 [code], q
+    static constexpr int IDX_EPS = 5 + (SPREAD ? 1 : 0);  // eps_jet follows theta in the state vector
 
     // state [Gamma, m2, U2_th, r, t_comv (, theta)]; theta is constant for non-spreading jets and its zero derivative
     // never contributes to the error norm, so it is only integrated when the jet spreads (forward-shock.tpp:36-40).
-    VAG_DEV void operator()(const double* s, double* d, double /*t*/) const {
+    VAG_DEV void operator()(const double* s, double* d, double t) const {
         const double Gamma = s[0], m2 = s[1], U = s[2], r = s[3], t_comv = s[4];
+        double deps_jet = 0;
+        if constexpr (INJECT) {  // ForwardState::eps_jet (forward-shock.hpp:36-44): d eps_jet / dt = deps_dt(t)
+            deps_jet = inj_L * exp2_sat(-inj_q * log2_fast(1 + t * inj_t0));
+            d[IDX_EPS] = deps_jet;
+        }
         const double u2 = (Gamma - 1) * (Gamma + 1);
         const double u = sqrt_fast(u2);
         const double dr = u * (Gamma + u) * C_C;
@@ -479,7 +521,7 @@ struct FwdShock {
             dlnV += sin_th * rcp_fast(1 - cos_th) * dth;
             Ueff = U * f_spread;
         }
-        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_swept;
+        const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_swept + deps_jet;  // energy_inject, forward-shock.tpp:89-91
         const double a2 = (ad - 1) * Gamma_eff * Ueff * dlnV;
         const double b1 = (m_jet0 + m_swept) * C_C2;
         const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * Ueff;

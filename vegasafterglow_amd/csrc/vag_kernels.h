@@ -29,7 +29,7 @@ VAG_DEV int find_model(const int* off, int nb, int idx) {  // largest m with off
 // (src/dynamics/forward-shock.tpp:175-208) with the lattice generated on the fly, state saved through
 // save_fwd_shock_state (forward-shock.tpp:151-173).  shock[VS_*] are SoA arrays over cells.
 // ------------------------------------------------------------------------------------------------
-template <bool SPREAD>
+template <bool SPREAD, bool INJECT>
 __global__ void __launch_bounds__(64)
 vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
@@ -45,7 +45,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
-    FwdShock<SPREAD> eq;
+    FwdShock<SPREAD, INJECT> eq;
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
     const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
@@ -74,7 +74,10 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     eq.eps_B = P.eps_B;
     eq.theta_s = 0;
     eq.dOmega0 = 1 - cos(theta0);
-    constexpr int NS = SPREAD ? 6 : 5;
+    eq.inj_L = (theta0 <= jet.theta_c) ? P.mag_L0 * (U_ERG / (4 * C_PI * U_SEC)) : 0.0;  // math::magnetar_injection, jet.h:518-527
+    eq.inj_t0 = 1 / (P.mag_t0 * U_SEC);
+    eq.inj_q = P.mag_q;
+    constexpr int NS = 5 + (SPREAD ? 1 : 0) + (INJECT ? 1 : 0);
     if constexpr (SPREAD) {  // jet_spreading_edge over [theta.front(), theta.back()], grid-refinement.h:113-135
         const double th_min = g_theta[(size_t)m * VAG_MAX_THETA], th_max = g_theta[(size_t)m * VAG_MAX_THETA + M.n_theta - 1];
         const double step = (th_max - th_min) / 256;
@@ -96,6 +99,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     // set_init_state, forward-shock.tpp:120-149
     double s[NS];
     if constexpr (SPREAD) s[5] = theta0;
+    if constexpr (INJECT) s[FwdShock<SPREAD, INJECT>::IDX_EPS] = jet_eps_k(jet, theta0);  // state.eps_jet, forward-shock.tpp:137-139
     const double beta4 = gamma_to_beta(Gamma4);
     s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
     s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;

@@ -139,6 +139,7 @@ struct PairShock {
     double gamma_m_coeff, gamma_c_coeff, eps_e_eff, p;  // RadiativeEfficiency(rad_fwd)
     double cs4;                                         // sound speed of the unshocked shell (constant)
     double beta4;
+    double inj_L, inj_t0, inj_q;                        // magnetar injection (0 when off / outside theta_c), cf. FwdShock
 
     VAG_DEV double shell_sigma(const double* s) const {
         const double sigma = s[RS_EPS4] / (Gamma4 * s[RS_M4] * C_C2) - 1;
@@ -163,7 +164,9 @@ struct PairShock {
         const double dm2 = r * r * rho * dr;
         d[RS_M2] = dm2;
         const double inject_w = smoothstep(T0 * 1.5, T0 * 0.5, t);
-        const double deps4 = (inject_w > 1e-6) ? inject_w * deps0_dt : 0;
+        // ejecta.deps_dt (magnetar) feeds region 4 and the energy balance (reverse-shock.tpp:84-86,228-230)
+        const double deps_inj = (inj_L != 0) ? inj_L * exp2_sat(-inj_q * log2_fast(1 + t * inj_t0)) : 0.0;
+        const double deps4 = ((inject_w > 1e-6) ? inject_w * deps0_dt : 0) + deps_inj;
         const double dm4 = (inject_w > 1e-6) ? inject_w * dm0_dt : 0;
         d[RS_EPS4] = deps4;
         d[RS_M4] = dm4;
@@ -242,7 +245,7 @@ struct PairShock {
             const double G2 = Gamma * Gamma;
             const double Geff2 = (ad2 * G2 - ad2 + 1) / Gamma, Geff3 = (ad3 * G2 - ad3 + 1) / Gamma;
             const double dGeff2 = (ad2 * G2 + ad2 - 1) / G2, dGeff3 = (ad3 * G2 + ad3 - 1) / G2;
-            const double a = (Gamma - 1) * C_C2 * dm2 + (Gamma - Gamma4) * C_C2 * dm3 + Geff2 * dU2 + Geff3 * dU3;
+            const double a = (Gamma - 1) * C_C2 * dm2 + (Gamma - Gamma4) * C_C2 * dm3 + Geff2 * dU2 + Geff3 * dU3 - deps_inj;
             const double b = (m2 + m3) * C_C2 + dGeff2 * U2 + dGeff3 * U3;
             const double q = -a / b;
             d[RS_GAMMA] = (b == 0 || isnan(q) || isinf(q)) ? 0 : q;

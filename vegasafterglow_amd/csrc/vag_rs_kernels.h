@@ -77,6 +77,9 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     eq.gamma_c_coeff = 6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B);
     eq.eps_e_eff = P.radiative_fireball ? P.eps_e : 0;
     eq.p = P.p;
+    eq.inj_L = (jet.magnetar && theta0 <= jet.theta_c) ? P.mag_L0 * (U_ERG / (4 * C_PI * U_SEC)) : 0.0;
+    eq.inj_t0 = jet.magnetar ? 1 / (P.mag_t0 * U_SEC) : 0.0;
+    eq.inj_q = P.mag_q;
     eq.cs4 = sound_speed(eq.Gamma4);
     eq.beta4 = gamma_to_beta(eq.Gamma4);
     const double eps_e_th = P.radiative_fireball ? P.eps_e : 0.0;

@@ -48,7 +48,7 @@ class ParamDef:
 MODEL_PARAM_DEFAULTS = dict(theta_v=0.0, n_ism=0.0, n0=math.inf, A_star=0.0, k_m=2.0, E_iso=1e52, Gamma0=300.0,
                             theta_c=0.1, k_e=2.0, k_g=2.0, tau=1.0, E_iso_w=1e52, Gamma0_w=300.0,
                             theta_w=math.pi / 2, p=2.3, eps_e=0.1, eps_B=0.01, xi_e=1.0,
-                            p_r=2.3, eps_e_r=0.1, eps_B_r=0.01, xi_e_r=1.0)
+                            p_r=2.3, eps_e_r=0.1, eps_B_r=0.01, xi_e_r=1.0, L0=0.0, t0=1.0, q=2.0)
 
 _dp = C.POINTER(C.c_double)
 
@@ -59,8 +59,7 @@ class Fitter:
     def __init__(self, z, lumi_dist, jet="tophat", medium="ism", resolution=None, rtol=1e-6,
                  radiative_fireball=True, device=0, fwd_ssc=False, kn=False, rvs_shock=False, rvs_ssc=False,
                  magnetar=False):
-        if magnetar:
-            raise NotImplementedError("magnetar injection is not on the accelerated path")
+        self.magnetar = bool(magnetar)
         if rvs_ssc and not rvs_shock:
             rvs_ssc = False  # the reference only builds rvs_rad when rvs_shock is on (fitter.py:476-484)
         self.fwd_ssc, self.kn, self.rvs_shock, self.rvs_ssc = bool(fwd_ssc), bool(kn), bool(rvs_shock), bool(rvs_ssc)
@@ -132,6 +131,11 @@ class Fitter:
         p.rtol = self.rtol
         p.radiative_fireball = 1 if self.radiative_fireball else 0
         p.flags = (_lib.FLAG_SSC if self.fwd_ssc else 0) | (_lib.FLAG_KN if self.kn else 0)  # fitter.py:466-473
+        if self.magnetar:  # fitting/utils.py:47-52: magnetar=Magnetar(L0, t0, q) on the jets that support it
+            if self.jet == "powerlaw_wing":
+                raise ValueError("powerlaw_wing takes no magnetar")
+            p.flags |= _lib.FLAG_MAGNETAR
+            p.mag_L0, p.mag_t0, p.mag_q = vals["L0"], vals["t0"], vals["q"]
         if self.rvs_shock:  # fitter.py:476-484: rvs_rad = Radiation(eps_e_r, eps_B_r, p_r, xi_e_r, ssc=rvs_ssc, kn=kn)
             p.flags |= _lib.FLAG_RVS | (_lib.FLAG_RVS_SSC if self.rvs_ssc else 0) | (_lib.FLAG_RVS_KN if self.kn else 0)
             p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e = vals["eps_e_r"], vals["eps_B_r"], vals["p_r"], vals["xi_e_r"]

@@ -33,6 +33,19 @@ class _Jet:
         raise NotImplementedError
 
 
+class Magnetar:
+    """Magnetar(L0, t0, q=2): energy injection L0 (1 + t / t0)^-q inside theta_c -- pybind.cpp:198-203, pymodel.h:34-54."""
+
+    def __init__(self, L0, t0, q=2.0):
+        _finite_pos("L0", L0)
+        _finite_pos("t0", t0)
+        _finite_pos("q", q)
+        self.L0, self.t0, self.q = float(L0), float(t0), float(q)
+
+    def __repr__(self):
+        return f"Magnetar(L0={self.L0:.6g}, t0={self.t0:.6g}, q={self.q:.6g})"
+
+
 class TophatJet(_Jet):
     """TophatJet(theta_c, E_iso, Gamma0, spreading=False, duration=1, magnetar=None) -- pybind.cpp:205."""
     jet_type = _lib.JET_TOPHAT
@@ -42,10 +55,10 @@ class TophatJet(_Jet):
         _finite_pos("E_iso", E_iso)
         _req(math.isfinite(Gamma0) and Gamma0 > 1, f"Gamma0 must be > 1, got {Gamma0}")
         _finite_pos("duration", duration)
-        if magnetar is not None:
-            raise NotImplementedError("magnetar injection is outside the MI355X hot path")
+        if magnetar is not None and not isinstance(magnetar, Magnetar):
+            raise TypeError("magnetar must be a Magnetar")
         self.theta_c, self.E_iso, self.Gamma0, self.duration = float(theta_c), float(E_iso), float(Gamma0), float(duration)
-        self.spreading = bool(spreading)
+        self.spreading, self.magnetar = bool(spreading), magnetar
 
     def _fill(self, p):
         p.jet_type = self.jet_type
@@ -284,6 +297,10 @@ class Model:
         p.flags = (_lib.FLAG_SSC if fwd_rad.ssc else 0) | (_lib.FLAG_KN if fwd_rad.kn else 0)
         if getattr(jet, "spreading", False):
             p.flags |= _lib.FLAG_SPREADING
+        mag = getattr(jet, "magnetar", None)
+        if mag is not None:
+            p.flags |= _lib.FLAG_MAGNETAR
+            p.mag_L0, p.mag_t0, p.mag_q = mag.L0, mag.t0, mag.q
         if rvs_rad is not None:
             p.flags |= _lib.FLAG_RVS | (_lib.FLAG_RVS_SSC if rvs_rad.ssc else 0) | (_lib.FLAG_RVS_KN if rvs_rad.kn else 0)
             p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e = rvs_rad.eps_e, rvs_rad.eps_B, rvs_rad.p, rvs_rad.xi_e
