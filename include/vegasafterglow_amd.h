@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 5
+#define VAG_ABI_VERSION 6
 
 /* error codes */
 #define VAG_OK 0
@@ -247,18 +247,40 @@ int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, i
 #define VAG_P_MAG_T0 31
 #define VAG_P_MAG_Q 32
 
+/* Not a Model field: the host-galaxy extinction A_V of ModelParams (types.py:77).  A free parameter with this slot only
+ * scales the point-data model fluxes by exp(-A_V * ext_kernel[i]) (fitter.py:512-519). */
+#define VAG_P_A_V 1000
+
+/* One band-integrated data group of Fitter.add_flux (fitter.py:316-377): Model.flux(t, nu_min, nu_max, num_points) is
+ * evaluated as its own request (own grid from its own time range), exactly like the reference's loop (fitter.py:524-531). */
+typedef struct vag_band_obs {
+    double nu_min, nu_max;  /* [Hz] */
+    int32_t num_points;     /* Boole nodes across the band */
+    int32_t n;              /* observations */
+    const double* t;        /* [n] ascending [s] */
+    const double* ln_flux;  /* [n] ln F_obs [erg/cm^2/s] */
+    const double* ln_err;   /* [n] err / F_obs */
+    const double* weight;   /* [n] */
+} vag_band_obs;
+
 typedef struct vag_fit_spec {
     vag_model_params base; /* fixed parameters + numerics */
     int32_t ndim;          /* number of free parameters (<= 16) */
     int32_t slot[16];      /* VAG_P_* target of each free parameter */
     int32_t is_log[16];    /* 1: value = 10**theta */
-    int32_t n_data;        /* number of point observations */
+    int32_t n_data;        /* number of point observations (may be 0 when only band data is fitted) */
     int32_t pad;
     const double* t;        /* [n_data] observer times, ascending [s] */
     const double* nu;       /* [n_data] frequencies [Hz] */
     const double* ln_flux;  /* [n_data] ln F_obs */
     const double* ln_err;   /* [n_data] err/F_obs */
     const double* weight;   /* [n_data] normalised weights */
+    /* ABI v6 */
+    const double* ext_kernel;   /* [n_data] 0.4 ln10 k(lambda_rest) of the extinction law, or NULL (fitter.py:439-449) */
+    double a_v_fixed;           /* A_V when it is not a free parameter (0 = no extinction) */
+    int32_t n_bands;            /* band-integrated groups */
+    int32_t pad2;
+    const vag_band_obs* bands;  /* [n_bands] */
 } vag_fit_spec;
 
 /* theta is [nb][ndim] (host); out is [nb] log-likelihoods (host).  Walkers whose

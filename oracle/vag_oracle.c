@@ -3498,27 +3498,51 @@ int vag_oracle_details_rvs(const vag_model_params* p, double t_min, double t_max
 int vag_oracle_loglike_batch(const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {
     if (ndim != spec->ndim || ndim > 16) return fail("ndim mismatch");
     const int n = spec->n_data;
-    double* F = malloc(sizeof(double) * (n > 0 ? n : 1));
+    int nmax = n > 0 ? n : 1;
+    for (int g = 0; g < spec->n_bands; ++g)
+        if (spec->bands[g].n > nmax) nmax = spec->bands[g].n;
+    double* F = malloc(sizeof(double) * nmax);
     for (int b = 0; b < nb; ++b) {
         vag_model_params p = spec->base;
         double* fields = &p.theta_c;
+        double a_v = spec->a_v_fixed;
         for (int d = 0; d < ndim; ++d) {
             const double v = theta[(size_t)b * ndim + d];
-            fields[spec->slot[d]] = spec->is_log[d] ? pow(10.0, v) : v;
-        }
-        if (vag_oracle_flux_density(&p, spec->t, spec->nu, n, F) != 0) {
-            out[b] = -INFINITY;
-            continue;
+            const double val = spec->is_log[d] ? pow(10.0, v) : v;
+            if (spec->slot[d] == VAG_P_A_V)
+                a_v = val;
+            else
+                fields[spec->slot[d]] = val;
         }
         double chi2 = 0;
-        for (int i = 0; i < n; ++i) {
-            const double f = F[i];
-            const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300); /* np.maximum propagates NaN */
-            const double diff = spec->ln_flux[i] - log(fm);
-            const double q = diff / spec->ln_err[i];
-            chi2 += spec->weight[i] * (q * q);
+        int bad = 0;
+        if (n > 0) { /* point data, fitter.py:510-522 */
+            if (vag_oracle_flux_density(&p, spec->t, spec->nu, n, F) != 0) bad = 1;
+            for (int i = 0; i < n && !bad; ++i) {
+                double f = F[i];
+                if (spec->ext_kernel && a_v != 0.0) f = f * exp(-a_v * spec->ext_kernel[i]);
+                const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300); /* np.maximum propagates NaN */
+                const double diff = spec->ln_flux[i] - log(fm);
+                const double q = diff / spec->ln_err[i];
+                chi2 += spec->weight[i] * (q * q);
+            }
         }
-        out[b] = isfinite(chi2) ? -0.5 * chi2 : -INFINITY;
+        for (int g = 0; g < spec->n_bands && !bad; ++g) { /* band-integrated groups, fitter.py:524-531 */
+            const vag_band_obs* bd = &spec->bands[g];
+            if (vag_oracle_flux(&p, bd->t, bd->n, bd->nu_min, bd->nu_max, bd->num_points, F) != 0) {
+                bad = 1;
+                break;
+            }
+            double c2 = 0;
+            for (int i = 0; i < bd->n; ++i) {
+                const double f = F[i];
+                const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300);
+                const double q = (bd->ln_flux[i] - log(fm)) / bd->ln_err[i];
+                c2 += bd->weight[i] * (q * q);
+            }
+            chi2 += c2;
+        }
+        out[b] = (!bad && isfinite(chi2)) ? -0.5 * chi2 : -INFINITY;
     }
     free(F);
     return 0;

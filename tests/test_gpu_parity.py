@@ -656,3 +656,42 @@ def test_magnetar_matches_oracle(eng, oracle, name):
         m = va.Model(va.GaussianJet(0.1, 1e52, 300.0, magnetar=va.Magnetar(*configs.MAG)), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2),
                      va.Radiation(0.1, 0.01, 2.3))
         assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)
+
+
+def test_loglike_with_band_groups_extinction_and_python_fitter(eng, oracle):
+    """vag_loglike_batch with band-integrated groups (own grid per group), extinction and a free A_V against the checker,
+    then the same through Fitter.add_flux / extinction= / ParamDef("A_V")."""
+    import test_oracle
+    lib, h = eng
+    kw = dict(jet="GaussianJet", z=0.5, lumi_dist=3e27)
+    rng = np.random.default_rng(2)
+    for with_points in (True, False):
+        spec, keep = test_oracle._band_spec(kw, with_points=with_points)
+        theta = np.column_stack([rng.uniform(51.5, 52.8, 6), rng.uniform(0.0, 0.3, 6), rng.uniform(0.0, 1.0, 6)])
+        want = test_oracle.oracle_loglike(spec, theta)
+        got = np.empty(6)
+        _lib.check(lib.vag_loglike_batch(h, C.byref(spec), theta.ctypes.data_as(dp), 6, 3, got.ctypes.data_as(dp)))
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+    # Python mirror
+    f = fitting.Fitter(z=0.5, lumi_dist=3e27, jet="gaussian", medium="ism", extinction=lambda lam: (5.5e-5 / lam) ** 1.1)
+    spec, keep = test_oracle._band_spec(kw)
+    t, nu, lnf, lne, w, ext = keep["pts"]
+    f.add_flux_density(nu, t, np.exp(lnf), lne * np.exp(lnf))
+    for g in range(2):
+        tb, lnfb, lneb, wb = keep[f"b{g}"]
+        bd = keep["bands"][g]
+        f.add_flux((bd.nu_min, bd.nu_max), tb, np.exp(lnfb), lneb * np.exp(lnfb), num_points=bd.num_points)
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e51, 1e53, S.log), P("theta_v", 0.0, 0.4, S.linear), P("A_V", 0.0, 2.0, S.linear),
+            P("n_ism", 1.0, 1.0, S.fixed, 1.0)]
+    theta = np.array([[52.3, 0.15, 0.4], [51.8, 0.05, 0.0]])
+    ll = f.loglike_batch(theta, defs)
+    f._consolidate_data()
+    for b, (lgE, thv, av) in enumerate(theta):
+        prm = _abi.make_params(**{**kw, "E_iso": 10 ** lgE, "theta_obs": thv})
+        F = oracle.flux_density(prm, f._all_t, f._all_nu) * np.exp(-av * f._ext_kernel)
+        chi2 = np.sum(f._all_weights * ((f._all_log_flux - np.log(np.maximum(F, 1e-300))) / f._all_log_err) ** 2)  # fitter.py:499
+        for bd in f._band_obs:
+            Fb = oracle.flux(prm, bd["t"], bd["nu_min"], bd["nu_max"], bd["num_points"])
+            chi2 += np.sum(bd["weights"] * ((bd["ln_flux"] - np.log(Fb)) / bd["ln_err"]) ** 2)
+        assert abs(ll[b] + 0.5 * chi2) <= 2e-6 * abs(chi2), (b, ll[b], -0.5 * chi2)

@@ -405,3 +405,66 @@ def test_oracle_magnetar_bit_identical_to_strict_reference_build(oracle, ref_str
     if name == "tophat_mag":  # the injection re-brightens the late light curve
         plain = oracle.flux_density_grid(_abi.make_params(), t, nu)
         assert 1.1 < (a[0] / plain)[1, 20] < 1.3
+
+
+def _band_spec(prm_kw, with_points=True):
+    """A vag_fit_spec with point data + two band groups + an extinction kernel, built directly on the C-ABI structs."""
+    import ctypes as C
+    from vegasafterglow_amd import _lib
+    rng = np.random.default_rng(9)
+    keep = {}
+    spec = _lib.FitSpec()
+    spec.base = _lib.ModelParams.from_buffer_copy(bytes(_abi.make_params(**prm_kw)))
+    spec.ndim = 3
+    for d, (name, lg) in enumerate((("E_iso", 1), ("theta_v", 0), ("A_V", 0))):
+        spec.slot[d] = _lib.P_A_V if name == "A_V" else _lib.PARAM_SLOTS[name]
+        spec.is_log[d] = lg
+    dp = C.POINTER(C.c_double)
+    if with_points:
+        t = np.sort(10 ** rng.uniform(3, 6, 24))
+        nu = 10 ** rng.choice([9.0, 14.7, 17.5], size=t.size)
+        keep["pts"] = [t, nu, rng.normal(-60, 1, t.size), np.full(t.size, 0.1), np.ones(t.size),
+                       0.4 * np.log(10.0) * (nu / 5e14) ** 1.1]
+        spec.n_data = t.size
+        spec.t, spec.nu, spec.ln_flux, spec.ln_err, spec.weight, spec.ext_kernel = (a.ctypes.data_as(dp) for a in keep["pts"])
+    bands = (_lib.BandObs * 2)()
+    for g, (lo, hi, npts, n) in enumerate(((7.25e16, 2.4e18, 5, 9), (1e9, 1e11, 9, 6))):
+        tb = np.sort(10 ** rng.uniform(3.5, 6.5, n))
+        arrs = [tb, rng.normal(-28, 1, n), np.full(n, 0.15), np.ones(n)]
+        keep[f"b{g}"] = arrs
+        bands[g].nu_min, bands[g].nu_max, bands[g].num_points, bands[g].n = lo, hi, npts, n
+        bands[g].t, bands[g].ln_flux, bands[g].ln_err, bands[g].weight = (a.ctypes.data_as(dp) for a in arrs)
+    spec.n_bands, spec.bands, spec.a_v_fixed = 2, bands, 0.0
+    keep["bands"] = bands
+    return spec, keep
+
+
+def oracle_loglike(spec, theta):
+    import ctypes as C
+    lib = _abi.load_oracle().lib
+    fn = lib.vag_oracle_loglike_batch
+    fn.restype = C.c_int
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    out = np.empty(theta.shape[0])
+    dp = C.POINTER(C.c_double)
+    assert fn(C.byref(spec), theta.ctypes.data_as(dp), theta.shape[0], theta.shape[1], out.ctypes.data_as(dp)) == 0
+    return out
+
+
+def test_oracle_loglike_with_band_groups_and_extinction(oracle):
+    """Fitter._evaluate (fitter.py:503-533): point data with the extinction factor + one Model.flux request per band group."""
+    kw = dict(jet="GaussianJet", z=0.5, lumi_dist=3e27)
+    spec, keep = _band_spec(kw)
+    theta = np.array([[52.3, 0.15, 0.4], [51.8, 0.05, 0.0]])
+    got = oracle_loglike(spec, theta)
+    for b, (lgE, thv, av) in enumerate(theta):
+        prm = _abi.make_params(**{**kw, "E_iso": 10 ** lgE, "theta_obs": thv})
+        t, nu, lnf, lne, w, ext = keep["pts"]
+        F = oracle.flux_density(prm, t, nu) * np.exp(-av * ext)
+        chi2 = np.sum(w * ((lnf - np.log(F)) / lne) ** 2)
+        for g in range(2):
+            tb, lnfb, lneb, wb = keep[f"b{g}"]
+            bd = keep["bands"][g]
+            Fb = oracle.flux(prm, tb, bd.nu_min, bd.nu_max, bd.num_points)
+            chi2 += np.sum(wb * ((lnfb - np.log(Fb)) / lneb) ** 2)
+        assert abs(got[b] + 0.5 * chi2) <= 1e-12 * abs(chi2)

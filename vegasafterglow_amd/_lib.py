@@ -43,12 +43,23 @@ class ModelParams(C.Structure):
     ]
 
 
+class BandObs(C.Structure):
+    _fields_ = [("nu_min", C.c_double), ("nu_max", C.c_double), ("num_points", C.c_int32), ("n", C.c_int32),
+                ("t", C.POINTER(C.c_double)), ("ln_flux", C.POINTER(C.c_double)), ("ln_err", C.POINTER(C.c_double)),
+                ("weight", C.POINTER(C.c_double))]
+
+
+P_A_V = 1000  # VAG_P_A_V
+
+
 class FitSpec(C.Structure):
     _fields_ = [
         ("base", ModelParams), ("ndim", C.c_int32), ("slot", C.c_int32 * 16), ("is_log", C.c_int32 * 16),
         ("n_data", C.c_int32), ("pad", C.c_int32),
         ("t", C.POINTER(C.c_double)), ("nu", C.POINTER(C.c_double)), ("ln_flux", C.POINTER(C.c_double)),
         ("ln_err", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
+        ("ext_kernel", C.POINTER(C.c_double)), ("a_v_fixed", C.c_double), ("n_bands", C.c_int32), ("pad2", C.c_int32),
+        ("bands", C.POINTER(BandObs)),
     ]
 
 

@@ -254,7 +254,7 @@ struct vag_ctx {
     // compact per-row / per-cell storage
     DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
     // fit spec cache
-    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux;
+    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux, d_chi2, d_bandobs;
     // plan of the last grid pass
     int nb = 0, n_rows = 0, max_k = 0, max_pairs = 0;
     long long n_cells = 0, total_pairs = 0, eat_cells = 0;
@@ -384,7 +384,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
-                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
@@ -1159,20 +1159,16 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     return check_status(c, nb);
 }
 
-// Model.flux for a batch: out_total (optional) receives the sum of the enabled components, out4 (optional) the
-// components {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} apart (NULL entries skipped).
-static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
-                          double nu_max, int num_nu, double* out_total, double* const* out4) {
-    if (!c) return set_err(VAG_E_INVALID, "null context");
+// Band request with parameters and times already in HBM: nu = logspace(nu_min, nu_max, num_nu) nodes with Boole weights
+// (Observer::flux, src/core/quadrature.h:153-196, pymodel.cpp:391-410), own grid from the request's own time range.
+// d_total (optional) [nb][nt] receives the sum of the enabled components, d4 (optional) the components apart.
+static int band_request_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt, double nu_min,
+                            double nu_max, int num_nu, double* d_total, double* const* d4) {
     if (!(nu_min > 0)) return set_err(VAG_E_INVALID, "nu_min must be positive");
     if (!(nu_max > nu_min)) return set_err(VAG_E_INVALID, "nu_max must be greater than nu_min");
     if (num_nu < 2) return set_err(VAG_E_INVALID, "num_nu must be at least 2");
     if (num_nu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d band frequencies", VAG_MAX_NU);
-    int rc = check_host_inputs(params, nb, t, nt);
-    if (rc) return rc;
-    if ((long long)nt * num_nu > FLUX_MAX_SLOTS)
-        return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_MAX_SLOTS);
-    // band grid and Boole weights are request metadata (src/core/quadrature.h:153-196, pymodel.cpp:398-399):
+    if ((long long)nt * num_nu > FLUX_MAX_SLOTS) return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_MAX_SLOTS);
     // nu = xt::logspace(log10(nu_min Hz), log10(nu_max Hz), num_nu) in code units
     std::vector<double> nu_code(num_nu), nu_cgs(num_nu), w(num_nu, 0.0);
     {
@@ -1211,31 +1207,42 @@ static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, co
         }
         for (int i = 0; i < n; ++i) w[i] *= nu_code[i];
     }
-    HIPCHK(hipSetDevice(c->device));
-    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
-    if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
     if (c->d_nu.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
     if (c->d_bandw.ensure(sizeof(double) * num_nu)) return VAG_E_HIP;
-    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt)) return VAG_E_HIP;
-    if (c->d_comp.ensure(sizeof(double) * (size_t)nb * nt * 4)) return VAG_E_HIP;
-    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nu.p, nu_cgs.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_bandw.p, w.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
-    rc = prep_times(c, c->d_t.as<double>(), nt, c->d_nu.as<double>(), num_nu);
+    int rc = prep_times(c, d_t, nt, c->d_nu.as<double>(), num_nu);
     if (rc) return rc;
     // the band nodes are exact code-unit values: overwrite log2(nu_cgs * Hz) with log2(nu_code) to avoid a round trip
     std::vector<double> lg2nu(num_nu);
     for (int i = 0; i < num_nu; ++i) lg2nu[i] = std::log2(nu_code[i]);
     HIPCHK(hipMemcpyAsync(c->d_lg2nu.p, lg2nu.data(), sizeof(double) * num_nu, hipMemcpyHostToDevice, c->stream));
-    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
+    HIPCHK(hipStreamSynchronize(c->stream));  // the staging vectors above are stack-local
+    rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
+    return grid_request(c, d_params, nb, nt, num_nu, c->d_bandw.as<double>(), d_total, d4);
+}
+
+// Model.flux for a batch: out_total (optional) receives the sum of the enabled components, out4 (optional) the
+// components {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} apart (NULL entries skipped).
+static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
+                          double nu_max, int num_nu, double* out_total, double* const* out4) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    int rc = check_host_inputs(params, nb, t, nt);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
+    if (c->d_out.ensure(sizeof(double) * (size_t)nb * nt)) return VAG_E_HIP;
+    if (c->d_comp.ensure(sizeof(double) * (size_t)nb * nt * 4)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * nt, hipMemcpyHostToDevice, c->stream));
     const size_t n_out = (size_t)nb * nt;
     double* d4[4] = {nullptr, nullptr, nullptr, nullptr};
     if (out4)
         for (int q = 0; q < 4; ++q) d4[q] = out4[q] ? c->d_comp.as<double>() + q * n_out : nullptr;
-    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, num_nu, c->d_bandw.as<double>(),
-                      out_total ? c->d_out.as<double>() : nullptr, out4 ? d4 : nullptr);
+    rc = band_request_dev(c, c->d_params.as<vag_model_params>(), nb, c->d_t.as<double>(), nt, nu_min, nu_max, num_nu,
+                          out_total ? c->d_out.as<double>() : nullptr, out4 ? d4 : nullptr);
     if (rc) return rc;
     if (out_total) HIPCHK(hipMemcpyAsync(out_total, c->d_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
     for (int q = 0; q < 4; ++q)
@@ -1265,38 +1272,85 @@ int vag_flux_components4_batch(vag_ctx* c, const vag_model_params* params, int n
 static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     if (ndim != spec->ndim || ndim <= 0 || ndim > 16) return set_err(VAG_E_INVALID, "ndim must match spec and be in 1..16");
     const int n = spec->n_data;
-    if (n <= 0) return set_err(VAG_E_INVALID, "fit spec has no data points");
-    for (int d = 0; d < ndim; ++d)
-        if (spec->slot[d] < 0 || (spec->slot[d] >= VAG_P_COUNT && (spec->slot[d] < VAG_P_RVS_EPS_E || spec->slot[d] > VAG_P_MAG_Q)))
-            return set_err(VAG_E_INVALID, "bad parameter slot");
+    if (n < 0 || spec->n_bands < 0 || (n == 0 && spec->n_bands == 0)) return set_err(VAG_E_INVALID, "fit spec has no data");
+    for (int d = 0; d < ndim; ++d) {
+        const int s = spec->slot[d];
+        if (s == VAG_P_A_V) continue;
+        if (s < 0 || (s >= VAG_P_COUNT && (s < VAG_P_RVS_EPS_E || s > VAG_P_MAG_Q))) return set_err(VAG_E_INVALID, "bad parameter slot");
+    }
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");
     for (int i = 1; i < n; ++i)
         if (spec->t[i] < spec->t[i - 1]) return set_err(VAG_E_INVALID, "data times must be ascending (fitter.py:420-428)");
-    // [t | nu | ln_flux | ln_err | weight]
-    if (c->d_fit.ensure(sizeof(double) * 5 * (size_t)n)) return VAG_E_HIP;
+    for (int g = 0; g < spec->n_bands; ++g) {
+        const vag_band_obs& bd = spec->bands[g];
+        if (bd.n <= 0) return set_err(VAG_E_INVALID, "band group %d has no observations", g);
+        for (int i = 0; i < bd.n; ++i)
+            if (!(bd.t[i] > 0) || (i > 0 && bd.t[i] < bd.t[i - 1]))
+                return set_err(VAG_E_INVALID, "band group %d: times must be positive and ascending", g);
+    }
+    // [t | nu | ln_flux | ln_err | weight | ext_kernel]
+    if (c->d_fit.ensure(sizeof(double) * 6 * (size_t)std::max(n, 1))) return VAG_E_HIP;
     if (c->d_slot.ensure(sizeof(int) * 32)) return VAG_E_HIP;
     double* d = c->d_fit.as<double>();
-    HIPCHK(hipMemcpyAsync(d, spec->t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d + n, spec->nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d + 2 * (size_t)n, spec->ln_flux, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d + 3 * (size_t)n, spec->ln_err, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d + 4 * (size_t)n, spec->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(d, spec->t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d + n, spec->nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d + 2 * (size_t)n, spec->ln_flux, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d + 3 * (size_t)n, spec->ln_err, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d + 4 * (size_t)n, spec->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        if (spec->ext_kernel)
+            HIPCHK(hipMemcpyAsync(d + 5 * (size_t)n, spec->ext_kernel, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(c->d_slot.p, spec->slot, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_slot.as<int>() + 16, spec->is_log, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
     return VAG_OK;
 }
 
-__global__ void vag_valid_from_meta(const VagGridMeta* meta, int nb, int* valid) {
+// valid[m] &= the model came through this pass (grid fits the engine, no ODE row failed); a walker whose Model raises
+// in the reference is caught by eval_one and scored -inf (samplers.py:61-70)
+__global__ void vag_update_valid(const VagGridMeta* meta, int nb, int* valid, int first) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < nb) valid[m] = meta[m].status == 0;
+    if (m < nb) valid[m] = (first ? 1 : valid[m]) && meta[m].status == 0;
 }
-
-// a walker whose ODE threw in the reference (no acceptable step) is caught by eval_one and scored -inf (samplers.py:61-70)
 __global__ void vag_invalidate_failed_rows(const int* __restrict__ row_status, const int* __restrict__ row_off, int nb,
                                            int n_rows, int* __restrict__ valid) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_rows && row_status[r] == 1) valid[vag::find_model(row_off, nb, r)] = 0;
+}
+
+// chi2[m] (+)= sum_i w_i ((ln F_obs,i - ln max(F_model,i e^{-A_V k_i}, 1e-300)) / sigma_i)^2  (Fitter._chi2_sum, fitter.py:497-501,
+// with the extinction factor of fitter.py:512-519); one wavefront per walker
+__global__ void __launch_bounds__(64)
+vag_chi2_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const double* __restrict__ ln_flux,
+                const double* __restrict__ ln_err, const double* __restrict__ weight, const double* __restrict__ ext /* or null */,
+                const double* __restrict__ a_v /* [nb] */, double* __restrict__ chi2, int accumulate) {
+    const int m = blockIdx.x;
+    const double av = (ext != nullptr) ? a_v[m] : 0.0;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        double f = flux[(size_t)m * n + i];
+        if (av != 0.0) f = f * exp(-av * ext[i]);
+        const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300);
+        const double q = (ln_flux[i] - log(fm)) / ln_err[i];
+        s += weight[i] * (q * q);
+    }
+    s = vag::wave_sum(s);
+    if (threadIdx.x == 0) chi2[m] = accumulate ? chi2[m] + s : s;
+}
+__global__ void vag_finish_loglike(const double* __restrict__ chi2, const int* __restrict__ valid, int nb, double* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nb) out[m] = (valid[m] && isfinite(chi2[m])) ? -0.5 * chi2[m] : -INFINITY;
+}
+// A_V per walker: the free parameter with slot VAG_P_A_V (10^theta for log-scale), else the fixed value
+__global__ void vag_av_kernel(const double* __restrict__ theta, int nb, int ndim, const int* __restrict__ slot,
+                              const int* __restrict__ is_log, double a_v_fixed, double* __restrict__ a_v) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    double v = a_v_fixed;
+    for (int d = 0; d < ndim; ++d)
+        if (slot[d] == VAG_P_A_V) v = is_log[d] ? pow(10.0, theta[(size_t)b * ndim + d]) : theta[(size_t)b * ndim + d];
+    a_v[b] = v;
 }
 
 int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
@@ -1306,27 +1360,65 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     int rc = upload_fit_spec(c, spec, ndim);
     if (rc) return rc;
     const int n = spec->n_data;
+    hipStream_t st = c->stream;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
-    if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
     if (c->d_valid.ensure(sizeof(int) * nb)) return VAG_E_HIP;
-    hipLaunchKernelGGL(vag_transform_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, spec->base, d_theta, nb, ndim,
-                       c->d_slot.as<int>(), c->d_slot.as<int>() + 16, c->d_params.as<vag_model_params>());
+    if (c->d_chi2.ensure(sizeof(double) * 2 * (size_t)nb)) return VAG_E_HIP;  // [chi2 | A_V]
+    double* d_chi2 = c->d_chi2.as<double>();
+    double* d_av = d_chi2 + nb;
+    vag_model_params* d_params = c->d_params.as<vag_model_params>();
+    hipLaunchKernelGGL(vag_transform_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, spec->base, d_theta, nb, ndim,
+                       c->d_slot.as<int>(), c->d_slot.as<int>() + 16, d_params);
+    hipLaunchKernelGGL(vag_av_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, d_theta, nb, ndim, c->d_slot.as<int>(),
+                       c->d_slot.as<int>() + 16, spec->a_v_fixed, d_av);
     HIPCHK(hipGetLastError());
-    double* d = c->d_fit.as<double>();
-    rc = prep_times(c, d, n, d + n, n);
-    if (rc) return rc;
-    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
-    if (rc) return rc;
-    rc = series_chunk(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
-                      c->d_lg2nu.as<double>(), n, c->d_series_flux.as<double>());
-    if (rc) return rc;
-    hipLaunchKernelGGL(vag_valid_from_meta, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb,
-                       c->d_valid.as<int>());
-    if (c->n_rows > 0)
-        hipLaunchKernelGGL(vag_invalidate_failed_rows, dim3((c->n_rows + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_row_status.as<int>(), c->d_row_off.as<int>(), nb, c->n_rows, c->d_valid.as<int>());
-    hipLaunchKernelGGL(vag_loglike_kernel, dim3(nb), dim3(64), 0, c->stream, c->d_series_flux.as<double>(), n,
-                       d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, c->d_valid.as<int>(), d_out);
+    bool first = true;
+    auto after_pass = [&]() -> int {  // fold this pass's per-model status into valid[]
+        hipLaunchKernelGGL(vag_update_valid, dim3((nb + 127) / 128), dim3(128), 0, st, c->d_meta.as<VagGridMeta>(), nb,
+                           c->d_valid.as<int>(), first ? 1 : 0);
+        if (c->n_rows > 0)
+            hipLaunchKernelGGL(vag_invalidate_failed_rows, dim3((c->n_rows + 255) / 256), dim3(256), 0, st,
+                               c->d_row_status.as<int>(), c->d_row_off.as<int>(), nb, c->n_rows, c->d_valid.as<int>());
+        HIPCHK(hipGetLastError());
+        return VAG_OK;
+    };
+    if (n > 0) {  // point data: one (t, nu) series per walker (fitter.py:510-522)
+        if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
+        double* d = c->d_fit.as<double>();
+        rc = prep_times(c, d, n, d + n, n);
+        if (rc) return rc;
+        rc = run_model_stages(c, d_params, nb, false);
+        if (rc) return rc;
+        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
+                          c->d_series_flux.as<double>());
+        if (rc) return rc;
+        rc = after_pass();
+        if (rc) return rc;
+        hipLaunchKernelGGL(vag_chi2_kernel, dim3(nb), dim3(64), 0, st, c->d_series_flux.as<double>(), n, d + 2 * (size_t)n,
+                           d + 3 * (size_t)n, d + 4 * (size_t)n, spec->ext_kernel ? d + 5 * (size_t)n : nullptr, d_av, d_chi2, 0);
+        HIPCHK(hipGetLastError());
+        first = false;
+    }
+    for (int g = 0; g < spec->n_bands; ++g) {  // band-integrated groups: one Model.flux request each (fitter.py:524-531)
+        const vag_band_obs& bd = spec->bands[g];
+        if (c->d_bandobs.ensure(sizeof(double) * 4 * (size_t)bd.n)) return VAG_E_HIP;
+        if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * std::max(bd.n, n))) return VAG_E_HIP;
+        double* db = c->d_bandobs.as<double>();
+        HIPCHK(hipMemcpyAsync(db, bd.t, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db + bd.n, bd.ln_flux, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db + 2 * (size_t)bd.n, bd.ln_err, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db + 3 * (size_t)bd.n, bd.weight, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
+        rc = band_request_dev(c, d_params, nb, db, bd.n, bd.nu_min, bd.nu_max, bd.num_points, c->d_series_flux.as<double>(),
+                              nullptr);
+        if (rc) return rc;
+        rc = after_pass();
+        if (rc) return rc;
+        hipLaunchKernelGGL(vag_chi2_kernel, dim3(nb), dim3(64), 0, st, c->d_series_flux.as<double>(), bd.n, db + bd.n,
+                           db + 2 * (size_t)bd.n, db + 3 * (size_t)bd.n, nullptr, d_av, d_chi2, first ? 0 : 1);
+        HIPCHK(hipGetLastError());
+        first = false;
+    }
+    hipLaunchKernelGGL(vag_finish_loglike, dim3((nb + 127) / 128), dim3(128), 0, st, d_chi2, c->d_valid.as<int>(), nb, d_out);
     HIPCHK(hipGetLastError());
     return VAG_OK;
 }

@@ -816,6 +816,7 @@ __global__ void vag_transform_kernel(vag_model_params base, const double* __rest
     vag_model_params p = base;
     double* f = &p.theta_c;
     for (int d = 0; d < ndim; ++d) {
+        if (slot[d] == VAG_P_A_V) continue;  // not a Model field (scales the point-data fluxes, see vag_av_kernel)
         const double v = theta[(size_t)b * ndim + d];
         f[slot[d]] = is_log[d] ? pow(10.0, v) : v;
     }

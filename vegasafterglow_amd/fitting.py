@@ -58,7 +58,12 @@ class Fitter:
 
     def __init__(self, z, lumi_dist, jet="tophat", medium="ism", resolution=None, rtol=1e-6,
                  radiative_fireball=True, device=0, fwd_ssc=False, kn=False, rvs_shock=False, rvs_ssc=False,
-                 magnetar=False):
+                 magnetar=False, extinction=None):
+        # extinction: k(lambda_rest [cm]) -> A_lambda / A_V of the host-galaxy law (a callable; fitter.py:379-397).  The
+        # point-data model fluxes are scaled by exp(-A_V * 0.4 ln10 * k) with A_V a (free or fixed) parameter.
+        if extinction is not None and not callable(extinction):
+            raise ValueError("extinction must be a callable k(lambda_rest_cm) (the reference's named laws are not shipped here)")
+        self.extinction = extinction
         self.magnetar = bool(magnetar)
         if rvs_ssc and not rvs_shock:
             rvs_ssc = False  # the reference only builds rvs_rad when rvs_shock is on (fitter.py:476-484)
@@ -74,6 +79,8 @@ class Fitter:
         self.resolution, self.rtol, self.radiative_fireball = tuple(resolution), float(rtol), bool(radiative_fireball)
         self.device = device
         self._point_t, self._point_nu, self._point_flux, self._point_err, self._point_weights = [], [], [], [], []
+        self._band_obs = []
+        self._ext_kernel = None
         self._all_t = None
 
     # fitter.py add_flux_density
@@ -91,12 +98,39 @@ class Fitter:
         self._point_weights.append(w)
         self._all_t = None
 
+    # fitter.py:316-377
+    def add_flux(self, band, t, flux, err, num_points=5, weights=None):
+        """Band-integrated fluxes [erg/cm^2/s] over band = (nu_min, nu_max) [Hz]; each group is one Model.flux request."""
+        try:
+            nu_min, nu_max = band
+        except (TypeError, ValueError):
+            raise ValueError(f"add_flux: band must be a (nu_min, nu_max) tuple in Hz, got {band!r}") from None
+        if not (np.isfinite(nu_min) and np.isfinite(nu_max) and 0 < nu_min < nu_max):
+            raise ValueError(f"add_flux: band must satisfy 0 < nu_min < nu_max with both finite; got nu_min={nu_min}, "
+                             f"nu_max={nu_max}")
+        if num_points < 2:
+            raise ValueError(f"add_flux: num_points must be >= 2 for band integration, got {num_points}")
+        t, flux, err = (np.asarray(a, dtype=np.float64) for a in (t, flux, err))
+        if not (t.shape == flux.shape == err.shape) or t.ndim != 1 or t.size == 0:
+            raise ValueError("add_flux: t, flux and err must be non-empty 1-D arrays of the same length")
+        if np.any(flux <= 0) or np.any(err <= 0):
+            raise ValueError("the log-flux likelihood requires strictly positive fluxes and errors")
+        w = np.ones_like(t) if weights is None else np.asarray(weights, dtype=np.float64)
+        order = np.argsort(t)
+        self._band_obs.append(dict(nu_min=float(nu_min), nu_max=float(nu_max), num_points=int(num_points),
+                                   t=np.ascontiguousarray(t[order]), ln_flux=np.ascontiguousarray(np.log(flux[order])),
+                                   ln_err=np.ascontiguousarray(err[order] / flux[order]),
+                                   weights=np.ascontiguousarray(w[order])))
+
     # fitter.py:407-451
     def _consolidate_data(self):
         if self._all_t is not None:
             return
         if not self._point_t:
-            raise ValueError("no data: call add_flux_density first")
+            if not self._band_obs:
+                raise ValueError("no data: call add_flux_density or add_flux first")
+            self._all_t = self._all_nu = self._all_log_flux = self._all_log_err = self._all_weights = np.array([])
+            return
         t = np.concatenate(self._point_t)
         nu = np.concatenate(self._point_nu)
         f = np.concatenate(self._point_flux)
@@ -113,6 +147,9 @@ class Fitter:
         self._all_log_flux = np.ascontiguousarray(np.log(f))
         self._all_log_err = np.ascontiguousarray(e / f)
         self._all_weights = np.ascontiguousarray(w)
+        if self.extinction is not None:  # fitter.py:439-449: rest-frame wavelengths, kernel = 0.4 ln10 k(lambda)
+            lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self.z)
+            self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self.extinction(lam_rest_cm), dtype=np.float64))
 
     def _base_params(self, fixed):
         vals = dict(MODEL_PARAM_DEFAULTS)
@@ -152,10 +189,23 @@ class Fitter:
         spec.base = self._base_params(fixed)
         spec.ndim = len(free)
         for d, pd in enumerate(free):
-            if pd.name not in _lib.PARAM_SLOTS:
+            if pd.name == "A_V":
+                spec.slot[d] = _lib.P_A_V
+            elif pd.name not in _lib.PARAM_SLOTS:
                 raise ValueError(f"parameter {pd.name} is not accepted by the accelerated path")
-            spec.slot[d] = _lib.PARAM_SLOTS[pd.name]
+            else:
+                spec.slot[d] = _lib.PARAM_SLOTS[pd.name]
             spec.is_log[d] = 1 if pd.scale is Scale.log else 0
+        spec.a_v_fixed = float(fixed.get("A_V", 0.0))
+        spec.ext_kernel = self._ext_kernel.ctypes.data_as(_dp) if self._ext_kernel is not None else None
+        self._band_structs = (_lib.BandObs * max(len(self._band_obs), 1))()
+        for g, bd in enumerate(self._band_obs):
+            b = self._band_structs[g]
+            b.nu_min, b.nu_max, b.num_points, b.n = bd["nu_min"], bd["nu_max"], bd["num_points"], bd["t"].size
+            b.t, b.ln_flux = bd["t"].ctypes.data_as(_dp), bd["ln_flux"].ctypes.data_as(_dp)
+            b.ln_err, b.weight = bd["ln_err"].ctypes.data_as(_dp), bd["weights"].ctypes.data_as(_dp)
+        spec.n_bands = len(self._band_obs)
+        spec.bands = self._band_structs
         spec.n_data = self._all_t.size
         spec.t = self._all_t.ctypes.data_as(_dp)
         spec.nu = self._all_nu.ctypes.data_as(_dp)
