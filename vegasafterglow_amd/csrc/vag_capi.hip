@@ -334,6 +334,9 @@ int vag_ctx_create(int device, vag_ctx** out) {
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<true, FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN, false, 256>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC, false, 256>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC, false, 256>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN, true>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC, true>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC, true>),
@@ -695,7 +698,17 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = ppb;
     if (c->n_rows > 0) {
-        if (spreading && mode == FLUX_SYN_IC)
+        // requests with few (nu, t) slots and short rows keep less than half of a 512-lane workgroup busy: use 256 lanes
+        // (+47 % on the C5 / C1b shapes; a 128-lane variant measured slower)
+        const bool small = !spreading && !a.work_count && (long long)nt * nnu <= 512 && (long long)ks * ((nnu + 1) / 2) <= 512 &&
+                           !std::getenv("VAG_FLUX_WIDE");
+        if (small && mode == FLUX_SYN_IC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
+        else if (small && mode == FLUX_SSC)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
+        else if (small)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
+        else if (spreading && mode == FLUX_SYN_IC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
         else if (spreading && mode == FLUX_SSC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);

@@ -374,8 +374,8 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
 
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
 // MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
-template <bool COUNT, int MODE, bool SPREAD = false>
-__global__ void __launch_bounds__(FLUX_THREADS, 4)
+template <bool COUNT, int MODE, bool SPREAD = false, int THREADS = FLUX_THREADS>
+__global__ void __launch_bounds__(THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
     const VagGridMeta* Mp = a.meta + m;
@@ -409,9 +409,9 @@ vag_flux_grid_kernel(FluxArgs a) {
     const double one_plus_z = 1 + Pp->z;
     {
         const double lg2_1pz = log2(one_plus_z);
-        for (int i = tid; i < nt; i += FLUX_THREADS) s_tobs[i] = a.lg2_t_obs[i];
-        for (int l = tid; l < nnu; l += FLUX_THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
-        for (int i = tid; i < SP_TABLE_DOUBLES; i += FLUX_THREADS) s_sp[i] = a.sp_table[i];
+        for (int i = tid; i < nt; i += THREADS) s_tobs[i] = a.lg2_t_obs[i];
+        for (int l = tid; l < nnu; l += THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
+        for (int i = tid; i < SP_TABLE_DOUBLES; i += THREADS) s_sp[i] = a.sp_table[i];
     }
     SpecConst sc;
     sc.init(Pp->p);
@@ -419,7 +419,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const float inv_nt = 1.0f / (float)nt;
 
-    for (int s = tid; s < slots; s += FLUX_THREADS) s_acc[s] = 0;
+    for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
 
     // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
@@ -432,13 +432,13 @@ vag_flux_grid_kernel(FluxArgs a) {
         const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K) * 3;
-            eat_row_spread(s_par, KS, K, tid, FLUX_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
+            eat_row_spread(s_par, KS, K, tid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
                            s_t + buf * KS, s_dop, s_geom);
         } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-            eat_row(s_par, KS, K, tid, FLUX_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
+            eat_row(s_par, KS, K, tid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
         }
     };
     int staged_rep = -1;
@@ -447,7 +447,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K) * VAG_NPAR;
 #pragma unroll 1
-            for (int q = tid; q < VAG_NPAR * K; q += FLUX_THREADS) {  // rare path: keep its register footprint small
+            for (int q = tid; q < VAG_NPAR * K; q += THREADS) {  // rare path: keep its register footprint small
                 const int par = (int)(((float)q + 0.5f) / (float)K);
                 s_par[par * KS + (q - par * K)] = src[q];
             }
@@ -457,7 +457,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                 __syncthreads();
                 const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K) * FLUX_IC_STRIDE;
 #pragma unroll 1
-                for (int q = tid; q < 5 * K; q += FLUX_THREADS) {
+                for (int q = tid; q < 5 * K; q += THREADS) {
                     const int kk = q / 5, w = q - kk * 5;
                     s_par[w * KS + kk] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
                 }
@@ -465,7 +465,7 @@ vag_flux_grid_kernel(FluxArgs a) {
             if constexpr (MODE == FLUX_SYN_IC) {
                 const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K) * FLUX_NQ;
 #pragma unroll 1
-                for (int q = tid; q < FLUX_NQ * K; q += FLUX_THREADS) {
+                for (int q = tid; q < FLUX_NQ * K; q += THREADS) {
                     const int par = (int)(((float)q + 0.5f) / (float)K);
                     s_q[par * KS + (q - par * K)] = srcq[q];
                 }
@@ -486,7 +486,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,
         //      405-433), interval reciprocals, and the observation window (observed_window, observer.h:324-338)
         const double row_t0 = s_tc[0], row_tN = s_tc[K - 1];
-        for (int idx = tid; idx < nt; idx += FLUX_THREADS) {
+        for (int idx = tid; idx < nt; idx += THREADS) {
             const double tq = s_tobs[idx];
             int kk = -1;
             double w = 0;
@@ -540,7 +540,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                 n_evals += (unsigned long long)nk * nnu;
                 n_interps += (unsigned long long)(n_ltN - n_lt0) * nnu;
             }
-            for (int q = tid; q < total; q += FLUX_THREADS) {
+            for (int q = tid; q < total; q += THREADS) {
                 const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
                 const int k = k_lo + (q - lg * nk);
                 const int l0 = lg * 2, l1 = min(l0 + 1, nnu - 1);
@@ -573,7 +573,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         //      always visited by the same lane, so the LDS accumulator needs no atomics and the sum order is fixed.
         if (in_window) {
 #pragma unroll 2
-            for (int slot = tid; slot < slots; slot += FLUX_THREADS) {
+            for (int slot = tid; slot < slots; slot += THREADS) {
                 const int l = (int)(((float)slot + 0.5f) * inv_nt);
                 const int idx = slot - l * nt;
                 const int k = s_kidx[idx];
@@ -604,7 +604,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
     double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
-    for (int s = tid; s < slots; s += FLUX_THREADS) my_partial[s] = s_acc[s];
+    for (int s = tid; s < slots; s += THREADS) my_partial[s] = s_acc[s];
 }
 
 // Deterministic sum over a model's workgroup partials + normalisation
