@@ -325,6 +325,8 @@ def main():
         raise SystemExit("bench produced non-finite fluxes or rejected models")
     walkers = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world)
     walkers_half = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512)
+    # an ensemble sized to the node (1024 walkers per GPU): the weak-scaling counterpart of the 1024-walker run above
+    walkers_weak = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=1024 * world) if (world > 1 and not args.no_walkers) else None
     tophat = tophat_sweep(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
     ensembles = ensemble_bench(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
 
@@ -366,6 +368,9 @@ def main():
         if walkers is not None:
             out["walker_steps"] = walkers
             out["walker_steps_redblue_half"] = walkers_half  # emcee red-blue moves evaluate nwalkers/2 per call
+            if walkers_weak:
+                walkers_weak["scaling"] = "weak"
+                out["walker_steps_1024_per_gpu"] = walkers_weak
         if tophat is not None:
             out["tophat_config0"] = tophat
         if ensembles:
