@@ -321,6 +321,12 @@ int vag_details(vag_ctx* ctx, const vag_model_params* params, double t_min, doub
 /* Same protocol for the reverse shock of a Model(rvs_rad=...) (Model.details().rvs, pybind/pymodel.cpp:315-348). */
 int vag_details_rvs(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                     const vag_details_out* out);
+/* ShockDetails' electron / photon arrays of the forward (rvs = 0) or reverse (rvs = 1) shock, each [n_theta][n_t] with the
+ * shape vag_details reports (save_electron_details / save_photon_details, pybind/pymodel.cpp:236-290):
+ *   arrays[0..10] = gamma_m, gamma_c, gamma_a, gamma_M, N_e, nu_m [Hz], nu_c, nu_a, nu_M, I_nu_max [erg/cm^2/s/Hz], theta.
+ * NULL entries are skipped.  With Radiation(ssc=True) these are the inverse-Compton-cooled values. */
+int vag_details_radiation(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int rvs,
+                          double* const* arrays);
 
 /* Per-stage device timings (ms) of the last batch call, stage names follow the reference's
  * profiler (pybind/pymodel.h:877-953): grid, dynamics, syn_cells, sync_flux, reduce, total. */

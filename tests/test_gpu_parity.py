@@ -695,3 +695,43 @@ def test_loglike_with_band_groups_extinction_and_python_fitter(eng, oracle):
             Fb = oracle.flux(prm, bd["t"], bd["nu_min"], bd["nu_max"], bd["num_points"])
             chi2 += np.sum(bd["weights"] * ((bd["ln_flux"] - np.log(Fb)) / bd["ln_err"]) ** 2)
         assert abs(ll[b] + 0.5 * chi2) <= 2e-6 * abs(chi2), (b, ll[b], -0.5 * chi2)
+
+
+_U_SEC = 3e10 / 1.5e13
+_U_HZ = 1 / _U_SEC
+_U_FLUX_DEN = ((1 / 2e33) * (1 / 1.5e13) ** 2 / _U_SEC ** 2) / (1 / 1.5e13) ** 2 / _U_SEC / _U_HZ
+
+
+def _check_radiation_details(d, o, rtol):
+    """ShockDetails electron / photon arrays (pybind.cpp:522-546) against the checker's per-cell spectra."""
+    for k in ("gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e"):
+        np.testing.assert_allclose(d[k], o[k], rtol=rtol, atol=1e-300, equal_nan=True, err_msg=k)
+    for k in ("nu_m", "nu_c", "nu_a", "nu_M"):
+        np.testing.assert_allclose(d[k], o[k] / _U_HZ, rtol=rtol, atol=1e-300, equal_nan=True, err_msg=k)
+    np.testing.assert_allclose(d["I_nu_max"], o["I_nu_max"] / _U_FLUX_DEN, rtol=rtol, atol=1e-300, equal_nan=True)
+
+
+def test_details_radiation_arrays(eng, oracle):
+    kw = configs.C4_TRUTH
+    prm = _abi.make_params(**kw)
+    m = va.Model(va.GaussianJet(kw["theta_c"], kw["E_iso"], kw["Gamma0"]), va.ISM(kw["n_ism"]),
+                 va.Observer(kw["lumi_dist"], kw["z"], kw["theta_obs"]), va.Radiation(kw["eps_e"], kw["eps_B"], kw["p"]))
+    d, o = m.details(1e2, 1e7), oracle.details(prm, 1e2, 1e7)
+    _check_radiation_details(d, o, 5e-6)
+    assert np.array_equal(d["theta_cell"], np.repeat(d["theta"][:, None], d["shape"]["n_t"], axis=1))
+    # inverse-Compton-cooled electrons of a Radiation(ssc=True, kn=True) model
+    m3 = va.Model(va.TophatJet(0.1, 1e52, 300.0), va.ISM(1.0), va.Observer(1e28, 1.0, 0.05),
+                  va.Radiation(0.1, 1e-4, 2.3, ssc=True, kn=True))
+    prm3 = _abi.ModelParams.from_buffer_copy(bytes(m3.params))
+    _check_radiation_details(m3.details(1e2, 1e7), oracle.details(prm3, 1e2, 1e7), 5e-6)
+    # reverse shock of a thick shell; the spreading jet reports its evolved polar angle per cell
+    kwr, t, _ = configs.RS_CASES["rs_thick_offaxis"]
+    mr = va.Model(va.TophatJet(0.1, 1e53, 100.0, duration=1000.0), va.ISM(1.0), va.Observer(3e28, 0.5, 0.15),
+                  va.Radiation(0.1, 1e-3, 2.3), rvs_rad=va.Radiation(0.1, 0.01, 2.5))
+    pr = _abi.make_params(**kwr)
+    _check_radiation_details(mr.details(t.min(), t.max(), rvs=True), oracle.details(pr, t.min(), t.max(), rvs=True), 5e-6)
+    _check_radiation_details(mr.details(t.min(), t.max()), oracle.details(pr, t.min(), t.max()), 5e-6)
+    ms = va.Model(va.GaussianJet(0.1, 1e52, 300.0, spreading=True), va.ISM(1.0), va.Observer(1e28, 1.0, 0.15),
+                  va.Radiation(0.1, 0.01, 2.3))
+    ds = ms.details(1e2, 1e8)
+    assert np.all(np.diff(ds["theta_cell"], axis=1) >= 0) and ds["theta_cell"][:, -1].max() > ds["theta"].max()

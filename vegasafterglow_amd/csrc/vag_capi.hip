@@ -1514,6 +1514,41 @@ int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double
     return details_impl(c, params, t_min, t_max, shape, out, false);
 }
 
+int vag_details_radiation(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int rvs, double* const* arrays) {
+    vag_details_shape sh;
+    int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, rvs != 0);  // runs the stages with the electron arrays kept
+    if (rc) return rc;
+    if (!arrays) return set_err(VAG_E_INVALID, "arrays must not be null");
+    const int nth = sh.n_theta, nt = sh.n_t;
+    const long long cells = c->n_cells;
+    std::vector<double> buf((size_t)cells * 11), th((size_t)cells, 0.0);
+    std::vector<int> rep_of(nth);
+    const DevBuf& det = rvs ? c->d_celldet_r : c->d_celldet;
+    const DevBuf& shock = rvs ? c->d_shock_r : c->d_shock;
+    HIPCHK(hipMemcpy(buf.data(), det.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rep_of.data(), c->d_rep_of.p, sizeof(int) * nth, hipMemcpyDeviceToHost));
+    const bool per_cell_theta = (params->flags & VAG_FLAG_SPREADING) != 0;
+    if (per_cell_theta)
+        HIPCHK(hipMemcpy(th.data(), static_cast<const double*>(shock.p) + (size_t)VS_THETA * cells, sizeof(double) * cells,
+                         hipMemcpyDeviceToHost));
+    std::vector<double> theta(nth);
+    HIPCHK(hipMemcpy(theta.data(), c->d_theta.p, sizeof(double) * nth, hipMemcpyDeviceToHost));
+    // VD_* rows: gamma_m, gamma_c, gamma_a, gamma_M, N_e, column_den, nu_m, nu_c, nu_a, nu_M, I_nu_max (code units)
+    const int src_row[10] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 10};
+    const double scale[10] = {1, 1, 1, 1, 1, 1 / U_HZ, 1 / U_HZ, 1 / U_HZ, 1 / U_HZ, 1 / U_FLUX_DEN_CGS};
+    for (int a = 0; a < 10; ++a) {
+        if (!arrays[a]) continue;
+        const double* src = buf.data() + (size_t)src_row[a] * cells;
+        for (int j = 0; j < nth; ++j)
+            for (int k = 0; k < nt; ++k) arrays[a][(size_t)j * nt + k] = src[(size_t)rep_of[j] * nt + k] * scale[a];
+    }
+    if (arrays[10])  // ShockDetails.theta: the evolved polar angle of a spreading jet, the grid angle otherwise
+        for (int j = 0; j < nth; ++j)
+            for (int k = 0; k < nt; ++k)
+                arrays[10][(size_t)j * nt + k] = (params->flags & VAG_FLAG_SPREADING) ? th[(size_t)rep_of[j] * nt + k] : theta[j];
+    return VAG_OK;
+}
+
 int vag_details_rvs(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                     const vag_details_out* out) {
     return details_impl(c, params, t_min, t_max, shape, out, true);

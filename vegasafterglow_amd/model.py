@@ -405,6 +405,13 @@ class Model:
             _lib.check(fn(h, C.byref(self.params), float(t_min), float(t_max), C.byref(sh), C.byref(out)))
         d["shape"] = dict(n_phi=sh.n_phi, n_theta=sh.n_theta, n_t=sh.n_t, n_reps=sh.n_reps, symmetry=sh.symmetry,
                           phi_mirrored=sh.phi_mirrored)
+        # electron / photon break arrays of ShockDetails (pybind.cpp:522-546), reference units
+        names = ("gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "nu_m", "nu_c", "nu_a", "nu_M", "I_nu_max", "theta_cell")
+        for n in names:
+            d[n] = np.zeros((sh.n_theta, sh.n_t))
+        arr = (_dp * 11)(*[d[n].ctypes.data_as(_dp) for n in names])
+        with lock:
+            _lib.check(lib.vag_details_radiation(h, C.byref(self.params), float(t_min), float(t_max), 1 if rvs else 0, arr))
         return d
 
     def stage_times(self):
