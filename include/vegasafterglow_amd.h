@@ -67,6 +67,9 @@ extern "C" {
 /* jet(..., magnetar=Magnetar(L0, t0, q)): energy injection L0 (1 + t/t0)^-q inside theta_c (src/environment/jet.h:518-527,
  * pybind/pymodel.cpp:38-45); the jet then runs on the generic Ejecta profile forms of the reference. */
 #define VAG_FLAG_MAGNETAR 64
+/* Model(..., axisymmetric=False): full-circle phi grid, no mirror / on-axis shortcut (grid-refinement.h:671-689,
+ * observer.cpp:215-222).  The named jets stay phi-independent, so every phi slice of the dynamics is the same solve. */
+#define VAG_FLAG_NON_AXISYMMETRIC 128
 
 /* media: src/environment/medium.h:50-133 (ISM, Wind with k_m = 2) */
 #define VAG_MEDIUM_ISM 0

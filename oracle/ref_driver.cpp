@@ -25,7 +25,7 @@ std::pair<Coord, Shock> solve_fwd_shock_like(JetVariant const& jet, MediumVarian
     return std::visit(
         [&](auto const& j, auto const& med) {
             auto coord = auto_grid(j, med, t_obs, theta_w, p.theta_obs, p.z, false, p.phi_resol, p.theta_resol,
-                                   p.t_resol, true);
+                                   p.t_resol, !(p.flags & VAG_FLAG_NON_AXISYMMETRIC));
             auto shock = generate_fwd_shock(coord, med, j, rad, p.rtol);
             return std::pair{std::move(coord), std::move(shock)};
         },
@@ -39,7 +39,7 @@ std::tuple<Coord, Shock, Shock> solve_shock_pair_like(JetVariant const& jet, Med
     return std::visit(
         [&](auto const& j, auto const& med) {
             auto coord = auto_grid(j, med, t_obs, theta_w, p.theta_obs, p.z, true, p.phi_resol, p.theta_resol, p.t_resol,
-                                   true);
+                                   !(p.flags & VAG_FLAG_NON_AXISYMMETRIC));
             auto [fwd, rvs] = generate_shock_pair(coord, med, j, fwd_rad, rvs_rad, p.rtol);
             return std::tuple{std::move(coord), std::move(fwd), std::move(rvs)};
         },

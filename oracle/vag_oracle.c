@@ -403,6 +403,8 @@ typedef struct {
     int* reps; /* representative theta indices */
     int symmetry, phi_mirrored;
     int spreading; /* Coord::spreading, mesh.h:92 */
+    int jet_3d;    /* Model(axisymmetric=False) with more than one phi node: Observer::jet_3d, observer.cpp:215. The named
+                    * jets are phi-independent, so every phi slice of t / Shock equals slice 0 and only slice 0 is kept. */
     double theta_view;
 } coord_t;
 
@@ -856,9 +858,9 @@ static void logspace_with_cross_refinement(double t_start, double t_end, double 
 }
 
 /* build_time_grid + scan_time_bounds + compute_time_grid_size + make_time_grid + store_time_grid,
- * src/core/grid-refinement.h:472-528,571-636 (axisymmetric => phi_size 1) */
+ * src/core/grid-refinement.h:472-528,571-636 */
 static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_min, double t_max, double z,
-                            double t_resol, int is_rvs) {
+                            double t_resol, int is_rvs, int is_axisymmetric) {
     const int nth = c->n_theta;
     const double t_end = 1.01 * t_max / (1 + z);
     const double cos_tv = cos(c->theta_view), sin_tv = sin(c->theta_view);
@@ -866,23 +868,29 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     double* t_dec = malloc(sizeof(double) * nth);
     double* t_start_row = malloc(sizeof(double) * nth); /* TimeScanResult::t_start / early_t, grid-refinement.h:462-469 */
     double* early_t_row = malloc(sizeof(double) * nth);
-    for (int j = 0; j < nth; ++j) {
-        const double b = gamma_to_beta(jet_Gamma0(jet, c->theta[j]));
-        const double cos_a = cos(c->theta[j]) * cos_tv + sin(c->theta[j]) * sin_tv * cos(c->phi[0]);
-        const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
-        const double td = estimate_t_dec(jet, med, c->theta[j]);
-        t_dec[j] = td;
-        double cut = dmin(0.01 * td, 1e-2 * U_SEC);
-        if (is_rvs) {
-            cut = dmin(cut, 0.01 * jet->T0);
-            max_ref = dmax(max_ref, 10.0 * dmax(td, jet->T0));
+    /* phi_size = |phi| for Model(axisymmetric=False): the global bounds then scan every phi node (:484-507); the per-row
+     * caches keep phi slice 0, the only one the (non-spreading) lattices below read */
+    const int phi_size = is_axisymmetric ? 1 : c->n_phi;
+    for (int i = 0; i < phi_size; ++i)
+        for (int j = 0; j < nth; ++j) {
+            const double b = gamma_to_beta(jet_Gamma0(jet, c->theta[j]));
+            const double cos_a = cos(c->theta[j]) * cos_tv + sin(c->theta[j]) * sin_tv * cos(c->phi[i]);
+            const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
+            const double td = (i == 0) ? estimate_t_dec(jet, med, c->theta[j]) : t_dec[j];
+            t_dec[j] = td;
+            double cut = dmin(0.01 * td, 1e-2 * U_SEC);
+            if (is_rvs) {
+                cut = dmin(cut, 0.01 * jet->T0);
+                max_ref = dmax(max_ref, 10.0 * dmax(td, jet->T0));
+            }
+            if (i == 0) {
+                t_start_row[j] = dmax(ts, cut);
+                early_t_row[j] = 0.99 * dmin(ts, cut);
+            }
+            min_raw = dmin(min_raw, ts);
+            min_guarded = dmin(min_guarded, dmax(ts, cut));
+            min_cut = dmin(min_cut, cut);
         }
-        t_start_row[j] = dmax(ts, cut);
-        early_t_row[j] = 0.99 * dmin(ts, cut);
-        min_raw = dmin(min_raw, ts);
-        min_guarded = dmin(min_guarded, dmax(ts, cut));
-        min_cut = dmin(min_cut, cut);
-    }
     const double min_t_early = min_raw, min_t_start = min_guarded;
     const int has_early = min_raw < min_cut;
     const size_t t_num_base = (size_t)(dmax(log10(t_end / min_t_start), 1.0) * t_resol);
@@ -941,7 +949,7 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
 /* auto_grid, src/core/grid-refinement.h:639-706 */
 static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t_obs_min, double t_obs_max,
                      double theta_cut, double theta_view, double z, double phi_resol, double theta_resol, double t_resol,
-                     int is_rvs) {
+                     int is_rvs, int is_axisymmetric) {
     memset(c, 0, sizeof *c);
     c->theta_view = theta_view;
     const size_t min_theta_num = DEF_MIN_THETA_POINTS;
@@ -965,10 +973,10 @@ static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t
 
     size_t phi_base = (size_t)(360 * phi_resol);
     if (phi_base < 1) phi_base = 1;
-    const int mirror_phi = theta_view != 0 && phi_base > 4; /* is_axisymmetric == true */
+    const int mirror_phi = is_axisymmetric && theta_view != 0 && phi_base > 4;
     if (mirror_phi) {
         const size_t n_half = (phi_base + 1) / 2;
-        c->phi = adaptive_phi_grid(jet, n_half, theta_view, c->theta, c->n_theta, 1, C_PI, 5.0, &c->n_phi);
+        c->phi = adaptive_phi_grid(jet, n_half, theta_view, c->theta, c->n_theta, is_axisymmetric, C_PI, 5.0, &c->n_phi);
         c->phi_mirrored = 1;
     } else {
         const double doppler_sharpness = jet_Gamma0(jet, theta_view) * sin(theta_view);
@@ -981,15 +989,16 @@ static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t
             linspace(0., 2 * C_PI, (int)phi_num, c->phi);
             c->n_phi = (int)phi_num;
         } else {
-            c->phi = adaptive_phi_grid(jet, phi_num, theta_view, c->theta, c->n_theta, 1, 2 * C_PI, 0, &c->n_phi);
+            c->phi = adaptive_phi_grid(jet, phi_num, theta_view, c->theta, c->n_theta, is_axisymmetric, 2 * C_PI, 0, &c->n_phi);
         }
         if (phi_num >= 2) {
             const double shift = 0.5 * (c->phi[1] - c->phi[0]);
             for (int i = 0; i < c->n_phi; ++i) c->phi[i] += shift;
         }
     }
+    c->jet_3d = !is_axisymmetric && c->n_phi > 1;
     detect_symmetry(c, jet);
-    build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol, is_rvs);
+    build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol, is_rvs, is_axisymmetric);
     return 0;
 }
 
@@ -1827,7 +1836,7 @@ static void eat_free(eat_t* e) {
 
 static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_dist, double z) {
     const int nth = c->n_theta, nt = c->n_t;
-    const int eff_phi = (c->theta_view == 0) ? 1 : c->n_phi; /* jet_3d == 0 */
+    const int eff_phi = (c->theta_view == 0 && !c->jet_3d) ? 1 : c->n_phi;
     o->n_phi_eff = eff_phi;
     o->n_theta = nth;
     o->n_t = nt;
@@ -1937,7 +1946,7 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
             }
             const double dOmega = fabs((cos_th_hi - cos_th_lo) * dphi_i);
             cos_th_carry = cos_th_hi;
-            const double lg2_dOmega = log2(dOmega);
+            const double lg2_dOmega = c->jet_3d ? 0 : log2(dOmega); /* geom_pre_logged_ = !spreading && jet_3d == 0 */
             for (int k = 0; k < nt; ++k) {
                 const size_t s = (size_t)j * nt + k;
                 const size_t q = ((size_t)i * nth + j) * nt + k;
@@ -1945,7 +1954,7 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
                 const double r = sh->r[s];
                 const double dop_lin = gamma_ - sqrt((gamma_ - 1) * (gamma_ + 1)) * cos_v;
                 const double time = c->t[s] * o->one_plus_z + t_coeff * r;
-                const double geom = lg2_dOmega + lg2_r2[s];
+                const double geom = c->jet_3d ? log2(dOmega * r * r) : lg2_dOmega + lg2_r2[s];
                 /* finalize_log_grids */
                 o->lg2_doppler[q] = -log2(dop_lin);
                 o->lg2_t[q] = log2(time);
@@ -3051,7 +3060,7 @@ int vag_oracle_params_validate(const vag_model_params* p) {
             return fail("this jet type takes no magnetar");
     }
     if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING |
-                     VAG_FLAG_MAGNETAR))
+                     VAG_FLAG_MAGNETAR | VAG_FLAG_NON_AXISYMMETRIC))
         return fail("unknown bits set in flags");
     if (!(isfinite(p->rtol) && p->rtol > 0 && p->rtol < 1)) return fail("rtol must be in (0, 1)");
     if (!finite_pos(p->phi_resol) || !finite_pos(p->theta_resol) || !finite_pos(p->t_resol))
@@ -3116,11 +3125,13 @@ static void pipeline_free(pipeline_t* pl) {
 static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_min, double t_obs_max) {
     memset(pl, 0, sizeof *pl);
     if (vag_oracle_params_validate(p) != 0) return -1;
+    if ((p->flags & VAG_FLAG_NON_AXISYMMETRIC) && (p->flags & VAG_FLAG_SPREADING)) /* per-phi lattices: not restated */
+        return fail("axisymmetric=False with a spreading jet is not supported");
     jet_init(&pl->jet, p);
     medium_init(&pl->med, p);
     pl->has_rvs = (p->flags & VAG_FLAG_RVS) != 0;
     auto_grid(&pl->coord, &pl->jet, &pl->med, t_obs_min, t_obs_max, C_PI / 2, p->theta_obs, p->z, p->phi_resol,
-              p->theta_resol, p->t_resol, pl->has_rvs);
+              p->theta_resol, p->t_resol, pl->has_rvs, !(p->flags & VAG_FLAG_NON_AXISYMMETRIC));
     const int rc = pl->has_rvs ? generate_shock_pair(&pl->shock, &pl->rvs_shock, &pl->coord, &pl->med, &pl->jet, p)
                                : generate_fwd_shock(&pl->shock, &pl->coord, &pl->med, &pl->jet, p);
     if (rc != 0) {

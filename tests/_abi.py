@@ -53,7 +53,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
                 theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, duration=1.0, n_ism=1.0, A_star=0.0,
                 n0=float("inf"), lumi_dist=1e28, z=1.0, theta_obs=0.0, eps_e=0.1, eps_B=0.01, p=2.3,
                 xi_e=1.0, resolutions=None, rtol=1e-6, radiative_fireball=True, ssc=False, kn=False, rvs=None, sigma0=0.0,
-                spreading=False, k_m=2.0, magnetar=None):
+                spreading=False, k_m=2.0, magnetar=None, axisymmetric=True):
     # magnetar = (L0, t0, q) mirrors jet(..., magnetar=Magnetar(L0, t0, q))
     # rvs = dict(eps_e, eps_B, p[, xi_e, ssc, kn]) mirrors Model(rvs_rad=Radiation(...)); the default resolutions are
     # mode-aware like the reference's Model ctor (pybind/pymodel.h:630-637)
@@ -73,7 +73,7 @@ def make_params(jet="TophatJet", medium="ISM", theta_c=0.1, E_iso=1e52, Gamma0=3
     q.sigma0 = sigma0
     q.k_m = k_m
     q.radiative_fireball = 1 if radiative_fireball else 0
-    q.flags = (1 if ssc else 0) | (2 if kn else 0) | (32 if spreading else 0)
+    q.flags = (1 if ssc else 0) | (2 if kn else 0) | (32 if spreading else 0) | (0 if axisymmetric else 128)
     if magnetar:
         q.flags |= 64
         q.mag_L0, q.mag_t0, q.mag_q = magnetar

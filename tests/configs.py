@@ -109,3 +109,15 @@ MAGNETAR_CASES = {
     "tophat_mag_rs": dict(magnetar=MAG, duration=100.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
     "tophat_mag_ssc": dict(magnetar=MAG, ssc=True, kn=True),
 }
+
+# Model(axisymmetric=False): full-circle phi grid with every phi node observed
+NONAXI_CASES = {
+    "tophat_onaxis_3d": dict(axisymmetric=False),
+    "tophat_offaxis_3d": dict(theta_obs=0.3, axisymmetric=False),
+    "gauss_offaxis_3d": dict(jet="GaussianJet", theta_obs=0.2, axisymmetric=False),
+    "two_comp_onaxis_3d": dict(jet="TwoComponentJet", theta_w=0.3, E_iso_w=1e51, Gamma0_w=50.0, axisymmetric=False),
+    "tophat_ssc_3d": dict(theta_obs=0.1, ssc=True, axisymmetric=False),
+    "tophat_rs_3d": dict(theta_obs=0.1, duration=100.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3), axisymmetric=False),
+    "powerlaw_wind_one_phi_3d": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.02,
+                                     resolutions=(0.005, 0.5, 5.0), axisymmetric=False),
+}

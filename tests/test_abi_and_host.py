@@ -110,7 +110,9 @@ def test_constructor_validation_matches_reference_error_types():
     with pytest.raises(ValueError):
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, resolutions=(0.0, 0.15, 6))
     with pytest.raises(NotImplementedError):  # out-of-scope tiers fail loudly instead of silently degrading
-        va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, axisymmetric=False)
+        va.Model(va.TophatJet(0.1, 1e52, 300, spreading=True), va.ISM(1.0), obs, rad, axisymmetric=False)
+    m3d = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, axisymmetric=False)
+    assert m3d.params.flags == 128 and not m3d.axisymmetric
     with pytest.raises(TypeError):
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=(0.1, 0.01, 2.3))
     m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rvs_rad=va.Radiation(0.2, 0.02, 2.6, ssc=True))

@@ -735,3 +735,24 @@ def test_details_radiation_arrays(eng, oracle):
                   va.Radiation(0.1, 0.01, 2.3))
     ds = ms.details(1e2, 1e8)
     assert np.all(np.diff(ds["theta_cell"], axis=1) >= 0) and ds["theta_cell"][:, -1].max() > ds["theta"].max()
+
+
+@pytest.mark.parametrize("name", list(configs.NONAXI_CASES))
+def test_non_axisymmetric_models_match_oracle(eng, oracle, name):
+    """Model(axisymmetric=False) on the named jets: full-circle phi grid, every phi node observed."""
+    prm = _abi.make_params(**configs.NONAXI_CASES[name])
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    got, want = gpu_components4(eng, prm, t, nu), oracle.flux_components4(prm, t, nu)
+    for c in range(4):
+        if want[c].max() > 0:
+            assert_close(got[c][0], want[c], rtol=5e-6)
+    if name == "tophat_offaxis_3d":
+        m = va.Model(va.TophatJet(0.1, 1e52, 300.0), va.ISM(1.0), va.Observer(1e28, 1.0, 0.3), va.Radiation(0.1, 0.01, 2.3),
+                     resolutions=(prm.phi_resol, prm.theta_resol, prm.t_resol), axisymmetric=False)
+        assert m.params.flags == prm.flags == 128
+        d, o = m.details(t.min(), t.max()), oracle.details(prm, t.min(), t.max())
+        assert d["shape"] == {k: o["shape"][k] for k in d["shape"]} and not d["shape"]["phi_mirrored"]
+        np.testing.assert_allclose(d["phi"], o["phi"], rtol=2e-6)
+        assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)
+        with pytest.raises(NotImplementedError):
+            gpu_grid(eng, _abi.make_params(spreading=True, axisymmetric=False), t, nu)

@@ -407,6 +407,32 @@ def test_oracle_magnetar_bit_identical_to_strict_reference_build(oracle, ref_str
         assert 1.1 < (a[0] / plain)[1, 20] < 1.3
 
 
+@pytest.mark.parametrize("name", list(configs.NONAXI_CASES))
+def test_oracle_non_axisymmetric_bit_identical_to_strict_reference_build(oracle, ref_strict, name):
+    """Model(axisymmetric=False): full-circle phi grid, global time bounds scanned over every phi node, all phi nodes
+    observed even on-axis, geometry not pre-logged (grid-refinement.h:484-507,671-689, observer.cpp:215-222,424-425)."""
+    kw = configs.NONAXI_CASES[name]
+    prm = _abi.make_params(**kw)
+    t, nu = configs.SPREAD_T, configs.SPREAD_NU
+    a, b = oracle.flux_components4(prm, t, nu), ref_strict.flux_components4(prm, t, nu)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].max() > 0
+    da, db = oracle.details(prm, t.min(), t.max()), ref_strict.details(prm, t.min(), t.max())
+    assert da["shape"] == db["shape"] and not da["shape"]["phi_mirrored"]
+    assert da["shape"]["n_phi_eff"] == da["shape"]["n_phi"]
+    for k in ("phi", "theta", "t_src", "lg2_t", "lg2_doppler", "lg2_geom"):
+        assert np.array_equal(da[k], db[k], equal_nan=True), k
+    # same physics as the axisymmetric run, a different phi quadrature
+    ax = oracle.flux_density_grid(_abi.make_params(**dict(kw, axisymmetric=True)), t, nu)
+    total = sum(a)
+    sel = ax > 1e-3 * ax.max(axis=1, keepdims=True)
+    assert np.max(np.abs(total[sel] / ax[sel] - 1)) < 0.2
+
+
+def test_oracle_rejects_non_axisymmetric_spreading(oracle):
+    with pytest.raises(ValueError):
+        oracle.flux_density_grid(_abi.make_params(spreading=True, axisymmetric=False), configs.SPREAD_T, configs.SPREAD_NU)
+
+
 def _band_spec(prm_kw, with_points=True):
     """A vag_fit_spec with point data + two band groups + an extinction kernel, built directly on the C-ABI structs."""
     import ctypes as C

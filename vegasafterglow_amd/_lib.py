@@ -15,6 +15,7 @@ MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
 VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY, VAG_E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
 FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING, FLAG_MAGNETAR = 1, 2, 4, 8, 16, 32, 64  # VAG_FLAG_* of include/vegasafterglow_amd.h
+FLAG_NON_AXISYMMETRIC = 128
 
 # VAG_P_* slots of the fit transformer (include/vegasafterglow_amd.h)
 PARAM_SLOTS = {

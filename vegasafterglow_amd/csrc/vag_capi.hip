@@ -170,7 +170,7 @@ static const char* validate_msg(const vag_model_params* p) {
         if (p->jet_type == VAG_JET_POWERLAW_WING || p->jet_type == VAG_JET_MAGNETIZED_TOPHAT) return "this jet type takes no magnetar";
     }
     if (p->flags & ~(VAG_FLAG_SSC | VAG_FLAG_KN | VAG_FLAG_RVS | VAG_FLAG_RVS_SSC | VAG_FLAG_RVS_KN | VAG_FLAG_SPREADING |
-                     VAG_FLAG_MAGNETAR))
+                     VAG_FLAG_MAGNETAR | VAG_FLAG_NON_AXISYMMETRIC))
         return "unknown bits set in flags";
     if (p->flags & VAG_FLAG_RVS) {  // rvs_rad is a Radiation too (pymodel.h:241-260)
         if (!range_oi(p->rvs_eps_e, 0.0, 1.0)) return "rvs eps_e must be in (0, 1]";
@@ -557,6 +557,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                     return set_err(VAG_E_UNSUPPORTED, "models with different Radiation(ssc, kn) flags in one batch");
             }
         c->batch_flags = flags < 0 ? 0 : flags;
+        // a spreading jet under axisymmetric=False would need one time lattice and one ODE solve per (phi, theta) node
+        // (grid-refinement.h:619-625); not built -- see DESIGN.md "out of scope"
+        if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING))
+            return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet is not supported");
     }
     c->nb = nb;
     c->n_rows = rows;

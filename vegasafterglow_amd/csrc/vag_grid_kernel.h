@@ -328,7 +328,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     {
         size_t phi_base = (size_t)(360 * P.phi_resol);
         if (phi_base < 1) phi_base = 1;
-        const bool mirror = theta_v != 0 && phi_base > 4;
+        const bool axisym = !(P.flags & VAG_FLAG_NON_AXISYMMETRIC);  // Model(axisymmetric=...)
+        const bool mirror = axisym && theta_v != 0 && phi_base > 4;
         size_t phi_num;
         double phi_max, boost_cap;
         if (mirror) {
@@ -345,7 +346,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             phi_max = 2 * C_PI;
             boost_cap = 0;
         }
-        const bool uniform = (!mirror && phi_num <= 2) || theta_v == 0;
+        const bool uniform = (!mirror && phi_num <= 2) || (theta_v == 0 && axisym);
         if (uniform) {
             if (phi_num > VAG_MAX_PHI) {
                 M.status = VAG_E_CAPACITY;
@@ -472,6 +473,13 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, dmax(ts, cut));
             min_cut = dmin(min_cut, cut);
+            if (P.flags & VAG_FLAG_NON_AXISYMMETRIC)  // phi_size = |phi|: the global bounds scan every phi node (:484-507)
+                for (int i = 1; i < n_phi; ++i) {
+                    const double cos_ai = cos(th) * cos_tv + sin(th) * sin_tv * cos(sh.phi[i]);
+                    const double tsi = 0.99 * t_min * (1 - b) / (1 - cos_ai * b) / (1 + z);
+                    min_raw = dmin(min_raw, tsi);
+                    min_guarded = dmin(min_guarded, dmax(tsi, cut));
+                }
         }
         min_raw = wave_min(min_raw);
         min_guarded = wave_min(min_guarded);
@@ -498,7 +506,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     M.n_reps = n_reps;
     M.symmetry = symmetry;
     M.phi_mirrored = phi_mirrored;
-    M.n_phi_eff = (theta_v == 0) ? 1 : n_phi;  // Observer::build_time_grid, observer.cpp:218-222
+    // Observer::build_time_grid, observer.cpp:215-222 (jet_3d = non-axisymmetric model with more than one phi node)
+    M.n_phi_eff = (theta_v == 0 && !((P.flags & VAG_FLAG_NON_AXISYMMETRIC) && n_phi > 1)) ? 1 : n_phi;
     __syncthreads();
     for (int i = lane; i < n_phi; i += WAVE) g_phi[(size_t)m * VAG_MAX_PHI + i] = sh.phi[i];
     for (int j = lane; j < n_theta; j += WAVE) {

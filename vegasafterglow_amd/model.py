@@ -274,8 +274,8 @@ class Model:
             raise TypeError("rvs_rad must be a Radiation")
         if fwd_rad.kn and not fwd_rad.ssc:
             pass  # Klein-Nishina corrections only act through the IC cooling enabled by ssc (pymodel.h:567-577)
-        if not axisymmetric:
-            raise NotImplementedError("axisymmetric=False is SURVEY section 8(f) rank 3")
+        if not axisymmetric and getattr(jet, "spreading", False):
+            raise NotImplementedError("axisymmetric=False with a spreading jet needs per-(phi, theta) solves; not built")
         _req(math.isfinite(rtol) and 0 < rtol < 1, f"rtol must be in (0, 1), got {rtol}")
         # forward-only runs default to the coarser calibrated grid, reverse-shock runs to the denser one (pymodel.h:630-637)
         default_res = (0.06, 0.2, 10.0) if rvs_rad is not None else (0.06, 0.15, 6.0)
@@ -283,7 +283,7 @@ class Model:
         for n, x in zip(("phi_resol", "theta_resol", "t_resol"), res):
             _finite_pos(n, x)
         self._jet, self._medium, self.observer, self.fwd_rad, self.rvs_rad = jet, medium, observer, fwd_rad, rvs_rad
-        self.resolutions, self.rtol, self.axisymmetric, self.radiative_fireball = res, float(rtol), True, bool(radiative_fireball)
+        self.resolutions, self.rtol, self.axisymmetric, self.radiative_fireball = res, float(rtol), bool(axisymmetric), bool(radiative_fireball)
         self._device = device
         p = ModelParams()
         _lib.load().vag_params_default(C.byref(p))
@@ -297,6 +297,8 @@ class Model:
         p.flags = (_lib.FLAG_SSC if fwd_rad.ssc else 0) | (_lib.FLAG_KN if fwd_rad.kn else 0)
         if getattr(jet, "spreading", False):
             p.flags |= _lib.FLAG_SPREADING
+        if not axisymmetric:  # full-circle phi grid, no mirror / on-axis shortcut (grid-refinement.h:671-689)
+            p.flags |= _lib.FLAG_NON_AXISYMMETRIC
         mag = getattr(jet, "magnetar", None)
         if mag is not None:
             p.flags |= _lib.FLAG_MAGNETAR
