@@ -220,3 +220,27 @@ def test_stretch_move_sampler_recovers_a_gaussian_posterior():
     assert 0.2 < acc.mean() < 0.8 and np.all(np.isfinite(logp))
     with pytest.raises(ValueError):
         sampling.run_stretch_move(log_prob_batch, pos0[:5], 10)
+
+
+def test_batch_pool_routes_point_queues_through_one_batched_call():
+    """BatchPool (the bilby `pool=` adapter): a queue of sampler-space points is ONE batch_fn call; anything else falls
+    back to the per-point callable, and non-finite likelihoods come back as -inf."""
+    from vegasafterglow_amd import sampling
+    seen = []
+
+    def batch_fn(v):
+        seen.append(v.shape)
+        out = -0.5 * np.sum(v * v, axis=1)
+        out[0] = np.nan
+        return out
+
+    pool = sampling.BatchPool(batch_fn, ndim=3, size=64)
+    pts = [np.full(3, 0.1 * i) for i in range(10)]
+    got = pool.map(lambda x: 123.0, pts)
+    assert seen == [(10, 3)] and pool.calls == 1 and got[0] == -np.inf
+    assert np.allclose(got[1:], [-0.5 * 3 * (0.1 * i) ** 2 for i in range(1, 10)])
+    assert pool.map(lambda x: x + 1, [1, 2, 3]) == [2, 3, 4] and pool.calls == 1  # not a point queue
+    assert pool.map(lambda x: x, []) == []
+    with pool as p:
+        assert p is pool
+    pool.close(), pool.join(), pool.shutdown(wait=True)

@@ -7,7 +7,9 @@ walkers over a thread pool (VegasAfterglow/fitting/samplers.py:59-106).  Here th
 * ``emcee_sampler``  -- the reference's own sampler object, wired to the device closure (needs emcee installed);
 * ``run_stretch_move`` -- a dependency-free affine-invariant ensemble sampler (Goodman & Weare stretch move with the
   red-blue split emcee uses by default), so an end-to-end fit runs wherever the engine does.  Each half-step
-  proposes nwalkers/2 walkers and evaluates them in ONE ``log_prob_batch`` call.
+  proposes nwalkers/2 walkers and evaluates them in ONE ``log_prob_batch`` call;
+* ``BatchPool`` -- the object handed to ``bilby.run_sampler(pool=...)`` in place of the reference's thread pool
+  (samplers.py:146-170): ``pool.map(loglikelihood, points)`` becomes one device call over the whole live-point queue.
 """
 from typing import Callable, Optional, Sequence
 
@@ -36,6 +38,48 @@ def emcee_sampler(fitter: Fitter, param_defs: Sequence[ParamDef], nwalkers: int,
     log_prob_batch = fitter.make_log_prob_batch(param_defs, loglike_fn=loglike_fn)
     spec, _, _ = fitter.build_spec(param_defs)
     return emcee.EnsembleSampler(nwalkers, spec.ndim, log_prob_batch, vectorize=True, moves=moves)
+
+
+class BatchPool:
+    """Drop-in for ThreadPoolWithClose (fitting/samplers.py:146-170) as bilby / dynesty use it: with
+    ``use_pool={"loglikelihood": True}`` the sampler calls ``pool.map(loglikelihood, queue)`` with ``queue_size`` points
+    in sampler space; here the whole queue goes through ``batch_fn(points[n, ndim]) -> float64[n]`` (one device call,
+    e.g. ``fitter.make_log_prob_batch(defs)`` or ``lambda v: fitter.loglike_batch(defs, v)``) and the per-point callable
+    is only used for anything that is not a point queue."""
+
+    def __init__(self, batch_fn: Callable[[np.ndarray], np.ndarray], ndim: int, size: int = 1024):
+        self.batch_fn, self.ndim, self.size = batch_fn, int(ndim), int(size)  # `size`: queue length dynesty should fill
+        self.calls = 0
+
+    def map(self, func, iterable, chunksize=None):
+        tasks = list(iterable)
+        if not tasks:
+            return []
+        try:
+            pts = np.asarray(tasks, dtype=np.float64)
+        except (TypeError, ValueError):
+            pts = None
+        if pts is None or pts.ndim != 2 or pts.shape[1] != self.ndim:
+            return [func(x) for x in tasks]
+        self.calls += 1
+        out = np.asarray(self.batch_fn(pts), dtype=np.float64)
+        out[~np.isfinite(out)] = -np.inf  # non-finite likelihoods are rejected points (samplers.py:66-70)
+        return list(out)
+
+    def close(self):
+        pass
+
+    def join(self):
+        pass
+
+    def shutdown(self, wait=True):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def run_stretch_move(log_prob_batch: Callable[[np.ndarray], np.ndarray], pos0: np.ndarray, nsteps: int,
