@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvegasafterglow_amd.so")
+LIB_PATH = os.environ.get("VAG_LIB_PATH") or os.path.join(_HERE, "libvegasafterglow_amd.so")  # override: kernel experiments
 
 JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT = 0, 1, 2, 3, 4
 JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6

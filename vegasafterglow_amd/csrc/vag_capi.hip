@@ -181,9 +181,9 @@ static const char* validate_msg(const vag_model_params* p) {
     return nullptr;
 }
 
-// g(a) = log2(1 + 2^-a) interpolation table for sp_fast (vag_device.h): per interval of width 1/SP_PER_UNIT the
-// degree-(SP_NCOEF-1) interpolant at Chebyshev nodes, converted to monomials in tau = a*SP_PER_UNIT - idx - 1/2,
-// all in long double.
+// g(a) = log2(1 + 2^-a) interpolation table for sp_fast (vag_device.h): interval i is centred on the node a = i/SP_PER_UNIT
+// and holds the degree-(SP_NCOEF-1) interpolant at Chebyshev nodes, converted to monomials in
+// tau = a*SP_PER_UNIT - i in [-1/2, 1/2], all in long double.
 // Returns the max abs error measured on a dense check grid.
 static double build_softplus_table(std::vector<double>& tab) {
     const int n = SP_NCOEF, NI = SP_INTERVALS, per = SP_PER_UNIT;
@@ -195,11 +195,11 @@ static double build_softplus_table(std::vector<double>& tab) {
     for (int k = 2; k < n; ++k)
         for (int q = 0; q < n; ++q) T[k][q] = (q > 0 ? 2 * T[k - 1][q - 1] : 0) - T[k - 2][q];
     for (int i = 0; i < NI; ++i) {
-        const long double a0 = (long double)i / per, h = 1.0L / per;
+        const long double ac = (long double)i / per, h = 1.0L / per;
         long double f[SP_NCOEF], c[SP_NCOEF], mono[SP_NCOEF] = {};
         for (int j = 0; j < n; ++j) {
             const long double t = cosl(PI * (2 * j + 1) / (2 * n));
-            f[j] = log2l(1 + exp2l(-(a0 + h / 2 + h / 2 * t)));
+            f[j] = log2l(1 + exp2l(-(ac + h / 2 * t)));
         }
         for (int k = 0; k < n; ++k) {
             long double s = 0;
@@ -216,11 +216,12 @@ static double build_softplus_table(std::vector<double>& tab) {
         }
     }
     double maxerr = 0;
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI - 1; ++i)
         for (int s = 0; s <= 32; ++s) {
-            double a = (i + s / 32.0) / per;
-            int idx = std::min((int)(a * per), NI - 1);
-            const double tau = (a * per - idx) - 0.5;
+            const double a = (i + s / 32.0) / per;
+            const double t = std::fma(a, (double)per, SP_MAGIC);  // same node selection as sp_fast
+            const int idx = std::min((int)(t - SP_MAGIC), NI - 1);
+            const double tau = std::fma(a, (double)per, -(t - SP_MAGIC));
             const double* c = &tab[(size_t)idx * n];
             double p = c[n - 1];
             for (int q = n - 2; q >= 0; --q) p = std::fma(p, tau, c[q]);

@@ -37,31 +37,32 @@ struct VagGridMeta {
     double t_end;    // 1.01 t_max / (1+z)
 };
 
-// Per-cell parameter block the flux kernels stage in LDS: [row][VAG_NPAR][n_t].
-// 0..12: cached SmoothPowerLawSyn members read by compute_log2_I_nu
-//        (src/radiation/smooth-power-law-syn.h:20-47); 13..16: what the EAT step needs
-//        (src/core/observer.cpp:143-205).
+// Per-cell parameter block: [row][VAG_NPAR][n_t] in HBM, [k][VAG_NPAR] (144 B per cell) once staged in LDS.
+// 0..12: cached SmoothPowerLawSyn members read by compute_log2_I_nu (src/radiation/smooth-power-law-syn.h:20-47);
+// 13..17: what the EAT step needs (src/core/observer.cpp:143-205).  Members used together sit in 16-byte aligned
+// pairs, so the staged block is read with seven conflict-free ds_read_b128.
 enum {
-    VP_LG2_I = 0,   // log2_I_nu_max
+    VP_LG2_LO = 0,  // log2_nu_lo_
+    VP_LG2_HI,      // log2_nu_hi_
+    VP_DLO,         // diff_lo_
+    VP_INV_SLO,     // 1 / smooth_lo_  (== log2_norm_, smooth-power-law-syn.cpp:151)
+    VP_DHI,         // diff_hi_
+    VP_INV_SHI,     // 1 / smooth_hi_
     VP_LG2_NUM,     // log2_nu_m
-    VP_LG2_NUMAX,   // log2_nu_M
-    VP_INV_NUMAX,   // log2(e) / nu_M
     VP_TNORM,       // log2_thick_norm_
     VP_SAB,         // s_a_blend_
     VP_INV_SAB,     // 1 / s_a_blend_
-    VP_LG2_LO,      // log2_nu_lo_
-    VP_LG2_HI,      // log2_nu_hi_
-    VP_DLO,         // diff_lo_
-    VP_DHI,         // diff_hi_
-    VP_INV_SLO,     // 1 / smooth_lo_  (== log2_norm_, smooth-power-law-syn.cpp:151)
-    VP_INV_SHI,     // 1 / smooth_hi_
+    VP_LG2_I,       // log2_I_nu_max
+    VP_LG2_NUMAX,   // log2_nu_M
+    VP_INV_NUMAX,   // log2(e) / nu_M
+    VP_LG2_R2,      // 2 log2 r
     VP_GAMMA,       // bulk Lorentz factor
     VP_U,           // sqrt((Gamma-1)(Gamma+1))
     VP_R,           // radius
-    VP_LG2_R2,      // 2 log2 r
     VP_TENG,        // engine-frame lattice time
     VAG_NPAR
 };
+static_assert(VAG_NPAR % 2 == 0 && VP_GAMMA % 2 == 0 && VP_R % 2 == 0, "16-byte pairs");
 
 // Shock-state arrays written by the dynamics kernel (Shock, src/dynamics/shock.h:26-88), SoA over cells.
 enum { VS_TENG = 0, VS_TCOMV, VS_R, VS_GAMMA, VS_GAMMA_TH, VS_B, VS_NP, VS_THETA /* spreading jets only */, VAG_NSHOCK };

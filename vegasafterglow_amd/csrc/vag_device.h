@@ -783,47 +783,117 @@ VAG_DEV double log2_I_nu(const PtrT c, int st, const SpecConst& sc, double lg2_n
 }
 
 // ---- fast FP64 kernels for the hot evaluator (accuracy verified at context creation / in tests) ----
-// g(a) = log2(1 + 2^-a) on [0, 20]: 200 intervals of width 1/10, degree-5 Chebyshev-node interpolants
-// (max abs error 2.7e-14 in log2 units, i.e. < 2e-14 relative in flux); table built on the host in extended
-// precision (vag_capi.hip: build_softplus_table).  Three 16-byte LDS reads + 6 FMA-class ops per call.
+// On CDNA4 every wave64 VALU instruction -- FP64 FMA, 32-bit integer add, register move alike -- occupies its SIMD for
+// four cycles, and 32-bit integer multiplies / 64-bit multiply-adds take four times that.  The kernels below are
+// therefore written for instruction COUNT: Horner chains with the coefficients in SGPRs (no accumulator copies),
+// magic-number rounding instead of float<->int conversions, 24-bit multiplies and 32-bit LDS addresses.
+//
+// g(a) = log2(1 + 2^-a) on [0, 20]: 201 node-centred intervals of width 1/10 (interval i covers |a*10 - i| <= 1/2),
+// degree-5 Chebyshev-node interpolants (max abs error < 5e-14 in log2 units); table built on the host in extended
+// precision (vag_capi.hip: build_softplus_table).  Three 16-byte reads + 5 FMAs per call.
 constexpr int SP_PER_UNIT = 10;
-constexpr int SP_INTERVALS = 20 * SP_PER_UNIT;
+constexpr int SP_INTERVALS = 20 * SP_PER_UNIT + 1;
 constexpr int SP_NCOEF = 6;
 constexpr int SP_TABLE_DOUBLES = SP_INTERVALS * SP_NCOEF;
+constexpr double SP_MAGIC = 6755399441055744.0;  // 1.5 * 2^52: adding it rounds to an integer held in the low word
+
+#ifdef VAG_HOST_DEBUG
+struct vdouble2 {
+    double x, y;
+};
+typedef const vdouble2* LdsTab;
+#else
+typedef double vdouble2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const vdouble2* LdsTab;  // softplus table in LDS: 32-bit address arithmetic
+#endif
+VAG_DEV LdsTab lds_tab(const double* p) { return (LdsTab)p; }
+VAG_DEV const vdouble2* sp_row(const double* tab, int idx) { return reinterpret_cast<const vdouble2*>(tab) + idx * (SP_NCOEF / 2); }
+#ifndef VAG_HOST_DEBUG
+VAG_DEV LdsTab sp_row(LdsTab tab, int idx) { return tab + __mul24(idx, SP_NCOEF / 2); }
+#endif
+
+// The 13 spectral members of one staged cell in registers: seven 16-byte LDS reads, shared by every frequency the
+// work item evaluates.  Indexed with the VP_* names like the strided blocks in HBM.
+struct SpecRegs {
+    double v[14];
+    VAG_DEV double operator[](int i) const { return v[i]; }
+};
+VAG_DEV SpecRegs load_spec_regs(LdsTab cell) {
+    SpecRegs r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const vdouble2 t = cell[i];
+        r.v[2 * i] = t.x;
+        r.v[2 * i + 1] = t.y;
+    }
+    return r;
+}
 
 // log2_softplus (src/util/fast-math.h:179-185) = max(z,0) + g(|z|) with the reference's +-20 shortcuts
-VAG_DEV double sp_fast(double z, const double* __restrict__ tab) {
+template <class Tab>
+VAG_DEV double sp_fast(double z, Tab tab) {
     const double a = fabs(z);
+#ifndef VAG_SP_BRANCHLESS
     if (a > 20.0) return z > 0 ? z : 0.0;
-    int idx = (int)(a * (double)SP_PER_UNIT);
-    idx = idx > SP_INTERVALS - 1 ? SP_INTERVALS - 1 : idx;
-    const double tau = (a * (double)SP_PER_UNIT - (double)idx) - 0.5;
-    // the table is 16-byte aligned: three ds_read_b128 (256 B/clk)
-    const double2* c2 = reinterpret_cast<const double2*>(tab) + idx * (SP_NCOEF / 2);
-    const double2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
-    // Estrin scheme: short dependency chain
-    const double t2 = tau * tau;
-    const double p01 = fma(c01.y, tau, c01.x), p23 = fma(c23.y, tau, c23.x), p45 = fma(c45.y, tau, c45.x);
-    const double p = fma(fma(p45, t2, p23), t2, p01);
-    return 0.5 * (z + a) + p;  // max(z, 0) = (z + |z|) / 2, exact
+#endif
+    const double t = fma(a, (double)SP_PER_UNIT, SP_MAGIC);  // nearest node: integer in the low mantissa word
+    const int idx = (int)min((unsigned)__double2loint(t), (unsigned)(SP_INTERVALS - 1));  // the clamp only acts on NaN
+    const double tau = fma(a, (double)SP_PER_UNIT, -(t - SP_MAGIC));  // in [-1/2, 1/2]
+    const auto c2 = sp_row(tab, idx);
+    const vdouble2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
+    double p = fma(c45.y, tau, c45.x);
+    p = fma(p, tau, c23.y);
+    p = fma(p, tau, c23.x);
+    p = fma(p, tau, c01.y);
+    p = fma(p, tau, c01.x);
+#ifdef VAG_SP_BRANCHLESS
+    p = a > 20.0 ? 0.0 : p;  // straight-line code: independent softplus terms of one evaluation interleave
+#endif
+    return fma(0.5, z + a, p);  // max(z, 0) = (z + |z|) / 2, exact
 }
 
 // 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
-// 3.3e-16) + ldexp.  Large |x| (and +-inf) saturate through v_ldexp_f64 (0 / inf) exactly like exp2.
+// 3.3e-16) + ldexp.  Large |x| saturate through v_ldexp_f64 (0 / inf) exactly like exp2.  Horner: 12 dependent FMAs,
+// each `v_fma_f64 p, p, f, s[coef]` -- the Estrin form needed 15 + 5 accumulator copies.
+#ifdef VAG_HOST_DEBUG
+VAG_DEV double fma3(double a, double b, double c) { return fma(a, b, c); }
+#else
+// a * b + c as ONE instruction when c is a loop-invariant constant: the compiler's own choice is the two-address
+// v_fmac_f64 plus a register copy of the constant per Horner step.
+VAG_DEV double fma3(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
 VAG_DEV double exp2_fast(double x) {  // finite x only: +-inf would give inf - inf in the range reduction (see exp2_sat)
     const double n = rint(x);
     const double f = x - n;
-    // Estrin scheme over 13 coefficients
+#ifdef VAG_EXP2_ESTRIN
     const double f2 = f * f, f4 = f2 * f2, f8 = f4 * f4;
-    const double q01 = fma(0.6931471805599453, f, 1.0), q23 = fma(0.05550410866482158, f, 0.24022650695910072);
-    const double q45 = fma(0.0013333558146428443, f, 0.009618129107628477);
-    const double q67 = fma(1.5252733804059841e-05, f, 0.0001540353039338161);
-    const double q89 = fma(1.01780860092397e-07, f, 1.321548679014431e-06);
-    const double qab = fma(4.4455382718708116e-10, f, 7.054911620801123e-09);
+    const double q01 = fma(0.6931471805599453, f, 1.0), q23 = fma3(0.05550410866482158, f, 0.24022650695910072);
+    const double q45 = fma3(0.0013333558146428443, f, 0.009618129107628477);
+    const double q67 = fma3(1.5252733804059841e-05, f, 0.0001540353039338161);
+    const double q89 = fma3(1.01780860092397e-07, f, 1.321548679014431e-06);
+    const double qab = fma3(4.4455382718708116e-10, f, 7.054911620801123e-09);
     const double q03 = fma(q23, f2, q01), q47 = fma(q67, f2, q45), q8b = fma(qab, f2, q89);
     const double q07 = fma(q47, f4, q03);
     const double q8c = fma(2.5678435993488206e-11, f4, q8b);
     const double p = fma(q8c, f8, q07);
+#else
+    double p = fma(2.5678435993488206e-11, f, 4.4455382718708116e-10);
+    p = fma3(p, f, 7.054911620801123e-09);
+    p = fma3(p, f, 1.01780860092397e-07);
+    p = fma3(p, f, 1.321548679014431e-06);
+    p = fma3(p, f, 1.5252733804059841e-05);
+    p = fma3(p, f, 0.0001540353039338161);
+    p = fma3(p, f, 0.0013333558146428443);
+    p = fma3(p, f, 0.009618129107628477);
+    p = fma3(p, f, 0.05550410866482158);
+    p = fma3(p, f, 0.24022650695910072);
+    p = fma3(p, f, 0.6931471805599453);
+    p = fma(p, f, 1.0);
+#endif
     return ldexp(p, (int)n);
 }
 
@@ -846,7 +916,9 @@ VAG_DEV double log2_fast(double x) {
         e += 1;
     }
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double den = 2.0 + f, rden = rcp_fast(den);  // den in [1.7, 2.42]
+    double s = f * rden;
+    s = fma(fma(-den, s, f), rden, s);  // one residual step: f / den to <= 1 ulp without the IEEE division sequence
     const double z = s * s, w = z * z;
     const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
     const double t2 = z * (6.666666666666735130e-01 +
@@ -858,8 +930,8 @@ VAG_DEV double log2_fast(double x) {
 }
 
 // compute_log2_I_nu (smooth-power-law-syn.cpp:15-46,80-92,159-167) on the fast kernels above.
-template <class PtrT>
-VAG_DEV double log2_I_nu_fast(const PtrT c, int st, const SpecConst& sc, double lg2_nu, const double* __restrict__ sp) {
+template <class PtrT, class Tab>
+VAG_DEV double log2_I_nu_fast(const PtrT& c, int st, const SpecConst& sc, double lg2_nu, Tab sp) {
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
     const double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
                         sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];

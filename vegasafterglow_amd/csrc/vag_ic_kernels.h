@@ -164,9 +164,8 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
 
 // IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92).  `c`/`st` address the
 // 18-parameter block, `qv`/`qst` the IC extras of the same cell.  log2((1+Y_c)/(1+Y(nu))) = log2(1+Y_c) - sp(log2 Y).
-template <class P1, class P2>
-VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu,
-                            const double* __restrict__ sp) {
+template <class P1, class P2, class Tab>
+VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp) {
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
     double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
                   sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];

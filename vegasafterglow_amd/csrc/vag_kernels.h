@@ -331,9 +331,8 @@ constexpr int FLUX_SYN = 0;     // synchrotron, no inverse-Compton cooling
 constexpr int FLUX_SYN_IC = 1;  // synchrotron with the IC correction above nu_c
 constexpr int FLUX_SSC = 2;     // SSC tables
 
-template <class P1, class P2>
-VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu,
-                            const double* __restrict__ sp);
+template <class P1, class P2, class Tab>
+VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp);
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
 VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
                                  double th_max, double x, int* breach);
@@ -341,17 +340,25 @@ constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
 constexpr int FLUX_IC_STRIDE = 166;  // == IC_STRIDE
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
-// (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.
+// (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.  s_par holds the staged row as
+// [k][VAG_NPAR] blocks (144 B apart: conflict-free 16-byte LDS reads, one address per cell).
 VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads, double cos_v,
                      double t_coeff, double one_plus_z, double lg2_dOmega, double* __restrict__ s_t,
                      double* __restrict__ s_dop, double* __restrict__ s_geom) {
     for (int k = tid; k < K; k += nthreads) {
-        const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+        const double* c = s_par + k * VAG_NPAR;
+        const LdsTab c2 = lds_tab(c);
+        const vdouble2 Gu = c2[VP_GAMMA / 2], rt = c2[VP_R / 2];
+        const double G = Gu.x, u = Gu.y, r = rt.x;
+#if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 8)
+        s_dop[k] = G, s_t[k] = 3.0 + 0.1 * k + u, s_geom[k] = r;
+        continue;
+#endif
         const double lg2_dop = -log2_fast(G - u * cos_v);
-        const double time = s_par[VP_TENG * KS + k] * one_plus_z + t_coeff * r;
+        const double time = rt.y * one_plus_z + t_coeff * r;
         s_dop[k] = lg2_dop;
         s_t[k] = log2_fast(time);
-        s_geom[k] = (lg2_dOmega + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+        s_geom[k] = (lg2_dOmega + c[VP_LG2_R2]) + 3.0 * lg2_dop;
     }
 }
 
@@ -362,13 +369,16 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
                             double one_plus_z, double* __restrict__ s_t, double* __restrict__ s_dop,
                             double* __restrict__ s_geom) {
     for (int k = tid; k < K; k += nthreads) {
-        const double G = s_par[VP_GAMMA * KS + k], u = s_par[VP_U * KS + k], r = s_par[VP_R * KS + k];
+        const double* c = s_par + k * VAG_NPAR;
+        const LdsTab c2 = lds_tab(c);
+        const vdouble2 Gu = c2[VP_GAMMA / 2], rt = c2[VP_R / 2];
+        const double G = Gu.x, u = Gu.y, r = rt.x;
         const double cos_v = geo[K + k] * cos_phi * sin_obs + geo[k] * cos_obs;
         const double lg2_dop = -log2_fast(G - u * cos_v);
-        const double time = (s_par[VP_TENG * KS + k] + (1 - cos_v) * r / C_C) * one_plus_z;
+        const double time = (rt.y + (1 - cos_v) * r / C_C) * one_plus_z;
         s_dop[k] = lg2_dop;
         s_t[k] = log2_fast(time);
-        s_geom[k] = ((geo[2 * K + k] + lg2_dphi) + s_par[VP_LG2_R2 * KS + k]) + 3.0 * lg2_dop;
+        s_geom[k] = ((geo[2 * K + k] + lg2_dphi) + c[VP_LG2_R2]) + 3.0 * lg2_dop;
     }
 }
 
@@ -392,7 +402,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;                      // [SP_TABLE_DOUBLES] softplus table first: keeps it 16-byte aligned
-    double* s_par = s_sp + SP_TABLE_DOUBLES; // [VAG_NPAR][KS] photon/shock parameters of the staged row
+    double* s_par = s_sp + SP_TABLE_DOUBLES; // [KS][VAG_NPAR] photon/shock parameter block of every cell of the staged row
     double* s_t = s_par + VAG_NPAR * KS;     // [2][KS] log2 observer time of the row's lattice nodes (double buffered)
     double* s_dop = s_t + 2 * KS;            // [KS] log2 Doppler factor
     double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
@@ -401,7 +411,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_nu = s_tobs + nt;              // [nnu]
     double* s_w = s_nu + nnu;                // [nt] fractional position of each requested time inside its interval
     double* s_acc = s_w + nt;                // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
-    double* s_q = s_acc + slots;             // [FLUX_NQ][KS] IC-correction constants (FLUX_SYN_IC only)
+    double* s_q = s_acc + slots;             // [KS][FLUX_NQ] IC-correction constants (FLUX_SYN_IC only)
     int* s_kidx = (int*)(s_q + (MODE == FLUX_SYN_IC ? FLUX_NQ * KS : 0));  // [nt]
     int breach = 0;
 
@@ -417,7 +427,11 @@ vag_flux_grid_kernel(FluxArgs a) {
     sc.init(Pp->p);
     const double cos_obs = cos(Pp->theta_obs), sin_obs = sin(Pp->theta_obs);
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
-    const float inv_nt = 1.0f / (float)nt;
+    const LdsTab sp_tab = lds_tab(s_sp);
+    // slot = l * nt + idx walks in steps of THREADS: (l, idx) advance by a fixed (dl, didx) with one carry -- no divisions
+    // or integer multiplies inside the per-row loops
+    const int slot_dl = THREADS / nt, slot_didx = THREADS - slot_dl * nt;
+    const int slot_l0 = tid / nt, slot_idx0 = tid - slot_l0 * nt;
 
     for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
@@ -449,7 +463,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #pragma unroll 1
             for (int q = tid; q < VAG_NPAR * K; q += THREADS) {  // rare path: keep its register footprint small
                 const int par = (int)(((float)q + 0.5f) / (float)K);
-                s_par[par * KS + (q - par * K)] = src[q];
+                s_par[(q - par * K) * VAG_NPAR + par] = src[q];
             }
             if constexpr (MODE == FLUX_SSC) {
                 // the SSC pass never evaluates the synchrotron block: its first five rows carry the table headers
@@ -459,7 +473,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #pragma unroll 1
                 for (int q = tid; q < 5 * K; q += THREADS) {
                     const int kk = q / 5, w = q - kk * 5;
-                    s_par[w * KS + kk] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
+                    s_par[kk * VAG_NPAR + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
                 }
             }
             if constexpr (MODE == FLUX_SYN_IC) {
@@ -467,7 +481,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #pragma unroll 1
                 for (int q = tid; q < FLUX_NQ * K; q += THREADS) {
                     const int par = (int)(((float)q + 0.5f) / (float)K);
-                    s_q[par * KS + (q - par * K)] = srcq[q];
+                    s_q[(q - par * K) * FLUX_NQ + par] = srcq[q];
                 }
             }
             staged_rep = rep;
@@ -490,7 +504,12 @@ vag_flux_grid_kernel(FluxArgs a) {
             const double tq = s_tobs[idx];
             int kk = -1;
             double w = 0;
+#if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 4)
+            if (tq >= row_t0 && tq < row_tN) kk = min(idx, K - 2), w = 0.5;
+            if (false) {
+#else
             if (tq >= row_t0 && tq < row_tN) {
+#endif
                 int lo = 0, hi = K - 1;  // invariant: s_tc[lo] <= tq < s_tc[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
@@ -514,6 +533,10 @@ vag_flux_grid_kernel(FluxArgs a) {
             //   n_le = #{k : t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)  (first node > w_hi)
             const int lane = tid & 63;
             int n_lt = 0, n_le = 0;
+#if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 16)
+            n_lt = 1, n_le = K;
+            if (false)
+#endif
             for (int base = 0; base < K; base += 64) {
                 const int kk = base + lane;
                 const double v = kk < K ? s_tc[kk] : INFINITY;
@@ -540,27 +563,46 @@ vag_flux_grid_kernel(FluxArgs a) {
                 n_evals += (unsigned long long)nk * nnu;
                 n_interps += (unsigned long long)(n_ltN - n_lt0) * nnu;
             }
+            // item q = lg * nk + kk walks in steps of THREADS: (lg, kk) advance by (dq_l, dq_k) with one carry
+            const int dq_l = THREADS / nk, dq_k = THREADS - dq_l * nk;  // block-uniform (scalar unit)
+            int lg = (int)(((float)tid + 0.5f) * inv_nk);               // tid / nk (exact: tid < 2^20)
+            int kk = tid - __mul24(lg, nk);
+            int bofs = __mul24(lg, 2 * KS);  // s_B offset of frequency row l0 = 2 lg
+            const int top = (nnu - 1) * KS;
             for (int q = tid; q < total; q += THREADS) {
-                const int lg = (int)(((float)q + 0.5f) * inv_nk);  // q / nk (exact for q < 2^20)
-                const int k = k_lo + (q - lg * nk);
+                const int k = k_lo + kk;
                 const int l0 = lg * 2, l1 = min(l0 + 1, nnu - 1);
                 const double dop = s_dop[k], geom = s_geom[k];
+                const double* cp = s_par + __mul24(k, VAG_NPAR);
                 double b0, b1;
+#if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 1)  // developer aid: phase timing by omission
+                b0 = cp[0], b1 = cp[1];
+                if (false)
+#endif
                 if constexpr (MODE == FLUX_SYN) {
-                    b0 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l0] - dop, s_sp);
-                    b1 = log2_I_nu_fast(s_par + k, KS, sc, s_nu[l1] - dop, s_sp);
+                    const SpecRegs regs = load_spec_regs(lds_tab(s_par) + __mul24(k, VAG_NPAR / 2));
+                    b0 = log2_I_nu_fast(regs, 1, sc, s_nu[l0] - dop, sp_tab);
+                    b1 = log2_I_nu_fast(regs, 1, sc, s_nu[l1] - dop, sp_tab);
                 } else if constexpr (MODE == FLUX_SYN_IC) {
-                    b0 = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, s_nu[l0] - dop, s_sp);
-                    b1 = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, s_nu[l1] - dop, s_sp);
+                    const double* cq = s_q + __mul24(k, FLUX_NQ);
+                    b0 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l0] - dop, sp_tab);
+                    b1 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l1] - dop, sp_tab);
                 } else {
                     const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
-                    const double h0 = s_par[k], h1 = s_par[KS + k], h2 = s_par[2 * KS + k], h3 = s_par[3 * KS + k],
-                                 h4 = s_par[4 * KS + k];
+                    const double h0 = cp[0], h1 = cp[1], h2 = cp[2], h3 = cp[3], h4 = cp[4];
                     b0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
                     b1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
                 }
-                s_B[l0 * KS + k] = b0 + geom;
-                s_B[l1 * KS + k] = b1 + geom;
+                s_B[bofs + k] = b0 + geom;
+                s_B[min(bofs + KS, top) + k] = b1 + geom;
+                kk += dq_k;
+                lg += dq_l;
+                bofs += dq_l * 2 * KS;
+                if (kk >= nk) {
+                    kk -= nk;
+                    ++lg;
+                    bofs += 2 * KS;
+                }
             }
         }
         __syncthreads();
@@ -572,15 +614,23 @@ vag_flux_grid_kernel(FluxArgs a) {
         // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433).  slot = l * nt + idx is
         //      always visited by the same lane, so the LDS accumulator needs no atomics and the sum order is fixed.
         if (in_window) {
+            int idx = slot_idx0, lKS = slot_l0 * KS;
+#if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 2)
+            if (false)
+#endif
 #pragma unroll 2
             for (int slot = tid; slot < slots; slot += THREADS) {
-                const int l = (int)(((float)slot + 0.5f) * inv_nt);
-                const int idx = slot - l * nt;
                 const int k = s_kidx[idx];
                 if (k >= 0) {
-                    const double lo = s_B[l * KS + k], hi = s_B[l * KS + k + 1];
+                    const double lo = s_B[lKS + k], hi = s_B[lKS + k + 1];
                     const double d = hi - lo;  // slope finite <=> d finite (observer.h:422-426)
                     if (isfinite(d)) s_acc[slot] += exp2_fast(fma(d, s_w[idx], lo));
+                }
+                idx += slot_didx;
+                lKS += slot_dl * KS;
+                if (idx >= nt) {
+                    idx -= nt;
+                    lKS += KS;
                 }
             }
         }
@@ -689,7 +739,8 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
-    double* s_q = s_geom + KS;  // [FLUX_NQ][KS], FLUX_SYN_IC only
+    double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
+    const LdsTab sp_tab = lds_tab(s_sp);
     for (int i = tid; i < SP_TABLE_DOUBLES; i += SERIES_THREADS) s_sp[i] = a.sp_table[i];
     int breach = 0;
 
@@ -720,14 +771,14 @@ vag_flux_series_kernel(SeriesArgs a) {
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
             for (int q = tid; q < VAG_NPAR * K; q += SERIES_THREADS) {
-                const int par = q / K, k = q - par * K;
-                s_par[par * KS + k] = src[q];
+                const int par = (int)(((float)q + 0.5f) / (float)K), k = q - par * K;  // q / K, exact for q < 2^20
+                s_par[k * VAG_NPAR + par] = src[q];
             }
             if (MODE == FLUX_SYN_IC) {
                 const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K) * FLUX_NQ;
                 for (int q = tid; q < FLUX_NQ * K; q += SERIES_THREADS) {
-                    const int par = q / K, k = q - par * K;
-                    s_q[par * KS + k] = srcq[q];
+                    const int par = (int)(((float)q + 0.5f) / (float)K), k = q - par * K;
+                    s_q[k * FLUX_NQ + par] = srcq[q];
                 }
             }
             staged_rep = rep;
@@ -763,11 +814,12 @@ vag_flux_series_kernel(SeriesArgs a) {
                     const int k = lo;
                     double blo, bhi;
                     if (MODE == FLUX_SYN) {
-                        blo = log2_I_nu_fast(s_par + k, KS, sc, nuq[q] - s_dop[k], s_sp);
-                        bhi = log2_I_nu_fast(s_par + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp);
+                        blo = log2_I_nu_fast(s_par + k * VAG_NPAR, 1, sc, nuq[q] - s_dop[k], sp_tab);
+                        bhi = log2_I_nu_fast(s_par + (k + 1) * VAG_NPAR, 1, sc, nuq[q] - s_dop[k + 1], sp_tab);
                     } else if (MODE == FLUX_SYN_IC) {
-                        blo = log2_I_nu_ic(s_par + k, KS, s_q + k, KS, sc, nuq[q] - s_dop[k], s_sp);
-                        bhi = log2_I_nu_ic(s_par + k + 1, KS, s_q + k + 1, KS, sc, nuq[q] - s_dop[k + 1], s_sp);
+                        blo = log2_I_nu_ic(s_par + k * VAG_NPAR, 1, s_q + k * FLUX_NQ, 1, sc, nuq[q] - s_dop[k], sp_tab);
+                        bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, s_q + (k + 1) * FLUX_NQ, 1, sc, nuq[q] - s_dop[k + 1],
+                                           sp_tab);
                     } else {
                         const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + k) * FLUX_IC_STRIDE;
                         blo = ic_table_eval(tab, nuq[q] - s_dop[k], &breach);
