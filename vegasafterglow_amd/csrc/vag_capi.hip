@@ -881,7 +881,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 3 + (mode == FLUX_SYN_IC ? VAG_NQ : 0)) * ks + SP_TABLE_DOUBLES);
+    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC) + SP_TABLE_DOUBLES);
+    const dim3 sgrid((max_blocks + SERIES_WAVES - 1) / SERIES_WAVES, nb), sblock(SERIES_THREADS * SERIES_WAVES);
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();
@@ -909,17 +910,17 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     c->plan.pairs_per_block = (int)ppb;
     if (c->n_rows > 0) {
         if (spreading && mode == FLUX_SYN_IC)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN_IC, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN_IC, true>), sgrid, sblock, lds, st, a);
         else if (spreading && mode == FLUX_SSC)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SSC, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SSC, true>), sgrid, sblock, lds, st, a);
         else if (spreading)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN, true>), dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN, true>), sgrid, sblock, lds, st, a);
         else if (mode == FLUX_SYN_IC)
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN_IC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN_IC>, sgrid, sblock, lds, st, a);
         else if (mode == FLUX_SSC)
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SSC>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SSC>, sgrid, sblock, lds, st, a);
         else
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN>, dim3(max_blocks, nb), dim3(SERIES_THREADS), lds, st, a);
+            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN>, sgrid, sblock, lds, st, a);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));

@@ -697,8 +697,20 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 // (row, point).  Sharing of boundary values between equal-frequency runs in the reference changes cost,
 // not values.  Output partial[m][block][n].
 // ------------------------------------------------------------------------------------------------
-constexpr int SERIES_THREADS = 64;
-constexpr int SERIES_MAX_SLOTS = 8;  // data points per lane: n <= 512
+constexpr int SERIES_THREADS = 64;    // lanes that share one (theta, phi) row: ONE wavefront, so rows need no block barrier
+constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup; they only share the softplus table in LDS
+constexpr int SERIES_MAX_SLOTS = 8;   // data points per lane: n <= 512
+// doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
+__host__ __device__ inline int series_region_doubles(int ks, bool ic) { return ((VAG_NPAR + 3 + (ic ? 14 : 0)) * ks + 1) & ~1; }
+
+// LDS produced and consumed by the same wavefront: program order suffices in hardware, the fence keeps the compiler from
+// moving accesses across it
+VAG_DEV void wave_sync() {
+#ifndef VAG_HOST_DEBUG
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 
 struct SeriesArgs {
     const vag_model_params* params;
@@ -721,27 +733,31 @@ struct SeriesArgs {
 };
 
 template <int MODE, bool SPREAD = false>
-__global__ void __launch_bounds__(SERIES_THREADS)
+__global__ void __launch_bounds__(SERIES_THREADS * SERIES_WAVES)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
-    const VagGridMeta M = a.meta[m];
-    double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * a.n;
-    if (M.status != 0) return;
-    const int n_pairs = M.n_theta * M.n_phi_eff;
-    const int p0 = blockIdx.x * a.pairs_per_block;
-    if (p0 >= n_pairs) return;
-    const int p1 = min(n_pairs, p0 + a.pairs_per_block);
-    const int tid = threadIdx.x;
-    const int K = M.n_t, KS = a.k_stride;
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;  // `tid`: lane inside this row's wavefront
+    const int KS = a.k_stride;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;
-    double* s_par = s_sp + SP_TABLE_DOUBLES;
+    for (int i = threadIdx.x; i < SP_TABLE_DOUBLES; i += SERIES_THREADS * SERIES_WAVES) s_sp[i] = a.sp_table[i];
+    __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
+    const int vb = blockIdx.x * SERIES_WAVES + wave;  // virtual block = wavefront
+    if (vb >= a.max_blocks) return;
+    const VagGridMeta M = a.meta[m];
+    double* my_partial = a.partial + ((size_t)m * a.max_blocks + vb) * a.n;
+    if (M.status != 0) return;
+    const int n_pairs = M.n_theta * M.n_phi_eff;
+    const int p0 = vb * a.pairs_per_block;
+    if (p0 >= n_pairs) return;
+    const int p1 = min(n_pairs, p0 + a.pairs_per_block);
+    const int K = M.n_t;
+    double* s_par = s_sp + SP_TABLE_DOUBLES + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC);
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
     double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
     const LdsTab sp_tab = lds_tab(s_sp);
-    for (int i = tid; i < SP_TABLE_DOUBLES; i += SERIES_THREADS) s_sp[i] = a.sp_table[i];
     int breach = 0;
 
     const vag_model_params P = a.params[m];
@@ -767,7 +783,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     for (int pair = p0; pair < p1; ++pair) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
         const int rep = rep_of[j];
-        __syncthreads();
+        wave_sync();
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
             for (int q = tid; q < VAG_NPAR * K; q += SERIES_THREADS) {
@@ -782,7 +798,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                 }
             }
             staged_rep = rep;
-            __syncthreads();
+            wave_sync();
         }
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
@@ -794,7 +810,7 @@ vag_flux_series_kernel(SeriesArgs a) {
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
             eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
         }
-        __syncthreads();
+        wave_sync();
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
 #pragma unroll
         for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
