@@ -231,6 +231,36 @@ static double build_softplus_table(std::vector<double>& tab) {
     return maxerr;
 }
 
+// log2_tab (vag_device.h): entry i = {rc = double(1 / c_i), -log2(rc)} with c_i the centre of the i-th 1/64 slice of [1, 2).
+// Returns the max error of the same arithmetic on the host relative to max(1, |log2 x|).
+static double append_log2_table(std::vector<double>& tab) {
+    for (int i = 0; i < LOG_TAB_N; ++i) {
+        const double rc = (double)(1.0L / (1.0L + (i + 0.5L) / LOG_TAB_N));
+        tab.push_back(rc);
+        tab.push_back((double)(-log2l((long double)rc)));
+    }
+    const double* lt = tab.data() + tab.size() - LOG_TAB_DOUBLES;
+    double maxerr = 0;
+    for (int s = 0; s < 200000; ++s) {
+        const double x = std::ldexp(1.0 + (s + 0.37) / 200000.0, (s % 41) - 20);
+        int e;
+        const double m = 2 * std::frexp(x, &e);  // [1, 2)
+        e -= 1;
+        const int idx = std::min((int)((m - 1) * LOG_TAB_N), LOG_TAB_N - 1);
+        const double r = std::fma(m, lt[2 * idx], -1.0);
+        double q = std::fma(1.0 / 7, r, -1.0 / 6);
+        q = std::fma(q, r, 0.2);
+        q = std::fma(q, r, -0.25);
+        q = std::fma(q, r, 1.0 / 3);
+        q = std::fma(q, r, -0.5);
+        const double ln_m = std::fma(q * r, r, r);
+        const double got = std::fma(ln_m, LOG2E, (double)e + lt[2 * idx + 1]);
+        const long double want = log2l((long double)x);
+        maxerr = std::max(maxerr, (double)(fabsl(got - want) / std::max(1.0L, fabsl(want))));
+    }
+    return maxerr;
+}
+
 struct vag_ctx {
     int device = 0;
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_ssc;
@@ -375,6 +405,8 @@ int vag_ctx_create(int device, vag_ctx** out) {
         std::vector<double> tab;
         const double err = build_softplus_table(tab);
         if (!(err < 5e-14)) return set_err(VAG_E_HIP, "softplus table accuracy check failed: %.3e", err);
+        const double lerr = append_log2_table(tab);  // [SP_TABLE_DOUBLES, SP_LDS_DOUBLES): log2_tab's {1/c, -log2(1/c)} pairs
+        if (!(lerr < 4e-16)) return set_err(VAG_E_HIP, "log2 table accuracy check failed: %.3e", lerr);
         if (c->d_sptab.ensure(sizeof(double) * tab.size())) return VAG_E_HIP;
         HIPCHK(hipMemcpy(c->d_sptab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
     }
@@ -665,7 +697,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
     const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4 + (mode == FLUX_SYN_IC ? VAG_NQ : 0)) * ks + (size_t)ks * nnu +
-                                         2 * nt + nnu + SP_TABLE_DOUBLES + slots) +
+                                         2 * nt + nnu + SP_LDS_DOUBLES + slots) +
                        sizeof(int) * nt;
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     FluxArgs a;
@@ -881,7 +913,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC) + SP_TABLE_DOUBLES);
+    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC) + SP_LDS_DOUBLES);
     const dim3 sgrid((max_blocks + SERIES_WAVES - 1) / SERIES_WAVES, nb), sblock(SERIES_THREADS * SERIES_WAVES);
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();

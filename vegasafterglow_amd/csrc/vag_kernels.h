@@ -344,7 +344,7 @@ constexpr int FLUX_IC_STRIDE = 166;  // == IC_STRIDE
 // [k][VAG_NPAR] blocks (144 B apart: conflict-free 16-byte LDS reads, one address per cell).
 VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads, double cos_v,
                      double t_coeff, double one_plus_z, double lg2_dOmega, double* __restrict__ s_t,
-                     double* __restrict__ s_dop, double* __restrict__ s_geom) {
+                     double* __restrict__ s_dop, double* __restrict__ s_geom, LdsTab lg) {
     for (int k = tid; k < K; k += nthreads) {
         const double* c = s_par + k * VAG_NPAR;
         const LdsTab c2 = lds_tab(c);
@@ -354,10 +354,10 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
         s_dop[k] = G, s_t[k] = 3.0 + 0.1 * k + u, s_geom[k] = r;
         continue;
 #endif
-        const double lg2_dop = -log2_fast(G - u * cos_v);
+        const double lg2_dop = -log2_tab(G - u * cos_v, lg);
         const double time = rt.y * one_plus_z + t_coeff * r;
         s_dop[k] = lg2_dop;
-        s_t[k] = log2_fast(time);
+        s_t[k] = log2_tab(time, lg);
         s_geom[k] = (lg2_dOmega + c[VP_LG2_R2]) + 3.0 * lg2_dop;
     }
 }
@@ -367,17 +367,17 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
 VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads,
                             const double* __restrict__ geo, double cos_phi, double sin_obs, double cos_obs, double lg2_dphi,
                             double one_plus_z, double* __restrict__ s_t, double* __restrict__ s_dop,
-                            double* __restrict__ s_geom) {
+                            double* __restrict__ s_geom, LdsTab lg) {
     for (int k = tid; k < K; k += nthreads) {
         const double* c = s_par + k * VAG_NPAR;
         const LdsTab c2 = lds_tab(c);
         const vdouble2 Gu = c2[VP_GAMMA / 2], rt = c2[VP_R / 2];
         const double G = Gu.x, u = Gu.y, r = rt.x;
         const double cos_v = geo[K + k] * cos_phi * sin_obs + geo[k] * cos_obs;
-        const double lg2_dop = -log2_fast(G - u * cos_v);
+        const double lg2_dop = -log2_tab(G - u * cos_v, lg);
         const double time = (rt.y + (1 - cos_v) * r / C_C) * one_plus_z;
         s_dop[k] = lg2_dop;
-        s_t[k] = log2_fast(time);
+        s_t[k] = log2_tab(time, lg);
         s_geom[k] = ((geo[2 * K + k] + lg2_dphi) + c[VP_LG2_R2]) + 3.0 * lg2_dop;
     }
 }
@@ -402,7 +402,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;                      // [SP_TABLE_DOUBLES] softplus table first: keeps it 16-byte aligned
-    double* s_par = s_sp + SP_TABLE_DOUBLES; // [KS][VAG_NPAR] photon/shock parameter block of every cell of the staged row
+    double* s_par = s_sp + SP_LDS_DOUBLES;   // [KS][VAG_NPAR] photon/shock parameter block of every cell of the staged row
     double* s_t = s_par + VAG_NPAR * KS;     // [2][KS] log2 observer time of the row's lattice nodes (double buffered)
     double* s_dop = s_t + 2 * KS;            // [KS] log2 Doppler factor
     double* s_geom = s_dop + KS;             // [KS] log2(dOmega r^2 D^3)
@@ -421,13 +421,13 @@ vag_flux_grid_kernel(FluxArgs a) {
         const double lg2_1pz = log2(one_plus_z);
         for (int i = tid; i < nt; i += THREADS) s_tobs[i] = a.lg2_t_obs[i];
         for (int l = tid; l < nnu; l += THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
-        for (int i = tid; i < SP_TABLE_DOUBLES; i += THREADS) s_sp[i] = a.sp_table[i];
+        for (int i = tid; i < SP_LDS_DOUBLES; i += THREADS) s_sp[i] = a.sp_table[i];  // softplus table + log2 table
     }
     SpecConst sc;
     sc.init(Pp->p);
     const double cos_obs = cos(Pp->theta_obs), sin_obs = sin(Pp->theta_obs);
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
-    const LdsTab sp_tab = lds_tab(s_sp);
+    const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     // slot = l * nt + idx walks in steps of THREADS: (l, idx) advance by a fixed (dl, didx) with one carry -- no divisions
     // or integer multiplies inside the per-row loops
     const int slot_dl = THREADS / nt, slot_didx = THREADS - slot_dl * nt;
@@ -447,12 +447,12 @@ vag_flux_grid_kernel(FluxArgs a) {
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K) * 3;
             eat_row_spread(s_par, KS, K, tid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
-                           s_t + buf * KS, s_dop, s_geom);
+                           s_t + buf * KS, s_dop, s_geom, lg_tab);
         } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-            eat_row(s_par, KS, K, tid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom);
+            eat_row(s_par, KS, K, tid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom, lg_tab);
         }
     };
     int staged_rep = -1;
@@ -740,7 +740,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int KS = a.k_stride;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;
-    for (int i = threadIdx.x; i < SP_TABLE_DOUBLES; i += SERIES_THREADS * SERIES_WAVES) s_sp[i] = a.sp_table[i];
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += SERIES_THREADS * SERIES_WAVES) s_sp[i] = a.sp_table[i];
     __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
     const int vb = blockIdx.x * SERIES_WAVES + wave;  // virtual block = wavefront
     if (vb >= a.max_blocks) return;
@@ -752,12 +752,12 @@ vag_flux_series_kernel(SeriesArgs a) {
     if (p0 >= n_pairs) return;
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int K = M.n_t;
-    double* s_par = s_sp + SP_TABLE_DOUBLES + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC);
+    double* s_par = s_sp + SP_LDS_DOUBLES + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC);
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
     double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
-    const LdsTab sp_tab = lds_tab(s_sp);
+    const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     int breach = 0;
 
     const vag_model_params P = a.params[m];
@@ -803,12 +803,12 @@ vag_flux_series_kernel(SeriesArgs a) {
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
             eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z, s_t,
-                           s_dop, s_geom);
+                           s_dop, s_geom, lg_tab);
         } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-            eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom);
+            eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
         }
         wave_sync();
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
