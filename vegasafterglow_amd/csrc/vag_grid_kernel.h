@@ -14,6 +14,12 @@ constexpr int WAVE = 64;
 constexpr int N_SCAN = 512;      // find_jet_jumps / find_theta_range scans
 constexpr int N_SAMPLES = 200;   // defaults::sampling::theta_samples
 
+#ifdef VAG_GRID_STAMPS  // developer aid: cycle stamps of model 0 at the section boundaries, printed by lane 0
+#define VAG_GRID_STAMP(i) do { if (m == 0 && lane == 0) stamps_[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VAG_GRID_STAMP(i) do { } while (0)
+#endif
+
 VAG_DEV double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
@@ -51,30 +57,85 @@ struct GridShared {
     int flag[VAG_MAX_THETA];
 };
 
+VAG_DEV double lane_value(double v, int src_lane) {  // wave-uniform copy of lane src_lane's v
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One accepted DOPRI5 step of d(cdf)/dx = pdf(x): the arithmetic of Dopri5<1>::step (vag_device.h) to the last bit, but
+// the right-hand side does not depend on cdf, so the stage abscissae x + {1/5, 3/10, 4/5, 8/9, 1} h are known up front and
+// their five pdf values are evaluated side by side (`stages(tx, kv)`; stages 6 and 7 share x + h) -- one pdf latency per
+// attempted step instead of six.
+template <class Stages>
+VAG_DEV bool quad_step(Dopri5<1>& s, Stages& stages) {
+    constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
+                     dc5 = c5 - -92097.0 / 339200, dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+    s.t_old = s.t;
+    for (int fails = 0; fails < 500; ++fails) {
+        const double h = s.dt;
+        const double tx[5] = {s.t + h * a2, s.t + h * a3, s.t + h * a4, s.t + h * a5, s.t + h};
+        double kv[5];
+        stages(tx, kv);
+        const double k3 = kv[1], k4 = kv[2], k5 = kv[3], k6 = kv[4], k7 = kv[4];
+        const double x = s.x[0], dx = s.dx[0];
+        const double xn = x + (h * c1) * dx + (h * c3) * k3 + (h * c4) * k4 + (h * c5) * k5 + (h * c6) * k6;
+        const double xe = (h * dc1) * dx + (h * dc3) * k3 + (h * dc4) * k4 + (h * dc5) * k5 + (h * dc6) * k6 + (h * dc7) * k7;
+        double err = dmax(0.0, fabs(xe) * rcp_fast(s.eps + s.eps * (fabs(x) + fabs(h) * fabs(dx))));
+        if (err > 1.0) {
+            s.dt = h * dmax(9.0 / 10.0 * exp2_sat(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
+            continue;
+        }
+        s.xo[0] = x;
+        s.dxo[0] = dx;
+        s.x[0] = xn;
+        s.dx[0] = k7;
+        s.k3[0] = k3;
+        s.k4[0] = k4;
+        s.k5[0] = k5;
+        s.k6[0] = k6;
+        s.t = s.t + h;
+        if (err < 0.5) {
+            err = dmax(3.2e-4, err);  // 5^-5
+            s.dt = h * (9.0 / 10.0 * exp2_fast(log2_fast(err) * (-1.0 / 5)));
+        }
+        return true;
+    }
+    return false;
+}
+
 // Integrate d(cdf)/dx = pdf(x) from lo to hi with boost's dense-output DOPRI5 at rtol=atol=1e-6 and
 // sample it at sh.xs[1..N_SAMPLES) (inverse_CFD_sampling, grid-refinement.h:138-161).
-// pdf(x) must be wave-uniform.
-template <class Pdf>
-VAG_DEV void integrate_cdf(GridShared& sh, Pdf& pdf, double lo, double hi) {
-    struct Rhs {
-        Pdf& pdf;
-        VAG_DEV void operator()(const double*, double* d, double x) const { d[0] = pdf(x); }
-    } rhs{pdf};
+// pdf0 = pdf(lo) (wave-uniform); stages(tx[5], kv[5]) returns the wave-uniform pdf at five abscissae.
+template <class Stages>
+VAG_DEV void integrate_cdf(GridShared& sh, double pdf0, Stages& stages, double lo, double hi) {
     const int lane = threadIdx.x;
     for (int k = lane; k < N_SAMPLES; k += WAVE) sh.cdf[k] = 0;
     __syncthreads();
     Dopri5<1> st;
-    const double x0 = 0;
-    st.init(&x0, lo, (hi - lo) / 1e3, 1e-6, rhs);
+    st.x[0] = 0;
+    st.dx[0] = pdf0;
+    st.t = lo;
+    st.dt = (hi - lo) / 1e3;
+    st.eps = 1e-6;
     int k = 1;
     for (int steps = 0; st.t <= hi;) {
-        if (!st.step(rhs)) break;
+        if (!quad_step(st, stages)) break;
         if (++steps > 100000) break;
-        while (k < N_SAMPLES && st.t > sh.xs[k]) {
-            double v;
-            st.interp(sh.xs[k], &v);
-            if (lane == 0) sh.cdf[k] = v;
-            ++k;
+        // dense output at every sample the step passed: one sample per lane (same arithmetic per sample as a serial sweep)
+        for (;;) {
+            const int kk = k + lane;
+            const bool in = kk < N_SAMPLES && st.t > sh.xs[kk];
+            if (in) {
+                double v;
+                st.interp(sh.xs[kk], &v);
+                sh.cdf[kk] = v;
+            }
+            const int cnt = __popcll(__ballot(in));  // xs ascends: the passed samples are a prefix of the lanes
+            k += cnt;
+            if (cnt < WAVE) break;
         }
     }
     __syncthreads();
@@ -86,15 +147,22 @@ VAG_DEV void invert_cdf(const GridShared& sh, int num, bool midpoint, double* ou
     for (int k = threadIdx.x; k < num; k += WAVE) {
         const double target = midpoint ? front + (back - front) * ((double)k + 0.5) / num : linspace_at(front, back, num, k);
         double x = 0;
-        for (int j = 0; j < N_SAMPLES; ++j) {
-            if (target <= sh.cdf[j]) {
-                if (j == 0) {
-                    x = sh.xs[0];
-                } else {
-                    const double denom = sh.cdf[j] - sh.cdf[j - 1];
-                    x = denom > 0 ? sh.xs[j - 1] + (sh.xs[j] - sh.xs[j - 1]) / denom * (target - sh.cdf[j - 1]) : sh.xs[j - 1];
-                }
-                break;
+        // first j with target <= cdf[j]; the CDF rises strictly (every pdf carries a positive floor)
+        int lo = -1, hi = N_SAMPLES;  // cdf[lo] < target <= cdf[hi], with virtual ends
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (target <= sh.cdf[mid])
+                hi = mid;
+            else
+                lo = mid;
+        }
+        if (hi < N_SAMPLES) {
+            const int j = hi;
+            if (j == 0) {
+                x = sh.xs[0];
+            } else {
+                const double denom = sh.cdf[j] - sh.cdf[j - 1];
+                x = denom > 0 ? sh.xs[j - 1] + (sh.xs[j] - sh.xs[j - 1]) / denom * (target - sh.cdf[j - 1]) : sh.xs[j - 1];
             }
         }
         out[k] = x;
@@ -133,6 +201,10 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     M.status = 0;
     M.flags = P.flags;
     M.t_num_base = 0;
+#ifdef VAG_GRID_STAMPS
+    long long stamps_[10] = {};
+#endif
+    VAG_GRID_STAMP(0);
 
     // ---- find_jet_jumps (grid-refinement.h:41-86): parallel profile scan, sequential jump logic ----
     const double th_lo = 1e-6, th_hi = C_PI / 2;
@@ -144,44 +216,66 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         const double dth = (th_hi - th_lo) / (N_SCAN - 1);
         for (int s = lane; s < N_SCAN; s += WAVE) sh.scan_g[s] = jet_Gamma0(jet, th_lo + dth * (double)s);
         __syncthreads();
-        double prev_th = th_lo, prev_G = sh.scan_g[0];
-        for (int s = 1; s < N_SCAN; ++s) {
-            const double cur_th = th_lo + dth * (double)s;
-            const double cur_G = sh.scan_g[s];
-            if (prev_G >= GAMMA_CUT || cur_G >= GAMMA_CUT) {
-                const double dG = fabs(cur_G - prev_G);
-                const double scale = dmax(prev_G - 1, cur_G - 1);
-                if (scale > 0 && dG > 0.5 * scale) {
-                    double lo = prev_th, hi = cur_th;
-                    while (hi - lo > 1e-9) {
-                        const double mid = 0.5 * (lo + hi);
-                        const double Gm = jet_Gamma0(jet, mid);
-                        if (fabs(Gm - prev_G) < fabs(Gm - cur_G))
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    if (n_jumps < VAG_MAX_JUMPS) jumps[n_jumps++] = prev_G > cur_G ? lo : hi;
+        // candidate intervals (s-1, s) are flagged in parallel; the rare flagged ones are bisected in scan order
+        for (int base = 1; base < N_SCAN; base += WAVE) {
+            const int s = base + lane;
+            bool cand = false;
+            double prev_G = 0, cur_G = 0;
+            if (s < N_SCAN) {
+                prev_G = sh.scan_g[s - 1];
+                cur_G = sh.scan_g[s];
+                if (prev_G >= GAMMA_CUT || cur_G >= GAMMA_CUT) {
+                    const double dG = fabs(cur_G - prev_G);
+                    const double scale = dmax(prev_G - 1, cur_G - 1);
+                    cand = scale > 0 && dG > 0.5 * scale;
                 }
             }
-            prev_th = cur_th;
-            prev_G = cur_G;
+            unsigned long long mask = __ballot(cand);
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int sj = base + src;
+                const double pG = sh.scan_g[sj - 1], cG = sh.scan_g[sj];
+                double lo = th_lo + dth * (double)(sj - 1), hi = th_lo + dth * (double)sj;
+                while (hi - lo > 1e-9) {
+                    const double mid = 0.5 * (lo + hi);
+                    const double Gm = jet_Gamma0(jet, mid);
+                    if (fabs(Gm - pG) < fabs(Gm - cG))
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                if (n_jumps < VAG_MAX_JUMPS) jumps[n_jumps++] = pG > cG ? lo : hi;
+            }
         }
         __syncthreads();
     }
 
+    VAG_GRID_STAMP(1);
     // ---- find_theta_range (grid-refinement.h:89-111).  The abscissae come from a running
     //      subtraction/addition (kept sequential, it is only adds); the profile evaluations are parallel.
     double inner_edge = th_lo, outer_edge = th_hi;
     {
         const double step = (th_hi - th_lo) / N_SCAN;
-        int n = 0;
-        if (lane == 0) {
-            for (double th = th_hi; th >= th_lo && n < N_SCAN + 8; th -= step) sh.scan_th[n++] = th;
+        // abscissae by running subtraction, as the reference's loop (its rounding accumulates); the exit test is taken out
+        // of the dependent chain: all N_SCAN + 8 candidates are generated, the valid ones (th >= th_lo) are a prefix
+        static_assert((N_SCAN + 8) % 8 == 0, "unrolled by 8");
+        {
+            double th = th_hi;
+            for (int b = 0; b < N_SCAN + 8; b += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (lane == 0) sh.scan_th[b + u] = th;
+                    th -= step;
+                }
+            }
         }
-        n = 0;
-        for (double th = th_hi; th >= th_lo && n < N_SCAN + 8; th -= step) ++n;
         __syncthreads();
+        int n = 0;
+        for (int b = 0; b < N_SCAN + 8; b += WAVE) {
+            const int s = b + lane;
+            n += __popcll(__ballot(s < N_SCAN + 8 && sh.scan_th[s] >= th_lo));
+        }
         int first = 1 << 30;
         for (int s = lane; s < n; s += WAVE)
             if (jet_Gamma0(jet, sh.scan_th[s]) >= GAMMA_CUT) {
@@ -204,29 +298,35 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     const double theta_max = dmin(outer_edge, C_PI / 2);
     const size_t base_pts = 36 + (size_t)((theta_max - theta_min) * 180 / C_PI * P.theta_resol);
 
+    VAG_GRID_STAMP(2);
     // ---- adaptive_theta_grid (grid-refinement.h:200-291) ----
     int n_base = 0;
     {
         constexpr int scan_pts = 100;
         const double extent = theta_max - theta_min;
-        for (int i = lane; i <= scan_pts; i += WAVE) sh.scan_g[i] = jet_Gamma0(jet, theta_min + extent * i / scan_pts);
-        __syncthreads();
-        double peak_weight = 0, Gamma_peak = 1.0, struct_sum = 0, Gamma_v = 1.0;
-        int last_bright = 0;
-        for (int i = 0; i <= scan_pts; ++i) {
+        double Gamma_v = 1.0;
+        for (int i = lane; i <= scan_pts; i += WAVE) {
             const double theta = theta_min + extent * i / scan_pts;
-            const double G = sh.scan_g[i];
-            const double w = structure_weight(G);
+            const double G = jet_Gamma0(jet, theta);
+            sh.scan_g[i] = G;
+            sh.scan_th[i] = structure_weight(G);  // scan_th is free again after find_theta_range
+            const double d = theta - theta_v;
+            Gamma_v = dmax(Gamma_v, G / sqrt(1.0 + G * G * d * d));
+        }
+        Gamma_v = -wave_min(-Gamma_v);  // a maximum: order-free
+        __syncthreads();
+        double peak_weight = 0, Gamma_peak = 1.0, struct_sum = 0;
+        int last_bright = 0;
+        for (int i = 0; i <= scan_pts; ++i) {  // running sum and peak tracking in scan order
+            const double w = sh.scan_th[i];
             struct_sum += w;
             if (w > peak_weight) {
                 peak_weight = w;
-                Gamma_peak = G;
+                Gamma_peak = sh.scan_g[i];
                 last_bright = i;
             } else if (w > 0.01 * peak_weight) {
                 last_bright = i;
             }
-            const double d = theta - theta_v;
-            Gamma_v = dmax(Gamma_v, G / sqrt(1.0 + G * G * d * d));
         }
         __syncthreads();
         const double floor_weight = 0.25 * peak_weight;
@@ -270,10 +370,28 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                    view_weight * Gv2 * fabs(d) / (1.0 + Gv2 * d * d) + (1 + doppler_alpha * doppler) * structure +
                    floor_weight;
         };
-        integrate_cdf(sh, pdf, theta_min, theta_max);
+        // the five stage abscissae of a step on lanes 0..4 (the pdf is scalar code: every lane may take its own theta)
+        auto stages = [&](const double* tx, double* kv) {
+            const double v = pdf(lane == 0 ? tx[0] : lane == 1 ? tx[1] : lane == 2 ? tx[2] : lane == 3 ? tx[3] : tx[4]);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) kv[i] = lane_value(v, i);
+        };
+#ifdef VAG_GRID_STAMPS
+        const long long s_a = __builtin_readcyclecounter();
+#endif
+        integrate_cdf(sh, pdf(theta_min), stages, theta_min, theta_max);
+#ifdef VAG_GRID_STAMPS
+        const long long s_b = __builtin_readcyclecounter();
+#endif
         invert_cdf(sh, n_base, false, sh.base);
+#ifdef VAG_GRID_STAMPS
+        if (m == 0 && lane == 0)
+            printf("  theta: preamble %lld integrate %lld invert %lld (n_base %d)\n", s_a - stamps_[2], s_b - s_a,
+                   (long long)__builtin_readcyclecounter() - s_b, n_base);
+#endif
     }
 
+    VAG_GRID_STAMP(3);
     // ---- jump_refinement_grid (grid-refinement.cpp:136-160) + merge_grids (grid-refinement.h:362-393) ----
     int n_theta = 0;
     {
@@ -323,6 +441,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         __syncthreads();
     }
 
+    VAG_GRID_STAMP(4);
     // ---- phi grid (grid-refinement.h:664-695, adaptive_phi_grid 296-360) ----
     int n_phi = 0, phi_mirrored = 0;
     {
@@ -384,11 +503,20 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             };
             constexpr int scan_pts = 100;
             double peak = 0, sum = 0;
-            for (int s = 0; s <= scan_pts; ++s) {
-                const double w = phi_weight(phi_max * (double)s / scan_pts);
+            for (int s = lane; s <= scan_pts; s += WAVE) {  // one scan point per lane, theta bins summed in grid order
+                const double cos_phi = cos(phi_max * (double)s / scan_pts);
+                double w = 0;
+                for (int j = 0; j < n_theta; ++j) {
+                    const double beta = sh.pj_beta[j];
+                    const double cos_alpha = sh.pj_ct[j] + sh.pj_st[j] * cos_phi;
+                    const double a = (1 - beta) / (1 - beta * cos_alpha);
+                    w += a * sh.pj_sw[j] * sh.pj_dcos[j];
+                }
                 peak = dmax(peak, w);
                 sum += w;
             }
+            peak = -wave_min(-peak);
+            sum = wave_sum(sum);
             const double floor_w = 0.05 * peak;
             if (boost_cap > 0 && peak > 0) {
                 const double mean_pdf = sum / (scan_pts + 1) + floor_w;
@@ -404,8 +532,29 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             }
             n_phi = (int)phi_num;
             for (int k = lane; k < N_SAMPLES; k += WAVE) sh.xs[k] = linspace_at(0, phi_max, N_SAMPLES, k);
-            auto pdf = [&](double phi) -> double { return phi_weight(phi) + floor_w; };
-            integrate_cdf(sh, pdf, 0, phi_max);
+            // five stage abscissae at once: their cosines on lanes 0..4, then every lane adds its theta bins to five
+            // running sums (same per-term arithmetic and the same wave reduction as phi_weight)
+            auto stages = [&](const double* tx, double* kv) {
+                const double cv = cos(lane == 0 ? tx[0] : lane == 1 ? tx[1] : lane == 2 ? tx[2] : lane == 3 ? tx[3] : tx[4]);
+                double cp[5], w[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    cp[i] = lane_value(cv, i);
+                    w[i] = 0;
+                }
+                for (int j = lane; j < n_theta; j += WAVE) {
+                    const double beta = sh.pj_beta[j], ct = sh.pj_ct[j], st = sh.pj_st[j], sw = sh.pj_sw[j], dc = sh.pj_dcos[j];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const double cos_alpha = ct + st * cp[i];
+                        const double a = (1 - beta) / (1 - beta * cos_alpha);
+                        w[i] += a * sw * dc;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) kv[i] = wave_sum(w[i]) + floor_w;
+            };
+            integrate_cdf(sh, phi_weight(0.0) + floor_w, stages, 0, phi_max);
             invert_cdf(sh, n_phi, half_range, sh.phi);
         }
         if (!mirror && phi_num >= 2) {
@@ -416,6 +565,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         }
     }
 
+    VAG_GRID_STAMP(5);
     // ---- Coord::detect_symmetry (src/core/mesh.h:121-187): contiguous groups of identical rows; a spreading jet
     //      evolves every row on its own (Symmetry::structured) ----
     const bool spreading = (P.flags & VAG_FLAG_SPREADING) != 0;
@@ -444,6 +594,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     const int symmetry = spreading ? VAG_SYM_STRUCTURED
                                    : (n_reps == 1 ? VAG_SYM_ISOTROPIC : (n_reps < n_theta ? VAG_SYM_PIECEWISE : VAG_SYM_PHI_SYMMETRIC));
 
+    VAG_GRID_STAMP(6);
     // ---- build_time_grid scalars (grid-refinement.h:472-528,594-636); is_rvs = Model(rvs_rad=...) ----
     {
         const bool is_rvs = (P.flags & VAG_FLAG_RVS) != 0;
@@ -520,6 +671,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = M.t_early;
         }
     }
+    VAG_GRID_STAMP(7);
     // Geometry factors of the equal-arrival-time step that depend on the angular grid only
     // (calc_eat_non_spreading + compute_dphi, src/core/observer.cpp:17-37,143-188): computed once per model
     // here instead of once per (theta, phi) row in the flux kernel.
@@ -553,6 +705,14 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         }
     }
     if (lane == 0) meta[m] = M;
+    VAG_GRID_STAMP(8);
+#ifdef VAG_GRID_STAMPS
+    if (m == 0 && lane == 0)
+        printf("grid cycles: jumps %lld  theta_range %lld  theta_cdf %lld  merge %lld  phi %lld  symmetry %lld  time %lld  geometry %lld  total %lld\n",
+               stamps_[1] - stamps_[0], stamps_[2] - stamps_[1], stamps_[3] - stamps_[2], stamps_[4] - stamps_[3],
+               stamps_[5] - stamps_[4], stamps_[6] - stamps_[5], stamps_[7] - stamps_[6], stamps_[8] - stamps_[7],
+               stamps_[8] - stamps_[0]);
+#endif
 }
 
 }  // namespace vag
