@@ -756,3 +756,32 @@ def test_non_axisymmetric_models_match_oracle(eng, oracle, name):
         assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)
         with pytest.raises(NotImplementedError):
             gpu_grid(eng, _abi.make_params(spreading=True, axisymmetric=False), t, nu)
+
+
+@pytest.mark.parametrize("kw", [dict(configs.C4_TRUTH, jet="GaussianJet"),
+                                dict(jet="TophatJet", theta_obs=0.1, ssc=True),
+                                dict(jet="TophatJet", theta_obs=0.1, duration=100.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+                                dict(jet="GaussianJet", theta_obs=0.2, spreading=True)],
+                         ids=["c4", "ssc", "rs", "spread"])
+def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
+    """A fit's few bands (host-pointer series call, n <= 64): the spectrum is evaluated once per (band, lattice node) and
+    shared by the points (observer.h:447-538); the device-pointer entry does not know the frequencies and evaluates per
+    point.  Same evaluator and interpolation arithmetic: the two must agree to the last bit."""
+    import torch
+    lib, h = eng
+    t, nu = configs.c4_mock_data()
+    prm = _abi.make_params(**kw)
+    shared = gpu_series(eng, prm, t, nu)[0]
+    dev = torch.device("cuda", 0)
+    d_p = torch.frombuffer(bytearray(bytes(prm)), dtype=torch.uint8).to(dev)
+    d_t, d_nu = torch.from_numpy(np.ascontiguousarray(t)).to(dev), torch.from_numpy(np.ascontiguousarray(nu)).to(dev)
+    d_out = torch.zeros((1, t.size), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.vag_flux_density_batch_dev(h, d_p.data_ptr(), 1, d_t.data_ptr(), d_nu.data_ptr(), t.size, d_out.data_ptr()))
+    _lib.check(lib.vag_ctx_synchronize(h))
+    per_point = d_out.cpu().numpy()[0]
+    assert np.array_equal(shared, per_point) and shared.max() > 0
+    assert_close(shared, oracle.flux_density(prm, t, nu), rtol=5e-6)
+    # all-distinct frequencies: nothing to share, the call silently takes the per-point path
+    nu2 = nu * (1 + 1e-3 * np.arange(nu.size))
+    assert_close(gpu_series(eng, prm, t, nu2)[0], oracle.flux_density(prm, t, nu2), rtol=5e-6)

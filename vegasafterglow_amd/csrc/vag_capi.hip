@@ -263,6 +263,10 @@ static double append_log2_table(std::vector<double>& tab) {
 
 struct vag_ctx {
     int device = 0;
+    DevBuf d_bandidx;  // [64 band index per point | 8 first point of each band] for the shared-node series path
+    int h_bandbuf[64 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
+    int h_bands_n = -1;
+    int pending_bands = 0;  // set by the host-pointer entry points that know the frequencies; consumed by the next series call
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_ssc;
     bool count_work = false;
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
@@ -399,7 +403,13 @@ int vag_ctx_create(int device, vag_ctx** out) {
     }
     for (const void* fn : {reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC>),
-                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC>)})
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, false, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, false, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, false, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, true, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, true, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, true, 1>)})
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
         std::vector<double> tab;
@@ -418,7 +428,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
+    for (DevBuf* b : {&c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
@@ -903,7 +913,7 @@ __global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ pa
 }
 
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
-                    int n, double* d_out, int mode = FLUX_SYN) {
+                    int n, double* d_out, int mode = FLUX_SYN, int n_bands = 0) {
     hipStream_t st = c->stream;
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
@@ -913,13 +923,17 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC) + SP_LDS_DOUBLES);
+    if (n > SERIES_THREADS) n_bands = 0;  // the shared-node path keeps one point per lane
+    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC, n_bands) + SP_LDS_DOUBLES + SERIES_MAX_BANDS);
     const dim3 sgrid((max_blocks + SERIES_WAVES - 1) / SERIES_WAVES, nb), sblock(SERIES_THREADS * SERIES_WAVES);
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();
     a.ic_status = c->d_icstatus.as<int>();
     a.cellgeo = c->d_cellgeo.as<double>();
+    a.n_bands = n_bands;
+    a.band_idx = c->d_bandidx.as<int>();
+    a.band_first = c->d_bandidx.as<int>() + SERIES_THREADS;
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
@@ -941,18 +955,27 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     c->plan.flux_blocks = max_blocks * nb;
     c->plan.pairs_per_block = (int)ppb;
     if (c->n_rows > 0) {
+        const bool one = n <= SERIES_THREADS;  // one data point per lane
+#define VAG_SERIES_LAUNCH(M_, S_)                                                                              \
+    do {                                                                                                       \
+        if (one)                                                                                               \
+            hipLaunchKernelGGL((vag_flux_series_kernel<M_, S_, 1>), sgrid, sblock, lds, st, a);                 \
+        else                                                                                                   \
+            hipLaunchKernelGGL((vag_flux_series_kernel<M_, S_, SERIES_MAX_SLOTS>), sgrid, sblock, lds, st, a);  \
+    } while (0)
         if (spreading && mode == FLUX_SYN_IC)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN_IC, true>), sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SYN_IC, true);
         else if (spreading && mode == FLUX_SSC)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SSC, true>), sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SSC, true);
         else if (spreading)
-            hipLaunchKernelGGL((vag_flux_series_kernel<FLUX_SYN, true>), sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SYN, true);
         else if (mode == FLUX_SYN_IC)
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN_IC>, sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SYN_IC, false);
         else if (mode == FLUX_SSC)
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SSC>, sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SSC, false);
         else
-            hipLaunchKernelGGL(vag_flux_series_kernel<FLUX_SYN>, sgrid, sblock, lds, st, a);
+            VAG_SERIES_LAUNCH(FLUX_SYN, false);
+#undef VAG_SERIES_LAUNCH
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
@@ -966,7 +989,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
 // One chunk of a (t, nu) series for the batch: the sum of every enabled component -> d_out[nb][n].  The comoving band
 // of an SSC table spans ALL requested frequencies (d_lg2nu_all[n_all], pymodel.h:896-909), not only this chunk's.
 int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
-                 const double* d_lg2nu_all, int n_all, double* d_out) {
+                 const double* d_lg2nu_all, int n_all, double* d_out, int n_bands = 0) {
     const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
     int rc = VAG_OK;
     bool first = true;
@@ -983,10 +1006,10 @@ int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
                 dst = c->d_ssc.as<double>();
             }
             if (pass == 0) {
-                rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+                rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN, n_bands);
             } else {
                 rc = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all);
-                if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC);
+                if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC, n_bands);
                 if (rc == VAG_OK) rc = check_ic_status(c, nb);
             }
             if (rc) break;
@@ -1092,11 +1115,15 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     return rc;
 }
 
+static int upload_series_bands(vag_ctx* c, const double* nu, int n);
+
 int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
                                const double* d_nu, int n, double* d_out) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
     HIPCHK(hipSetDevice(c->device));
+    const int n_bands = c->pending_bands;  // only the host-pointer wrapper below knows the frequencies
+    c->pending_bands = 0;
     int rc = prep_times(c, d_t, n, d_nu, n);  // the grid sees the extrema of ALL requested times
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
@@ -1104,7 +1131,7 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
     if (n <= chunk)
         return series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
-                            d_out);
+                            d_out, n_bands);
     DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
     if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
     for (int s0 = 0; s0 < n; s0 += chunk) {
@@ -1201,8 +1228,10 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    c->pending_bands = upload_series_bands(c, nu, n);
     rc = vag_flux_density_batch_dev(c, c->d_params.as<vag_model_params>(), nb, c->d_t.as<double>(), c->d_nu.as<double>(), n,
                                     c->d_out.as<double>());
+    c->pending_bands = 0;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1318,6 +1347,38 @@ int vag_flux_components4_batch(vag_ctx* c, const vag_model_params* params, int n
                                double nu_max, int num_nu, double* const* out4) {
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
     return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, nullptr, out4);
+}
+
+// Distinct frequencies of a short series (n <= 64, at most 8 of them): uploads [band of point s | first point of band b]
+// and returns the number of bands, 0 when the shared-node path does not apply.
+static int upload_series_bands(vag_ctx* c, const double* nu, int n) {
+    constexpr int MAXB = SERIES_MAX_BANDS;
+    if (n <= 0 || n > SERIES_THREADS) return 0;
+    int buf[SERIES_THREADS + MAXB] = {};
+    double vals[MAXB];
+    int nbands = 0;
+    for (int s = 0; s < n; ++s) {
+        int b = 0;
+        while (b < nbands && vals[b] != nu[s]) ++b;
+        if (b == nbands) {
+            if (nbands == MAXB) return 0;
+            vals[nbands] = nu[s];
+            buf[SERIES_THREADS + nbands] = s;
+            ++nbands;
+        }
+        buf[s] = b;
+    }
+    if (2 * nbands > n) return 0;  // nothing to share
+    if (c->h_bands_n == nbands && std::memcmp(c->h_bandbuf, buf, sizeof buf) == 0) return nbands;  // already resident
+    if (c->d_bandidx.ensure(sizeof buf)) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;  // an earlier copy may still read h_bandbuf
+    std::memcpy(c->h_bandbuf, buf, sizeof buf);
+    c->h_bands_n = nbands;
+    if (hipMemcpyAsync(c->d_bandidx.p, c->h_bandbuf, sizeof buf, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        c->h_bands_n = -1;
+        return 0;
+    }
+    return nbands;
 }
 
 static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
@@ -1441,7 +1502,7 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
         rc = run_model_stages(c, d_params, nb, false);
         if (rc) return rc;
         rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
-                          c->d_series_flux.as<double>());
+                          c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
         if (rc) return rc;
         rc = after_pass();
         if (rc) return rc;

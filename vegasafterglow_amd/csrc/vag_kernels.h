@@ -127,11 +127,23 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     Dopri5<NS> st;
     st.init(s, t0, 0.01 * t0, P.rtol, eq);
     int status = 0;
+#ifdef VAG_DYN_STAMPS  // developer aid: cycles of row 0 spent stepping / saving
+    long long c_step = 0, c_save = 0, c_mark = __builtin_readcyclecounter();
+    const long long c_begin = c_mark;
+    int n_steps = 0;
+#define VAG_DYN_MARK(acc) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - c_mark; c_mark = now_; } while (0)
+#else
+#define VAG_DYN_MARK(acc) do { } while (0)
+#endif
     for (int steps = 0; st.t <= t_last;) {
         if (!st.step(eq)) {
             status = 1;
             break;
         }
+        VAG_DYN_MARK(c_step);
+#ifdef VAG_DYN_STAMPS
+        ++n_steps;
+#endif
         if (++steps > 100000) {
             status = 2;
             break;
@@ -155,7 +167,13 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
             ++k;
             if (k < nt) t_k = node(k);
         }
+        VAG_DYN_MARK(c_save);
     }
+#ifdef VAG_DYN_STAMPS
+    if (row == 0)
+        printf("dyn row 0: steps %d saves %d  cycles: stepping %lld saving %lld  (init before: see total) \n", n_steps, k, c_step, c_save);
+    (void)c_begin;
+#endif
     for (; k < nt; ++k) {  // unreached nodes keep the Shock constructor's defaults
         o_teng[k] = node(k);
         o_tcomv[k] = 0;
@@ -700,8 +718,11 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 constexpr int SERIES_THREADS = 64;    // lanes that share one (theta, phi) row: ONE wavefront, so rows need no block barrier
 constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup; they only share the softplus table in LDS
 constexpr int SERIES_MAX_SLOTS = 8;   // data points per lane: n <= 512
+constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
-__host__ __device__ inline int series_region_doubles(int ks, bool ic) { return ((VAG_NPAR + 3 + (ic ? 14 : 0)) * ks + 1) & ~1; }
+__host__ __device__ inline int series_region_doubles(int ks, bool ic, int n_bands) {
+    return ((VAG_NPAR + 3 + (ic ? 14 : 0) + n_bands) * ks + 1) & ~1;
+}
 
 // LDS produced and consumed by the same wavefront: program order suffices in hardware, the fence keeps the compiler from
 // moving accesses across it
@@ -730,9 +751,16 @@ struct SeriesArgs {
     const double* ictab;  // FLUX_SSC: [cells][FLUX_IC_STRIDE]
     int* ic_status;       // FLUX_SSC: per-model breach flag
     const double* cellgeo; // SPREAD: [rows][3][n_t] per-cell polar geometry
+    // few distinct frequencies (a fit's bands), n <= 64: point s observes band band_idx[s], whose log2 nu is
+    // lg2_nu_obs[band_first[b]].  n_bands = 0 turns the shared-node path off.
+    int n_bands;
+    const int* band_idx;
+    const int* band_first;
 };
 
-template <int MODE, bool SPREAD = false>
+// NSLOT = data points per lane (n <= 64 * NSLOT): short series (a walker's 60 points) keep one point per lane in
+// registers instead of eight, which is the difference between 3 and 5 resident wavefronts per SIMD.
+template <int MODE, bool SPREAD = false, int NSLOT = SERIES_MAX_SLOTS>
 __global__ void __launch_bounds__(SERIES_THREADS * SERIES_WAVES)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -741,6 +769,8 @@ vag_flux_series_kernel(SeriesArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += SERIES_THREADS * SERIES_WAVES) s_sp[i] = a.sp_table[i];
+    double* s_band = s_sp + SP_LDS_DOUBLES;  // [SERIES_MAX_BANDS] log2 nu of the fit's bands (shared-node path)
+    if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]];
     __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
     const int vb = blockIdx.x * SERIES_WAVES + wave;  // virtual block = wavefront
     if (vb >= a.max_blocks) return;
@@ -752,11 +782,12 @@ vag_flux_series_kernel(SeriesArgs a) {
     if (p0 >= n_pairs) return;
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int K = M.n_t;
-    double* s_par = s_sp + SP_LDS_DOUBLES + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC);
+    double* s_par = s_band + SERIES_MAX_BANDS + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC, a.n_bands);
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
     double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
+    double* s_Bw = s_q + (MODE == FLUX_SYN_IC ? FLUX_NQ * KS : 0);  // [n_bands][KS] boundary values of the shared-node path
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     int breach = 0;
 
@@ -771,19 +802,27 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const int n_phi_eff = M.n_phi_eff;
 
-    double acc[SERIES_MAX_SLOTS], tq[SERIES_MAX_SLOTS], nuq[SERIES_MAX_SLOTS];
+    double acc[NSLOT], tq[NSLOT], nuq[NSLOT];
 #pragma unroll
-    for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+    for (int q = 0; q < NSLOT; ++q) {
         acc[q] = 0;
         const int s = tid + q * SERIES_THREADS;
         tq[q] = s < a.n ? a.lg2_t_obs[s] : 0;
         nuq[q] = s < a.n ? a.lg2_nu_obs[s] + lg2_1pz : 0;
     }
+    const int my_band = (NSLOT == 1 && a.n_bands > 0 && tid < a.n) ? a.band_idx[tid] : 0;
     int staged_rep = -1;
+#ifdef VAG_SERIES_STAMPS  // developer aid: cycles of wavefront 0 of model 0 per phase
+    long long c_stage = 0, c_eat = 0, c_pts = 0, c_mark = __builtin_readcyclecounter();
+#define VAG_SER_MARK(acc) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - c_mark; c_mark = now_; } while (0)
+#else
+#define VAG_SER_MARK(acc) do { } while (0)
+#endif
     for (int pair = p0; pair < p1; ++pair) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
         const int rep = rep_of[j];
         wave_sync();
+        VAG_SER_MARK(c_pts);
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
             for (int q = tid; q < VAG_NPAR * K; q += SERIES_THREADS) {
@@ -800,6 +839,7 @@ vag_flux_series_kernel(SeriesArgs a) {
             staged_rep = rep;
             wave_sync();
         }
+        VAG_SER_MARK(c_stage);
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
             eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z, s_t,
@@ -811,9 +851,63 @@ vag_flux_series_kernel(SeriesArgs a) {
             eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
         }
         wave_sync();
+        VAG_SER_MARK(c_eat);
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
+        if constexpr (NSLOT == 1) {
+            if (a.n_bands > 0) {
+                // Shared-node path (the reference's specific_flux_series shares boundary evaluations between points of one
+                // band, observer.h:447-538): the sorted points of a fit fall into a short run of lattice intervals, so the
+                // spectrum is evaluated once per (band, node of that run) and every point interpolates between two of them.
+                // Same evaluator, same arguments, same interpolation arithmetic as the per-point path: identical results.
+                const double t = tq[0];
+                const bool in = tid < a.n && t >= row_t0 && t <= row_tN;
+                int k = 0;
+                if (in) {
+                    int lo = 0, hi = K - 1;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_t[mid] < t)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    k = lo;
+                }
+                const unsigned long long mask = __ballot(in);
+                if (mask != 0) {  // wave-uniform
+                    const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
+                    const int kmin = __builtin_amdgcn_readlane(k, first);  // t ascends with the point index, and so does k
+                    const int nn = __builtin_amdgcn_readlane(k, last) + 2 - kmin;
+                    const int total = nn * a.n_bands;
+                    const float inv_nn = 1.0f / (float)nn;
+                    for (int idx = tid; idx < total; idx += SERIES_THREADS) {
+                        const int b = (int)(((float)idx + 0.5f) * inv_nn);
+                        const int kk = kmin + idx - b * nn;
+                        const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
+                        double v;
+                        if (MODE == FLUX_SYN) {
+                            v = log2_I_nu_fast(s_par + kk * VAG_NPAR, 1, sc, x, sp_tab);
+                        } else if (MODE == FLUX_SYN_IC) {
+                            v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
+                        } else {
+                            const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + kk) * FLUX_IC_STRIDE;
+                            v = ic_table_eval(tab, x, &breach);
+                        }
+                        s_Bw[b * KS + kk] = v + s_geom[kk];
+                    }
+                    wave_sync();
+                    if (in) {
+                        const double* Bb = s_Bw + my_band * KS;
+                        const double blo = Bb[k], bhi = Bb[k + 1];
+                        const double sl = (bhi - blo) * (1.0 / (s_t[k + 1] - s_t[k]));
+                        if (isfinite(sl)) acc[0] += exp2_fast(blo + (t - s_t[k]) * sl);
+                    }
+                }
+                continue;
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+        for (int q = 0; q < NSLOT; ++q) {
             const int s = tid + q * SERIES_THREADS;
             if (s < a.n) {
                 const double t = tq[q];
@@ -849,8 +943,13 @@ vag_flux_series_kernel(SeriesArgs a) {
             }
         }
     }
+    VAG_SER_MARK(c_pts);
+#ifdef VAG_SERIES_STAMPS
+    if (m == 0 && vb == 0 && tid == 0)
+        printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  points %lld\n", p1 - p0, K, c_stage, c_eat, c_pts);
+#endif
 #pragma unroll
-    for (int q = 0; q < SERIES_MAX_SLOTS; ++q) {
+    for (int q = 0; q < NSLOT; ++q) {
         const int s = tid + q * SERIES_THREADS;
         if (s < a.n) my_partial[s] = acc[q];
     }
