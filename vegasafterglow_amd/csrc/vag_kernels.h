@@ -825,9 +825,24 @@ vag_flux_series_kernel(SeriesArgs a) {
         VAG_SER_MARK(c_pts);
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
-            for (int q = tid; q < VAG_NPAR * K; q += SERIES_THREADS) {
-                const int par = (int)(((float)q + 0.5f) / (float)K), k = q - par * K;  // q / K, exact for q < 2^20
-                s_par[k * VAG_NPAR + par] = src[q];
+            // four loads in flight per lane before the first LDS store: a wavefront stages alone, so the HBM / L2 latency of
+            // its ~11 dependent round trips is otherwise fully exposed
+            const float inv_K = 1.0f / (float)K;
+            for (int q0 = tid; q0 < VAG_NPAR * K; q0 += 4 * SERIES_THREADS) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * SERIES_THREADS;
+                    v[u] = q < VAG_NPAR * K ? src[q] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * SERIES_THREADS;
+                    if (q < VAG_NPAR * K) {
+                        const int par = (int)(((float)q + 0.5f) * inv_K), k = q - par * K;  // q / K, exact for q < 2^20
+                        s_par[k * VAG_NPAR + par] = v[u];
+                    }
+                }
             }
             if (MODE == FLUX_SYN_IC) {
                 const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K) * FLUX_NQ;
