@@ -785,3 +785,34 @@ def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
     # all-distinct frequencies: nothing to share, the call silently takes the per-point path
     nu2 = nu * (1 + 1e-3 * np.arange(nu.size))
     assert_close(gpu_series(eng, prm, t, nu2)[0], oracle.flux_density(prm, t, nu2), rtol=5e-6)
+
+
+@pytest.mark.parametrize("case", ["c5_like", "rs_ssc", "spread_ssc"])
+def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
+    """Radiation(ssc=True): the synchrotron and SSC components normally come out of ONE flux pass (shared EAT logs, bracket
+    search and barriers); VAG_NO_FUSED=1 restores the two-pass form.  Same per-component arithmetic: bitwise equal."""
+    kw = {"c5_like": dict(jet="TwoComponentJet", theta_c=0.06, theta_w=0.3, E_iso_w=1e50, Gamma0_w=50.0, theta_obs=0.15, ssc=True),
+          "rs_ssc": dict(configs.C3),
+          "spread_ssc": dict(jet="GaussianJet", theta_obs=0.2, spreading=True, ssc=True, kn=True)}[case]
+    prm = _abi.make_params(**kw)
+    t, nu = configs.C3_T[::4], configs.C3_NU
+    fused = gpu_components4(eng, prm, t, nu)
+    os.environ["VAG_NO_FUSED"] = "1"
+    try:
+        two_pass = gpu_components4(eng, prm, t, nu)
+    finally:
+        del os.environ["VAG_NO_FUSED"]
+    for a, b in zip(fused, two_pass):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert fused[1].max() > 0
+    lib, h = eng
+    band_f = np.empty((1, t.size))
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e17, 1e19, 7, band_f.ctypes.data_as(dp)))
+    os.environ["VAG_NO_FUSED"] = "1"
+    try:
+        band_t = np.empty((1, t.size))
+        _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e17, 1e19, 7, band_t.ctypes.data_as(dp)))
+    finally:
+        del os.environ["VAG_NO_FUSED"]
+    assert np.array_equal(band_f, band_t)

@@ -263,6 +263,7 @@ static double append_log2_table(std::vector<double>& tab) {
 
 struct vag_ctx {
     int device = 0;
+    DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
     DevBuf d_bandidx;  // [64 band index per point | 8 first point of each band] for the shared-node series path
     int h_bandbuf[64 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
     int h_bands_n = -1;
@@ -375,6 +376,9 @@ int vag_ctx_create(int device, vag_ctx** out) {
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN, true>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN_IC, true>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SSC, true>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_FUSED>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_FUSED, false, 256>),
+                           reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_FUSED, true>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, true>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, true>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, true>)})
@@ -428,7 +432,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
+    for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
@@ -695,9 +699,19 @@ int choose_pairs_per_block(const vag_ctx* c) {
     return (int)std::max<long long>(1, ppb);
 }
 
+// dynamic LDS of vag_flux_grid_kernel (layout at the top of the kernel)
+static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
+    const size_t slots = (size_t)nt * nnu;
+    size_t d = (size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + 2 * (size_t)nt + nnu + SP_LDS_DOUBLES + slots;
+    if (mode == FLUX_SYN_IC || mode == FLUX_FUSED) d += (size_t)VAG_NQ * ks;
+    if (mode == FLUX_FUSED) d += 6 * (size_t)ks + (size_t)ks * nnu + slots;
+    return sizeof(double) * d + sizeof(int) * nt;
+}
+
 // Stage 4-5 for a (t, nu) grid request: d_lg2t/d_lg2nu are log2 of code-unit times / frequencies.
 int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt,
-                  const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN) {
+                  const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN,
+                  double* d_out2 = nullptr /* FLUX_FUSED: the SSC component */) {
     hipStream_t st = c->stream;
     const int slots = nt * nnu;
     if (slots > FLUX_MAX_SLOTS)
@@ -706,10 +720,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     const int ks = c->max_k;
-    const size_t lds = sizeof(double) * ((size_t)(VAG_NPAR + 4 + (mode == FLUX_SYN_IC ? VAG_NQ : 0)) * ks + (size_t)ks * nnu +
-                                         2 * nt + nnu + SP_LDS_DOUBLES + slots) +
-                       sizeof(int) * nt;
+    const size_t lds = flux_grid_lds_bytes(mode, ks, nt, nnu);
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
+    if (mode == FLUX_FUSED && c->d_partial2.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
     FluxArgs a;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
@@ -726,6 +739,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.max_blocks = max_blocks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
+    a.partial2 = c->d_partial2.as<double>();
     a.sp_table = c->d_sptab.as<double>();
     a.work_count = nullptr;
     a.cellq = c->d_cellq.as<double>();
@@ -749,7 +763,13 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         // (+47 % on the C5 / C1b shapes; a 128-lane variant measured slower)
         const bool small = !spreading && !a.work_count && (long long)nt * nnu <= 512 && (long long)ks * ((nnu + 1) / 2) <= 512 &&
                            !std::getenv("VAG_FLUX_WIDE");
-        if (small && mode == FLUX_SYN_IC)
+        if (small && mode == FLUX_FUSED)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
+        else if (spreading && mode == FLUX_FUSED)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (mode == FLUX_FUSED)
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);
+        else if (small && mode == FLUX_SYN_IC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SYN_IC, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
         else if (small && mode == FLUX_SSC)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_SSC, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
@@ -782,6 +802,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int out_slots = d_bandw ? nt : slots;
     hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
                        c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out);
+    if (mode == FLUX_FUSED)
+        hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
+                           c->d_meta.as<VagGridMeta>(), c->d_partial2.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
     return VAG_OK;
@@ -837,6 +860,26 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
     return check_ic_status(c, nb);
 }
 
+// Synchrotron (IC-cooled) and SSC components of one emitter in ONE flux pass: the tables are built first, then both
+// spectra ride the same EAT logs, bracket search and barriers (the two-pass form pays that row skeleton twice -- 35-45 %
+// of a pass on the C5 / C3 shapes).  Falls back to two passes when the doubled buffers would not fit in LDS twice.
+static bool fused_fits(vag_ctx* c, int nt, int nnu) {
+    if (std::getenv("VAG_NO_FUSED")) return false;
+    // the second set of buffers must not cost a resident workgroup: on the C5 / C3 shapes it does (63 vs 51 KB: two
+    // workgroups per CU instead of three) and the fused pass measured 18 % SLOWER than two passes there
+    const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, c->max_k, nt, nnu),
+                 two = flux_grid_lds_bytes(FLUX_SYN_IC, c->max_k, nt, nnu);
+    return fused <= cu && std::min<size_t>(cu / fused, 4) >= std::min<size_t>(cu / two, 4);
+}
+int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
+                   int nnu, const double* d_bandw, double* d_syn, double* d_ssc) {
+    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu, nnu);
+    if (rc) return rc;
+    rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
+    if (rc) return rc;
+    return check_ic_status(c, nb);
+}
+
 __global__ void vag_copy_kernel(double* __restrict__ out, const double* __restrict__ src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = src[i];
 }
@@ -853,6 +896,7 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
     int rc = VAG_OK;
     for (int e = 0; e < 2 && rc == VAG_OK; ++e) {
         if (e < n_em) select_emitter(c, e, d_params);
+        double* fused_ssc = nullptr;  // set once the fused pass has produced this emitter's SSC component
         for (int pass = 0; pass < 2 && rc == VAG_OK; ++pass) {
             double* dst_comp = d_comp ? d_comp[2 * e + pass] : nullptr;
             const bool enabled = e < n_em && (pass == 0 || c->cur_ssc);
@@ -861,25 +905,41 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
                 continue;
             }
             double* dst = dst_comp;
-            if (!dst) {
-                if (!d_total) continue;  // nobody wants this component
-                if (first) {
-                    dst = d_total;
-                } else {
-                    if (c->d_ssc.ensure(sizeof(double) * n_out)) {
-                        rc = VAG_E_HIP;
-                        break;
+            if (pass == 1 && fused_ssc) {
+                dst = fused_ssc;
+            } else {
+                if (!dst) {
+                    if (!d_total) continue;  // nobody wants this component
+                    if (first) {
+                        dst = d_total;
+                    } else {
+                        if (c->d_ssc.ensure(sizeof(double) * n_out)) {
+                            rc = VAG_E_HIP;
+                            break;
+                        }
+                        dst = c->d_ssc.as<double>();
                     }
-                    dst = c->d_ssc.as<double>();
                 }
+                const double* lg2t = c->d_lg2t.as<double>() + t_off;
+                double* want_ssc = d_comp ? d_comp[2 * e + 1] : nullptr;
+                if (pass == 0 && c->cur_ssc && (want_ssc || d_total) && fused_fits(c, nt, nnu)) {
+                    if (!want_ssc) {
+                        if (c->d_ssc2.ensure(sizeof(double) * n_out)) {
+                            rc = VAG_E_HIP;
+                            break;
+                        }
+                        want_ssc = c->d_ssc2.as<double>();
+                    }
+                    rc = run_flux_fused(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst, want_ssc);
+                    fused_ssc = want_ssc;
+                } else if (pass == 0) {
+                    rc = run_flux_grid(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst,
+                                       c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+                } else {
+                    rc = run_flux_ssc(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst);
+                }
+                if (rc) break;
             }
-            if (pass == 0)
-                rc = run_flux_grid(c, c->cur_params, nb, c->d_lg2t.as<double>() + t_off, nt, c->d_lg2nu.as<double>(), nnu, d_bandw,
-                                   dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
-            else
-                rc = run_flux_ssc(c, c->cur_params, nb, c->d_lg2t.as<double>() + t_off, nt, c->d_lg2nu.as<double>(), nnu, d_bandw,
-                                  dst);
-            if (rc) break;
             if (d_total) {
                 if (first) {
                     if (dst != d_total) hipLaunchKernelGGL(vag_copy_kernel, dim3(256), dim3(256), 0, c->stream, d_total, dst, n_out);

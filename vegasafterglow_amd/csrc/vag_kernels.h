@@ -332,6 +332,7 @@ struct FluxArgs {
     const double* lg2_nu_obs; // [nnu]  log2(nu * unit::Hz)
     const double* sp_table;   // [SP_TABLE_DOUBLES] softplus interpolant (vag_device.h: sp_fast)
     double* partial;          // [nb][max_blocks][nnu*nt]
+    double* partial2;         // FLUX_FUSED: the SSC component's partial grids, same shape
     int nt, nnu;
     int pairs_per_block;
     int max_blocks;  // blocks per model (gridDim.x)
@@ -348,6 +349,7 @@ struct FluxArgs {
 constexpr int FLUX_SYN = 0;     // synchrotron, no inverse-Compton cooling
 constexpr int FLUX_SYN_IC = 1;  // synchrotron with the IC correction above nu_c
 constexpr int FLUX_SSC = 2;     // SSC tables
+constexpr int FLUX_FUSED = 3;   // FLUX_SYN_IC and FLUX_SSC in one pass: EAT logs, bracket search and barriers paid once
 
 template <class P1, class P2, class Tab>
 VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp);
@@ -429,8 +431,12 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_nu = s_tobs + nt;              // [nnu]
     double* s_w = s_nu + nnu;                // [nt] fractional position of each requested time inside its interval
     double* s_acc = s_w + nt;                // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
-    double* s_q = s_acc + slots;             // [KS][FLUX_NQ] IC-correction constants (FLUX_SYN_IC only)
-    int* s_kidx = (int*)(s_q + (MODE == FLUX_SYN_IC ? FLUX_NQ * KS : 0));  // [nt]
+    double* s_q = s_acc + slots;             // [KS][FLUX_NQ] IC-correction constants (FLUX_SYN_IC / FLUX_FUSED)
+    constexpr bool HAS_Q = MODE == FLUX_SYN_IC || MODE == FLUX_FUSED;
+    double* s_hdr = s_q + (HAS_Q ? FLUX_NQ * KS : 0);                 // FLUX_FUSED: [KS][6] SSC table headers
+    double* s_B2 = s_hdr + (MODE == FLUX_FUSED ? 6 * KS : 0);         // FLUX_FUSED: [nnu][KS] SSC boundary values
+    double* s_acc2 = s_B2 + (MODE == FLUX_FUSED ? (size_t)KS * nnu : 0);  // FLUX_FUSED: [nnu*nt] SSC partial grid
+    int* s_kidx = (int*)(s_acc2 + (MODE == FLUX_FUSED ? slots : 0));  // [nt]
     int breach = 0;
 
     const vag_model_params* Pp = a.params + m;
@@ -452,6 +458,8 @@ vag_flux_grid_kernel(FluxArgs a) {
     const int slot_l0 = tid / nt, slot_idx0 = tid - slot_l0 * nt;
 
     for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
+    if constexpr (MODE == FLUX_FUSED)
+        for (int s = tid; s < slots; s += THREADS) s_acc2[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
 
     // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
@@ -494,7 +502,15 @@ vag_flux_grid_kernel(FluxArgs a) {
                     s_par[kk * VAG_NPAR + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
                 }
             }
-            if constexpr (MODE == FLUX_SYN_IC) {
+            if constexpr (MODE == FLUX_FUSED) {
+                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K) * FLUX_IC_STRIDE;
+#pragma unroll 1
+                for (int q = tid; q < 5 * K; q += THREADS) {
+                    const int kk = q / 5, w = q - kk * 5;
+                    s_hdr[kk * 6 + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
+                }
+            }
+            if constexpr (HAS_Q) {
                 const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K) * FLUX_NQ;
 #pragma unroll 1
                 for (int q = tid; q < FLUX_NQ * K; q += THREADS) {
@@ -601,10 +617,19 @@ vag_flux_grid_kernel(FluxArgs a) {
                     const SpecRegs regs = load_spec_regs(lds_tab(s_par) + __mul24(k, VAG_NPAR / 2));
                     b0 = log2_I_nu_fast(regs, 1, sc, s_nu[l0] - dop, sp_tab);
                     b1 = log2_I_nu_fast(regs, 1, sc, s_nu[l1] - dop, sp_tab);
-                } else if constexpr (MODE == FLUX_SYN_IC) {
+                } else if constexpr (HAS_Q) {
                     const double* cq = s_q + __mul24(k, FLUX_NQ);
                     b0 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l0] - dop, sp_tab);
                     b1 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l1] - dop, sp_tab);
+                    if constexpr (MODE == FLUX_FUSED) {
+                        const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
+                        const double* hp = s_hdr + __mul24(k, 6);
+                        const double h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
+                        const double c0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
+                        const double c1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
+                        s_B2[bofs + k] = c0 + geom;
+                        s_B2[min(bofs + KS, top) + k] = c1 + geom;
+                    }
                 } else {
                     const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
                     const double h0 = cp[0], h1 = cp[1], h2 = cp[2], h3 = cp[3], h4 = cp[4];
@@ -643,6 +668,11 @@ vag_flux_grid_kernel(FluxArgs a) {
                     const double lo = s_B[lKS + k], hi = s_B[lKS + k + 1];
                     const double d = hi - lo;  // slope finite <=> d finite (observer.h:422-426)
                     if (isfinite(d)) s_acc[slot] += exp2_fast(fma(d, s_w[idx], lo));
+                    if constexpr (MODE == FLUX_FUSED) {
+                        const double lo2 = s_B2[lKS + k], hi2 = s_B2[lKS + k + 1];
+                        const double d2 = hi2 - lo2;
+                        if (isfinite(d2)) s_acc2[slot] += exp2_fast(fma(d2, s_w[idx], lo2));
+                    }
                 }
                 idx += slot_didx;
                 lKS += slot_dl * KS;
@@ -666,13 +696,17 @@ vag_flux_grid_kernel(FluxArgs a) {
             atomicAdd(a.work_count + 1, n_interps);
         }
     }
-    if constexpr (MODE == FLUX_SSC) {
+    if constexpr (MODE == FLUX_SSC || MODE == FLUX_FUSED) {
         if (breach) atomicOr(a.ic_status + m, 2);
     }
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
     double* my_partial = a.partial + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
     for (int s = tid; s < slots; s += THREADS) my_partial[s] = s_acc[s];
+    if constexpr (MODE == FLUX_FUSED) {
+        double* my_partial2 = a.partial2 + ((size_t)m * a.max_blocks + blockIdx.x) * slots;
+        for (int s = tid; s < slots; s += THREADS) my_partial2[s] = s_acc2[s];
+    }
 }
 
 // Deterministic sum over a model's workgroup partials + normalisation
