@@ -330,6 +330,12 @@ int vag_details_rvs(vag_ctx* ctx, const vag_model_params* params, double t_min, 
  * NULL entries are skipped.  With Radiation(ssc=True) these are the inverse-Compton-cooled values. */
 int vag_details_radiation(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int rvs,
                           double* const* arrays);
+/* ShockDetails.t_obs [s] and .Doppler of every (phi, theta, k) cell (pybind/pymodel.cpp:296-298; shared by the forward
+ * and the reverse shock, which ride the same contact discontinuity): [n_phi_eff][n_theta][n_t] with the shape
+ * vag_details reports and n_phi_eff = Observer::eff_phi_grid (1 for an on-axis axisymmetric model).  Call with
+ * t_obs = doppler = NULL to query n_phi_eff. */
+int vag_details_eat(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int* n_phi_eff, double* t_obs,
+                    double* doppler);
 
 /* Per-stage device timings (ms) of the last batch call, stage names follow the reference's
  * profiler (pybind/pymodel.h:877-953): grid, dynamics, syn_cells, sync_flux, reduce, total. */

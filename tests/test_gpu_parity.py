@@ -719,6 +719,10 @@ def test_details_radiation_arrays(eng, oracle):
     d, o = m.details(1e2, 1e7), oracle.details(prm, 1e2, 1e7)
     _check_radiation_details(d, o, 5e-6)
     assert np.array_equal(d["theta_cell"], np.repeat(d["theta"][:, None], d["shape"]["n_t"], axis=1))
+    # ShockDetails.t_obs / .Doppler: the linear forms of the equal-arrival-time logs, every (phi, theta, t) cell
+    assert d["t_obs"].shape == o["lg2_t"].shape == (o["shape"]["n_phi_eff"], d["shape"]["n_theta"], d["shape"]["n_t"])
+    np.testing.assert_allclose(d["t_obs"], np.exp2(o["lg2_t"]) / _U_SEC, rtol=5e-6)
+    np.testing.assert_allclose(d["Doppler"], np.exp2(o["lg2_doppler"]), rtol=5e-6)
     # inverse-Compton-cooled electrons of a Radiation(ssc=True, kn=True) model
     m3 = va.Model(va.TophatJet(0.1, 1e52, 300.0), va.ISM(1.0), va.Observer(1e28, 1.0, 0.05),
                   va.Radiation(0.1, 1e-4, 2.3, ssc=True, kn=True))
@@ -735,6 +739,9 @@ def test_details_radiation_arrays(eng, oracle):
                   va.Radiation(0.1, 0.01, 2.3))
     ds = ms.details(1e2, 1e8)
     assert np.all(np.diff(ds["theta_cell"], axis=1) >= 0) and ds["theta_cell"][:, -1].max() > ds["theta"].max()
+    os_ = oracle.details(_abi.ModelParams.from_buffer_copy(bytes(ms.params)), 1e2, 1e8)
+    np.testing.assert_allclose(ds["t_obs"], np.exp2(os_["lg2_t"]) / _U_SEC, rtol=5e-6)
+    np.testing.assert_allclose(ds["Doppler"], np.exp2(os_["lg2_doppler"]), rtol=5e-6)
 
 
 @pytest.mark.parametrize("name", list(configs.NONAXI_CASES))

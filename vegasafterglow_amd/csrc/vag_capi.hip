@@ -1673,6 +1673,35 @@ int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double
     return details_impl(c, params, t_min, t_max, shape, out, false);
 }
 
+int vag_details_eat(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int* n_phi_eff, double* t_obs,
+                    double* doppler) {
+    vag_details_shape sh;
+    int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, false);
+    if (rc) return rc;
+    const VagGridMeta M = c->h_meta.as<VagGridMeta>()[0];
+    if (n_phi_eff) *n_phi_eff = M.n_phi_eff;
+    if (!t_obs && !doppler) return VAG_OK;  // shape query
+    if (!t_obs || !doppler) return set_err(VAG_E_INVALID, "t_obs and doppler must be given together");
+    const size_t total = (size_t)M.n_phi_eff * M.n_theta * M.n_t;
+    DevBuf tmp;
+    if (tmp.ensure(sizeof(double) * 2 * total)) return VAG_E_HIP;
+    double* d_t = tmp.as<double>();
+    hipLaunchKernelGGL(vag_eat_details_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_params.as<vag_model_params>(), c->d_meta.as<VagGridMeta>(), c->d_geo_th.as<double>(),
+                       c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(), c->d_cellpar.as<double>(),
+                       (params->flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr, d_t, d_t + total);
+    if (hipGetLastError() != hipSuccess) {
+        tmp.release();
+        return set_err(VAG_E_HIP, "vag_eat_details_kernel launch failed");
+    }
+    hipError_t e1 = hipMemcpyAsync(t_obs, d_t, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipMemcpyAsync(doppler, d_t + total, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    tmp.release();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_err(VAG_E_HIP, "copying the EAT details failed");
+    return VAG_OK;
+}
+
 int vag_details_radiation(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int rvs, double* const* arrays) {
     vag_details_shape sh;
     int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, rvs != 0);  // runs the stages with the electron arrays kept

@@ -402,6 +402,38 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
     }
 }
 
+// Model.details(): observer time [s] and Doppler factor of every (phi, theta, k) cell of model 0, the linear forms of what
+// eat_row keeps as logs (ShockDetails.t_obs = obs.time / sec, .Doppler = exp2(lg2_doppler), pybind/pymodel.cpp:296-298).
+// out_* are [n_phi_eff][n_theta][n_t]; one lane per cell.
+__global__ void __launch_bounds__(256)
+vag_eat_details_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
+                       const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ rep_of,
+                       const double* __restrict__ cellpar, const double* __restrict__ cellgeo /* spreading jets, else null */,
+                       double* __restrict__ out_t, double* __restrict__ out_dop) {
+    const VagGridMeta M = meta[0];
+    if (M.status != 0) return;
+    const int K = M.n_t, nth = M.n_theta;
+    const long long total = (long long)M.n_phi_eff * nth * K;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const int k = (int)(q % K), j = (int)((q / K) % nth), i = (int)(q / ((long long)K * nth));
+    const vag_model_params P = params[0];
+    const double one_plus_z = 1 + P.z, cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
+    const double* par = cellpar + (long long)rep_of[j] * K * VAG_NPAR;
+    const double G = par[VP_GAMMA * K + k], u = par[VP_U * K + k], r = par[VP_R * K + k], teng = par[VP_TENG * K + k];
+    double cos_v, time;
+    if (cellgeo) {
+        const double* geo = cellgeo + (long long)rep_of[j] * K * 3;
+        cos_v = geo[K + k] * geo_ph[i] * sin_obs + geo[k] * cos_obs;
+        time = (teng + (1 - cos_v) * r / C_C) * one_plus_z;
+    } else {
+        cos_v = geo_th[VAG_MAX_THETA + j] * geo_ph[i] * sin_obs + geo_th[j] * cos_obs;
+        time = teng * one_plus_z + (1 - cos_v) / C_C * one_plus_z * r;
+    }
+    out_t[q] = time / U_SEC;
+    out_dop[q] = 1.0 / (G - u * cos_v);
+}
+
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
 // MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
 template <bool COUNT, int MODE, bool SPREAD = false, int THREADS = FLUX_THREADS>

@@ -414,6 +414,13 @@ class Model:
         arr = (_dp * 11)(*[d[n].ctypes.data_as(_dp) for n in names])
         with lock:
             _lib.check(lib.vag_details_radiation(h, C.byref(self.params), float(t_min), float(t_max), 1 if rvs else 0, arr))
+            # observer-frame time and Doppler factor of every (phi, theta, t) cell (ShockDetails.t_obs / .Doppler)
+            npe = C.c_int(0)
+            _lib.check(lib.vag_details_eat(h, C.byref(self.params), float(t_min), float(t_max), C.byref(npe), None, None))
+            d["t_obs"] = np.zeros((npe.value, sh.n_theta, sh.n_t))
+            d["Doppler"] = np.zeros((npe.value, sh.n_theta, sh.n_t))
+            _lib.check(lib.vag_details_eat(h, C.byref(self.params), float(t_min), float(t_max), C.byref(npe),
+                                           d["t_obs"].ctypes.data_as(_dp), d["Doppler"].ctypes.data_as(_dp)))
         return d
 
     def stage_times(self):
