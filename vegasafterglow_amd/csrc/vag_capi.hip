@@ -653,7 +653,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                               : (inject ? vag_dynamics_kernel<false, true> : vag_dynamics_kernel<false, false>);
         hipLaunchKernelGGL(kern, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                            c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
-                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>());
+                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>());
     }
     HIPCHK(hipGetLastError());
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;

@@ -42,6 +42,20 @@ constexpr double SQRT3 = 1.732050807568877293527446341505872367;
 VAG_DEV double exp2_fast(double x);
 VAG_DEV double exp2_sat(double x);
 VAG_DEV double log2_fast(double x);
+#ifdef VAG_HOST_DEBUG
+struct vdouble2 {
+    double x, y;
+};
+typedef const vdouble2* LdsTab;
+#else
+typedef double vdouble2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const vdouble2* LdsTab;  // softplus table in LDS: 32-bit address arithmetic
+#endif
+VAG_DEV LdsTab lds_tab(const double* p) { return (LdsTab)p; }
+constexpr int LOG_TAB_N = 64;
+constexpr int LOG_TAB_DOUBLES = 2 * LOG_TAB_N;
+VAG_DEV double log2_tab(double x, LdsTab tab);  // 17-instruction log2 on a 64-entry LDS table, defined with the fast kernels below
+
 VAG_DEV double dmin(double a, double b) { return b < a ? b : a; }
 VAG_DEV double dmax(double a, double b) { return a < b ? b : a; }
 
@@ -349,13 +363,15 @@ struct Dopri5 {
     VAG_DEV void interp(double tq, double* out) const {
         constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
         const double h = t - t_old;
-        const double th = (tq - t_old) / h;
-        const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) / 11282082432.0;
-        const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) / 32700410799.0;
-        const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) / 1880347072.0;
-        const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) / 199316789632.0;
-        const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) / 822651844.0;
-        const double X7 = 10.0 * (7414447.0 - 829305.0 * th) / 29380423.0;
+        // boost's dense-output polynomials; the constant denominators are folded into reciprocals (<= 1 ulp apart from the
+        // divisions, and seven IEEE division sequences shorter per saved node)
+        const double th = (tq - t_old) * rcp_fast(h);
+        const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) * (1.0 / 11282082432.0);
+        const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) * (1.0 / 32700410799.0);
+        const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) * (1.0 / 1880347072.0);
+        const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) * (1.0 / 199316789632.0);
+        const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) * (1.0 / 822651844.0);
+        const double X7 = 10.0 * (7414447.0 - 829305.0 * th) * (1.0 / 29380423.0);
         const double thm1 = th - 1.0, th2 = th * th;
         const double A = th2 * (3.0 - 2.0 * th);
         const double B = th2 * thm1;
@@ -468,6 +484,7 @@ struct FwdShock {
     double m_jet0, gamma_m_coeff, gamma_c_coeff, eps_e_eff, p, eps_B;
     double theta_s, dOmega0;  // SPREAD: jet_spreading_edge (grid-refinement.h:113-135), 1 - cos(theta0)
     double inj_L, inj_t0, inj_q;  // INJECT: magnetar luminosity per solid angle in code units (0 outside theta_c), t0 [code], q
+    LdsTab lg_tab;                // log2_tab's table, staged in LDS by the dynamics kernel
     static constexpr int IDX_EPS = 5 + (SPREAD ? 1 : 0);  // eps_jet follows theta in the state vector
 
     // state [Gamma, m2, U2_th, r, t_comv (, theta)]; theta is constant for non-spreading jets and its zero derivative
@@ -504,7 +521,7 @@ struct FwdShock {
             const double gamma_bar = gamma_c_coeff * rcp_fast(e_th * t_comv);
             const double gamma_c = 0.5 * (gamma_bar + sqrt_fast(gamma_bar * gamma_bar + 4));
             const double ratio = gamma_m * rcp_fast(gamma_c);
-            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
+            eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_tab(ratio, lg_tab)) : eps_e_eff;
         }
         const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
         const double Gamma2 = Gamma * Gamma;
@@ -797,16 +814,6 @@ constexpr int SP_NCOEF = 6;
 constexpr int SP_TABLE_DOUBLES = SP_INTERVALS * SP_NCOEF;
 constexpr double SP_MAGIC = 6755399441055744.0;  // 1.5 * 2^52: adding it rounds to an integer held in the low word
 
-#ifdef VAG_HOST_DEBUG
-struct vdouble2 {
-    double x, y;
-};
-typedef const vdouble2* LdsTab;
-#else
-typedef double vdouble2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const vdouble2* LdsTab;  // softplus table in LDS: 32-bit address arithmetic
-#endif
-VAG_DEV LdsTab lds_tab(const double* p) { return (LdsTab)p; }
 VAG_DEV const vdouble2* sp_row(const double* tab, int idx) { return reinterpret_cast<const vdouble2*>(tab) + idx * (SP_NCOEF / 2); }
 #ifndef VAG_HOST_DEBUG
 VAG_DEV LdsTab sp_row(LdsTab tab, int idx) { return tab + __mul24(idx, SP_NCOEF / 2); }
@@ -933,8 +940,6 @@ VAG_DEV double log2_fast(double x) {
 // {1/c_i rounded, -log2(that rounded value)} over the mantissa, r = m / c_i - 1 with |r| <= 2^-7, degree-7 series of
 // ln(1 + r) (truncation 2e-18).  17 instructions instead of the 40 of log2_fast; the table (1 KB) sits behind the
 // softplus table in LDS.  Zero, subnormal, negative, inf, NaN go to the library log2.
-constexpr int LOG_TAB_N = 64;
-constexpr int LOG_TAB_DOUBLES = 2 * LOG_TAB_N;
 constexpr int SP_LDS_DOUBLES = SP_TABLE_DOUBLES + LOG_TAB_DOUBLES;  // what a flux workgroup keeps in LDS
 VAG_DEV double log2_tab(double x, LdsTab tab) {
     const int hi = __double2hiint(x), lo = __double2loint(x);

@@ -34,7 +34,10 @@ __global__ void __launch_bounds__(64)
 vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                     const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
-                    long long n_cells, int* __restrict__ row_status) {
+                    long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table) {
+    __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];  // log2_tab's table for the right-hand sides
+    for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
+    __syncthreads();
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const int m = find_model(lay.row_off, nb, row);
@@ -46,6 +49,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     Jet jet;
     jet_init(jet, P);
     FwdShock<SPREAD, INJECT> eq;
+    eq.lg_tab = lds_tab(s_lg);
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
     const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
