@@ -81,9 +81,13 @@ VAG_DEV double sqrt_fast(double x) {
     double y = __builtin_amdgcn_rsq(x);               // ~ 1/sqrt(x)
     y = y * fma(-0.5 * x * y, y, 1.5);                // Newton on 1/sqrt
     double s = x * y;                                 // ~ sqrt(x)
-    s = fma(fma(-s, s, x), 0.5 * y, s);               // Newton on sqrt with the residual in fma
-    s = fma(fma(-s, s, x), 0.5 * y, s);
-    return s;
+    s = fma(fma(-s, s, x), 0.5 * y, s);               // one correction with the residual in fma: 1.1e-16 measured
+    return s;                                         // (profiles/micro/rcp_accuracy.hip; a second one changes nothing)
+}
+// 1/x to 2e-15 (one Newton step on the 4.6e-8 hardware estimate): enough inside an ODE right-hand side integrated to 1e-6
+VAG_DEV double rcp_ode(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
 }
 
 // src/core/physics.h:36-61
@@ -501,12 +505,12 @@ struct FwdShock {
         const double dr = u * (Gamma + u) * C_C;
         d[3] = dr;
         d[4] = Gamma + u;
-        const double inv_G = rcp_fast(Gamma);
+        const double inv_G = rcp_ode(Gamma);
         double dth = 0, sin_th = 0, cos_th = 1;
         if constexpr (SPREAD) {
             const double theta = s[5];
             if (theta < 0.5 * C_PI)  // compute_dtheta_dt, shock-physics.h:141-145
-                dth = dr * rcp_fast(2 * Gamma * r) * sqrt_fast((2 * u2 + 3) * rcp_fast(4 * u2 + 3)) * rcp_fast(1 + u * theta_s * 7);
+                dth = dr * rcp_ode(2 * Gamma * r) * sqrt_fast((2 * u2 + 3) * rcp_ode(4 * u2 + 3)) * rcp_ode(1 + u * theta_s * 7);
             d[5] = dth;
             sin_th = sin(theta);
             cos_th = cos(theta);
@@ -518,39 +522,39 @@ struct FwdShock {
         double eps_rad = 0;  // RadiativeEfficiency, shock-physics.h:247-288
         if (eps_e_eff != 0) {
             const double gamma_m = gamma_m_coeff * (Gamma - 1) + 1;
-            const double gamma_bar = gamma_c_coeff * rcp_fast(e_th * t_comv);
+            const double gamma_bar = gamma_c_coeff * rcp_ode(e_th * t_comv);
             const double gamma_c = 0.5 * (gamma_bar + sqrt_fast(gamma_bar * gamma_bar + 4));
-            const double ratio = gamma_m * rcp_fast(gamma_c);
+            const double ratio = gamma_m * rcp_ode(gamma_c);
             eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_tab(ratio, lg_tab)) : eps_e_eff;
         }
         const double ad = 4.0 / 3.0 + inv_G / 3;  // adiabatic_idx
         const double Gamma2 = Gamma * Gamma;
         const double Gamma_eff = (ad * (Gamma2 - 1) + 1) * inv_G;
         const double dGamma_eff = (ad * (Gamma2 + 1) - 1) * (inv_G * inv_G);
-        const double inv_r = rcp_fast(r);
+        const double inv_r = rcp_ode(r);
         double dlnV = 3 * inv_r * dr;
         double dm_swept = dm, m_swept = m2, Ueff = U;
         if constexpr (SPREAD) {  // compute_dGamma_dt, forward-shock.tpp:77-84
-            const double inv_dO = rcp_fast(dOmega0);
+            const double inv_dO = rcp_ode(dOmega0);
             const double f_spread = (1 - cos_th) * inv_dO;
             dm_swept = dm * f_spread + m2 * inv_dO * sin_th * dth;
             m_swept = m2 * f_spread;
-            dlnV += sin_th * rcp_fast(1 - cos_th) * dth;
+            dlnV += sin_th * rcp_ode(1 - cos_th) * dth;
             Ueff = U * f_spread;
         }
         const double a1 = -(Gamma - 1) * (Gamma_eff + 1) * C_C2 * dm_swept + deps_jet;  // energy_inject, forward-shock.tpp:89-91
         const double a2 = (ad - 1) * Gamma_eff * Ueff * dlnV;
         const double b1 = (m_jet0 + m_swept) * C_C2;
         const double b2 = (dGamma_eff + Gamma_eff * (ad - 1) * inv_G) * Ueff;
-        const double dG = (a1 + a2) * rcp_fast(b1 + b2);
+        const double dG = (a1 + a2) * rcp_ode(b1 + b2);
         d[0] = dG;
         double dlnV2 = 3 * inv_r * dr - dG * inv_G;
         double dm_u = dm;
         if constexpr (SPREAD) {  // compute_dU_dt, forward-shock.tpp:109-115
-            const double factor = sin_th * rcp_fast(1 - cos_th) * dth;
+            const double factor = sin_th * rcp_ode(1 - cos_th) * dth;
             dm_u = dm + m2 * factor;
             dlnV2 += factor;
-            dlnV2 += factor * rcp_fast(ad - 1);
+            dlnV2 += factor * rcp_ode(ad - 1);
         }
         d[2] = (1 - eps_rad) * (Gamma - 1) * C_C2 * dm_u - (ad - 1) * dlnV2 * U;
     }
