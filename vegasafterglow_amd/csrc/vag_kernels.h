@@ -494,6 +494,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     const int slot_l0 = tid / nt, slot_idx0 = tid - slot_l0 * nt;
 
     for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
+    for (int i = tid; i < nt; i += THREADS) s_kidx[i] = -1;  // no bracket hint yet
     if constexpr (MODE == FLUX_FUSED)
         for (int s = tid; s < slots; s += THREADS) s_acc2[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
@@ -580,7 +581,29 @@ vag_flux_grid_kernel(FluxArgs a) {
 #else
             if (tq >= row_t0 && tq < row_tN) {
 #endif
-                int lo = 0, hi = K - 1;  // invariant: s_tc[lo] <= tq < s_tc[hi]
+                // invariant: s_tc[lo] <= tq < s_tc[hi].  Neighbouring rows shift the lattice only slightly, so the bracket is
+                // grown outwards from the previous row's interval (still in s_kidx) before it is bisected: two dependent
+                // LDS reads in the common case instead of log2(K).
+                int lo = s_kidx[idx], hi;
+                lo = lo < 0 ? 0 : lo;  // first row of the workgroup, or a time the previous row did not cover
+                if (s_tc[lo] <= tq) {
+                    int step = 1;
+                    hi = lo + 1;
+                    while (hi < K - 1 && s_tc[hi] <= tq) {
+                        lo = hi;
+                        step <<= 1;
+                        hi = min(lo + step, K - 1);
+                    }
+                } else {
+                    int step = 1;
+                    hi = lo;
+                    lo = hi - 1;
+                    while (s_tc[lo] > tq) {  // ends at the latest at node 0: s_tc[0] = row_t0 <= tq
+                        hi = lo;
+                        step <<= 1;
+                        lo = max(hi - step, 0);
+                    }
+                }
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (s_tc[mid] <= tq)
@@ -828,6 +851,38 @@ struct SeriesArgs {
     const int* band_first;
 };
 
+// Series kernels: k with s_t[k] < t <= s_t[k+1] (t == s_t[0] -> 0), grown outwards from `hint` (the interval of the same
+// point in the previous row) and then bisected.  Requires s_t[0] <= t <= s_t[K-1].
+VAG_DEV int series_bracket(const double* __restrict__ s_t, int K, double t, int hint) {
+    int lo = hint < 0 ? 0 : (hint > K - 2 ? K - 2 : hint), hi;
+    if (s_t[lo] < t || lo == 0) {
+        int step = 1;
+        hi = lo + 1;
+        while (hi < K - 1 && s_t[hi] < t) {
+            lo = hi;
+            step <<= 1;
+            hi = min(lo + step, K - 1);
+        }
+    } else {
+        int step = 1;
+        hi = lo;
+        lo = hi - 1;
+        while (lo > 0 && !(s_t[lo] < t)) {
+            hi = lo;
+            step <<= 1;
+            lo = max(hi - step, 0);
+        }
+    }
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_t[mid] < t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 // NSLOT = data points per lane (n <= 64 * NSLOT): short series (a walker's 60 points) keep one point per lane in
 // registers instead of eight, which is the difference between 3 and 5 resident wavefronts per SIMD.
 template <int MODE, bool SPREAD = false, int NSLOT = SERIES_MAX_SLOTS>
@@ -873,9 +928,11 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int n_phi_eff = M.n_phi_eff;
 
     double acc[NSLOT], tq[NSLOT], nuq[NSLOT];
+    int kprev[NSLOT];  // each point's interval in the previous row: the next row's search starts there
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
         acc[q] = 0;
+        kprev[q] = -1;
         const int s = tid + q * SERIES_THREADS;
         tq[q] = s < a.n ? a.lg2_t_obs[s] : 0;
         nuq[q] = s < a.n ? a.lg2_nu_obs[s] + lg2_1pz : 0;
@@ -947,17 +1004,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                 const double t = tq[0];
                 const bool in = tid < a.n && t >= row_t0 && t <= row_tN;
                 int k = 0;
-                if (in) {
-                    int lo = 0, hi = K - 1;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_t[mid] < t)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    k = lo;
-                }
+                if (in) k = kprev[0] = series_bracket(s_t, K, t, kprev[0]);
                 const unsigned long long mask = __ballot(in);
                 if (mask != 0) {  // wave-uniform
                     const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
@@ -998,15 +1045,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                 const double t = tq[q];
                 // iterate_through (observer.h:316-320): a point equal to a node belongs to the interval it closes
                 if (t >= row_t0 && t <= row_tN) {
-                    int lo = 0, hi = K - 1;  // find k with s_t[k] < t <= s_t[k+1]; t == row_t0 -> k = 0
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_t[mid] < t)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    const int k = lo;
+                    const int k = kprev[q] = series_bracket(s_t, K, t, kprev[q]);  // s_t[k] < t <= s_t[k+1]; t == row_t0 -> 0
                     double blo, bhi;
                     if (MODE == FLUX_SYN) {
                         blo = log2_I_nu_fast(s_par + k * VAG_NPAR, 1, sc, nuq[q] - s_dop[k], sp_tab);
