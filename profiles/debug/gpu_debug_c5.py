@@ -1,4 +1,4 @@
-"""Ad-hoc: parity of individual C5 ensemble members, per component and with SSC off (python tests/gpu_debug_c5.py)."""
+"""Ad-hoc: parity of individual C5 ensemble members, per component and with SSC off (python profiles/debug/gpu_debug_c5.py)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

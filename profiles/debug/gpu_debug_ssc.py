@@ -1,8 +1,9 @@
-"""Ad-hoc GPU parity probe for the SSC tier (not a pytest file): python tests/gpu_debug_ssc.py"""
+"""Ad-hoc GPU parity probe for the SSC tier (not a pytest file): python profiles/debug/gpu_debug_ssc.py"""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
+sys.path.insert(0, _ROOT)
 import _abi, configs
 import ctypes as C
 from vegasafterglow_amd import _lib
