@@ -1,7 +1,7 @@
 """Ad-hoc: parity of individual C5 ensemble members, per component and with SSC off (python profiles/debug/gpu_debug_c5.py)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "profiles"))
 import ctypes as C
 import _abi
