@@ -264,12 +264,22 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
 // seed lattice is a suffix scan done with wave shuffles (two seed bins per lane), the accumulation onto the
 // phase-locked output lattice is integer-indexed with one output node per lane (registers).
 // ------------------------------------------------------------------------------------------------
+// LDS of one wavefront (= one cell).  The setup arrays are dead once every lane holds its two seed nodes in registers, so
+// the accumulation loop's exchange rows and the KN-correction lattice reuse their memory: 13 KB instead of 21 KB per
+// wavefront, i.e. 12 resident wavefronts per CU instead of 7 for a kernel that lives on latency hiding.
 struct IcShared {
-    double nu[IC_MAX_NU], lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU],
-        inv_lg2r[IC_MAX_NU], cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU], ex[IC_MAX_NU];
-    double T[4][IC_MAX_NU];  // per-bin terms of four electron energies (exchange rows of the accumulation loop)
+    double nu[IC_MAX_NU], ex[IC_MAX_NU];  // live throughout
     double gam[IC_MAX_G], dNe[IC_MAX_G];
-    double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
+    union {
+        struct {  // setup only
+            double lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU], inv_lg2r[IC_MAX_NU],
+                cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU];
+        };
+        struct {  // accumulation loop
+            double T[4][IC_MAX_NU];  // per-bin terms of four electron energies (exchange rows of the accumulation loop)
+            double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
+        };
+    };
 };
 
 VAG_DEV double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, double nu_hi, double lg2f_lo, double lg2f_hi,
@@ -445,13 +455,6 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
 #endif
-    if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
-        const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
-        const double lg2_base = log2(sh.gam[0]) + sh.lg2nu[0];
-        for (int q = lane; q < n_lat; q += 64)
-            compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
-        __syncthreads();
-    }
     // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527).
     // Register-resident form: every lane keeps two seed nodes, in REVERSED lane order (j0 = 2 (63 - lane), j1 = j0 + 1),
     // so the suffix sums of the scattering CDF are a prefix sum over lanes and the value at node j + 1 is the lane's own
@@ -481,6 +484,15 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         __syncthreads();
     }
     const double cdf0_th = sh.cdf_th[0];
+    const double lg2nu_first = sh.lg2nu[0];
+    __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
+    if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
+        const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
+        const double lg2_base = log2(sh.gam[0]) + lg2nu_first;
+        for (int q = lane; q < n_lat; q += 64)
+            compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+        __syncthreads();
+    }
     const int n_lo_i = (int)n_lo;
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): dNe and the KN split index
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
