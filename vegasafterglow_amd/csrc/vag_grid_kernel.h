@@ -42,18 +42,30 @@ VAG_DEV double linspace_at(double start, double stop, int n, int i) {
     return (n > 1 && i == n - 1) ? stop : start + step * (double)i;
 }
 
+// LDS of one wavefront (= one model).  Arrays with disjoint lifetimes share memory (25.6 KB instead of 38.9 KB: six
+// resident models per CU instead of four when a batch is larger than the chip):
+//   profile scans + theta quantiles (find_jet_jumps ... merge_grids)   |  phi-weight constants (adaptive_phi_grid)
+//   CDF samples (both inverse_CFD_sampling calls)                       |  t_dec per row (build_time_grid, after the phi grid)
 struct GridShared {
-    double scan_th[N_SCAN + 8];  // scan abscissae (find_theta_range accumulates them sequentially)
-    double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae
-    double xs[N_SAMPLES];        // CDF sample abscissae
-    double cdf[N_SAMPLES];       // CDF at xs
+    union {
+        struct {
+            double scan_th[N_SCAN + 8];  // scan abscissae (find_theta_range accumulates them sequentially)
+            double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae
+            double base[VAG_MAX_THETA];  // theta quantiles before the jump nodes are merged in
+        };
+        struct {  // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
+            double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA], pj_st[VAG_MAX_THETA];
+        };
+    };
+    union {
+        struct {
+            double xs[N_SAMPLES];   // CDF sample abscissae
+            double cdf[N_SAMPLES];  // CDF at xs
+        };
+        double tdec[VAG_MAX_THETA];
+    };
     double theta[VAG_MAX_THETA + 64];
-    double base[VAG_MAX_THETA];
     double phi[VAG_MAX_PHI];
-    // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
-    double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA],
-        pj_st[VAG_MAX_THETA];
-    double tdec[VAG_MAX_THETA];
     int flag[VAG_MAX_THETA];
 };
 
