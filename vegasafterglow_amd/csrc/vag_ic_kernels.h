@@ -267,16 +267,21 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
 // LDS of one wavefront (= one cell).  The setup arrays are dead once every lane holds its two seed nodes in registers, so
 // the accumulation loop's exchange rows and the KN-correction lattice reuse their memory: 13 KB instead of 21 KB per
 // wavefront, i.e. 12 resident wavefronts per CU instead of 7 for a kernel that lives on latency hiding.
+#ifdef VAG_IC_U
+#define VAG_IC_U_ROWS VAG_IC_U
+#else
+#define VAG_IC_U_ROWS 3
+#endif
 struct IcShared {
     double nu[IC_MAX_NU], ex[IC_MAX_NU];  // live throughout
-    double gam[IC_MAX_G], dNe[IC_MAX_G];
     union {
         struct {  // setup only
             double lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU], inv_lg2r[IC_MAX_NU],
                 cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU];
+            double gam[IC_MAX_G], dNe[IC_MAX_G];
         };
         struct {  // accumulation loop
-            double T[4][IC_MAX_NU];  // per-bin terms of four electron energies (exchange rows of the accumulation loop)
+            double T[VAG_IC_U_ROWS][IC_MAX_NU];  // per-bin terms of U electron energies (exchange rows of the accumulation loop)
             double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
         };
     };
@@ -286,7 +291,7 @@ VAG_DEV double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, do
                                       double lg2r, double inv_lg2r, double trap) {
     if (!(f_lo > 0) || !(f_hi > 0)) return trap;
     const double s1 = 1 + (lg2f_hi - lg2f_lo) * inv_lg2r;
-    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) / s1;
+    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) * rcp_fast(s1);  // 1e-3 < |s1| < inf: no IEEE division needed
     return f_lo * nu_lo * lg2r * 0.6931471805599453;
 }
 
@@ -485,20 +490,22 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     }
     const double cdf0_th = sh.cdf_th[0];
     const double lg2nu_first = sh.lg2nu[0];
+    // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
+    const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
+    const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
+    const double gam_first = sh.gam[0];
     __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
     if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
         const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
-        const double lg2_base = log2(sh.gam[0]) + lg2nu_first;
+        const double lg2_base = log2(gam_first) + lg2nu_first;
         for (int q = lane; q < n_lat; q += 64)
             compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
         __syncthreads();
     }
     const int n_lo_i = (int)n_lo;
-    // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): dNe and the KN split index
-    const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
     int my_split = 0;
     if (KN && lane < g_size) {
-        const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / sh.gam[lane];
+        const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
         // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
         const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
         int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) / step);
@@ -546,7 +553,10 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 1) g_size = 0;
 #endif
-    constexpr int U = 4;  // electron energies per exchange round: four independent dependency chains in flight
+#ifndef VAG_IC_U
+#define VAG_IC_U 3  // measured: 3 beats 4 (one exchange row less of LDS: 13 resident wavefronts per CU) and 2
+#endif
+    constexpr int U = VAG_IC_U;  // electron energies per exchange round: four independent dependency chains in flight
     for (int ib = 0; ib < g_size; ib += U) {
         double dNe_u[U], cdf0_u[U];
         bool live[U];
