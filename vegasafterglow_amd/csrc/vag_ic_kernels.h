@@ -273,12 +273,12 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
 #define VAG_IC_U_ROWS 3
 #endif
 struct IcShared {
-    double nu[IC_MAX_NU], ex[IC_MAX_NU];  // live throughout
+    double nu[IC_MAX_NU];  // live throughout
     union {
         struct {  // setup only
             double lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU], inv_lg2r[IC_MAX_NU],
                 cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU];
-            double gam[IC_MAX_G], dNe[IC_MAX_G];
+            double gam[IC_MAX_G], dNe[IC_MAX_G], ex[IC_MAX_NU];
         };
         struct {  // accumulation loop
             double T[VAG_IC_U_ROWS][IC_MAX_NU];  // per-bin terms of U electron energies (exchange rows of the accumulation loop)
@@ -334,7 +334,10 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-__global__ void __launch_bounds__(64)
+#ifndef VAG_IC_WAVES
+#define VAG_IC_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, VAG_IC_WAVES)
 vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                      long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
                      const double* __restrict__ cellpar, const double* __restrict__ cellq, const double* __restrict__ band,
@@ -480,14 +483,6 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double nuN0 = nu1;
     const double nuN1 = from_lane_below(nu0);
     const double rth0 = bin0 ? sh.ratio_th[j0] : 1.0, rth1 = bin1 ? sh.ratio_th[j1] : 1.0;
-    if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
-        const double fN0 = fth1, fN1 = from_lane_below(fth0);
-        const double cN0 = cth1, cN1 = from_lane_below(cth0);
-        __syncthreads();
-        if (bin0) sh.ex[j0] = cN0 + 0.5 * (fth0 + fN0) * dnu0 * rth0;  // sh.ex doubles as the exchange row T[j]
-        if (bin1) sh.ex[j1] = cN1 + 0.5 * (fth1 + fN1) * dnu1 * rth1;
-        __syncthreads();
-    }
     const double cdf0_th = sh.cdf_th[0];
     const double lg2nu_first = sh.lg2nu[0];
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
@@ -495,6 +490,13 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
     const double gam_first = sh.gam[0];
     __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
+    if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
+        const double fN0 = fth1, fN1 = from_lane_below(fth0);
+        const double cN0 = cth1, cN1 = from_lane_below(cth0);
+        if (bin0) sh.T[0][j0] = cN0 + 0.5 * (fth0 + fN0) * dnu0 * rth0;  // one exchange row serves every energy
+        if (bin1) sh.T[0][j1] = cN1 + 0.5 * (fth1 + fN1) * dnu1 * rth1;
+        __syncthreads();
+    }
     if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
         const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
         const double lg2_base = log2(gam_first) + lg2nu_first;
@@ -578,7 +580,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!live[u] || cdf0_u[u] <= 0) continue;  // uniform
-            const double* Trow = KN ? sh.T[u] : sh.ex;
+            const double* Trow = KN ? sh.T[u] : sh.T[0];
             const int jb = n_lo_i - 2 * (ib + u) + lane;
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
