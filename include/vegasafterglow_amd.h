@@ -336,6 +336,10 @@ int vag_details_radiation(vag_ctx* ctx, const vag_model_params* params, double t
  * t_obs = doppler = NULL to query n_phi_eff. */
 int vag_details_eat(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int* n_phi_eff, double* t_obs,
                     double* doppler);
+/* Model.jet_E_iso(phi, theta), Model.jet_Gamma0(phi, theta), Model.medium(phi, theta, r) (pybind.cpp:441-448,
+ * pymodel.cpp:572-594) for the named, phi-independent profiles: kind 0 -> isotropic-equivalent energy [erg] at theta[n],
+ * 1 -> initial Lorentz factor at theta[n], 2 -> mass density [g/cm^3] at radius r[n] [cm]. */
+int vag_profile_eval(vag_ctx* ctx, const vag_model_params* params, int kind, const double* x, int n, double* out);
 
 /* Per-stage device timings (ms) of the last batch call, stage names follow the reference's
  * profiler (pybind/pymodel.h:877-953): grid, dynamics, syn_cells, sync_flux, reduce, total. */

@@ -3492,6 +3492,27 @@ static int details_impl(const vag_model_params* p, double t_min, double t_max, v
     return 0;
 }
 
+/* Model.jet_E_iso / jet_Gamma0 / medium (pybind/pymodel.cpp:572-594): kind 0 -> E_iso(theta) [erg], 1 -> Gamma0(theta),
+ * 2 -> rho(r [cm]) [g/cm^3] */
+int vag_oracle_profile(const vag_model_params* p, int kind, const double* x, int n, double* out) {
+    if (vag_oracle_params_validate(p) != 0) return -1;
+    jet_t jet;
+    medium_t med;
+    jet_init(&jet, p);
+    medium_init(&med, p);
+    for (int i = 0; i < n; ++i) {
+        if (kind == 0)
+            out[i] = jet_eps_k(&jet, x[i]) / (U_ERG / (4 * C_PI));
+        else if (kind == 1)
+            out[i] = jet_Gamma0(&jet, x[i]);
+        else if (kind == 2)
+            out[i] = medium_rho(&med, x[i] * U_CM) / (U_G / U_CM3);
+        else
+            return fail("profile kind must be 0, 1 or 2");
+    }
+    return 0;
+}
+
 int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
                        const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
                        const double* probe_lg2_nu, int n_probe) {

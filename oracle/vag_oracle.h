@@ -43,6 +43,8 @@ int vag_oracle_details(const vag_model_params* p, double t_min, double t_max, va
 int vag_oracle_details_rvs(const vag_model_params* p, double t_min, double t_max, vag_details_shape* shape,
                            const vag_details_out* out, double** extra, int n_extra, int* n_phi_eff,
                            const double* probe_lg2_nu, int n_probe);
+/* Model.jet_E_iso / jet_Gamma0 / medium (pybind/pymodel.cpp:572-594): kind 0 E_iso(theta) [erg], 1 Gamma0(theta), 2 rho(r [cm]) [g/cm^3] */
+int vag_oracle_profile(const vag_model_params* p, int kind, const double* x, int n, double* out);
 /* Fitter log-likelihood for nb walkers (fitter.py:497-533, samplers.py:61-70): out[nb]. */
 int vag_oracle_loglike_batch(const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out);
 /* Same validation rules as the product's vag_params_validate (pybind/pymodel.cpp:47-186). */

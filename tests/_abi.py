@@ -190,6 +190,15 @@ class CpuLib:
         self._check(fn(C.byref(prm), _p(t), _p(nu), _p(expo), t.size, num_points, _p(out)))
         return out
 
+    def profile(self, prm, kind, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        fn = getattr(self.lib, self.prefix + "_profile")
+        fn.argtypes = [C.POINTER(ModelParams), C.c_int, _dp, C.c_int, _dp]
+        fn.restype = C.c_int
+        self._check(fn(C.byref(prm), kind, _p(x), x.size, _p(out)))
+        return out
+
     EXTRA_NAMES = ["gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "column_den", "nu_m", "nu_c", "nu_a",
                    "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe", "injection_idx"]
 

@@ -823,3 +823,25 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     finally:
         del os.environ["VAG_NO_FUSED"]
     assert np.array_equal(band_f, band_t)
+
+
+def test_profile_evaluators_match_the_checker(eng, oracle):
+    """Model.jet_E_iso / jet_Gamma0 / medium (pybind.cpp:441-448) for every named profile family."""
+    theta = np.linspace(1e-4, 1.5, 97)
+    r = np.logspace(14, 20, 61)
+    jets = [va.TophatJet(0.1, 1e52, 300.0), va.GaussianJet(0.1, 1e52, 300.0), va.PowerLawJet(0.1, 1e52, 300.0, 2.0, 1.5),
+            va.TwoComponentJet(0.05, 1e52, 300.0, 0.3, 1e50, 30.0), va.StepPowerLawJet(0.05, 1e52, 300.0, 3e51, 100.0, 3.0, 2.0),
+            va.PowerLawWing(0.05, 3e51, 100.0, 3.0, 2.0), va.GaussianJet(0.1, 1e52, 300.0, magnetar=va.Magnetar(1e47, 1e3, 2.0))]
+    media = [va.ISM(0.3), va.Wind(0.1), va.Wind(0.1, n_ism=1e-3, n0=10.0), va.Wind(0.1, k_m=1.5)]
+    for jet in jets:
+        m = va.Model(jet, media[0], va.Observer(1e28, 1.0, 0.1), va.Radiation(0.1, 0.01, 2.3))
+        prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+        np.testing.assert_allclose(m.jet_E_iso(0.0, theta), oracle.profile(prm, 0, theta), rtol=1e-13, atol=0)
+        np.testing.assert_allclose(m.jet_Gamma0(0.0, theta), oracle.profile(prm, 1, theta), rtol=1e-13, atol=0)
+    for med in media:
+        m = va.Model(jets[0], med, va.Observer(1e28, 1.0, 0.1), va.Radiation(0.1, 0.01, 2.3))
+        prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+        np.testing.assert_allclose(m.medium(0.0, 0.0, r), oracle.profile(prm, 2, r), rtol=1e-12, atol=0)
+    m = va.Model(jets[0], media[0], va.Observer(1e28, 1.0, 0.1), va.Radiation(0.1, 0.01, 2.3))
+    assert m.jet_E_iso(0.0, [0.05, 0.2]).tolist() == [1e52, 0.0] and m.jet_Gamma0(0.0, [0.05, 0.2]).tolist() == [300.0, 1.0]
+    assert abs(m.medium(0.0, 0.0, [1e17])[0] / (0.3 * 1.67e-24) - 1) < 1e-12

@@ -1673,6 +1673,31 @@ int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double
     return details_impl(c, params, t_min, t_max, shape, out, false);
 }
 
+int vag_profile_eval(vag_ctx* c, const vag_model_params* params, int kind, const double* x, int n, double* out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (kind < 0 || kind > 2) return set_err(VAG_E_INVALID, "profile kind must be 0 (E_iso), 1 (Gamma0) or 2 (rho)");
+    if (n <= 0 || !x || !out) return set_err(VAG_E_INVALID, "empty abscissa array");
+    const char* msg = validate_msg(params);
+    if (msg) return set_err(VAG_E_INVALID, "%s", msg);
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d_params.ensure(sizeof(vag_model_params))) return VAG_E_HIP;
+    DevBuf tmp;
+    if (tmp.ensure(sizeof(double) * 2 * (size_t)n)) return VAG_E_HIP;
+    double* d_x = tmp.as<double>();
+    hipError_t e = hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(vag_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_params.as<vag_model_params>(),
+                           kind, d_x, n, d_x + n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_x + n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    if (e != hipSuccess) return set_err(VAG_E_HIP, "profile evaluation failed: %s", hipGetErrorString(e));
+    return VAG_OK;
+}
+
 int vag_details_eat(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int* n_phi_eff, double* t_obs,
                     double* doppler) {
     vag_details_shape sh;

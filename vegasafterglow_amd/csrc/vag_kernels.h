@@ -406,6 +406,25 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
     }
 }
 
+// Model.jet_E_iso / jet_Gamma0 / medium (pybind/pymodel.cpp:572-594): the engine's own profile functions on n abscissae.
+// kind 0 -> E_iso(theta) [erg], 1 -> Gamma0(theta), 2 -> rho(r [cm]) [g/cm^3].
+__global__ void __launch_bounds__(256)
+vag_profile_kernel(const vag_model_params* __restrict__ params, int kind, const double* __restrict__ x, int n,
+                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vag_model_params P = params[0];
+    if (kind == 2) {
+        Medium med;
+        medium_init(med, P);
+        out[i] = medium_rho(med, x[i] * U_CM) / (U_G / U_CM3);
+    } else {
+        Jet jet;
+        jet_init(jet, P);
+        out[i] = kind == 0 ? jet_eps_k(jet, x[i]) / (U_ERG / (4 * C_PI)) : jet_Gamma0(jet, x[i]);
+    }
+}
+
 // Model.details(): observer time [s] and Doppler factor of every (phi, theta, k) cell of model 0, the linear forms of what
 // eat_row keeps as logs (ShockDetails.t_obs = obs.time / sec, .Doppler = exp2(lg2_doppler), pybind/pymodel.cpp:296-298).
 // out_* are [n_phi_eff][n_theta][n_t]; one lane per cell.

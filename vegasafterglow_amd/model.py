@@ -371,6 +371,27 @@ class Model:
         return FluxDict(out)
 
     # -- Model.flux_density_exposures: pybind.cpp:433-434, pymodel.cpp:412-496 --
+    def _profile(self, kind, x):
+        x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+        out = np.empty_like(x)
+        lib = _lib.load()
+        h, lock = get_context(self._device)
+        with lock:
+            _lib.check(lib.vag_profile_eval(h, C.byref(self.params), kind, x.ctypes.data_as(_dp), x.size, out.ctypes.data_as(_dp)))
+        return out
+
+    def jet_E_iso(self, phi, theta):
+        """Isotropic-equivalent energy [erg] of the jet at theta (pybind.cpp:444; the named profiles do not depend on phi)."""
+        return self._profile(0, theta)
+
+    def jet_Gamma0(self, phi, theta):
+        """Initial Lorentz factor of the jet at theta (pybind.cpp:447)."""
+        return self._profile(1, theta)
+
+    def medium(self, phi, theta, r):
+        """Mass density [g/cm^3] of the circumburst medium at radius r [cm] (pybind.cpp:441)."""
+        return self._profile(2, r)
+
     def flux_density_exposures(self, t, nu, expo_time, num_points=10):
         """Exposure-averaged flux density: `num_points` samples across each [t_i, t_i + expo_time_i] window are
         evaluated as one sorted (t, nu) series on the device and averaged per exposure."""
