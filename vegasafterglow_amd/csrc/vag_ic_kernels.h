@@ -623,8 +623,9 @@ VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, dou
                                  double th_max, double x, int* breach) {
     const int n = (int)h_n;
     if (n < 2) return -INFINITY;
-    const long idx0 = (long)h_idx0;
-    auto node = [&](int q) { return phase + IC_Q * (double)(idx0 + 2L * q); };
+    // lattice node q = phase + IC_Q * (idx0 + 2 q): idx0 + 2 q is an integer far below 2^53, so it is formed in double
+    // (exactly the value the reference converts from its integer) -- no 64-bit integer conversions in this hot evaluator
+    auto node = [&](int q) { return phase + IC_Q * (h_idx0 + 2.0 * (double)q); };
     const double first = node(0), last = node(n - 1);
     if ((x > last && x < th_max) || (x < first && x > th_min)) *breach = 1;
     if (x > last) return -INFINITY;
@@ -633,9 +634,10 @@ VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, dou
     while (idx + 2 < n && node(idx + 1) <= x) ++idx;  // settle exactly like the reference's forward scan
     while (idx > 0 && node(idx) > x) --idx;
     const double Ilo = tab[IC_HDR + idx], Ihi = tab[IC_HDR + idx + 1];
-    const double dl = node(idx + 1) - node(idx);
-    const double slope = dl != 0 ? (Ihi - Ilo) / dl : 0;
-    return Ilo + (x - node(idx)) * slope;
+    const double n_lo = node(idx);
+    const double dl = node(idx + 1) - n_lo;
+    const double slope = dl != 0 ? (Ihi - Ilo) * rcp_fast(dl) : 0;  // dl ~ 2 IC_Q: finite, normal
+    return Ilo + (x - n_lo) * slope;
 }
 
 }  // namespace vag
