@@ -244,3 +244,28 @@ def test_batch_pool_routes_point_queues_through_one_batched_call():
     with pool as p:
         assert p is pool
     pool.close(), pool.join(), pool.shutdown(wait=True)
+
+
+def test_fitter_add_spectrum_and_validate_parameters():
+    """Fitter.add_spectrum (fitter.py:284-314) files one point per frequency at a fixed time; validate_parameters rejects
+    what the reference's fitting/params.py rejects before any sampler runs."""
+    f = fitting.Fitter(z=0.1, lumi_dist=1e27, jet="tophat", medium="ism")
+    nu = np.array([1e9, 1e14, 1e18])
+    f.add_spectrum(3e5, nu, np.array([1e-27, 2e-28, 3e-31]), np.array([1e-28, 2e-29, 3e-32]))
+    f.add_flux_density(5e14, np.array([1e4, 1e6]), np.array([1e-27, 1e-28]), np.array([1e-28, 1e-29]))
+    f._consolidate_data()
+    assert f._all_t.size == 5 and np.all(np.diff(f._all_t) >= 0)
+    assert sorted(f._all_nu[f._all_t == 3e5].tolist()) == nu.tolist()
+    with pytest.raises(ValueError):
+        f.add_spectrum(-1.0, nu, nu, nu)
+    with pytest.raises(ValueError):
+        f.add_spectrum(1e5, np.array([1e9, -1.0]), np.ones(2), np.ones(2))
+    P, S = fitting.ParamDef, fitting.Scale
+    f.validate_parameters([P("E_iso", 1e50, 1e54, S.log), P("theta_v", 0.0, 0.5, S.linear), P("p", 2.3, 2.3, S.fixed)])
+    for bad in ([P("E_iso", 1e50, 1e54, S.log), P("E_iso", 1e50, 1e54, S.log)],      # duplicate
+                [P("E_iso", 0.0, 1e54, S.log)],                                        # log scale from zero
+                [P("theta_v", 0.5, 0.1, S.linear)],                                    # inverted bounds
+                [P("not_a_parameter", 0.0, 1.0, S.linear)],
+                [P("A_V", 0.0, 1.0, S.linear)]):                                       # no extinction law configured
+        with pytest.raises(ValueError):
+            f.validate_parameters(bad)

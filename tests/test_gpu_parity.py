@@ -845,3 +845,34 @@ def test_profile_evaluators_match_the_checker(eng, oracle):
     m = va.Model(jets[0], media[0], va.Observer(1e28, 1.0, 0.1), va.Radiation(0.1, 0.01, 2.3))
     assert m.jet_E_iso(0.0, [0.05, 0.2]).tolist() == [1e52, 0.0] and m.jet_Gamma0(0.0, [0.05, 0.2]).tolist() == [300.0, 1.0]
     assert abs(m.medium(0.0, 0.0, [1e17])[0] / (0.3 * 1.67e-24) - 1) < 1e-12
+
+
+def test_fitter_predictions_at_a_sample(eng, oracle):
+    """Fitter.model / flux_density_grid / flux (fitter.py:779-833,1089-1099): the Model at a point of sampler space, with
+    the host-galaxy extinction applied per frequency to the grid."""
+    k_law = lambda lam_cm: (5.5e-5 / np.asarray(lam_cm)) ** 1.1  # a smooth stand-in for a named extinction law
+    f = fitting.Fitter(z=0.5, lumi_dist=3e28, jet="gaussian", medium="ism", extinction=k_law, fwd_ssc=True)
+    t, nu = np.logspace(3, 7, 12), np.array([1e9, 4.84e14, 1e18])
+    f.add_flux_density(4.84e14, t, np.full(t.size, 1e-28), np.full(t.size, 1e-29))
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e50, 1e54, S.log), P("theta_v", 0.0, 0.5, S.linear), P("A_V", 0.0, 2.0, S.linear),
+            P("theta_c", 0.1, 0.1, S.fixed), P("Gamma0", 300.0, 300.0, S.fixed), P("n_ism", 1.0, 1.0, S.fixed),
+            P("eps_e", 0.1, 0.1, S.fixed), P("eps_B", 0.01, 0.01, S.fixed), P("p", 2.3, 2.3, S.fixed)]
+    f.validate_parameters(defs)
+    sample = np.array([52.3, 0.17, 0.8])
+    m = f.model(sample, defs)
+    assert (m.params.E_iso, m.params.theta_obs, m.params.flags & 1) == (10 ** 52.3, 0.17, 1)
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    want = oracle.flux_components4(prm, t, nu)
+    raw = m.flux_density_grid(t, nu)
+    assert_close(raw.fwd.sync, want[0])
+    assert_close(raw.fwd.ssc, want[1], rtol=5e-6)
+    att = np.exp(-0.8 * 0.4 * np.log(10.0) * k_law((2.99792458e10 / nu) / 1.5))[:, None]
+    got = f.flux_density_grid(sample, t, nu, defs)
+    assert np.array_equal(got.fwd.sync, raw.fwd.sync * att) and np.array_equal(got.fwd.ssc, raw.fwd.ssc * att)
+    assert np.allclose(got.total, (raw.fwd.sync + raw.fwd.ssc) * att, rtol=1e-15) and got.rvs.sync.shape == ()
+    assert_close(f.flux(sample, t, (1e17, 1e19), defs, num_points=9).total, oracle.flux(prm, t, 1e17, 1e19, 9))
+    coarse = f.model(sample, defs, resolution=(0.1, 0.3, 8.0))
+    assert coarse.resolutions == (0.1, 0.3, 8.0)
+    with pytest.raises(ValueError):
+        f.model(sample[:2], defs)

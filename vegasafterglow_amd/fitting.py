@@ -98,6 +98,16 @@ class Fitter:
         self._point_weights.append(w)
         self._all_t = None
 
+    # fitter.py:284-314
+    def add_spectrum(self, t, nu, f_nu, err, weights=None):
+        """A broadband spectrum at one time t [s]: one point-data row per frequency."""
+        if not np.isfinite(t) or t <= 0:
+            raise ValueError(f"add_spectrum: t must be finite and > 0, got {t}")
+        nu = np.asarray(nu, dtype=np.float64)
+        if nu.size == 0 or not np.isfinite(nu).all() or (nu <= 0).any():
+            raise ValueError("add_spectrum: nu must be non-empty, finite and > 0 at every point")
+        self.add_flux_density(nu, np.full_like(nu, float(t)), f_nu, err, weights)
+
     # fitter.py:316-377
     def add_flux(self, band, t, flux, err, num_points=5, weights=None):
         """Band-integrated fluxes [erg/cm^2/s] over band = (nu_min, nu_max) [Hz]; each group is one Model.flux request."""
@@ -216,6 +226,75 @@ class Fitter:
         lower = np.array([np.log10(pd.lower) if pd.scale is Scale.log else pd.lower for pd in free], dtype=np.float64)
         upper = np.array([np.log10(pd.upper) if pd.scale is Scale.log else pd.upper for pd in free], dtype=np.float64)
         return spec, lower, upper
+
+    # fitting/params.py validate_parameters: the checks that do not depend on the sampler
+    def validate_parameters(self, param_defs: Sequence[ParamDef]) -> None:
+        names = [pd.name for pd in param_defs]
+        if len(set(names)) != len(names):
+            raise ValueError("duplicate parameter names")
+        for pd in param_defs:
+            if pd.name != "A_V" and pd.name not in _lib.PARAM_SLOTS:
+                raise ValueError(f"parameter {pd.name} is not accepted by the accelerated path")
+            if pd.scale is Scale.fixed:
+                continue
+            if not (np.isfinite(pd.lower) and np.isfinite(pd.upper) and pd.lower < pd.upper):
+                raise ValueError(f"{pd.name}: need finite lower < upper, got [{pd.lower}, {pd.upper}]")
+            if pd.scale is Scale.log and pd.lower <= 0:
+                raise ValueError(f"{pd.name}: log-scale parameters need lower > 0")
+        if "A_V" in names and self.extinction is None:
+            raise ValueError("A_V needs Fitter(extinction=...)")
+
+    def _params_at(self, sample, param_defs, resolution=None):
+        """vag_model_params and A_V of one point of sampler space (the transformer of fitting/utils.py:110-135)."""
+        spec, _, _ = self.build_spec(param_defs)
+        sample = np.asarray(sample, dtype=np.float64).reshape(-1)
+        if sample.size != spec.ndim:
+            raise ValueError(f"expected {spec.ndim} free parameters, got {sample.size}")
+        p = _lib.ModelParams.from_buffer_copy(bytes(spec.base))
+        fields = (C.c_double * 40).from_address(C.addressof(p) + _lib.ModelParams.theta_c.offset)
+        a_v = spec.a_v_fixed
+        for d in range(spec.ndim):
+            val = 10.0 ** sample[d] if spec.is_log[d] else sample[d]
+            if spec.slot[d] == _lib.P_A_V:
+                a_v = val
+            else:
+                fields[spec.slot[d]] = val
+        if resolution is not None:
+            p.phi_resol, p.theta_resol, p.t_resol = (float(x) for x in resolution)
+        return p, float(a_v)
+
+    # fitter.py:1089-1099
+    def model(self, best_params, param_defs, resolution=None):
+        """The underlying Model at a point of sampler space (no extinction applied)."""
+        from .model import Model
+        return Model.from_params(self._params_at(best_params, param_defs, resolution)[0], device=self.device)
+
+    # fitter.py:779-804
+    def flux_density_grid(self, best_params, t, nu, param_defs, resolution=None):
+        """FluxDict on a (t, nu) grid at a point of sampler space; host-galaxy extinction (Fitter(extinction=...), A_V != 0) is
+        applied per frequency to every component, like the fitter's own chi-squared path."""
+        from .model import Model, FluxDict
+        p, a_v = self._params_at(best_params, param_defs, resolution)
+        res = Model.from_params(p, device=self.device).flux_density_grid(t, nu)
+        if self.extinction is None or a_v == 0.0:
+            return res
+        lam_rest_cm = (2.99792458e10 / np.asarray(nu, dtype=np.float64)) / (1.0 + self.z)
+        att = np.exp(-a_v * 0.4 * np.log(10.0) * np.asarray(self.extinction(lam_rest_cm), dtype=np.float64))[:, None]
+        comps = [c * att if np.ndim(c) == 2 else None for c in (res.fwd.sync, res.fwd.ssc, res.rvs.sync, res.rvs.ssc)]
+        return FluxDict(*comps)
+
+    # fitter.py:806-833
+    def flux(self, best_params, t, band, param_defs, num_points=5, resolution=None):
+        """Band-integrated flux [erg/cm^2/s] over band = (nu_min, nu_max) at a point of sampler space (no extinction)."""
+        nu_min, nu_max = band
+        return self.model(best_params, param_defs, resolution).flux(t, nu_min, nu_max, num_points)
+
+    # fitter.py:545-674 (the emcee branch; the stretch-move sampler of vegasafterglow_amd.sampling needs no third-party package)
+    def fit(self, param_defs, nwalkers=None, nsteps=1000, nburn=0, seed=0, **kw):
+        from . import sampling
+        self.validate_parameters(param_defs)
+        ndim = sum(1 for pd in param_defs if pd.scale is not Scale.fixed)
+        return sampling.fit(self, param_defs, nwalkers=nwalkers or max(2 * ndim + 2, 32), nsteps=nsteps, nburn=nburn, seed=seed, **kw)
 
     def loglike_batch(self, samples, param_defs):
         """ln L for each row of samples[nb, ndim] (one batched device call)."""

@@ -309,6 +309,26 @@ class Model:
         _lib.check(_lib.load().vag_params_validate(C.byref(p)))
         self.params = p
 
+    @classmethod
+    def from_params(cls, params, device=0):
+        """A Model around an already filled vag_model_params (what Fitter._build_model hands to the engine,
+        fitter.py:455-495); validated like the constructor's."""
+        self = cls.__new__(cls)
+        p = ModelParams.from_buffer_copy(bytes(params))
+        _lib.check(_lib.load().vag_params_validate(C.byref(p)))
+        self.params, self._device = p, device
+        self._jet = self._medium = None
+        self.observer = Observer(p.lumi_dist, p.z, p.theta_obs)
+        self.fwd_rad = Radiation(p.eps_e, p.eps_B, p.p, p.xi_e, ssc=bool(p.flags & _lib.FLAG_SSC), kn=bool(p.flags & _lib.FLAG_KN))
+        self.rvs_rad = None
+        if p.flags & _lib.FLAG_RVS:
+            self.rvs_rad = Radiation(p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e, ssc=bool(p.flags & _lib.FLAG_RVS_SSC),
+                                     kn=bool(p.flags & _lib.FLAG_RVS_KN))
+        self.resolutions = (p.phi_resol, p.theta_resol, p.t_resol)
+        self.rtol, self.radiative_fireball = p.rtol, bool(p.radiative_fireball)
+        self.axisymmetric = not (p.flags & _lib.FLAG_NON_AXISYMMETRIC)
+        return self
+
     def _has_components(self):
         return self.fwd_rad.ssc or self.rvs_rad is not None
 
