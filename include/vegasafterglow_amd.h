@@ -188,6 +188,10 @@ int vag_flux_density_grid_components4_batch(vag_ctx* ctx, const vag_model_params
  */
 int vag_flux_density_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, const double* nu,
                            int n, double* out);
+/* The same series with FluxDict's components apart (pymodel.cpp:373-389): out4[i] != NULL receives component i of
+ * {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} as [nb][n]; components the model does not enable come back as zeros. */
+int vag_flux_density_components4_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, const double* nu,
+                                       int n, double* const* out4);
 
 /*
  * Model.flux(t[nt], nu_min, nu_max, num_nu) -> band flux[nt]

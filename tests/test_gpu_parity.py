@@ -876,3 +876,120 @@ def test_fitter_predictions_at_a_sample(eng, oracle):
     assert coarse.resolutions == (0.1, 0.3, 8.0)
     with pytest.raises(ValueError):
         f.model(sample[:2], defs)
+
+
+# ---- the reference's corner sweep (tests/python/test_parameter_corners.py) on the named profiles, against the checker ----
+_CT = np.logspace(2, 7, 20)
+_CNU = np.full_like(_CT, 1e14)
+_CNUS = np.array([1e9, 1e14, 1e17])
+_CJETS = {
+    "tophat": lambda: va.TophatJet(0.1, 1e53, 300),
+    "tophat_spread": lambda: va.TophatJet(0.1, 1e53, 300, spreading=True),
+    "tophat_thick": lambda: va.TophatJet(0.1, 1e53, 300, duration=1000),
+    "tophat_magnetar": lambda: va.TophatJet(0.1, 1e53, 300, magnetar=va.Magnetar(1e47, 1e3, 2)),
+    "gaussian": lambda: va.GaussianJet(0.05, 1e53, 300),
+    "powerlaw": lambda: va.PowerLawJet(0.05, 1e53, 300, 2, 1),
+    "two_component": lambda: va.TwoComponentJet(0.05, 1e53, 300, 0.3, 1e51, 30),
+    "step_powerlaw": lambda: va.StepPowerLawJet(0.05, 1e53, 300, 1e51, 30, 2, 1),
+    "powerlaw_wing": lambda: va.PowerLawWing(0.05, 1e52, 100, 2, 1),
+}
+_CMEDIA = {"ism": lambda: va.ISM(1.0), "ism_thin": lambda: va.ISM(1e-4), "wind": lambda: va.Wind(0.1),
+           "wind_full": lambda: va.Wind(0.5, n_ism=1.0, n0=1e6, k_m=1.5)}
+_CRADS = {"plain": lambda: va.Radiation(0.1, 0.01, 2.3), "ssc": lambda: va.Radiation(0.1, 1e-4, 2.3, ssc=True),
+          "ssc_kn": lambda: va.Radiation(0.1, 1e-4, 2.3, ssc=True, kn=True), "p_near2": lambda: va.Radiation(0.1, 0.01, 2.02),
+          "p_steep": lambda: va.Radiation(0.3, 0.3, 2.9), "xi_e": lambda: va.Radiation(0.1, 0.01, 2.3, xi_e=0.1)}
+
+
+def _corner_model(jet="tophat", medium="ism", rad="plain", off_axis=False, rvs=None, **kw):
+    obs = va.Observer(3e28, 0.5, 0.4) if off_axis else va.Observer(3e28, 1.0, 0.0)
+    return va.Model(_CJETS[jet](), _CMEDIA[medium](), obs, _CRADS[rad](), rvs_rad=_CRADS[rvs]() if rvs else None, **kw)
+
+
+def _corner_check(m, oracle, rtol=5e-6, contract=False):
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    f = m.flux_density(_CT, _CNU)
+    assert f.total.shape == _CT.shape and np.all(np.isfinite(f.total)) and np.all(f.total > 0)
+    want = oracle.flux_density(prm, _CT, _CNU)
+    if contract:  # structured jets with a reverse shock: the reference's own builds differ by up to 7e-3
+        assert within_contract(f.total, want)
+    else:
+        assert_close(f.total, want, rtol=rtol)
+    return f, prm
+
+
+@pytest.mark.parametrize("jet_name", sorted(_CJETS))
+def test_corner_jets(eng, oracle, jet_name):
+    _corner_check(_corner_model(jet=jet_name), oracle)
+
+
+@pytest.mark.parametrize("medium_name", sorted(_CMEDIA))
+def test_corner_media(eng, oracle, medium_name):
+    _corner_check(_corner_model(medium=medium_name), oracle)
+
+
+@pytest.mark.parametrize("rad_name", sorted(_CRADS))
+def test_corner_radiation(eng, oracle, rad_name):
+    _corner_check(_corner_model(rad=rad_name), oracle)
+
+
+@pytest.mark.parametrize("rad_name", sorted(_CRADS))
+def test_corner_reverse_shock(eng, oracle, rad_name):
+    f, _ = _corner_check(_corner_model(jet="tophat_thick", rvs=rad_name), oracle)
+    assert f.rvs.sync.shape == _CT.shape and np.all(np.isfinite(f.rvs.sync)) and np.all(f.rvs.sync >= 0)
+
+
+@pytest.mark.parametrize("jet_name", ["tophat", "gaussian", "two_component"])
+def test_corner_off_axis(eng, oracle, jet_name):
+    m = _corner_model(jet=jet_name, off_axis=True)
+    _, prm = _corner_check(m, oracle)
+    grid = m.flux_density_grid(_CT, _CNUS).total
+    assert grid.shape == (_CNUS.size, _CT.size) and np.all(np.isfinite(grid)) and np.all(grid > 0)
+    assert_close(grid, oracle.flux_density_grid(prm, _CT, _CNUS), rtol=5e-6)
+
+
+def test_corner_resolution_rtol_and_methods(eng, oracle):
+    _corner_check(_corner_model(resolutions=(0.3, 1.0, 20), rtol=1e-4), oracle, rtol=2e-4)  # both sides integrate to 1e-4
+    m = _corner_model()
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    band = m.flux(_CT, 1e17, 1e19, 8).total
+    assert band.shape == _CT.shape and np.all(band > 0)
+    assert_close(band, oracle.flux(prm, _CT, 1e17, 1e19, 8))
+    d = m.details(1e2, 1e6)
+    assert np.all(d["Gamma"] >= 1) and np.all(d["r"] > 0) and np.all(np.isfinite(d["t_obs"]))
+    fe = m.flux_density_exposures(_CT[:5], _CNU[:5], np.full(5, 10.0), 4).total
+    assert fe.shape == (5,) and np.all(np.isfinite(fe)) and np.all(fe > 0)
+    g = _corner_model(jet="gaussian")
+    theta = np.array([0.0, 0.02, 0.05])
+    assert np.all(g.jet_E_iso(0.0, theta) > 0) and np.all(g.jet_Gamma0(0.0, theta) > 1)
+
+
+def test_series_components_of_ssc_and_reverse_shock_models(eng, oracle):
+    """Model.flux_density returns FluxDict's components for a series too (pymodel.cpp:373-389): fwd.sync / fwd.ssc /
+    rvs.sync / rvs.ssc of paired (t, nu) points == the diagonal of the component grids, short and long (chunked) series,
+    and the exposure average keeps them apart."""
+    m = va.Model(va.TophatJet(0.1, 1e53, 300, duration=1000), va.ISM(1.0), va.Observer(3e28, 1.0, 0.05),
+                 va.Radiation(0.1, 1e-3, 2.3, ssc=True), rvs_rad=va.Radiation(0.1, 0.01, 2.5, ssc=True, kn=True))
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    t = np.logspace(2, 7, 20)
+    nu = np.tile([1e9, 1e14, 1e18, 1e24], 5)
+    f = m.flux_density(t, nu)
+    want = oracle.flux_components4(prm, t, np.array([1e9, 1e14, 1e18, 1e24]))  # [4 comps][nu][t]
+    pick = np.tile(np.arange(4), 5)
+    for got, w in zip((f.fwd.sync, f.fwd.ssc, f.rvs.sync, f.rvs.ssc), want):
+        assert got.shape == t.shape
+        assert_close(got, w[pick, np.arange(t.size)], rtol=5e-6)
+    assert np.allclose(f.total, f.fwd.sync + f.fwd.ssc + f.rvs.sync + f.rvs.ssc, rtol=1e-15)
+    assert_close(f.total, oracle.flux_density(prm, t, nu), rtol=5e-6)
+    # a forward-only model keeps the 0-d placeholders
+    plain = va.Model(va.TophatJet(0.1, 1e53, 300), va.ISM(1.0), va.Observer(3e28, 1.0, 0.05), va.Radiation(0.1, 1e-3, 2.3))
+    assert plain.flux_density(t, nu).rvs.sync.shape == () and plain.flux_density(t, nu).fwd.ssc.shape == ()
+    # long series: 700 sorted points go through the engine in chunks on one grid
+    tl = np.logspace(2, 7, 700)
+    nul = np.full(700, 1e14)
+    fl = m.flux_density(tl, nul)
+    wl = oracle.flux_components4(prm, tl, np.array([1e14]))
+    for got, w in zip((fl.fwd.sync, fl.fwd.ssc, fl.rvs.sync, fl.rvs.ssc), wl):
+        assert_close(got, w[0], rtol=5e-6)
+    fe = m.flux_density_exposures(t[:6], nu[:6], np.full(6, 50.0), 5)
+    assert fe.rvs.sync.shape == (6,) and np.all(fe.total > 0)
+    assert np.allclose(fe.total, fe.fwd.sync + fe.fwd.ssc + fe.rvs.sync + fe.rvs.ssc, rtol=1e-14)

@@ -95,7 +95,7 @@ EXPORTS = [
     "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
-    "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
+    "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
     "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
@@ -129,6 +129,7 @@ def load():
     lib.vag_flux_density_grid_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp]
     lib.vag_flux_density_grid_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
     lib.vag_flux_density_grid_components4_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.POINTER(_dp)]
+    lib.vag_flux_density_components4_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, C.POINTER(_dp)]
     lib.vag_flux_components4_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]
     lib.vag_flux_density_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, _dp]
     lib.vag_flux_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]

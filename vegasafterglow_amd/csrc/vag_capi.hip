@@ -1048,22 +1048,36 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
 
 // One chunk of a (t, nu) series for the batch: the sum of every enabled component -> d_out[nb][n].  The comoving band
 // of an SSC table spans ALL requested frequencies (d_lg2nu_all[n_all], pymodel.h:896-909), not only this chunk's.
+// One chunk of a (t, nu) series for the batch.  d_out (optional) [nb][n] receives the sum of every enabled component in
+// PyFlux::calc_total order; d_comp (optional) -> d_comp[i] != nullptr receives component i of {fwd.sync, fwd.ssc, rvs.sync,
+// rvs.ssc} [nb][n], zeros when that component is disabled.
 int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
-                 const double* d_lg2nu_all, int n_all, double* d_out, int n_bands = 0) {
+                 const double* d_lg2nu_all, int n_all, double* d_out, int n_bands = 0, double* const* d_comp = nullptr) {
     const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
+    const size_t n_out = (size_t)nb * n;
     int rc = VAG_OK;
     bool first = true;
-    for (int e = 0; e < n_em && rc == VAG_OK; ++e) {
-        select_emitter(c, e, d_params);
+    for (int e = 0; e < 2 && rc == VAG_OK; ++e) {
+        if (e < n_em) select_emitter(c, e, d_params);
         for (int pass = 0; pass < 2 && rc == VAG_OK; ++pass) {
-            if (pass == 1 && !c->cur_ssc) continue;
-            double* dst = d_out;
-            if (!first) {
-                if (c->d_ssc.ensure(sizeof(double) * (size_t)nb * n)) {
-                    rc = VAG_E_HIP;
-                    break;
+            double* dst_comp = d_comp ? d_comp[2 * e + pass] : nullptr;
+            const bool enabled = e < n_em && (pass == 0 || c->cur_ssc);
+            if (!enabled) {
+                if (dst_comp && hipMemsetAsync(dst_comp, 0, sizeof(double) * n_out, c->stream) != hipSuccess) rc = VAG_E_HIP;
+                continue;
+            }
+            double* dst = dst_comp;
+            if (!dst) {
+                if (!d_out) continue;  // nobody wants this component
+                if (first) {
+                    dst = d_out;
+                } else {
+                    if (c->d_ssc.ensure(sizeof(double) * n_out)) {
+                        rc = VAG_E_HIP;
+                        break;
+                    }
+                    dst = c->d_ssc.as<double>();
                 }
-                dst = c->d_ssc.as<double>();
             }
             if (pass == 0) {
                 rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN, n_bands);
@@ -1073,8 +1087,12 @@ int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
                 if (rc == VAG_OK) rc = check_ic_status(c, nb);
             }
             if (rc) break;
-            if (!first) {
-                hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_out, dst, (size_t)nb * n);
+            if (d_out) {
+                if (first) {
+                    if (dst != d_out) hipLaunchKernelGGL(vag_copy_kernel, dim3(256), dim3(256), 0, c->stream, d_out, dst, n_out);
+                } else {
+                    hipLaunchKernelGGL(vag_add_kernel, dim3(256), dim3(256), 0, c->stream, d_out, dst, n_out);
+                }
                 if (hipGetLastError() != hipSuccess) rc = VAG_E_HIP;
             }
             first = false;
@@ -1294,6 +1312,61 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     c->pending_bands = 0;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, c->d_out.p, sizeof(double) * (size_t)nb * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)collect_times(c);
+    return check_status(c, nb);
+}
+
+// Model.flux_density with its components apart (FluxDict.fwd / .rvs of a series, pymodel.cpp:373-389): out4[i] != NULL
+// receives component i of {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} [nb][n]; disabled components come back as zeros.
+int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu,
+                                       int n, double* const* out4) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
+    int rc = check_host_inputs(params, nb, t, n);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n_out = (size_t)nb * n;
+    if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
+    if (c->d_t.ensure(sizeof(double) * n)) return VAG_E_HIP;
+    if (c->d_nu.ensure(sizeof(double) * n)) return VAG_E_HIP;
+    if (c->d_comp.ensure(sizeof(double) * 4 * n_out)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_params.p, params, sizeof(vag_model_params) * nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_t.p, t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nu.p, nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    const int n_bands = upload_series_bands(c, nu, n);
+    rc = prep_times(c, c->d_t.as<double>(), n, c->d_nu.as<double>(), n);  // the grid sees the extrema of ALL requested times
+    if (rc) return rc;
+    rc = run_model_stages(c, c->d_params.as<vag_model_params>(), nb, false);
+    if (rc) return rc;
+    double* d4[4];
+    for (int i = 0; i < 4; ++i) d4[i] = out4[i] ? c->d_comp.as<double>() + (size_t)i * n_out : nullptr;
+    const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
+    if (n <= chunk) {
+        rc = series_chunk(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n,
+                          c->d_lg2nu.as<double>(), n, nullptr, n_bands, d4);
+        if (rc) return rc;
+    } else {  // long series (exposure sampling): chunks of sorted points on the same grid
+        DevBuf tmp;
+        if (tmp.ensure(sizeof(double) * 4 * (size_t)nb * chunk)) return VAG_E_HIP;
+        for (int s0 = 0; s0 < n && rc == VAG_OK; s0 += chunk) {
+            const int mlen = std::min(chunk, n - s0);
+            double* t4[4];
+            for (int i = 0; i < 4; ++i) t4[i] = d4[i] ? tmp.as<double>() + (size_t)i * nb * chunk : nullptr;
+            rc = series_chunk(c, c->d_params.as<vag_model_params>(), nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0,
+                              mlen, c->d_lg2nu.as<double>(), n, nullptr, 0, t4);
+            for (int i = 0; i < 4 && rc == VAG_OK; ++i)
+                if (d4[i] && hipMemcpy2DAsync(d4[i] + s0, sizeof(double) * n, t4[i], sizeof(double) * mlen, sizeof(double) * mlen,
+                                              (size_t)nb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                    rc = VAG_E_HIP;
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        tmp.release();
+        if (rc) return rc;
+        if (e != hipSuccess) return set_err(VAG_E_HIP, "series components: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i)
+        if (out4[i]) HIPCHK(hipMemcpyAsync(out4[i], d4[i], sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)collect_times(c);
     return check_status(c, nb);

@@ -367,6 +367,12 @@ class Model:
                                 "output, use the generic `flux_density_grid` instead")
         out = np.empty(t.size)
         h, lock = get_context(self._device)
+        if self._has_components():
+            comps, arr = self._component_buffers((t.size,))
+            with lock:
+                _lib.check(_lib.load().vag_flux_density_components4_batch(
+                    h, C.byref(self.params), 1, t.ctypes.data_as(_dp), nu.ctypes.data_as(_dp), t.size, arr))
+            return FluxDict(*comps)
         with lock:
             _lib.check(_lib.load().vag_flux_density_batch(
                 h, C.byref(self.params), 1, t.ctypes.data_as(_dp), nu.ctypes.data_as(_dp), t.size,
@@ -427,10 +433,16 @@ class Model:
         nu_s = np.repeat(nu, num_points)
         idx = np.repeat(np.arange(t.size), num_points)
         order = np.argsort(t_s, kind="stable")
-        series = self.flux_density(t_s[order], nu_s[order]).total
-        summed = np.zeros(t.size)
-        np.add.at(summed, idx[order], series)                        # average_exposure_flux, pymodel.cpp:452-470
-        return FluxDict(summed / float(num_points))
+        series = self.flux_density(t_s[order], nu_s[order])
+
+        def avg(a):                                                  # average_exposure_flux, pymodel.cpp:452-470
+            if np.ndim(a) == 0:
+                return None                                          # disabled component
+            summed = np.zeros(t.size)
+            np.add.at(summed, idx[order], a)
+            return summed / float(num_points)
+
+        return FluxDict(avg(series.fwd.sync), avg(series.fwd.ssc), avg(series.rvs.sync), avg(series.rvs.ssc))
 
     # -- Model.details (shock part): pybind.cpp:448, pymodel.cpp:315-348 --
     def details(self, t_min, t_max, rvs=False):
