@@ -993,3 +993,42 @@ def test_series_components_of_ssc_and_reverse_shock_models(eng, oracle):
     fe = m.flux_density_exposures(t[:6], nu[:6], np.full(6, 50.0), 5)
     assert fe.rvs.sync.shape == (6,) and np.all(fe.total > 0)
     assert np.allclose(fe.total, fe.fwd.sync + fe.fwd.ssc + fe.rvs.sync + fe.rvs.ssc, rtol=1e-14)
+
+
+# ---- degenerate observation windows (tests/python/test_features.py:148-240): every time-lattice construction path ----
+_GRID_PATHS = {
+    "fwd_ism": dict(medium=("ism", 0.1), rvs=False, theta_obs=0.0),
+    "fwd_wind": dict(medium=("wind", 0.1), rvs=False, theta_obs=0.0),
+    "fwd_offaxis": dict(medium=("ism", 0.1), rvs=False, theta_obs=0.3),
+    "rvs_ism": dict(medium=("ism", 0.1), rvs=True, theta_obs=0.0),
+    "rvs_wind": dict(medium=("wind", 0.1), rvs=True, theta_obs=0.0),
+}
+_WINDOWS = [[10.0], [1e6], [10.0, 11.0], [1e3, 1.1e3], [1e6, 1.1e6]]
+
+
+@pytest.mark.parametrize("path", sorted(_GRID_PATHS))
+def test_degenerate_windows_all_grid_paths(eng, oracle, path):
+    cfg = _GRID_PATHS[path]
+    kind, value = cfg["medium"]
+    medium = va.ISM(value) if kind == "ism" else va.Wind(value)
+    rad = va.Radiation(0.1, 0.01, 2.3)
+    m = va.Model(va.TophatJet(0.1, 1e52, 300, duration=1.0), medium, va.Observer(1e26, 0.1, cfg["theta_obs"]), rad,
+                 rvs_rad=va.Radiation(0.1, 0.01, 2.3) if cfg["rvs"] else None)
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    for window in _WINDOWS:
+        t = np.array(window)
+        total = m.flux_density_grid(t, np.array([1e14])).total
+        assert np.all(np.isfinite(total)) and np.all(total > 0), (path, window)
+        assert_close(total, oracle.flux_density_grid(prm, t, np.array([1e14])), rtol=5e-6)
+
+
+def test_single_epochs_and_eat_nodes(eng, oracle):
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(0.1), va.Observer(1e26, 0.1, 0.0), va.Radiation(0.1, 0.5, 2.5))
+    prm = _abi.ModelParams.from_buffer_copy(bytes(m.params))
+    for t in np.logspace(0, 7, 15):
+        total = m.flux_density_grid(np.array([t]), np.array([1e14, 1e17])).total
+        assert np.all(total > 0), f"zero flux at single epoch t={t:g}s"
+        assert_close(total, oracle.flux_density_grid(prm, np.array([t]), np.array([1e14, 1e17])), rtol=5e-6)
+    for t_min, t_max in [(1.0, 2.0), (9.0, 11.0), (5.0, 1e3), (1e4, 1e6)]:
+        d = m.details(t_min, t_max)
+        assert np.all(np.isfinite(d["t_obs"])) and np.all(np.isfinite(d["Doppler"])) and np.all(d["Doppler"] > 0)
