@@ -269,3 +269,12 @@ def test_fitter_add_spectrum_and_validate_parameters():
                 [P("A_V", 0.0, 1.0, S.linear)]):                                       # no extinction law configured
         with pytest.raises(ValueError):
             f.validate_parameters(bad)
+
+
+def test_reprs_follow_the_reference_format():
+    """__repr__ of the value classes (pymodel.h:55-58,262-272,316-334)."""
+    assert repr(va.Observer(1e28, 1.0, 0.0)) == "Observer(lumi_dist=1e+28, z=1, theta_obs=0)"
+    assert repr(va.Observer(1e28, 1.0, 0.1, 0.5)) == "Observer(lumi_dist=1e+28, z=1, theta_obs=0.1, phi_obs=0.5)"
+    assert repr(va.Radiation(0.1, 0.01, 2.2)) == "Radiation(eps_e=0.1, eps_B=0.01, p=2.2)"
+    assert repr(va.Radiation(0.1, 0.01, 2.2, xi_e=0.5, ssc=True, kn=True)) == "Radiation(eps_e=0.1, eps_B=0.01, p=2.2, xi_e=0.5, ssc=True, kn=True)"
+    assert "Magnetar(L0=1e+47" in repr(va.Magnetar(1e47, 1e3, 2))

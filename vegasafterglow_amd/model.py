@@ -201,6 +201,10 @@ class Observer:
         _req(math.isfinite(phi_obs), f"phi_obs must be finite, got {phi_obs}")
         self.lumi_dist, self.z, self.theta_obs, self.phi_obs = float(lumi_dist), float(z), float(theta_obs), float(phi_obs)
 
+    def __repr__(self):  # pymodel.h:262-272
+        extra = f", phi_obs={self.phi_obs:.6g}" if self.phi_obs != 0 else ""
+        return f"Observer(lumi_dist={self.lumi_dist:.6g}, z={self.z:.6g}, theta_obs={self.theta_obs:.6g}{extra})"
+
 
 class Radiation:
     """Radiation(eps_e, eps_B, p, xi_e=1, ssc=False, kn=False) -- pybind.cpp:368-377, pymodel.h:241-260."""
@@ -210,6 +214,12 @@ class Radiation:
             _req(math.isfinite(x) and 0 < x <= 1, f"{name} must be in (0, 1], got {x}")
         _req(math.isfinite(p) and p > 1, f"p must be > 1, got {p}")
         self.eps_e, self.eps_B, self.p, self.xi_e, self.ssc, self.kn = float(eps_e), float(eps_B), float(p), float(xi_e), bool(ssc), bool(kn)
+
+    def __repr__(self):  # pymodel.h:316-334
+        s = f"Radiation(eps_e={self.eps_e:.6g}, eps_B={self.eps_B:.6g}, p={self.p:.6g}"
+        if self.xi_e != 1:
+            s += f", xi_e={self.xi_e:.6g}"
+        return s + (", ssc=True" if self.ssc else "") + (", kn=True" if self.kn else "") + ")"
 
 
 class Flux:
