@@ -278,3 +278,34 @@ def test_reprs_follow_the_reference_format():
     assert repr(va.Radiation(0.1, 0.01, 2.2)) == "Radiation(eps_e=0.1, eps_B=0.01, p=2.2)"
     assert repr(va.Radiation(0.1, 0.01, 2.2, xi_e=0.5, ssc=True, kn=True)) == "Radiation(eps_e=0.1, eps_B=0.01, p=2.2, xi_e=0.5, ssc=True, kn=True)"
     assert "Magnetar(L0=1e+47" in repr(va.Magnetar(1e47, 1e3, 2))
+
+
+def test_fitter_observation_validation_rules():
+    """The add_* boundary checks of the reference Fitter (fitter.py:212-282,316-377): clear ValueErrors for empty data, shape
+    mismatches, non-finite fluxes, non-positive errors, bad weights, bad frequencies and bad bands."""
+    f = fitting.Fitter(z=0.5, lumi_dist=1e28)
+    t, fl, er = np.array([1e3, 1e4, 1e5]), np.array([1e-26, 5e-27, 1e-27]), np.array([1e-27, 5e-28, 1e-28])
+    f.add_flux_density(4.84e14, t, fl, er, weights=[1.0, 0.5, 0.0], label="r")
+    for bad_nu in (0, -1e14, np.nan, np.inf):
+        with pytest.raises(ValueError, match="nu must be finite and > 0"):
+            f.add_flux_density(bad_nu, t, fl, er)
+    with pytest.raises(ValueError, match="same shape"):
+        f.add_flux_density(1e14, t, fl[:2], er)
+    with pytest.raises(ValueError, match="empty"):
+        f.add_flux_density(1e14, [], [], [])
+    with pytest.raises(ValueError, match="non-finite"):
+        f.add_flux_density(1e14, t, np.array([1e-26, np.nan, 1e-27]), er)
+    for bad_err in ([1e-27, 0.0, 1e-28], [1e-27, -1e-28, 1e-28], [1e-27, np.nan, 1e-28], [1e-27, np.inf, 1e-28]):
+        with pytest.raises(ValueError, match="err must be finite and > 0"):
+            f.add_flux_density(1e14, t, fl, np.array(bad_err))
+    with pytest.raises(ValueError, match="weights.shape"):
+        f.add_flux_density(1e14, t, fl, er, weights=[1.0, 1.0])
+    with pytest.raises(ValueError, match="weights must be finite and >= 0"):
+        f.add_flux_density(1e14, t, fl, er, weights=[1.0, -1.0, 1.0])
+    with pytest.raises(ValueError, match="same shape"):
+        f.add_flux((1e17, 1e18), t, fl[:2], er)
+    for bad_band in (1e17, (1e17,), (1e18, 1e17), (0.0, 1e17), (1e17, np.inf)):
+        with pytest.raises(ValueError):
+            f.add_flux(bad_band, t, fl, er)
+    with pytest.raises(ValueError, match="num_points"):
+        f.add_flux((1e17, 1e18), t, fl, er, num_points=1)

@@ -83,30 +83,58 @@ class Fitter:
         self._ext_kernel = None
         self._all_t = None
 
-    # fitter.py add_flux_density
-    def add_flux_density(self, nu, t, f_nu, err, weights=None):
-        t = np.asarray(t, dtype=np.float64)
-        f_nu = np.asarray(f_nu, dtype=np.float64)
-        err = np.asarray(err, dtype=np.float64)
+    @staticmethod
+    def _checked_observations(t, f_nu, err, weights, who):
+        """The boundary checks of every add_* method (fitter.py:212-254): same shapes, non-empty, finite fluxes, finite
+        positive errors, finite non-negative weights.  Returns float64 arrays (weights default to ones)."""
+        t, f_nu, err = (np.asarray(a, dtype=np.float64) for a in (t, f_nu, err))
+        if t.size == 0:
+            raise ValueError(f"{who}: time array is empty")
         if not (t.shape == f_nu.shape == err.shape):
-            raise ValueError("t, f_nu and err must have the same shape")
-        w = np.ones_like(t) if weights is None else np.asarray(weights, dtype=np.float64)
+            raise ValueError(f"{who}: t, f_nu, err must have the same shape; got t.shape={t.shape}, "
+                             f"f_nu.shape={f_nu.shape}, err.shape={err.shape}")
+        if not np.isfinite(f_nu).all():
+            raise ValueError(f"{who}: f_nu contains {int((~np.isfinite(f_nu)).sum())} non-finite (NaN or inf) values")
+        if not np.isfinite(err).all() or (err <= 0).any():
+            raise ValueError(f"{who}: err must be finite and > 0 at every point (got min={float(err.min())}, "
+                             f"max={float(err.max())})")
+        if weights is None:
+            w = np.ones_like(t)
+        else:
+            w = np.asarray(weights, dtype=np.float64)
+            if w.shape != t.shape:
+                raise ValueError(f"{who}: weights.shape={w.shape} must match t.shape={t.shape}")
+            if not np.isfinite(w).all() or (w < 0).any():
+                raise ValueError(f"{who}: weights must be finite and >= 0 at every point")
+        return t, f_nu, err, w
+
+    def _add_points(self, t, nu, f_nu, err, w):
         self._point_t.append(t)
-        self._point_nu.append(np.full_like(t, float(nu)) if np.ndim(nu) == 0 else np.asarray(nu, dtype=np.float64))
+        self._point_nu.append(nu)
         self._point_flux.append(f_nu)
         self._point_err.append(err)
         self._point_weights.append(w)
         self._all_t = None
 
+    # fitter.py:256-282
+    def add_flux_density(self, nu, t, f_nu, err, weights=None, label=None):
+        """Light-curve data at one frequency nu [Hz] (`label` is accepted for API compatibility; it only names plot legends)."""
+        if np.ndim(nu) != 0 or not np.isfinite(nu) or nu <= 0:
+            raise ValueError(f"add_flux_density: nu must be finite and > 0, got {nu}")
+        t, f_nu, err, w = self._checked_observations(t, f_nu, err, weights, "add_flux_density")
+        self._add_points(t, np.full_like(t, float(nu)), f_nu, err, w)
+
     # fitter.py:284-314
     def add_spectrum(self, t, nu, f_nu, err, weights=None):
         """A broadband spectrum at one time t [s]: one point-data row per frequency."""
-        if not np.isfinite(t) or t <= 0:
+        if np.ndim(t) != 0 or not np.isfinite(t) or t <= 0:
             raise ValueError(f"add_spectrum: t must be finite and > 0, got {t}")
         nu = np.asarray(nu, dtype=np.float64)
-        if nu.size == 0 or not np.isfinite(nu).all() or (nu <= 0).any():
-            raise ValueError("add_spectrum: nu must be non-empty, finite and > 0 at every point")
-        self.add_flux_density(nu, np.full_like(nu, float(t)), f_nu, err, weights)
+        if nu.size and (not np.isfinite(nu).all() or (nu <= 0).any()):
+            raise ValueError(f"add_spectrum: nu must be finite and > 0 at every point (got min={float(nu.min())}, "
+                             f"max={float(nu.max())})")
+        nu, f_nu, err, w = self._checked_observations(nu, f_nu, err, weights, "add_spectrum")  # nu is the axis array here
+        self._add_points(np.full_like(nu, float(t)), nu, f_nu, err, w)
 
     # fitter.py:316-377
     def add_flux(self, band, t, flux, err, num_points=5, weights=None):
@@ -120,12 +148,11 @@ class Fitter:
                              f"nu_max={nu_max}")
         if num_points < 2:
             raise ValueError(f"add_flux: num_points must be >= 2 for band integration, got {num_points}")
-        t, flux, err = (np.asarray(a, dtype=np.float64) for a in (t, flux, err))
-        if not (t.shape == flux.shape == err.shape) or t.ndim != 1 or t.size == 0:
-            raise ValueError("add_flux: t, flux and err must be non-empty 1-D arrays of the same length")
-        if np.any(flux <= 0) or np.any(err <= 0):
-            raise ValueError("the log-flux likelihood requires strictly positive fluxes and errors")
-        w = np.ones_like(t) if weights is None else np.asarray(weights, dtype=np.float64)
+        t, flux, err, w = self._checked_observations(t, flux, err, weights, "add_flux")
+        if t.ndim != 1:
+            raise ValueError("add_flux: t, flux and err must be 1-D arrays")
+        if np.any(flux <= 0):
+            raise ValueError("add_flux: the log-flux likelihood requires strictly positive fluxes")
         order = np.argsort(t)
         self._band_obs.append(dict(nu_min=float(nu_min), nu_max=float(nu_max), num_points=int(num_points),
                                    t=np.ascontiguousarray(t[order]), ln_flux=np.ascontiguousarray(np.log(flux[order])),
