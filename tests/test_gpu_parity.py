@@ -1032,3 +1032,19 @@ def test_single_epochs_and_eat_nodes(eng, oracle):
     for t_min, t_max in [(1.0, 2.0), (9.0, 11.0), (5.0, 1e3), (1e4, 1e6)]:
         d = m.details(t_min, t_max)
         assert np.all(np.isfinite(d["t_obs"])) and np.all(np.isfinite(d["Doppler"])) and np.all(d["Doppler"] > 0)
+
+
+def test_details_object_matches_reference_layout(eng):
+    """Model.details() is used like the reference's SimulationDetails (tests/python/test_features.py:100-110,
+    test_advanced.py, test_parameter_corners.py:166-177): .fwd / .rvs ShockDetails with 3-D arrays."""
+    m = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.2),
+                 rvs_rad=va.Radiation(0.1, 0.01, 2.2))
+    det = m.details(t_min=1e2, t_max=1e5)
+    nth, nt = det["Gamma"].shape
+    assert det.rvs is not None and det.rvs.Gamma.size > 0 and det.fwd.Gamma.shape == det.rvs.Gamma.shape == (1, nth, nt)
+    assert det.t_src.shape == (1, nth, nt) and det.phi.ndim == 1 and det.theta.shape == (nth,)
+    assert np.all(det.fwd.Gamma >= 1) and np.all(det.fwd.r > 0) and np.all(np.isfinite(det.fwd.t_obs))
+    assert det.fwd.t_obs.shape[1:] == (nth, nt) and np.array_equal(det.fwd.t_obs, det.rvs.t_obs)  # one contact discontinuity
+    assert np.array_equal(det.fwd.B_comv[0], det["B"]) and np.array_equal(det.rvs.Gamma[0], m.details(1e2, 1e5, rvs=True)["Gamma"])
+    plain = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.2))
+    assert plain.details(1e2, 1e5).rvs is None

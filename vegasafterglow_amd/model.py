@@ -230,6 +230,29 @@ class Flux:
         self.ssc = np.zeros(()) if ssc is None else ssc
 
 
+class ShockDetails:
+    """One shock of Model.details() with the reference's attribute names and array ranks (pybind.cpp:522-576)."""
+
+    _MAP = {"t_comv": "t_comv", "r": "r", "theta": "theta_cell", "Gamma": "Gamma", "Gamma_th": "Gamma_th", "B_comv": "B",
+            "N_p": "N_p", "gamma_m": "gamma_m", "gamma_c": "gamma_c", "gamma_a": "gamma_a", "gamma_M": "gamma_M", "N_e": "N_e",
+            "nu_m": "nu_m", "nu_c": "nu_c", "nu_a": "nu_a", "nu_M": "nu_M", "I_nu_max": "I_nu_max"}
+
+    def __init__(self, d):
+        for attr, key in self._MAP.items():
+            setattr(self, attr, d[key][None, :, :])
+        self.t_obs, self.Doppler = d["t_obs"], d["Doppler"]
+
+    def __repr__(self):
+        return f"ShockDetails(shape={self.Gamma.shape})"
+
+
+class SimulationDetails(dict):
+    """Model.details(): attribute access like the reference's SimulationDetails, dict access to one shock's 2-D arrays."""
+
+    def __repr__(self):
+        return f"SimulationDetails(phi={self['phi'].size}, theta={self['theta'].size}, t_src={self['t_src'].shape[-1]})"
+
+
 class FluxDict:
     """FluxDict{total, fwd, rvs} (pybind.cpp:478-483, pymodel.cpp:350-364)."""
 
@@ -456,7 +479,21 @@ class Model:
 
     # -- Model.details (shock part): pybind.cpp:448, pymodel.cpp:315-348 --
     def details(self, t_min, t_max, rvs=False):
-        """Shock arrays of the forward shock, or with rvs=True of the reverse shock (Model.details().rvs)."""
+        """Model.details(t_min, t_max) (pybind.cpp:448,522-584): the returned object is used like the reference's
+        SimulationDetails -- `.phi`, `.theta`, `.t_src`, `.fwd` and `.rvs` (ShockDetails with t_comv, r, theta, Gamma,
+        Gamma_th, B_comv, N_p, gamma_m/c/a/M, N_e, nu_m/c/a/M, I_nu_max as (1, n_theta, n_t) arrays -- one solved phi
+        slice -- and t_obs, Doppler as (n_phi_eff, n_theta, n_t)); `.rvs` is None without rvs_rad.  It is also a dict of
+        the 2-D [n_theta][n_t] arrays of one shock (the forward one, or with rvs=True the reverse one)."""
+        d = SimulationDetails(self._details_of(t_min, t_max, rvs))
+        fwd = d if not rvs else self._details_of(t_min, t_max, False)
+        d.fwd = ShockDetails(fwd)
+        d.rvs = None
+        if self.rvs_rad is not None:
+            d.rvs = ShockDetails(d if rvs else self._details_of(t_min, t_max, True))
+        d.phi, d.theta, d.t_src = fwd["phi"], fwd["theta"], fwd["t_src"][None, :, :]
+        return d
+
+    def _details_of(self, t_min, t_max, rvs):
         lib = _lib.load()
         h, lock = get_context(self._device)
         sh = _lib.DetailsShape()
