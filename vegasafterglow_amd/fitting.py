@@ -119,10 +119,13 @@ class Fitter:
     # fitter.py:256-282
     def add_flux_density(self, nu, t, f_nu, err, weights=None, label=None):
         """Light-curve data at one frequency nu [Hz] (`label` is accepted for API compatibility; it only names plot legends)."""
-        if np.ndim(nu) != 0 or not np.isfinite(nu) or nu <= 0:
+        nu_arr = np.asarray(nu, dtype=np.float64)
+        if not np.isfinite(nu_arr).all() or (nu_arr <= 0).any():
             raise ValueError(f"add_flux_density: nu must be finite and > 0, got {nu}")
         t, f_nu, err, w = self._checked_observations(t, f_nu, err, weights, "add_flux_density")
-        self._add_points(t, np.full_like(t, float(nu)), f_nu, err, w)
+        if nu_arr.ndim != 0 and nu_arr.shape != t.shape:  # extension: one frequency per point
+            raise ValueError(f"add_flux_density: an array nu must have the shape of t, got {nu_arr.shape} vs {t.shape}")
+        self._add_points(t, np.full_like(t, float(nu_arr)) if nu_arr.ndim == 0 else nu_arr.copy(), f_nu, err, w)
 
     # fitter.py:284-314
     def add_spectrum(self, t, nu, f_nu, err, weights=None):
