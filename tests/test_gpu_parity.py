@@ -1048,3 +1048,41 @@ def test_details_object_matches_reference_layout(eng):
     assert np.array_equal(det.fwd.B_comv[0], det["B"]) and np.array_equal(det.rvs.Gamma[0], m.details(1e2, 1e5, rvs=True)["Gamma"])
     plain = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.0), va.Radiation(0.1, 0.01, 2.2))
     assert plain.details(1e2, 1e5).rvs is None
+
+
+def test_series_components_batch_equals_single_calls(eng):
+    """vag_flux_density_components4_batch on a ragged batch == one call per model, bitwise, short and chunked series."""
+    lib, h = eng
+    kws = [dict(theta_obs=0.05, duration=1000.0, ssc=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.5, ssc=True)),
+           dict(jet="GaussianJet", theta_obs=0.2, duration=10.0, ssc=True, rvs=dict(eps_e=0.05, eps_B=0.02, p=2.3, ssc=True)),
+           dict(theta_obs=0.0, E_iso=1e53, duration=300.0, ssc=True, rvs=dict(eps_e=0.2, eps_B=0.005, p=2.2, ssc=True))]
+    prms = [_abi.make_params(**kw) for kw in kws]
+
+    def run(ps, t, nu):
+        arr = (_lib.ModelParams * len(ps))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in ps])
+        comps = [np.empty((len(ps), t.size)) for _ in range(4)]
+        out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+        _lib.check(lib.vag_flux_density_components4_batch(h, arr, len(ps), t.ctypes.data_as(dp), nu.ctypes.data_as(dp), t.size, out4))
+        return comps
+
+    for n in (30, 600):
+        t = np.logspace(2, 7, n)
+        nu = np.tile([1e9, 1e14, 1e18], n // 3)
+        batch = run(prms, t, nu)
+        for i, p in enumerate(prms):
+            one = run([p], t, nu)
+            assert all(np.array_equal(batch[c][i], one[c][0]) for c in range(4))
+        assert all(np.all(np.isfinite(c)) for c in batch) and batch[2].max() > 0 and batch[3].max() > 0
+
+
+def test_series_on_long_lattices_uses_fewer_wavefronts_per_workgroup(eng, oracle):
+    """Long time lattices (t_resol = 25: K ~ 250) with SSC: the series kernel's private rows no longer fit four times into
+    LDS, so the launch falls back to two or one wavefront per workgroup instead of failing."""
+    for kw in (dict(jet="GaussianJet", theta_obs=0.2, ssc=True, resolutions=(0.1, 0.2, 25.0)),
+               dict(theta_obs=0.05, duration=1000.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.5), resolutions=(0.1, 0.2, 25.0))):
+        prm = _abi.make_params(**kw)
+        t = np.logspace(2, 7.5, 45)
+        nu = np.tile([1e9, 4.84e14, 1e18], 15)
+        assert_close(gpu_series(eng, prm, t, nu)[0], oracle.flux_density(prm, t, nu), rtol=5e-6)
+        tl = np.logspace(2, 7.5, 300)
+        assert_close(gpu_series(eng, prm, tl, np.full(300, 1e14))[0], oracle.flux_density(prm, tl, np.full(300, 1e14)), rtol=5e-6)

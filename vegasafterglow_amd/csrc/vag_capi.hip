@@ -984,8 +984,15 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
     if (n > SERIES_THREADS) n_bands = 0;  // the shared-node path keeps one point per lane
-    const size_t lds = sizeof(double) * ((size_t)SERIES_WAVES * series_region_doubles(ks, mode == FLUX_SYN_IC, n_bands) + SP_LDS_DOUBLES + SERIES_MAX_BANDS);
-    const dim3 sgrid((max_blocks + SERIES_WAVES - 1) / SERIES_WAVES, nb), sblock(SERIES_THREADS * SERIES_WAVES);
+    // wavefronts per workgroup: four when their private rows fit next to the shared tables, else two or one
+    int waves = SERIES_WAVES;
+    auto lds_for = [&](int w) {
+        return sizeof(double) * ((size_t)w * series_region_doubles(ks, mode == FLUX_SYN_IC, n_bands) + SP_LDS_DOUBLES + SERIES_MAX_BANDS);
+    };
+    while (waves > 1 && lds_for(waves) > 160 * 1024) waves >>= 1;
+    const size_t lds = lds_for(waves);
+    if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d)", lds, ks);
+    const dim3 sgrid((max_blocks + waves - 1) / waves, nb), sblock(SERIES_THREADS * waves);
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();

@@ -828,7 +828,7 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 // not values.  Output partial[m][block][n].
 // ------------------------------------------------------------------------------------------------
 constexpr int SERIES_THREADS = 64;    // lanes that share one (theta, phi) row: ONE wavefront, so rows need no block barrier
-constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup; they only share the softplus table in LDS
+constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup (fewer when long lattices need the LDS); they only share the tables
 constexpr int SERIES_MAX_SLOTS = 8;   // data points per lane: n <= 512
 constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
@@ -912,11 +912,11 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int KS = a.k_stride;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;
-    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += SERIES_THREADS * SERIES_WAVES) s_sp[i] = a.sp_table[i];
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     double* s_band = s_sp + SP_LDS_DOUBLES;  // [SERIES_MAX_BANDS] log2 nu of the fit's bands (shared-node path)
     if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]];
     __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
-    const int vb = blockIdx.x * SERIES_WAVES + wave;  // virtual block = wavefront
+    const int vb = blockIdx.x * (blockDim.x >> 6) + wave;  // virtual block = wavefront (the host launches 4, 2 or 1 per workgroup)
     if (vb >= a.max_blocks) return;
     const VagGridMeta M = a.meta[m];
     double* my_partial = a.partial + ((size_t)m * a.max_blocks + vb) * a.n;
