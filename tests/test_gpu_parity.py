@@ -1086,3 +1086,26 @@ def test_series_on_long_lattices_uses_fewer_wavefronts_per_workgroup(eng, oracle
         assert_close(gpu_series(eng, prm, t, nu)[0], oracle.flux_density(prm, t, nu), rtol=5e-6)
         tl = np.logspace(2, 7.5, 300)
         assert_close(gpu_series(eng, prm, tl, np.full(300, 1e14))[0], oracle.flux_density(prm, tl, np.full(300, 1e14)), rtol=5e-6)
+
+
+def test_long_time_axes_are_chunked_for_every_request_kind(eng, oracle):
+    """nt * nnu beyond one launch's accumulator (and long lattices): total grids, component grids and band fluxes are
+    computed in time chunks on ONE model grid and assembled; each equals the checker's un-chunked answer."""
+    lib, h = eng
+    prm = _abi.make_params(theta_obs=0.05, duration=300.0, ssc=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.4, ssc=True))
+    t = np.logspace(2, 7.5, 700)
+    nu = np.logspace(9, 19, 8)
+    got = gpu_components4(eng, prm, t, nu)
+    want = oracle.flux_components4(prm, t, nu)
+    for c in range(4):
+        assert_close(got[c][0], want[c], rtol=5e-6)
+    assert_close(gpu_grid(eng, prm, t, nu)[0], sum(want), rtol=5e-6)
+    tb = np.logspace(2, 7.5, 500)
+    band = np.empty((1, tb.size))
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    _lib.check(lib.vag_flux_batch(h, arr, 1, tb.ctypes.data_as(dp), tb.size, 1e17, 1e19, 17, band.ctypes.data_as(dp)))
+    assert_close(band[0], oracle.flux(prm, tb, 1e17, 1e19, 17), rtol=5e-6)
+    # a long lattice (t_resol 40 -> K ~ 390) with 16 frequencies: the chunk shrinks until the workgroup's LDS fits
+    big = _abi.make_params(jet="GaussianJet", theta_obs=0.25, resolutions=(0.15, 0.5, 40.0))
+    tg, nug = np.logspace(2, 8, 300), np.logspace(9, 19, 16)
+    assert_close(gpu_grid(eng, big, tg, nug)[0], oracle.flux_density_grid(big, tg, nug), rtol=5e-6)

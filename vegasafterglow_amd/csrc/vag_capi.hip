@@ -955,6 +955,40 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
     return rc;
 }
 
+// grid_request with the time axis cut into chunks whose (nu, t) accumulator and boundary values fit the workgroup's LDS
+// (<= 4096 slots, and fewer when the lattice is long): outputs are assembled into [nb][rows][nt], rows = nnu (1 for a band).
+int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw,
+                         double* d_total, double* const* d_comp) {
+    const bool any_ssc = (c->batch_flags & (VAG_FLAG_SSC | VAG_FLAG_RVS_SSC)) != 0;
+    int chunk = std::max(1, 4096 / nnu);
+    while (chunk > 8 && flux_grid_lds_bytes(any_ssc ? FLUX_SYN_IC : FLUX_SYN, c->max_k, std::min(chunk, nt), nnu) > 160 * 1024)
+        chunk >>= 1;
+    if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, d_bandw, d_total, d_comp);
+    const size_t rows = (size_t)nb * (d_bandw ? 1 : nnu);
+    DevBuf tmp;
+    if (tmp.ensure(sizeof(double) * 5 * rows * chunk)) return VAG_E_HIP;
+    double* t_total = d_total ? tmp.as<double>() : nullptr;
+    double* t_comp[4];
+    for (int i = 0; i < 4; ++i) t_comp[i] = (d_comp && d_comp[i]) ? tmp.as<double>() + (size_t)(i + 1) * rows * chunk : nullptr;
+    int rc = VAG_OK;
+    for (int t0 = 0; t0 < nt && rc == VAG_OK; t0 += chunk) {
+        const int n = std::min(chunk, nt - t0);
+        rc = grid_request(c, d_params, nb, n, nnu, d_bandw, t_total, d_comp ? t_comp : nullptr, t0);
+        auto put = [&](double* dst, const double* src) {
+            if (rc == VAG_OK && dst &&
+                hipMemcpy2DAsync(dst + t0, sizeof(double) * nt, src, sizeof(double) * n, sizeof(double) * n, rows,
+                                 hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                rc = VAG_E_HIP;
+        };
+        put(d_total, t_total);
+        for (int i = 0; i < 4; ++i) put(d_comp ? d_comp[i] : nullptr, t_comp[i]);
+    }
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    if (rc == VAG_OK && e != hipSuccess) return set_err(VAG_E_HIP, "chunked grid request: %s", hipGetErrorString(e));
+    return rc;
+}
+
 __global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                                          const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
                                          double* __restrict__ out) {
@@ -1182,22 +1216,7 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    // chunk the time axis so each launch keeps its (idx, l) slots in registers
-    const int chunk = std::max(1, 4096 / nnu);  // keeps the LDS accumulator <= 32 KiB
-    if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
-    // chunks write [nb][nnu][chunk] blocks (every enabled component summed); assemble into [nb][nnu][nt]
-    DevBuf tmp;
-    if (tmp.ensure(sizeof(double) * (size_t)nb * nnu * chunk)) return VAG_E_HIP;
-    for (int t0 = 0; t0 < nt; t0 += chunk) {
-        const int n = std::min(chunk, nt - t0);
-        rc = grid_request(c, d_params, nb, n, nnu, nullptr, tmp.as<double>(), nullptr, t0);
-        if (rc) break;
-        HIPCHK(hipMemcpy2DAsync(d_out + t0, sizeof(double) * nt, tmp.p, sizeof(double) * n, sizeof(double) * n,
-                                (size_t)nb * nnu, hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    tmp.release();
-    return rc;
+    return grid_request_chunked(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
 }
 
 static int upload_series_bands(vag_ctx* c, const double* nu, int n);
@@ -1263,7 +1282,6 @@ static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int 
     if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
-    if ((long long)nt * nnu > 4096) return set_err(VAG_E_CAPACITY, "component requests need nt * nnu <= 4096 per call");
     HIPCHK(hipSetDevice(c->device));
     const size_t n_out = (size_t)nb * nnu * nt;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
@@ -1279,7 +1297,7 @@ static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int 
     if (rc) return rc;
     double* d4[4];
     for (int q = 0; q < 4; ++q) d4[q] = out4[q] ? c->d_comp.as<double>() + q * n_out : nullptr;
-    rc = grid_request(c, c->d_params.as<vag_model_params>(), nb, nt, nnu, nullptr, nullptr, d4);
+    rc = grid_request_chunked(c, c->d_params.as<vag_model_params>(), nb, nt, nnu, nullptr, nullptr, d4);
     if (rc) return rc;
     for (int q = 0; q < 4; ++q)
         if (out4[q]) HIPCHK(hipMemcpyAsync(out4[q], d4[q], sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
@@ -1388,7 +1406,6 @@ static int band_request_dev(vag_ctx* c, const vag_model_params* d_params, int nb
     if (!(nu_max > nu_min)) return set_err(VAG_E_INVALID, "nu_max must be greater than nu_min");
     if (num_nu < 2) return set_err(VAG_E_INVALID, "num_nu must be at least 2");
     if (num_nu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d band frequencies", VAG_MAX_NU);
-    if ((long long)nt * num_nu > FLUX_MAX_SLOTS) return set_err(VAG_E_CAPACITY, "nt*num_nu exceeds %d", FLUX_MAX_SLOTS);
     // nu = xt::logspace(log10(nu_min Hz), log10(nu_max Hz), num_nu) in code units
     std::vector<double> nu_code(num_nu), nu_cgs(num_nu), w(num_nu, 0.0);
     {
@@ -1440,7 +1457,7 @@ static int band_request_dev(vag_ctx* c, const vag_model_params* d_params, int nb
     HIPCHK(hipStreamSynchronize(c->stream));  // the staging vectors above are stack-local
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    return grid_request(c, d_params, nb, nt, num_nu, c->d_bandw.as<double>(), d_total, d4);
+    return grid_request_chunked(c, d_params, nb, nt, num_nu, c->d_bandw.as<double>(), d_total, d4);
 }
 
 // Model.flux for a batch: out_total (optional) receives the sum of the enabled components, out4 (optional) the
