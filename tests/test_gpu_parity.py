@@ -1109,3 +1109,27 @@ def test_long_time_axes_are_chunked_for_every_request_kind(eng, oracle):
     big = _abi.make_params(jet="GaussianJet", theta_obs=0.25, resolutions=(0.15, 0.5, 40.0))
     tg, nug = np.logspace(2, 8, 300), np.logspace(9, 19, 16)
     assert_close(gpu_grid(eng, big, tg, nug)[0], oracle.flux_density_grid(big, tg, nug), rtol=5e-6)
+
+
+def test_loglike_with_more_data_points_than_one_series_launch(eng, oracle):
+    """A fit with 700 point data (> 512 per series launch): ln L from the device == the fitter formula on the checker's
+    fluxes (fitter.py:497-522)."""
+    rng = np.random.default_rng(5)
+    t = np.sort(10 ** rng.uniform(3, 7, 700))
+    nu = rng.choice([3e9, 5.06e14, 2.41e17], size=700)
+    truth = _abi.make_params(jet="GaussianJet", theta_obs=0.2)
+    f_obs = oracle.flux_density(truth, t, nu) * (1 + 0.05 * rng.standard_normal(700))
+    err = 0.1 * f_obs
+    f = fitting.Fitter(z=truth.z, lumi_dist=truth.lumi_dist, jet="gaussian", medium="ism")
+    f.add_flux_density(nu, t, f_obs, err)
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e51, 1e53, S.log), P("theta_v", 0.0, 0.5, S.linear), P("theta_c", 0.1, 0.1, S.fixed),
+            P("Gamma0", 300.0, 300.0, S.fixed), P("n_ism", 1.0, 1.0, S.fixed), P("eps_e", 0.1, 0.1, S.fixed),
+            P("eps_B", 0.01, 0.01, S.fixed), P("p", 2.3, 2.3, S.fixed)]
+    samples = np.array([[52.0, 0.2], [52.3, 0.1], [51.6, 0.35]])
+    got = f.loglike_batch(samples, defs)
+    for s, g in zip(samples, got):
+        prm = _abi.make_params(jet="GaussianJet", E_iso=10 ** s[0], theta_obs=s[1])
+        model = np.maximum(oracle.flux_density(prm, t, nu), 1e-300)
+        chi2 = np.sum(((np.log(f_obs) - np.log(model)) / (err / f_obs)) ** 2)
+        assert abs(g - (-0.5 * chi2)) <= 2e-5 * abs(0.5 * chi2) + 1e-6

@@ -1221,6 +1221,31 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
 
 static int upload_series_bands(vag_ctx* c, const double* nu, int n);
 
+// The whole (t, nu) series already in c->d_lg2t / c->d_lg2nu (prep_times) -> d_out[nb][n], the sum of every enabled
+// component.  Longer series than one launch holds (exposure sampling, large data sets) go through in chunks of sorted
+// points on the same model grid.
+static int series_request(vag_ctx* c, const vag_model_params* d_params, int nb, int n, double* d_out, int n_bands) {
+    const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
+    if (n <= chunk)
+        return series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
+                            d_out, n_bands);
+    DevBuf tmp;
+    if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
+    int rc = VAG_OK;
+    for (int s0 = 0; s0 < n && rc == VAG_OK; s0 += chunk) {
+        const int m = std::min(chunk, n - s0);
+        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m,
+                          c->d_lg2nu.as<double>(), n, tmp.as<double>());
+        if (rc == VAG_OK && hipMemcpy2DAsync(d_out + s0, sizeof(double) * n, tmp.p, sizeof(double) * m, sizeof(double) * m,
+                                             (size_t)nb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            rc = VAG_E_HIP;
+    }
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    if (rc == VAG_OK && e != hipSuccess) return set_err(VAG_E_HIP, "chunked series: %s", hipGetErrorString(e));
+    return rc;
+}
+
 int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
                                const double* d_nu, int n, double* d_out) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
@@ -1232,23 +1257,7 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     if (rc) return rc;
     rc = run_model_stages(c, d_params, nb, false);
     if (rc) return rc;
-    const int chunk = SERIES_THREADS * SERIES_MAX_SLOTS;
-    if (n <= chunk)
-        return series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
-                            d_out, n_bands);
-    DevBuf tmp;  // long series (exposure sampling): evaluate in chunks of sorted points on the same grid
-    if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
-    for (int s0 = 0; s0 < n; s0 += chunk) {
-        const int m = std::min(chunk, n - s0);
-        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>() + s0, c->d_lg2nu.as<double>() + s0, m,
-                          c->d_lg2nu.as<double>(), n, tmp.as<double>());
-        if (rc) break;
-        HIPCHK(hipMemcpy2DAsync(d_out + s0, sizeof(double) * n, tmp.p, sizeof(double) * m, sizeof(double) * m, (size_t)nb,
-                                hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    tmp.release();
-    return rc;
+    return series_request(c, d_params, nb, n, d_out, n_bands);
 }
 
 int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
@@ -1658,8 +1667,7 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
         if (rc) return rc;
         rc = run_model_stages(c, d_params, nb, false);
         if (rc) return rc;
-        rc = series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
-                          c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
+        rc = series_request(c, d_params, nb, n, c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
         if (rc) return rc;
         rc = after_pass();
         if (rc) return rc;
