@@ -1111,6 +1111,27 @@ def test_long_time_axes_are_chunked_for_every_request_kind(eng, oracle):
     assert_close(gpu_grid(eng, big, tg, nug)[0], oracle.flux_density_grid(big, tg, nug), rtol=5e-6)
 
 
+def test_wide_spectra_are_chunked_along_frequency(eng, oracle):
+    """More frequencies than one launch carries (broad-band SEDs): the frequency axis is cut into chunks, the SSC seed
+    band stays clamped over ALL requested frequencies (as one reference call does), and every component equals the
+    checker's un-chunked answer; with a long time axis both cuts combine."""
+    nu = np.logspace(8, 27, 150)
+    t = np.logspace(3, 6.5, 6)
+    syn = _abi.make_params(jet="GaussianJet", theta_obs=0.2)
+    assert_close(gpu_grid(eng, syn, t, nu)[0], oracle.flux_density_grid(syn, t, nu), rtol=2e-6)
+    prm = _abi.make_params(theta_obs=0.05, duration=300.0, ssc=True, kn=True, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.4, ssc=True))
+    got = gpu_components4(eng, prm, t, nu)
+    want = oracle.flux_components4(prm, t, nu)
+    for c in range(4):
+        assert_close(got[c][0], want[c], rtol=5e-6)
+    assert_close(gpu_grid(eng, prm, t, nu)[0], sum(want), rtol=5e-6)
+    tl, nul = np.logspace(2, 7.5, 130), np.logspace(9, 24, 70)   # 70 x 130 slots: two frequency x three time chunks
+    got = gpu_components4(eng, prm, tl, nul)
+    want = oracle.flux_components4(prm, tl, nul)
+    for c in range(4):
+        assert_close(got[c][0], want[c], rtol=5e-6)
+
+
 def test_loglike_with_more_data_points_than_one_series_launch(eng, oracle):
     """A fit with 700 point data (> 512 per series launch): ln L from the device == the fitter formula on the checker's
     fluxes (fitter.py:497-522)."""

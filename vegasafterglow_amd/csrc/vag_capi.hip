@@ -851,9 +851,11 @@ int check_ic_status(vag_ctx* c, int nb) {
     return VAG_OK;
 }
 
+// d_lg2nu_all / nnu_all: every frequency of the request (the seed band is clamped over all of them, also when the
+// frequency axis is evaluated in chunks)
 int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
-                 int nnu, const double* d_bandw, double* d_ssc) {
-    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu, nnu);
+                 int nnu, const double* d_bandw, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
+    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all);
     if (rc) return rc;
     rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
     if (rc) return rc;
@@ -872,8 +874,8 @@ static bool fused_fits(vag_ctx* c, int nt, int nnu) {
     return fused <= cu && std::min<size_t>(cu / fused, 4) >= std::min<size_t>(cu / two, 4);
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
-                   int nnu, const double* d_bandw, double* d_syn, double* d_ssc) {
-    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu, nnu);
+                   int nnu, const double* d_bandw, double* d_syn, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
+    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all);
     if (rc) return rc;
     rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
     if (rc) return rc;
@@ -889,7 +891,11 @@ __global__ void vag_copy_kernel(double* __restrict__ out, const double* __restri
 // d_comp (optional) -> d_comp[i] != nullptr receives component i, zeros when that component is disabled;
 // d_total (optional) receives the sum of the enabled components in PyFlux::calc_total order (pymodel.cpp:350-364).
 int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw, double* d_total,
-                 double* const* d_comp, int t_off = 0) {  // t_off: first requested time of this call (time-axis chunking)
+                 double* const* d_comp, int t_off = 0, int nu_off = 0, int nnu_all = 0) {
+    // t_off / nu_off: first requested time / frequency of this call, nnu_all: frequencies of the whole request (chunking)
+    if (nnu_all == 0) nnu_all = nnu;
+    const double* lg2nu_all = c->d_lg2nu.as<double>();
+    const double* lg2nu = lg2nu_all + nu_off;
     const size_t n_out = (size_t)nb * (d_bandw ? nt : (size_t)nt * nnu);
     const int n_em = (c->batch_flags & VAG_FLAG_RVS) ? 2 : 1;
     bool first = true;
@@ -930,13 +936,12 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
                         }
                         want_ssc = c->d_ssc2.as<double>();
                     }
-                    rc = run_flux_fused(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst, want_ssc);
+                    rc = run_flux_fused(c, c->cur_params, nb, lg2t, nt, lg2nu, nnu, d_bandw, dst, want_ssc, lg2nu_all, nnu_all);
                     fused_ssc = want_ssc;
                 } else if (pass == 0) {
-                    rc = run_flux_grid(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst,
-                                       c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
+                    rc = run_flux_grid(c, c->cur_params, nb, lg2t, nt, lg2nu, nnu, d_bandw, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN);
                 } else {
-                    rc = run_flux_ssc(c, c->cur_params, nb, lg2t, nt, c->d_lg2nu.as<double>(), nnu, d_bandw, dst);
+                    rc = run_flux_ssc(c, c->cur_params, nb, lg2t, nt, lg2nu, nnu, d_bandw, dst, lg2nu_all, nnu_all);
                 }
                 if (rc) break;
             }
@@ -955,33 +960,58 @@ int grid_request(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, i
     return rc;
 }
 
-// grid_request with the time axis cut into chunks whose (nu, t) accumulator and boundary values fit the workgroup's LDS
-// (<= 4096 slots, and fewer when the lattice is long): outputs are assembled into [nb][rows][nt], rows = nnu (1 for a band).
+// [nb][rows][n] chunk results -> their place in the [nb][rows_all][nt] output
+__global__ void vag_place_kernel(double* __restrict__ dst, const double* __restrict__ src, int rows, int n, int rows_all, int nt,
+                                 int row0, int t0, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % n);
+        const size_t r = i / n;
+        const int l = (int)(r % rows);
+        const size_t m = r / rows;
+        dst[(m * rows_all + row0 + l) * nt + t0 + j] = src[i];
+    }
+}
+
+// grid_request with the frequency axis cut into chunks of <= VAG_MAX_NU and the time axis into chunks whose (nu, t)
+// accumulator and boundary values fit the workgroup's LDS (<= 4096 slots, fewer when the lattice is long): outputs are
+// assembled into [nb][rows][nt], rows = nnu (1 for a band).
 int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, int nt, int nnu, const double* d_bandw,
                          double* d_total, double* const* d_comp) {
     const bool any_ssc = (c->batch_flags & (VAG_FLAG_SSC | VAG_FLAG_RVS_SSC)) != 0;
-    int chunk = std::max(1, 4096 / nnu);
-    while (chunk > 8 && flux_grid_lds_bytes(any_ssc ? FLUX_SYN_IC : FLUX_SYN, c->max_k, std::min(chunk, nt), nnu) > 160 * 1024)
+    // a band integrates all of its frequencies in one launch; a grid is cut into near-equal frequency chunks
+    const int nu_parts = d_bandw ? 1 : (nnu + VAG_MAX_NU - 1) / VAG_MAX_NU;
+    const int nu_chunk = (nnu + nu_parts - 1) / nu_parts;
+    int chunk = std::max(1, 4096 / nu_chunk);
+    while (chunk > 8 &&
+           flux_grid_lds_bytes(any_ssc ? FLUX_SYN_IC : FLUX_SYN, c->max_k, std::min(chunk, nt), nu_chunk) > 160 * 1024)
         chunk >>= 1;
-    if (nt <= chunk) return grid_request(c, d_params, nb, nt, nnu, d_bandw, d_total, d_comp);
-    const size_t rows = (size_t)nb * (d_bandw ? 1 : nnu);
+    if (nt <= chunk && nu_parts == 1) return grid_request(c, d_params, nb, nt, nnu, d_bandw, d_total, d_comp);
+    chunk = std::min(chunk, nt);
+    const int rows_all = d_bandw ? 1 : nnu;
+    const size_t cap = (size_t)nb * (d_bandw ? 1 : nu_chunk) * chunk;
     DevBuf tmp;
-    if (tmp.ensure(sizeof(double) * 5 * rows * chunk)) return VAG_E_HIP;
+    if (tmp.ensure(sizeof(double) * 5 * cap)) return VAG_E_HIP;
     double* t_total = d_total ? tmp.as<double>() : nullptr;
     double* t_comp[4];
-    for (int i = 0; i < 4; ++i) t_comp[i] = (d_comp && d_comp[i]) ? tmp.as<double>() + (size_t)(i + 1) * rows * chunk : nullptr;
+    for (int i = 0; i < 4; ++i) t_comp[i] = (d_comp && d_comp[i]) ? tmp.as<double>() + (size_t)(i + 1) * cap : nullptr;
     int rc = VAG_OK;
-    for (int t0 = 0; t0 < nt && rc == VAG_OK; t0 += chunk) {
-        const int n = std::min(chunk, nt - t0);
-        rc = grid_request(c, d_params, nb, n, nnu, d_bandw, t_total, d_comp ? t_comp : nullptr, t0);
-        auto put = [&](double* dst, const double* src) {
-            if (rc == VAG_OK && dst &&
-                hipMemcpy2DAsync(dst + t0, sizeof(double) * nt, src, sizeof(double) * n, sizeof(double) * n, rows,
-                                 hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                rc = VAG_E_HIP;
-        };
-        put(d_total, t_total);
-        for (int i = 0; i < 4; ++i) put(d_comp ? d_comp[i] : nullptr, t_comp[i]);
+    for (int l0 = 0; l0 < nnu && rc == VAG_OK; l0 += nu_chunk) {
+        const int nl = std::min(nu_chunk, nnu - l0);
+        const int rows = d_bandw ? 1 : nl;
+        for (int t0 = 0; t0 < nt && rc == VAG_OK; t0 += chunk) {
+            const int n = std::min(chunk, nt - t0);
+            rc = grid_request(c, d_params, nb, n, d_bandw ? nnu : nl, d_bandw, t_total, d_comp ? t_comp : nullptr, t0, l0, nnu);
+            const size_t total = (size_t)nb * rows * n;
+            auto put = [&](double* dst, const double* src) {
+                if (rc != VAG_OK || !dst) return;
+                hipLaunchKernelGGL(vag_place_kernel, dim3(256), dim3(256), 0, c->stream, dst, src, rows, n, rows_all, nt,
+                                   d_bandw ? 0 : l0, t0, total);
+                if (hipGetLastError() != hipSuccess) rc = VAG_E_HIP;
+            };
+            put(d_total, t_total);
+            for (int i = 0; i < 4; ++i) put(d_comp ? d_comp[i] : nullptr, t_comp[i]);
+        }
+        if (d_bandw) break;
     }
     const hipError_t e = hipStreamSynchronize(c->stream);
     tmp.release();
@@ -1210,7 +1240,6 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
                                     const double* d_nu, int nnu, double* d_out) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
-    if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
     HIPCHK(hipSetDevice(c->device));
     int rc = prep_times(c, d_t, nt, d_nu, nnu);
     if (rc) return rc;
@@ -1288,7 +1317,6 @@ static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int 
                                 int nnu, double* const* out4) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
-    if (nnu > VAG_MAX_NU) return set_err(VAG_E_CAPACITY, "at most %d frequencies per call", VAG_MAX_NU);
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
