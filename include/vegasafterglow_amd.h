@@ -159,7 +159,7 @@ typedef struct vag_limits {
     int32_t max_theta; /* theta nodes per model */
     int32_t max_phi;   /* phi nodes per model */
     int32_t max_time;  /* time-lattice nodes per row */
-    int32_t max_nu;    /* frequencies per call */
+    int32_t max_nu;    /* frequencies per launch (grids with more are chunked inside the engine; a band integrates at most this many) */
 } vag_limits;
 void vag_get_limits(vag_limits* out);
 

@@ -309,3 +309,14 @@ def test_fitter_observation_validation_rules():
             f.add_flux(bad_band, t, fl, er)
     with pytest.raises(ValueError, match="num_points"):
         f.add_flux((1e17, 1e18), t, fl, er, num_points=1)
+
+
+def test_logscale_screen_thins_to_a_density_per_decade():
+    """pybind.h:40-107: end points kept, log-uniform targets snapped to the nearest interior sample, no duplicates."""
+    import vegasafterglow_amd as va
+    assert va.logscale_screen(np.array([1.0, 2.0, 5.0, 10.0, 20.0, 50.0, 100.0]), 1) == [0, 3, 6]
+    assert va.logscale_screen(np.array([42.0]), 10) == [0] and va.logscale_screen(np.array([]), 10) == []
+    assert va.logscale_screen(np.array([1.0, 2.0, 3.0]), 0) == [0, 1, 2]
+    assert va.logscale_screen(np.array([1.0, 1.5]), 10) == [0, 1]
+    idx = va.logscale_screen(np.logspace(1, 5, 1000), 10)
+    assert len(idx) == 41 and idx[0] == 0 and idx[-1] == 999 and idx == sorted(set(idx))

@@ -6,7 +6,8 @@ Drop-in names for the accelerated path of the reference's Python API
 from . import _lib
 from .model import (ISM, Flux, FluxDict, GaussianJet, Magnetar, MagnetizedTophatJet, Model, Observer, PowerLawJet, PowerLawWing,
                     Radiation, StepPowerLawJet, TophatJet, TwoComponentJet, Wind, get_context)
+from .fitting import logscale_screen
 
 __all__ = ["ISM", "Wind", "TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing", "MagnetizedTophatJet", "Magnetar", "Observer", "Radiation",
-           "Model", "Flux", "FluxDict", "get_context"]
+           "Model", "Flux", "FluxDict", "get_context", "logscale_screen"]
 __version__ = "0.1.0"

@@ -28,6 +28,29 @@ JET_TYPES = {"tophat": _lib.JET_TOPHAT, "gaussian": _lib.JET_GAUSSIAN, "powerlaw
 MEDIUM_TYPES = {"ism": _lib.MEDIUM_ISM, "wind": _lib.MEDIUM_WIND}
 
 
+def logscale_screen(data, data_density):
+    """Indices that thin a sorted positive array to about `data_density` points per decade, end points always kept
+    (pybind.h:40-107): the targets are log-uniform between data[0] and data[-1], each replaced by the interior sample
+    nearest to it in LINEAR distance (first one on ties), duplicates dropped.  Host-side data preparation for a fit."""
+    x = np.asarray(data, dtype=np.float64).ravel()
+    n, density = x.size, int(data_density)
+    if n <= 1:
+        return list(range(n))
+    if density == 0:
+        return list(range(n))
+    lo, hi = np.log10(x[0]), np.log10(x[-1])
+    n_targets = int(np.ceil((hi - lo) * density)) + 1
+    keep = {0, n - 1}
+    if n_targets > 2 and n > 2:
+        step = (hi - lo) / (n_targets - 1)
+        interior = x[1:n - 1]
+        for i in range(1, n_targets - 1):
+            keep.add(1 + int(np.argmin(np.abs(interior - 10.0 ** (lo + i * step)))))
+    elif n_targets > 2:
+        keep.add(1)
+    return sorted(keep)
+
+
 class Scale(Enum):
     linear = "linear"
     log = "log"
