@@ -320,3 +320,42 @@ def test_logscale_screen_thins_to_a_density_per_decade():
     assert va.logscale_screen(np.array([1.0, 1.5]), 10) == [0, 1]
     idx = va.logscale_screen(np.logspace(1, 5, 1000), 10)
     assert len(idx) == 41 and idx[0] == 0 and idx[-1] == 999 and idx == sorted(set(idx))
+
+
+@pytest.mark.parametrize("law", ["smc", "lmc", "mw"])
+def test_pei92_extinction_laws(law):
+    """The properties the reference asserts of its laws (tests/python/test_extinction.py:11-55) and three values computed
+    by hand from Pei (1992) Table 4."""
+    from vegasafterglow_amd import extinction as ex
+    assert ex.pei92(5.5e-5, law) == pytest.approx(1.0, rel=1e-12)
+    assert np.array_equal(ex.pei92(np.array([0.5, 0.9, 0.99]) * 912e-8, law), np.zeros(3))
+    assert ex.pei92(2000e-8, law) > ex.pei92(7000e-8, law) > 0
+    lam = np.geomspace(1000e-8, 3e-4, 25).reshape(5, 5)
+    out = ex.pei92(lam, law)
+    assert out.shape == lam.shape and np.all(np.isfinite(out)) and np.all(out >= 0)
+    assert np.array_equal(ex.BUILTIN_LAWS[law](lam), out) and set(ex.BUILTIN_LAWS) == {"smc", "lmc", "mw"}
+    # independent scalar evaluation of the six-term sum at 1500 A
+    r_v, terms = ex._TERMS[law]
+
+    def raw(l_um):
+        return (1 + 1 / r_v) * sum(a / ((l_um / li) ** n + (li / l_um) ** n + b) for a, li, b, n in terms)
+
+    assert ex.pei92(1500e-8, law) == pytest.approx(raw(0.15) / raw(0.55), rel=1e-13)
+
+
+def test_fitter_accepts_named_extinction_laws():
+    from vegasafterglow_amd import fitting, extinction as ex
+    f = fitting.Fitter(z=1.0, lumi_dist=1e28, extinction="smc")
+    assert f.extinction is ex.smc
+    with pytest.raises(ValueError, match="Unknown extinction law"):
+        fitting.Fitter(z=1.0, lumi_dist=1e28, extinction="calzetti")
+    with pytest.raises(ValueError):
+        fitting.Fitter(z=1.0, lumi_dist=1e28, extinction=3.1)
+
+
+def test_pei92_laws_equal_the_reference_vectors():
+    """k(lambda) on 43 wavelengths from the reference's own module (tests/golden/make_extinction_vectors.py)."""
+    from vegasafterglow_amd import extinction as ex
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extinction_pei92.npz"))
+    for law in ("smc", "lmc", "mw"):
+        np.testing.assert_allclose(ex.pei92(g["lam_cm"], law), g[law], rtol=1e-14, atol=0)

@@ -84,8 +84,15 @@ class Fitter:
                  magnetar=False, extinction=None):
         # extinction: k(lambda_rest [cm]) -> A_lambda / A_V of the host-galaxy law (a callable; fitter.py:379-397).  The
         # point-data model fluxes are scaled by exp(-A_V * 0.4 ln10 * k) with A_V a (free or fixed) parameter.
-        if extinction is not None and not callable(extinction):
-            raise ValueError("extinction must be a callable k(lambda_rest_cm) (the reference's named laws are not shipped here)")
+        # A name selects a built-in Pei92 law; a custom callable is evaluated ONCE per data set (it must not depend on the
+        # sampled parameters: the device likelihood applies one fixed kernel per datum).
+        if isinstance(extinction, str):
+            from .extinction import BUILTIN_LAWS
+            if extinction not in BUILTIN_LAWS:
+                raise ValueError(f"Unknown extinction law: {extinction!r}. Expected one of {sorted(BUILTIN_LAWS)} or a callable.")
+            self.extinction_name, extinction = extinction, BUILTIN_LAWS[extinction]
+        elif extinction is not None and not callable(extinction):
+            raise ValueError("extinction must be None, 'smc' / 'lmc' / 'mw', or a callable k(lambda_rest_cm)")
         self.extinction = extinction
         self.magnetar = bool(magnetar)
         if rvs_ssc and not rvs_shock:
