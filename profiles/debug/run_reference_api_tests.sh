@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer cross-check (only where /root/reference is mounted, never on the GPU box): run the reference's OWN Python API
 # tests that need no emcee/bilby/plotting against this package, through a throw-away `VegasAfterglow` alias package.
-# At the time of writing: test_pybind_validation (102 of 102 non-callback cases), test_validation (11),
+# At the time of writing: test_pybind_validation (102 of 102 non-callback cases), test_validation (11), test_extinction (14),
 # test_fitter_data_validation (36) pass.
 set -e
 REPO=$(cd "$(dirname "$0")/../.." && pwd)
@@ -15,9 +15,7 @@ for _n in dir(_va):
 from vegasafterglow_amd.fitting import Fitter, ParamDef, Scale  # noqa: F401,E402
 PY
 cat > "$SHIM/VegasAfterglow/units.py" <<'PY'
-keV = 1e3 * 1.602176634e-12 / 6.62607015e-27  # Hz per keV
-def band(name):
-    return {"XRT": (0.3 * keV, 10 * keV)}[name]
+from vegasafterglow_amd.units import *  # noqa: F401,F403
 PY
 cd /tmp
 PYTHONPATH="$SHIM:$REPO" python -m pytest -q -p no:cacheprovider \

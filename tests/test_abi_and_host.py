@@ -359,3 +359,18 @@ def test_pei92_laws_equal_the_reference_vectors():
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extinction_pei92.npz"))
     for law in ("smc", "lmc", "mw"):
         np.testing.assert_allclose(ex.pei92(g["lam_cm"], law), g[law], rtol=1e-14, atol=0)
+
+
+def test_units_multipliers_magnitudes_and_named_bands():
+    """units.py:36-88,172-205,339-367 of the reference: engine conventions are s, Hz, cm, rad, erg/cm^2/s/Hz."""
+    from vegasafterglow_amd import units as u
+    assert u.day == 86400.0 and u.yr == pytest.approx(3.15569e7, rel=1e-5) and u.GHz == 1e9 and u.mJy == 1e-26
+    assert u.keV == pytest.approx(2.417989e17, rel=1e-6) and u.Mpc == pytest.approx(3.0857e24, rel=1e-4)
+    assert u.deg * 180 == pytest.approx(np.pi) and u.arcsec * 3600 == pytest.approx(u.deg)
+    assert u.ABmag_to_cgs(0.0) == pytest.approx(3.631e-20) and u.ABmag_to_cgs(23.9) == pytest.approx(1e-29, rel=2e-3)
+    mags = np.array([15.0, 20.0, 25.0])
+    np.testing.assert_allclose(u.cgs_to_ABmag(u.ABmag_to_cgs(mags)), mags, rtol=1e-14)
+    lo, hi = u.band("XRT")
+    assert lo == pytest.approx(0.3 * u.keV) and hi == pytest.approx(10 * u.keV) and u.band("LAT")[1] == pytest.approx(300 * u.GeV)
+    with pytest.raises(ValueError, match="Unknown band"):
+        u.band("nope")
