@@ -201,3 +201,34 @@ def test_model_properties_and_single_point_requests():
     assert m.flux_density_grid(np.array([1e4]), np.logspace(9, 18, 5)).total.shape == (5, 1)
     idx = va.logscale_screen(np.logspace(1, 5, 1000), 10)
     assert 0 < len(idx) < 1000 and idx[0] == 0 and idx[-1] == 999
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Blandford-McKee phase scalings of the forward shock through Model.details (tests/python/test_shock_scalings.py:35-62
+# with the tables of tests/validation/regression/run_regression.py:20-47: on-axis top-hat, E_iso 1e52, theta_c 0.1,
+# eps_e = eps_B = 0.01, p 2.2, resolutions (0.3, 2, 15); ISM n 0.1 / Gamma0 300 over t_obs 5e2..5e3 s, wind
+# A_star 0.3 / Gamma0 70 over 1e4..1e5 s; slope tolerance 0.1)
+# ---------------------------------------------------------------------------------------------------------------
+_BM = {"ISM": (dict(medium=ISM(n_ism=0.1), Gamma0=300), (5e2, 5e3), {"u": -3 / 8, "r": 1 / 4, "B_comv": -3 / 8, "N_p": 3 / 4}),
+       "wind": (dict(medium=Wind(A_star=0.3), Gamma0=70), (1e4, 1e5), {"u": -1 / 4, "r": 1 / 2, "B_comv": -3 / 4, "N_p": 1 / 2})}
+
+
+@pytest.mark.parametrize("medium", ["ISM", "wind"])
+def test_blandford_mckee_phase_scalings(medium):
+    cfg, (t_lo, t_hi), expected = _BM[medium]
+    m = Model(TophatJet(theta_c=0.1, E_iso=1e52, Gamma0=cfg["Gamma0"]), cfg["medium"], Observer(lumi_dist=1e28, z=1.0, theta_obs=0.0),
+              Radiation(eps_e=0.01, eps_B=0.01, p=2.2, xi_e=1.0), resolutions=(0.3, 2, 15))
+    d = m.details(t_lo, t_hi)
+    t = np.asarray(d.fwd.t_obs)[0, 0, :]
+    order = np.argsort(t)
+    t = t[order]
+    G = np.asarray(d.fwd.Gamma)[0, 0, :][order]
+    series = {"u": G * np.sqrt(1.0 - 1.0 / (G * G))}
+    for key in ("r", "B_comv", "N_p"):
+        series[key] = np.asarray(getattr(d.fwd, key))[0, 0, :][order]
+    w = (t >= t_lo) & (t <= t_hi)
+    assert w.sum() >= 5
+    for key, want in expected.items():
+        y = series[key]
+        ok = w & (y > 0) & np.isfinite(y)
+        assert abs(_slope(t[ok], y[ok]) - want) < 0.1, (medium, key, _slope(t[ok], y[ok]), want)
