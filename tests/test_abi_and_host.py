@@ -374,3 +374,15 @@ def test_units_multipliers_magnitudes_and_named_bands():
     assert lo == pytest.approx(0.3 * u.keV) and hi == pytest.approx(10 * u.keV) and u.band("LAT")[1] == pytest.approx(300 * u.GeV)
     with pytest.raises(ValueError, match="Unknown band"):
         u.band("nope")
+
+
+def test_custom_extinction_callables_in_either_signature():
+    """k(lambda) and the reference's (lambda, params) form both work; a law that needs the sampled params fails loudly."""
+    from vegasafterglow_amd import fitting
+    lam = np.array([3e-5, 6e-5])
+    one = fitting.Fitter(z=1.0, lumi_dist=1e28, extinction=lambda l: 5.5e-5 / l)
+    two = fitting.Fitter(z=1.0, lumi_dist=1e28, extinction=lambda l, params: 5.5e-5 / l)
+    assert np.array_equal(one._k_lambda(lam), two._k_lambda(lam))
+    needs = fitting.Fitter(z=1.0, lumi_dist=1e28, extinction=lambda l, params: params["R_V"] / l)
+    with pytest.raises(TypeError):
+        needs._k_lambda(lam)

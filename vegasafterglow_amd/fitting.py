@@ -219,7 +219,19 @@ class Fitter:
         self._all_weights = np.ascontiguousarray(w)
         if self.extinction is not None:  # fitter.py:439-449: rest-frame wavelengths, kernel = 0.4 ln10 k(lambda)
             lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self.z)
-            self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self.extinction(lam_rest_cm), dtype=np.float64))
+            self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
+
+    def _k_lambda(self, lam_rest_cm):
+        """k(lambda) of the configured law.  The reference hands custom callables (lam_rest_cm, params) (fitter.py:445-449);
+        such a two-argument law is called with params=None here, so one that really depends on the sampled parameters
+        fails loudly instead of being frozen silently."""
+        import inspect
+        try:
+            n_pos = sum(1 for q in inspect.signature(self.extinction).parameters.values()
+                        if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) and q.default is q.empty)
+        except (TypeError, ValueError):
+            n_pos = 1
+        return self.extinction(lam_rest_cm, None) if n_pos >= 2 else self.extinction(lam_rest_cm)
 
     def _base_params(self, fixed):
         vals = dict(MODEL_PARAM_DEFAULTS)
@@ -339,7 +351,7 @@ class Fitter:
         if self.extinction is None or a_v == 0.0:
             return res
         lam_rest_cm = (2.99792458e10 / np.asarray(nu, dtype=np.float64)) / (1.0 + self.z)
-        att = np.exp(-a_v * 0.4 * np.log(10.0) * np.asarray(self.extinction(lam_rest_cm), dtype=np.float64))[:, None]
+        att = np.exp(-a_v * 0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))[:, None]
         comps = [c * att if np.ndim(c) == 2 else None for c in (res.fwd.sync, res.fwd.ssc, res.rvs.sync, res.rvs.ssc)]
         return FluxDict(*comps)
 
