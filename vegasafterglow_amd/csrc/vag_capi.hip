@@ -517,7 +517,8 @@ void select_emitter(vag_ctx* c, int e, const vag_model_params* d_params) {
 
 // Stage 3 for the selected emitter: electrons + photons per cell (generate_syn_electrons / generate_syn_photons),
 // then apply_ic_cooling (pybind/pymodel.h:567-577) when its Radiation has ssc.
-int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, const int* d_inj, bool ssc, bool want_details) {
+int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, const int* d_inj, bool ssc, bool want_details,
+                  bool raw_shock = false) {
     hipStream_t st = c->stream;
     const long long cells = c->n_cells;
     const int rows = c->n_rows;
@@ -527,7 +528,7 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
     hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
                        c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
-                       want_details ? c->d_celldet.as<double>() : nullptr, d_inj);
+                       want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr);
     HIPCHK(hipGetLastError());
     if (ssc) {  // cool the electrons row by row, then rebuild the photons
         if (c->d_icy.ensure(sizeof(double) * (size_t)cells * VAG_NICY)) return VAG_E_HIP;
@@ -542,6 +543,18 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
         HIPCHK(hipGetLastError());
     }
     return VAG_OK;
+}
+
+// ODE rows per wavefront of the dynamics kernels (one lane integrates one row).  Measured (profiles/r02_rpw.txt): fewer
+// rows per wavefront do NOT pay for the general kernel -- at 256 VGPRs only one wavefront fits a SIMD and the dispatcher
+// does not spread single-wavefront workgroups evenly -- so full wavefronts stay the default; the knob remains for tuning.
+int dyn_rows_per_wave(int rows) {
+    (void)rows;
+    if (const char* e = std::getenv("VAG_DYN_RPW")) {
+        const int v = std::atoi(e);
+        if (v > 0) return std::min(v, 64);
+    }
+    return 64;
 }
 
 // Stage 1-3: adaptive grid -> blast-wave dynamics -> per-cell radiation, for nb models whose
@@ -574,7 +587,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     long long* h_cell = c->h_off.as<long long>();
     int* h_row = reinterpret_cast<int*>(h_cell + (nb + 1));
     long long cells = 0, pairs = 0, eat = 0;
-    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_invalid = 0, n_capacity = 0;
+    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_invalid = 0, n_capacity = 0, dyn_class = 0;
     for (int m = 0; m < nb; ++m) {
         h_row[m] = rows;
         h_cell[m] = cells;
@@ -586,6 +599,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             max_pairs = std::max(max_pairs, pr);
             pairs += pr;
             eat += (long long)pr * hm[m].n_t;
+            dyn_class |= hm[m].dyn_class;
             ++n_ok;
         } else if (hm[m].status == VAG_E_CAPACITY) {
             ++n_capacity;
@@ -637,6 +651,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_shock.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
     if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+    bool raw_shock = false;
     if (rvs) {  // generate_shock_pair (reverse-shock.tpp:592-614): both shocks from one ODE state per row
         if (c->d_shock_r.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
         if (c->d_inj.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
@@ -647,13 +662,21 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
                            c->d_inj.as<int>(), c->d_row_status.as<int>());
+    } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
+        raw_shock = true;
+        const int rpw = dyn_rows_per_wave(rows);
+        hipLaunchKernelGGL(vag_dynamics_fast_kernel, dim3((rows + rpw - 1) / rpw), dim3(128), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+                           c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>(),
+                           c->d_sptab.as<double>(), rpw);
     } else {
         const bool inject = (c->batch_flags & VAG_FLAG_MAGNETAR) != 0;
         auto kern = spreading ? (inject ? vag_dynamics_kernel<true, true> : vag_dynamics_kernel<true, false>)
                               : (inject ? vag_dynamics_kernel<false, true> : vag_dynamics_kernel<false, false>);
-        hipLaunchKernelGGL(kern, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
+        const int rpw = dyn_rows_per_wave(rows);
+        hipLaunchKernelGGL(kern, dim3((rows + rpw - 1) / rpw), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                            c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
-                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>());
+                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>(), rpw);
     }
     HIPCHK(hipGetLastError());
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
@@ -671,7 +694,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->cur_emitter = 0;
     c->cur_params = d_params;
     c->cur_ssc = (c->batch_flags & VAG_FLAG_SSC) != 0;
-    int rc = run_radiation(c, d_params, nb, nullptr, c->cur_ssc, want_details);
+    int rc = run_radiation(c, d_params, nb, nullptr, c->cur_ssc, want_details, raw_shock);
     if (rc) return rc;
     if (rvs) {
         select_emitter(c, 1, d_params);

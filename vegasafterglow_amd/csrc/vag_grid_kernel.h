@@ -213,6 +213,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     M.status = 0;
     M.flags = P.flags;
     M.t_num_base = 0;
+    M.dyn_class = (med.generic || (P.flags & (VAG_FLAG_SPREADING | VAG_FLAG_MAGNETAR | VAG_FLAG_RVS))) ? 1 : 0;
+    M.pad_ = 0;
 #ifdef VAG_GRID_STAMPS
     long long stamps_[10] = {};
 #endif

@@ -2,6 +2,7 @@
 #pragma once
 #include "vag_device.h"
 #include "vag_grid_kernel.h"
+#include "vag_dyn_fast.h"
 
 namespace vag {
 
@@ -34,12 +35,14 @@ __global__ void __launch_bounds__(64)
 vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                     const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
-                    long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table) {
+                    long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];  // log2_tab's table for the right-hand sides
     for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
     __syncthreads();
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    // a wavefront carries rows_per_wave rows (the host spreads a small batch over the chip: lanes of one wavefront pay for
+    // each other's rejected steps and save loops)
+    const int row = blockIdx.x * rows_per_wave + threadIdx.x;
+    if ((int)threadIdx.x >= rows_per_wave || row >= n_rows) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -191,6 +194,141 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     row_status[row] = status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same solve for the common case (VagGridMeta::dyn_class == 0 for every model of the batch): vag_dyn_fast.h.  A workgroup is
+// two wavefronts over the same rows_per_wave rows -- wavefront 0 integrates (flat attempt loop), wavefront 1 saves (dense
+// output at the lattice nodes) -- coupled by an LDS ring.  Writes the interpolated state only: slot VS_GAMMA_TH holds U2_th
+// and slot VS_NP holds m2 until vag_cells_kernel(raw_shock) finishes them (Gamma_th, B, N_p of save_fwd_shock_state).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                         const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
+                         const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
+                         long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave) {
+    __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
+    __shared__ DynRing ring;
+    __shared__ int s_status[64];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0 integrates, role 1 saves
+    for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 128) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
+    if (threadIdx.x == 0) ring.head = ring.tail = ring.fin = 0;
+    if (role == 0) s_status[lane] = 0;
+    const int row = blockIdx.x * rows_per_wave + lane;
+    bool active = lane < rows_per_wave && row < n_rows;
+    int m = 0;
+    VagGridMeta M = {};
+    if (active) {
+        m = find_model(lay.row_off, nb, row);
+        M = meta[m];
+        active = M.status == 0;
+    }
+    const int nt = M.n_t;
+    double s[5] = {2.0, 1.0, 1.0, 1.0, 1.0};
+    double t0 = 1, t_last = 0, t_start_row = 1, t_early_row = 1, rtol = 1e-6;
+    double *o_teng = nullptr, *o_tcomv = nullptr, *o_r = nullptr, *o_G = nullptr, *o_U = nullptr, *o_m2 = nullptr, *o_B = nullptr;
+    TimeLattice lat;
+    lat.init(1.0, 2.0, 1.0, 2);
+    FsRhs<true> eq;
+    eq.lg = lds_tab(s_lg);
+    eq.m_jet0 = eq.gm_coeff = eq.inv_gc2 = eq.eps_e = eq.pm2 = eq.rho_ism = 1;
+    eq.A = eq.r02 = 0;
+    bool stopped = false;
+    if (active) {
+        const int r = row - lay.row_off[m];
+        const int j = g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+        const vag_model_params P = params[m];
+        Jet jet;
+        jet_init(jet, P);
+        Medium med;
+        medium_init(med, P);
+        const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
+        const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
+        t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
+        t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+        const long long c0 = lay.cell_off[m] + (long long)r * nt;
+        o_teng = shock + VS_TENG * n_cells + c0;
+        o_tcomv = shock + VS_TCOMV * n_cells + c0;
+        o_r = shock + VS_R * n_cells + c0;
+        o_G = shock + VS_GAMMA * n_cells + c0;
+        o_U = shock + VS_GAMMA_TH * n_cells + c0;
+        o_B = shock + VS_B * n_cells + c0;
+        o_m2 = shock + VS_NP * n_cells + c0;
+        lat.init(t_start_row, M.t_end, t_dec, M.t_num_tot);
+        const double Gamma4 = jet_Gamma0(jet, theta0);
+        eq.m_jet0 = jet_eps_k(jet, theta0) / Gamma4 / C_C2 / (1 + jet.sigma0);
+        eq.gm_coeff = (P.p - 2) / (P.p - 1) * P.eps_e * C_MP / C_ME / P.xi_e;
+        eq.inv_gc2 = 2 / (6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B));
+        eq.eps_e = P.radiative_fireball ? P.eps_e : 0;
+        eq.pm2 = P.p > 2 ? P.p - 2 : 0.0;
+        eq.rho_ism = med.rho_ism;
+        eq.A = med.type == VAG_MEDIUM_ISM ? 0.0 : med.A;
+        eq.r02 = med.type == VAG_MEDIUM_ISM ? 0.0 : med.r02;
+        rtol = P.rtol;
+        auto node0 = [&](int k) -> double { return M.has_early ? (k == 0 ? t_early_row : lat.node(k - 1)) : lat.node(k); };
+        const double t_first = node0(0);
+        t_last = node0(nt - 1);
+        t0 = dmin(t_first, dmin(0.1 * U_SEC, 0.1 * t_dec));
+        // set_init_state, forward-shock.tpp:120-149
+        const double beta4 = gamma_to_beta(Gamma4);
+        s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
+        s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
+        s[0] = Gamma4;
+        if (role == 0) {  // the integrator's start values (the saver only needs the lattice)
+            s[1] = medium_mass(med, s[3]);
+            s[2] = enclosed_thermal_energy(med, s[3], s[0], adiabatic_idx(s[0]), P.radiative_fireball ? P.eps_e : 0.0);
+        }
+        stopped = s[0] <= GAMMA_CUT;  // set_stopping_shock, shock-physics.h:388-397
+    }
+    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? t_early_row : lat.node(k - 1)) : lat.node(k); };
+    __syncthreads();
+#ifdef VAG_DYN_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);  // HW_REG_HW_ID
+        printf("  role %d: hw_id 0x%08x wave %u simd %u pipe %u cu %u sh %u se %u\n", role, hw, hw & 15, (hw >> 4) & 3, (hw >> 6) & 3,
+               (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7);
+    }
+#endif
+    if (role == 0) {
+        int status;
+        const bool go = active && !stopped;
+        if (__any(go && eq.A != 0)) {
+            status = fs_integrator(eq, s, t0, rtol, t_last, go, eq.lg, ring, lane);
+        } else {  // every row of this wavefront sits in a uniform medium
+            FsRhs<false> ei;
+            ei.m_jet0 = eq.m_jet0, ei.gm_coeff = eq.gm_coeff, ei.inv_gc2 = eq.inv_gc2, ei.eps_e = eq.eps_e, ei.pm2 = eq.pm2;
+            ei.rho_ism = eq.rho_ism, ei.A = 0, ei.r02 = 0, ei.lg = eq.lg;
+            status = fs_integrator(ei, s, t0, rtol, t_last, go, eq.lg, ring, lane);
+        }
+        s_status[lane] = status;
+    } else {
+        int k = 0;
+        if (active && stopped) {  // raw form of the stopped shock: m2 = 0 finishes to Gamma_th = 1, B = N_p = 0
+            for (; k < nt; ++k) {
+                o_teng[k] = node(k);
+                o_tcomv[k] = s[4];
+                o_r[k] = s[3];
+                o_G[k] = 1;
+                o_U[k] = 0;
+                o_B[k] = 0;
+                o_m2[k] = 0;
+            }
+        }
+        const int kk = fs_saver(ring, lane, active && !stopped, nt, node, o_teng, o_tcomv, o_r, o_G, o_U, o_m2);
+        if (active && !stopped) {
+            for (k = kk; k < nt; ++k) {  // unreached nodes keep the Shock constructor's defaults (shock.cpp:12-24)
+                o_teng[k] = node(k);
+                o_tcomv[k] = 0;
+                o_r[k] = 0;
+                o_G[k] = 1;
+                o_U[k] = 0;
+                o_B[k] = 0;
+                o_m2[k] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (role == 1 && active) row_status[row] = stopped ? 0 : s_status[lane];
+}
+
 // ODE rows per outcome (row_status written by the dynamics kernels): fail[s] += 1 for s in {1, 2, 3}.
 __global__ void vag_count_row_status(const int* __restrict__ row_status, int n_rows, int* __restrict__ fail) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,9 +400,10 @@ vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
-                 const double* __restrict__ shock, long long n_cells, double* __restrict__ cellpar,
+                 const double* shock, long long n_cells, double* __restrict__ cellpar,
                  double* __restrict__ cell_details /* optional [11][n_cells] */,
-                 const int* __restrict__ inj_idx /* optional, per row: reverse shock's injection cutoff */) {
+                 const int* __restrict__ inj_idx /* optional, per row: reverse shock's injection cutoff */,
+                 double* raw_shock /* = shock when vag_dynamics_fast_kernel left (U2_th, m2) to be finished */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     // find model by cell offset
@@ -283,6 +422,24 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
     const long long local = c - lay.cell_off[m];
     const int r = (int)(local / nt), k = (int)(local % nt);
     const vag_model_params P = params[m];
+    double c_Gth = shock[VS_GAMMA_TH * n_cells + c], c_B = shock[VS_B * n_cells + c], c_Np = shock[VS_NP * n_cells + c];
+    if (raw_shock) {  // save_fwd_shock_state (forward-shock.tpp:151-173) on the interpolated state of this cell
+        const double m2 = c_Np, U = c_Gth;
+        c_Gth = 1, c_B = 0, c_Np = 0;
+        if (m2 != 0) {
+            Medium med;
+            medium_init(med, P);
+            const double comp = compression_fwd(shock[VS_GAMMA * n_cells + c]);
+            const double rho = medium_rho(med, shock[VS_R * n_cells + c]);
+            c_Gth = U * rcp_fast(m2 * C_C2) + 1;
+            const double e_th = (c_Gth - 1) * (rho * comp) * C_C2;
+            c_B = sqrt_fast(8 * C_PI * P.eps_B * e_th);
+            c_Np = m2 / C_MP;
+        }
+        raw_shock[VS_GAMMA_TH * n_cells + c] = c_Gth;
+        raw_shock[VS_B * n_cells + c] = c_B;
+        raw_shock[VS_NP * n_cells + c] = c_Np;
+    }
     CellOut o;
     ElecBasic inj;
     bool relic = false;
@@ -296,8 +453,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
         }
     }
     syn_cell(o, shock[VS_TENG * n_cells + c], shock[VS_TCOMV * n_cells + c], shock[VS_R * n_cells + c],
-             shock[VS_GAMMA * n_cells + c], shock[VS_GAMMA_TH * n_cells + c], shock[VS_B * n_cells + c],
-             shock[VS_NP * n_cells + c], P.eps_e, P.p, P.xi_e, relic ? &inj : nullptr);
+             shock[VS_GAMMA * n_cells + c], c_Gth, c_B, c_Np, P.eps_e, P.p, P.xi_e, relic ? &inj : nullptr);
     double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
 #pragma unroll
     for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];
