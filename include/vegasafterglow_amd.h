@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 6
+#define VAG_ABI_VERSION 7
 
 /* error codes */
 #define VAG_OK 0
@@ -288,14 +288,31 @@ typedef struct vag_fit_spec {
     int32_t n_bands;            /* band-integrated groups */
     int32_t pad2;
     const vag_band_obs* bands;  /* [n_bands] */
+    /* ABI v7: the bounds mask and the priors of log_prob_batch (fitting/samplers.py:72-91) on the device.
+     * use_priors = 0: the call returns ln L for every walker (ABI v6 behaviour).
+     * use_priors = 1: a walker with any theta[d] outside [lower[d], upper[d]] is NOT evaluated and scores -inf; the others
+     * score ln L + sum_d ln prior_d(theta[d]) with prior_kind[d] one of VAG_PRIOR_* acting on the SAMPLER-space value
+     * (bilby.core.prior.Uniform / Gaussian / LogUniform.ln_prob; params.py:209-227 builds Uniform(lower, upper) by default). */
+    int32_t use_priors;
+    int32_t pad3;
+    double lower[16], upper[16];
+    int32_t prior_kind[16];
+    double prior_a[16]; /* GAUSSIAN: mu;    LOG_UNIFORM: minimum (> 0); UNIFORM: unused (the bounds are the support) */
+    double prior_b[16]; /* GAUSSIAN: sigma; LOG_UNIFORM: maximum */
 } vag_fit_spec;
+#define VAG_PRIOR_UNIFORM 0     /* -ln(upper - lower) */
+#define VAG_PRIOR_GAUSSIAN 1    /* -(x - mu)^2 / (2 sigma^2) - ln(sigma sqrt(2 pi)) */
+#define VAG_PRIOR_LOG_UNIFORM 2 /* -ln(x ln(max / min)) for min <= x <= max, else -inf */
+#define VAG_PRIOR_NONE 3        /* 0 inside the bounds: the caller adds its own ln prior for this parameter */
 
 /* theta is [nb][ndim] (host); out is [nb] log-likelihoods (host).  Walkers whose
  * transformed parameters fail validation get -inf, like eval_one's except branch. */
 int vag_loglike_batch(vag_ctx* ctx, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out);
 
-/* Same with theta/out in HBM; the data arrays of spec are host pointers copied once per call
- * unless identical to the previous call's (cached by content hash). */
+/* Same with theta/out in HBM.  The data arrays of spec are host pointers: their CONTENT is hashed on every call and they are
+ * uploaded (one pinned staging copy) only when it differs from the previous call's, so a sampler loop moves no data.
+ * Stream-ordered on the context stream, but host-blocking: the call returns after the batch's device plan has been read back
+ * (see DESIGN.md "host synchronisation"). */
 int vag_loglike_batch_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim,
                           double* d_out);
 
@@ -370,6 +387,9 @@ typedef struct vag_plan {
     int32_t n_models_capacity; /* adaptive grid larger than the engine limits: NOT evaluated (NaN / -inf) */
     int32_t n_rows_failed;     /* ODE rows without an acceptable step after 500 rejections (error in the reference) */
     int32_t n_rows_gave_up;    /* ODE rows that hit the 100000-step cap or stalled (warning in the reference; row kept) */
+    /* ABI v7, likelihood calls only, tallied over ALL passes (point data + every band group) of the last call */
+    int32_t n_walkers_rejected;   /* walkers scored -inf: out of bounds, invalid parameters, grid over capacity, failed ODE row, SSC failure, non-finite chi2 */
+    int32_t n_walkers_ssc_failed; /* of those: SSC tables over capacity or queried outside their clamped band */
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert lib.vag_abi_version() == 6
+    assert lib.vag_abi_version() == 7
     assert b"gfx950" in lib.vag_version()
 
 
@@ -47,7 +47,10 @@ def test_struct_layouts_match_the_header():
         field = {"tau": "duration", "theta_v": "theta_obs", "eps_e_r": "rvs_eps_e", "eps_B_r": "rvs_eps_B", "p_r": "rvs_p",
                  "xi_e_r": "rvs_xi_e", "L0": "mag_L0", "t0": "mag_t0", "q": "mag_q"}.get(key, key)
         assert getattr(_lib.ModelParams, field).offset == 8 + 8 * slot, key
-    assert C.sizeof(_lib.FitSpec) == 272 + 4 + 64 + 64 + 8 + 5 * 8 + 4 + 8 + 8 + 8 + 8  # ... + ext_kernel, a_v_fixed, n_bands+pad, bands
+    v6 = 272 + 4 + 64 + 64 + 8 + 5 * 8 + 4 + 8 + 8 + 8 + 8  # ... + ext_kernel, a_v_fixed, n_bands+pad, bands
+    assert _lib.FitSpec.use_priors.offset == v6  # ABI v7 appends: use_priors+pad, lower, upper, prior_kind, prior_a, prior_b
+    assert C.sizeof(_lib.FitSpec) == v6 + 8 + 128 + 128 + 64 + 128 + 128
+    assert C.sizeof(_lib.Plan) == 4 + 4 + 5 * 8 + 6 * 4 + 2 * 4
 
 
 def test_defaults_and_validation_through_the_c_abi(lib):

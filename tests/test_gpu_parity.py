@@ -1154,3 +1154,53 @@ def test_loglike_with_more_data_points_than_one_series_launch(eng, oracle):
         model = np.maximum(oracle.flux_density(prm, t, nu), 1e-300)
         chi2 = np.sum(((np.log(f_obs) - np.log(model)) / (err / f_obs)) ** 2)
         assert abs(g - (-0.5 * chi2)) <= 2e-5 * abs(0.5 * chi2) + 1e-6
+
+
+def test_bounds_mask_and_priors_run_on_the_device(eng, oracle):
+    """log_prob_batch of fitting/samplers.py:72-91 in one device call: out-of-bounds walkers score -inf without being evaluated;
+    the others ln L + sum ln prior with Uniform (default), Gaussian and LogUniform priors on the device and an arbitrary
+    ``ln_prob`` object on the host.  The data cache must follow a change of the observations."""
+    f, defs = _c4_fitter(oracle)
+    rng = np.random.default_rng(3)
+    _, lo, hi = f.build_spec(defs)
+    samples = lo + (hi - lo) * rng.random((32, len(defs)))
+    samples[3, 0] = hi[0] + 0.5   # above the upper bound
+    samples[7, 5] = lo[5] - 1e-9  # just below the lower bound
+    ll = f.loglike_batch(samples, defs)
+    inside = np.all((samples >= lo) & (samples <= hi), axis=1)
+    assert (~inside).sum() == 2 and np.isfinite(ll[~inside]).all()  # ln L alone does not mask
+    got = f.log_prob_batch(samples, defs)
+    want = np.where(inside, ll - np.sum(np.log(hi - lo)), -np.inf)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    np.testing.assert_allclose(got[inside], want[inside], rtol=1e-13)
+    assert f.last_plan.n_walkers_rejected == int((~np.isfinite(want)).sum())
+
+    class Gaussian:  # shaped like bilby.core.prior.Gaussian
+        def __init__(self, mu, sigma):
+            self.mu, self.sigma = mu, sigma
+
+    class LogUniform:
+        def __init__(self, minimum, maximum):
+            self.minimum, self.maximum = minimum, maximum
+
+    class Triangle:  # anything with ln_prob stays on the host
+        def ln_prob(self, x):
+            return np.log(np.maximum(1e-300, 1 - np.abs(x - 0.4) / 0.5))
+
+    names = [d.name for d in defs]
+    i_p, i_tc, i_tv = names.index("p"), names.index("theta_c"), names.index("theta_v")
+    priors = {"p": Gaussian(2.3, 0.2), "theta_c": LogUniform(0.01, 0.5), "theta_v": Triangle()}
+    got2 = f.log_prob_batch(samples, defs, priors=priors)
+    uni = [d for d in range(len(defs)) if d not in (i_p, i_tc, i_tv)]
+    lp = -np.sum(np.log(hi[uni] - lo[uni]))
+    lp = lp - 0.5 * ((samples[:, i_p] - 2.3) / 0.2) ** 2 - np.log(0.2 * np.sqrt(2 * np.pi))
+    lp = lp - np.log(samples[:, i_tc] * np.log(0.5 / 0.01)) + Triangle().ln_prob(samples[:, i_tv])
+    want2 = np.where(inside, ll + lp, -np.inf)
+    np.testing.assert_allclose(got2[inside], want2[inside], rtol=1e-12)
+    assert np.all(got2[~inside] == -np.inf)
+    # same spec, new observations: the resident copy must be replaced
+    f2, _ = _c4_fitter(oracle)
+    f2._point_flux = [x * 1.3 for x in f2._point_flux]
+    f2._all_t = None
+    ll2 = f2.loglike_batch(samples[:4], defs)
+    assert not np.allclose(ll2, ll[:4]) and np.allclose(f.loglike_batch(samples[:4], defs), ll[:4], rtol=1e-13)

@@ -61,7 +61,13 @@ class FitSpec(C.Structure):
         ("ln_err", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
         ("ext_kernel", C.POINTER(C.c_double)), ("a_v_fixed", C.c_double), ("n_bands", C.c_int32), ("pad2", C.c_int32),
         ("bands", C.POINTER(BandObs)),
+        # ABI v7: bounds mask + priors on the device
+        ("use_priors", C.c_int32), ("pad3", C.c_int32), ("lower", C.c_double * 16), ("upper", C.c_double * 16),
+        ("prior_kind", C.c_int32 * 16), ("prior_a", C.c_double * 16), ("prior_b", C.c_double * 16),
     ]
+
+
+PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_LOG_UNIFORM, PRIOR_NONE = 0, 1, 2, 3
 
 
 class DetailsShape(C.Structure):
@@ -83,7 +89,8 @@ class Plan(C.Structure):
                 ("eat_cells", C.c_int64), ("spec_evals", C.c_int64), ("interps", C.c_int64),
                 ("flux_blocks", C.c_int32), ("pairs_per_block", C.c_int32),
                 ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32),
-                ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32)]
+                ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32),
+                ("n_walkers_rejected", C.c_int32), ("n_walkers_ssc_failed", C.c_int32)]
 
 
 class Limits(C.Structure):

@@ -289,8 +289,15 @@ struct vag_ctx {
     HostBuf h_meta, h_off;
     // compact per-row / per-cell storage
     DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
-    // fit spec cache
-    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux, d_chi2, d_bandobs;
+    // fit spec cache (upload_fit_spec): content hash of what d_fit holds, its size, where the prior block starts
+    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux, d_chi2, d_bandobs, d_fitstat;
+    HostBuf h_fit;
+    uint64_t fit_hash = 0;
+    size_t fit_doubles = 0, fit_prior_off = 0;
+    bool fit_hash_valid = false;
+    bool fit_stats_pending = false;  // d_fitstat of the last likelihood call not read back yet
+    bool ic_need_reset = true;       // first SSC table build of a pass clears d_icstatus
+    bool ic_soft_fail = false;       // likelihood calls: SSC table failures invalidate the walker instead of raising
     // plan of the last grid pass
     int nb = 0, n_rows = 0, max_k = 0, max_pairs = 0;
     long long n_cells = 0, total_pairs = 0, eat_cells = 0;
@@ -441,6 +448,8 @@ void vag_ctx_destroy(vag_ctx* c) {
         b->release();
     c->h_meta.release();
     c->h_off.release();
+    c->h_fit.release();
+    c->d_fitstat.release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -465,6 +474,14 @@ static int read_row_failures(vag_ctx* c) {
     }
     c->plan.n_rows_failed = f[1];
     c->plan.n_rows_gave_up = f[2] + f[3];
+    if (c->fit_stats_pending && c->d_fitstat.p) {  // the last likelihood call's tallies over ALL of its passes
+        int fs[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(fs, c->d_fitstat.p, sizeof fs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->plan.n_walkers_rejected = fs[0];
+        c->plan.n_walkers_ssc_failed = fs[1];
+        c->fit_stats_pending = false;
+    }
     return VAG_OK;
 }
 
@@ -573,11 +590,14 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->h_off.ensure((sizeof(int) + sizeof(long long)) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
+    if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
 
+    c->ic_need_reset = true;
     HIPCHK(hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                        c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
-                       c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>());
+                       c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
+                       c->d_fail.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], st));
     // grid shapes decide the compact layout and the launch geometry of everything downstream
@@ -632,6 +652,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->eat_cells = eat;
     c->n_ok = n_ok;
     c->plan = vag_plan{};
+    c->fit_stats_pending = false;
     c->plan.n_models_ok = n_ok;
     c->plan.n_rows = rows;
     c->plan.n_cells = cells;
@@ -661,14 +682,14 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         hipLaunchKernelGGL(vag_dynamics_pair_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
-                           c->d_inj.as<int>(), c->d_row_status.as<int>());
+                           c->d_inj.as<int>(), c->d_row_status.as<int>(), c->d_fail.as<int>());
     } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
         const int rpw = dyn_rows_per_wave(rows);
         hipLaunchKernelGGL(vag_dynamics_fast_kernel, dim3((rows + rpw - 1) / rpw), dim3(128), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>(),
-                           c->d_sptab.as<double>(), rpw);
+                           c->d_sptab.as<double>(), rpw, c->d_fail.as<int>());
     } else {
         const bool inject = (c->batch_flags & VAG_FLAG_MAGNETAR) != 0;
         auto kern = spreading ? (inject ? vag_dynamics_kernel<true, true> : vag_dynamics_kernel<true, false>)
@@ -676,13 +697,9 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         const int rpw = dyn_rows_per_wave(rows);
         hipLaunchKernelGGL(kern, dim3((rows + rpw - 1) / rpw), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                            c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
-                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>(), rpw);
+                           c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>(), rpw,
+                           c->d_fail.as<int>());
     }
-    HIPCHK(hipGetLastError());
-    if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
-    HIPCHK(hipMemsetAsync(c->d_fail.p, 0, sizeof(int) * 4, st));
-    hipLaunchKernelGGL(vag_count_row_status, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_status.as<int>(), rows,
-                       c->d_fail.as<int>());
     HIPCHK(hipGetLastError());
     if (spreading) {  // per-cell viewing geometry from the evolved theta (both shocks ride the same contact discontinuity)
         if (c->d_cellgeo.ensure(sizeof(double) * (size_t)cells * 3)) return VAG_E_HIP;
@@ -844,7 +861,9 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
     if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
-    HIPCHK(hipMemsetAsync(c->d_icstatus.p, 0, sizeof(int) * (size_t)nb, st));
+    if (!c->ic_soft_fail || c->ic_need_reset)  // a likelihood pass ORs the failures of both shocks' tables into one status per walker
+        HIPCHK(hipMemsetAsync(c->d_icstatus.p, 0, sizeof(int) * (size_t)nb, st));
+    c->ic_need_reset = false;
     if (c->n_rows > 0) {
         Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
         hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
@@ -862,6 +881,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
 }
 
 int check_ic_status(vag_ctx* c, int nb) {
+    if (c->ic_soft_fail) return VAG_OK;  // vag_fit_back_kernel folds d_icstatus into the walker's validity (-inf), samplers.py:61-70
     hipStream_t st = c->stream;
     std::vector<int> h(nb);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_icstatus.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
@@ -1042,9 +1062,15 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
     return rc;
 }
 
-__global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
-                                         const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
-                                         double* __restrict__ out) {
+// Fixed-order sum of the workgroup partials of a series request.  A workgroup is 64 points x 4 block groups: group g adds the
+// partial blocks b = g, g + 4, ... with four loads in flight, then the four group sums are added in order -- the same
+// result run to run, and the walk over up to a few hundred blocks is no longer one dependent load after another
+// (63 us per 128-walker call before).
+__global__ void __launch_bounds__(256)
+vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
+                         const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
+                         double* __restrict__ out) {
+    __shared__ double s_part[4][64];
     const int m = blockIdx.y;
     const VagGridMeta M = meta[m];
     const vag_model_params P = params[m];
@@ -1052,9 +1078,23 @@ __global__ void vag_series_reduce_kernel(const vag_model_params* __restrict__ pa
     const double d_L = P.lumi_dist * U_CM;
     const double norm = (1 + P.z) / (d_L * d_L);
     const double* src = partial + (size_t)m * max_blocks * n;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        double v = 0;
-        for (int b = 0; b < nblk; ++b) v += src[(size_t)b * n + s];
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 64 + lane;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (s < n) {
+        int b = g;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += src[(size_t)b * n + s];
+            a1 += src[(size_t)(b + 4) * n + s];
+            a2 += src[(size_t)(b + 8) * n + s];
+            a3 += src[(size_t)(b + 12) * n + s];
+        }
+        for (; b < nblk; b += 4) a0 += src[(size_t)b * n + s];
+    }
+    s_part[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && s < n) {
+        const double v = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
         out[(size_t)m * n + s] = (M.status == 0) ? (v * norm) / U_FLUX_DEN_CGS : NAN;
     }
 }
@@ -1133,7 +1173,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, st, d_params,
+    hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params,
                        c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, (int)ppb, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
@@ -1598,6 +1638,16 @@ static int upload_series_bands(vag_ctx* c, const double* nu, int n) {
     return nbands;
 }
 
+// ---- fit data cache: the observation arrays, the slot map and the priors of a vag_fit_spec live in ONE device buffer, uploaded
+//      through one pinned staging copy only when their content hash changes (a sampler loop calls with the same spec) ----
+// layout in doubles: [t | nu | ln_flux | ln_err | weight | ext] (n each), then per band group [t | ln_flux | ln_err | weight]
+// (bd.n each), then [lower | upper | prior_a | prior_b] (16 each), then int32 [slot | is_log | prior_kind] (16 each).
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
 static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
     if (ndim != spec->ndim || ndim <= 0 || ndim > 16) return set_err(VAG_E_INVALID, "ndim must match spec and be in 1..16");
     const int n = spec->n_data;
@@ -1607,79 +1657,190 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
         if (s == VAG_P_A_V) continue;
         if (s < 0 || (s >= VAG_P_COUNT && (s < VAG_P_RVS_EPS_E || s > VAG_P_MAG_Q))) return set_err(VAG_E_INVALID, "bad parameter slot");
     }
+    if (spec->use_priors)
+        for (int d = 0; d < ndim; ++d) {
+            if (!(spec->lower[d] < spec->upper[d])) return set_err(VAG_E_INVALID, "prior bounds of parameter %d: need lower < upper", d);
+            const int k = spec->prior_kind[d];
+            if (k < VAG_PRIOR_UNIFORM || k > VAG_PRIOR_NONE) return set_err(VAG_E_INVALID, "unknown prior kind %d", k);
+            if (k == VAG_PRIOR_GAUSSIAN && !(spec->prior_b[d] > 0)) return set_err(VAG_E_INVALID, "Gaussian prior needs sigma > 0");
+            if (k == VAG_PRIOR_LOG_UNIFORM && !(spec->prior_a[d] > 0 && spec->prior_b[d] > spec->prior_a[d]))
+                return set_err(VAG_E_INVALID, "LogUniform prior needs 0 < minimum < maximum");
+        }
+    uint64_t h = 1469598103934665603ull;
+    const int head[4] = {n, spec->n_bands, ndim, spec->ext_kernel ? 1 : 0};
+    h = fnv1a(h, head, sizeof head);
+    size_t total = 6 * (size_t)std::max(n, 1);
+    for (const double* arr : {spec->t, spec->nu, spec->ln_flux, spec->ln_err, spec->weight, spec->ext_kernel})
+        if (arr && n > 0) h = fnv1a(h, arr, sizeof(double) * n);
+    for (int g = 0; g < spec->n_bands; ++g) {
+        const vag_band_obs& bd = spec->bands[g];
+        if (bd.n <= 0) return set_err(VAG_E_INVALID, "band group %d has no observations", g);
+        h = fnv1a(h, &bd.n, sizeof bd.n);
+        for (const double* arr : {bd.t, bd.ln_flux, bd.ln_err, bd.weight}) h = fnv1a(h, arr, sizeof(double) * bd.n);
+        total += 4 * (size_t)bd.n;
+    }
+    h = fnv1a(h, spec->slot, sizeof spec->slot);
+    h = fnv1a(h, spec->is_log, sizeof spec->is_log);
+    h = fnv1a(h, &spec->use_priors, sizeof spec->use_priors);
+    if (spec->use_priors) {
+        h = fnv1a(h, spec->lower, sizeof spec->lower);
+        h = fnv1a(h, spec->upper, sizeof spec->upper);
+        h = fnv1a(h, spec->prior_kind, sizeof spec->prior_kind);
+        h = fnv1a(h, spec->prior_a, sizeof spec->prior_a);
+        h = fnv1a(h, spec->prior_b, sizeof spec->prior_b);
+    }
+    const size_t prior_off = total;
+    total += 4 * 16 + 3 * 16 / 2;  // four double[16] + three int32[16]
+    c->fit_prior_off = prior_off;
+    if (c->fit_hash_valid && c->fit_hash == h && c->fit_doubles == total) return VAG_OK;  // resident already
+
+    // content changed: validate it (once), stage and upload
     for (int i = 0; i < n; ++i)
         if (!(spec->t[i] > 0)) return set_err(VAG_E_INVALID, "data times must be positive");
     for (int i = 1; i < n; ++i)
         if (spec->t[i] < spec->t[i - 1]) return set_err(VAG_E_INVALID, "data times must be ascending (fitter.py:420-428)");
     for (int g = 0; g < spec->n_bands; ++g) {
         const vag_band_obs& bd = spec->bands[g];
-        if (bd.n <= 0) return set_err(VAG_E_INVALID, "band group %d has no observations", g);
         for (int i = 0; i < bd.n; ++i)
             if (!(bd.t[i] > 0) || (i > 0 && bd.t[i] < bd.t[i - 1]))
                 return set_err(VAG_E_INVALID, "band group %d: times must be positive and ascending", g);
     }
-    // [t | nu | ln_flux | ln_err | weight | ext_kernel]
-    if (c->d_fit.ensure(sizeof(double) * 6 * (size_t)std::max(n, 1))) return VAG_E_HIP;
-    if (c->d_slot.ensure(sizeof(int) * 32)) return VAG_E_HIP;
-    double* d = c->d_fit.as<double>();
+    c->fit_hash_valid = false;
+    HIPCHK(hipStreamSynchronize(c->stream));  // an earlier staging copy may still be in flight
+    if (c->h_fit.ensure(sizeof(double) * total)) return VAG_E_HIP;
+    if (c->d_fit.ensure(sizeof(double) * total)) return VAG_E_HIP;
+    double* hp = c->h_fit.as<double>();
+    std::memset(hp, 0, sizeof(double) * total);
     if (n > 0) {
-        HIPCHK(hipMemcpyAsync(d, spec->t, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d + n, spec->nu, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d + 2 * (size_t)n, spec->ln_flux, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d + 3 * (size_t)n, spec->ln_err, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(d + 4 * (size_t)n, spec->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        if (spec->ext_kernel)
-            HIPCHK(hipMemcpyAsync(d + 5 * (size_t)n, spec->ext_kernel, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        const double* src[6] = {spec->t, spec->nu, spec->ln_flux, spec->ln_err, spec->weight, spec->ext_kernel};
+        for (int q = 0; q < 6; ++q)
+            if (src[q]) std::memcpy(hp + (size_t)q * n, src[q], sizeof(double) * n);
     }
-    HIPCHK(hipMemcpyAsync(c->d_slot.p, spec->slot, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_slot.as<int>() + 16, spec->is_log, sizeof(int) * 16, hipMemcpyHostToDevice, c->stream));
+    size_t off = 6 * (size_t)std::max(n, 1);
+    for (int g = 0; g < spec->n_bands; ++g) {
+        const vag_band_obs& bd = spec->bands[g];
+        const double* src[4] = {bd.t, bd.ln_flux, bd.ln_err, bd.weight};
+        for (int q = 0; q < 4; ++q) std::memcpy(hp + off + (size_t)q * bd.n, src[q], sizeof(double) * bd.n);
+        off += 4 * (size_t)bd.n;
+    }
+    std::memcpy(hp + prior_off, spec->lower, sizeof spec->lower);
+    std::memcpy(hp + prior_off + 16, spec->upper, sizeof spec->upper);
+    std::memcpy(hp + prior_off + 32, spec->prior_a, sizeof spec->prior_a);
+    std::memcpy(hp + prior_off + 48, spec->prior_b, sizeof spec->prior_b);
+    int* hi = reinterpret_cast<int*>(hp + prior_off + 64);
+    std::memcpy(hi, spec->slot, sizeof spec->slot);
+    std::memcpy(hi + 16, spec->is_log, sizeof spec->is_log);
+    std::memcpy(hi + 32, spec->prior_kind, sizeof spec->prior_kind);
+    HIPCHK(hipMemcpyAsync(c->d_fit.p, hp, sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+    c->fit_hash = h;
+    c->fit_doubles = total;
+    c->fit_hash_valid = true;
     return VAG_OK;
 }
 
-// valid[m] &= the model came through this pass (grid fits the engine, no ODE row failed); a walker whose Model raises
-// in the reference is caught by eval_one and scored -inf (samplers.py:61-70)
-__global__ void vag_update_valid(const VagGridMeta* meta, int nb, int* valid, int first) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < nb) valid[m] = (first ? 1 : valid[m]) && meta[m].status == 0;
-}
-__global__ void vag_invalidate_failed_rows(const int* __restrict__ row_status, const int* __restrict__ row_off, int nb,
-                                           int n_rows, int* __restrict__ valid) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_rows && row_status[r] == 1) valid[vag::find_model(row_off, nb, r)] = 0;
-}
-
-// chi2[m] (+)= sum_i w_i ((ln F_obs,i - ln max(F_model,i e^{-A_V k_i}, 1e-300)) / sigma_i)^2  (Fitter._chi2_sum, fitter.py:497-501,
-// with the extinction factor of fitter.py:512-519); one wavefront per walker
-__global__ void __launch_bounds__(64)
-vag_chi2_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const double* __restrict__ ln_flux,
-                const double* __restrict__ ln_err, const double* __restrict__ weight, const double* __restrict__ ext /* or null */,
-                const double* __restrict__ a_v /* [nb] */, double* __restrict__ chi2, int accumulate) {
-    const int m = blockIdx.x;
-    const double av = (ext != nullptr) ? a_v[m] : 0.0;
-    double s = 0;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        double f = flux[(size_t)m * n + i];
-        if (av != 0.0) f = f * exp(-av * ext[i]);
-        const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300);
-        const double q = (ln_flux[i] - log(fm)) / ln_err[i];
-        s += weight[i] * (q * q);
+// The front of a likelihood call, one launch: bounds mask and ln prior (log_prob_batch, fitting/samplers.py:72-91), the
+// transformer of fitting/utils.py:110-135 (theta[nb][ndim] -> params[nb], 10^theta for log-scale parameters), A_V per walker,
+// and -- block 0 -- log2 of the point data's times / frequencies and their time extrema for the grid stage.
+__global__ void __launch_bounds__(128)
+vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, int nb, int ndim, const double* __restrict__ prior,
+                     int use_priors, double a_v_fixed, vag_model_params* __restrict__ out, double* __restrict__ a_v,
+                     double* __restrict__ ln_prior, int* __restrict__ fitstat, const double* __restrict__ t, int n,
+                     const double* __restrict__ nu, double* __restrict__ lg2_t, double* __restrict__ lg2_nu,
+                     double* __restrict__ tminmax) {
+    const int* slot = reinterpret_cast<const int*>(prior + 64);
+    const int* is_log = slot + 16;
+    const int* kind = slot + 32;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 4) fitstat[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            lg2_t[i] = log2(t[i] * U_SEC);  // xt::log2(t_obs), observer.h:359
+            lg2_nu[i] = log2(nu[i] * U_HZ);
+        }
+        if (threadIdx.x == 0 && n > 0) {  // ascending data (fitter.py:420-428)
+            tminmax[0] = t[0];
+            tminmax[1] = t[n - 1];
+        }
     }
-    s = vag::wave_sum(s);
-    if (threadIdx.x == 0) chi2[m] = accumulate ? chi2[m] + s : s;
-}
-__global__ void vag_finish_loglike(const double* __restrict__ chi2, const int* __restrict__ valid, int nb, double* __restrict__ out) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < nb) out[m] = (valid[m] && isfinite(chi2[m])) ? -0.5 * chi2[m] : -INFINITY;
-}
-// A_V per walker: the free parameter with slot VAG_P_A_V (10^theta for log-scale), else the fixed value
-__global__ void vag_av_kernel(const double* __restrict__ theta, int nb, int ndim, const int* __restrict__ slot,
-                              const int* __restrict__ is_log, double a_v_fixed, double* __restrict__ a_v) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    double v = a_v_fixed;
-    for (int d = 0; d < ndim; ++d)
-        if (slot[d] == VAG_P_A_V) v = is_log[d] ? pow(10.0, theta[(size_t)b * ndim + d]) : theta[(size_t)b * ndim + d];
-    a_v[b] = v;
+    vag_model_params p = base;
+    double* f = &p.theta_c;
+    double av = a_v_fixed, lp = 0;
+    bool inside = true;
+    for (int d = 0; d < ndim; ++d) {
+        const double v = theta[(size_t)b * ndim + d];
+        if (use_priors) {
+            const double lo = prior[d], hi = prior[16 + d];
+            inside = inside && (v >= lo) && (v <= hi);
+            if (kind[d] == VAG_PRIOR_GAUSSIAN) {
+                const double z = (v - prior[32 + d]) / prior[48 + d];
+                lp += -0.5 * z * z - log(prior[48 + d] * 2.5066282746310002);
+            } else if (kind[d] == VAG_PRIOR_LOG_UNIFORM) {
+                const double mn = prior[32 + d], mx = prior[48 + d];
+                lp += (v >= mn && v <= mx) ? -log(v * log(mx / mn)) : -INFINITY;
+            } else if (kind[d] == VAG_PRIOR_UNIFORM) {
+                lp += -log(hi - lo);
+            }
+        }
+        const double val = is_log[d] ? pow(10.0, v) : v;
+        if (slot[d] == VAG_P_A_V)
+            av = val;  // not a Model field: scales the point-data fluxes (fitter.py:512-519)
+        else
+            f[slot[d]] = val;
+    }
+    if (!inside) {  // never evaluated by the reference either: an invalid parameter set stops at the grid stage with no work
+        p.theta_c = NAN;
+        lp = -INFINITY;
+    }
+    out[b] = p;
+    a_v[b] = av;
+    ln_prior[b] = use_priors ? lp : 0.0;
+}
+
+// The back of one pass of a likelihood call, one wavefront per walker:
+//   chi2[m] (+)= sum_i w_i ((ln F_obs,i - ln max(F_model,i e^{-A_V k_i}, 1e-300)) / sigma_i)^2   (Fitter._chi2_sum, fitter.py:497-501,
+//   with the extinction factor of fitter.py:512-519);
+//   valid[m] &= this pass evaluated the walker -- parameters valid, grid within the engine limits, no ODE row without an acceptable
+//   step, SSC tables within their capacity -- else the walker scores -inf like eval_one's except branch (samplers.py:61-70);
+//   last pass: out[m] = valid ? -chi2 / 2 + ln prior : -inf.
+__global__ void __launch_bounds__(64)
+vag_fit_back_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const double* __restrict__ ln_flux,
+                    const double* __restrict__ ln_err, const double* __restrict__ weight, const double* __restrict__ ext /* or null */,
+                    const double* __restrict__ a_v, const VagGridMeta* __restrict__ meta, const int* __restrict__ row_status,
+                    const int* __restrict__ row_off, const int* __restrict__ ic_status /* or null */, double* __restrict__ chi2,
+                    int* __restrict__ valid, const double* __restrict__ ln_prior, int first, int last, double* __restrict__ out,
+                    int* __restrict__ fitstat /* [0] walkers scored -inf, [1] of those: SSC table failures */) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const double av = (ext != nullptr) ? a_v[m] : 0.0;
+    const bool grid_ok = meta[m].status == 0;
+    double s = 0;
+    if (grid_ok)
+        for (int i = lane; i < n; i += 64) {
+            double f = flux[(size_t)m * n + i];
+            if (av != 0.0) f = f * exp(-av * ext[i]);
+            const double fm = (f != f) ? f : (f > 1e-300 ? f : 1e-300);
+            const double q = (ln_flux[i] - log(fm)) / ln_err[i];
+            s += weight[i] * (q * q);
+        }
+    s = vag::wave_sum(s);
+    bool bad_row = false;
+    if (grid_ok)
+        for (int r = row_off[m] + lane; r < row_off[m + 1]; r += 64) bad_row = bad_row || row_status[r] == 1;
+    const bool any_bad = __any(bad_row);
+    if (lane == 0) {
+        const bool ic_bad = grid_ok && ic_status && ic_status[m] != 0;
+        const int ok = (first ? 1 : valid[m]) && grid_ok && !any_bad && !ic_bad;
+        const double acc = first ? s : chi2[m] + s;
+        valid[m] = ok;
+        chi2[m] = acc;
+        if (ic_bad) atomicAdd(fitstat + 1, 1);
+        if (last) {
+            const double lp = ln_prior[m];
+            const bool fin = ok && isfinite(acc) && lp > -INFINITY;
+            out[m] = fin ? -0.5 * acc + lp : -INFINITY;
+            if (!fin) atomicAdd(fitstat, 1);
+        }
+    }
 }
 
 int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
@@ -1692,63 +1853,59 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     hipStream_t st = c->stream;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
     if (c->d_valid.ensure(sizeof(int) * nb)) return VAG_E_HIP;
-    if (c->d_chi2.ensure(sizeof(double) * 2 * (size_t)nb)) return VAG_E_HIP;  // [chi2 | A_V]
+    if (c->d_chi2.ensure(sizeof(double) * 3 * (size_t)nb)) return VAG_E_HIP;  // [chi2 | A_V | ln prior]
+    if (c->d_fitstat.ensure(sizeof(int) * 4)) return VAG_E_HIP;
+    if (c->d_lg2t.ensure(sizeof(double) * std::max(n, 1))) return VAG_E_HIP;
+    if (c->d_lg2nu.ensure(sizeof(double) * std::max(n, 1))) return VAG_E_HIP;
+    if (c->d_tminmax.ensure(sizeof(double) * 2)) return VAG_E_HIP;
     double* d_chi2 = c->d_chi2.as<double>();
     double* d_av = d_chi2 + nb;
+    double* d_lp = d_chi2 + 2 * (size_t)nb;
+    double* d = c->d_fit.as<double>();
+    const double* d_prior = d + c->fit_prior_off;
     vag_model_params* d_params = c->d_params.as<vag_model_params>();
-    hipLaunchKernelGGL(vag_transform_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, spec->base, d_theta, nb, ndim,
-                       c->d_slot.as<int>(), c->d_slot.as<int>() + 16, d_params);
-    hipLaunchKernelGGL(vag_av_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, d_theta, nb, ndim, c->d_slot.as<int>(),
-                       c->d_slot.as<int>() + 16, spec->a_v_fixed, d_av);
+    hipLaunchKernelGGL(vag_fit_front_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, spec->base, d_theta, nb, ndim, d_prior,
+                       spec->use_priors, spec->a_v_fixed, d_params, d_av, d_lp, c->d_fitstat.as<int>(), d, n, d + n,
+                       c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), c->d_tminmax.as<double>());
     HIPCHK(hipGetLastError());
-    bool first = true;
-    auto after_pass = [&]() -> int {  // fold this pass's per-model status into valid[]
-        hipLaunchKernelGGL(vag_update_valid, dim3((nb + 127) / 128), dim3(128), 0, st, c->d_meta.as<VagGridMeta>(), nb,
-                           c->d_valid.as<int>(), first ? 1 : 0);
-        if (c->n_rows > 0)
-            hipLaunchKernelGGL(vag_invalidate_failed_rows, dim3((c->n_rows + 255) / 256), dim3(256), 0, st,
-                               c->d_row_status.as<int>(), c->d_row_off.as<int>(), nb, c->n_rows, c->d_valid.as<int>());
+    const int n_pass = (n > 0 ? 1 : 0) + spec->n_bands;
+    int pass = 0, n_cap = 0, n_inv = 0;  // per-pass rejection counts: the call reports the worst pass
+    // the SSC tables of a pass report per-model failures in d_icstatus: in a fit they invalidate the walker, they do not raise
+    auto back = [&](const double* flux, int npts, const double* lnf, const double* lne, const double* w, const double* ext) -> int {
+        const bool ssc = (c->batch_flags & (VAG_FLAG_SSC | VAG_FLAG_RVS_SSC)) != 0;
+        hipLaunchKernelGGL(vag_fit_back_kernel, dim3(nb), dim3(64), 0, st, flux, npts, lnf, lne, w, ext, d_av,
+                           c->d_meta.as<VagGridMeta>(), c->d_row_status.as<int>(), c->d_row_off.as<int>(),
+                           (ssc && c->d_icstatus.p) ? c->d_icstatus.as<int>() : nullptr, d_chi2, c->d_valid.as<int>(), d_lp,
+                           pass == 0 ? 1 : 0, pass == n_pass - 1 ? 1 : 0, d_out, c->d_fitstat.as<int>());
         HIPCHK(hipGetLastError());
+        ++pass;
+        n_cap = std::max(n_cap, c->plan.n_models_capacity);
+        n_inv = std::max(n_inv, c->plan.n_models_invalid);
         return VAG_OK;
     };
+    c->ic_soft_fail = true;
     if (n > 0) {  // point data: one (t, nu) series per walker (fitter.py:510-522)
         if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
-        double* d = c->d_fit.as<double>();
-        rc = prep_times(c, d, n, d + n, n);
-        if (rc) return rc;
         rc = run_model_stages(c, d_params, nb, false);
-        if (rc) return rc;
-        rc = series_request(c, d_params, nb, n, c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
-        if (rc) return rc;
-        rc = after_pass();
-        if (rc) return rc;
-        hipLaunchKernelGGL(vag_chi2_kernel, dim3(nb), dim3(64), 0, st, c->d_series_flux.as<double>(), n, d + 2 * (size_t)n,
-                           d + 3 * (size_t)n, d + 4 * (size_t)n, spec->ext_kernel ? d + 5 * (size_t)n : nullptr, d_av, d_chi2, 0);
-        HIPCHK(hipGetLastError());
-        first = false;
+        if (rc == VAG_OK) rc = series_request(c, d_params, nb, n, c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
+        if (rc == VAG_OK)
+            rc = back(c->d_series_flux.as<double>(), n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n,
+                      spec->ext_kernel ? d + 5 * (size_t)n : nullptr);
     }
-    for (int g = 0; g < spec->n_bands; ++g) {  // band-integrated groups: one Model.flux request each (fitter.py:524-531)
+    size_t off = 6 * (size_t)std::max(n, 1);
+    for (int g = 0; g < spec->n_bands && rc == VAG_OK; ++g) {  // band-integrated groups: one Model.flux request each (fitter.py:524-531)
         const vag_band_obs& bd = spec->bands[g];
-        if (c->d_bandobs.ensure(sizeof(double) * 4 * (size_t)bd.n)) return VAG_E_HIP;
         if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * std::max(bd.n, n))) return VAG_E_HIP;
-        double* db = c->d_bandobs.as<double>();
-        HIPCHK(hipMemcpyAsync(db, bd.t, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(db + bd.n, bd.ln_flux, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(db + 2 * (size_t)bd.n, bd.ln_err, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(db + 3 * (size_t)bd.n, bd.weight, sizeof(double) * bd.n, hipMemcpyHostToDevice, st));
-        rc = band_request_dev(c, d_params, nb, db, bd.n, bd.nu_min, bd.nu_max, bd.num_points, c->d_series_flux.as<double>(),
-                              nullptr);
-        if (rc) return rc;
-        rc = after_pass();
-        if (rc) return rc;
-        hipLaunchKernelGGL(vag_chi2_kernel, dim3(nb), dim3(64), 0, st, c->d_series_flux.as<double>(), bd.n, db + bd.n,
-                           db + 2 * (size_t)bd.n, db + 3 * (size_t)bd.n, nullptr, d_av, d_chi2, first ? 0 : 1);
-        HIPCHK(hipGetLastError());
-        first = false;
+        double* db = d + off;
+        off += 4 * (size_t)bd.n;
+        rc = band_request_dev(c, d_params, nb, db, bd.n, bd.nu_min, bd.nu_max, bd.num_points, c->d_series_flux.as<double>(), nullptr);
+        if (rc == VAG_OK) rc = back(c->d_series_flux.as<double>(), bd.n, db + bd.n, db + 2 * (size_t)bd.n, db + 3 * (size_t)bd.n, nullptr);
     }
-    hipLaunchKernelGGL(vag_finish_loglike, dim3((nb + 127) / 128), dim3(128), 0, st, d_chi2, c->d_valid.as<int>(), nb, d_out);
-    HIPCHK(hipGetLastError());
-    return VAG_OK;
+    c->ic_soft_fail = false;
+    c->plan.n_models_capacity = n_cap;
+    c->plan.n_models_invalid = n_inv;
+    c->fit_stats_pending = true;
+    return rc;
 }
 
 int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {

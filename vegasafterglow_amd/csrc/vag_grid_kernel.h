@@ -189,10 +189,12 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 VagGridMeta* __restrict__ meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
                 double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
-                double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */) {
+                double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */,
+                int* __restrict__ fail /* [4] ODE-row failure counters of the dynamics stage, reset here */) {
     const int m = blockIdx.x;
     if (m >= nb) return;
     const int lane = threadIdx.x;
+    if (m == 0 && lane < 4) fail[lane] = 0;
     __shared__ GridShared sh;
     const vag_model_params P = params[m];
     const double t_min_s = tminmax[0], t_max_s = tminmax[1];

@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(64)
 vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                     const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
-                    long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave) {
+                    long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave,
+                    int* __restrict__ fail /* [4]: rows per non-zero status, zeroed by vag_grid_kernel */) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];  // log2_tab's table for the right-hand sides
     for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
     __syncthreads();
@@ -192,6 +193,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
         if constexpr (SPREAD) o_th[k] = 0;
     }
     row_status[row] = status;
+    if (status > 0 && status < 4) atomicAdd(fail + status, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -204,7 +206,8 @@ __global__ void __launch_bounds__(128)
 vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                          const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
-                         long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave) {
+                         long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave,
+                         int* __restrict__ fail) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
     __shared__ DynRing ring;
     __shared__ int s_status[64];
@@ -326,15 +329,10 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
         }
     }
     __syncthreads();
-    if (role == 1 && active) row_status[row] = stopped ? 0 : s_status[lane];
-}
-
-// ODE rows per outcome (row_status written by the dynamics kernels): fail[s] += 1 for s in {1, 2, 3}.
-__global__ void vag_count_row_status(const int* __restrict__ row_status, int n_rows, int* __restrict__ fail) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_rows) {
-        const int s = row_status[r];
-        if (s > 0 && s < 4) atomicAdd(fail + s, 1);
+    if (role == 1 && active) {
+        const int status = stopped ? 0 : s_status[lane];
+        row_status[row] = status;
+        if (status > 0 && status < 4) atomicAdd(fail + status, 1);
     }
 }
 

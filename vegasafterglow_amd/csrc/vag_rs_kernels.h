@@ -31,7 +31,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
                          const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock_fwd,
                          double* __restrict__ shock_rvs, long long n_cells, int* __restrict__ inj_idx,
-                         int* __restrict__ row_status) {
+                         int* __restrict__ row_status, int* __restrict__ fail) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const int m = find_model(lay.row_off, nb, row);
@@ -199,6 +199,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     }
     inj_idx[row] = inj;
     row_status[row] = status;
+    if (status > 0 && status < 4) atomicAdd(fail + status, 1);
     // reverse_shock_early_extrap, reverse-shock.tpp:428-469 (this lane re-reads its own row)
     {
         const double* Gth = R + VS_GAMMA_TH * n_cells;

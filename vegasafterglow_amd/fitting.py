@@ -76,6 +76,31 @@ MODEL_PARAM_DEFAULTS = dict(theta_v=0.0, n_ism=0.0, n0=math.inf, A_star=0.0, k_m
 _dp = C.POINTER(C.c_double)
 
 
+def _device_prior(prior):
+    """(VAG_PRIOR_* kind, a, b) of a prior the device evaluates itself; PRIOR_NONE hands an unknown object's ln_prob to the host.
+    Recognised by shape, not by import: bilby.core.prior.Uniform(minimum, maximum) -- taken as the ParamDef's own Uniform --,
+    Gaussian(mu, sigma), LogUniform(minimum, maximum), or tuples ("uniform",), ("gaussian", mu, sigma), ("log_uniform", lo, hi)."""
+    if prior is None:
+        return _lib.PRIOR_UNIFORM, 0.0, 0.0
+    if isinstance(prior, (tuple, list)):
+        name = str(prior[0]).lower()
+        if name == "uniform":
+            return _lib.PRIOR_UNIFORM, 0.0, 0.0
+        if name in ("gaussian", "normal"):
+            return _lib.PRIOR_GAUSSIAN, float(prior[1]), float(prior[2])
+        if name in ("log_uniform", "loguniform"):
+            return _lib.PRIOR_LOG_UNIFORM, float(prior[1]), float(prior[2])
+        raise ValueError(f"unknown prior {prior!r}")
+    cls = type(prior).__name__
+    if cls in ("Gaussian", "Normal") and hasattr(prior, "mu") and hasattr(prior, "sigma"):
+        return _lib.PRIOR_GAUSSIAN, float(prior.mu), float(prior.sigma)
+    if cls == "LogUniform" and hasattr(prior, "minimum") and hasattr(prior, "maximum"):
+        return _lib.PRIOR_LOG_UNIFORM, float(prior.minimum), float(prior.maximum)
+    if not hasattr(prior, "ln_prob"):
+        raise ValueError(f"prior {prior!r} has no ln_prob")
+    return _lib.PRIOR_NONE, 0.0, 0.0
+
+
 class Fitter:
     """Fitter(z, lumi_dist, jet=..., medium=..., resolution=..., rtol=...) for point flux-density data."""
 
@@ -260,8 +285,10 @@ class Fitter:
             p.rvs_eps_e, p.rvs_eps_B, p.rvs_p, p.rvs_xi_e = vals["eps_e_r"], vals["eps_B_r"], vals["p_r"], vals["xi_e_r"]
         return p
 
-    def build_spec(self, param_defs: Sequence[ParamDef]):
-        """The transformer of fitting/utils.py:110-135 as a C-ABI slot map (vag_fit_spec)."""
+    def build_spec(self, param_defs: Sequence[ParamDef], priors=None, use_priors=False):
+        """The transformer of fitting/utils.py:110-135 as a C-ABI slot map (vag_fit_spec).  With ``use_priors`` the spec also
+        carries the sampler-space bounds and the priors of fitting/params.py:209-227 (Uniform(lower, upper) unless ``priors``
+        names another one), so that the device applies the bounds mask and adds sum ln prior (samplers.py:72-91)."""
         self._consolidate_data()
         fixed = {pd.name: (pd.initial if pd.initial is not None else pd.lower) for pd in param_defs if pd.scale is Scale.fixed}
         free = [pd for pd in param_defs if pd.scale is not Scale.fixed]
@@ -297,6 +324,14 @@ class Fitter:
         # sampler-space bounds: log10 of the ParamDef bounds for LOG-scale parameters (fitting/params.py:196-201)
         lower = np.array([np.log10(pd.lower) if pd.scale is Scale.log else pd.lower for pd in free], dtype=np.float64)
         upper = np.array([np.log10(pd.upper) if pd.scale is Scale.log else pd.upper for pd in free], dtype=np.float64)
+        self._host_priors = []
+        spec.use_priors = 1 if use_priors else 0
+        for d, pd in enumerate(free):
+            spec.lower[d], spec.upper[d] = lower[d], upper[d]
+            kind, a, b = _device_prior((priors or {}).get(pd.name))
+            if kind == _lib.PRIOR_NONE:
+                self._host_priors.append((d, priors[pd.name]))
+            spec.prior_kind[d], spec.prior_a[d], spec.prior_b[d] = kind, a, b
         return spec, lower, upper
 
     # fitting/params.py validate_parameters: the checks that do not depend on the sampler
@@ -374,6 +409,9 @@ class Fitter:
         samples = np.ascontiguousarray(samples, dtype=np.float64)
         if samples.ndim != 2 or samples.shape[1] != spec.ndim:
             raise ValueError("samples must be [nb, ndim]")
+        return self._device_loglike(spec, samples)
+
+    def _device_loglike(self, spec, samples):
         out = np.empty(samples.shape[0])
         h, lock = get_context(self.device)
         plan = _lib.Plan()
@@ -385,16 +423,37 @@ class Fitter:
             # never silent: these walkers were NOT evaluated (their adaptive grid exceeds the engine's static limits)
             logger.warning("%d of %d walkers exceeded the engine grid limits and were assigned -inf",
                            plan.n_models_capacity, samples.shape[0])
+        if plan.n_walkers_ssc_failed:
+            logger.warning("%d of %d walkers had SSC tables outside the engine's capacity and were assigned -inf",
+                           plan.n_walkers_ssc_failed, samples.shape[0])
         self.last_plan = plan
         return out
 
-    def make_log_prob_batch(self, param_defs, loglike_fn=None):
-        """log_prob_batch(samples) of fitting/samplers.py:72-91 with uniform priors:
-        out-of-bounds -> -inf; otherwise ln L + sum ln prior.  ``loglike_fn`` lets a caller substitute a
-        sharded evaluator (vegasafterglow_amd.dist.sharded_loglike)."""
+    def log_prob_batch(self, samples, param_defs, priors=None):
+        """log_prob_batch of fitting/samplers.py:72-91 in ONE device call: walkers outside the ParamDef bounds are not evaluated
+        and score -inf, the others ln L + sum ln prior.  ``priors`` maps parameter names to priors acting on the SAMPLER-space
+        value: objects shaped like bilby.core.prior.Uniform / Gaussian / LogUniform (or ("gaussian", mu, sigma),
+        ("log_uniform", minimum, maximum), ("uniform",)) run on the device; any other object with ``ln_prob`` is added on the host.
+        Parameters without an entry get Uniform(lower, upper) (params.py:209-227)."""
+        spec, _, _ = self.build_spec(param_defs, priors=priors, use_priors=True)
+        samples = np.ascontiguousarray(np.atleast_2d(np.asarray(samples, dtype=np.float64)))
+        if samples.shape[1] != spec.ndim:
+            raise ValueError("samples must be [nb, ndim]")
+        out = self._device_loglike(spec, samples)
+        for d, prior in self._host_priors:
+            out = out + np.asarray(prior.ln_prob(samples[:, d]), dtype=np.float64)
+        out[~np.isfinite(out)] = -np.inf
+        return out
+
+    def make_log_prob_batch(self, param_defs, loglike_fn=None, priors=None):
+        """log_prob_batch(samples) of fitting/samplers.py:72-91: out-of-bounds -> -inf; otherwise ln L + sum ln prior, evaluated
+        by the device in one call (Fitter.log_prob_batch).  ``loglike_fn`` substitutes an evaluator of ln L alone (e.g. one that
+        shards walkers over ranks); mask and uniform priors are then applied here on the host."""
+        if loglike_fn is None:
+            return lambda samples: self.log_prob_batch(samples, param_defs, priors=priors)
         _, lower, upper = self.build_spec(param_defs)
         ln_prior = -np.sum(np.log(upper - lower))
-        fn = loglike_fn if loglike_fn is not None else (lambda s: self.loglike_batch(s, param_defs))
+        fn = loglike_fn
 
         def log_prob_batch(samples):
             samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
