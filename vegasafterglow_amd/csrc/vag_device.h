@@ -100,7 +100,7 @@ VAG_DEV double structure_weight(double G) { return G * sqrt(dmax((G - 1) * G, 0.
 //      unit handling of pybind/pymodel.cpp:47-210 ----
 struct Jet {
     int type;
-    double theta_c, eps_k, Gamma0, k_e, k_g, norm;
+    double theta_c, eps_k, Gamma0, k_e, k_g, norm, inv_theta_c;
     double theta_w, E_iso_cgs, E_iso_w_cgs, Gm1, Gm1_w, T0;
     double sigma0;  // constant ejecta magnetisation (VAG_JET_MAGNETIZED_TOPHAT), 0 otherwise
     int magnetar;   // jet(..., magnetar=Magnetar(L0, t0, q)): generic-Ejecta profile forms + energy injection
@@ -121,6 +121,7 @@ VAG_DEV void jet_init(Jet& j, const vag_model_params& p) {
     j.k_e = p.k_e;
     j.k_g = p.k_g;
     j.norm = -1 / (2 * p.theta_c * p.theta_c);
+    j.inv_theta_c = 1 / p.theta_c;
     j.theta_w = p.theta_w;
     j.E_iso_cgs = p.E_iso;
     j.E_iso_w_cgs = p.E_iso_w;
@@ -960,6 +961,26 @@ VAG_DEV double log2_tab(double x, LdsTab tab) {
     const double ln_m = fma(q * r, r, r);
     return fma(ln_m, LOG2E, (double)(eb - 1023) + t.y);
 }
+
+#ifndef VAG_HOST_DEBUG
+// ---- cross-lane helpers on the DPP path (no LDS round trip): gfx9 row_shr / row_bcast / wave_shr controls ----
+template <int CTRL, int ROW_MASK>
+VAG_DEV double dpp_zero(double v) {  // value of the DPP source lane; 0 where the source is invalid or the row is masked off
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+VAG_DEV double wave_prefix_sum(double x) {  // inclusive sum over lanes 0..lane (Kogge-Stone in rows of 16, then row totals)
+    x += dpp_zero<0x111, 0xf>(x);  // row_shr:1
+    x += dpp_zero<0x112, 0xf>(x);  // row_shr:2
+    x += dpp_zero<0x114, 0xf>(x);  // row_shr:4
+    x += dpp_zero<0x118, 0xf>(x);  // row_shr:8
+    x += dpp_zero<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3 add the total of the row before
+    x += dpp_zero<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3 add the total of rows 0-1
+    return x;
+}
+VAG_DEV double from_lane_below(double v) { return dpp_zero<0x138, 0xf>(v); }  // wave_shr:1: lane - 1's value, 0 into lane 0
+#endif
 
 // compute_log2_I_nu (smooth-power-law-syn.cpp:15-46,80-92,159-167) on the fast kernels above.
 template <class PtrT, class Tab>

@@ -13,6 +13,7 @@ namespace vag {
 constexpr int WAVE = 64;
 constexpr int N_SCAN = 512;      // find_jet_jumps / find_theta_range scans
 constexpr int N_SAMPLES = 200;   // defaults::sampling::theta_samples
+constexpr int QUAD_REC = 96;     // accepted CDF-quadrature steps buffered before their samples are interpolated
 
 #ifdef VAG_GRID_STAMPS  // developer aid: cycle stamps of model 0 at the section boundaries, printed by lane 0
 #define VAG_GRID_STAMP(i) do { if (m == 0 && lane == 0) stamps_[i] = __builtin_readcyclecounter(); } while (0)
@@ -20,10 +21,11 @@ constexpr int N_SAMPLES = 200;   // defaults::sampling::theta_samples
 #define VAG_GRID_STAMP(i) do { } while (0)
 #endif
 
+// Sum over the wavefront, the same value in every lane: DPP prefix scan (VALU only; the __shfl_xor butterfly makes six
+// round trips through the LDS crossbar) + a broadcast of lane 63's total.
 VAG_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
+    v = wave_prefix_sum(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 VAG_DEV double wave_min(double v) {
 #pragma unroll
@@ -67,7 +69,46 @@ struct GridShared {
     double theta[VAG_MAX_THETA + 64];
     double phi[VAG_MAX_PHI];
     int flag[VAG_MAX_THETA];
+    double rec[9][QUAD_REC];          // accepted quadrature steps awaiting their dense-output pass (integrate_cdf)
+    double jumps[VAG_MAX_JUMPS];      // find_jet_jumps results (dynamically indexed: LDS, not scratch)
+    double feat[3 * VAG_MAX_JUMPS];   // jump_refinement_grid nodes
 };
+
+// cos(x) for |x| <= pi + a bit: 1 - 2 sin^2(x/2) with sin's odd series on [-pi/2, pi/2] to x^21 (truncation 3e-16 at the end of
+// the range).  The CDF integrands (theta - theta_v, phi in [0, 2 pi] folded below) only ever need this range.
+VAG_DEV double cos_small(double x) {
+    const double h = 0.5 * x, z = h * h;
+    double p = fma(z, -1.9572941063391263e-20, 8.22063524662433e-18);
+    p = fma(p, z, -2.8114572543455206e-15);
+    p = fma(p, z, 7.647163731819816e-13);
+    p = fma(p, z, -1.6059043836821613e-10);
+    p = fma(p, z, 2.505210838544172e-08);
+    p = fma(p, z, -2.7557319223985893e-06);
+    p = fma(p, z, 0.0001984126984126984);
+    p = fma(p, z, -0.008333333333333333);
+    p = fma(p, z, 0.16666666666666666);
+    const double sn = fma(-(p * z), h, h);  // h - h^3/6 + ...
+    return fma(-2.0 * sn, sn, 1.0);
+}
+// cos(phi) for phi in [0, 2 pi]: cos(phi) = -cos(phi - pi)
+VAG_DEV double cos_0_2pi(double phi) { return -cos_small(phi - C_PI); }
+
+// jet.Gamma0(theta) through the fast exp2 / log2 (used by the CDF integrands only: every other use -- cuts, symmetry classes,
+// initial conditions -- keeps jet_Gamma0)
+VAG_DEV double jet_Gamma0_fast(const Jet& j, double theta) {
+    if (j.magnetar) return jet_Gamma0(j, theta);
+    switch (j.type) {
+        case VAG_JET_GAUSSIAN: return (j.Gamma0 - 1) * exp2_sat(theta * theta * (j.norm * LOG2E)) + 1;
+        case VAG_JET_POWERLAW: return (j.Gamma0 - 1) * rcp_fast(1 + exp2_sat(j.k_g * log2_fast(theta * j.inv_theta_c))) + 1;
+        case VAG_JET_STEP_POWERLAW:
+            return (theta <= j.theta_c ? j.Gm1 : j.Gm1_w * exp2_sat(-j.k_g * log2_fast(theta * j.inv_theta_c))) + 1;
+        case VAG_JET_POWERLAW_WING:
+            return (theta <= j.theta_c ? 0. : j.Gm1_w * exp2_sat(-j.k_g * log2_fast(theta * j.inv_theta_c))) + 1;
+        default: return jet_Gamma0(j, theta);  // piecewise-constant profiles: comparisons only
+    }
+}
+VAG_DEV double beta_fast(double g) { return sqrt_fast((g - 1) * (g + 1)) * rcp_fast(g); }
+VAG_DEV double structure_weight_fast(double G) { return G * sqrt_fast(dmax((G - 1) * G, 0.0)); }
 
 VAG_DEV double lane_value(double v, int src_lane) {  // wave-uniform copy of lane src_lane's v
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -79,6 +120,10 @@ VAG_DEV double lane_value(double v, int src_lane) {  // wave-uniform copy of lan
 // the right-hand side does not depend on cdf, so the stage abscissae x + {1/5, 3/10, 4/5, 8/9, 1} h are known up front and
 // their five pdf values are evaluated side by side (`stages(tx, kv)`; stages 6 and 7 share x + h) -- one pdf latency per
 // attempted step instead of six.
+#ifdef VAG_GRID_STAMPS
+__device__ long long g_stage_cycles, g_dense_cycles;
+__device__ int g_quad_steps;
+#endif
 template <class Stages>
 VAG_DEV bool quad_step(Dopri5<1>& s, Stages& stages) {
     constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
@@ -90,7 +135,13 @@ VAG_DEV bool quad_step(Dopri5<1>& s, Stages& stages) {
         const double h = s.dt;
         const double tx[5] = {s.t + h * a2, s.t + h * a3, s.t + h * a4, s.t + h * a5, s.t + h};
         double kv[5];
+#ifdef VAG_GRID_STAMPS
+        const long long q0_ = __builtin_readcyclecounter();
+#endif
         stages(tx, kv);
+#ifdef VAG_GRID_STAMPS
+        g_stage_cycles += __builtin_readcyclecounter() - q0_;
+#endif
         const double k3 = kv[1], k4 = kv[2], k5 = kv[3], k6 = kv[4], k7 = kv[4];
         const double x = s.x[0], dx = s.dx[0];
         const double xn = x + (h * c1) * dx + (h * c3) * k3 + (h * c4) * k4 + (h * c5) * k5 + (h * c6) * k6;
@@ -118,9 +169,52 @@ VAG_DEV bool quad_step(Dopri5<1>& s, Stages& stages) {
     return false;
 }
 
+// Dense output of the buffered steps at the samples they passed: sample kk belongs to the first step whose end exceeds
+// xs[kk] (`current_time() > x`, grid-refinement.h:150-158); one sample per lane, same arithmetic per sample as the serial sweep.
+// Returns the index of the first sample not yet passed.
+VAG_DEV int flush_quad_steps(GridShared& sh, int n_rec, int k) {
+    const int lane = threadIdx.x;
+    if (n_rec == 0) return k;
+    const double t_end = sh.rec[1][n_rec - 1];
+    for (;;) {
+        const int kk = k + lane;
+        const bool in = kk < N_SAMPLES && t_end > sh.xs[kk];
+        if (in) {
+            const double x = sh.xs[kk];
+            int lo = 0, hi = n_rec - 1;  // first record with t > x
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sh.rec[1][mid] > x)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            Dopri5<1> st;
+            st.t_old = sh.rec[0][lo];
+            st.t = sh.rec[1][lo];
+            st.xo[0] = sh.rec[2][lo];
+            st.dxo[0] = sh.rec[3][lo];
+            st.k3[0] = sh.rec[4][lo];
+            st.k4[0] = sh.rec[5][lo];
+            st.k5[0] = sh.rec[6][lo];
+            st.k6[0] = sh.rec[7][lo];
+            st.dx[0] = sh.rec[8][lo];
+            double v;
+            st.interp(x, &v);
+            sh.cdf[kk] = v;
+        }
+        const int cnt = __popcll(__ballot(in));  // xs ascends: the passed samples are a prefix of the lanes
+        k += cnt;
+        if (cnt < WAVE) break;
+    }
+    return k;
+}
+
 // Integrate d(cdf)/dx = pdf(x) from lo to hi with boost's dense-output DOPRI5 at rtol=atol=1e-6 and
 // sample it at sh.xs[1..N_SAMPLES) (inverse_CFD_sampling, grid-refinement.h:138-161).
 // pdf0 = pdf(lo) (wave-uniform); stages(tx[5], kv[5]) returns the wave-uniform pdf at five abscissae.
+// The dense output is off the stepping chain: accepted steps are buffered in LDS (nine doubles each) and interpolated at the
+// samples they passed afterwards, one sample per lane.
 template <class Stages>
 VAG_DEV void integrate_cdf(GridShared& sh, double pdf0, Stages& stages, double lo, double hi) {
     const int lane = threadIdx.x;
@@ -132,24 +226,39 @@ VAG_DEV void integrate_cdf(GridShared& sh, double pdf0, Stages& stages, double l
     st.t = lo;
     st.dt = (hi - lo) / 1e3;
     st.eps = 1e-6;
-    int k = 1;
+    int k = 1, n_rec = 0;
     for (int steps = 0; st.t <= hi;) {
         if (!quad_step(st, stages)) break;
         if (++steps > 100000) break;
-        // dense output at every sample the step passed: one sample per lane (same arithmetic per sample as a serial sweep)
-        for (;;) {
-            const int kk = k + lane;
-            const bool in = kk < N_SAMPLES && st.t > sh.xs[kk];
-            if (in) {
-                double v;
-                st.interp(sh.xs[kk], &v);
-                sh.cdf[kk] = v;
-            }
-            const int cnt = __popcll(__ballot(in));  // xs ascends: the passed samples are a prefix of the lanes
-            k += cnt;
-            if (cnt < WAVE) break;
+#ifdef VAG_GRID_STAMPS
+        ++g_quad_steps;
+#endif
+        if (lane == 0) {
+            sh.rec[0][n_rec] = st.t_old;
+            sh.rec[1][n_rec] = st.t;
+            sh.rec[2][n_rec] = st.xo[0];
+            sh.rec[3][n_rec] = st.dxo[0];
+            sh.rec[4][n_rec] = st.k3[0];
+            sh.rec[5][n_rec] = st.k4[0];
+            sh.rec[6][n_rec] = st.k5[0];
+            sh.rec[7][n_rec] = st.k6[0];
+            sh.rec[8][n_rec] = st.dx[0];
+        }
+        if (++n_rec == QUAD_REC) {
+            __syncthreads();
+            k = flush_quad_steps(sh, n_rec, k);
+            __syncthreads();
+            n_rec = 0;
         }
     }
+    __syncthreads();
+#ifdef VAG_GRID_STAMPS
+    const long long d0_ = __builtin_readcyclecounter();
+#endif
+    k = flush_quad_steps(sh, n_rec, k);
+#ifdef VAG_GRID_STAMPS
+    g_dense_cycles += __builtin_readcyclecounter() - d0_;
+#endif
     __syncthreads();
 }
 
@@ -224,7 +333,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
 
     // ---- find_jet_jumps (grid-refinement.h:41-86): parallel profile scan, sequential jump logic ----
     const double th_lo = 1e-6, th_hi = C_PI / 2;
-    double jumps[VAG_MAX_JUMPS];
+    double* jumps = sh.jumps;  // every lane writes the same value: wave-uniform list
     int n_jumps = 0;
     if (jet_Gamma0(jet, th_hi) >= GAMMA_CUT) {
         jumps[n_jumps++] = th_hi;
@@ -273,34 +382,39 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     double inner_edge = th_lo, outer_edge = th_hi;
     {
         const double step = (th_hi - th_lo) / N_SCAN;
-        // abscissae by running subtraction, as the reference's loop (its rounding accumulates); the exit test is taken out
-        // of the dependent chain: all N_SCAN + 8 candidates are generated, the valid ones (th >= th_lo) are a prefix
-        static_assert((N_SCAN + 8) % 8 == 0, "unrolled by 8");
+        // The reference walks th -= step down from pi/2 and its rounding accumulates, so abscissa s is the result of s dependent
+        // subtractions.  Every lane runs the chain once over the nine block starts (s = 64 b, static indices: registers), then
+        // walks its own `lane` further steps on all nine chains side by side: bit-identical abscissae, ~7 k cycles instead of
+        // the 40 k of a single lane filling LDS.
+        constexpr int NBLK = (N_SCAN + 8 + WAVE - 1) / WAVE;  // 9 blocks of 64 candidates
+        double mine[NBLK];
         {
             double th = th_hi;
-            for (int b = 0; b < N_SCAN + 8; b += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (lane == 0) sh.scan_th[b + u] = th;
-                    th -= step;
+            for (int b = 0; b < NBLK; ++b) {
+                mine[b] = th;
+#pragma unroll 8
+                for (int u = 0; u < WAVE; ++u) th -= step;
+            }
+            for (int u = 0; u < lane; ++u) {
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) mine[b] -= step;
+            }
+        }
+        // first abscissa (descending) inside [th_lo, pi/2] with Gamma0 >= cut: blocks in order, lanes in parallel
+        int first = 1 << 30;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            if (first == (1 << 30)) {  // wave-uniform
+                const bool hit = mine[b] >= th_lo && jet_Gamma0(jet, mine[b]) >= GAMMA_CUT;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    first = b * WAVE + src;
+                    outer_edge = lane_value(mine[b], src);
                 }
             }
         }
-        __syncthreads();
-        int n = 0;
-        for (int b = 0; b < N_SCAN + 8; b += WAVE) {
-            const int s = b + lane;
-            n += __popcll(__ballot(s < N_SCAN + 8 && sh.scan_th[s] >= th_lo));
-        }
-        int first = 1 << 30;
-        for (int s = lane; s < n; s += WAVE)
-            if (jet_Gamma0(jet, sh.scan_th[s]) >= GAMMA_CUT) {
-                first = s;
-                break;
-            }
-        first = wave_min_int(first);
-        if (first < n) outer_edge = sh.scan_th[first];
-        __syncthreads();
         // upward scan: the first abscissa almost always qualifies; stay sequential with early exit
         for (double th = th_lo; th <= th_hi; th += step) {
             if (jet_Gamma0(jet, th) >= GAMMA_CUT) {
@@ -320,31 +434,63 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     {
         constexpr int scan_pts = 100;
         const double extent = theta_max - theta_min;
+        // 101 scan points, two per lane (i = lane, lane + 64).  The reference's sequential pass -- running sum, running peak
+        // (strict >, so the first maximum wins) and last_bright = last i whose weight exceeds 1 % of the peak SO FAR -- becomes a
+        // wave prefix-maximum: last_bright = max{i : w_i > 0.01 max_{j<i} w_j} (a new peak satisfies that too).
         double Gamma_v = 1.0;
-        for (int i = lane; i <= scan_pts; i += WAVE) {
-            const double theta = theta_min + extent * i / scan_pts;
-            const double G = jet_Gamma0(jet, theta);
-            sh.scan_g[i] = G;
-            sh.scan_th[i] = structure_weight(G);  // scan_th is free again after find_theta_range
-            const double d = theta - theta_v;
-            Gamma_v = dmax(Gamma_v, G / sqrt(1.0 + G * G * d * d));
-        }
-        Gamma_v = -wave_min(-Gamma_v);  // a maximum: order-free
-        __syncthreads();
-        double peak_weight = 0, Gamma_peak = 1.0, struct_sum = 0;
-        int last_bright = 0;
-        for (int i = 0; i <= scan_pts; ++i) {  // running sum and peak tracking in scan order
-            const double w = sh.scan_th[i];
-            struct_sum += w;
-            if (w > peak_weight) {
-                peak_weight = w;
-                Gamma_peak = sh.scan_g[i];
-                last_bright = i;
-            } else if (w > 0.01 * peak_weight) {
-                last_bright = i;
+        double wv[2], gv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = lane + q * WAVE;
+            wv[q] = -1.0;
+            gv[q] = 1.0;
+            if (i <= scan_pts) {
+                const double theta = theta_min + extent * i / scan_pts;
+                const double G = jet_Gamma0(jet, theta);
+                gv[q] = G;
+                wv[q] = structure_weight(G);
+                const double d = theta - theta_v;
+                Gamma_v = dmax(Gamma_v, G / sqrt(1.0 + G * G * d * d));
             }
         }
-        __syncthreads();
+        Gamma_v = -wave_min(-Gamma_v);  // a maximum: order-free
+        double struct_sum = 0;
+        {   // the sum in scan order: lanes 0..63 hold i = 0..63, then 64..100
+            double acc = 0;
+            for (int src = 0; src < WAVE; ++src) acc += lane_value(dmax(wv[0], 0.0), src);
+            for (int src = 0; src <= scan_pts - WAVE; ++src) acc += lane_value(dmax(wv[1], 0.0), src);
+            struct_sum = acc;
+        }
+        // exclusive prefix maximum over i (weights are >= 0; -1 marks "no point")
+        double pm0 = wv[0];  // inclusive scan of the first 64
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const double o = __shfl_up(pm0, off, WAVE);
+            if (lane >= off) pm0 = dmax(pm0, o);
+        }
+        const double tot0 = lane_value(pm0, WAVE - 1);
+        double ex0 = __shfl_up(pm0, 1, WAVE);
+        if (lane == 0) ex0 = 0.0;
+        double pm1 = wv[1];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const double o = __shfl_up(pm1, off, WAVE);
+            if (lane >= off) pm1 = dmax(pm1, o);
+        }
+        double ex1 = __shfl_up(pm1, 1, WAVE);
+        ex1 = lane == 0 ? tot0 : dmax(ex1, tot0);
+        const double peak_weight = dmax(dmax(tot0, lane_value(pm1, WAVE - 1)), 0.0);
+        int lb = -1;
+        if (wv[0] > 0.01 * dmax(ex0, 0.0) && wv[0] >= 0) lb = lane;
+        if (lane + WAVE <= scan_pts && wv[1] > 0.01 * dmax(ex1, 0.0)) lb = lane + WAVE;
+        const int last_bright = max(0, -wave_min_int(-lb));
+        // Gamma at the FIRST maximum of the weight
+        int arg = 1 << 30;
+        if (wv[0] == peak_weight) arg = lane;
+        else if (lane + WAVE <= scan_pts && wv[1] == peak_weight) arg = lane + WAVE;
+        arg = wave_min_int(arg);
+        double Gamma_peak = 1.0;
+        if (peak_weight > 0) Gamma_peak = arg < WAVE ? lane_value(gv[0], arg) : lane_value(gv[1], arg - WAVE);
         const double floor_weight = 0.25 * peak_weight;
         const double CDF_est = (struct_sum / scan_pts + floor_weight) * extent;
         const double theta_bright = theta_min + extent * last_bright / scan_pts;
@@ -374,16 +520,18 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         // sample abscissae: xt::logspace(log10(min), log10(max), 200)
         {
             const double a = log10(theta_min), b = log10(theta_max);
-            for (int k = lane; k < N_SAMPLES; k += WAVE) sh.xs[k] = pow(10.0, linspace_at(a, b, N_SAMPLES, k));
+            for (int k = lane; k < N_SAMPLES; k += WAVE)  // 10^x through the fast exp2 (3e-16)
+                sh.xs[k] = exp2_fast(linspace_at(a, b, N_SAMPLES, k) * 3.321928094887362347870319429489390175865);
         }
+        // the integrand on the fast scalar kernels (exp2 / log2 / rsq / rcp forms, 1e-16 apart from the library calls)
         auto pdf = [&](double theta) -> double {
-            const double G = jet_Gamma0(jet, theta);
-            const double beta = gamma_to_beta(G);
-            const double doppler = (1 - beta) / (1 - beta * cos(theta - theta_v));
-            const double structure = structure_weight(G);
+            const double G = jet_Gamma0_fast(jet, theta);
+            const double beta = beta_fast(G);
             const double d = theta - theta_v;
-            return core_weight * Gp2 * theta / (1.0 + Gp2 * theta * theta) +
-                   view_weight * Gv2 * fabs(d) / (1.0 + Gv2 * d * d) + (1 + doppler_alpha * doppler) * structure +
+            const double doppler = (1 - beta) * rcp_fast(1 - beta * cos_small(d));
+            const double structure = structure_weight_fast(G);
+            return core_weight * Gp2 * theta * rcp_fast(1.0 + Gp2 * theta * theta) +
+                   view_weight * Gv2 * fabs(d) * rcp_fast(1.0 + Gv2 * d * d) + (1 + doppler_alpha * doppler) * structure +
                    floor_weight;
         };
         // the five stage abscissae of a step on lanes 0..4 (the pdf is scalar code: every lane may take its own theta)
@@ -394,6 +542,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         };
 #ifdef VAG_GRID_STAMPS
         const long long s_a = __builtin_readcyclecounter();
+        if (m == 0 && lane == 0) g_stage_cycles = g_dense_cycles = 0, g_quad_steps = 0;
 #endif
         integrate_cdf(sh, pdf(theta_min), stages, theta_min, theta_max);
 #ifdef VAG_GRID_STAMPS
@@ -402,7 +551,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         invert_cdf(sh, n_base, false, sh.base);
 #ifdef VAG_GRID_STAMPS
         if (m == 0 && lane == 0)
-            printf("  theta: preamble %lld integrate %lld invert %lld (n_base %d)\n", s_a - stamps_[2], s_b - s_a,
+            printf("  theta: preamble %lld integrate %lld (steps %d: stage evaluations %lld, dense output %lld) invert %lld (n_base %d)\n",
+                   s_a - stamps_[2], s_b - s_a, g_quad_steps, g_stage_cycles, g_dense_cycles,
                    (long long)__builtin_readcyclecounter() - s_b, n_base);
 #endif
     }
@@ -411,7 +561,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     // ---- jump_refinement_grid (grid-refinement.cpp:136-160) + merge_grids (grid-refinement.h:362-393) ----
     int n_theta = 0;
     {
-        double feat[3 * VAG_MAX_JUMPS];
+        double* feat = sh.feat;  // wave-uniform list in LDS (every lane writes the same values)
         int nf = 0;
         const double tight = ((theta_max - theta_min) / n_base) / 8;
         for (int q = 0; q < n_jumps; ++q) {
@@ -434,26 +584,43 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         for (int a = 0; a < nf; ++a)
             if (nu == 0 || feat[nu - 1] != feat[a]) feat[nu++] = feat[a];
         nf = nu;
-        // sequential merge executed by lane 0 into shared memory
-        if (lane == 0) {
-            int n = 0, i = 0, j = 0;
-            auto add = [&](double v) {
-                if (n == 0 || sh.theta[n - 1] != v) sh.theta[n++] = v;
-            };
-            while (i < n_base && j < nf) {
-                if (sh.base[i] <= feat[j]) {
-                    add(sh.base[i++]);
-                    if (sh.base[i - 1] == feat[j]) j++;
-                } else {
-                    add(feat[j++]);
-                }
-            }
-            while (i < n_base) add(sh.base[i++]);
-            while (j < nf) add(feat[j++]);
-            sh.flag[0] = n;
-        }
         __syncthreads();
-        n_theta = sh.flag[0];
+        // merge_grids (grid-refinement.h:362-393): sorted union without repeats.  Both lists ascend (the base grid strictly:
+        // its CDF rises strictly), so an element's slot in the union is its own index plus the number of elements of the other
+        // list before it; a feature equal to a base node is dropped.  One element per lane and round.
+        n_theta = 0;
+        {
+            int n_dup = 0;
+            for (int j = lane; j < nf; j += WAVE) {  // features: rank among the base nodes (binary search), skipped when equal to one
+                const double v = feat[j];
+                int lo = 0, hi = n_base;  // first base index with base[idx] >= v
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh.base[mid] < v)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                const bool dup = lo < n_base && sh.base[lo] == v;
+                sh.flag[j] = dup ? -1 : lo;  // base nodes before this feature
+                n_dup += dup ? 1 : 0;
+            }
+            __syncthreads();
+            for (int off = 32; off > 0; off >>= 1) n_dup += __shfl_xor(n_dup, off, WAVE);
+            n_theta = n_base + nf - n_dup;
+            for (int i = lane; i < n_base; i += WAVE) {  // base nodes: shifted by the kept features strictly below them
+                const double v = sh.base[i];
+                int before = 0;
+                for (int j = 0; j < nf; ++j) before += (sh.flag[j] >= 0 && feat[j] < v) ? 1 : 0;
+                sh.theta[i + before] = v;
+            }
+            for (int j = lane; j < nf; j += WAVE) {
+                if (sh.flag[j] < 0) continue;
+                int kept_before = 0;
+                for (int q = 0; q < j; ++q) kept_before += sh.flag[q] >= 0 ? 1 : 0;
+                sh.theta[sh.flag[j] + kept_before] = feat[j];
+            }
+        }
         __syncthreads();
     }
 
@@ -506,28 +673,26 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 sh.pj_st[j] = sin(th) * sin_tv;
             }
             __syncthreads();
+            // per-bin term a_j sw_j dcos_j with a_j = (1 - beta_j) / (1 - beta_j cos_alpha_j): the reciprocal through rcp_fast
+            // (two Newton steps, <= 2 ulp) instead of the IEEE division sequence, cos(phi) through cos_0_2pi
+            auto bin_term = [&](int j, double cos_phi) -> double {
+                const double beta = sh.pj_beta[j];
+                const double cos_alpha = sh.pj_ct[j] + sh.pj_st[j] * cos_phi;
+                const double a = (1 - beta) * rcp_fast(1 - beta * cos_alpha);
+                return a * sh.pj_sw[j] * sh.pj_dcos[j];
+            };
             auto phi_weight = [&](double phi) -> double {
-                const double cos_phi = cos(phi);
+                const double cos_phi = cos_0_2pi(phi);
                 double w = 0;
-                for (int j = lane; j < n_theta; j += WAVE) {
-                    const double beta = sh.pj_beta[j];
-                    const double cos_alpha = sh.pj_ct[j] + sh.pj_st[j] * cos_phi;
-                    const double a = (1 - beta) / (1 - beta * cos_alpha);
-                    w += a * sh.pj_sw[j] * sh.pj_dcos[j];
-                }
+                for (int j = lane; j < n_theta; j += WAVE) w += bin_term(j, cos_phi);
                 return wave_sum(w);
             };
             constexpr int scan_pts = 100;
             double peak = 0, sum = 0;
             for (int s = lane; s <= scan_pts; s += WAVE) {  // one scan point per lane, theta bins summed in grid order
-                const double cos_phi = cos(phi_max * (double)s / scan_pts);
+                const double cos_phi = cos_0_2pi(phi_max * (double)s / scan_pts);
                 double w = 0;
-                for (int j = 0; j < n_theta; ++j) {
-                    const double beta = sh.pj_beta[j];
-                    const double cos_alpha = sh.pj_ct[j] + sh.pj_st[j] * cos_phi;
-                    const double a = (1 - beta) / (1 - beta * cos_alpha);
-                    w += a * sh.pj_sw[j] * sh.pj_dcos[j];
-                }
+                for (int j = 0; j < n_theta; ++j) w += bin_term(j, cos_phi);
                 peak = dmax(peak, w);
                 sum += w;
             }
@@ -551,7 +716,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
             // five stage abscissae at once: their cosines on lanes 0..4, then every lane adds its theta bins to five
             // running sums (same per-term arithmetic and the same wave reduction as phi_weight)
             auto stages = [&](const double* tx, double* kv) {
-                const double cv = cos(lane == 0 ? tx[0] : lane == 1 ? tx[1] : lane == 2 ? tx[2] : lane == 3 ? tx[3] : tx[4]);
+                const double cv = cos_0_2pi(lane == 0 ? tx[0] : lane == 1 ? tx[1] : lane == 2 ? tx[2] : lane == 3 ? tx[3] : tx[4]);
                 double cp[5], w[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
@@ -560,10 +725,11 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 }
                 for (int j = lane; j < n_theta; j += WAVE) {
                     const double beta = sh.pj_beta[j], ct = sh.pj_ct[j], st = sh.pj_st[j], sw = sh.pj_sw[j], dc = sh.pj_dcos[j];
+                    const double omb = 1 - beta;
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
                         const double cos_alpha = ct + st * cp[i];
-                        const double a = (1 - beta) / (1 - beta * cos_alpha);
+                        const double a = omb * rcp_fast(1 - beta * cos_alpha);
                         w[i] += a * sw * dc;
                     }
                 }
@@ -598,12 +764,18 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
         __syncthreads();
         int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
         int* rep_start = g_rep_start + (size_t)m * VAG_MAX_THETA;
-        for (int j = 0; j < n_theta; ++j) {
-            if (sh.flag[j]) {
-                if (lane == 0) rep_start[n_reps] = j;
-                ++n_reps;
+        // group index of row j = (number of group starts in [0, j]) - 1: ballot prefix counts, 64 rows per round
+        for (int base = 0; base < n_theta; base += WAVE) {
+            const int j = base + lane;
+            const bool start = j < n_theta && sh.flag[j] != 0;
+            const unsigned long long mask = __ballot(start);
+            const int before = __popcll(mask & ((1ull << lane) - 1ull));  // starts among the lower lanes of this round
+            if (j < n_theta) {
+                const int g = n_reps + before + (start ? 1 : 0) - 1;
+                rep_of[j] = g;
+                if (start) rep_start[g] = j;
             }
-            if (lane == 0) rep_of[j] = n_reps - 1;
+            n_reps += __popcll(mask);
         }
         __syncthreads();
     }

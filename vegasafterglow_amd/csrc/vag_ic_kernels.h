@@ -312,23 +312,6 @@ VAG_DEV void suffix_scan(const double* __restrict__ ex, double* __restrict__ cdf
     if (j0 <= n) cdf[j0] = j0 < n ? c1 + a : 0.0;
 }
 
-// ---- cross-lane helpers on the DPP path (no LDS round trip): gfx9 row_shr / row_bcast / wave_shr controls ----
-template <int CTRL, int ROW_MASK>
-VAG_DEV double dpp_zero(double v) {  // value of the DPP source lane; 0 where the source is invalid or the row is masked off
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-VAG_DEV double wave_prefix_sum(double x) {  // inclusive sum over lanes 0..lane (Kogge-Stone in rows of 16, then row totals)
-    x += dpp_zero<0x111, 0xf>(x);  // row_shr:1
-    x += dpp_zero<0x112, 0xf>(x);  // row_shr:2
-    x += dpp_zero<0x114, 0xf>(x);  // row_shr:4
-    x += dpp_zero<0x118, 0xf>(x);  // row_shr:8
-    x += dpp_zero<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3 add the total of the row before
-    x += dpp_zero<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3 add the total of rows 0-1
-    return x;
-}
-VAG_DEV double from_lane_below(double v) { return dpp_zero<0x138, 0xf>(v); }  // wave_shr:1: lane - 1's value, 0 into lane 0
 VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
     const int l = __builtin_amdgcn_readfirstlane(src);
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
