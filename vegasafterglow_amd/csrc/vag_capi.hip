@@ -11,6 +11,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <chrono>
 
 #include "vag_ic_kernels.h"
 #include "vag_kernels.h"
@@ -286,7 +288,20 @@ struct vag_ctx {
     DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
     // grid results
     DevBuf d_meta, d_phi, d_theta, d_rep_of, d_rep_start, d_tdec, d_geo_th, d_geo_ph;
-    HostBuf h_meta, h_off;
+    HostBuf h_meta, h_off, h_plan;
+    DevBuf d_plan;                // VagDevPlan of the current batch (vag_plan_kernel)
+    DevBuf d_chunk;               // staging of chunked requests
+    VagDevPlan hint{};            // the last plan the host read back: sizes the next call of the same batch size in advance
+    int hint_nb = 0;
+    bool hint_valid = false;
+    bool allow_spec = false;      // set by the entry points that end with finish_speculation()
+    bool spec_pending = false;    // the current call was planned from the hint and has not been verified yet
+    VagDevPlan* d_hplan = nullptr;  // device address of h_plan
+    int plan_seq = 0;
+    bool plan_counter_ready = false;
+    int spec_cap_k = 0;
+    int spec_margin_k = 2;        // lattice nodes of head room in a planned-ahead call; grows when a call had to be repeated
+    bool meta_on_host = false;    // h_meta holds the current batch's grid results (copied on demand)
     // compact per-row / per-cell storage
     DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
     // fit spec cache (upload_fit_spec): content hash of what d_fit holds, its size, where the prior block starts
@@ -361,14 +376,10 @@ void vag_get_limits(vag_limits* out) {
     out->max_nu = VAG_MAX_NU;
 }
 
-int vag_ctx_create(int device, vag_ctx** out) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        return set_err(VAG_E_NO_DEVICE, "no HIP device available: the engine has no CPU path");
-    if (device < 0 || device >= n) return set_err(VAG_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
-    HIPCHK(hipSetDevice(device));
-    vag_ctx* c = new vag_ctx();
-    c->device = device;
+}  // extern "C"
+
+// streams, events, kernel attributes and the request-independent tables of a fresh context
+static int ctx_init(vag_ctx* c) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
@@ -431,6 +442,24 @@ int vag_ctx_create(int device, vag_ctx** out) {
         if (c->d_sptab.ensure(sizeof(double) * tab.size())) return VAG_E_HIP;
         HIPCHK(hipMemcpy(c->d_sptab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
     }
+    return VAG_OK;
+}
+
+extern "C" {
+
+int vag_ctx_create(int device, vag_ctx** out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_err(VAG_E_NO_DEVICE, "no HIP device available: the engine has no CPU path");
+    if (device < 0 || device >= n) return set_err(VAG_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    vag_ctx* c = new vag_ctx();
+    c->device = device;
+    const int rc = ctx_init(c);
+    if (rc) {  // nothing half-built survives a failed creation
+        vag_ctx_destroy(c);
+        return rc;
+    }
     *out = c;
     return VAG_OK;
 }
@@ -448,6 +477,9 @@ void vag_ctx_destroy(vag_ctx* c) {
         b->release();
     c->h_meta.release();
     c->h_off.release();
+    c->h_plan.release();
+    c->d_plan.release();
+    c->d_chunk.release();
     c->h_fit.release();
     c->d_fitstat.release();
     for (auto& e : c->ev)
@@ -457,6 +489,7 @@ void vag_ctx_destroy(vag_ctx* c) {
 }
 
 int vag_ctx_set_stream(vag_ctx* c, void* s) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return VAG_OK;
 }
@@ -562,6 +595,23 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
     return VAG_OK;
 }
 
+// Wait until the grid kernel of the current call has published its batch summary in pinned host memory (plan_scan_wave writes
+// the sequence number last).  A spin on host memory: no copy, no stream synchronisation, the queue behind the grid kernel keeps
+// running.  Falls back to a stream synchronisation if the number does not arrive (a failed launch).
+int wait_plan(vag_ctx* c) {
+    volatile VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long spins = 0; hp->seq != c->plan_seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (hp->seq != c->plan_seq) return set_err(VAG_E_HIP, "the grid stage did not publish its batch summary");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return VAG_OK;
+}
+
 // ODE rows per wavefront of the dynamics kernels (one lane integrates one row).  Measured (profiles/r02_rpw.txt): fewer
 // rows per wavefront do NOT pay for the general kernel -- at 256 VGPRs only one wavefront fits a SIMD and the dispatcher
 // does not spread single-wavefront workgroups evenly -- so full wavefronts stay the default; the knob remains for tuning.
@@ -586,63 +636,78 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_rep_of.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_rep_start.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->h_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
-    if (c->h_off.ensure((sizeof(int) + sizeof(long long)) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
 
+    // Grid shapes decide the compact layout and the launch geometry of everything downstream.  The last wavefront of
+    // vag_grid_kernel scans them on the device and publishes an 80-byte summary in pinned host memory; the host spins on its
+    // sequence number (wait_plan: ~6 us after the kernel's end, no copy, no stream synchronisation) and launches the rest.
+    // VAG_PLAN_AHEAD=1 instead plans from the previous call's summary with a margin and verifies afterwards
+    // (finish_speculation): no host wait in the middle of the pipeline at all.  Measured equal within 3 % in a sampler loop
+    // (0.716 vs 0.715 ms per 128-walker call) and slower when calls are queued back to back without reading ln L
+    // (0.775 vs 0.693 ms), because its flux launches are sized for the margin -- so waiting is the default.
+    static const bool plan_ahead = std::getenv("VAG_PLAN_AHEAD") != nullptr;
+    const bool spec = plan_ahead && c->allow_spec && !want_details && c->hint_valid && c->hint_nb == nb;
+    int cap_rows = INT32_MAX, cap_k = INT32_MAX, cap_pairs = INT32_MAX;
+    long long cap_cells = INT64_MAX;
+    if (spec) {
+        cap_rows = c->hint.rows + c->hint.rows / 4 + 64;
+        cap_cells = c->hint.cells + c->hint.cells / 4 + 4096;
+        cap_k = std::min(VAG_MAX_TIME, c->hint.max_k + c->spec_margin_k);  // LDS of the flux kernels scales with it: keep it tight
+        cap_pairs = c->hint.max_pairs + c->hint.max_pairs / 2 + 64;
+        c->spec_cap_k = cap_k;
+    }
+    if (c->d_plan.ensure(sizeof(VagDevPlan) + 64)) return VAG_E_HIP;
+    if (!c->h_plan.p) {  // pinned, host-mapped, COHERENT (fine-grained: a store from a running kernel reaches the host after a
+                         // system-scope fence, not only at the end of the queue): the grid kernel's last wavefront writes the
+                         // batch summary straight into it
+        HIPCHK(hipHostMalloc(&c->h_plan.p, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        c->h_plan.cap = 256;
+        std::memset(c->h_plan.p, 0, sizeof(VagDevPlan));
+        void* dp = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dp, c->h_plan.p, 0));
+        c->d_hplan = static_cast<VagDevPlan*>(dp);
+    }
+    if (!c->plan_counter_ready) {  // the ticket counter behind the plan: zeroed once, the kernel leaves it at zero
+        HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan), 0, 64, st));
+        c->plan_counter_ready = true;
+    }
     c->ic_need_reset = true;
     HIPCHK(hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                        c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
                        c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
-                       c->d_fail.as<int>());
+                       c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
+                       c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
+                       cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
+                       spec ? c->hint.dyn_class : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], st));
-    // grid shapes decide the compact layout and the launch geometry of everything downstream
-    VagGridMeta* hm = c->h_meta.as<VagGridMeta>();
-    HIPCHK(hipMemcpyAsync(hm, c->d_meta.p, sizeof(VagGridMeta) * nb, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    long long* h_cell = c->h_off.as<long long>();
-    int* h_row = reinterpret_cast<int*>(h_cell + (nb + 1));
-    long long cells = 0, pairs = 0, eat = 0;
-    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_invalid = 0, n_capacity = 0, dyn_class = 0;
-    for (int m = 0; m < nb; ++m) {
-        h_row[m] = rows;
-        h_cell[m] = cells;
-        if (hm[m].status == 0) {
-            rows += hm[m].n_reps;
-            cells += (long long)hm[m].n_reps * hm[m].n_t;
-            max_k = std::max(max_k, hm[m].n_t);
-            const int pr = hm[m].n_theta * hm[m].n_phi_eff;
-            max_pairs = std::max(max_pairs, pr);
-            pairs += pr;
-            eat += (long long)pr * hm[m].n_t;
-            dyn_class |= hm[m].dyn_class;
-            ++n_ok;
-        } else if (hm[m].status == VAG_E_CAPACITY) {
-            ++n_capacity;
-        } else {
-            ++n_invalid;
-        }
+    long long cells, pairs, eat;
+    int rows, max_k, max_pairs, n_ok, n_invalid = 0, n_capacity = 0, dyn_class, flags;
+    c->spec_pending = false;
+    if (!spec) {
+        VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
+        if (int rcw = wait_plan(c)) return rcw;
+        if (hp->flags_mixed) return set_err(VAG_E_UNSUPPORTED, "models with different Radiation(ssc, kn) flags in one batch");
+        rows = hp->rows, cells = hp->cells, pairs = hp->pairs, eat = hp->eat, max_k = hp->max_k, max_pairs = hp->max_pairs;
+        n_ok = hp->n_ok, n_invalid = hp->n_invalid, n_capacity = hp->n_capacity, dyn_class = hp->dyn_class;
+        flags = hp->flags_first < 0 ? 0 : hp->flags_first;
+        c->hint = *hp;
+        c->hint_nb = nb;
+        c->hint_valid = hp->n_ok > 0;
+    } else {  // launch geometry and strides from the capacities, kernel choice from the previous call's flags
+        rows = cap_rows, cells = cap_cells, max_k = cap_k, max_pairs = cap_pairs;
+        pairs = c->hint.pairs, eat = c->hint.eat, n_ok = c->hint.n_ok, dyn_class = c->hint.dyn_class;
+        flags = c->hint.flags_first < 0 ? 0 : c->hint.flags_first;
+        c->spec_pending = true;
     }
-    h_row[nb] = rows;
-    h_cell[nb] = cells;
-    {
-        int flags = -1;
-        for (int m = 0; m < nb; ++m)
-            if (hm[m].status == 0) {
-                if (flags < 0) flags = hm[m].flags;
-                if (hm[m].flags != flags)
-                    return set_err(VAG_E_UNSUPPORTED, "models with different Radiation(ssc, kn) flags in one batch");
-            }
-        c->batch_flags = flags < 0 ? 0 : flags;
-        // a spreading jet under axisymmetric=False would need one time lattice and one ODE solve per (phi, theta) node
-        // (grid-refinement.h:619-625); not built -- see DESIGN.md "out of scope"
-        if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING))
-            return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet is not supported");
-    }
+    c->batch_flags = flags;
+    // a spreading jet under axisymmetric=False would need one time lattice and one ODE solve per (phi, theta) node
+    // (grid-refinement.h:619-625); not built -- see DESIGN.md "out of scope"
+    if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING))
+        return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet is not supported");
     c->nb = nb;
     c->n_rows = rows;
     c->n_cells = cells;
@@ -660,8 +725,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->plan.eat_cells = eat;
     c->plan.n_models_invalid = n_invalid;
     c->plan.n_models_capacity = n_capacity;
-    HIPCHK(hipMemcpyAsync(c->d_cell_off.p, h_cell, sizeof(long long) * (nb + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_row_off.p, h_row, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, st));
+    c->meta_on_host = false;
     if (rows == 0) {
         HIPCHK(hipEventRecord(c->ev[2], st));
         HIPCHK(hipEventRecord(c->ev[3], st));
@@ -1032,7 +1096,7 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
     chunk = std::min(chunk, nt);
     const int rows_all = d_bandw ? 1 : nnu;
     const size_t cap = (size_t)nb * (d_bandw ? 1 : nu_chunk) * chunk;
-    DevBuf tmp;
+    DevBuf& tmp = c->d_chunk;  // grow-only context scratch: the stream orders its reuse
     if (tmp.ensure(sizeof(double) * 5 * cap)) return VAG_E_HIP;
     double* t_total = d_total ? tmp.as<double>() : nullptr;
     double* t_comp[4];
@@ -1056,9 +1120,6 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
         }
         if (d_bandw) break;
     }
-    const hipError_t e = hipStreamSynchronize(c->stream);
-    tmp.release();
-    if (rc == VAG_OK && e != hipSuccess) return set_err(VAG_E_HIP, "chunked grid request: %s", hipGetErrorString(e));
     return rc;
 }
 
@@ -1282,11 +1343,56 @@ int check_host_inputs(const vag_model_params* params, int nb, const double* t, i
     return VAG_OK;
 }
 
+// the batch's grid results on the host, copied only when someone needs more than the plan's totals
+int fetch_meta(vag_ctx* c) {
+    if (c->meta_on_host) return VAG_OK;
+    if (c->h_meta.ensure(sizeof(VagGridMeta) * (size_t)c->nb)) return VAG_E_HIP;
+    HIPCHK(hipMemcpyAsync(c->h_meta.p, c->d_meta.p, sizeof(VagGridMeta) * (size_t)c->nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->meta_on_host = true;
+    return VAG_OK;
+}
+
+// End of a call that was planned from the previous call's summary (run_model_stages, spec): read this batch's own summary and
+// verify the assumptions.  VAG_RETRY: a capacity was exceeded (the device then skipped every model) or the flags / kernel class
+// differ -- the caller repeats the call on the waiting path, which also refreshes the hint.
+constexpr int VAG_RETRY = 1;
+int finish_speculation(vag_ctx* c) {
+    if (!c->spec_pending) return VAG_OK;
+    c->spec_pending = false;
+    VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
+    if (int rcw = wait_plan(c)) return rcw;  // the grid stage finished long ago: the later stages keep running behind this check
+    const int flags = hp->flags_first < 0 ? 0 : hp->flags_first, hflags = c->hint.flags_first < 0 ? 0 : c->hint.flags_first;
+    if (hp->overflow || hp->flags_mixed || (hp->n_ok > 0 && (flags != hflags || hp->dyn_class != c->hint.dyn_class))) {
+        if (std::getenv("VAG_DEBUG_SPEC"))
+            std::fprintf(stderr, "[vag] planned-ahead call repeated: overflow %d mixed %d flags %d/%d dyn %d/%d rows %d cells %lld max_k %d (cap %d) max_pairs %d; hint rows %d cells %lld max_k %d max_pairs %d\n",
+                         hp->overflow, hp->flags_mixed, flags, hflags, hp->dyn_class, c->hint.dyn_class, hp->rows, (long long)hp->cells,
+                         hp->max_k, c->spec_cap_k, hp->max_pairs, c->hint.rows, (long long)c->hint.cells, c->hint.max_k, c->hint.max_pairs);
+        if (hp->overflow && hp->max_k > c->spec_cap_k)  // the lattice outgrew its head room: plan the next calls with more
+            c->spec_margin_k = std::min(32, 2 * c->spec_margin_k + 2);
+        c->hint_valid = false;
+        return VAG_RETRY;
+    }
+    c->hint = *hp;
+    c->hint_valid = hp->n_ok > 0;
+    c->n_ok = hp->n_ok;
+    c->plan.n_models_ok = hp->n_ok;
+    c->plan.n_rows = hp->rows;
+    c->plan.n_cells = hp->cells;
+    c->plan.total_pairs = hp->pairs;
+    c->plan.eat_cells = hp->eat;
+    c->plan.n_models_invalid = hp->n_invalid;
+    c->plan.n_models_capacity = hp->n_capacity;
+    return VAG_OK;
+}
+
 int check_status(vag_ctx* c, int nb) {
     const int rf = read_row_failures(c);
     if (rf) return rf;
     if (c->plan.n_rows_failed > 0)
         return set_err(VAG_E_NUMERIC, "%d ODE row(s): no acceptable step size after 500 rejections", c->plan.n_rows_failed);
+    if (c->plan.n_models_capacity == 0) return VAG_OK;
+    if (fetch_meta(c)) return VAG_E_HIP;
     const VagGridMeta* hm = c->h_meta.as<VagGridMeta>();
     for (int m = 0; m < nb; ++m)
         if (hm[m].status == VAG_E_CAPACITY)
@@ -1304,11 +1410,25 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
     HIPCHK(hipSetDevice(c->device));
-    int rc = prep_times(c, d_t, nt, d_nu, nnu);
-    if (rc) return rc;
-    rc = run_model_stages(c, d_params, nb, false);
-    if (rc) return rc;
-    return grid_request_chunked(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
+    int rc = VAG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {  // planned ahead from the previous call's summary, verified at the end
+        rc = prep_times(c, d_t, nt, d_nu, nnu);
+        if (rc) return rc;
+        c->allow_spec = attempt == 0 && !c->count_work;
+        rc = run_model_stages(c, d_params, nb, false);
+        c->allow_spec = false;
+        if (rc == VAG_OK) rc = grid_request_chunked(c, d_params, nb, nt, nnu, nullptr, d_out, nullptr);
+        if (rc) {
+            if (!c->spec_pending) return rc;
+            c->spec_pending = false;  // an error while planning from stale sizes is not the caller's: repeat on the waiting path
+            c->hint_valid = false;
+            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead grid call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            continue;
+        }
+        rc = finish_speculation(c);
+        if (rc != VAG_RETRY) break;
+    }
+    return rc;
 }
 
 static int upload_series_bands(vag_ctx* c, const double* nu, int n);
@@ -1321,7 +1441,7 @@ static int series_request(vag_ctx* c, const vag_model_params* d_params, int nb, 
     if (n <= chunk)
         return series_chunk(c, d_params, nb, c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), n, c->d_lg2nu.as<double>(), n,
                             d_out, n_bands);
-    DevBuf tmp;
+    DevBuf& tmp = c->d_chunk;  // grow-only context scratch: the stream orders its reuse
     if (tmp.ensure(sizeof(double) * (size_t)nb * chunk)) return VAG_E_HIP;
     int rc = VAG_OK;
     for (int s0 = 0; s0 < n && rc == VAG_OK; s0 += chunk) {
@@ -1332,9 +1452,6 @@ static int series_request(vag_ctx* c, const vag_model_params* d_params, int nb, 
                                              (size_t)nb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             rc = VAG_E_HIP;
     }
-    const hipError_t e = hipStreamSynchronize(c->stream);
-    tmp.release();
-    if (rc == VAG_OK && e != hipSuccess) return set_err(VAG_E_HIP, "chunked series: %s", hipGetErrorString(e));
     return rc;
 }
 
@@ -1345,11 +1462,25 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     HIPCHK(hipSetDevice(c->device));
     const int n_bands = c->pending_bands;  // only the host-pointer wrapper below knows the frequencies
     c->pending_bands = 0;
-    int rc = prep_times(c, d_t, n, d_nu, n);  // the grid sees the extrema of ALL requested times
-    if (rc) return rc;
-    rc = run_model_stages(c, d_params, nb, false);
-    if (rc) return rc;
-    return series_request(c, d_params, nb, n, d_out, n_bands);
+    int rc = VAG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = prep_times(c, d_t, n, d_nu, n);  // the grid sees the extrema of ALL requested times
+        if (rc) return rc;
+        c->allow_spec = attempt == 0 && !c->count_work;
+        rc = run_model_stages(c, d_params, nb, false);
+        c->allow_spec = false;
+        if (rc == VAG_OK) rc = series_request(c, d_params, nb, n, d_out, n_bands);
+        if (rc) {
+            if (!c->spec_pending) return rc;
+            c->spec_pending = false;
+            c->hint_valid = false;
+            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead series call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            continue;
+        }
+        rc = finish_speculation(c);
+        if (rc != VAG_RETRY) break;
+    }
+    return rc;
 }
 
 int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
@@ -1472,7 +1603,7 @@ int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* param
                           c->d_lg2nu.as<double>(), n, nullptr, n_bands, d4);
         if (rc) return rc;
     } else {  // long series (exposure sampling): chunks of sorted points on the same grid
-        DevBuf tmp;
+        DevBuf& tmp = c->d_chunk;  // grow-only context scratch: the stream orders its reuse
         if (tmp.ensure(sizeof(double) * 4 * (size_t)nb * chunk)) return VAG_E_HIP;
         for (int s0 = 0; s0 < n && rc == VAG_OK; s0 += chunk) {
             const int mlen = std::min(chunk, n - s0);
@@ -1485,10 +1616,7 @@ int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* param
                                               (size_t)nb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
                     rc = VAG_E_HIP;
         }
-        hipError_t e = hipStreamSynchronize(c->stream);
-        tmp.release();
         if (rc) return rc;
-        if (e != hipSuccess) return set_err(VAG_E_HIP, "series components: %s", hipGetErrorString(e));
     }
     for (int i = 0; i < 4; ++i)
         if (out4[i]) HIPCHK(hipMemcpyAsync(out4[i], d4[i], sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
@@ -1843,12 +1971,8 @@ vag_fit_back_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const 
     }
 }
 
-int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
-    if (!c) return set_err(VAG_E_INVALID, "null context");
-    if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
-    HIPCHK(hipSetDevice(c->device));
-    int rc = upload_fit_spec(c, spec, ndim);
-    if (rc) return rc;
+static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out, bool try_spec) {
+    int rc = VAG_OK;
     const int n = spec->n_data;
     hipStream_t st = c->stream;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
@@ -1886,11 +2010,23 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     c->ic_soft_fail = true;
     if (n > 0) {  // point data: one (t, nu) series per walker (fitter.py:510-522)
         if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
+        c->allow_spec = try_spec;
         rc = run_model_stages(c, d_params, nb, false);
+        c->allow_spec = false;
         if (rc == VAG_OK) rc = series_request(c, d_params, nb, n, c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
         if (rc == VAG_OK)
             rc = back(c->d_series_flux.as<double>(), n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n,
                       spec->ext_kernel ? d + 5 * (size_t)n : nullptr);
+        if (rc == VAG_OK) {
+            rc = finish_speculation(c);  // before a band group's own grid pass reuses the plan buffers
+            n_cap = std::max(n_cap, c->plan.n_models_capacity);
+            n_inv = std::max(n_inv, c->plan.n_models_invalid);
+        } else if (c->spec_pending) {  // an error while planning from stale sizes: repeat the call on the waiting path
+            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead likelihood call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            c->spec_pending = false;
+            c->hint_valid = false;
+            rc = VAG_RETRY;
+        }
     }
     size_t off = 6 * (size_t)std::max(n, 1);
     for (int g = 0; g < spec->n_bands && rc == VAG_OK; ++g) {  // band-integrated groups: one Model.flux request each (fitter.py:524-531)
@@ -1905,6 +2041,17 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     c->plan.n_models_capacity = n_cap;
     c->plan.n_models_invalid = n_inv;
     c->fit_stats_pending = true;
+    return rc;
+}
+
+int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = upload_fit_spec(c, spec, ndim);
+    if (rc) return rc;
+    rc = loglike_body(c, spec, d_theta, nb, ndim, d_out, !c->count_work);
+    if (rc == VAG_RETRY) rc = loglike_body(c, spec, d_theta, nb, ndim, d_out, false);
     return rc;
 }
 
@@ -1942,6 +2089,7 @@ static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min
     HIPCHK(hipStreamSynchronize(c->stream));
     rc = check_status(c, 1);
     if (rc) return rc;
+    if (fetch_meta(c)) return VAG_E_HIP;
     const VagGridMeta M = c->h_meta.as<VagGridMeta>()[0];
     shape->n_phi = M.n_phi;
     shape->n_theta = M.n_theta;
@@ -2016,6 +2164,7 @@ int vag_details_eat(vag_ctx* c, const vag_model_params* params, double t_min, do
     vag_details_shape sh;
     int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, false);
     if (rc) return rc;
+    if (fetch_meta(c)) return VAG_E_HIP;
     const VagGridMeta M = c->h_meta.as<VagGridMeta>()[0];
     if (n_phi_eff) *n_phi_eff = M.n_phi_eff;
     if (!t_obs && !doppler) return VAG_OK;  // shape query

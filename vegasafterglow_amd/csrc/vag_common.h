@@ -39,6 +39,19 @@ struct VagGridMeta {
     double t_end;    // 1.01 t_max / (1+z)
 };
 
+// Batch plan computed on the device from the grid results (vag_plan_kernel): the compact layout's totals, what decides
+// the kernels of the later stages, and whether the buffers the host sized in advance were large enough.
+struct VagDevPlan {
+    int32_t rows, max_k, max_pairs, n_ok, n_invalid, n_capacity;
+    int32_t flags_first;  // VAG_FLAG_* of the first valid model (-1: none)
+    int32_t flags_mixed;  // some valid model carries other flags
+    int32_t dyn_class;    // OR of VagGridMeta::dyn_class
+    int32_t overflow;     // a total exceeds the capacity the host launched with: every model was invalidated, nothing was written
+    int64_t cells, pairs, eat;
+    int32_t seq;          // host copy only: the call this summary belongs to (written last, after a system-scope fence)
+    int32_t pad_;
+};
+
 // Per-cell parameter block: [row][VAG_NPAR][n_t] in HBM, [k][VAG_NPAR] (144 B per cell) once staged in LDS.
 // 0..12: cached SmoothPowerLawSyn members read by compute_log2_I_nu (src/radiation/smooth-power-law-syn.h:20-47);
 // 13..17: what the EAT step needs (src/core/observer.cpp:143-205).  Members used together sit in 16-byte aligned

@@ -291,17 +291,117 @@ VAG_DEV void invert_cdf(const GridShared& sh, int num, bool midpoint, double* ou
     __syncthreads();
 }
 
-// One wavefront (blockDim.x == 64) per model.
+// Compact layout of a batch from its grid results, by ONE wavefront (the last one of vag_grid_kernel to finish): exclusive
+// scans of rows (n_reps) and cells (n_reps x n_t) over the models -> row_off / cell_off [nb + 1], and the totals / maxima /
+// flag summary the host plans the later stages with (VagDevPlan).  When a total exceeds the capacity the host sized its
+// buffers and launches for (it plans ahead from the previous call of the same batch size instead of waiting for this
+// summary), every model is marked VAG_E_CAPACITY and the offsets are zeroed: the later kernels find no work and write
+// nothing; the host sees `overflow` at the end of the call and repeats it.
+VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off, long long* __restrict__ cell_off,
+                            VagDevPlan* __restrict__ plan, VagDevPlan* host_plan /* pinned, host-mapped */, int seq, int cap_rows,
+                            long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn) {
+    const int t = threadIdx.x;
+    const int per = (nb + WAVE - 1) / WAVE, m0 = min(nb, t * per), m1 = min(nb, m0 + per);
+    long long cells = 0, pairs = 0, eat = 0;
+    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_inv = 0, n_cap = 0, first = -1, mixed = 0, dyn = 0;
+    for (int m = m0; m < m1; ++m) {
+        const VagGridMeta M = meta[m];
+        if (M.status == 0) {
+            rows += M.n_reps;
+            cells += (long long)M.n_reps * M.n_t;
+            max_k = max(max_k, M.n_t);
+            const int pr = M.n_theta * M.n_phi_eff;
+            max_pairs = max(max_pairs, pr);
+            pairs += pr;
+            eat += (long long)pr * M.n_t;
+            dyn |= M.dyn_class;
+            if (first < 0) first = M.flags;
+            mixed |= (M.flags != first) ? 1 : 0;
+            ++n_ok;
+        } else if (M.status == VAG_E_CAPACITY) {
+            ++n_cap;
+        } else {
+            ++n_inv;
+        }
+    }
+    // inclusive scans of rows / cells over the lanes, totals and summaries by butterflies
+    int r_inc = rows;
+    long long c_inc = cells;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int ro = __shfl_up(r_inc, off, WAVE);
+        const long long co = __shfl_up(c_inc, off, WAVE);
+        if (t >= off) {
+            r_inc += ro;
+            c_inc += co;
+        }
+    }
+    const int tot_rows = __shfl(r_inc, WAVE - 1, WAVE);
+    const long long tot_cells = __shfl(c_inc, WAVE - 1, WAVE);
+    int first_all = first < 0 ? INT32_MAX : t;  // lane of the first valid model
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pairs += __shfl_xor(pairs, off, WAVE);
+        eat += __shfl_xor(eat, off, WAVE);
+        max_k = max(max_k, __shfl_xor(max_k, off, WAVE));
+        max_pairs = max(max_pairs, __shfl_xor(max_pairs, off, WAVE));
+        n_ok += __shfl_xor(n_ok, off, WAVE);
+        n_inv += __shfl_xor(n_inv, off, WAVE);
+        n_cap += __shfl_xor(n_cap, off, WAVE);
+        dyn |= __shfl_xor(dyn, off, WAVE);
+        mixed |= __shfl_xor(mixed, off, WAVE);
+        first_all = min(first_all, __shfl_xor(first_all, off, WAVE));
+    }
+    const int flags_first = first_all == INT32_MAX ? -1 : __shfl(first, first_all, WAVE);
+    mixed |= __any(first >= 0 && first != flags_first) ? 1 : 0;
+    // a planned-ahead call also fixed the kernels of the later stages from the flags it expected (expect_flags >= 0): any
+    // difference is treated like an exceeded capacity, so a call that must be repeated never leaves plausible numbers behind
+    bool overflow = tot_rows > cap_rows || tot_cells > cap_cells || max_k > cap_k || max_pairs > cap_pairs;
+    if (expect_flags >= 0 && n_ok > 0) overflow = overflow || mixed || flags_first != expect_flags || dyn != expect_dyn;
+    if (t == 0) {
+        VagDevPlan P;
+        P.rows = tot_rows, P.cells = tot_cells, P.pairs = pairs, P.eat = eat, P.max_k = max_k, P.max_pairs = max_pairs;
+        P.n_ok = n_ok, P.n_invalid = n_inv, P.n_capacity = n_cap, P.flags_first = flags_first, P.flags_mixed = mixed;
+        P.dyn_class = dyn, P.overflow = overflow ? 1 : 0;
+        P.seq = seq, P.pad_ = 0;
+        *plan = P;
+        // the host's copy: written straight into pinned host memory while the later stages are still queued, summary first,
+        // sequence number last -- the host spins on the number instead of paying a copy + stream synchronisation
+        VagDevPlan H = P;
+        H.seq = host_plan->seq;  // not yet
+        *host_plan = H;
+        __threadfence_system();
+        __hip_atomic_store(&host_plan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();  // push the number itself out of the L2: nothing else in this kernel would
+    }
+    int r = r_inc - rows;  // exclusive prefixes of this lane's chunk
+    long long c = c_inc - cells;
+    for (int m = m0; m < m1; ++m) {
+        row_off[m] = overflow ? 0 : r;
+        cell_off[m] = overflow ? 0 : c;
+        const VagGridMeta M = meta[m];
+        if (M.status == 0) {
+            r += M.n_reps;
+            c += (long long)M.n_reps * M.n_t;
+            if (overflow) meta[m].status = VAG_E_CAPACITY;
+        }
+    }
+    if (t == 0) {
+        row_off[nb] = overflow ? 0 : tot_rows;
+        cell_off[nb] = overflow ? 0 : tot_cells;
+    }
+}
+
+// The adaptive grid of model m = blockIdx.x, by one wavefront.
 // tminmax[0..1]: min / max of the requested observer times [s] (device memory).
-__global__ void __launch_bounds__(WAVE)
-vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
+VAG_DEV void
+grid_model(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* __restrict__ meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
                 double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
                 double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */,
                 int* __restrict__ fail /* [4] ODE-row failure counters of the dynamics stage, reset here */) {
     const int m = blockIdx.x;
-    if (m >= nb) return;
     const int lane = threadIdx.x;
     if (m == 0 && lane < 4) fail[lane] = 0;
     __shared__ GridShared sh;
@@ -901,6 +1001,28 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                stamps_[5] - stamps_[4], stamps_[6] - stamps_[5], stamps_[7] - stamps_[6], stamps_[8] - stamps_[7],
                stamps_[8] - stamps_[0]);
 #endif
+}
+
+// One wavefront (blockDim.x == 64) per model; the last wavefront to finish also lays the batch out (plan_scan_wave): no
+// separate launch, no host round trip between the grids and the stages that depend on their sizes.
+__global__ void __launch_bounds__(WAVE)
+vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
+                VagGridMeta* meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
+                int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
+                double* __restrict__ g_geo_th, double* __restrict__ g_geo_ph, int* __restrict__ fail,
+                int* __restrict__ done_counter /* zero between launches */, int* __restrict__ row_off,
+                long long* __restrict__ cell_off, VagDevPlan* __restrict__ plan, VagDevPlan* host_plan, int seq, int cap_rows,
+                long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn) {
+    if ((int)blockIdx.x < nb) grid_model(params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail);
+    __shared__ int s_last;
+    __threadfence();  // this model's results are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done_counter, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *done_counter = 0;
+    plan_scan_wave(meta, nb, row_off, cell_off, plan, host_plan, seq, cap_rows, cap_cells, cap_k, cap_pairs, expect_flags, expect_dyn);
 }
 
 }  // namespace vag

@@ -40,7 +40,7 @@ vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const
                       double* __restrict__ det, double* __restrict__ icy,
                       const int* __restrict__ inj_idx /* optional: reverse shock's injection cutoff per row */) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    if (row >= n_rows || row >= lay.row_off[nb]) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -122,7 +122,7 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
                       Layout lay, const double* __restrict__ shock, long long n_cells, double* __restrict__ det,
                       const double* __restrict__ icy, double* __restrict__ cellpar, double* __restrict__ cellq) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
+    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     int lo = 0, hi = nb;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -327,7 +327,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                      const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* __restrict__ ictab,
                      int* __restrict__ ic_status) {
     const long long c = blockIdx.x;
-    if (c >= n_cells) return;
+    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int lane = threadIdx.x;
     __shared__ IcShared sh;
     int lo = 0, hi = nb;

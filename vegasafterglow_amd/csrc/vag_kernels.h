@@ -43,7 +43,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     // a wavefront carries rows_per_wave rows (the host spreads a small batch over the chip: lanes of one wavefront pay for
     // each other's rejected steps and save loops)
     const int row = blockIdx.x * rows_per_wave + threadIdx.x;
-    if ((int)threadIdx.x >= rows_per_wave || row >= n_rows) return;
+    if ((int)threadIdx.x >= rows_per_wave || row >= n_rows || row >= lay.row_off[nb]) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -216,7 +216,7 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
     if (threadIdx.x == 0) ring.head = ring.tail = ring.fin = 0;
     if (role == 0) s_status[lane] = 0;
     const int row = blockIdx.x * rows_per_wave + lane;
-    bool active = lane < rows_per_wave && row < n_rows;
+    bool active = lane < rows_per_wave && row < n_rows && row < lay.row_off[nb];
     int m = 0;
     VagGridMeta M = {};
     if (active) {
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256)
 vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, const double* __restrict__ shock,
                       long long n_cells, double* __restrict__ cellgeo) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
+    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     int lo = 0, hi = nb;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -403,7 +403,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
                  const int* __restrict__ inj_idx /* optional, per row: reverse shock's injection cutoff */,
                  double* raw_shock /* = shock when vag_dynamics_fast_kernel left (U2_th, m2) to be finished */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
+    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     // find model by cell offset
     int lo = 0, hi = nb;
     while (hi - lo > 1) {

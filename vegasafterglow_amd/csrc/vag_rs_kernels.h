@@ -33,7 +33,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
                          double* __restrict__ shock_rvs, long long n_cells, int* __restrict__ inj_idx,
                          int* __restrict__ row_status, int* __restrict__ fail) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    if (row >= n_rows || row >= lay.row_off[nb]) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
