@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- light-curves/s of the MI355X afterglow engine on BASELINE.json's configs[1].
+"""bench.py -- light-curves/s and MCMC walker-steps/s of the MI355X afterglow engine on BASELINE.json's configs.
 
-One "step" = one pass of the hot path (adaptive grid -> blast-wave ODE -> per-cell synchrotron -> EAT flux
-integration) over one batch of synthetic models: `--batch` Gaussian-jet off-axis models of the C2
-configuration (GaussianJet(0.1, 1e52, 300) + ISM(1), theta_obs = 0.3,
-resolutions (0.355, 0.31, 20.5) -> ~(64, 64, 199) grid, 200 times x 10 bands) with +-10 % jitter on the
-physical parameters.  Inputs (parameter structs, t, nu) are resident in HBM before the timed region and the
-fluxes stay in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 launch with torch.distributed.run
-(one rank per GPU): models are block-sharded (weak scaling: --batch models per rank), and each step ends with the
-all-gather of a per-model summary (8 B/model) that a sampler would consume.
+Headline (`value`): one "step" = one pass of the hot path (adaptive grid -> blast-wave ODE -> per-cell synchrotron -> EAT flux
+integration) over one batch of synthetic models: `--batch` Gaussian-jet off-axis models of BASELINE configs[1] (SURVEY.md 8d C2:
+GaussianJet(0.1, 1e52, 300) + ISM(1), theta_obs = 0.3, resolutions (0.355, 0.31, 20.5) -> ~(64, 64, 199) grid, 200 times x 10
+bands), every physical parameter jittered log-uniformly by +-10 % so that the batch is ragged like a real ensemble.  Inputs
+(parameter structs, t, nu) are resident in HBM before the timed region and the fluxes stay in HBM.
 
-Prints ONE JSON line (see README / DESIGN.md for the roofline conventions).
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 launch with torch.distributed.run (one rank per GPU): models are
+block-sharded (weak scaling: --batch models per rank) and each step ends with the all-gather of a per-model summary (8 B/model).
+
+The same JSON line carries what BASELINE.json's north_star asks for, each next to the reference CPU path timed on this box:
+  walker_steps*     MCMC walker-steps/s on configs[3] through the product's sharded evaluator (dist.WalkerSharder over
+                    Fitter.device_evaluator): 1024 and 512 (red-blue half) walkers over all ranks, ln L read by the host after
+                    every call as a sampler does; and, on one GPU, the per-rank shares of an 8-GPU run (128 / 64 walkers) with the
+                    strong-scaling ceiling they imply;
+  tophat_config0    configs[0] (the >= 100x target): single-call latency and batched throughput, on-axis and theta_obs = 0.05,
+                    with the reference on 1 core and on all host cores;
+  ensembles         configs[2] (FS + RS + SSC + KN) and configs[4] (two-component SSC ensemble, 1024 members) with tallied
+                    FP64 rooflines of their flux passes.
+Prints ONE JSON line (see DESIGN.md for the roofline conventions).
 """
 import argparse
 import ctypes as C
@@ -27,7 +36,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F_SPEC = 210.0   # FP64 flop-equivalents per spectrum evaluation
 F_INTERP = 26.0  # per log-log interpolation + exp2 + accumulate
-PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F_TABLE = 30.0   # per tabulated SSC spectrum evaluation (ICPhoton::compute_log2_I_nu: index + linear interpolation)
+PEAK_HBM_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP64_TFLOPS = 78.6  # FP64 vector = half the 157.3 TF FP32 vector peak of MI355X_MICROARCH.md
 
 
@@ -51,8 +61,7 @@ def c2_batch(nb, seed):
     return arr
 
 
-def cpu_baseline(arr, t, nu, budget_s=12.0):
-    """Reference CPU path timed on this box's host, one thread, on a bounded sample of the same workload."""
+def _cpu_lib():
     import _abi
     lib, kind = _abi.load_ref(), "reference"
     if lib is None:
@@ -61,23 +70,25 @@ def cpu_baseline(arr, t, nu, budget_s=12.0):
             import subprocess
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"])
             lib = _abi.load_oracle(fast=True)
+    return lib, kind
+
+
+def cpu_rate(call, n_items, budget_s, unit, what, min_calls=2):
+    """`call(i)` on ONE host thread for about budget_s seconds, cycling over n_items inputs."""
+    lib_kind = _cpu_lib()[1]
     n, t0 = 0, time.perf_counter()
-    while n < len(arr) and (time.perf_counter() - t0 < budget_s or n < 2):
-        lib.flux_density_grid(arr[n], t, nu)
+    while time.perf_counter() - t0 < budget_s or n < min_calls:
+        call(n % n_items)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "light-curves/s", "cores": 1, "kind": kind,
-            "sample": f"{n} models of the timed batch (C2: 200 t x 10 nu), single thread, {dt:.1f} s"}
+    return {"value": n / dt, "unit": unit, "cores": 1, "kind": lib_kind, "sample": f"{n} {what}, single thread, {dt:.1f} s"}
 
 
-def cpu_baseline_all_cores(arr, t, nu, budget_s=4.0):
-    """Same reference path on many host cores, one model per thread (the reference's own scheme:
-    ThreadPoolExecutor over walkers with the GIL released, fitting/samplers.py:59-91; ctypes drops the GIL too).
-    The box may expose more logical CPUs than its CPU quota grants, so a few thread counts are tried and the best
-    throughput is reported with the thread count that produced it."""
-    import _abi
+def cpu_rate_all_cores(call, n_items, budget_s, unit, what):
+    """Same on many host cores, one model per thread (the reference's own scheme: ThreadPoolExecutor over walkers with the GIL
+    released, fitting/samplers.py:59-91; ctypes drops the GIL too).  The box may expose more logical CPUs than its quota
+    grants, so a few thread counts are tried and the best throughput is reported with the count that produced it."""
     from concurrent.futures import ThreadPoolExecutor
-    lib = _abi.load_ref() or _abi.load_oracle(fast=True)
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -89,7 +100,7 @@ def cpu_baseline_all_cores(arr, t, nu, budget_s=4.0):
         def worker(w):
             n, i = 0, w
             while time.perf_counter() < deadline:
-                lib.flux_density_grid(arr[i % len(arr)], t, nu)
+                call(i % n_items)
                 n += 1
                 i += nthreads
             return n
@@ -98,66 +109,130 @@ def cpu_baseline_all_cores(arr, t, nu, budget_s=4.0):
         with ThreadPoolExecutor(nthreads) as ex:
             total = sum(ex.map(worker, range(nthreads)))
         dt = time.perf_counter() - t0
-        r = {"value": total / dt, "unit": "light-curves/s", "cores": nthreads,
-             "sample": f"{total} models, {nthreads} threads, {dt:.1f} s (host exposes {ncpu} logical CPUs)"}
+        r = {"value": total / dt, "unit": unit, "cores": nthreads, "kind": _cpu_lib()[1],
+             "sample": f"{total} {what}, {nthreads} threads, {dt:.1f} s (host exposes {ncpu} logical CPUs)"}
         if best is None or r["value"] > best["value"]:
             best = r
     return best
 
 
-def tophat_sweep(lib, h, _lib, dev):
+def timed_steps(step, steps, warmup, world, sync, barrier, max_over_ranks):
+    """The timing contract of the driver: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a device
+    synchronisation on both sides; the elapsed time is the MAX over ranks.  Backend-agnostic (sync / barrier / max_over_ranks
+    are callables) so that the N > 1 logic runs under gloo in the CPU tests."""
+    for _ in range(warmup):
+        step(False)
+    sync()
+    if world > 1:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    sync()
+    if world > 1:
+        barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    return max_over_ranks(elapsed) if world > 1 else elapsed
+
+
+def _dist_helpers(world, dev):
+    import torch
+    import torch.distributed as dist
+
+    def max_over_ranks(x):
+        el = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    return sync, (dist.barrier if world > 1 else (lambda: None)), max_over_ranks
+
+
+def _grid_call(lib, h, _lib, dev, prms, t, nu):
+    """Device-resident flux_density_grid call over a list / ctypes array of parameter structs."""
+    import torch
+    import _abi
+    nb = len(prms)
+    arr = prms if isinstance(prms, C.Array) else (_abi.ModelParams * nb)(*prms)
+    d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    d_t, d_nu = torch.from_numpy(np.ascontiguousarray(t)).to(dev), torch.from_numpy(np.ascontiguousarray(nu)).to(dev)
+    d_o = torch.empty((nb, nu.size, t.size), dtype=torch.float64, device=dev)
+    keep = (d_p, d_t, d_nu)
+
+    def call():
+        _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), nb, d_t.data_ptr(), t.size, d_nu.data_ptr(), nu.size,
+                                                       d_o.data_ptr()))
+    call.out, call.keep, call.arr = d_o, keep, arr
+    return call
+
+
+def tophat_sweep(lib, h, _lib, dev, with_cpu):
     """BASELINE configs[0] (the >= 100x target config): top-hat + ISM, resolutions (0.089, 0.05, 12),
-    100 times x 3 bands; single-call latency and batched throughput, on-axis (C1a) and theta_obs = 0.05 (C1b)."""
+    100 times x 3 bands; single-call latency and batched throughput, on-axis (C1a) and theta_obs = 0.05 (C1b), next to the
+    reference CPU path on this box (1 core and all cores)."""
     import torch
     import _abi
     import configs
     out = {}
     t, nu = configs.C1_T, configs.C1_NU
-    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
     for name, kw, batches in (("C1a_onaxis", configs.C1A, (1, 64, 1024, 4096)), ("C1b_theta_obs_0.05", configs.C1B, (1, 64, 1024))):
         res = {}
         for nb in batches:
             rng = np.random.default_rng(1)
-            arr = (_abi.ModelParams * nb)()
+            prms = []
             for i in range(nb):
                 k = dict(kw)
                 for key in ("E_iso", "n_ism", "eps_B"):
                     k[key] *= float(np.exp(rng.uniform(-0.1, 0.1)))
-                arr[i] = _abi.make_params(**k)
-            d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            d_o = torch.empty((nb, nu.size, t.size), dtype=torch.float64, device=dev)
-            call = lambda: _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), nb, d_t.data_ptr(), t.size,
-                                                                            d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+                prms.append(_abi.make_params(**k))
+            call = _grid_call(lib, h, _lib, dev, prms, t, nu)
             call()
             torch.cuda.synchronize()
+            reps = 20 if nb == 1 else 5
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(reps):
                 call()
+                if nb == 1:
+                    torch.cuda.synchronize()  # latency of ONE light curve: the caller waits for each
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 5
+            dt = (time.perf_counter() - t0) / reps
             res[f"batch_{nb}"] = {"ms_per_call": 1e3 * dt, "light_curves_per_s": nb / dt}
+        if with_cpu:
+            cpu, _ = _cpu_lib()
+            rng = np.random.default_rng(1)
+            cprm = []
+            for i in range(64):
+                k = dict(kw)
+                for key in ("E_iso", "n_ism", "eps_B"):
+                    k[key] *= float(np.exp(rng.uniform(-0.1, 0.1)))
+                cprm.append(_abi.make_params(**k))
+            f = lambda i: cpu.flux_density_grid(cprm[i], t, nu)
+            one = cpu_rate(f, 64, 2.0, "light-curves/s", "models of this config")
+            allc = cpu_rate_all_cores(f, 64, 2.0, "light-curves/s", "models")
+            res["cpu_baseline"], res["cpu_baseline_all_cores"] = one, allc
+            best = max(v["light_curves_per_s"] for k2, v in res.items() if k2.startswith("batch_"))
+            res["speedup_vs_reference"] = {"batched_vs_1_core": best / one["value"], "batched_vs_all_cores": best / allc["value"],
+                                           "single_call_vs_1_core": res["batch_1"]["light_curves_per_s"] / one["value"]}
         out[name] = res
     return out
 
 
 def ensemble_bench(lib, h, _lib, dev):
-    """BASELINE configs[2] and [4] as batched ensembles on one GPU: C3 = power-law jet in a wind,
-    forward + reverse shock with SSC + Klein-Nishina on both (jittered parameters); C5 = prior-predictive sweep of
-    two-component SSC jets.  100 times x 4 bands (incl. 2.4e26 Hz), device-resident inputs."""
+    """BASELINE configs[2] and [4] as batched ensembles on one GPU: C3 = power-law jet in a wind, forward +
+    reverse shock with SSC + Klein-Nishina on both (jittered parameters); C5 = prior-predictive sweep of two-component SSC
+    jets, 1024 members.  100 times x 4 bands (incl. 2.4e26 Hz), device-resident inputs.  The flux passes' FP64 roofline uses the
+    kernels' own work tallies (one extra untimed pass with vag_ctx_count_work): spectrum evaluations x 210 (synchrotron) or
+    x 30 (tabulated SSC spectrum) + interpolations x 26, over the flux stage's HIP-event time."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
     from ssc_ensemble import c3_batch, c5_batch
     t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
-    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
     out = {}
-    for name, prms, ref_ms in (("C3_fs_rs_ssc_kn", c3_batch(128), 1197.0), ("C5_two_component_ssc", c5_batch(256), 1120.0)):
+    for name, prms, ref_ms in (("C3_fs_rs_ssc_kn", c3_batch(128), 1197.0), ("C5_two_component_ssc", c5_batch(1024), 1120.0)):
         nb = len(prms)
-        import _abi
-        arr = (_abi.ModelParams * nb)(*prms)
-        d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        d_o = torch.empty((nb, nu.size, t.size), dtype=torch.float64, device=dev)
-        call = lambda: _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), nb, d_t.data_ptr(), t.size,
-                                                                        d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+        call = _grid_call(lib, h, _lib, dev, prms, t, nu)
         call()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -165,26 +240,35 @@ def ensemble_bench(lib, h, _lib, dev):
             call()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
+        st = _lib.StageTimes()
+        lib.vag_last_stage_times(h, C.byref(st))
+        _lib.check(lib.vag_ctx_count_work(h, 1))
+        call()
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_ctx_count_work(h, 0))
         plan = _lib.Plan()
         lib.vag_last_plan(h, C.byref(plan))
-        out[name] = {"batch": nb, "ms_per_batch": 1e3 * dt, "light_curves_per_s": nb / dt, "finite": bool(torch.isfinite(d_o).all()),
-                     "ode_rows": plan.n_rows, "cells": plan.n_cells,
+        # the tallies cover every flux pass of the call (synchrotron and SSC of each shock); half of the evaluations are the
+        # tabulated SSC spectrum on these SSC-on configurations
+        flops = plan.spec_evals * 0.5 * (F_SPEC + F_TABLE) + plan.interps * F_INTERP
+        out[name] = {"batch": nb, "ms_per_batch": 1e3 * dt, "light_curves_per_s": nb / dt,
+                     "finite": bool(torch.isfinite(call.out).all()), "ode_rows": plan.n_rows, "cells": plan.n_cells,
+                     "stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "cells_cooling_tables": st.cells_ms,
+                                  "flux_passes": st.flux_ms, "reduce": st.reduce_ms},
+                     "roofline_fp64_flux_passes": {"spec_evals": plan.spec_evals, "interps": plan.interps,
+                                                   "achieved": flops / (st.flux_ms * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+                                                   "unit": "TFLOP/s", "frac": flops / (st.flux_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
                      "reference_cpu_ms_per_model_survey": ref_ms}
     return out
 
 
-def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
-    """Secondary metric of BASELINE.json: MCMC walker-steps/s on the C4 problem: GW170817-like mock,
-    60 data points (3 bands x 20 epochs), 8 free parameters, default resolutions, 1024 walkers drawn uniformly
-    from the prior box, block-sharded over the ranks with one all-gather of ln L per step."""
-    import torch
-    import torch.distributed as dist
+def c4_fitter(lib, h, _lib):
+    """The C4 problem: GW170817-like mock from the engine's own truth model (+5 % noise, 10 % errors), 3 bands x 20
+    epochs, 8 free parameters with the prior box of configs.C4_FREE."""
     import configs
     from vegasafterglow_amd import fitting
-    from vegasafterglow_amd.dist import shard_range
     t, nu = configs.c4_mock_data()
     kw = configs.C4_TRUTH
-    # mock data from the engine's own truth model (+5 % noise, 10 % errors), built through the C-ABI
     truth = np.empty(t.size)
     p = _lib.ModelParams()
     lib.vag_params_default(C.byref(p))
@@ -201,41 +285,74 @@ def walker_bench(lib, h, _lib, dev, rank, world, steps=5, nwalkers=1024):
         fit.add_flux_density(b, t[sel], f_obs[sel], 0.1 * f_obs[sel])
     defs = [fitting.ParamDef(n, 10.0 ** lo if lg else lo, 10.0 ** hi if lg else hi,
                              fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
+    return fit, defs, (t, nu, f_obs)
+
+
+def walker_bench(lib, h, _lib, dev, rank, world, steps=10, nwalkers=1024, sharder_cls=None, host_consumes=True):
+    """MCMC walker-steps/s on the C4 problem: `nwalkers` drawn uniformly from the prior box, evaluated through the product's
+    sharded evaluator (dist.WalkerSharder: walkers dealt to the ranks by the engine's cost report, one all-gather of
+    [ln L | cost] per call).  host_consumes: the host reads ln L after every call (pinned copy + stream synchronisation), as a
+    sampler must before it can propose the next step; False queues the calls back to back."""
+    import torch
+    import torch.distributed as dist
+    from vegasafterglow_amd.dist import WalkerSharder
+    fit, defs, _ = c4_fitter(lib, h, _lib)
     spec, lo, hi = fit.build_spec(defs)
     theta = lo + (hi - lo) * np.random.default_rng(0).random((nwalkers, len(defs)))
-    a, b = shard_range(nwalkers, rank, world)
-    per = (nwalkers + world - 1) // world
-    d_theta = torch.from_numpy(np.ascontiguousarray(theta[a:b])).to(dev)
-    d_ll = torch.full((per,), float("nan"), dtype=torch.float64, device=dev)
-    d_all = torch.empty((per * world,), dtype=torch.float64, device=dev) if world > 1 else None
+    d_theta = torch.from_numpy(np.ascontiguousarray(theta)).to(dev)
+    sharder = (sharder_cls or WalkerSharder)(fit.device_evaluator(defs, context=(h, _NullLock())), device=dev)
+    h_ll = torch.empty((nwalkers,), dtype=torch.float64).pin_memory()
+    last = {}
 
-    def step():
-        _lib.check(lib.vag_loglike_batch_dev(h, C.byref(spec), d_theta.data_ptr(), b - a, spec.ndim, d_ll.data_ptr()))
-        if world > 1:
-            dist.all_gather_into_tensor(d_all, d_ll)
+    def step(_record):
+        ll = sharder(d_theta)
+        if host_consumes:
+            h_ll.copy_(ll, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        last["ll"] = ll
 
-    step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dt = float(el.item())
+    sync, barrier, max_over_ranks = _dist_helpers(world, dev)
+    dt = timed_steps(step, steps, 2, world, sync, barrier, max_over_ranks)
     st = _lib.StageTimes()
     lib.vag_last_stage_times(h, C.byref(st))
-    finite = int(torch.isfinite(d_ll[: b - a]).sum().item())
-    return {"value": nwalkers * steps / dt, "unit": "walker-steps/s", "walkers": nwalkers, "steps": steps,
-            "ms_per_step": 1e3 * dt / steps, "scaling": "strong", "finite_on_rank0": finite, "walkers_on_rank0": b - a,
-            "rank0_stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "syn_cells": st.cells_ms,
-                               "series_flux": st.flux_ms, "reduce": st.reduce_ms}}
+    finite = int(torch.isfinite(last["ll"]).sum().item())
+    res = {"value": nwalkers * steps / dt, "unit": "walker-steps/s", "walkers": nwalkers, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "scaling": "strong", "ln_L_read_by_host_every_call": host_consumes, "finite_walkers": finite,
+           "rank0_stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "syn_cells": st.cells_ms, "series_flux": st.flux_ms,
+                              "reduce": st.reduce_ms}}
+    if world > 1:
+        cpr = sharder.costs_per_rank()
+        if cpr is not None:
+            res["cost_per_rank_max_over_mean"] = float(cpr.max() / cpr.mean())
+    return res
+
+
+class _NullLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def walker_cpu_baseline(lib, h, _lib, budget_s=5.0):
+    """The reference's per-walker likelihood on one host core: Model.flux_density at the walker's parameters over the 60 C4 data
+    points (the chi^2 itself is negligible), prior draws of the same box."""
+    import _abi
+    import configs
+    cpu, _ = _cpu_lib()
+    fit, defs, (t, nu, _) = c4_fitter(lib, h, _lib)
+    _, lo, hi = fit.build_spec(defs)
+    theta = lo + (hi - lo) * np.random.default_rng(0).random((64, len(defs)))
+    prms = []
+    for s in theta:
+        kw = dict(configs.C4_TRUTH)
+        for (name, lg, _, _), v in zip(configs.C4_FREE, s):
+            kw[{"theta_v": "theta_obs"}.get(name, name)] = 10 ** v if lg else v
+        prms.append(_abi.make_params(**kw))
+    order = np.argsort(t)
+    ts, nus = np.ascontiguousarray(t[order]), np.ascontiguousarray(nu[order])
+    return cpu_rate(lambda i: cpu.flux_density(prms[i], ts, nus), 64, budget_s, "walker-steps/s", "prior draws of the C4 box (60 data points each)")
 
 
 def main():
@@ -245,7 +362,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="models per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-walkers", action="store_true", help="skip the secondary walker-steps/s measurement")
+    ap.add_argument("--no-walkers", action="store_true", help="skip everything but the headline measurement")
     args = ap.parse_args()
 
     import torch
@@ -269,24 +386,20 @@ def main():
     h = C.c_void_p()
     _lib.check(lib.vag_ctx_create(local_rank, C.byref(h)))
     stream = torch.cuda.current_stream()
-    _lib.check(lib.vag_ctx_set_stream(h, C.c_void_p(stream.cuda_stream)))
+    _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(stream)))
 
     nb = args.batch
     t_np, nu_np = configs.C2_T, configs.C2_NU
     nt, nnu = t_np.size, nu_np.size
     arr = c2_batch(nb, seed=1234 + rank)
     dev = torch.device("cuda", local_rank)
-    d_params = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-    d_t = torch.from_numpy(t_np).to(dev)
-    d_nu = torch.from_numpy(nu_np).to(dev)
-    d_out = torch.empty((nb, nnu, nt), dtype=torch.float64, device=dev)
+    call = _grid_call(lib, h, _lib, dev, arr, t_np, nu_np)
+    d_out = call.out
     gathered = torch.empty((world * nb,), dtype=torch.float64, device=dev) if world > 1 else None
-
     flux_ms = []
 
     def step(record):
-        _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_params.data_ptr(), nb, d_t.data_ptr(), nt, d_nu.data_ptr(), nnu,
-                                                       d_out.data_ptr()))
+        call()
         if world > 1:
             # what a sampler consumes per model (here: the band-summed fluence proxy), 8 B/model over RCCL
             dist.all_gather_into_tensor(gathered, d_out.sum(dim=(1, 2)))
@@ -295,24 +408,8 @@ def main():
             _lib.check(lib.vag_last_stage_times(h, C.byref(st)))  # HIP events on the kernel's own stream
             flux_ms.append((st.grid_ms, st.dynamics_ms, st.cells_ms, st.flux_ms, st.reduce_ms, st.total_ms))
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    sync, barrier, max_over_ranks = _dist_helpers(world, dev)
+    elapsed = timed_steps(step, args.steps, args.warmup, world, sync, barrier, max_over_ranks)
 
     # one extra UNTIMED pass with the kernel's work tallies on: exact spectrum-evaluation / interpolation counts
     _lib.check(lib.vag_ctx_count_work(h, 1))
@@ -323,12 +420,24 @@ def main():
     lib.vag_last_plan(h, C.byref(plan))
     if not bool(torch.isfinite(d_out).all()) or plan.n_models_ok != nb:
         raise SystemExit("bench produced non-finite fluxes or rejected models")
-    walkers = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world)
-    walkers_half = None if args.no_walkers else walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512)
+    extra = not args.no_walkers
+    walkers = walker_bench(lib, h, _lib, dev, rank, world) if extra else None
+    walkers_half = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512) if extra else None
+    walkers_queued = walker_bench(lib, h, _lib, dev, rank, world, host_consumes=False) if extra else None
     # an ensemble sized to the node (1024 walkers per GPU): the weak-scaling counterpart of the 1024-walker run above
-    walkers_weak = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=1024 * world) if (world > 1 and not args.no_walkers) else None
-    tophat = tophat_sweep(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
-    ensembles = ensemble_bench(lib, h, _lib, dev) if (not args.no_walkers and world == 1) else None
+    walkers_weak = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=1024 * world) if (world > 1 and extra) else None
+    shares = None
+    if extra and world == 1:  # what ONE rank of an 8-GPU run evaluates per call, measured here: the strong-scaling ceiling
+        s128 = walker_bench(lib, h, _lib, dev, 0, 1, nwalkers=128)
+        s64 = walker_bench(lib, h, _lib, dev, 0, 1, nwalkers=64)
+        shares = {"128_walkers_per_rank": s128, "64_walkers_per_rank_redblue": s64,
+                  "implied_8gpu_walker_steps_per_s": 1024.0 / (s128["ms_per_step"] * 1e-3),
+                  "implied_8gpu_redblue_walker_steps_per_s": 512.0 / (s64["ms_per_step"] * 1e-3),
+                  "implied_8gpu_speedup_over_1gpu": walkers["ms_per_step"] / s128["ms_per_step"],
+                  "note": "per-rank block of a 1024-walker (512 red-blue) step at 8 GPUs, timed on one GPU without the all-gather"}
+    with_cpu = not args.no_cpu_baseline and world == 1
+    tophat = tophat_sweep(lib, h, _lib, dev, with_cpu) if (extra and world == 1) else None
+    ensembles = ensemble_bench(lib, h, _lib, dev) if (extra and world == 1) else None
 
     if rank == 0:
         st = np.mean(np.array(flux_ms), axis=0)
@@ -345,7 +454,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: GaussianJet off-axis (theta_obs=0.3) + ISM, synchrotron+SSA, "
-                                   "resolutions (0.355,0.31,20.5) -> ~64x64x199 cells/model, 200 time bins x 10 bands",
+                                   "resolutions (0.355,0.31,20.5) -> ~64x64x199 cells/model, 200 time bins x 10 bands; "
+                                   "every physical parameter jittered +-10 % log-uniformly (ragged batch)",
                        "models_per_gpu_per_step": nb, "global_batch": world * nb, "parallelism": f"walker-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "vag_flux_grid_kernel",
                          "achieved": alg_bytes / flux_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -362,22 +472,38 @@ def main():
         }
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh; FETCH_SIZE x2 per the gfx950 note, calibrated on a kernel with known bytes)
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tp) and nb == 512 and world == 1:
-            out["roofline"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
+        for tp in ("r02_traffic.json", "r01_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", tp)
+            if os.path.exists(tp) and nb == 512 and world == 1:
+                out["roofline"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
+                break
         if walkers is not None:
             out["walker_steps"] = walkers
             out["walker_steps_redblue_half"] = walkers_half  # emcee red-blue moves evaluate nwalkers/2 per call
+            out["walker_steps_queued_back_to_back"] = walkers_queued
             if walkers_weak:
                 walkers_weak["scaling"] = "weak"
                 out["walker_steps_1024_per_gpu"] = walkers_weak
+            if shares:
+                out["walker_steps_per_rank_share_of_8gpu"] = shares
         if tophat is not None:
             out["tophat_config0"] = tophat
+            c1a = tophat.get("C1a_onaxis", {}).get("speedup_vs_reference")
+            if c1a:
+                out["north_star_100x_on_config0"] = {"batched_vs_reference_1_core": c1a["batched_vs_1_core"],
+                                                     "batched_vs_reference_all_cores": c1a["batched_vs_all_cores"],
+                                                     "met_vs_all_cores": bool(c1a["batched_vs_all_cores"] >= 100.0)}
         if ensembles:
             out["ensembles_config2_config4"] = ensembles
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(arr, t_np, nu_np)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(arr, t_np, nu_np)
+        if with_cpu:
+            cpu, _ = _cpu_lib()
+            f = lambda i: cpu.flux_density_grid(arr[i], t_np, nu_np)
+            out["cpu_baseline"] = cpu_rate(f, len(arr), 12.0, "light-curves/s", "models of the timed batch (C2: 200 t x 10 nu)")
+            out["cpu_baseline_all_cores"] = cpu_rate_all_cores(f, len(arr), 4.0, "light-curves/s", "models")
+            if walkers is not None:
+                wc = walker_cpu_baseline(lib, h, _lib)
+                out["walker_steps"]["cpu_baseline"] = wc
+                out["walker_steps"]["speedup_vs_reference_1_core"] = walkers["value"] / wc["value"]
         print(json.dumps(out))
     lib.vag_ctx_destroy(h)
     if world > 1:

@@ -150,7 +150,10 @@ typedef struct vag_ctx vag_ctx;
 
 int vag_ctx_create(int device, vag_ctx** out);
 void vag_ctx_destroy(vag_ctx* ctx);
-/* Use an external HIP stream (hipStream_t passed as void*); NULL = context's own stream. */
+/* Use an external HIP stream (hipStream_t passed as void*); NULL = the context's own (non-blocking) stream.
+ * The legacy default stream has the handle 0 and cannot be told apart from NULL: pass VAG_STREAM_LEGACY_DEFAULT for it
+ * (PyTorch's default `torch.cuda.current_stream()` IS that stream: its `.cuda_stream` is 0). */
+#define VAG_STREAM_LEGACY_DEFAULT ((void*)1)
 int vag_ctx_set_stream(vag_ctx* ctx, void* hip_stream);
 int vag_ctx_synchronize(vag_ctx* ctx);
 
@@ -315,6 +318,12 @@ int vag_loglike_batch(vag_ctx* ctx, const vag_fit_spec* spec, const double* thet
  * (see DESIGN.md "host synchronisation"). */
 int vag_loglike_batch_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim,
                           double* d_out);
+
+/* Relative cost of every model of the last batch call on this context, into HBM: d_cost[nb] = n_theta * n_phi_eff * n_t, the
+ * (theta, phi, t) cell count the equal-arrival-time integration walks (0 for a model that was not evaluated).  Stream-ordered,
+ * no host synchronisation.  A sharded sampler balances the next call's walker blocks with it: walker cost varies 8x over a
+ * prior box because every walker builds its own adaptive grid (fitter.py:503-533). */
+int vag_last_model_costs_dev(vag_ctx* ctx, int nb, double* d_cost);
 
 /*
  * Model.details(t_min, t_max) intermediates for ONE model (pybind/pymodel.cpp:315-348):

@@ -23,7 +23,7 @@ h = C.c_void_p()
 _lib.check(lib.vag_ctx_create(0, C.byref(h)))
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
-_lib.check(lib.vag_ctx_set_stream(h, C.c_void_p(stream.cuda_stream)))
+_lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(stream)))
 out = {}
 t, nu = configs.C1_T, configs.C1_NU
 d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)

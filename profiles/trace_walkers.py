@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 if os.environ.get("OWN_STREAM"):  # a torch side stream instead of the legacy default stream
     own = torch.cuda.Stream()
     torch.cuda.set_stream(own)
-_lib.check(lib.vag_ctx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+_lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream())))
 r = bench.walker_bench(lib, h, _lib, dev, 0, 1, steps=10, nwalkers=n)
 print(r["ms_per_step"], r["rank0_stage_ms"])
 

@@ -110,3 +110,124 @@ def test_sharded_loglike_world2_gloo_matches_single_process():
     for rank, full, calls in results:
         assert calls == [4] if rank == 0 else calls == [3]
         np.testing.assert_array_equal(full, want)  # every rank holds the full, identical vector
+
+
+# ---- the device-resident, cost-balanced sharder (the path bench.py and a sharded sampler use) ----
+
+def test_balanced_assignment_equal_counts_near_equal_costs():
+    rng = np.random.default_rng(1)
+    for n, world in ((1024, 8), (1027, 8), (7, 2), (3, 8), (512, 4)):
+        costs = np.exp(rng.uniform(np.log(1.0), np.log(8.0), n))  # the 8x spread of walker cost over a prior box
+        table = vdist.balanced_assignment(costs, world)
+        assert table.shape == (world, -(-n // world))
+        used = table[table >= 0]
+        assert np.array_equal(np.sort(used), np.arange(n))  # every unit exactly once
+        counts = (table >= 0).sum(axis=1)
+        assert counts.max() - counts.min() <= 1
+        if n >= 16 * world:
+            sums = np.array([costs[row[row >= 0]].sum() for row in table])
+            by_count = np.array([costs[a:b].sum() for a, b in (vdist.shard_range(n, r, world) for r in range(world))])
+            assert sums.max() / sums.mean() < 1.01  # dealt by cost: within 1 % of perfect
+            assert sums.max() / sums.mean() <= by_count.max() / by_count.mean()
+
+
+def _sharder_worker(rank, world, port, samples, data, q):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def eval_dev(theta):  # the oracle stands in for this rank's GPU; cost = a strong function of the viewing angle
+        block = theta.numpy()
+        calls.append(len(block))
+        return torch.from_numpy(_oracle_loglike(block, data)), torch.from_numpy(1.0 + 50.0 * block[:, 3] ** 2)
+
+    sharder = vdist.WalkerSharder(eval_dev)
+    first = sharder(torch.from_numpy(samples)).numpy().copy()
+    second = sharder(torch.from_numpy(samples)).numpy().copy()  # now dealt by the costs the first call reported
+    cpr = sharder.costs_per_rank()
+    grid = vdist.sharded_flux_density_grid(list(range(5)), lambda blk: torch.tensor([[float(i), 2.0 * i] for i in blk],
+                                                                                 dtype=torch.float64), (2,))
+    lo, hi, mine = vdist.sharded_flux_density_grid(list(range(5)), lambda blk: torch.tensor([[float(i), 2.0 * i] for i in blk],
+                                                                                             dtype=torch.float64), (2,), gather=False)
+    q.put((rank, first, second, calls, cpr, sharder.last_table.copy(), grid.numpy(), (lo, hi, mine.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_walker_sharder_world2_gloo_device_path_and_cost_balance():
+    data = _c4_spec_and_data()
+    rng = np.random.default_rng(0)
+    lo = np.array([f[2] for f in configs.C4_FREE])
+    hi = np.array([f[3] for f in configs.C4_FREE])
+    samples = lo + (hi - lo) * rng.random((9, len(lo)))  # odd count: ragged shards 5 + 4
+    samples[3, 2] = -1.0  # invalid theta_c -> -inf, not a crashed rank
+    want = _oracle_loglike(samples, data)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharder_worker, args=(r, 2, port, samples, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tables = []
+    for rank, first, second, calls, cpr, table, grid, (glo, ghi, gmine) in results:
+        np.testing.assert_array_equal(first, want)   # full, identical vector on every rank ...
+        np.testing.assert_array_equal(second, want)  # ... whatever the deal
+        assert sorted(calls) == sorted([5, 5] if rank == 0 else [4, 4])
+        costs = 1.0 + 50.0 * samples[:, 3] ** 2
+        by_count = np.array([costs[:5].sum(), costs[5:].sum()])
+        assert cpr.max() / cpr.mean() <= by_count.max() / by_count.mean() + 1e-12
+        tables.append(table)
+        np.testing.assert_array_equal(grid, np.array([[i, 2.0 * i] for i in range(5)]))
+        assert (glo, ghi) == ((0, 3) if rank == 0 else (3, 5))
+        np.testing.assert_array_equal(gmine, np.array([[i, 2.0 * i] for i in range(glo, ghi)]))
+    np.testing.assert_array_equal(tables[0], tables[1])  # both ranks computed the same deal without talking
+
+
+def _bench_logic_worker(rank, world, port, q):
+    """bench.py's N > 1 branch on CPU: the timing contract (warm-up, barrier, EXACT step count, max over ranks) and the
+    per-step collective, with a sleep standing in for the GPU step."""
+    import time
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, _abi.ROOT)
+    import bench
+    dev = torch.device("cpu")
+    counted = {"steps": 0, "recorded": 0}
+    gathered = torch.empty((world * 4,), dtype=torch.float64)
+
+    def step(record):
+        time.sleep(0.01 * (1 + rank))  # rank 1 is the slow one
+        dist.all_gather_into_tensor(gathered, torch.full((4,), float(rank), dtype=torch.float64))
+        counted["steps"] += 1
+        counted["recorded"] += 1 if record else 0
+
+    sync, barrier, max_over_ranks = bench._dist_helpers(world, dev)
+    elapsed = bench.timed_steps(step, 5, 2, world, sync, barrier, max_over_ranks)
+    q.put((rank, elapsed, dict(counted), gathered.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_timing_contract_under_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_logic_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, e0, c0, g0), (r1, e1, c1, g1) = results
+    assert c0 == c1 == {"steps": 7, "recorded": 5}  # 2 warm-up + exactly 5 timed
+    assert e0 == e1 and e0 >= 5 * 0.02  # the MAX over ranks (the slow rank's 5 x 20 ms), identical on both
+    np.testing.assert_array_equal(g0, [0, 0, 0, 0, 1, 1, 1, 1])

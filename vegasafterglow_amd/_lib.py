@@ -103,7 +103,7 @@ EXPORTS = [
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_last_model_costs_dev", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
 _lib = None
@@ -116,6 +116,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); the engine links the system one (/opt/rocm/lib).
+    # Both carry the same SONAME, so whichever is mapped first serves both -- and torch does not initialise on the system
+    # runtime ("No HIP GPUs are available").  Streams and device pointers are shared with torch (vag_ctx_set_stream, the *_dev
+    # entry points), so the process must run ONE runtime: torch's, mapped before the engine.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a torch-free process uses the system runtime
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the gfx950 engine first (python -c 'import __graft_entry__ as g; g.build()')")
@@ -145,6 +153,7 @@ def load():
     lib.vag_flux_density_batch_dev.argtypes = [v, v, C.c_int, v, v, C.c_int, v]
     lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
     lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
+    lib.vag_last_model_costs_dev.argtypes = [v, C.c_int, v]
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_rvs.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_radiation.argtypes = [v, _pp, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]
@@ -155,6 +164,13 @@ def load():
     lib.vag_ctx_count_work.argtypes = [v, C.c_int]
     _lib = lib
     return lib
+
+
+def torch_stream_handle(stream):
+    """The void* vag_ctx_set_stream takes for a torch.cuda.Stream: its HIP handle, or VAG_STREAM_LEGACY_DEFAULT for torch's default
+    stream (handle 0 = the legacy default stream; a plain 0 would select the context's own stream and the engine would race
+    with torch's kernels)."""
+    return C.c_void_p(stream.cuda_stream or 1)
 
 
 def last_error():

@@ -490,7 +490,10 @@ void vag_ctx_destroy(vag_ctx* c) {
 
 int vag_ctx_set_stream(vag_ctx* c, void* s) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
-    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    if (s == VAG_STREAM_LEGACY_DEFAULT)
+        c->stream = nullptr;  // the legacy default stream
+    else
+        c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return VAG_OK;
 }
 
@@ -1165,11 +1168,15 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     hipStream_t st = c->stream;
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
-    // series work per pair is small: fewer, longer workgroups
-    long long ppb = std::max<long long>(8, (c->total_pairs + 32767) / 32768);
-    ppb = std::min<long long>(ppb, std::max(1, c->max_pairs));
+    // series work per (theta, phi) row is small: fewer, longer wavefronts as the batch grows.  The partial sums are kept per
+    // SERIES_CHUNK rows whatever this choice is, so a model's result does not depend on what else is in the batch (a walker
+    // scores the same bits alone, in a block of 64, or among 1024).
+    long long ppb = std::max<long long>(SERIES_CHUNK, (c->total_pairs + 32767) / 32768);
+    ppb = (ppb + SERIES_CHUNK - 1) / SERIES_CHUNK * SERIES_CHUNK;
+    if (const char* e = std::getenv("VAG_SERIES_PPB")) ppb = std::max(1, std::atoi(e)) * SERIES_CHUNK;  // tuning override (in chunks)
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
-    if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * n)) return VAG_E_HIP;
+    const int max_chunks = std::max(1, (c->max_pairs + SERIES_CHUNK - 1) / SERIES_CHUNK);
+    if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_chunks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
     if (n > SERIES_THREADS) n_bands = 0;  // the shared-node path keeps one point per lane
     // wavefronts per workgroup: four when their private rows fit next to the shared tables, else two or one
@@ -1202,6 +1209,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.n = n;
     a.pairs_per_block = (int)ppb;
     a.max_blocks = max_blocks;
+    a.max_chunks = max_chunks;
     a.k_stride = ks;
     a.partial = c->d_partial.as<double>();
     a.sp_table = c->d_sptab.as<double>();
@@ -1235,7 +1243,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params,
-                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, (int)ppb, n, d_out);
+                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_chunks, SERIES_CHUNK, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
     return VAG_OK;
@@ -2053,6 +2061,22 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     rc = loglike_body(c, spec, d_theta, nb, ndim, d_out, !c->count_work);
     if (rc == VAG_RETRY) rc = loglike_body(c, spec, d_theta, nb, ndim, d_out, false);
     return rc;
+}
+
+__global__ void vag_model_cost_kernel(const VagGridMeta* __restrict__ meta, int nb, double* __restrict__ cost) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nb) return;
+    const VagGridMeta M = meta[m];
+    cost[m] = M.status == 0 ? (double)M.n_theta * (double)M.n_phi_eff * (double)M.n_t : 0.0;
+}
+
+int vag_last_model_costs_dev(vag_ctx* c, int nb, double* d_cost) {
+    if (!c || !d_cost) return set_err(VAG_E_INVALID, "null context or buffer");
+    if (nb <= 0 || nb != c->nb || !c->d_meta.p) return set_err(VAG_E_INVALID, "no batch of %d models has been evaluated on this context", nb);
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(vag_model_cost_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb, d_cost);
+    HIPCHK(hipGetLastError());
+    return VAG_OK;
 }
 
 int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {

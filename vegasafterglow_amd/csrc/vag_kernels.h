@@ -984,6 +984,7 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 constexpr int SERIES_THREADS = 64;    // lanes that share one (theta, phi) row: ONE wavefront, so rows need no block barrier
 constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup (fewer when long lattices need the LDS); they only share the tables
 constexpr int SERIES_MAX_SLOTS = 8;   // data points per lane: n <= 512
+constexpr int SERIES_CHUNK = 8;       // (theta, phi) rows per partial sum: the unit of a model's summation tree, whatever the batch
 constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
 __host__ __device__ inline int series_region_doubles(int ks, bool ic, int n_bands) {
@@ -1010,8 +1011,8 @@ struct SeriesArgs {
     const double* lg2_t_obs;  // [n]
     const double* lg2_nu_obs; // [n]
     int n;
-    int pairs_per_block, max_blocks, k_stride;
-    double* partial; // [nb][max_blocks][n]
+    int pairs_per_block /* multiple of SERIES_CHUNK */, max_blocks, max_chunks, k_stride;
+    double* partial; // [nb][max_chunks][n]
     const double* sp_table;
     const double* cellq;  // FLUX_SYN_IC: [cells][FLUX_NQ]
     const double* ictab;  // FLUX_SSC: [cells][FLUX_IC_STRIDE]
@@ -1073,7 +1074,9 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int vb = blockIdx.x * (blockDim.x >> 6) + wave;  // virtual block = wavefront (the host launches 4, 2 or 1 per workgroup)
     if (vb >= a.max_blocks) return;
     const VagGridMeta M = a.meta[m];
-    double* my_partial = a.partial + ((size_t)m * a.max_blocks + vb) * a.n;
+    // partial sums are written per CHUNK of SERIES_CHUNK (theta, phi) rows, not per wavefront: the host picks the rows per
+    // wavefront from the batch size, and a model's summation tree must not depend on what else is in the batch
+    double* chunk_partial = a.partial + (size_t)m * a.max_chunks * a.n;
     if (M.status != 0) return;
     const int n_pairs = M.n_theta * M.n_phi_eff;
     const int p0 = vb * a.pairs_per_block;
@@ -1121,6 +1124,15 @@ vag_flux_series_kernel(SeriesArgs a) {
     for (int pair = p0; pair < p1; ++pair) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
         const int rep = rep_of[j];
+        if (pair > p0 && (pair - p0) % SERIES_CHUNK == 0) {  // p0 is a multiple of SERIES_CHUNK: close the chunk before this row
+            double* dst = chunk_partial + (size_t)(pair / SERIES_CHUNK - 1) * a.n;
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+                const int s = tid + q * SERIES_THREADS;
+                if (s < a.n) dst[s] = acc[q];
+                acc[q] = 0;
+            }
+        }
         wave_sync();
         VAG_SER_MARK(c_pts);
         if (rep != staged_rep) {
@@ -1245,10 +1257,13 @@ vag_flux_series_kernel(SeriesArgs a) {
     if (m == 0 && vb == 0 && tid == 0)
         printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  points %lld\n", p1 - p0, K, c_stage, c_eat, c_pts);
 #endif
+    {
+        double* dst = chunk_partial + (size_t)((p1 - 1) / SERIES_CHUNK) * a.n;  // the last (possibly short) chunk of this wavefront
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-        const int s = tid + q * SERIES_THREADS;
-        if (s < a.n) my_partial[s] = acc[q];
+        for (int q = 0; q < NSLOT; ++q) {
+            const int s = tid + q * SERIES_THREADS;
+            if (s < a.n) dst[s] = acc[q];
+        }
     }
     if (MODE == FLUX_SSC && breach) atomicOr(a.ic_status + m, 2);
 }

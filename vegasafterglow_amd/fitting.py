@@ -411,6 +411,37 @@ class Fitter:
             raise ValueError("samples must be [nb, ndim]")
         return self._device_loglike(spec, samples)
 
+    def device_evaluator(self, param_defs, priors=None, use_priors=False, context=None):
+        """eval_dev(theta) -> (values, costs) for vegasafterglow_amd.dist.WalkerSharder: theta is a float64 torch tensor [k, ndim]
+        on this fitter's GPU; values = ln L (use_priors=False) or ln L + ln prior with the bounds mask (use_priors=True),
+        costs = the engine's per-walker cell counts -- both float64[k] tensors on the device.  The call runs on torch's current
+        stream through vag_loglike_batch_dev: nothing crosses PCIe.  Priors that only exist as host objects are not accepted
+        here (the device path must be self-contained)."""
+        import torch
+        spec, _, _ = self.build_spec(param_defs, priors=priors, use_priors=use_priors)
+        if self._host_priors:
+            raise ValueError("device_evaluator: priors must be Uniform / Gaussian / LogUniform (evaluated on the device)")
+        lib = _lib.load()
+        if context is None:
+            h, lock = get_context(self.device)
+        else:
+            h, lock = context
+        dev = torch.device("cuda", self.device)
+        keep = [spec]  # the spec's arrays are owned by this Fitter; the struct itself by this closure
+
+        def eval_dev(theta):
+            theta = theta.contiguous()
+            k = theta.shape[0]
+            values = torch.empty((k,), dtype=torch.float64, device=dev)
+            costs = torch.empty((k,), dtype=torch.float64, device=dev)
+            with lock:
+                _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+                _lib.check(lib.vag_loglike_batch_dev(h, C.byref(keep[0]), theta.data_ptr(), k, keep[0].ndim, values.data_ptr()))
+                _lib.check(lib.vag_last_model_costs_dev(h, k, costs.data_ptr()))
+            return values, costs
+
+        return eval_dev
+
     def _device_loglike(self, spec, samples):
         out = np.empty(samples.shape[0])
         h, lock = get_context(self.device)
