@@ -389,3 +389,117 @@ def test_custom_extinction_callables_in_either_signature():
     needs = fitting.Fitter(z=1.0, lumi_dist=1e28, extinction=lambda l, params: params["R_V"] / l)
     with pytest.raises(TypeError):
         needs._k_lambda(lam)
+
+
+def _toy_fitter():
+    f = fitting.Fitter(z=0.1, lumi_dist=1e27, jet="tophat", medium="ism")
+    f.add_flux_density(5e14, np.array([1e4, 1e5, 1e6]), np.array([1e-26, 1e-27, 1e-28]), np.array([1e-27, 1e-28, 1e-29]))
+    P, S = fitting.ParamDef, fitting.Scale
+    return f, [P("E_iso", 1e50, 1e54, S.log), P("theta_v", 0.0, 0.8, S.linear), P("p", 2.05, 2.8, S.linear)]
+
+
+def test_emcee_adapter_follows_the_vectorized_ensemble_sampler_protocol(monkeypatch):
+    """sampling.emcee_sampler against a stand-in with emcee 3's call protocol for vectorize=True (ensemble.py compute_log_prob):
+    the log-probability function receives a float64 [n, ndim] block -- the whole ensemble first, then one red-blue half per
+    move --, must return n values, NaN raises "Probability function returned NaN", -inf is a legal rejection.  The closure
+    built by Fitter.make_log_prob_batch has to satisfy that contract without emcee being installed here."""
+    import sys
+    import types
+    from vegasafterglow_amd import sampling
+    calls = []
+
+    class EnsembleSampler:  # the part of emcee.EnsembleSampler the reference uses (fitting/samplers.py:100-130)
+        def __init__(self, nwalkers, ndim, log_prob_fn, vectorize=False, moves=None, **kw):
+            assert vectorize is True, "the reference passes vectorize=True"
+            self.nwalkers, self.ndim, self.fn, self.moves = nwalkers, ndim, log_prob_fn, moves
+            self.chain, self.lnprob = [], []
+
+        def compute_log_prob(self, coords):
+            p = np.asarray(coords, dtype=np.float64)
+            assert p.ndim == 2 and p.shape[1] == self.ndim
+            results = self.fn(p)  # vectorize: ONE call with the block
+            calls.append(p.shape[0])
+            try:
+                log_prob = np.array([float(r[0]) for r in results])
+            except (IndexError, TypeError):
+                log_prob = np.array([float(r) for r in results])
+            assert log_prob.shape == (p.shape[0],)
+            if np.any(np.isnan(log_prob)):
+                raise ValueError("Probability function returned NaN")
+            return log_prob
+
+        def run_mcmc(self, initial_state, nsteps, rng=np.random.default_rng(0)):
+            pos = np.array(initial_state, dtype=np.float64)
+            lp = self.compute_log_prob(pos)
+            half = self.nwalkers // 2
+            for _ in range(nsteps):
+                for s, c in ((slice(0, half), slice(half, None)), (slice(half, None), slice(0, half))):
+                    z = ((2.0 - 1.0) * rng.random(half) + 1.0) ** 2 / 2.0
+                    partner = pos[c][rng.integers(half, size=half)]
+                    prop = partner + z[:, None] * (pos[s] - partner)
+                    new = self.compute_log_prob(prop)
+                    take = np.log(rng.random(half)) < (self.ndim - 1) * np.log(z) + new - lp[s]
+                    pos[s] = np.where(take[:, None], prop, pos[s])
+                    lp[s] = np.where(take, new, lp[s])
+                self.chain.append(pos.copy())
+                self.lnprob.append(lp.copy())
+            return pos
+
+    monkeypatch.setitem(sys.modules, "emcee", types.SimpleNamespace(EnsembleSampler=EnsembleSampler))
+    f, defs = _toy_fitter()
+    _, lo, hi = f.build_spec(defs)
+    centre = 0.5 * (lo + hi)
+
+    def fake_loglike(s):  # stands in for the device: a Gaussian in sampler space; one walker per call comes back NaN
+        out = -0.5 * np.sum(((s - centre) / (0.05 * (hi - lo))) ** 2, axis=1)
+        out[0] = np.nan  # the closure must turn a non-finite likelihood into -inf, never hand NaN to the sampler
+        return out
+
+    sampler = sampling.emcee_sampler(f, defs, nwalkers=16, loglike_fn=fake_loglike)
+    assert isinstance(sampler, EnsembleSampler) and sampler.ndim == 3
+    rng = np.random.default_rng(1)
+    pos0 = sampling.initial_positions(lo, hi, 16, rng)
+    pos0[3, 0] = hi[0] + 1.0  # an out-of-bounds walker: -inf, not an exception
+    sampler.run_mcmc(pos0, 40)
+    assert calls[0] == 16 and set(calls[1:]) == {8}  # whole ensemble, then red-blue halves
+    lnp = np.array(sampler.lnprob)
+    assert not np.any(np.isnan(lnp)) and np.isfinite(lnp[-1]).sum() >= 14
+    chain = np.array(sampler.chain)[:, np.isfinite(lnp[-1])]
+    assert np.all(chain >= lo) and np.all(chain <= hi)  # accepted positions never leave the prior box
+
+
+def test_batch_pool_serves_a_nested_sampler_queue_like_bilby_drives_it():
+    """BatchPool against the way bilby hands a pool to dynesty (bilby/core/sampler/dynesty.py: `pool.map(loglikelihood, points)`
+    with queue_size points per call, `use_pool={"loglikelihood": True}`, then pool.close() / pool.join() when the run ends;
+    fitting/samplers.py:157-188 builds exactly that): every queue is ONE batched evaluation, the per-point callable is never
+    needed for point queues, results keep the queue's order, and the pool object survives close/join like a thread pool."""
+    from vegasafterglow_amd import sampling
+    f, defs = _toy_fitter()
+    _, lo, hi = f.build_spec(defs)
+    evaluated = []
+
+    def fake_loglike(s):
+        evaluated.append(len(s))
+        return -np.sum((s - lo) / (hi - lo), axis=1)
+
+    log_prob = f.make_log_prob_batch(defs, loglike_fn=fake_loglike)
+    pool = sampling.BatchPool(log_prob, ndim=3, size=24)
+
+    def per_point(v):  # bilby's _log_likelihood_wrapper: must not be called for a point queue
+        raise AssertionError("point queues go through the batched call")
+
+    rng = np.random.default_rng(2)
+    live = lo + (hi - lo) * rng.random((100, 3))
+    logl = np.array(pool.map(per_point, list(live)))        # initial live points: one call
+    assert logl.shape == (100,) and evaluated == [100]
+    for it in range(5):                                      # each iteration fills a queue of `size` proposals
+        queue = [lo + (hi - lo) * rng.random(3) for _ in range(pool.size)]
+        queue[0] = hi + 1.0                                   # a proposal outside the prior box: -inf, still one call
+        out = pool.map(per_point, queue)
+        assert len(out) == pool.size and out[0] == -np.inf and np.all(np.isfinite(out[1:]))
+        want = -np.sum((np.array(queue[1:]) - lo) / (hi - lo), axis=1) - np.sum(np.log(hi - lo))
+        np.testing.assert_allclose(out[1:], want, rtol=1e-13)  # order preserved
+    assert evaluated == [100] + [pool.size - 1] * 5 and pool.calls == 6
+    pool.close()
+    pool.join()
+    assert pool.map(per_point, [live[0]])[0] == logl[0]      # like ThreadPoolWithClose, still usable by a resumed run

@@ -432,7 +432,7 @@ RS_TIGHT = ["rs_thin_tophat", "rs_thick_offaxis", "rs_two_component", "rs_tophat
 
 @pytest.mark.parametrize("name", ["C3"] + list(configs.RS_CASES))
 def test_rs_components_match_oracle(eng, oracle, name):
-    kw, t, nu = {"C3": (configs.C3, configs.C3_T[::2], configs.C3_NU)}.get(name) or configs.RS_CASES[name]
+    kw, t, nu = {"C3": (configs.C3, configs.C3_T, configs.C3_NU)}.get(name) or configs.RS_CASES[name]
     prm = _abi.make_params(**kw)
     want = oracle.flux_components4(prm, t, nu)
     got = gpu_components4(eng, prm, t, nu)
@@ -1204,3 +1204,29 @@ def test_bounds_mask_and_priors_run_on_the_device(eng, oracle):
     f2._all_t = None
     ll2 = f2.loglike_batch(samples[:4], defs)
     assert not np.allclose(ll2, ll[:4]) and np.allclose(f.loglike_batch(samples[:4], defs), ll[:4], rtol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["rs_gaussian_adiabatic", "gauss_ism_rs", "step_powerlaw_rs_spread"])
+def test_rs_structured_jet_deviations_collapse_with_ode_tolerance(eng, oracle, name):
+    """The three reverse-shock-on-structured-jet cases that are only held to the reference's golden contract at the default ODE
+    tolerance (their low-Gamma wing rows amplify last-bit differences of the coupled 11-variable solve into a different step
+    sequence; the reference's own -O3 and strict builds differ by 1e-3 ... 5e-3 on the same rows,
+    profiles/r02_rs_structured_diagnostic.txt).  If that is the whole story the disagreement must vanish when BOTH sides
+    integrate to rtol = 1e-9; a defect in the pair solver or the relic cooling would stay.  Measured: 3.6e-4 -> 1.8e-6,
+    7.0e-3 -> 1.7e-5, 2.5e-3 -> 3.6e-8 (rvs.sync); forward shock <= 4e-7."""
+    if name == "gauss_ism_rs":
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        prm, t, nu = _abi.params_from_golden_config(json.loads(str(g["config"]))), np.ascontiguousarray(g["t"]), np.ascontiguousarray(g["nus"])
+    elif name == "step_powerlaw_rs_spread":
+        prm, t, nu = _abi.make_params(**configs.PROFILE_CASES[name]), configs.SPREAD_T, configs.SPREAD_NU
+    else:
+        kw, t, nu = configs.RS_CASES[name]
+        prm = _abi.make_params(**kw)
+    prm.rtol = 1e-9
+    want = oracle.flux_components4(prm, t, nu)
+    got = gpu_components4(eng, prm, t, nu)
+    for g_, w, comp in zip(got, want, COMPONENTS):
+        if w.max() == 0:
+            assert np.all(g_[0] == 0), comp
+        else:
+            assert_close(g_[0], w, rtol=5e-5 if comp == "rvs_sync" else 2e-6, floor=1e-2)

@@ -102,9 +102,10 @@ def _device_prior(prior):
 
 
 class Fitter:
-    """Fitter(z, lumi_dist, jet=..., medium=..., resolution=..., rtol=...) for point flux-density data."""
+    """Fitter(*, z=0.0, lumi_dist=1e26, jet=..., medium=..., resolution=..., rtol=...): keyword-only with the reference's
+    defaults (fitter.py:96-135)."""
 
-    def __init__(self, z, lumi_dist, jet="tophat", medium="ism", resolution=None, rtol=1e-6,
+    def __init__(self, *, z=0.0, lumi_dist=1e26, jet="tophat", medium="ism", resolution=None, rtol=1e-6,
                  radiative_fireball=True, device=0, fwd_ssc=False, kn=False, rvs_shock=False, rvs_ssc=False,
                  magnetar=False, extinction=None):
         # extinction: k(lambda_rest [cm]) -> A_lambda / A_V of the host-galaxy law (a callable; fitter.py:379-397).  The
@@ -275,10 +276,8 @@ class Fitter:
         p.rtol = self.rtol
         p.radiative_fireball = 1 if self.radiative_fireball else 0
         p.flags = (_lib.FLAG_SSC if self.fwd_ssc else 0) | (_lib.FLAG_KN if self.kn else 0)  # fitter.py:466-473
-        if self.magnetar:  # fitting/utils.py:47-52: magnetar=Magnetar(L0, t0, q) on the jets that support it
-            if self.jet == "powerlaw_wing":
-                raise ValueError("powerlaw_wing takes no magnetar")
-            p.flags |= _lib.FLAG_MAGNETAR
+        if self.magnetar and self.jet != "powerlaw_wing":  # fitting/utils.py:47-52: Magnetar(L0, t0, q) on the jets that take one
+            p.flags |= _lib.FLAG_MAGNETAR                      # (config.py:99-121: powerlaw_wing has supports_magnetar=False: it is left out)
             p.mag_L0, p.mag_t0, p.mag_q = vals["L0"], vals["t0"], vals["q"]
         if self.rvs_shock:  # fitter.py:476-484: rvs_rad = Radiation(eps_e_r, eps_B_r, p_r, xi_e_r, ssc=rvs_ssc, kn=kn)
             p.flags |= _lib.FLAG_RVS | (_lib.FLAG_RVS_SSC if self.rvs_ssc else 0) | (_lib.FLAG_RVS_KN if self.kn else 0)
@@ -296,6 +295,15 @@ class Fitter:
             raise ValueError("at most 16 free parameters")
         spec = _lib.FitSpec()
         spec.base = self._base_params(fixed)
+        # fixed parameters that are Model / Observer fields rather than ModelParams entries (z, lumi_dist, sigma0, the theta_obs /
+        # duration aliases ...) go straight into their slot, exactly like a free parameter would
+        base_fields = (C.c_double * 40).from_address(C.addressof(spec.base) + _lib.ModelParams.theta_c.offset)
+        for name, value in fixed.items():
+            if name in MODEL_PARAM_DEFAULTS or name == "A_V":
+                continue
+            if name not in _lib.PARAM_SLOTS:
+                raise ValueError(f"parameter {name} is not accepted by the accelerated path")
+            base_fields[_lib.PARAM_SLOTS[name]] = float(value)
         spec.ndim = len(free)
         for d, pd in enumerate(free):
             if pd.name == "A_V":

@@ -44,7 +44,7 @@ class BatchPool:
     """Drop-in for ThreadPoolWithClose (fitting/samplers.py:146-170) as bilby / dynesty use it: with
     ``use_pool={"loglikelihood": True}`` the sampler calls ``pool.map(loglikelihood, queue)`` with ``queue_size`` points
     in sampler space; here the whole queue goes through ``batch_fn(points[n, ndim]) -> float64[n]`` (one device call,
-    e.g. ``fitter.make_log_prob_batch(defs)`` or ``lambda v: fitter.loglike_batch(defs, v)``) and the per-point callable
+    e.g. ``fitter.make_log_prob_batch(defs)`` or ``lambda v: fitter.loglike_batch(v, defs)``) and the per-point callable
     is only used for anything that is not a point queue."""
 
     def __init__(self, batch_fn: Callable[[np.ndarray], np.ndarray], ndim: int, size: int = 1024):
