@@ -812,6 +812,14 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     for a, b in zip(fused, two_pass):
         assert np.array_equal(a, b, equal_nan=True)
     assert fused[1].max() > 0
+    os.environ["VAG_GRID_ROWWISE"] = "1"  # the wavefront-per-row kernel on the same small grid (measured slower: not the default)
+    try:
+        rowwise = gpu_components4(eng, prm, t, nu)  # same algorithm, another summation order
+    finally:
+        del os.environ["VAG_GRID_ROWWISE"]
+    for a, b in zip(rowwise, two_pass):
+        m = b > 1e-12 * b.max() if b.max() > 0 else np.zeros_like(b, dtype=bool)
+        assert np.all(np.abs(a - b)[m] <= 1e-11 * b[m]) and np.all(a[~m] <= 1e-11 * max(b.max(), 1e-300))
     lib, h = eng
     band_f = np.empty((1, t.size))
     arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))

@@ -816,11 +816,22 @@ static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
 }
 
 // Stage 4-5 for a (t, nu) grid request: d_lg2t/d_lg2nu are log2 of code-unit times / frequencies.
+int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
+                    double* d_out, int mode = FLUX_SYN, int n_bands = 0, int grid_nt = 0);
+
 int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt,
                   const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN,
                   double* d_out2 = nullptr /* FLUX_FUSED: the SSC component */) {
     hipStream_t st = c->stream;
     const int slots = nt * nnu;
+    // Rows of a few hundred (nu, t) slots keep a 256-lane workgroup 22-78 % busy between its two barriers (C3, C5, C1: four or
+    // three frequencies).  The wavefront-per-row kernel can serve them (VAG_GRID_ROWWISE=1: same algorithm -- boundary spectra
+    // per (nu, lattice node of the window), log-log interpolation --, no workgroup barrier, accumulators in registers), but
+    // MEASURED SLOWER on every such shape (C5 2.2 k vs 4.5 k light curves/s, C3 1.27 k vs 1.79 k, C1a 1.28 M vs 2.58 M: eight
+    // points per lane cost the occupancy, and every lane walks its own bracket searches), so the workgroup kernel stays.
+    if (slots <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !d_bandw && mode != FLUX_FUSED && !c->count_work &&
+        std::getenv("VAG_GRID_ROWWISE"))
+        return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, slots, d_out, mode, nnu, nt);
     if (slots > FLUX_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_MAX_SLOTS);
     const int ppb = choose_pairs_per_block(c);
@@ -977,6 +988,8 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
 // of a pass on the C5 / C3 shapes).  Falls back to two passes when the doubled buffers would not fit in LDS twice.
 static bool fused_fits(vag_ctx* c, int nt, int nnu) {
     if (std::getenv("VAG_NO_FUSED")) return false;
+    if (std::getenv("VAG_GRID_ROWWISE") && nt * nnu <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !c->count_work)
+        return false;  // experiment switch of run_flux_grid: two passes of the wavefront-per-row kernel
     // the second set of buffers must not cost a resident workgroup: on the C5 / C3 shapes it does (63 vs 51 KB: two
     // workgroups per CU instead of three) and the fused pass measured 18 % SLOWER than two passes there
     const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, c->max_k, nt, nnu),
@@ -1164,7 +1177,7 @@ vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagG
 }
 
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
-                    int n, double* d_out, int mode = FLUX_SYN, int n_bands = 0) {
+                    int n, double* d_out, int mode, int n_bands, int grid_nt) {
     hipStream_t st = c->stream;
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
@@ -1175,10 +1188,13 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     ppb = (ppb + SERIES_CHUNK - 1) / SERIES_CHUNK * SERIES_CHUNK;
     if (const char* e = std::getenv("VAG_SERIES_PPB")) ppb = std::max(1, std::atoi(e)) * SERIES_CHUNK;  // tuning override (in chunks)
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
-    const int max_chunks = std::max(1, (c->max_pairs + SERIES_CHUNK - 1) / SERIES_CHUNK);
+    // a small (nu, t) grid served by this kernel keeps one partial per wavefront (its 128 x 128 rows would need thousands of
+    // 8-row chunks per model); a grid request makes no batch-independence promise, as the workgroup kernel does not either
+    const int chunk = grid_nt > 0 ? (int)ppb : SERIES_CHUNK;
+    const int max_chunks = std::max(1, (c->max_pairs + chunk - 1) / chunk);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_chunks * n)) return VAG_E_HIP;
     const int ks = c->max_k;
-    if (n > SERIES_THREADS) n_bands = 0;  // the shared-node path keeps one point per lane
+    if (n > SERIES_THREADS && grid_nt == 0) n_bands = 0;  // a fit's shared-node path keeps one point per lane
     // wavefronts per workgroup: four when their private rows fit next to the shared tables, else two or one
     int waves = SERIES_WAVES;
     auto lds_for = [&](int w) {
@@ -1194,6 +1210,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.ic_status = c->d_icstatus.as<int>();
     a.cellgeo = c->d_cellgeo.as<double>();
     a.n_bands = n_bands;
+    a.grid_nt = grid_nt;
+    a.chunk = chunk;
     a.band_idx = c->d_bandidx.as<int>();
     a.band_first = c->d_bandidx.as<int>() + SERIES_THREADS;
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
@@ -1243,7 +1261,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params,
-                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_chunks, SERIES_CHUNK, n, d_out);
+                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_chunks, chunk, n, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
     return VAG_OK;

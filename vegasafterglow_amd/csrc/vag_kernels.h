@@ -1011,7 +1011,8 @@ struct SeriesArgs {
     const double* lg2_t_obs;  // [n]
     const double* lg2_nu_obs; // [n]
     int n;
-    int pairs_per_block /* multiple of SERIES_CHUNK */, max_blocks, max_chunks, k_stride;
+    int pairs_per_block /* multiple of chunk */, max_blocks, max_chunks, k_stride;
+    int chunk;  // rows per partial sum: SERIES_CHUNK for point series (batch-independent summation tree), pairs_per_block for grids
     double* partial; // [nb][max_chunks][n]
     const double* sp_table;
     const double* cellq;  // FLUX_SYN_IC: [cells][FLUX_NQ]
@@ -1023,6 +1024,9 @@ struct SeriesArgs {
     int n_bands;
     const int* band_idx;
     const int* band_first;
+    // A small (nu, t) GRID served by this kernel (grid_nt > 0): point s = l * grid_nt + idx observes frequency lg2_nu_obs[l] at
+    // time lg2_t_obs[idx]; n = n_bands * grid_nt; band_idx / band_first are not read.
+    int grid_nt;
 };
 
 // Series kernels: k with s_t[k] < t <= s_t[k+1] (t == s_t[0] -> 0), grown outwards from `hint` (the interval of the same
@@ -1069,7 +1073,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_sp = lds;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     double* s_band = s_sp + SP_LDS_DOUBLES;  // [SERIES_MAX_BANDS] log2 nu of the fit's bands (shared-node path)
-    if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]];
+    if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[a.grid_nt > 0 ? (int)threadIdx.x : a.band_first[threadIdx.x]];
     __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
     const int vb = blockIdx.x * (blockDim.x >> 6) + wave;  // virtual block = wavefront (the host launches 4, 2 or 1 per workgroup)
     if (vb >= a.max_blocks) return;
@@ -1105,13 +1109,22 @@ vag_flux_series_kernel(SeriesArgs a) {
 
     double acc[NSLOT], tq[NSLOT], nuq[NSLOT];
     int kprev[NSLOT];  // each point's interval in the previous row: the next row's search starts there
+    int bandq[NSLOT];  // grid mode: the frequency index of each of this lane's points
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
         acc[q] = 0;
         kprev[q] = -1;
+        bandq[q] = 0;
         const int s = tid + q * SERIES_THREADS;
-        tq[q] = s < a.n ? a.lg2_t_obs[s] : 0;
-        nuq[q] = s < a.n ? a.lg2_nu_obs[s] + lg2_1pz : 0;
+        if (a.grid_nt > 0) {
+            const int l = s < a.n ? s / a.grid_nt : 0;
+            bandq[q] = l;
+            tq[q] = s < a.n ? a.lg2_t_obs[s - l * a.grid_nt] : 0;
+            nuq[q] = s < a.n ? a.lg2_nu_obs[l] + lg2_1pz : 0;
+        } else {
+            tq[q] = s < a.n ? a.lg2_t_obs[s] : 0;
+            nuq[q] = s < a.n ? a.lg2_nu_obs[s] + lg2_1pz : 0;
+        }
     }
     const int my_band = (NSLOT == 1 && a.n_bands > 0 && tid < a.n) ? a.band_idx[tid] : 0;
     int staged_rep = -1;
@@ -1124,8 +1137,8 @@ vag_flux_series_kernel(SeriesArgs a) {
     for (int pair = p0; pair < p1; ++pair) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
         const int rep = rep_of[j];
-        if (pair > p0 && (pair - p0) % SERIES_CHUNK == 0) {  // p0 is a multiple of SERIES_CHUNK: close the chunk before this row
-            double* dst = chunk_partial + (size_t)(pair / SERIES_CHUNK - 1) * a.n;
+        if (pair > p0 && (pair - p0) % a.chunk == 0) {  // p0 is a multiple of the chunk: close the chunk before this row
+            double* dst = chunk_partial + (size_t)(pair / a.chunk - 1) * a.n;
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
                 const int s = tid + q * SERIES_THREADS;
@@ -1180,6 +1193,61 @@ vag_flux_series_kernel(SeriesArgs a) {
         wave_sync();
         VAG_SER_MARK(c_eat);
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
+        if (a.grid_nt > 0) {
+            // A (nu, t) grid on the shared-node path: every frequency sees the same times, so the boundary spectra are evaluated
+            // once per (frequency, lattice node of the row's observation window) -- Observer::specific_flux's own scheme
+            // (observer.h:355-445) -- and each of the lane's points interpolates between two of them.  One wavefront per row,
+            // accumulators in registers, no workgroup barrier: rows of a few hundred (nu, t) slots do not fill a workgroup.
+            int kq[NSLOT];
+            int kmin = 1 << 30, kmax = -1;
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+                const int s = tid + q * SERIES_THREADS;
+                kq[q] = -1;
+                if (s < a.n && tq[q] >= row_t0 && tq[q] <= row_tN) {
+                    kq[q] = kprev[q] = series_bracket(s_t, K, tq[q], kprev[q]);
+                    kmin = min(kmin, kq[q]);
+                    kmax = max(kmax, kq[q]);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                kmin = min(kmin, __shfl_xor(kmin, off, 64));
+                kmax = max(kmax, __shfl_xor(kmax, off, 64));
+            }
+            if (kmax >= 0) {  // wave-uniform
+                const int nn = kmax + 2 - kmin;
+                const int total = nn * a.n_bands;
+                const float inv_nn = 1.0f / (float)nn;
+                for (int idx = tid; idx < total; idx += SERIES_THREADS) {
+                    const int b = (int)(((float)idx + 0.5f) * inv_nn);
+                    const int kk = kmin + idx - b * nn;
+                    const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
+                    double v;
+                    if (MODE == FLUX_SYN) {
+                        v = log2_I_nu_fast(s_par + kk * VAG_NPAR, 1, sc, x, sp_tab);
+                    } else if (MODE == FLUX_SYN_IC) {
+                        v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
+                    } else {
+                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + kk) * FLUX_IC_STRIDE;
+                        v = ic_table_eval(tab, x, &breach);
+                    }
+                    s_Bw[b * KS + kk] = v + s_geom[kk];
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    if (kq[q] >= 0) {
+                        const int k = kq[q];
+                        const double* Bb = s_Bw + bandq[q] * KS;
+                        const double blo = Bb[k], bhi = Bb[k + 1];
+                        const double sl = (bhi - blo) * (1.0 / (s_t[k + 1] - s_t[k]));
+                        if (isfinite(sl)) acc[q] += exp2_fast(blo + (tq[q] - s_t[k]) * sl);
+                    }
+                }
+            }
+            continue;
+        }
         if constexpr (NSLOT == 1) {
             if (a.n_bands > 0) {
                 // Shared-node path (the reference's specific_flux_series shares boundary evaluations between points of one
@@ -1258,7 +1326,7 @@ vag_flux_series_kernel(SeriesArgs a) {
         printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  points %lld\n", p1 - p0, K, c_stage, c_eat, c_pts);
 #endif
     {
-        double* dst = chunk_partial + (size_t)((p1 - 1) / SERIES_CHUNK) * a.n;  // the last (possibly short) chunk of this wavefront
+        double* dst = chunk_partial + (size_t)((p1 - 1) / a.chunk) * a.n;  // the last (possibly short) chunk of this wavefront
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             const int s = tid + q * SERIES_THREADS;
