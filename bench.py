@@ -242,6 +242,11 @@ def ensemble_bench(lib, h, _lib, dev):
         dt = (time.perf_counter() - t0) / 3
         st = _lib.StageTimes()
         lib.vag_last_stage_times(h, C.byref(st))
+        _lib.check(lib.vag_ctx_profile(h, 1))  # one more pass under the named-stage profiler (reference stage names)
+        call()
+        prof = _lib.Profile()
+        _lib.check(lib.vag_last_profile(h, C.byref(prof)))
+        _lib.check(lib.vag_ctx_profile(h, 0))
         _lib.check(lib.vag_ctx_count_work(h, 1))
         call()
         torch.cuda.synchronize()
@@ -255,6 +260,7 @@ def ensemble_bench(lib, h, _lib, dev):
                      "finite": bool(torch.isfinite(call.out).all()), "ode_rows": plan.n_rows, "cells": plan.n_cells,
                      "stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "cells_cooling_tables": st.cells_ms,
                                   "flux_passes": st.flux_ms, "reduce": st.reduce_ms},
+                     "stage_ms_reference_names": {n: getattr(prof, n) for n, _ in _lib.Profile._fields_},
                      "roofline_fp64_flux_passes": {"spec_evals": plan.spec_evals, "interps": plan.interps,
                                                    "achieved": flops / (st.flux_ms * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": flops / (st.flux_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},

@@ -378,6 +378,23 @@ typedef struct vag_stage_times {
 } vag_stage_times;
 int vag_last_stage_times(vag_ctx* ctx, vag_stage_times* out);
 
+/* Per-stage device time of the last call under the reference profiler's stage names (AFTERGLOW_PROFILE_SCOPE in
+ * pybind/pymodel.h:877-953; Model.profile_data(), pybind.cpp:458-459), measured with HIP events around the kernels of each
+ * stage.  Off by default (every scope costs two event records): vag_ctx_profile(ctx, 1) turns it on for the following calls.
+ * What each name covers here, where kernels are fused differently from the reference's loops:
+ *   dynamics      adaptive grid + blast-wave ODE (both shocks);
+ *   EAT_grid      always 0: the equal-arrival-time logs are recomputed inside the flux kernels (counted in *_flux);
+ *   syn_electrons vag_cells_kernel: electrons AND photons of every cell in one pass;
+ *   cooling       inverse-Compton cooling recurrence (vag_ic_cooling_kernel);
+ *   syn_photons   the photon rebuild from the cooled electrons (vag_photons_ic_kernel; 0 without SSC);
+ *   sync_flux     synchrotron flux passes (both shocks) incl. their reductions; the fused synchrotron + SSC pass counts here;
+ *   ic_photons    seed band + per-cell SSC spectrum tables;   ssc_flux  SSC flux passes;   total  first to last kernel. */
+typedef struct vag_profile {
+    double dynamics, EAT_grid, syn_electrons, syn_photons, cooling, sync_flux, ic_photons, ssc_flux, total; /* ms */
+} vag_profile;
+int vag_ctx_profile(vag_ctx* ctx, int enable);
+int vag_last_profile(vag_ctx* ctx, vag_profile* out);
+
 /* Work done by the last batch call, for roofline accounting (SURVEY.md section 8d units):
  *   eat_cells  = sum over models of (theta x phi_eff pairs) x n_t  -- (phi, theta, k) cells of Observer::observe
  *   spec_evals = eat_cells x nnu (grid) or 2 x pairs x n (series)  -- calls of SmoothPowerLawSyn::compute_log2_I_nu

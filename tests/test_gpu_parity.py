@@ -1238,3 +1238,33 @@ def test_rs_structured_jet_deviations_collapse_with_ode_tolerance(eng, oracle, n
             assert np.all(g_[0] == 0), comp
         else:
             assert_close(g_[0], w, rtol=5e-5 if comp == "rvs_sync" else 2e-6, floor=1e-2)
+
+
+def test_profile_data_uses_the_reference_stage_names(eng):
+    """Model.profile_data() (pybind.cpp:458-459): the stage names of AFTERGLOW_PROFILE_SCOPE (pymodel.h:877-953), filled from
+    HIP events around each stage's kernels while the run-time profiler switch is on."""
+    t, nu = configs.C3_T[::4], configs.C3_NU
+    names = {"dynamics", "EAT_grid", "syn_electrons", "syn_photons", "cooling", "sync_flux", "ic_photons", "ssc_flux", "total"}
+    plain = va.Model(va.GaussianJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2), va.Radiation(0.1, 0.01, 2.3))
+    full = va.Model(va.PowerLawJet(0.1, 1e52, 300, 2.0, 2.0, duration=1.0), va.Wind(0.1), va.Observer(1e28, 1.0, 0.2),
+                    va.Radiation(0.1, 0.01, 2.3, ssc=True, kn=True), rvs_rad=va.Radiation(0.1, 0.01, 2.3, ssc=True, kn=True))
+    va.Model.profile_enable(True)
+    try:
+        want = plain.flux_density_grid(t, nu).total
+        p0 = va.Model.profile_data()
+        os.environ["VAG_NO_FUSED"] = "1"  # the fused synchrotron + SSC pass is booked under sync_flux: ask for separate passes
+        full.flux_density_grid(t, nu)
+        p1 = va.Model.profile_data()
+    finally:
+        os.environ.pop("VAG_NO_FUSED", None)
+        va.Model.profile_enable(False)
+    assert set(p0) == names == set(p1)
+    assert all(v >= 0 for v in p0.values()) and all(v >= 0 for v in p1.values())
+    for k in ("dynamics", "syn_electrons", "sync_flux"):
+        assert p0[k] > 0 and p1[k] > 0
+    assert p0["cooling"] == p0["ic_photons"] == p0["ssc_flux"] == p0["syn_photons"] == 0.0  # no SSC: those stages never run
+    assert p1["cooling"] > 0 and p1["ic_photons"] > 0 and p1["ssc_flux"] > 0 and p1["syn_photons"] > 0
+    for p in (p0, p1):
+        assert p["EAT_grid"] == 0.0  # fused into the flux kernels here
+        assert sum(v for k, v in p.items() if k != "total") <= p["total"] * 1.001
+    assert np.array_equal(plain.flux_density_grid(t, nu).total, want)  # the switch changes nothing but the timing records

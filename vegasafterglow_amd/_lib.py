@@ -84,6 +84,11 @@ class StageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("grid_ms", "dynamics_ms", "cells_ms", "flux_ms", "reduce_ms", "total_ms")]
 
 
+class Profile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("dynamics", "EAT_grid", "syn_electrons", "syn_photons", "cooling", "sync_flux", "ic_photons",
+                                          "ssc_flux", "total")]
+
+
 class Plan(C.Structure):
     _fields_ = [("n_models_ok", C.c_int32), ("n_rows", C.c_int32), ("n_cells", C.c_int64), ("total_pairs", C.c_int64),
                 ("eat_cells", C.c_int64), ("spec_evals", C.c_int64), ("interps", C.c_int64),
@@ -103,7 +108,7 @@ EXPORTS = [
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_last_model_costs_dev", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_last_model_costs_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
 _lib = None
@@ -154,6 +159,8 @@ def load():
     lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
     lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
     lib.vag_last_model_costs_dev.argtypes = [v, C.c_int, v]
+    lib.vag_ctx_profile.argtypes = [v, C.c_int]
+    lib.vag_last_profile.argtypes = [v, C.POINTER(Profile)]
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_rvs.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_radiation.argtypes = [v, _pp, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include <atomic>
@@ -88,6 +89,8 @@ struct HostBuf {  // pinned
         return reinterpret_cast<T*>(p);
     }
 };
+
+enum { PS_DYNAMICS = 0, PS_SYN_ELECTRONS, PS_SYN_PHOTONS, PS_COOLING, PS_SYNC_FLUX, PS_IC_PHOTONS, PS_SSC_FLUX, PS_COUNT };
 
 // prepares log2 arrays and the observer-time extrema on the device (single workgroup)
 __global__ void vag_prep_kernel(const double* __restrict__ t, int nt, const double* __restrict__ nu, int nnu,
@@ -299,6 +302,12 @@ struct vag_ctx {
     VagDevPlan* d_hplan = nullptr;  // device address of h_plan
     int plan_seq = 0;
     bool plan_counter_ready = false;
+    // named-stage profiler (vag_ctx_profile): spans of (stage id, begin event, end event) recorded during a call
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    struct ProfSpan { int id, e0, e1; };
+    std::vector<ProfSpan> prof_spans;
+    int prof_used = 0;
     int spec_cap_k = 0;
     int spec_margin_k = 2;        // lattice nodes of head room in a planned-ahead call; grows when a call had to be repeated
     bool meta_on_host = false;    // h_meta holds the current batch's grid results (copied on demand)
@@ -319,6 +328,29 @@ struct vag_ctx {
     int n_ok = 0;
     vag_plan plan{};
     vag_stage_times times{};
+};
+
+// One profiled stage: begin / end events on the context stream while the profiler is on (vag_ctx_profile)
+struct StageScope {
+    vag_ctx* c;
+    int span = -1;
+    StageScope(vag_ctx* ctx, int id) : c(ctx) {
+        if (!c->prof_on) return;
+        if (c->prof_used + 2 > (int)c->prof_ev.size()) {
+            for (int i = 0; i < 16; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                c->prof_ev.push_back(e);
+            }
+        }
+        span = (int)c->prof_spans.size();
+        c->prof_spans.push_back({id, c->prof_used, c->prof_used + 1});
+        (void)hipEventRecord(c->prof_ev[c->prof_used], c->stream);
+        c->prof_used += 2;
+    }
+    ~StageScope() {
+        if (span >= 0) (void)hipEventRecord(c->prof_ev[c->prof_spans[span].e1], c->stream);
+    }
 };
 
 extern "C" {
@@ -484,6 +516,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_fitstat.release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -533,6 +566,31 @@ int vag_ctx_synchronize(vag_ctx* c) {
 }
 
 static int collect_times_fwd(vag_ctx* c);
+int vag_ctx_profile(vag_ctx* c, int enable) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    c->prof_on = enable != 0;
+    return VAG_OK;
+}
+
+int vag_last_profile(vag_ctx* c, vag_profile* out) {
+    if (!c || !out) return set_err(VAG_E_INVALID, "null context or output");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double acc[PS_COUNT] = {0};
+    float first = 0, last = 0;
+    for (size_t i = 0; i < c->prof_spans.size(); ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[c->prof_spans[i].e0], c->prof_ev[c->prof_spans[i].e1]));
+        acc[c->prof_spans[i].id] += ms;
+        float to_end = 0;
+        HIPCHK(hipEventElapsedTime(&to_end, c->prof_ev[c->prof_spans[0].e0], c->prof_ev[c->prof_spans[i].e1]));
+        last = std::max(last, to_end);
+    }
+    (void)first;
+    *out = vag_profile{acc[PS_DYNAMICS], 0.0, acc[PS_SYN_ELECTRONS], acc[PS_SYN_PHOTONS], acc[PS_COOLING], acc[PS_SYNC_FLUX],
+                       acc[PS_IC_PHOTONS], acc[PS_SSC_FLUX], (double)last};
+    return VAG_OK;
+}
+
 int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
     // measured with HIP events recorded on the context stream around each kernel of the last batch call
     const int rc = collect_times_fwd(c);
@@ -579,20 +637,29 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
     if (ssc) want_details = true;  // the cooling pass works on the electron arrays
     if (want_details && c->d_celldet.ensure(sizeof(double) * (size_t)cells * VAG_NDET)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
-    hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
-                       c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
-                       want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr);
+    {
+        StageScope ps(c, PS_SYN_ELECTRONS);
+        hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
+                           want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr);
+    }
     HIPCHK(hipGetLastError());
     if (ssc) {  // cool the electrons row by row, then rebuild the photons
         if (c->d_icy.ensure(sizeof(double) * (size_t)cells * VAG_NICY)) return VAG_E_HIP;
         if (c->d_cellq.ensure(sizeof(double) * (size_t)cells * VAG_NQ)) return VAG_E_HIP;
-        hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_rad_params, nb,
-                           c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                           c->d_icy.as<double>(), d_inj);
+        {
+            StageScope ps(c, PS_COOLING);
+            hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_rad_params, nb,
+                               c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                               c->d_icy.as<double>(), d_inj);
+        }
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
-                           c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                           c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
+        {
+            StageScope ps(c, PS_SYN_PHOTONS);
+            hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
+                               c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
+                               c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
+        }
         HIPCHK(hipGetLastError());
     }
     return VAG_OK;
@@ -677,7 +744,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         c->plan_counter_ready = true;
     }
     c->ic_need_reset = true;
+    c->prof_spans.clear();
+    c->prof_used = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
+    std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
     hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                        c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
                        c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
@@ -685,6 +755,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                        c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
                        cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
                        spec ? c->hint.dyn_class : 0);
+    ps_grid.reset();
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], st));
     long long cells, pairs, eat;
@@ -740,6 +811,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_row_status.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
     Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
     bool raw_shock = false;
+    std::unique_ptr<StageScope> ps_dyn(new StageScope(c, PS_DYNAMICS));
     if (rvs) {  // generate_shock_pair (reverse-shock.tpp:592-614): both shocks from one ODE state per row
         if (c->d_shock_r.ensure(sizeof(double) * (size_t)cells * VAG_NSHOCK)) return VAG_E_HIP;
         if (c->d_inj.ensure(sizeof(int) * (size_t)rows)) return VAG_E_HIP;
@@ -774,6 +846,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellgeo.as<double>());
         HIPCHK(hipGetLastError());
     }
+    ps_dyn.reset();
     HIPCHK(hipEventRecord(c->ev[2], st));
     c->cur_emitter = 0;
     c->cur_params = d_params;
@@ -823,6 +896,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
                   const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN,
                   double* d_out2 = nullptr /* FLUX_FUSED: the SSC component */) {
     hipStream_t st = c->stream;
+    StageScope ps(c, mode == FLUX_SSC ? PS_SSC_FLUX : PS_SYNC_FLUX);
     const int slots = nt * nnu;
     // Rows of a few hundred (nu, t) slots keep a 256-lane workgroup 22-78 % busy between its two barriers (C3, C5, C1: four or
     // three frequencies).  The wavefront-per-row kernel can serve them (VAG_GRID_ROWWISE=1: same algorithm -- boundary spectra
@@ -936,6 +1010,7 @@ __global__ void vag_add_kernel(double* __restrict__ out, const double* __restric
 // observation band per k -> SSC table per representative cell -> EAT flux integration over the tables.
 int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2nu, int nnu) {
     hipStream_t st = c->stream;
+    StageScope ps(c, PS_IC_PHOTONS);
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
     if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
@@ -1179,6 +1254,7 @@ vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagG
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
                     int n, double* d_out, int mode, int n_bands, int grid_nt) {
     hipStream_t st = c->stream;
+    StageScope ps(c, mode == FLUX_SSC ? PS_SSC_FLUX : PS_SYNC_FLUX);
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
     // series work per (theta, phi) row is small: fewer, longer wavefronts as the batch grows.  The partial sums are kept per

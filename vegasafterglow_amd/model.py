@@ -523,6 +523,22 @@ class Model:
                                            d["t_obs"].ctypes.data_as(_dp), d["Doppler"].ctypes.data_as(_dp)))
         return d
 
+    @staticmethod
+    def profile_enable(on=True, device=0):
+        """Turn the per-stage profiler on / off for the following calls on this device (the reference needs a build with
+        -DAFTERGLOW_PROFILE; here it is a run-time switch because every stage costs two event records)."""
+        h, _ = get_context(device)
+        _lib.check(_lib.load().vag_ctx_profile(h, 1 if on else 0))
+
+    @staticmethod
+    def profile_data(device=0):
+        """Model.profile_data() (pybind.cpp:458-459): per-stage device time [ms] of the last computation under the reference
+        profiler's stage names (pymodel.h:877-953); see vag_profile in the C header for what each covers here."""
+        h, _ = get_context(device)
+        p = _lib.Profile()
+        _lib.check(_lib.load().vag_last_profile(h, C.byref(p)))
+        return {n: getattr(p, n) for n, _ in _lib.Profile._fields_}
+
     def stage_times(self):
         """Per-stage device milliseconds of the last call (names follow pybind/pymodel.h:877-953)."""
         st = _lib.StageTimes()
