@@ -357,13 +357,22 @@ def test_ssc_batch_band_model_api_and_loud_limits(eng, oracle):
     assert_close(fd.fwd.sync, o_sync)
     assert_close(fd.fwd.ssc, o_ssc)
     assert_close(fd.total, o_sync + o_ssc)
-    # limits fail loudly: mixed Radiation flags in one batch, SSC in the series / log-likelihood forms
+    # mixed Radiation flags in one host-pointer batch: split inside the call (test_mixed_flag_batches_are_split_inside_the_call);
+    # a device-resident batch cannot be regrouped behind the caller's back and says so
+    import torch
     mixed = (_lib.ModelParams * 2)(_lib.ModelParams.from_buffer_copy(bytes(prm)),
                                    _lib.ModelParams.from_buffer_copy(bytes(_abi.make_params(jet="GaussianJet"))))
     out = np.empty((2, SSC_NU.size, SSC_T.size))
-    rc = lib.vag_flux_density_grid_batch(h, mixed, 2, SSC_T.ctypes.data_as(dp), SSC_T.size, SSC_NU.ctypes.data_as(dp),
-                                         SSC_NU.size, out.ctypes.data_as(dp))
-    assert rc == _lib.VAG_E_UNSUPPORTED
+    assert lib.vag_flux_density_grid_batch(h, mixed, 2, SSC_T.ctypes.data_as(dp), SSC_T.size, SSC_NU.ctypes.data_as(dp),
+                                           SSC_NU.size, out.ctypes.data_as(dp)) == 0
+    assert_close(out[0], o_sync + o_ssc)
+    dev = torch.device("cuda", 0)
+    d_p = torch.frombuffer(bytearray(bytes(mixed)), dtype=torch.uint8).to(dev)
+    d_t, d_nu = torch.from_numpy(SSC_T).to(dev), torch.from_numpy(SSC_NU).to(dev)
+    d_o = torch.empty((2, SSC_NU.size, SSC_T.size), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    rc = lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), 2, d_t.data_ptr(), SSC_T.size, d_nu.data_ptr(), SSC_NU.size, d_o.data_ptr())
+    assert rc == _lib.VAG_E_UNSUPPORTED and b"split it by flags" in lib.vag_last_error()
 
 
 def test_ssc_series_and_loglike(eng, oracle):
@@ -1268,3 +1277,36 @@ def test_profile_data_uses_the_reference_stage_names(eng):
         assert p["EAT_grid"] == 0.0  # fused into the flux kernels here
         assert sum(v for k, v in p.items() if k != "total") <= p["total"] * 1.001
     assert np.array_equal(plain.flux_density_grid(t, nu).total, want)  # the switch changes nothing but the timing records
+
+
+def test_mixed_flag_batches_are_split_inside_the_call(eng, oracle):
+    """The reference evaluates any mix of models side by side (samplers.py:59-91).  One launch sequence here serves one flag set,
+    so a batch mixing plain, SSC, reverse-shock and spreading models is split by flags inside the host-pointer call and each
+    model must come back exactly as it does in a call of its own -- grid, series, band and component outputs alike."""
+    t, nu = np.logspace(3, 7, 12), np.array([1e9, 4.84e14, 1e18])
+    kws = [dict(jet="GaussianJet", theta_obs=0.2), dict(jet="TophatJet", theta_obs=0.05, ssc=True),
+           dict(jet="GaussianJet", theta_obs=0.3, n_ism=0.3), dict(jet="TophatJet", theta_obs=0.1, duration=50.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+           dict(jet="TophatJet", theta_obs=0.05, ssc=True, kn=True), dict(jet="GaussianJet", theta_obs=0.15, spreading=True),
+           dict(jet="TophatJet", theta_obs=0.05, ssc=True, eps_e=0.05)]
+    prms = [_abi.make_params(**kw) for kw in kws]
+    assert len({p.flags for p in prms}) == 5
+    mixed = gpu_grid(eng, prms, t, nu)
+    for i, p in enumerate(prms):
+        assert np.array_equal(mixed[i], gpu_grid(eng, p, t, nu)[0]), i
+        assert_close(mixed[i], oracle.flux_density_grid(p, t, nu), rtol=5e-5)  # (this test is about the split; the per-tier gates live above)
+    ts, nus = np.repeat(t, 3), np.tile(nu, t.size)
+    ser = gpu_series(eng, prms, ts, nus)
+    for i, p in enumerate(prms):
+        assert np.array_equal(ser[i], gpu_series(eng, p, ts, nus)[0]), i
+    lib, h = eng
+    arr = (_lib.ModelParams * len(prms))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    band = np.empty((len(prms), t.size))
+    _lib.check(lib.vag_flux_batch(h, arr, len(prms), t.ctypes.data_as(dp), t.size, 1e14, 1e15, 8, band.ctypes.data_as(dp)))
+    one = np.empty((1, t.size))
+    for i in (1, 3, 5):
+        a1 = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prms[i])))
+        _lib.check(lib.vag_flux_batch(h, a1, 1, t.ctypes.data_as(dp), t.size, 1e14, 1e15, 8, one.ctypes.data_as(dp)))
+        assert np.array_equal(band[i], one[0]), i
+    comps = gpu_components4(eng, prms, t, nu)
+    assert comps[1][0].max() == 0 and comps[1][1].max() > 0 and comps[2][3].max() > 0 and comps[2][0].max() == 0
+    np.testing.assert_allclose(comps[0] + comps[1] + comps[2] + comps[3], mixed, rtol=1e-12)

@@ -764,7 +764,9 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (!spec) {
         VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
         if (int rcw = wait_plan(c)) return rcw;
-        if (hp->flags_mixed) return set_err(VAG_E_UNSUPPORTED, "models with different Radiation(ssc, kn) flags in one batch");
+        if (hp->flags_mixed)
+            return set_err(VAG_E_UNSUPPORTED, "models with different Radiation / shock flags in one device-resident batch: split it by flags "
+                                              "(the host-pointer entry points do that themselves)");
         rows = hp->rows, cells = hp->cells, pairs = hp->pairs, eat = hp->eat, max_k = hp->max_k, max_pairs = hp->max_pairs;
         n_ok = hp->n_ok, n_invalid = hp->n_invalid, n_capacity = hp->n_capacity, dyn_class = hp->dyn_class;
         flags = hp->flags_first < 0 ? 0 : hp->flags_first;
@@ -1505,6 +1507,55 @@ int check_status(vag_ctx* c, int nb) {
 
 }  // namespace
 
+// ---- batches whose models carry different Radiation / shock flags (ssc, kn, rvs, spreading, magnetar, non-axisymmetric) ----
+// One launch sequence serves one flag set (the flags pick kernels and passes).  The reference evaluates any mix of models
+// side by side (samplers.py:59-91), so a mixed batch handed over the host-pointer API is split by flags, every group runs as
+// its own batch -- same entry point, same arithmetic as if the caller had split it --, and the groups' rows are put back in
+// place.  OutRows: one output array of `stride` doubles per model (NULL: not requested).
+struct OutRows {
+    double* p;
+    size_t stride;
+};
+static bool uniform_flags(const vag_model_params* params, int nb) {
+    for (int m = 1; m < nb; ++m)
+        if (params[m].flags != params[0].flags) return false;
+    return true;
+}
+template <class Call>
+static int run_flag_groups(const vag_model_params* params, int nb, const std::vector<OutRows>& outs, Call call) {
+    std::vector<int> keys;
+    std::vector<std::vector<int>> groups;
+    for (int m = 0; m < nb; ++m) {
+        size_t g = 0;
+        while (g < keys.size() && keys[g] != params[m].flags) ++g;
+        if (g == keys.size()) {
+            keys.push_back(params[m].flags);
+            groups.emplace_back();
+        }
+        groups[g].push_back(m);
+    }
+    for (const std::vector<int>& idx : groups) {
+        const int ng = (int)idx.size();
+        std::vector<vag_model_params> gp(ng);
+        for (int i = 0; i < ng; ++i) gp[i] = params[idx[i]];
+        std::vector<std::vector<double>> bufs(outs.size());
+        std::vector<double*> ptrs(outs.size(), nullptr);
+        for (size_t q = 0; q < outs.size(); ++q)
+            if (outs[q].p) {
+                bufs[q].resize((size_t)ng * outs[q].stride);
+                ptrs[q] = bufs[q].data();
+            }
+        const int rc = call(gp.data(), ng, ptrs);
+        if (rc) return rc;
+        for (size_t q = 0; q < outs.size(); ++q)
+            if (outs[q].p)
+                for (int i = 0; i < ng; ++i)
+                    std::memcpy(outs[q].p + (size_t)idx[i] * outs[q].stride, bufs[q].data() + (size_t)i * outs[q].stride,
+                                sizeof(double) * outs[q].stride);
+    }
+    return VAG_OK;
+}
+
 extern "C" {
 
 int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt,
@@ -1591,6 +1642,10 @@ int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int 
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
+    if (!uniform_flags(params, nb))
+        return run_flag_groups(params, nb, {{out, (size_t)nnu * nt}}, [&](const vag_model_params* gp, int ng, const std::vector<double*>& o) {
+            return vag_flux_density_grid_batch(c, gp, ng, t, nt, nu, nnu, o[0]);
+        });
     HIPCHK(hipSetDevice(c->device));
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
     if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
@@ -1615,6 +1670,14 @@ static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int 
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
+    if (!uniform_flags(params, nb)) {
+        const size_t st = (size_t)nnu * nt;
+        return run_flag_groups(params, nb, {{out4[0], st}, {out4[1], st}, {out4[2], st}, {out4[3], st}},
+                               [&](const vag_model_params* gp, int ng, const std::vector<double*>& o) {
+                                   double* o4[4] = {o[0], o[1], o[2], o[3]};
+                                   return grid_components_impl(c, gp, ng, t, nt, nu, nnu, o4);
+                               });
+    }
     HIPCHK(hipSetDevice(c->device));
     const size_t n_out = (size_t)nb * nnu * nt;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
@@ -1656,6 +1719,10 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
     if (!c) return set_err(VAG_E_INVALID, "null context");
     int rc = check_host_inputs(params, nb, t, n);
     if (rc) return rc;
+    if (!uniform_flags(params, nb))
+        return run_flag_groups(params, nb, {{out, (size_t)n}}, [&](const vag_model_params* gp, int ng, const std::vector<double*>& o) {
+            return vag_flux_density_batch(c, gp, ng, t, nu, n, o[0]);
+        });
     HIPCHK(hipSetDevice(c->device));
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
     if (c->d_t.ensure(sizeof(double) * n)) return VAG_E_HIP;
@@ -1683,6 +1750,12 @@ int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* param
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
     int rc = check_host_inputs(params, nb, t, n);
     if (rc) return rc;
+    if (!uniform_flags(params, nb))
+        return run_flag_groups(params, nb, {{out4[0], (size_t)n}, {out4[1], (size_t)n}, {out4[2], (size_t)n}, {out4[3], (size_t)n}},
+                               [&](const vag_model_params* gp, int ng, const std::vector<double*>& o) {
+                                   double* o4[4] = {o[0], o[1], o[2], o[3]};
+                                   return vag_flux_density_components4_batch(c, gp, ng, t, nu, n, o4);
+                               });
     HIPCHK(hipSetDevice(c->device));
     const size_t n_out = (size_t)nb * n;
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
@@ -1797,6 +1870,16 @@ static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, co
     if (!c) return set_err(VAG_E_INVALID, "null context");
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
+    if (!uniform_flags(params, nb)) {
+        const size_t st = (size_t)nt;
+        return run_flag_groups(params, nb,
+                               {{out_total, st}, {out4 ? out4[0] : nullptr, st}, {out4 ? out4[1] : nullptr, st},
+                                {out4 ? out4[2] : nullptr, st}, {out4 ? out4[3] : nullptr, st}},
+                               [&](const vag_model_params* gp, int ng, const std::vector<double*>& o) {
+                                   double* o4[4] = {o[1], o[2], o[3], o[4]};
+                                   return flux_band_impl(c, gp, ng, t, nt, nu_min, nu_max, num_nu, o[0], out4 ? o4 : nullptr);
+                               });
+    }
     HIPCHK(hipSetDevice(c->device));
     if (c->d_params.ensure(sizeof(vag_model_params) * nb)) return VAG_E_HIP;
     if (c->d_t.ensure(sizeof(double) * nt)) return VAG_E_HIP;
