@@ -36,6 +36,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F_SPEC = 210.0   # FP64 flop-equivalents per spectrum evaluation
 F_INTERP = 26.0  # per log-log interpolation + exp2 + accumulate
+F_IC_TERM = 14.0  # FP64 flops per (electron energy, seed frequency) term of the SSC table build: CDF difference, bin integral, accumulate
+F_IC_NODE = 240.0 # per lattice node of its set-up: one synchrotron spectrum / electron distribution / output evaluation
 F_TABLE = 30.0   # per tabulated SSC spectrum evaluation (ICPhoton::compute_log2_I_nu: index + linear interpolation)
 PEAK_HBM_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP64_TFLOPS = 78.6  # FP64 vector = half the 157.3 TF FP32 vector peak of MI355X_MICROARCH.md
@@ -264,6 +266,11 @@ def ensemble_bench(lib, h, _lib, dev):
                      "roofline_fp64_flux_passes": {"spec_evals": plan.spec_evals, "interps": plan.interps,
                                                    "achieved": flops / (st.flux_ms * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": flops / (st.flux_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
+                     "roofline_fp64_ic_photons": {"kernel": "vag_ic_photon_kernel (+ seed band)", "ic_terms": plan.ic_terms, "ic_nodes": plan.ic_nodes,
+                                                  "ms": prof.ic_photons,
+                                                  "achieved": (plan.ic_terms * F_IC_TERM + plan.ic_nodes * F_IC_NODE) / max(prof.ic_photons * 1e-3, 1e-12) / 1e12,
+                                                  "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": (plan.ic_terms * F_IC_TERM + plan.ic_nodes * F_IC_NODE) / max(prof.ic_photons * 1e-3, 1e-12) / 1e12 / PEAK_FP64_TFLOPS},
                      "reference_cpu_ms_per_model_survey": ref_ms}
     return out
 

@@ -416,6 +416,10 @@ typedef struct vag_plan {
     /* ABI v7, likelihood calls only, tallied over ALL passes (point data + every band group) of the last call */
     int32_t n_walkers_rejected;   /* walkers scored -inf: out of bounds, invalid parameters, grid over capacity, failed ODE row, SSC failure, non-finite chi2 */
     int32_t n_walkers_ssc_failed; /* of those: SSC tables over capacity or queried outside their clamped band */
+    /* with vag_ctx_count_work(1): the SSC table build's work (ICPhoton::generate_spectrum, inverse-compton.h:529-607), summed over
+     * both shocks: ic_terms = sum over cells of (electron-energy nodes x seed-frequency nodes), the accumulation's unit;
+     * ic_nodes = sum over cells of (electron + seed + output lattice nodes), the set-up's unit */
+    int64_t ic_terms, ic_nodes;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -294,6 +294,7 @@ struct vag_ctx {
     HostBuf h_meta, h_off, h_plan;
     DevBuf d_plan;                // VagDevPlan of the current batch (vag_plan_kernel)
     DevBuf d_chunk;               // staging of chunked requests
+    DevBuf d_icwork;              // work tallies of vag_ic_photon_kernel (vag_ctx_count_work)
     VagDevPlan hint{};            // the last plan the host read back: sizes the next call of the same batch size in advance
     int hint_nb = 0;
     bool hint_valid = false;
@@ -463,7 +464,10 @@ static int ctx_init(vag_ctx* c) {
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, false, 1>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, true, 1>),
                            reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, true, 1>),
-                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, true, 1>)})
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, true, 1>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN, false, SERIES_MAX_SLOTS, true>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SYN_IC, false, SERIES_MAX_SLOTS, true>),
+                           reinterpret_cast<const void*>(vag_flux_series_kernel<FLUX_SSC, false, SERIES_MAX_SLOTS, true>)})
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
         std::vector<double> tab;
@@ -512,6 +516,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->h_plan.release();
     c->d_plan.release();
     c->d_chunk.release();
+    c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
     for (auto& e : c->ev)
@@ -906,7 +911,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     // MEASURED SLOWER on every such shape (C5 2.2 k vs 4.5 k light curves/s, C3 1.27 k vs 1.79 k, C1a 1.28 M vs 2.58 M: eight
     // points per lane cost the occupancy, and every lane walks its own bracket searches), so the workgroup kernel stays.
     if (slots <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !d_bandw && mode != FLUX_FUSED && !c->count_work &&
-        std::getenv("VAG_GRID_ROWWISE"))
+        std::getenv("VAG_GRID_ROWWISE") && !(c->batch_flags & VAG_FLAG_SPREADING))
         return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, slots, d_out, mode, nnu, nt);
     if (slots > FLUX_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_MAX_SLOTS);
@@ -1026,11 +1031,23 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
                            c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
                            (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr);
         HIPCHK(hipGetLastError());
+        if (c->count_work) {
+            if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
+            HIPCHK(hipMemsetAsync(c->d_icwork.p, 0, 2 * sizeof(unsigned long long), st));
+        }
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
                            c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_band.as<double>(), c->d_sptab.as<double>(),
-                           c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>());
+                           c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
+                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr);
         HIPCHK(hipGetLastError());
+        if (c->count_work) {
+            unsigned long long h[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h, c->d_icwork.p, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            c->plan.ic_terms += (long long)h[0];
+            c->plan.ic_nodes += (long long)h[1];
+        }
     }
     return VAG_OK;
 }
@@ -1317,7 +1334,9 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         const bool one = n <= SERIES_THREADS;  // one data point per lane
 #define VAG_SERIES_LAUNCH(M_, S_)                                                                              \
     do {                                                                                                       \
-        if (one)                                                                                               \
+        if (grid_nt > 0)                                                                                       \
+            hipLaunchKernelGGL((vag_flux_series_kernel<M_, false, SERIES_MAX_SLOTS, true>), sgrid, sblock, lds, st, a); \
+        else if (one)                                                                                          \
             hipLaunchKernelGGL((vag_flux_series_kernel<M_, S_, 1>), sgrid, sblock, lds, st, a);                 \
         else                                                                                                   \
             hipLaunchKernelGGL((vag_flux_series_kernel<M_, S_, SERIES_MAX_SLOTS>), sgrid, sblock, lds, st, a);  \

@@ -325,7 +325,8 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                      long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
                      const double* __restrict__ cellpar, const double* __restrict__ cellq, const double* __restrict__ band,
                      const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* __restrict__ ictab,
-                     int* __restrict__ ic_status) {
+                     int* __restrict__ ic_status,
+                     unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */) {
     const long long c = blockIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int lane = threadIdx.x;
@@ -399,6 +400,10 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
         }
         return;
+    }
+    if (work && lane == 0) {  // instrumentation: the unit of this kernel's work model (bench.py)
+        atomicAdd(work, (unsigned long long)g_size * (unsigned long long)nu_size);
+        atomicAdd(work + 1, (unsigned long long)(g_size + nu_size + n_ic));
     }
     __syncthreads();
     for (int j = lane; j < nu_size; j += 64) {

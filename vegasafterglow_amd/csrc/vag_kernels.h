@@ -1063,7 +1063,9 @@ VAG_DEV int series_bracket(const double* __restrict__ s_t, int K, double t, int 
 
 // NSLOT = data points per lane (n <= 64 * NSLOT): short series (a walker's 60 points) keep one point per lane in
 // registers instead of eight, which is the difference between 3 and 5 resident wavefronts per SIMD.
-template <int MODE, bool SPREAD = false, int NSLOT = SERIES_MAX_SLOTS>
+// GRID: the kernel serves a small (nu, t) grid (SeriesArgs::grid_nt); a compile-time switch so that the fit instantiations do not
+// carry its registers.
+template <int MODE, bool SPREAD = false, int NSLOT = SERIES_MAX_SLOTS, bool GRID = false>
 __global__ void __launch_bounds__(SERIES_THREADS * SERIES_WAVES)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -1073,7 +1075,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_sp = lds;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     double* s_band = s_sp + SP_LDS_DOUBLES;  // [SERIES_MAX_BANDS] log2 nu of the fit's bands (shared-node path)
-    if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[a.grid_nt > 0 ? (int)threadIdx.x : a.band_first[threadIdx.x]];
+    if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[GRID ? (int)threadIdx.x : a.band_first[threadIdx.x]];
     __syncthreads();  // the only workgroup-wide barrier: from here on every wavefront works alone on its own rows
     const int vb = blockIdx.x * (blockDim.x >> 6) + wave;  // virtual block = wavefront (the host launches 4, 2 or 1 per workgroup)
     if (vb >= a.max_blocks) return;
@@ -1109,14 +1111,13 @@ vag_flux_series_kernel(SeriesArgs a) {
 
     double acc[NSLOT], tq[NSLOT], nuq[NSLOT];
     int kprev[NSLOT];  // each point's interval in the previous row: the next row's search starts there
-    int bandq[NSLOT];  // grid mode: the frequency index of each of this lane's points
+    int bandq[GRID ? NSLOT : 1];  // grid mode: the frequency index of each of this lane's points
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
         acc[q] = 0;
         kprev[q] = -1;
-        bandq[q] = 0;
         const int s = tid + q * SERIES_THREADS;
-        if (a.grid_nt > 0) {
+        if constexpr (GRID) {
             const int l = s < a.n ? s / a.grid_nt : 0;
             bandq[q] = l;
             tq[q] = s < a.n ? a.lg2_t_obs[s - l * a.grid_nt] : 0;
@@ -1193,7 +1194,7 @@ vag_flux_series_kernel(SeriesArgs a) {
         wave_sync();
         VAG_SER_MARK(c_eat);
         const double row_t0 = s_t[0], row_tN = s_t[K - 1];
-        if (a.grid_nt > 0) {
+        if constexpr (GRID) {
             // A (nu, t) grid on the shared-node path: every frequency sees the same times, so the boundary spectra are evaluated
             // once per (frequency, lattice node of the row's observation window) -- Observer::specific_flux's own scheme
             // (observer.h:355-445) -- and each of the lane's points interpolates between two of them.  One wavefront per row,
@@ -1225,7 +1226,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                     const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
                     double v;
                     if (MODE == FLUX_SYN) {
-                        v = log2_I_nu_fast(s_par + kk * VAG_NPAR, 1, sc, x, sp_tab);
+                        v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                     } else if (MODE == FLUX_SYN_IC) {
                         v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
                     } else {
@@ -1271,7 +1272,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
                         double v;
                         if (MODE == FLUX_SYN) {
-                            v = log2_I_nu_fast(s_par + kk * VAG_NPAR, 1, sc, x, sp_tab);
+                            v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                         } else if (MODE == FLUX_SYN_IC) {
                             v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
                         } else {
@@ -1301,8 +1302,8 @@ vag_flux_series_kernel(SeriesArgs a) {
                     const int k = kprev[q] = series_bracket(s_t, K, t, kprev[q]);  // s_t[k] < t <= s_t[k+1]; t == row_t0 -> 0
                     double blo, bhi;
                     if (MODE == FLUX_SYN) {
-                        blo = log2_I_nu_fast(s_par + k * VAG_NPAR, 1, sc, nuq[q] - s_dop[k], sp_tab);
-                        bhi = log2_I_nu_fast(s_par + (k + 1) * VAG_NPAR, 1, sc, nuq[q] - s_dop[k + 1], sp_tab);
+                        blo = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(k, VAG_NPAR / 2)), 1, sc, nuq[q] - s_dop[k], sp_tab);
+                        bhi = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(k + 1, VAG_NPAR / 2)), 1, sc, nuq[q] - s_dop[k + 1], sp_tab);
                     } else if (MODE == FLUX_SYN_IC) {
                         blo = log2_I_nu_ic(s_par + k * VAG_NPAR, 1, s_q + k * FLUX_NQ, 1, sc, nuq[q] - s_dop[k], sp_tab);
                         bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, s_q + (k + 1) * FLUX_NQ, 1, sc, nuq[q] - s_dop[k + 1],
