@@ -1299,6 +1299,9 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const size_t lds = lds_for(waves);
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d)", lds, ks);
     const dim3 sgrid((max_blocks + waves - 1) / waves, nb), sblock(SERIES_THREADS * waves);
+    if (std::getenv("VAG_DEBUG_LAUNCH"))
+        std::fprintf(stderr, "[vag] series launch: n=%d bands=%d max_k=%d rows/wave=%lld waves/wg=%d lds=%zu B grid=(%u,%u)\n", n, n_bands,
+                     ks, ppb, waves, lds, sgrid.x, sgrid.y);
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();

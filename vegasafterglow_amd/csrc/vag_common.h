@@ -37,6 +37,9 @@ struct VagGridMeta {
     double t_early;  // engine frame, code units
     double t_start;  // min_t_start
     double t_end;    // 1.01 t_max / (1+z)
+    // observer constants every flux wavefront needs (computed once here instead of once per wavefront)
+    double cos_obs, sin_obs;  // of theta_obs
+    double lg2_1pz;           // log2(1 + z)
 };
 
 // Batch plan computed on the device from the grid results (vag_plan_kernel): the compact layout's totals, what decides

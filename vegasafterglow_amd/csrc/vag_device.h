@@ -782,6 +782,13 @@ struct SpecConst {
         smooth_thick = (3.44 * p - 1.41) / LN2;
         log2_x_far = 1.5 * log2(20.0 / smooth_thick);
     }
+    // the same through the 64-entry log2 table of a flux workgroup: the value only places the shortcut beyond which the
+    // optically thick softplus term is dropped, so the last bits of it do not reach the spectrum
+    template <class Tab>
+    VAG_DEV void init_fast(double p, Tab lg) {
+        smooth_thick = (3.44 * p - 1.41) / LN2;
+        log2_x_far = 1.5 * (4.321928094887363 - log2_tab(smooth_thick, lg));
+    }
 };
 
 // SmoothPowerLawSyn::compute_log2_I_nu without IC (smooth-power-law-syn.cpp:15-46,80-92,159-167).

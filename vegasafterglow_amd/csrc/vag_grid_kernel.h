@@ -992,6 +992,9 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
             gph[VAG_MAX_PHI + i] = log2(fabs(dphi));
         }
     }
+    M.cos_obs = cos(theta_v);
+    M.sin_obs = sin(theta_v);
+    M.lg2_1pz = log2(1 + z);
     if (lane == 0) meta[m] = M;
     VAG_GRID_STAMP(8);
 #ifdef VAG_GRID_STAMPS

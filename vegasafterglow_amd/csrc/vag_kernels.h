@@ -651,14 +651,14 @@ vag_flux_grid_kernel(FluxArgs a) {
     const vag_model_params* Pp = a.params + m;
     const double one_plus_z = 1 + Pp->z;
     {
-        const double lg2_1pz = log2(one_plus_z);
+        const double lg2_1pz = Mp->lg2_1pz;
         for (int i = tid; i < nt; i += THREADS) s_tobs[i] = a.lg2_t_obs[i];
         for (int l = tid; l < nnu; l += THREADS) s_nu[l] = a.lg2_nu_obs[l] + lg2_1pz;
         for (int i = tid; i < SP_LDS_DOUBLES; i += THREADS) s_sp[i] = a.sp_table[i];  // softplus table + log2 table
     }
     SpecConst sc;
     sc.init(Pp->p);
-    const double cos_obs = cos(Pp->theta_obs), sin_obs = sin(Pp->theta_obs);
+    const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     // slot = l * nt + idx walks in steps of THREADS: (l, idx) advance by a fixed (dl, didx) with one carry -- no divisions
@@ -988,6 +988,9 @@ constexpr int SERIES_CHUNK = 8;       // (theta, phi) rows per partial sum: the 
 constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
 __host__ __device__ inline int series_region_doubles(int ks, bool ic, int n_bands) {
+#ifdef VAG_SERIES_NOSTAGE
+    if (!ic) return ((3 + n_bands) * ks + 1) & ~1;
+#endif
     return ((VAG_NPAR + 3 + (ic ? 14 : 0) + n_bands) * ks + 1) & ~1;
 }
 
@@ -1073,6 +1076,12 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int KS = a.k_stride;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* s_sp = lds;
+    {  // a workgroup whose rows all lie beyond this model's grid (the launch is sized for the largest grid of the batch) leaves
+       // before it stages anything
+        const VagGridMeta* Mp = a.meta + m;
+        if (Mp->status != 0 || (long long)blockIdx.x * (blockDim.x >> 6) * a.pairs_per_block >= (long long)Mp->n_theta * Mp->n_phi_eff)
+            return;
+    }
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     double* s_band = s_sp + SP_LDS_DOUBLES;  // [SERIES_MAX_BANDS] log2 nu of the fit's bands (shared-node path)
     if (threadIdx.x < a.n_bands) s_band[threadIdx.x] = a.lg2_nu_obs[GRID ? (int)threadIdx.x : a.band_first[threadIdx.x]];
@@ -1090,7 +1099,12 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int K = M.n_t;
     double* s_par = s_band + SERIES_MAX_BANDS + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC, a.n_bands);
-    double* s_t = s_par + VAG_NPAR * KS;
+#ifdef VAG_SERIES_NOSTAGE
+    constexpr bool NOSTAGE = MODE == FLUX_SYN && !SPREAD && NSLOT == 1 && !GRID;
+#else
+    constexpr bool NOSTAGE = false;
+#endif
+    double* s_t = s_par + (NOSTAGE ? 0 : VAG_NPAR * KS);
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
     double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
@@ -1098,16 +1112,37 @@ vag_flux_series_kernel(SeriesArgs a) {
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     int breach = 0;
 
-    const vag_model_params P = a.params[m];
-    const double one_plus_z = 1 + P.z;
-    const double lg2_1pz = log2(one_plus_z);
+    const double one_plus_z = 1 + a.params[m].z;
+    const double lg2_1pz = M.lg2_1pz;  // observer constants come from the grid kernel: no library calls per wavefront
     SpecConst sc;
-    sc.init(P.p);
-    const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
+    sc.init_fast(a.params[m].p, lg_tab);
+    const double cos_obs = M.cos_obs, sin_obs = M.sin_obs;
     const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
     const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const int n_phi_eff = M.n_phi_eff;
+    // Row geometry of the next 64 (theta, phi) rows, one row per lane, read back with v_readlane when the row's turn comes: the
+    // five dependent global loads and the index division of a row leave its critical path (a wavefront works alone: nothing
+    // else would hide them).  g_a / g_b / g_c = (cos of the viewing angle, time coefficient, log2 dOmega); a spreading jet
+    // keeps (cos phi, -, log2 dphi) because its polar angle is per cell.
+    double g_a = 0, g_b = 0, g_c = 0;
+    int g_rep = 0;
+    auto load_row_geometry = [&](int base) {
+        const int pr = min(base + tid, p1 - 1);
+        const int j = pr / n_phi_eff, i = pr - j * n_phi_eff;
+        g_rep = rep_of[j];
+        if constexpr (SPREAD) {
+            g_a = gph[i];
+            g_c = gph[VAG_MAX_PHI + i];
+        } else {
+            g_a = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            g_b = (1 - g_a) / C_C * one_plus_z;
+            g_c = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+        }
+    };
+    auto lane_value = [&](double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
 
     double acc[NSLOT], tq[NSLOT], nuq[NSLOT];
     int kprev[NSLOT];  // each point's interval in the previous row: the next row's search starts there
@@ -1136,8 +1171,9 @@ vag_flux_series_kernel(SeriesArgs a) {
 #define VAG_SER_MARK(acc) do { } while (0)
 #endif
     for (int pair = p0; pair < p1; ++pair) {
-        const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
-        const int rep = rep_of[j];
+        const int gl = (pair - p0) & 63;
+        if (gl == 0) load_row_geometry(pair);
+        const int rep = __builtin_amdgcn_readlane(g_rep, gl);
         if (pair > p0 && (pair - p0) % a.chunk == 0) {  // p0 is a multiple of the chunk: close the chunk before this row
             double* dst = chunk_partial + (size_t)(pair / a.chunk - 1) * a.n;
 #pragma unroll
@@ -1149,8 +1185,9 @@ vag_flux_series_kernel(SeriesArgs a) {
         }
         wave_sync();
         VAG_SER_MARK(c_pts);
-        if (rep != staged_rep) {
-            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+        const double* rowpar = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+        if (!NOSTAGE && rep != staged_rep) {
+            const double* src = rowpar;
             // four loads in flight per lane before the first LDS store: a wavefront stages alone, so the HBM / L2 latency of
             // its ~11 dependent round trips is otherwise fully exposed
             const float inv_K = 1.0f / (float)K;
@@ -1183,13 +1220,23 @@ vag_flux_series_kernel(SeriesArgs a) {
         VAG_SER_MARK(c_stage);
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
-            eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z, s_t,
-                           s_dop, s_geom, lg_tab);
+            eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, lane_value(g_a, gl), sin_obs, cos_obs, lane_value(g_c, gl),
+                           one_plus_z, s_t, s_dop, s_geom, lg_tab);
         } else {
-            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
-            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-            eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
+            const double cos_v = lane_value(g_a, gl), t_coeff = lane_value(g_b, gl), lg2_dOmega = lane_value(g_c, gl);
+            if constexpr (NOSTAGE) {
+                for (int k = tid; k < K; k += SERIES_THREADS) {
+                    const double G = rowpar[VP_GAMMA * K + k], u = rowpar[VP_U * K + k], r = rowpar[VP_R * K + k];
+                    const double teng = rowpar[VP_TENG * K + k], lr2 = rowpar[VP_LG2_R2 * K + k];
+                    const double lg2_dop = -log2_tab(G - u * cos_v, lg_tab);
+                    const double time = teng * one_plus_z + t_coeff * r;
+                    s_dop[k] = lg2_dop;
+                    s_t[k] = log2_tab(time, lg_tab);
+                    s_geom[k] = (lg2_dOmega + lr2) + 3.0 * lg2_dop;
+                }
+            } else {
+                eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
+            }
         }
         wave_sync();
         VAG_SER_MARK(c_eat);
@@ -1271,7 +1318,12 @@ vag_flux_series_kernel(SeriesArgs a) {
                         const int kk = kmin + idx - b * nn;
                         const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
                         double v;
-                        if (MODE == FLUX_SYN) {
+                        if constexpr (NOSTAGE) {
+                            SpecRegs regs;
+#pragma unroll
+                            for (int w = 0; w < 14; ++w) regs.v[w] = rowpar[w * K + kk];
+                            v = log2_I_nu_fast(regs, 1, sc, x, sp_tab);
+                        } else if (MODE == FLUX_SYN) {
                             v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                         } else if (MODE == FLUX_SYN_IC) {
                             v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
