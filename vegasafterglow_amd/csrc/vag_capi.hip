@@ -266,8 +266,14 @@ static double append_log2_table(std::vector<double>& tab) {
     return maxerr;
 }
 
+struct SeriesOcc {
+    int waves;
+    size_t lds;
+    int wg;
+};
 struct vag_ctx {
     int device = 0;
+    std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
     DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
     DevBuf d_bandidx;  // [64 band index per point | 8 first point of each band] for the shared-node series path
     int h_bandbuf[64 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
@@ -1270,6 +1276,19 @@ vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagG
     }
 }
 
+// resident workgroups per CU of a series launch with `waves` wavefronts and `lds` bytes (occupancy query, remembered per shape)
+static int series_wg_per_cu(vag_ctx* c, int waves, size_t lds) {
+    for (const auto& e : c->series_occ)
+        if (e.waves == waves && e.lds == lds) return e.wg;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_series_kernel<FLUX_SYN, false, 1>, SERIES_THREADS * waves, lds) !=
+        hipSuccess)
+        occ = (int)((144 * 1024) / std::max<size_t>(lds, 1));
+    if (c->series_occ.size() > 256) c->series_occ.clear();
+    c->series_occ.push_back({waves, lds, occ});
+    return occ;
+}
+
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu,
                     int n, double* d_out, int mode, int n_bands, int grid_nt) {
     hipStream_t st = c->stream;
@@ -1291,17 +1310,28 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int ks = c->max_k;
     if (n > SERIES_THREADS && grid_nt == 0) n_bands = 0;  // a fit's shared-node path keeps one point per lane
     // wavefronts per workgroup: four when their private rows fit next to the shared tables, else two or one
-    int waves = SERIES_WAVES;
     auto lds_for = [&](int w) {
         return sizeof(double) * ((size_t)w * series_region_doubles(ks, mode == FLUX_SYN_IC, n_bands) + SP_LDS_DOUBLES + SERIES_MAX_BANDS);
     };
-    while (waves > 1 && lds_for(waves) > 160 * 1024) waves >>= 1;
+    // the workgroup shape that keeps the most wavefronts resident on a CU (each workgroup carries one copy of the tables);
+    // ties go to the smaller workgroup
+    // (the runtime's occupancy query decides what fits: two 80 KB workgroups do not share a CU's 160 KB)
+    int waves = 1, best = 0;
+    for (int w = 1; w <= SERIES_WAVES; w <<= 1) {
+        if (lds_for(w) > 160 * 1024) break;
+        const int resident = std::min(series_wg_per_cu(c, w, lds_for(w)) * w, 16);
+        if (resident >= best) best = resident, waves = w;
+    }
+    if (const char* e = std::getenv("VAG_SERIES_WAVES")) waves = std::max(1, std::min(SERIES_WAVES, std::atoi(e)));
     const size_t lds = lds_for(waves);
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d)", lds, ks);
     const dim3 sgrid((max_blocks + waves - 1) / waves, nb), sblock(SERIES_THREADS * waves);
-    if (std::getenv("VAG_DEBUG_LAUNCH"))
-        std::fprintf(stderr, "[vag] series launch: n=%d bands=%d max_k=%d rows/wave=%lld waves/wg=%d lds=%zu B grid=(%u,%u)\n", n, n_bands,
-                     ks, ppb, waves, lds, sgrid.x, sgrid.y);
+    if (std::getenv("VAG_DEBUG_LAUNCH")) {
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_series_kernel<FLUX_SYN, false, 1>, SERIES_THREADS * waves, lds);
+        std::fprintf(stderr, "[vag] series launch: n=%d bands=%d max_k=%d rows/wave=%lld waves/wg=%d lds=%zu B grid=(%u,%u) wg/CU=%d\n", n,
+                     n_bands, ks, ppb, waves, lds, sgrid.x, sgrid.y, occ);
+    }
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
     a.ictab = c->d_ictab.as<double>();

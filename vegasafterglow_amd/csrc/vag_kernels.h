@@ -982,15 +982,12 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 // not values.  Output partial[m][block][n].
 // ------------------------------------------------------------------------------------------------
 constexpr int SERIES_THREADS = 64;    // lanes that share one (theta, phi) row: ONE wavefront, so rows need no block barrier
-constexpr int SERIES_WAVES = 4;       // independent wavefronts per workgroup (fewer when long lattices need the LDS); they only share the tables
+constexpr int SERIES_WAVES = 4;       // most independent wavefronts per workgroup (the host picks 4, 2 or 1 by what stays resident); they only share the tables
 constexpr int SERIES_MAX_SLOTS = 8;   // data points per lane: n <= 512
 constexpr int SERIES_CHUNK = 8;       // (theta, phi) rows per partial sum: the unit of a model's summation tree, whatever the batch
 constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
 __host__ __device__ inline int series_region_doubles(int ks, bool ic, int n_bands) {
-#ifdef VAG_SERIES_NOSTAGE
-    if (!ic) return ((3 + n_bands) * ks + 1) & ~1;
-#endif
     return ((VAG_NPAR + 3 + (ic ? 14 : 0) + n_bands) * ks + 1) & ~1;
 }
 
@@ -1099,12 +1096,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int K = M.n_t;
     double* s_par = s_band + SERIES_MAX_BANDS + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC, a.n_bands);
-#ifdef VAG_SERIES_NOSTAGE
-    constexpr bool NOSTAGE = MODE == FLUX_SYN && !SPREAD && NSLOT == 1 && !GRID;
-#else
-    constexpr bool NOSTAGE = false;
-#endif
-    double* s_t = s_par + (NOSTAGE ? 0 : VAG_NPAR * KS);
+    double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
     double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
@@ -1165,7 +1157,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int my_band = (NSLOT == 1 && a.n_bands > 0 && tid < a.n) ? a.band_idx[tid] : 0;
     int staged_rep = -1;
 #ifdef VAG_SERIES_STAMPS  // developer aid: cycles of wavefront 0 of model 0 per phase
-    long long c_stage = 0, c_eat = 0, c_pts = 0, c_mark = __builtin_readcyclecounter();
+    long long c_stage = 0, c_eat = 0, c_pts = 0, c_brk = 0, c_items = 0, c_mark = __builtin_readcyclecounter();
 #define VAG_SER_MARK(acc) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - c_mark; c_mark = now_; } while (0)
 #else
 #define VAG_SER_MARK(acc) do { } while (0)
@@ -1185,9 +1177,8 @@ vag_flux_series_kernel(SeriesArgs a) {
         }
         wave_sync();
         VAG_SER_MARK(c_pts);
-        const double* rowpar = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
-        if (!NOSTAGE && rep != staged_rep) {
-            const double* src = rowpar;
+        if (rep != staged_rep) {
+            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
             // four loads in flight per lane before the first LDS store: a wavefront stages alone, so the HBM / L2 latency of
             // its ~11 dependent round trips is otherwise fully exposed
             const float inv_K = 1.0f / (float)K;
@@ -1224,19 +1215,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                            one_plus_z, s_t, s_dop, s_geom, lg_tab);
         } else {
             const double cos_v = lane_value(g_a, gl), t_coeff = lane_value(g_b, gl), lg2_dOmega = lane_value(g_c, gl);
-            if constexpr (NOSTAGE) {
-                for (int k = tid; k < K; k += SERIES_THREADS) {
-                    const double G = rowpar[VP_GAMMA * K + k], u = rowpar[VP_U * K + k], r = rowpar[VP_R * K + k];
-                    const double teng = rowpar[VP_TENG * K + k], lr2 = rowpar[VP_LG2_R2 * K + k];
-                    const double lg2_dop = -log2_tab(G - u * cos_v, lg_tab);
-                    const double time = teng * one_plus_z + t_coeff * r;
-                    s_dop[k] = lg2_dop;
-                    s_t[k] = log2_tab(time, lg_tab);
-                    s_geom[k] = (lg2_dOmega + lr2) + 3.0 * lg2_dop;
-                }
-            } else {
-                eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
-            }
+            eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
         }
         wave_sync();
         VAG_SER_MARK(c_eat);
@@ -1307,6 +1286,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                 int k = 0;
                 if (in) k = kprev[0] = series_bracket(s_t, K, t, kprev[0]);
                 const unsigned long long mask = __ballot(in);
+                VAG_SER_MARK(c_brk);
                 if (mask != 0) {  // wave-uniform
                     const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
                     const int kmin = __builtin_amdgcn_readlane(k, first);  // t ascends with the point index, and so does k
@@ -1318,12 +1298,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         const int kk = kmin + idx - b * nn;
                         const double x = (s_band[b] + lg2_1pz) - s_dop[kk];
                         double v;
-                        if constexpr (NOSTAGE) {
-                            SpecRegs regs;
-#pragma unroll
-                            for (int w = 0; w < 14; ++w) regs.v[w] = rowpar[w * K + kk];
-                            v = log2_I_nu_fast(regs, 1, sc, x, sp_tab);
-                        } else if (MODE == FLUX_SYN) {
+                        if (MODE == FLUX_SYN) {
                             v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                         } else if (MODE == FLUX_SYN_IC) {
                             v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
@@ -1334,6 +1309,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         s_Bw[b * KS + kk] = v + s_geom[kk];
                     }
                     wave_sync();
+                    VAG_SER_MARK(c_items);
                     if (in) {
                         const double* Bb = s_Bw + my_band * KS;
                         const double blo = Bb[k], bhi = Bb[k + 1];
@@ -1376,7 +1352,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     VAG_SER_MARK(c_pts);
 #ifdef VAG_SERIES_STAMPS
     if (m == 0 && vb == 0 && tid == 0)
-        printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  points %lld\n", p1 - p0, K, c_stage, c_eat, c_pts);
+        printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  bracket %lld  items %lld  interp+rest %lld\n", p1 - p0, K, c_stage, c_eat, c_brk, c_items, c_pts);
 #endif
     {
         double* dst = chunk_partial + (size_t)((p1 - 1) / a.chunk) * a.n;  // the last (possibly short) chunk of this wavefront
