@@ -28,14 +28,14 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 7
+#define VAG_ABI_VERSION 8
 
 /* error codes */
 #define VAG_OK 0
 #define VAG_E_INVALID (-1)   /* bad argument: the reference raises ValueError (pybind/error_handling.h:31-69) */
 #define VAG_E_NO_DEVICE (-2) /* no HIP device / HIP runtime failure at context creation */
 #define VAG_E_HIP (-3)       /* a HIP call failed; message carries hipGetErrorString */
-#define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (reverse shock, SSC, ...) */
+#define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (today: a non-axisymmetric jet that also spreads) */
 #define VAG_E_CAPACITY (-5)  /* grid larger than the engine's static limits */
 #define VAG_E_NUMERIC (-6)   /* an ODE row could not find a step size (the reference throws odeint's step_adjustment_error) */
 
@@ -420,6 +420,10 @@ typedef struct vag_plan {
      * both shocks: ic_terms = sum over cells of (electron-energy nodes x seed-frequency nodes), the accumulation's unit;
      * ic_nodes = sum over cells of (electron + seed + output lattice nodes), the set-up's unit */
     int64_t ic_terms, ic_nodes;
+    /* ABI v8: models whose SSC tables were rebuilt over their full theoretical range because a flux pass queried them outside the
+     * clamped band (ICPhoton::compute_log2_I_nu's self-healing path, inverse-compton.h:626-635); the pass was then repeated */
+    int32_t n_models_ssc_rebuilt;
+    int32_t pad_plan;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -842,6 +842,46 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     assert np.array_equal(band_f, band_t)
 
 
+@pytest.mark.parametrize("case", ["grid", "series", "fused"])
+def test_ssc_band_breach_rebuilds_the_tables_unclamped(eng, case):
+    """ICPhoton::compute_log2_I_nu drops a cell's band clamp and rebuilds its spectrum when a query falls outside the clamped
+    band but inside the theoretical range (inverse-compton.h:626-635).  The engine derives the clamp from the very Doppler
+    extremes the flux pass uses, so the case does not arise by itself; VAG_DEBUG_IC_NARROW shrinks the clamp's upper edge so that it
+    does.  The pass must then rebuild those models' tables over the full range, repeat, and return what the clamped tables
+    return (the lattice is phase-locked: shared nodes carry the same values) -- not raise."""
+    lib, h = eng
+    prm = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=(case != "fused"))
+    t, nu = np.logspace(3, 7, 24), np.array([1e9, 1e15, 1e18, 1e24])
+
+    def run():
+        if case == "series":
+            tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+            comps = [np.empty((1, tt.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+            _lib.check(lib.vag_flux_density_components4_batch(h, arr, 1, tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
+        else:
+            if case == "grid":
+                os.environ["VAG_NO_FUSED"] = "1"
+            try:
+                comps = gpu_components4(eng, prm, t, nu)
+            finally:
+                os.environ.pop("VAG_NO_FUSED", None)
+        pl = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(pl))
+        return comps, pl.n_models_ssc_rebuilt
+    want, rebuilt0 = run()
+    assert rebuilt0 == 0 and want[1].max() > 0
+    os.environ["VAG_DEBUG_IC_NARROW"] = "1e-9"
+    try:
+        got, rebuilt = run()
+    finally:
+        del os.environ["VAG_DEBUG_IC_NARROW"]
+    assert rebuilt >= 1
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+
+
 def test_profile_evaluators_match_the_checker(eng, oracle):
     """Model.jet_E_iso / jet_Gamma0 / medium (pybind.cpp:441-448) for every named profile family."""
     theta = np.linspace(1e-4, 1.5, 97)

@@ -279,7 +279,7 @@ struct vag_ctx {
     int h_bandbuf[64 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
     int h_bands_n = -1;
     int pending_bands = 0;  // set by the host-pointer entry points that know the frequencies; consumed by the next series call
-    DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_ssc;
+    DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_icunclamp, d_ssc;
     bool count_work = false;
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
@@ -1021,21 +1021,32 @@ __global__ void vag_add_kernel(double* __restrict__ out, const double* __restric
 
 // SSC emission of the whole batch on a (t, nu) grid (single_shock_emission, pybind/pymodel.h:896-919):
 // observation band per k -> SSC table per representative cell -> EAT flux integration over the tables.
-int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2nu, int nnu) {
+// rebuild = the pass before this one ended with band breaches (status bit 2): those models' tables are rebuilt unclamped
+int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2nu, int nnu, bool rebuild = false) {
     hipStream_t st = c->stream;
     StageScope ps(c, PS_IC_PHOTONS);
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
     if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
-    if (!c->ic_soft_fail || c->ic_need_reset)  // a likelihood pass ORs the failures of both shocks' tables into one status per walker
-        HIPCHK(hipMemsetAsync(c->d_icstatus.p, 0, sizeof(int) * (size_t)nb, st));
+    if (c->d_icunclamp.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
+    if (rebuild) {
+        hipLaunchKernelGGL(vag_ic_unclamp_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, c->d_icstatus.as<int>(),
+                           c->d_icunclamp.as<int>(), nb);
+    } else {
+        if (!c->ic_soft_fail || c->ic_need_reset)  // a likelihood pass ORs the failures of both shocks' tables into one status per walker
+            HIPCHK(hipMemsetAsync(c->d_icstatus.p, 0, sizeof(int) * (size_t)nb, st));
+        HIPCHK(hipMemsetAsync(c->d_icunclamp.p, 0, sizeof(int) * (size_t)nb, st));
+    }
     c->ic_need_reset = false;
     if (c->n_rows > 0) {
         Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+        double narrow = 1.0;  // test hook: VAG_DEBUG_IC_NARROW=<factor> shrinks the clamp so that the flux pass breaches it
+        if (const char* e = std::getenv("VAG_DEBUG_IC_NARROW")) narrow = std::atof(e);
         hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
                            c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
                            c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
-                           (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr);
+                           (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr,
+                           c->d_icunclamp.as<int>(), narrow);
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
@@ -1058,29 +1069,39 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     return VAG_OK;
 }
 
+// > 0: not an error code of the C-ABI -- a flux pass breached a clamped band, the caller rebuilds those tables unclamped and repeats
+constexpr int VAG_IC_REBUILD = 1000;
 int check_ic_status(vag_ctx* c, int nb) {
     if (c->ic_soft_fail) return VAG_OK;  // vag_fit_back_kernel folds d_icstatus into the walker's validity (-inf), samplers.py:61-70
     hipStream_t st = c->stream;
     std::vector<int> h(nb);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_icstatus.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    bool breach = false;
     for (int m = 0; m < nb; ++m) {
         if (h[m] & 1) return set_err(VAG_E_CAPACITY, "model %d: SSC lattices exceed the engine limits", m);
-        if (h[m] & 2)
-            return set_err(VAG_E_UNSUPPORTED, "model %d: SSC query left the clamped band (the reference would rebuild the cell)", m);
+        if (h[m] & 2) {
+            breach = true;
+            ++c->plan.n_models_ssc_rebuilt;
+        }
     }
-    return VAG_OK;
+    return breach ? VAG_IC_REBUILD : VAG_OK;
 }
 
 // d_lg2nu_all / nnu_all: every frequency of the request (the seed band is clamped over all of them, also when the
 // frequency axis is evaluated in chunks)
 int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
                  int nnu, const double* d_bandw, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
-    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all);
-    if (rc) return rc;
-    rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
-    if (rc) return rc;
-    return check_ic_status(c, nb);
+    int rc = VAG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, attempt > 0);
+        if (rc) return rc;
+        rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
+        if (rc) return rc;
+        rc = check_ic_status(c, nb);
+        if (rc != VAG_IC_REBUILD) return rc;
+    }
+    return set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
 }
 
 // Synchrotron (IC-cooled) and SSC components of one emitter in ONE flux pass: the tables are built first, then both
@@ -1098,11 +1119,16 @@ static bool fused_fits(vag_ctx* c, int nt, int nnu) {
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
                    int nnu, const double* d_bandw, double* d_syn, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
-    int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all);
-    if (rc) return rc;
-    rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
-    if (rc) return rc;
-    return check_ic_status(c, nb);
+    int rc = VAG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, attempt > 0);
+        if (rc) return rc;
+        rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
+        if (rc) return rc;
+        rc = check_ic_status(c, nb);
+        if (rc != VAG_IC_REBUILD) return rc;
+    }
+    return set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
 }
 
 __global__ void vag_copy_kernel(double* __restrict__ out, const double* __restrict__ src, size_t n) {
@@ -1433,9 +1459,13 @@ int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
             if (pass == 0) {
                 rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN, n_bands);
             } else {
-                rc = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all);
-                if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC, n_bands);
-                if (rc == VAG_OK) rc = check_ic_status(c, nb);
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    rc = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all, attempt > 0);
+                    if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC, n_bands);
+                    if (rc == VAG_OK) rc = check_ic_status(c, nb);
+                    if (rc != VAG_IC_REBUILD) break;
+                }
+                if (rc == VAG_IC_REBUILD) rc = set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
             }
             if (rc) break;
             if (d_out) {

@@ -20,7 +20,7 @@ enum {
 };
 
 // SSC table of one cell: header + log2 I on the phase-locked output lattice (inverse-compton.h:354-369,595-606)
-constexpr int IC_MAX_OUT = 160;
+constexpr int IC_MAX_OUT = 192;  // three output nodes per lane; an unclamped table needs at most ~(IC_MAX_NU - 1) + (IC_MAX_G - 1) + 3
 constexpr int IC_HDR = 6;  // n_ic, phase, idx0, log2 theory min, log2 theory max, spare
 constexpr int IC_STRIDE = IC_HDR + IC_MAX_OUT;
 constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = 2 * (IC_MAX_G - 1) + 2 * (IC_MAX_NU - 1) + 1;
@@ -205,10 +205,19 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
                    const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ g_rep_of,
                    const long long* __restrict__ cell_off, const double* __restrict__ cellpar,
                    const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][VAG_MAX_TIME] */,
-                   const double* __restrict__ cellgeo /* spreading jets: [rows][3][n_t], else nullptr */) {
+                   const double* __restrict__ cellgeo /* spreading jets: [rows][3][n_t], else nullptr */,
+                   const int* __restrict__ unclamp /* [nb]: the model's tables span the full theoretical range */,
+                   double debug_narrow /* 1, or a test's factor on the upper band edge (forces a band breach) */) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
+    if (unclamp[m]) {  // ICPhoton::compute_log2_I_nu's self-healing path (inverse-compton.h:626-635): nu_eval = [0, inf)
+        for (int k = lane; k < M.n_t; k += 64) {
+            band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = 0.0;
+            band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = INFINITY;
+        }
+        return;
+    }
     __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
     const vag_model_params P = params[m];
     const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
@@ -254,8 +263,18 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
             dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
         }
         band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
-        band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = exp2((nu_hi + lg2_1pz) - dmin_k);  // nu_eval_max_k
+        band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = exp2((nu_hi + lg2_1pz) - dmin_k) * debug_narrow;  // nu_eval_max_k
     }
+}
+
+// A flux pass saw a query outside a model's clamped band but inside its theoretical range (status bit 2): the reference drops the
+// clamp of that cell and rebuilds it (inverse-compton.h:626-635); here the model's tables are rebuilt unclamped -- the lattice is
+// phase-locked, so the nodes both share carry the same values -- and the pass is repeated.
+__global__ void vag_ic_unclamp_kernel(int* __restrict__ status, int* __restrict__ unclamp, int nb) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nb) return;
+    if (status[m] & 2) unclamp[m] = 1;
+    status[m] &= ~2;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -515,7 +515,7 @@ VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* brea
 VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
                                  double th_max, double x, int* breach);
 constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
-constexpr int FLUX_IC_STRIDE = 166;  // == IC_STRIDE
+constexpr int FLUX_IC_STRIDE = 198;  // == IC_STRIDE
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
 // (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.  s_par holds the staged row as
