@@ -882,6 +882,60 @@ def test_ssc_band_breach_rebuilds_the_tables_unclamped(eng, case):
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("case", ["tophat", "gaussian_offaxis", "ssc_kn", "rs", "spreading"])
+def test_lattices_longer_than_the_staged_row_are_taken_in_pieces(eng, case):
+    """The flux kernels stage at most 512 lattice nodes of a row at a time and take a longer lattice in pieces that overlap by
+    one node (each requested time falls into exactly one piece).  VAG_FLUX_K_CAP makes ordinary models take that path with
+    pieces of 12 nodes: grid, series and band results must come back as from the one-piece form, per component, to summation
+    rounding."""
+    lib, h = eng
+    kw = {"tophat": configs.C1A, "gaussian_offaxis": configs.C2, "ssc_kn": dict(configs.C1B, ssc=True, kn=True),
+          "rs": dict(configs.C3, ssc=False, kn=False, rvs=dict(configs.C3["rvs"], ssc=False, kn=False)),
+          "spreading": dict(jet="GaussianJet", theta_obs=0.25, spreading=True)}[case]
+    prm = _abi.make_params(**kw)
+    t, nu = np.logspace(2.5, 7.5, 37), np.array([1e9, 4.84e14, 1e18])
+    tt, nn = np.repeat(t, nu.size)[::2], np.tile(nu, t.size)[::2]
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+
+    def run():
+        grid = gpu_components4(eng, prm, t, nu)
+        series = gpu_series(eng, prm, tt, nn)
+        band = np.empty((1, t.size))
+        _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e17, 1e19, 7, band.ctypes.data_as(dp)))
+        pl = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(pl))
+        return grid, series, band, pl.n_cells // max(pl.n_rows, 1)
+    g1, s1, b1, k_nodes = run()
+    assert k_nodes > 40  # several pieces of 12
+    os.environ["VAG_FLUX_K_CAP"] = "12"
+    try:
+        g2, s2, b2, _ = run()
+    finally:
+        del os.environ["VAG_FLUX_K_CAP"]
+    for a, b in zip(g2 + [s2, b2], g1 + [s1, b1]):
+        assert np.all(np.isfinite(a))
+        np.testing.assert_allclose(a, b, rtol=2e-13, atol=1e-300)
+    assert g1[0].max() > 0
+
+
+def test_a_lattice_of_more_than_512_nodes_matches_the_oracle(eng, oracle):
+    """resolutions = (0.3, 1, 70): 70 time nodes per decade give a lattice of more than 512 nodes (VAG_E_CAPACITY before the flux
+    kernels took lattices in pieces).  Grid and series against the oracle at the tolerance of the default-resolution cases."""
+    lib, h = eng
+    prm = _abi.make_params(**dict(configs.C1B, resolutions=(0.3, 1.0, 70.0)))
+    t, nu = np.logspace(2, 7, 40), np.array([1e9, 1e14, 1e18])
+    got = gpu_grid(eng, prm, t, nu)[0]
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_ok == 1 and pl.n_cells // pl.n_rows > 512
+    want = oracle.flux_density_grid(prm, t, nu)
+    m = want > 1e-9 * want.max()
+    assert np.max(np.abs(got - want)[m] / want[m]) < 2e-6
+    tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+    ser = gpu_series(eng, prm, tt, nn)[0]
+    np.testing.assert_allclose(ser.reshape(t.size, nu.size).T[m], got[m], rtol=1e-9)
+
+
 def test_profile_evaluators_match_the_checker(eng, oracle):
     """Model.jet_E_iso / jet_Gamma0 / medium (pybind.cpp:441-448) for every named profile family."""
     theta = np.linspace(1e-4, 1.5, 97)

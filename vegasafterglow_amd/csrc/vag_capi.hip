@@ -892,6 +892,14 @@ int choose_pairs_per_block(const vag_ctx* c) {
     return (int)std::max<long long>(1, ppb);
 }
 
+// Lattice nodes the flux kernels stage at a time (their LDS scales with it).  Longer lattices are taken in overlapping pieces
+// inside the kernels; VAG_FLUX_K_CAP is a test hook that makes ordinary models take that path.
+static int flux_ks(const vag_ctx* c) {
+    int cap = 512;
+    if (const char* e = std::getenv("VAG_FLUX_K_CAP")) cap = std::max(4, std::atoi(e));
+    return std::max(2, std::min(c->max_k, cap));
+}
+
 // dynamic LDS of vag_flux_grid_kernel (layout at the top of the kernel)
 static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
     const size_t slots = (size_t)nt * nnu;
@@ -924,7 +932,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const int ppb = choose_pairs_per_block(c);
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
-    const int ks = c->max_k;
+    const int ks = flux_ks(c);
     const size_t lds = flux_grid_lds_bytes(mode, ks, nt, nnu);
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d, nnu=%d)", lds, ks, nnu);
     if (mode == FLUX_FUSED && c->d_partial2.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
@@ -1025,7 +1033,8 @@ __global__ void vag_add_kernel(double* __restrict__ out, const double* __restric
 int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2nu, int nnu, bool rebuild = false) {
     hipStream_t st = c->stream;
     StageScope ps(c, PS_IC_PHOTONS);
-    if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_TIME)) return VAG_E_HIP;
+    const int band_stride = std::max(c->max_k, 1);  // [nb][2][band_stride]
+    if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * band_stride)) return VAG_E_HIP;
     if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
     if (c->d_icunclamp.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
@@ -1046,7 +1055,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
                            c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
                            c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
                            (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr,
-                           c->d_icunclamp.as<int>(), narrow);
+                           c->d_icunclamp.as<int>(), narrow, band_stride);
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
@@ -1056,7 +1065,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
                            c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_band.as<double>(), c->d_sptab.as<double>(),
                            c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
-                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr);
+                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride);
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             unsigned long long h[2] = {0, 0};
@@ -1113,8 +1122,8 @@ static bool fused_fits(vag_ctx* c, int nt, int nnu) {
         return false;  // experiment switch of run_flux_grid: two passes of the wavefront-per-row kernel
     // the second set of buffers must not cost a resident workgroup: on the C5 / C3 shapes it does (63 vs 51 KB: two
     // workgroups per CU instead of three) and the fused pass measured 18 % SLOWER than two passes there
-    const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, c->max_k, nt, nnu),
-                 two = flux_grid_lds_bytes(FLUX_SYN_IC, c->max_k, nt, nnu);
+    const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, flux_ks(c), nt, nnu),
+                 two = flux_grid_lds_bytes(FLUX_SYN_IC, flux_ks(c), nt, nnu);
     return fused <= cu && std::min<size_t>(cu / fused, 4) >= std::min<size_t>(cu / two, 4);
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
@@ -1232,7 +1241,7 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
     const int nu_chunk = (nnu + nu_parts - 1) / nu_parts;
     int chunk = std::max(1, 4096 / nu_chunk);
     while (chunk > 8 &&
-           flux_grid_lds_bytes(any_ssc ? FLUX_SYN_IC : FLUX_SYN, c->max_k, std::min(chunk, nt), nu_chunk) > 160 * 1024)
+           flux_grid_lds_bytes(any_ssc ? FLUX_SYN_IC : FLUX_SYN, flux_ks(c), std::min(chunk, nt), nu_chunk) > 160 * 1024)
         chunk >>= 1;
     if (nt <= chunk && nu_parts == 1) return grid_request(c, d_params, nb, nt, nnu, d_bandw, d_total, d_comp);
     chunk = std::min(chunk, nt);
@@ -1333,7 +1342,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     const int chunk = grid_nt > 0 ? (int)ppb : SERIES_CHUNK;
     const int max_chunks = std::max(1, (c->max_pairs + chunk - 1) / chunk);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_chunks * n)) return VAG_E_HIP;
-    const int ks = c->max_k;
+    const int ks = flux_ks(c);
     if (n > SERIES_THREADS && grid_nt == 0) n_bands = 0;  // a fit's shared-node path keeps one point per lane
     // wavefronts per workgroup: four when their private rows fit next to the shared tables, else two or one
     auto lds_for = [&](int w) {

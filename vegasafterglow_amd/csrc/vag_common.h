@@ -8,7 +8,7 @@
 // the actual sizes at run time; these bound them).
 #define VAG_MAX_THETA 320   // theta nodes per model
 #define VAG_MAX_PHI 640     // phi nodes per model
-#define VAG_MAX_TIME 512    // time-lattice nodes per row
+#define VAG_MAX_TIME 8192   // time-lattice nodes per row (the flux kernels stage at most 512 at a time and take longer lattices in pieces)
 #define VAG_MAX_NU 64       // frequencies per grid call
 #define VAG_MAX_JUMPS 16
 

@@ -204,17 +204,18 @@ __global__ void __launch_bounds__(64)
 vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                    const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ g_rep_of,
                    const long long* __restrict__ cell_off, const double* __restrict__ cellpar,
-                   const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][VAG_MAX_TIME] */,
+                   const double* __restrict__ lg2_nu_obs, int nnu, double* __restrict__ band /* [nb][2][band_stride] */,
                    const double* __restrict__ cellgeo /* spreading jets: [rows][3][n_t], else nullptr */,
                    const int* __restrict__ unclamp /* [nb]: the model's tables span the full theoretical range */,
-                   double debug_narrow /* 1, or a test's factor on the upper band edge (forces a band breach) */) {
+                   double debug_narrow /* 1, or a test's factor on the upper band edge (forces a band breach) */,
+                   int band_stride /* >= the longest lattice of the batch */) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     if (unclamp[m]) {  // ICPhoton::compute_log2_I_nu's self-healing path (inverse-compton.h:626-635): nu_eval = [0, inf)
         for (int k = lane; k < M.n_t; k += 64) {
-            band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = 0.0;
-            band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = INFINITY;
+            band[((size_t)m * 2 + 0) * band_stride + k] = 0.0;
+            band[((size_t)m * 2 + 1) * band_stride + k] = INFINITY;
         }
         return;
     }
@@ -262,8 +263,8 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
             dmax_k = fmax(dmax_k, -log2(G - u * cvmax));
             dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
         }
-        band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
-        band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k] = exp2((nu_hi + lg2_1pz) - dmin_k) * debug_narrow;  // nu_eval_max_k
+        band[((size_t)m * 2 + 0) * band_stride + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
+        band[((size_t)m * 2 + 1) * band_stride + k] = exp2((nu_hi + lg2_1pz) - dmin_k) * debug_narrow;  // nu_eval_max_k
     }
 }
 
@@ -345,7 +346,8 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                      const double* __restrict__ cellpar, const double* __restrict__ cellq, const double* __restrict__ band,
                      const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* __restrict__ ictab,
                      int* __restrict__ ic_status,
-                     unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */) {
+                     unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
+                     int band_stride) {
     const long long c = blockIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int lane = threadIdx.x;
@@ -373,8 +375,8 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double Y_c = det[VD_YC * n_cells + c];
     const int regime = (int)det[VD_REGIME * n_cells + c];
     const double nu_m = det[VD_NU_M * n_cells + c], nu_a = det[VD_NU_A * n_cells + c], nu_M = det[VD_NU_MAX * n_cells + c];
-    const double nu_eval_min = band[((size_t)m * 2 + 0) * VAG_MAX_TIME + k];
-    const double nu_eval_max = band[((size_t)m * 2 + 1) * VAG_MAX_TIME + k];
+    const double nu_eval_min = band[((size_t)m * 2 + 0) * band_stride + k];
+    const double nu_eval_max = band[((size_t)m * 2 + 1) * band_stride + k];
     // compute_grid_params, inverse-compton.h:297-338
     const double tail_factor = dmax(-log(1e-2), 5.0);
     const double gamma_min = dmin(gamma_m, gamma_c) / 30;

@@ -545,18 +545,18 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
 VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads,
                             const double* __restrict__ geo, double cos_phi, double sin_obs, double cos_obs, double lg2_dphi,
                             double one_plus_z, double* __restrict__ s_t, double* __restrict__ s_dop,
-                            double* __restrict__ s_geom, LdsTab lg) {
+                            double* __restrict__ s_geom, LdsTab lg, int GS /* stride of geo's three rows: the row's whole lattice */) {
     for (int k = tid; k < K; k += nthreads) {
         const double* c = s_par + k * VAG_NPAR;
         const LdsTab c2 = lds_tab(c);
         const vdouble2 Gu = c2[VP_GAMMA / 2], rt = c2[VP_R / 2];
         const double G = Gu.x, u = Gu.y, r = rt.x;
-        const double cos_v = geo[K + k] * cos_phi * sin_obs + geo[k] * cos_obs;
+        const double cos_v = geo[GS + k] * cos_phi * sin_obs + geo[k] * cos_obs;
         const double lg2_dop = -log2_tab(G - u * cos_v, lg);
         const double time = (rt.y + (1 - cos_v) * r / C_C) * one_plus_z;
         s_dop[k] = lg2_dop;
         s_t[k] = log2_tab(time, lg);
-        s_geom[k] = ((geo[2 * K + k] + lg2_dphi) + c[VP_LG2_R2]) + 3.0 * lg2_dop;
+        s_geom[k] = ((geo[2 * GS + k] + lg2_dphi) + c[VP_LG2_R2]) + 3.0 * lg2_dop;
     }
 }
 
@@ -613,6 +613,9 @@ vag_eat_details_kernel(const vag_model_params* __restrict__ params, const VagGri
 
 // COUNT = true is the instrumentation variant (exact work tallies); timed runs use COUNT = false.
 // MODE selects the photon source (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
+// 128 VGPRs (four workgroups of 256, two of 512 per CU) is what the occupancy of every measured shape hangs on: the C2 launch asks
+// for 80 KB of LDS, two workgroups per CU, and a 136-VGPR scratch-free build of this kernel (launch bound 1) leaves ONE resident:
+// 39.3 ms instead of 24.0 ms per 512 models.  The few spilled values (36 B per lane) sit outside the inner loops.
 template <bool COUNT, int MODE, bool SPREAD = false, int THREADS = FLUX_THREADS>
 __global__ void __launch_bounds__(THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
@@ -625,7 +628,12 @@ vag_flux_grid_kernel(FluxArgs a) {
     if (p0 >= n_pairs) return;
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
     const int tid = threadIdx.x;
-    const int K = Mp->n_t, KS = a.k_stride;
+    // A lattice longer than the staged row (KS nodes) is taken in pieces [k0, k0 + K) that overlap by one node: every requested
+    // time falls into exactly one piece's [first node, last node), the window / bracket / boundary-spectra steps are the same
+    // per piece, and the accumulators stay in LDS across pieces.  K_all <= KS (every default-resolution model) is one piece.
+    const int K_all = Mp->n_t, KS = a.k_stride;
+    const int n_pieces = K_all <= KS ? 1 : (K_all - 1 + KS - 2) / (KS - 1);
+    int K = min(K_all, KS), k0 = 0;
     const int nt = a.nt, nnu = a.nnu;
     const int slots = nt * nnu;
 
@@ -681,9 +689,9 @@ vag_flux_grid_kernel(FluxArgs a) {
         const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
         const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
         if constexpr (SPREAD) {
-            const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K) * 3;
+            const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K_all) * 3 + k0;
             eat_row_spread(s_par, KS, K, tid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
-                           s_t + buf * KS, s_dop, s_geom, lg_tab);
+                           s_t + buf * KS, s_dop, s_geom, lg_tab, K_all);
         } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
@@ -695,17 +703,17 @@ vag_flux_grid_kernel(FluxArgs a) {
     auto stage_row = [&](int pair) {  // block-uniform: (re)load the photon block when the representative row changes
         const int rep = rep_of[pair / n_phi_eff];
         if (rep != staged_rep) {
-            const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+            const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K_all) * VAG_NPAR + k0;
 #pragma unroll 1
             for (int q = tid; q < VAG_NPAR * K; q += THREADS) {  // rare path: keep its register footprint small
                 const int par = (int)(((float)q + 0.5f) / (float)K);
-                s_par[(q - par * K) * VAG_NPAR + par] = src[q];
+                s_par[(q - par * K) * VAG_NPAR + par] = src[(size_t)par * K_all + (q - par * K)];
             }
             if constexpr (MODE == FLUX_SSC) {
                 // the SSC pass never evaluates the synchrotron block: its first five rows carry the table headers
                 // (n, phase, idx0, theory_min, theory_max) instead, saving a dependent global round trip per evaluation
                 __syncthreads();
-                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K) * FLUX_IC_STRIDE;
+                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_STRIDE;
 #pragma unroll 1
                 for (int q = tid; q < 5 * K; q += THREADS) {
                     const int kk = q / 5, w = q - kk * 5;
@@ -713,7 +721,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                 }
             }
             if constexpr (MODE == FLUX_FUSED) {
-                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K) * FLUX_IC_STRIDE;
+                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_STRIDE;
 #pragma unroll 1
                 for (int q = tid; q < 5 * K; q += THREADS) {
                     const int kk = q / 5, w = q - kk * 5;
@@ -721,11 +729,11 @@ vag_flux_grid_kernel(FluxArgs a) {
                 }
             }
             if constexpr (HAS_Q) {
-                const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K) * FLUX_NQ;
+                const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K_all) * FLUX_NQ + k0;
 #pragma unroll 1
                 for (int q = tid; q < FLUX_NQ * K; q += THREADS) {
                     const int par = (int)(((float)q + 0.5f) / (float)K);
-                    s_q[(q - par * K) * FLUX_NQ + par] = srcq[q];
+                    s_q[(q - par * K) * FLUX_NQ + par] = srcq[(size_t)par * K_all + (q - par * K)];
                 }
             }
             staged_rep = rep;
@@ -733,6 +741,13 @@ vag_flux_grid_kernel(FluxArgs a) {
         }
         return false;
     };
+    for (int piece = 0; piece < n_pieces; ++piece) {
+    k0 = piece * (KS - 1);
+    K = min(KS, K_all - k0);
+    if (piece > 0) {
+        staged_rep = -1;
+        for (int i = tid; i < nt; i += THREADS) s_kidx[i] = -1;
+    }
     __syncthreads();
     stage_row(p0);
     __syncthreads();
@@ -854,7 +869,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                     b0 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l0] - dop, sp_tab);
                     b1 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l1] - dop, sp_tab);
                     if constexpr (MODE == FLUX_FUSED) {
-                        const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
+                        const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                         const double* hp = s_hdr + __mul24(k, 6);
                         const double h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
                         const double c0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
@@ -863,7 +878,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                         s_B2[min(bofs + KS, top) + k] = c1 + geom;
                     }
                 } else {
-                    const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K + k) * FLUX_IC_STRIDE;
+                    const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                     const double h0 = cp[0], h1 = cp[1], h2 = cp[2], h3 = cp[3], h4 = cp[4];
                     b0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
                     b1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
@@ -922,6 +937,7 @@ vag_flux_grid_kernel(FluxArgs a) {
             __syncthreads();
         }
     }
+    }  // pieces of the lattice
     if constexpr (COUNT) {
         if (tid == 0) {
             atomicAdd(a.work_count, n_evals);
@@ -1094,7 +1110,10 @@ vag_flux_series_kernel(SeriesArgs a) {
     const int p0 = vb * a.pairs_per_block;
     if (p0 >= n_pairs) return;
     const int p1 = min(n_pairs, p0 + a.pairs_per_block);
-    const int K = M.n_t;
+    // a lattice longer than the staged row is taken in overlapping pieces [k0, k0 + K), as in vag_flux_grid_kernel
+    const int K_all = M.n_t;
+    const int n_pieces = K_all <= KS ? 1 : (K_all - 1 + KS - 2) / (KS - 1);
+    int K = min(K_all, KS), k0 = 0;
     double* s_par = s_band + SERIES_MAX_BANDS + (size_t)wave * series_region_doubles(KS, MODE == FLUX_SYN_IC, a.n_bands);
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
@@ -1162,6 +1181,14 @@ vag_flux_series_kernel(SeriesArgs a) {
 #else
 #define VAG_SER_MARK(acc) do { } while (0)
 #endif
+    for (int piece = 0; piece < n_pieces; ++piece) {
+    k0 = piece * (KS - 1);
+    K = min(KS, K_all - k0);
+    if (piece > 0) {
+        staged_rep = -1;
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) acc[q] = 0, kprev[q] = -1;
+    }
     for (int pair = p0; pair < p1; ++pair) {
         const int gl = (pair - p0) & 63;
         if (gl == 0) load_row_geometry(pair);
@@ -1171,14 +1198,14 @@ vag_flux_series_kernel(SeriesArgs a) {
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
                 const int s = tid + q * SERIES_THREADS;
-                if (s < a.n) dst[s] = acc[q];
+                if (s < a.n) dst[s] = piece == 0 ? acc[q] : dst[s] + acc[q];
                 acc[q] = 0;
             }
         }
         wave_sync();
         VAG_SER_MARK(c_pts);
         if (rep != staged_rep) {
-            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;
+            const double* src = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K_all) * VAG_NPAR + k0;
             // four loads in flight per lane before the first LDS store: a wavefront stages alone, so the HBM / L2 latency of
             // its ~11 dependent round trips is otherwise fully exposed
             const float inv_K = 1.0f / (float)K;
@@ -1187,7 +1214,8 @@ vag_flux_series_kernel(SeriesArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int q = q0 + u * SERIES_THREADS;
-                    v[u] = q < VAG_NPAR * K ? src[q] : 0.0;
+                    const int par = (int)(((float)q + 0.5f) * inv_K);
+                    v[u] = q < VAG_NPAR * K ? src[(size_t)par * K_all + (q - par * K)] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1199,10 +1227,10 @@ vag_flux_series_kernel(SeriesArgs a) {
                 }
             }
             if (MODE == FLUX_SYN_IC) {
-                const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K) * FLUX_NQ;
+                const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K_all) * FLUX_NQ + k0;
                 for (int q = tid; q < FLUX_NQ * K; q += SERIES_THREADS) {
                     const int par = (int)(((float)q + 0.5f) / (float)K), k = q - par * K;
-                    s_q[k * FLUX_NQ + par] = srcq[q];
+                    s_q[k * FLUX_NQ + par] = srcq[(size_t)par * K_all + k];
                 }
             }
             staged_rep = rep;
@@ -1210,9 +1238,9 @@ vag_flux_series_kernel(SeriesArgs a) {
         }
         VAG_SER_MARK(c_stage);
         if constexpr (SPREAD) {
-            const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K) * 3;
+            const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K_all) * 3 + k0;
             eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, lane_value(g_a, gl), sin_obs, cos_obs, lane_value(g_c, gl),
-                           one_plus_z, s_t, s_dop, s_geom, lg_tab);
+                           one_plus_z, s_t, s_dop, s_geom, lg_tab, K_all);
         } else {
             const double cos_v = lane_value(g_a, gl), t_coeff = lane_value(g_b, gl), lg2_dOmega = lane_value(g_c, gl);
             eat_row(s_par, KS, K, tid, SERIES_THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t, s_dop, s_geom, lg_tab);
@@ -1256,7 +1284,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                     } else if (MODE == FLUX_SYN_IC) {
                         v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
                     } else {
-                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + kk) * FLUX_IC_STRIDE;
+                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
                         v = ic_table_eval(tab, x, &breach);
                     }
                     s_Bw[b * KS + kk] = v + s_geom[kk];
@@ -1303,7 +1331,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         } else if (MODE == FLUX_SYN_IC) {
                             v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
                         } else {
-                            const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + kk) * FLUX_IC_STRIDE;
+                            const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
                             v = ic_table_eval(tab, x, &breach);
                         }
                         s_Bw[b * KS + kk] = v + s_geom[kk];
@@ -1337,7 +1365,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, s_q + (k + 1) * FLUX_NQ, 1, sc, nuq[q] - s_dop[k + 1],
                                            sp_tab);
                     } else {
-                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K + k) * FLUX_IC_STRIDE;
+                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                         blo = ic_table_eval(tab, nuq[q] - s_dop[k], &breach);
                         bhi = ic_table_eval(tab + FLUX_IC_STRIDE, nuq[q] - s_dop[k + 1], &breach);
                     }
@@ -1349,19 +1377,20 @@ vag_flux_series_kernel(SeriesArgs a) {
             }
         }
     }
-    VAG_SER_MARK(c_pts);
-#ifdef VAG_SERIES_STAMPS
-    if (m == 0 && vb == 0 && tid == 0)
-        printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  bracket %lld  items %lld  interp+rest %lld\n", p1 - p0, K, c_stage, c_eat, c_brk, c_items, c_pts);
-#endif
     {
         double* dst = chunk_partial + (size_t)((p1 - 1) / a.chunk) * a.n;  // the last (possibly short) chunk of this wavefront
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             const int s = tid + q * SERIES_THREADS;
-            if (s < a.n) dst[s] = acc[q];
+            if (s < a.n) dst[s] = piece == 0 ? acc[q] : dst[s] + acc[q];
         }
     }
+    }  // pieces of the lattice
+    VAG_SER_MARK(c_pts);
+#ifdef VAG_SERIES_STAMPS
+    if (m == 0 && vb == 0 && tid == 0)
+        printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  bracket %lld  items %lld  interp+rest %lld\n", p1 - p0, K, c_stage, c_eat, c_brk, c_items, c_pts);
+#endif
     if (MODE == FLUX_SSC && breach) atomicOr(a.ic_status + m, 2);
 }
 
