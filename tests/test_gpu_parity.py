@@ -261,9 +261,9 @@ def test_device_pointer_entry_points_match_host_entry_points(eng):
 
 
 def test_capacity_and_argument_errors_are_loud(eng):
-    prm = _abi.make_params(**dict(configs.C1A, resolutions=(5.0, 0.05, 12.0)))  # 1800 phi nodes > engine limit
-    with pytest.raises(ValueError, match="capacity"):
-        gpu_grid(eng, _abi.make_params(**dict(configs.C1B, resolutions=(5.0, 0.05, 12.0))), configs.C1_T, configs.C1_NU)
+    prm = _abi.make_params(**dict(configs.C1A, resolutions=(5.0, 0.05, 12.0)))
+    with pytest.raises(ValueError, match="capacity"):  # 7200 phi nodes: beyond even the large layout (2560)
+        gpu_grid(eng, _abi.make_params(**dict(configs.C1B, resolutions=(20.0, 0.05, 12.0))), configs.C1_T, configs.C1_NU)
     with pytest.raises(ValueError):
         gpu_grid(eng, _abi.make_params(theta_c=-1.0), configs.C1_T, configs.C1_NU)
     assert prm.phi_resol == 5.0
@@ -934,6 +934,32 @@ def test_a_lattice_of_more_than_512_nodes_matches_the_oracle(eng, oracle):
     tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
     ser = gpu_series(eng, prm, tt, nn)[0]
     np.testing.assert_allclose(ser.reshape(t.size, nu.size).T[m], got[m], rtol=1e-9)
+
+
+@pytest.mark.parametrize("res, n_theta, n_phi", [((2.0, 4.0, 5.0), 413, 360), ((4.0, 1.0, 5.0), None, 720)])
+def test_angular_grids_beyond_the_small_layout_of_the_grid_kernel(eng, oracle, res, n_theta, n_phi):
+    """resolutions a user may pass to the reference (grid-refinement.h:639-706 sizes the grids freely): more than 320 theta nodes,
+    more than 640 phi nodes.  The grid kernel's default LDS layout does not hold them (VAG_E_CAPACITY before); the batch is laid out
+    again with the large layout.  Grid against the oracle; a default-resolution model in the same batch comes back as in a batch
+    of its own (to summation rounding: a grid request groups its rows by the batch total)."""
+    lib, h = eng
+    big = _abi.make_params(jet="GaussianJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, theta_obs=0.3,
+                           resolutions=res)
+    small = _abi.make_params(**configs.C1B)
+    t, nu = np.logspace(3, 7, 12), np.array([1e9, 1e15])
+    got = gpu_grid(eng, [big, small], t, nu)
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_ok == 2 and pl.n_models_capacity == 0
+    d = oracle.details(big, t.min(), t.max())["shape"]
+    assert d["n_phi"] == n_phi and (n_theta is None or d["n_theta"] == n_theta)
+    assert d["n_theta"] > 320 or d["n_phi"] > 640
+    want = oracle.flux_density_grid(big, t, nu)
+    m = want > 1e-9 * want.max()
+    assert np.max(np.abs(got[0] - want)[m] / want[m]) < 2e-6
+    for _ in range(9):  # the context goes back to the small layout after a run of batches that fit it
+        alone = gpu_grid(eng, small, t, nu)[0]
+    np.testing.assert_allclose(alone, got[1], rtol=1e-12)
 
 
 def test_profile_evaluators_match_the_checker(eng, oracle):

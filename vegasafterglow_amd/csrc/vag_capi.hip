@@ -273,6 +273,8 @@ struct SeriesOcc {
 };
 struct vag_ctx {
     int device = 0;
+    bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > 320 theta / > 640 phi nodes)
+    int grid_large_idle = 0;  // consecutive batches that would have fitted the small one
     std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
     DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
     DevBuf d_bandidx;  // [64 band index per point | 8 first point of each band] for the shared-node series path
@@ -759,13 +761,17 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->prof_used = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
     std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
-    hipLaunchKernelGGL(vag_grid_kernel, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
-                       c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
-                       c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
-                       c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
-                       c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
-                       cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
-                       spec ? c->hint.dyn_class : 0);
+    auto launch_grid = [&](bool large) {
+        auto kern = large ? vag_grid_kernel<true> : vag_grid_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
+                           c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
+                           c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
+                           c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
+                           c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
+                           cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
+                           spec ? c->hint.dyn_class : 0);
+    };
+    launch_grid(c->grid_large);
     ps_grid.reset();
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], st));
@@ -775,6 +781,21 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (!spec) {
         VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
         if (int rcw = wait_plan(c)) return rcw;
+        if (hp->n_capacity > 0 && !c->grid_large) {
+            // some model's angular grid outgrew the small layout of the grid kernel: lay the batch out again with the large one
+            // (the same grids for every model that fitted), and keep using it while the caller keeps sending such models
+            c->grid_large = true;
+            if (std::getenv("VAG_DEBUG_LAUNCH"))
+                std::fprintf(stderr, "[vag] grid: %d of %d models over the small layout's capacity, laying the batch out again\n", hp->n_capacity, nb);
+            launch_grid(true);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[1], st));
+            if (int rcw = wait_plan(c)) return rcw;
+        } else if (hp->n_capacity == 0 && c->grid_large && ++c->grid_large_idle >= 8) {
+            c->grid_large = false;  // eight batches in a row fitted: back to the small layout (several models per CU)
+            c->grid_large_idle = 0;
+        }
+        if (hp->n_capacity > 0) c->grid_large_idle = 0;
         if (hp->flags_mixed)
             return set_err(VAG_E_UNSUPPORTED, "models with different Radiation / shock flags in one device-resident batch: split it by flags "
                                               "(the host-pointer entry points do that themselves)");

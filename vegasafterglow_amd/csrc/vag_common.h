@@ -6,8 +6,10 @@
 
 // Static per-model capacities of the adaptive grid (src/core/grid-refinement.h:639-706 decides
 // the actual sizes at run time; these bound them).
-#define VAG_MAX_THETA 320   // theta nodes per model
-#define VAG_MAX_PHI 640     // phi nodes per model
+#define VAG_MAX_THETA 1280  // theta nodes per model: stride of the per-model angular arrays in HBM
+#define VAG_MAX_PHI 2560    // phi nodes per model
+#define VAG_GRID_THETA 320  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
+#define VAG_GRID_PHI 640    //   with the large layout (vag_grid_kernel<true>)
 #define VAG_MAX_TIME 8192   // time-lattice nodes per row (the flux kernels stage at most 512 at a time and take longer lattices in pieces)
 #define VAG_MAX_NU 64       // frequencies per grid call
 #define VAG_MAX_JUMPS 16

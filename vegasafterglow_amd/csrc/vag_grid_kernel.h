@@ -6,6 +6,8 @@
 // the theta sum inside the phi weight, per-theta deceleration times, inverse-CDF lookups) is
 // spread over the lanes, with __shfl_xor butterflies for the sums/minima.
 #pragma once
+#include <type_traits>
+
 #include "vag_device.h"
 
 namespace vag {
@@ -48,15 +50,20 @@ VAG_DEV double linspace_at(double start, double stop, int n, int i) {
 // resident models per CU instead of four when a batch is larger than the chip):
 //   profile scans + theta quantiles (find_jet_jumps ... merge_grids)   |  phi-weight constants (adaptive_phi_grid)
 //   CDF samples (both inverse_CFD_sampling calls)                       |  t_dec per row (build_time_grid, after the phi grid)
-struct GridShared {
+// The wavefront's scratch arrays.  Two sizes exist: the angular grids of every default-resolution model fit (320, 640) -- 32 KB,
+// several models resident per CU --, and a batch in which some model asks for more is laid out again with (MAXTH,
+// MAXPH) -- 100 KB, one model per CU.  The arrays in HBM are strided by the large size either way.
+template <int MAXTH, int MAXPH>
+struct GridSharedT {
+    static constexpr int max_theta = MAXTH, max_phi = MAXPH;
     union {
         struct {
             double scan_th[N_SCAN + 8];  // scan abscissae (find_theta_range accumulates them sequentially)
             double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae
-            double base[VAG_MAX_THETA];  // theta quantiles before the jump nodes are merged in
+            double base[MAXTH];  // theta quantiles before the jump nodes are merged in
         };
         struct {  // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
-            double pj_beta[VAG_MAX_THETA], pj_sw[VAG_MAX_THETA], pj_dcos[VAG_MAX_THETA], pj_ct[VAG_MAX_THETA], pj_st[VAG_MAX_THETA];
+            double pj_beta[MAXTH], pj_sw[MAXTH], pj_dcos[MAXTH], pj_ct[MAXTH], pj_st[MAXTH];
         };
     };
     union {
@@ -64,11 +71,11 @@ struct GridShared {
             double xs[N_SAMPLES];   // CDF sample abscissae
             double cdf[N_SAMPLES];  // CDF at xs
         };
-        double tdec[VAG_MAX_THETA];
+        double tdec[MAXTH];
     };
-    double theta[VAG_MAX_THETA + 64];
-    double phi[VAG_MAX_PHI];
-    int flag[VAG_MAX_THETA];
+    double theta[MAXTH + 64];
+    double phi[MAXPH];
+    int flag[MAXTH];
     double rec[9][QUAD_REC];          // accepted quadrature steps awaiting their dense-output pass (integrate_cdf)
     double jumps[VAG_MAX_JUMPS];      // find_jet_jumps results (dynamically indexed: LDS, not scratch)
     double feat[3 * VAG_MAX_JUMPS];   // jump_refinement_grid nodes
@@ -172,7 +179,8 @@ VAG_DEV bool quad_step(Dopri5<1>& s, Stages& stages) {
 // Dense output of the buffered steps at the samples they passed: sample kk belongs to the first step whose end exceeds
 // xs[kk] (`current_time() > x`, grid-refinement.h:150-158); one sample per lane, same arithmetic per sample as the serial sweep.
 // Returns the index of the first sample not yet passed.
-VAG_DEV int flush_quad_steps(GridShared& sh, int n_rec, int k) {
+template <class SH>
+VAG_DEV int flush_quad_steps(SH& sh, int n_rec, int k) {
     const int lane = threadIdx.x;
     if (n_rec == 0) return k;
     const double t_end = sh.rec[1][n_rec - 1];
@@ -215,8 +223,8 @@ VAG_DEV int flush_quad_steps(GridShared& sh, int n_rec, int k) {
 // pdf0 = pdf(lo) (wave-uniform); stages(tx[5], kv[5]) returns the wave-uniform pdf at five abscissae.
 // The dense output is off the stepping chain: accepted steps are buffered in LDS (nine doubles each) and interpolated at the
 // samples they passed afterwards, one sample per lane.
-template <class Stages>
-VAG_DEV void integrate_cdf(GridShared& sh, double pdf0, Stages& stages, double lo, double hi) {
+template <class SH, class Stages>
+VAG_DEV void integrate_cdf(SH& sh, double pdf0, Stages& stages, double lo, double hi) {
     const int lane = threadIdx.x;
     for (int k = lane; k < N_SAMPLES; k += WAVE) sh.cdf[k] = 0;
     __syncthreads();
@@ -263,7 +271,8 @@ VAG_DEV void integrate_cdf(GridShared& sh, double pdf0, Stages& stages, double l
 }
 
 // x_out[k] for CDF quantiles (grid-refinement.h:163-188); lanes split k.  out may alias nothing in sh.xs/cdf.
-VAG_DEV void invert_cdf(const GridShared& sh, int num, bool midpoint, double* out) {
+template <class SH>
+VAG_DEV void invert_cdf(const SH& sh, int num, bool midpoint, double* out) {
     const double front = sh.cdf[0], back = sh.cdf[N_SAMPLES - 1];
     for (int k = threadIdx.x; k < num; k += WAVE) {
         const double target = midpoint ? front + (back - front) * ((double)k + 0.5) / num : linspace_at(front, back, num, k);
@@ -394,8 +403,9 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
 
 // The adaptive grid of model m = blockIdx.x, by one wavefront.
 // tminmax[0..1]: min / max of the requested observer times [s] (device memory).
+template <class SH>
 VAG_DEV void
-grid_model(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
+grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* __restrict__ meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
                 double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
@@ -404,7 +414,6 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
     const int m = blockIdx.x;
     const int lane = threadIdx.x;
     if (m == 0 && lane < 4) fail[lane] = 0;
-    __shared__ GridShared sh;
     const vag_model_params P = params[m];
     const double t_min_s = tminmax[0], t_max_s = tminmax[1];
     if (!params_valid(P)) {  // the reference raises ValueError; batched walkers get status != 0 (-> NaN / -inf)
@@ -611,7 +620,7 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
         const double tl = theta_v - theta_min, tr = theta_max - theta_v;
         const double view_cdf = 0.5 * (log(1.0 + Gv2 * tl * tl) + log(1.0 + Gv2 * tr * tr));
         const double view_weight = (view_pts > 0 && view_cdf > 0) ? (double)view_pts / base_pts * CDF_est / view_cdf : 0.0;
-        if (total_pts > VAG_MAX_THETA - 3 * VAG_MAX_JUMPS) {
+        if (total_pts > SH::max_theta - 3 * VAG_MAX_JUMPS) {
             M.status = VAG_E_CAPACITY;
             if (lane == 0) meta[m] = M;
             return;
@@ -750,7 +759,7 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
         }
         const bool uniform = (!mirror && phi_num <= 2) || (theta_v == 0 && axisym);
         if (uniform) {
-            if (phi_num > VAG_MAX_PHI) {
+            if (phi_num > SH::max_phi) {
                 M.status = VAG_E_CAPACITY;
                 if (lane == 0) meta[m] = M;
                 return;
@@ -806,7 +815,7 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
                 boost = boost < 1.0 ? 1.0 : (boost_cap < boost ? boost_cap : boost);
                 phi_num = (size_t)((double)phi_num * boost);
             }
-            if (phi_num > VAG_MAX_PHI) {
+            if (phi_num > SH::max_phi) {
                 M.status = VAG_E_CAPACITY;
                 if (lane == 0) meta[m] = M;
                 return;
@@ -1008,6 +1017,7 @@ grid_model(const vag_model_params* __restrict__ params, int nb, const double* __
 
 // One wavefront (blockDim.x == 64) per model; the last wavefront to finish also lays the batch out (plan_scan_wave): no
 // separate launch, no host round trip between the grids and the stages that depend on their sizes.
+template <bool LARGE>
 __global__ void __launch_bounds__(WAVE)
 vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
@@ -1016,7 +1026,10 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 int* __restrict__ done_counter /* zero between launches */, int* __restrict__ row_off,
                 long long* __restrict__ cell_off, VagDevPlan* __restrict__ plan, VagDevPlan* host_plan, int seq, int cap_rows,
                 long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn) {
-    if ((int)blockIdx.x < nb) grid_model(params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail);
+    using Shared = typename std::conditional<LARGE, GridSharedT<VAG_MAX_THETA, VAG_MAX_PHI>, GridSharedT<VAG_GRID_THETA, VAG_GRID_PHI>>::type;
+    __shared__ Shared sh;  // declared here, not in grid_model: LDS of a device function is charged to every kernel of the module
+    if ((int)blockIdx.x < nb)
+        grid_model<Shared>(sh, params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail);
     __shared__ int s_last;
     __threadfence();  // this model's results are visible device-wide before the ticket is taken
     __syncthreads();
