@@ -925,7 +925,6 @@ static int flux_ks(const vag_ctx* c) {
 static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
     const size_t slots = (size_t)nt * nnu;
     size_t d = (size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + 2 * (size_t)nt + nnu + SP_LDS_DOUBLES + slots;
-    if (mode == FLUX_SYN_IC || mode == FLUX_FUSED) d += (size_t)VAG_NQ * ks;
     if (mode == FLUX_FUSED) d += 6 * (size_t)ks + (size_t)ks * nnu + slots;
     return sizeof(double) * d + sizeof(int) * nt;
 }
@@ -997,6 +996,19 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         // (+47 % on the C5 / C1b shapes; a 128-lane variant measured slower)
         const bool small = !spreading && !a.work_count && (long long)nt * nnu <= 512 && (long long)ks * ((nnu + 1) / 2) <= 512 &&
                            !std::getenv("VAG_FLUX_WIDE");
+        if (std::getenv("VAG_DEBUG_LAUNCH")) {
+            int occ = -1;
+            if (small && mode == FLUX_SSC)
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_grid_kernel<false, FLUX_SSC, false, 256>, 256, lds);
+            else if (small && mode == FLUX_SYN_IC)
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_grid_kernel<false, FLUX_SYN_IC, false, 256>, 256, lds);
+            else if (small)
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_grid_kernel<false, FLUX_SYN, false, 256>, 256, lds);
+            else if (mode == FLUX_SYN && !spreading)
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_grid_kernel<false, FLUX_SYN>, FLUX_THREADS, lds);
+            std::fprintf(stderr, "[vag] grid flux launch: mode %d nt=%d nnu=%d ks=%d rows/wg=%d lanes=%d lds=%zu B wg/CU=%d\n", mode, nt, nnu, ks,
+                         ppb, small ? 256 : FLUX_THREADS, lds, occ);
+        }
         if (small && mode == FLUX_FUSED)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
         else if (spreading && mode == FLUX_FUSED)

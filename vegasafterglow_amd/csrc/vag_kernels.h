@@ -648,9 +648,12 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_nu = s_tobs + nt;              // [nnu]
     double* s_w = s_nu + nnu;                // [nt] fractional position of each requested time inside its interval
     double* s_acc = s_w + nt;                // [nnu*nt] this workgroup's partial grid (each lane owns fixed slots)
-    double* s_q = s_acc + slots;             // [KS][FLUX_NQ] IC-correction constants (FLUX_SYN_IC / FLUX_FUSED)
+    double* s_q = s_acc + slots;             // end of the common part
+    // The 14 IC-correction constants of a cell (FLUX_SYN_IC / FLUX_FUSED) are read from L2 where an evaluation lies above the
+    // cooling break, not staged: 14 x KS doubles less LDS is one more resident workgroup per CU on the C5 and C3 shapes
+    // (27.5 -> 23.9 ms and 11.8 -> 9.8 ms per synchrotron pass).
     constexpr bool HAS_Q = MODE == FLUX_SYN_IC || MODE == FLUX_FUSED;
-    double* s_hdr = s_q + (HAS_Q ? FLUX_NQ * KS : 0);                 // FLUX_FUSED: [KS][6] SSC table headers
+    double* s_hdr = s_q;                                              // FLUX_FUSED: [KS][6] SSC table headers
     double* s_B2 = s_hdr + (MODE == FLUX_FUSED ? 6 * KS : 0);         // FLUX_FUSED: [nnu][KS] SSC boundary values
     double* s_acc2 = s_B2 + (MODE == FLUX_FUSED ? (size_t)KS * nnu : 0);  // FLUX_FUSED: [nnu*nt] SSC partial grid
     int* s_kidx = (int*)(s_acc2 + (MODE == FLUX_FUSED ? slots : 0));  // [nt]
@@ -726,14 +729,6 @@ vag_flux_grid_kernel(FluxArgs a) {
                 for (int q = tid; q < 5 * K; q += THREADS) {
                     const int kk = q / 5, w = q - kk * 5;
                     s_hdr[kk * 6 + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
-                }
-            }
-            if constexpr (HAS_Q) {
-                const double* srcq = a.cellq + (a.cell_off[m] + (long long)rep * K_all) * FLUX_NQ + k0;
-#pragma unroll 1
-                for (int q = tid; q < FLUX_NQ * K; q += THREADS) {
-                    const int par = (int)(((float)q + 0.5f) / (float)K);
-                    s_q[(q - par * K) * FLUX_NQ + par] = srcq[(size_t)par * K_all + (q - par * K)];
                 }
             }
             staged_rep = rep;
@@ -865,9 +860,9 @@ vag_flux_grid_kernel(FluxArgs a) {
                     b0 = log2_I_nu_fast(regs, 1, sc, s_nu[l0] - dop, sp_tab);
                     b1 = log2_I_nu_fast(regs, 1, sc, s_nu[l1] - dop, sp_tab);
                 } else if constexpr (HAS_Q) {
-                    const double* cq = s_q + __mul24(k, FLUX_NQ);
-                    b0 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l0] - dop, sp_tab);
-                    b1 = log2_I_nu_ic(cp, 1, cq, 1, sc, s_nu[l1] - dop, sp_tab);
+                    const double* cq = a.cellq + (a.cell_off[m] + (long long)staged_rep * K_all) * FLUX_NQ + k0 + k;
+                    b0 = log2_I_nu_ic(cp, 1, cq, K_all, sc, s_nu[l0] - dop, sp_tab);
+                    b1 = log2_I_nu_ic(cp, 1, cq, K_all, sc, s_nu[l1] - dop, sp_tab);
                     if constexpr (MODE == FLUX_FUSED) {
                         const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                         const double* hp = s_hdr + __mul24(k, 6);
@@ -1004,7 +999,8 @@ constexpr int SERIES_CHUNK = 8;       // (theta, phi) rows per partial sum: the 
 constexpr int SERIES_MAX_BANDS = 8;   // distinct frequencies the shared-node path handles
 // doubles of LDS one series wavefront owns (kept even: the cell blocks are read with 16-byte loads)
 __host__ __device__ inline int series_region_doubles(int ks, bool ic, int n_bands) {
-    return ((VAG_NPAR + 3 + (ic ? 14 : 0) + n_bands) * ks + 1) & ~1;
+    (void)ic;  // the IC-correction constants are read from L2, not staged
+    return ((VAG_NPAR + 3 + n_bands) * ks + 1) & ~1;
 }
 
 // LDS produced and consumed by the same wavefront: program order suffices in hardware, the fence keeps the compiler from
@@ -1118,8 +1114,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     double* s_t = s_par + VAG_NPAR * KS;
     double* s_dop = s_t + KS;
     double* s_geom = s_dop + KS;
-    double* s_q = s_geom + KS;  // [KS][FLUX_NQ], FLUX_SYN_IC only
-    double* s_Bw = s_q + (MODE == FLUX_SYN_IC ? FLUX_NQ * KS : 0);  // [n_bands][KS] boundary values of the shared-node path
+    double* s_Bw = s_geom + KS;  // [n_bands][KS] boundary values of the shared-node path
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     int breach = 0;
 
@@ -1226,17 +1221,12 @@ vag_flux_series_kernel(SeriesArgs a) {
                     }
                 }
             }
-            if (MODE == FLUX_SYN_IC) {
-                const double* srcq = a.cellq + (a.lay.cell_off[m] + (long long)rep * K_all) * FLUX_NQ + k0;
-                for (int q = tid; q < FLUX_NQ * K; q += SERIES_THREADS) {
-                    const int par = (int)(((float)q + 0.5f) / (float)K), k = q - par * K;
-                    s_q[k * FLUX_NQ + par] = srcq[(size_t)par * K_all + k];
-                }
-            }
             staged_rep = rep;
             wave_sync();
         }
         VAG_SER_MARK(c_stage);
+        // IC-correction constants of the row's cells, read from L2 where an evaluation lies above the cooling break (FLUX_SYN_IC)
+        const double* cq_row = MODE == FLUX_SYN_IC ? a.cellq + (a.lay.cell_off[m] + (long long)rep * K_all) * FLUX_NQ + k0 : nullptr;
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.lay.cell_off[m] + (long long)rep * K_all) * 3 + k0;
             eat_row_spread(s_par, KS, K, tid, SERIES_THREADS, geo, lane_value(g_a, gl), sin_obs, cos_obs, lane_value(g_c, gl),
@@ -1282,7 +1272,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                     if (MODE == FLUX_SYN) {
                         v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                     } else if (MODE == FLUX_SYN_IC) {
-                        v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
+                        v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, cq_row + kk, K_all, sc, x, sp_tab);
                     } else {
                         const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
                         v = ic_table_eval(tab, x, &breach);
@@ -1329,7 +1319,7 @@ vag_flux_series_kernel(SeriesArgs a) {
                         if (MODE == FLUX_SYN) {
                             v = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(kk, VAG_NPAR / 2)), 1, sc, x, sp_tab);  // seven 16-byte reads
                         } else if (MODE == FLUX_SYN_IC) {
-                            v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, s_q + kk * FLUX_NQ, 1, sc, x, sp_tab);
+                            v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, cq_row + kk, K_all, sc, x, sp_tab);
                         } else {
                             const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
                             v = ic_table_eval(tab, x, &breach);
@@ -1361,8 +1351,8 @@ vag_flux_series_kernel(SeriesArgs a) {
                         blo = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(k, VAG_NPAR / 2)), 1, sc, nuq[q] - s_dop[k], sp_tab);
                         bhi = log2_I_nu_fast(load_spec_regs(lds_tab(s_par) + __mul24(k + 1, VAG_NPAR / 2)), 1, sc, nuq[q] - s_dop[k + 1], sp_tab);
                     } else if (MODE == FLUX_SYN_IC) {
-                        blo = log2_I_nu_ic(s_par + k * VAG_NPAR, 1, s_q + k * FLUX_NQ, 1, sc, nuq[q] - s_dop[k], sp_tab);
-                        bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, s_q + (k + 1) * FLUX_NQ, 1, sc, nuq[q] - s_dop[k + 1],
+                        blo = log2_I_nu_ic(s_par + k * VAG_NPAR, 1, cq_row + k, K_all, sc, nuq[q] - s_dop[k], sp_tab);
+                        bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, cq_row + (k + 1), K_all, sc, nuq[q] - s_dop[k + 1],
                                            sp_tab);
                     } else {
                         const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + k) * FLUX_IC_STRIDE;
