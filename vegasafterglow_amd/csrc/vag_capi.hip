@@ -1157,6 +1157,7 @@ static bool fused_fits(vag_ctx* c, int nt, int nnu) {
     // workgroups per CU instead of three) and the fused pass measured 18 % SLOWER than two passes there
     const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, flux_ks(c), nt, nnu),
                  two = flux_grid_lds_bytes(FLUX_SYN_IC, flux_ks(c), nt, nnu);
+    if (std::getenv("VAG_FORCE_FUSED")) return fused <= cu;
     return fused <= cu && std::min<size_t>(cu / fused, 4) >= std::min<size_t>(cu / two, 4);
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,

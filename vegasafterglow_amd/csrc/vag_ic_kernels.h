@@ -631,22 +631,27 @@ VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* brea
 VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
                                  double th_max, double x, int* breach) {
     const int n = (int)h_n;
-    if (n < 2) return -INFINITY;
     // lattice node q = phase + IC_Q * (idx0 + 2 q): idx0 + 2 q is an integer far below 2^53, so it is formed in double
     // (exactly the value the reference converts from its integer) -- no 64-bit integer conversions in this hot evaluator
     auto node = [&](int q) { return phase + IC_Q * (h_idx0 + 2.0 * (double)q); };
     const double first = node(0), last = node(n - 1);
-    if ((x > last && x < th_max) || (x < first && x > th_min)) *breach = 1;
-    if (x > last) return -INFINITY;
+    const bool empty = n < 2;
+    if (!empty && ((x > last && x < th_max) || (x < first && x > th_min))) *breach = 1;
+    // Straight-line from here (no early return before the table reads): the reads of the evaluations a work item makes are
+    // in flight together, which is what this L2-latency-bound evaluator lives on (C5 SSC pass 22.9 -> 17.8 ms per 256 models).
     int idx = (int)floor((x - first) * (1.0 / (2 * IC_Q)));
-    idx = idx < 0 ? 0 : (idx > n - 2 ? n - 2 : idx);
-    while (idx + 2 < n && node(idx + 1) <= x) ++idx;  // settle exactly like the reference's forward scan
-    while (idx > 0 && node(idx) > x) --idx;
+    const int top = n - 2 > 0 ? n - 2 : 0;
+    idx = idx < 0 ? 0 : (idx > top ? top : idx);
+    // settle exactly where the reference's forward scan stops (the largest node <= x): the estimate is off by at most one node
+    // (the lattice is exact to rounding), so one step each way does it
+    idx += (idx + 2 < n && node(idx + 1) <= x) ? 1 : 0;
+    idx -= (idx > 0 && node(idx) > x) ? 1 : 0;
     const double Ilo = tab[IC_HDR + idx], Ihi = tab[IC_HDR + idx + 1];
     const double n_lo = node(idx);
     const double dl = node(idx + 1) - n_lo;
     const double slope = dl != 0 ? (Ihi - Ilo) * rcp_fast(dl) : 0;  // dl ~ 2 IC_Q: finite, normal
-    return Ilo + (x - n_lo) * slope;
+    const double v = Ilo + (x - n_lo) * slope;
+    return (empty || x > last) ? -INFINITY : v;
 }
 
 }  // namespace vag
