@@ -1009,7 +1009,27 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
             std::fprintf(stderr, "[vag] grid flux launch: mode %d nt=%d nnu=%d ks=%d rows/wg=%d lanes=%d lds=%zu B wg/CU=%d\n", mode, nt, nnu, ks,
                          ppb, small ? 256 : FLUX_THREADS, lds, occ);
         }
-        if (small && mode == FLUX_FUSED)
+        const bool pieces = c->max_k > ks;  // some lattice is longer than the staged row: the instantiations with the piece loop
+        if (pieces) {
+            a.work_count = nullptr;  // the tallying instantiation has no piece loop: the plan keeps the upper bounds
+            const dim3 g(max_blocks, nb), b(FLUX_THREADS);
+#define VAG_PIECES_LAUNCH(M_)                                                                                          \
+    do {                                                                                                               \
+        if (spreading)                                                                                                 \
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, M_, true, FLUX_THREADS, true>), g, b, lds, st, a);          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((vag_flux_grid_kernel<false, M_, false, FLUX_THREADS, true>), g, b, lds, st, a);         \
+    } while (0)
+            if (mode == FLUX_FUSED)
+                VAG_PIECES_LAUNCH(FLUX_FUSED);
+            else if (mode == FLUX_SYN_IC)
+                VAG_PIECES_LAUNCH(FLUX_SYN_IC);
+            else if (mode == FLUX_SSC)
+                VAG_PIECES_LAUNCH(FLUX_SSC);
+            else
+                VAG_PIECES_LAUNCH(FLUX_SYN);
+#undef VAG_PIECES_LAUNCH
+        } else if (small && mode == FLUX_FUSED)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED, false, 256>), dim3(max_blocks, nb), dim3(256), lds, st, a);
         else if (spreading && mode == FLUX_FUSED)
             hipLaunchKernelGGL((vag_flux_grid_kernel<false, FLUX_FUSED, true>), dim3(max_blocks, nb), dim3(FLUX_THREADS), lds, st, a);

@@ -616,7 +616,9 @@ vag_eat_details_kernel(const vag_model_params* __restrict__ params, const VagGri
 // 128 VGPRs (four workgroups of 256, two of 512 per CU) is what the occupancy of every measured shape hangs on: the C2 launch asks
 // for 80 KB of LDS, two workgroups per CU, and a 136-VGPR scratch-free build of this kernel (launch bound 1) leaves ONE resident:
 // 39.3 ms instead of 24.0 ms per 512 models.  The few spilled values (36 B per lane) sit outside the inner loops.
-template <bool COUNT, int MODE, bool SPREAD = false, int THREADS = FLUX_THREADS>
+// PIECES: some lattice of the batch is longer than the staged row (see K_all below); the loop over pieces costs the C2 shape
+// 3 % when it is compiled in, so the one-piece form is its own instantiation.
+template <bool COUNT, int MODE, bool SPREAD = false, int THREADS = FLUX_THREADS, bool PIECES = false>
 __global__ void __launch_bounds__(THREADS, 4)
 vag_flux_grid_kernel(FluxArgs a) {
     const int m = blockIdx.y;
@@ -632,7 +634,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     // time falls into exactly one piece's [first node, last node), the window / bracket / boundary-spectra steps are the same
     // per piece, and the accumulators stay in LDS across pieces.  K_all <= KS (every default-resolution model) is one piece.
     const int K_all = Mp->n_t, KS = a.k_stride;
-    const int n_pieces = K_all <= KS ? 1 : (K_all - 1 + KS - 2) / (KS - 1);
+    const int n_pieces = (!PIECES || K_all <= KS) ? 1 : (K_all - 1 + KS - 2) / (KS - 1);
     int K = min(K_all, KS), k0 = 0;
     const int nt = a.nt, nnu = a.nnu;
     const int slots = nt * nnu;
@@ -1078,7 +1080,7 @@ VAG_DEV int series_bracket(const double* __restrict__ s_t, int K, double t, int 
 // GRID: the kernel serves a small (nu, t) grid (SeriesArgs::grid_nt); a compile-time switch so that the fit instantiations do not
 // carry its registers.
 template <int MODE, bool SPREAD = false, int NSLOT = SERIES_MAX_SLOTS, bool GRID = false>
-__global__ void __launch_bounds__(SERIES_THREADS * SERIES_WAVES)
+__global__ void __launch_bounds__(SERIES_THREADS * SERIES_WAVES)  // (a 128-VGPR cap spills and measured 12 % slower on the C4 fit)
 vag_flux_series_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;  // `tid`: lane inside this row's wavefront
