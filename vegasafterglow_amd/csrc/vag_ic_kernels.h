@@ -164,24 +164,50 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
 
 // IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92).  `c`/`st` address the
 // 18-parameter block, `qv`/`qst` the IC extras of the same cell.  log2((1+Y_c)/(1+Y(nu))) = log2(1+Y_c) - sp(log2 Y).
-template <class P1, class P2, class Tab>
-VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp) {
+// The cell's IC constants are requested in two batches -- (nu_c, has-IC) decide whether the correction applies; the other twelve
+// are loaded together, not one per comparison, when it does -- so that an evaluation above the cooling break pays two memory
+// round trips, not five (the constants come from L2 in the flux kernels).
+struct IcQ {
+    double lg2_nuc, has;
+    double l1pyc, lg2_kb, nseg, c0, s0, l1, c1, s1, l2, c2, s2;
+    template <class P2>
+    VAG_DEV void head(const P2 qv, int qst) {
+        lg2_nuc = qv[VQ_LG2_NUC * qst];
+        has = qv[VQ_HASIC * qst];
+    }
+    template <class P2>
+    VAG_DEV void rest(const P2 qv, int qst) {
+        l1pyc = qv[VQ_L1PYC * qst], lg2_kb = qv[VQ_LG2_KB * qst], nseg = qv[VQ_NSEG * qst];
+        c0 = qv[VQ_C0 * qst], s0 = qv[VQ_S0 * qst];
+        l1 = qv[VQ_L1 * qst], c1 = qv[VQ_C1 * qst], s1 = qv[VQ_S1 * qst];
+        l2 = qv[VQ_L2 * qst], c2 = qv[VQ_C2 * qst], s2 = qv[VQ_S2 * qst];
+    }
+    VAG_DEV bool applies(double lg2_nu) const { return lg2_nu > lg2_nuc && has != 0.0; }
+};
+
+// log2((1+Y_c)/(1+Y(nu))) = log2(1+Y_c) - sp(log2 Y) for an evaluation above the cooling break (q.rest loaded)
+template <class Tab>
+VAG_DEV double ic_thin_correction(const IcQ& q, double lg2_nu, Tab sp) {
+    const double lg = 0.5 * (lg2_nu + q.lg2_kb);  // log2 gamma of the electrons radiating at nu
+    const int n = (int)q.nseg;
+    double z = q.c0 + q.s0 * lg;
+    if (n > 2 && lg >= q.l2)
+        z = q.c2 + q.s2 * lg;
+    else if (n > 1 && lg >= q.l1)
+        z = q.c1 + q.s1 * lg;
+    // log2(1 + 2^z) without the reference's +-20 softplus shortcut (this term is an exact log2 there)
+    const double a = fabs(z);
+    const double g = a > 20.0 ? exp2_sat(-a) * LOG2E : (sp_fast(-a, sp));
+    return q.l1pyc - (0.5 * (z + a) + g);
+}
+
+// IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92) given the thin-branch correction
+template <class P1, class Tab>
+VAG_DEV double log2_I_nu_ic_core(const P1 c, int st, bool corrected, const IcQ& q, const SpecConst& sc, double lg2_nu, Tab sp) {
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
     double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
                   sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];
-    if (lg2_nu > qv[VQ_LG2_NUC * qst] && qv[VQ_HASIC * qst] != 0.0) {
-        const double lg = 0.5 * (lg2_nu + qv[VQ_LG2_KB * qst]);  // log2 gamma of the electrons radiating at nu
-        const int n = (int)qv[VQ_NSEG * qst];
-        double z = qv[VQ_C0 * qst] + qv[VQ_S0 * qst] * lg;
-        if (n > 2 && lg >= qv[VQ_L2 * qst])
-            z = qv[VQ_C2 * qst] + qv[VQ_S2 * qst] * lg;
-        else if (n > 1 && lg >= qv[VQ_L1 * qst])
-            z = qv[VQ_C1 * qst] + qv[VQ_S1 * qst] * lg;
-        // log2(1 + 2^z) without the reference's +-20 softplus shortcut (this term is an exact log2 there)
-        const double a = fabs(z);
-        const double g = a > 20.0 ? exp2_sat(-a) * LOG2E : (sp_fast(-a, sp));
-        thin += qv[VQ_L1PYC * qst] - (0.5 * (z + a) + g);
-    }
+    if (corrected) thin += ic_thin_correction(q, lg2_nu, sp);
     const double lx = lg2_nu - c[VP_LG2_NUM * st];
     double thick = 2.5 * lx;
     if (!(lx > sc.log2_x_far)) {
@@ -193,6 +219,28 @@ VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const Spec
     const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
+}
+
+// `c`/`st` address the 18-parameter block, `qv`/`qst` the IC extras of the same cell.
+template <class P1, class P2, class Tab>
+VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp) {
+    IcQ q;
+    q.head(qv, qst);
+    const bool corrected = q.applies(lg2_nu);
+    if (corrected) q.rest(qv, qst);
+    return log2_I_nu_ic_core(c, st, corrected, q, sc, lg2_nu, sp);
+}
+
+// two frequencies on one cell (a work item of the grid flux kernel): the constants are loaded once for both
+template <class P1, class P2, class Tab>
+VAG_DEV void log2_I_nu_ic_pair(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double x0, double x1, Tab sp, double& b0,
+                               double& b1) {
+    IcQ q;
+    q.head(qv, qst);
+    const bool corr0 = q.applies(x0), corr1 = q.applies(x1);
+    if (corr0 || corr1) q.rest(qv, qst);
+    b0 = log2_I_nu_ic_core(c, st, corr0, q, sc, x0, sp);
+    b1 = log2_I_nu_ic_core(c, st, corr1, q, sc, x1, sp);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -511,6 +511,9 @@ constexpr int FLUX_FUSED = 3;   // FLUX_SYN_IC and FLUX_SSC in one pass: EAT log
 
 template <class P1, class P2, class Tab>
 VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp);
+template <class P1, class P2, class Tab>
+VAG_DEV void log2_I_nu_ic_pair(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double x0, double x1, Tab sp, double& b0,
+                               double& b1);
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
 VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
                                  double th_max, double x, int* breach);
@@ -863,8 +866,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                     b1 = log2_I_nu_fast(regs, 1, sc, s_nu[l1] - dop, sp_tab);
                 } else if constexpr (HAS_Q) {
                     const double* cq = a.cellq + (a.cell_off[m] + (long long)staged_rep * K_all) * FLUX_NQ + k0 + k;
-                    b0 = log2_I_nu_ic(cp, 1, cq, K_all, sc, s_nu[l0] - dop, sp_tab);
-                    b1 = log2_I_nu_ic(cp, 1, cq, K_all, sc, s_nu[l1] - dop, sp_tab);
+                    log2_I_nu_ic_pair(cp, 1, cq, K_all, sc, s_nu[l0] - dop, s_nu[l1] - dop, sp_tab, b0, b1);
                     if constexpr (MODE == FLUX_FUSED) {
                         const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                         const double* hp = s_hdr + __mul24(k, 6);
