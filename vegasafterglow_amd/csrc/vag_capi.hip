@@ -323,7 +323,7 @@ struct vag_ctx {
     // compact per-row / per-cell storage
     DevBuf d_row_off, d_cell_off, d_shock, d_cellpar, d_row_status, d_celldet, d_partial;
     // fit spec cache (upload_fit_spec): content hash of what d_fit holds, its size, where the prior block starts
-    DevBuf d_fit, d_theta_in, d_slot, d_valid, d_series_flux, d_chi2, d_bandobs, d_fitstat;
+    DevBuf d_fit, d_theta_in, d_valid, d_series_flux, d_chi2, d_bandobs, d_fitstat;
     HostBuf h_fit;
     uint64_t fit_hash = 0;
     size_t fit_doubles = 0, fit_prior_off = 0;
@@ -517,7 +517,7 @@ void vag_ctx_destroy(vag_ctx* c) {
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
-                      &c->d_fit, &c->d_theta_in, &c->d_slot, &c->d_valid, &c->d_series_flux})
+                      &c->d_fit, &c->d_theta_in, &c->d_valid, &c->d_series_flux})
         b->release();
     c->h_meta.release();
     c->h_off.release();
@@ -2221,8 +2221,8 @@ vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, in
     }
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    vag_model_params p = base;
-    double* f = &p.theta_c;
+    out[b] = base;  // the sampled fields are patched in place (a private copy indexed by slot would live in scratch)
+    double* f = &out[b].theta_c;
     double av = a_v_fixed, lp = 0;
     bool inside = true;
     for (int d = 0; d < ndim; ++d) {
@@ -2247,10 +2247,9 @@ vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, in
             f[slot[d]] = val;
     }
     if (!inside) {  // never evaluated by the reference either: an invalid parameter set stops at the grid stage with no work
-        p.theta_c = NAN;
+        out[b].theta_c = NAN;
         lp = -INFINITY;
     }
-    out[b] = p;
     a_v[b] = av;
     ln_prior[b] = use_priors ? lp : 0.0;
 }

@@ -20,19 +20,27 @@ struct Bpl {
         lg2_lower[0] = ll;
         lg2_const[0] = log2(norm) - sl * ll;
     }
+    // (constant indices throughout: with a running index the three small arrays live in scratch memory, 168 B per lane of
+    // vag_ic_cooling_kernel, and every evaluation of Y(gamma) in its fixed-point loops went through it)
     VAG_DEV void add(double lower, double sl) {
         const double ll = log2(lower);
-        const int p = size - 1;
-        const double val = lg2_const[p] + slope[p] * ll;
-        slope[size] = sl;
-        lg2_lower[size] = ll;
-        lg2_const[size] = val - sl * ll;
+        if (size == 1) {
+            const double val = lg2_const[0] + slope[0] * ll;
+            slope[1] = sl;
+            lg2_lower[1] = ll;
+            lg2_const[1] = val - sl * ll;
+        } else {
+            const double val = lg2_const[1] + slope[1] * ll;
+            slope[2] = sl;
+            lg2_lower[2] = ll;
+            lg2_const[2] = val - sl * ll;
+        }
         ++size;
     }
     VAG_DEV double eval(double x) const {
         const double lx = log2(x);
-        for (int i = size - 1; i > 0; --i)
-            if (lx >= lg2_lower[i]) return exp2(lg2_const[i] + slope[i] * lx);
+        if (size > 2 && lx >= lg2_lower[2]) return exp2(lg2_const[2] + slope[2] * lx);
+        if (size > 1 && lx >= lg2_lower[1]) return exp2(lg2_const[1] + slope[1] * lx);
         return size > 0 ? exp2(lg2_const[0] + slope[0] * lx) : 0.0;
     }
 };
@@ -186,6 +194,7 @@ VAG_DEV void icy_store(const IcY& y, double* base, long long n_cells, long long 
     base[VY_YT * n_cells + c] = y.Y_T;
     base[VY_B * n_cells + c] = y.B_;
     base[VY_NSEG * n_cells + c] = (double)y.seg.size;
+#pragma unroll
     for (int s = 0; s < 3; ++s) {
         base[(VY_S0 + 3 * s) * n_cells + c] = s < y.seg.size ? y.seg.slope[s] : 0;
         base[(VY_L0 + 3 * s) * n_cells + c] = s < y.seg.size ? y.seg.lg2_lower[s] : INFINITY;

@@ -1406,20 +1406,4 @@ vag_loglike_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const d
     if (threadIdx.x == 0) out[m] = (valid[m] && isfinite(chi2)) ? -0.5 * chi2 : -INFINITY;
 }
 
-// Transformer of fitting/utils.py:110-135 on the device: theta[nb][ndim] -> params[nb]
-__global__ void vag_transform_kernel(vag_model_params base, const double* __restrict__ theta, int nb, int ndim,
-                                     const int* __restrict__ slot, const int* __restrict__ is_log,
-                                     vag_model_params* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    vag_model_params p = base;
-    double* f = &p.theta_c;
-    for (int d = 0; d < ndim; ++d) {
-        if (slot[d] == VAG_P_A_V) continue;  // not a Model field (scales the point-data fluxes, see vag_av_kernel)
-        const double v = theta[(size_t)b * ndim + d];
-        f[slot[d]] = is_log[d] ? pow(10.0, v) : v;
-    }
-    out[b] = p;
-}
-
 }  // namespace vag
