@@ -481,6 +481,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     }
     for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_sat(lg2_g0 + step * (double)i);
     __syncthreads();
+#ifdef VAG_IC_ABLATE
+    if (VAG_IC_ABLATE >= 4) { tab[0] = 0; return; }  // prologue only: loads, lattice parameters, lattice nodes
+#endif
     // sample_distributions, inverse-compton.h:371-399
     const double* par = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
     const double* qv = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
@@ -499,6 +502,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         sh.lg2fv[j] = f > 0 ? log2_fast(f) : -INFINITY;
     }
     __syncthreads();
+#ifdef VAG_IC_ABLATE
+    if (VAG_IC_ABLATE >= 3) { tab[0] = 0; return; }  // ... + the sampled electron and seed distributions
+#endif
     const int nu_last = nu_size - 1;
     for (int j = lane; j < nu_last; j += 64) {
         sh.dnu[j] = sh.nu[j + 1] - sh.nu[j];
