@@ -12,9 +12,13 @@
  *  - all physical inputs are in the reference's user units (CGS: erg, cm, s, Hz, rad);
  *    flux densities come back in erg cm^-2 s^-1 Hz^-1, band fluxes in erg cm^-2 s^-1
  *    (pybind/pymodel.cpp:368-371,506-508).
- *  - the *_dev entry points take DEVICE pointers (HBM resident inputs/outputs) and run
- *    asynchronously on the context's HIP stream; the host-pointer forms stage through
- *    the context's buffers and synchronise before returning.
+ *  - the *_dev entry points take DEVICE pointers (HBM resident inputs/outputs) and are
+ *    ordered on the context's HIP stream.  They are not fire-and-forget: the host waits
+ *    (spinning on a pinned, coherent summary the grid kernel's last wavefront publishes --
+ *    no copy, no stream synchronisation) for the batch's layout before it can size the
+ *    later launches, and returns with those launches queued; results are complete when
+ *    the stream reaches that point.  The host-pointer forms stage through the context's
+ *    buffers and synchronise before returning.
  *  - there is no CPU fallback: without a HIP device vag_ctx_create fails with
  *    VAG_E_NO_DEVICE.
  */
@@ -210,7 +214,7 @@ int vag_flux_components_batch(vag_ctx* ctx, const vag_model_params* params, int 
 int vag_flux_components4_batch(vag_ctx* ctx, const vag_model_params* params, int nb, const double* t, int nt,
                                double nu_min, double nu_max, int num_nu, double* const* out4);
 
-/* Device-pointer forms: params/t/nu/out are HBM addresses; asynchronous on the context stream. */
+/* Device-pointer forms: params/t/nu/out are HBM addresses; stream-ordered on the context stream (see the note at the top). */
 int vag_flux_density_grid_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,
                                     int nt, const double* d_nu, int nnu, double* d_out);
 int vag_flux_density_batch_dev(vag_ctx* ctx, const vag_model_params* d_params, int nb, const double* d_t,
