@@ -124,6 +124,36 @@ def test_config4_two_component_ssc_ensemble_512_members(eng, oracle):
     np.testing.assert_allclose(out[:8] / o8, 4.0, rtol=1e-12)
 
 
+def test_config4_at_the_full_4096_members(eng, oracle):
+    """configs[4] at the size BASELINE.json names: 4096 members of the two-component SSC sweep in one call (0.9 M SSC tables, 67 M
+    (theta, phi) rows).  Size-independent properties: every flux finite and non-negative, the first 64 members equal a 64-member
+    call to summation rounding, members at the far end of the batch against the oracle."""
+    from ssc_ensemble import c5_batch
+    lib, h = eng
+    n = 4096
+    prms = c5_batch(n)
+    t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
+    arr = (_lib.ModelParams * n)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    out = np.empty((n, nu.size, t.size))
+    _lib.check(lib.vag_flux_density_grid_batch(h, arr, n, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size,
+                                               out.ctypes.data_as(dp)))
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_ok == n and pl.n_models_ssc_rebuilt == 0
+    assert np.all(np.isfinite(out)) and np.all(out >= 0) and out[:, :3].min() > 0
+    head = np.empty((64, nu.size, t.size))
+    sub = (_lib.ModelParams * 64)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms[:64]])
+    _lib.check(lib.vag_flux_density_grid_batch(h, sub, 64, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size,
+                                               head.ctypes.data_as(dp)))
+    np.testing.assert_allclose(head, out[:64], rtol=1e-12)
+    errs = []
+    for i in (4000, 4095):
+        w = oracle.flux_density_grid(prms[i], t, nu)
+        m = w > 1e-9 * w.max()
+        errs.append(np.max(np.abs(out[i] - w)[m] / w[m]))
+    assert max(errs) < 2e-4, errs
+
+
 def test_sharded_evaluator_over_rccl_world_size_1(eng, oracle):
     """The multi-GPU code path end to end on one GPU: a world-size-1 `nccl` (= RCCL) process group, dist.WalkerSharder over
     Fitter.device_evaluator (theta and ln L stay in HBM, one all-gather of [ln L | cost]), cost feedback from
