@@ -82,6 +82,31 @@ def test_config3_1024_walkers_full_batch(eng, oracle):
         assert np.array_equal(f.loglike_batch(samples[i:i + 1], defs), ll[i:i + 1])  # single-walker calls
 
 
+def test_fit_kernel_partial_sums_do_not_depend_on_the_launch_shape(eng, oracle):
+    """The likelihood's flux pass (vag_flux_fit_rows_kernel: one (theta, phi) row per lane) cuts every block of 64 rows into four
+    lattice segments with a partial sum each and lets 1, 2 or 4 wavefronts walk them, chosen from the batch size: ln L must be
+    the same bits for every choice (a wavefront arriving at a cut holds exactly what one starting there computes), and agree
+    with the row-per-wavefront series kernel (another summation order) to rounding."""
+    f, defs = _c4_fitter(oracle)
+    _, lo, hi = f.build_spec(defs)
+    samples = lo + (hi - lo) * np.random.default_rng(7).random((192, len(defs)))
+    samples[11, 3] = 0.0  # an on-axis walker: one phi row per theta row
+    base = f.loglike_batch(samples, defs)
+    try:
+        for w in ("1", "2", "4"):
+            os.environ["VAG_FIT_WAVES_PER_BLOCK"] = w
+            assert np.array_equal(f.loglike_batch(samples, defs), base), w
+        os.environ.pop("VAG_FIT_WAVES_PER_BLOCK")
+        os.environ["VAG_SERIES_ROW_PER_WAVE"] = "1"
+        other = f.loglike_batch(samples, defs)
+    finally:
+        os.environ.pop("VAG_FIT_WAVES_PER_BLOCK", None)
+        os.environ.pop("VAG_SERIES_ROW_PER_WAVE", None)
+    ok = np.isfinite(base)
+    assert np.array_equal(np.isfinite(other), ok) and ok.sum() > 150
+    np.testing.assert_allclose(base[ok], other[ok], rtol=1e-13)
+
+
 def test_config4_two_component_ssc_ensemble_512_members(eng, oracle):
     """configs[4]: 512 members of the prior-predictive two-component SSC sweep (128 x 128 grids, 100 t x 4 nu incl. 2.4e26 Hz) in
     one call: sub-sample against the oracle per member, run-to-run determinism (bitwise), batch == sub-batch to rounding, exact

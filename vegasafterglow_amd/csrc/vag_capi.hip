@@ -18,6 +18,7 @@
 #include "vag_ic_kernels.h"
 #include "vag_kernels.h"
 #include "vag_rs_kernels.h"
+#include "vag_fit_rows.h"
 
 using namespace vag;
 
@@ -1335,12 +1336,12 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
 __global__ void __launch_bounds__(256)
 vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                          const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
-                         double* __restrict__ out) {
+                         double* __restrict__ out, int parts /* partial sums per block of rows */) {
     __shared__ double s_part[4][64];
     const int m = blockIdx.y;
     const VagGridMeta M = meta[m];
     const vag_model_params P = params[m];
-    const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block : 0;
+    const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block * parts : 0;
     const double d_L = P.lumi_dist * U_CM;
     const double norm = (1 + P.z) / (d_L * d_L);
     const double* src = partial + (size_t)m * max_blocks * n;
@@ -1384,6 +1385,53 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     StageScope ps(c, mode == FLUX_SSC ? PS_SSC_FLUX : PS_SYNC_FLUX);
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
+    // A fit's shape (plain synchrotron, <= 64 points in a few bands): the row-per-lane kernel (vag_fit_rows.h)
+    if (mode == FLUX_SYN && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= SERIES_THREADS && n_bands > 0 &&
+        n_bands <= FITROWS_BANDS && !std::getenv("VAG_SERIES_ROW_PER_WAVE")) {
+        const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
+        if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * FITROWS_SEGS * n)) return VAG_E_HIP;
+        SeriesArgs a{};
+        a.params = d_params;
+        a.meta = c->d_meta.as<VagGridMeta>();
+        a.geo_th = c->d_geo_th.as<double>();
+        a.geo_ph = c->d_geo_ph.as<double>();
+        a.g_rep_of = c->d_rep_of.as<int>();
+        a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+        a.cellpar = c->d_cellpar.as<double>();
+        a.lg2_t_obs = d_lg2t;
+        a.lg2_nu_obs = d_lg2nu;
+        a.n = n;
+        a.pairs_per_block = FITROWS_ROWS;
+        a.max_blocks = max_blocks;
+        a.max_chunks = max_blocks * FITROWS_SEGS;  // one partial sum per (block of 64 rows, lattice segment)
+        a.chunk = FITROWS_ROWS;
+        a.partial = c->d_partial.as<double>();
+        a.sp_table = c->d_sptab.as<double>();
+        a.n_bands = n_bands;
+        a.band_idx = c->d_bandidx.as<int>();
+        a.band_first = c->d_bandidx.as<int>() + SERIES_THREADS;
+        c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
+        c->plan.interps = c->total_pairs * (long long)n;
+        c->plan.flux_blocks = max_blocks * nb;
+        c->plan.pairs_per_block = FITROWS_ROWS;
+        if (c->n_rows > 0) {
+            // wavefronts per block of 64 rows: four while the batch leaves the GPU room (each walks a quarter of the lattice),
+            // one when there are blocks enough to fill it (one prologue per block).  The partial sums are the same either way.
+            const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
+            int wpb = blocks <= 4096 ? 4 : (blocks <= 8192 ? 2 : 1);
+            if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
+            a.grid_nt = wpb;
+            const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
+            hipLaunchKernelGGL(vag_flux_fit_rows_kernel, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(), st, a);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev[4], st));
+        hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
+                           c->d_partial.as<double>(), max_blocks * FITROWS_SEGS, FITROWS_ROWS, n, d_out, FITROWS_SEGS);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[5], st));
+        return VAG_OK;
+    }
     // series work per (theta, phi) row is small: fewer, longer wavefronts as the batch grows.  The partial sums are kept per
     // SERIES_CHUNK rows whatever this choice is, so a model's result does not depend on what else is in the batch (a walker
     // scores the same bits alone, in a block of 64, or among 1024).
@@ -1480,7 +1528,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     }
     HIPCHK(hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params,
-                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_chunks, chunk, n, d_out);
+                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_chunks, chunk, n, d_out, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
     return VAG_OK;

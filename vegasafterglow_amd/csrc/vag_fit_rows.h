@@ -1,0 +1,241 @@
+// vag_fit_rows.h -- the likelihood's flux pass with ONE (theta, phi) ROW PER LANE.
+//
+// vag_flux_series_kernel (vag_kernels.h) gives a row to a wavefront: four short phases (EAT logs of the lattice nodes, bracket
+// search per point, boundary spectra per (band, node of the points' window), interpolation per point) that each wait on the one
+// before and each fill part of the wavefront.  On a fit's shape -- a few bands, <= 64 data points, lattices of 14-46 nodes, ~770
+// rows per walker -- that is 347 VALU instructions per row at 54 % VALU busy with the LDS of the staged rows holding occupancy
+// at three wavefronts per SIMD (profiles/r02_pmc_walker_kernels.txt).
+//
+// Here a wavefront takes 64 consecutive rows of a model, one per lane, and all lanes walk the lattice nodes k together:
+//   * the node's observer time and Doppler factor per lane (calc_eat_non_spreading, observer.cpp:143-205), one node ahead;
+//   * the data points are sorted in time, so each lane keeps a cursor into them: the points inside (t[k-1], t[k]] are the next few;
+//   * the node's boundary spectra for the fit's bands are evaluated where a lane has points next to it (the wavefront skips the
+//     node when no lane does), SmoothPowerLawSyn::compute_log2_I_nu through the same evaluator as the other flux kernels;
+//   * each of the lane's points in the interval is interpolated log-log (observer.h:405-433) and added to the wavefront's
+//     per-point accumulator in LDS (ds_add_f64: lanes of one instruction are applied in lane order, so the sum is reproducible).
+// No staged rows, no per-row LDS arrays, no phase barriers: every lane is busy on every step, and the only LDS besides the
+// evaluator's tables is 64 accumulators per wavefront.  A wavefront's 64 rows and their order depend on the model alone, and it
+// writes one partial sum per data point, so a walker's ln L does not depend on what else is in the batch.
+//
+// Reference: Observer::specific_flux_series (src/core/observer.h:447-538).
+#pragma once
+#include "vag_kernels.h"
+
+namespace vag {
+
+constexpr int FITROWS_WAVES = 4;   // wavefronts per workgroup (they only share the tables and the data points)
+constexpr int FITROWS_BANDS = 4;   // distinct frequencies handled (a fit with more goes through vag_flux_series_kernel)
+constexpr int FITROWS_ROWS = 64;   // rows per block = lanes of a wavefront
+constexpr int FITROWS_SEGS = 4;    // lattice segments per block: each (block, segment) is one partial sum of the model's tree
+
+// bytes of LDS of one workgroup
+__host__ __device__ inline size_t fit_rows_lds_bytes() {
+    return sizeof(double) * (SP_LDS_DOUBLES + SERIES_THREADS + SERIES_MAX_BANDS + FITROWS_WAVES * SERIES_THREADS) + sizeof(int) * SERIES_THREADS;
+}
+
+#ifndef VAG_HOST_DEBUG
+VAG_DEV void lds_add_f64(double* p, double v) {
+    asm volatile("ds_add_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double*)p), "v"(v) : "memory");
+}
+#endif
+
+// a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.
+__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES)
+vag_flux_fit_rows_kernel(SeriesArgs a) {
+    const int m = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;
+    const VagGridMeta* Mp = a.meta + m;
+    const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
+    const int W = a.grid_nt, blocks_per_wg = FITROWS_WAVES / W;
+    if ((long long)blockIdx.x * blocks_per_wg * FITROWS_ROWS >= n_pairs) return;  // nothing of this model here (or model not evaluated)
+    double* s_tp = s_sp + SP_LDS_DOUBLES;             // [64] log2 of the data points' times, ascending; +inf beyond n
+    double* s_band = s_tp + SERIES_THREADS;           // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
+    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * SERIES_THREADS;  // this wavefront's per-point sums
+    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * SERIES_THREADS);  // [64] band of each point
+    const int n = a.n, NB = a.n_bands;
+    const double lg2_1pz = Mp->lg2_1pz;
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
+    if (threadIdx.x < SERIES_THREADS) {
+        s_tp[threadIdx.x] = (int)threadIdx.x < n ? a.lg2_t_obs[threadIdx.x] : INFINITY;
+        s_band_of[threadIdx.x] = (int)threadIdx.x < n ? a.band_idx[threadIdx.x] : 0;
+    }
+    if (threadIdx.x < NB) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]] + lg2_1pz;
+    s_acc[lane] = 0;
+    __syncthreads();  // the only workgroup-wide barrier
+    // The lattice of a block is cut into FITROWS_SEGS segments, each with its own partial sum: the intervals between nodes are
+    // independent, a segment starts from nothing but its first node.  W wavefronts share the block and take FITROWS_SEGS / W
+    // consecutive segments each; one that walks several in a row flushes its accumulators at the cuts, and its running state
+    // at a cut (cursor, the cut node's boundary values) is bit for bit what a wavefront starting there computes.  So the
+    // partial sums do not depend on W: the host picks W = 4 for small batches (the longest sequential chain of the pass is a
+    // quarter as long) and W = 1 for large ones (one prologue per block instead of four).
+    const int vb = blockIdx.x * blocks_per_wg + wave / W, wseg = wave % W;
+    const int p0 = vb * FITROWS_ROWS;
+    if (p0 >= n_pairs) return;
+    const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
+    const int K = Mp->n_t, n_phi_eff = Mp->n_phi_eff;
+    const double one_plus_z = 1 + a.params[m].z;
+    SpecConst sc;
+    sc.init_fast(a.params[m].p, lg_tab);
+    int seg = wseg * (FITROWS_SEGS / W);                 // current segment
+    const int seg_end = seg + FITROWS_SEGS / W;           // one past this wavefront's last segment
+    auto cut = [&](int s) { return (K - 1) * s / FITROWS_SEGS; };  // segment s covers the steps (cut(s), cut(s + 1)]
+    double* my_partial = a.partial + ((size_t)m * a.max_chunks + (size_t)vb * FITROWS_SEGS) * n;
+    auto flush = [&](int s) {  // close segment s: its partial sum leaves, the accumulators start over
+        wave_sync();
+        if (lane < n) my_partial[(size_t)s * n + lane] = s_acc[lane];
+        s_acc[lane] = 0;
+        wave_sync();
+    };
+    const int k_first = cut(seg), k_last = cut(seg_end);
+    if (k_last <= k_first) {  // fewer intervals than segments: nothing to walk here
+        for (; seg < seg_end; ++seg) flush(seg);
+        return;
+    }
+
+    // this lane's row
+    const bool valid = p0 + lane < n_pairs;
+    const int pair = valid ? p0 + lane : n_pairs - 1;
+    const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j];
+    const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * Mp->sin_obs + gth[j] * Mp->cos_obs;
+    const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+    const double* row = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;  // [VAG_NPAR][K]
+
+    // EAT quantities of node k: log2 observer time, log2 Doppler factor, 2 log2 r
+    // (explicit fma: a wavefront that starts at a node and one that arrives there must form these two sums the same way)
+    auto eat = [&](double G, double u, double r, double teng, double& lt, double& dop) {
+        dop = -log2_tab(fma(-u, cos_v, G), lg_tab);
+        lt = log2_tab(fma(t_coeff, r, teng * one_plus_z), lg_tab);
+    };
+    auto node = [&](int k, double& lt, double& dop, double& lr2) {
+        lr2 = row[VP_LG2_R2 * K + k];
+        eat(row[VP_GAMMA * K + k], row[VP_U * K + k], row[VP_R * K + k], row[VP_TENG * K + k], lt, dop);
+    };
+    // boundary values B[b] = log2 I'(nu_b (1+z) / D_k) + log2(dOmega r^2 D^3) of node k for the fit's bands
+    auto boundary = [&](int k, double dop, double lr2, double (&B)[FITROWS_BANDS]) {
+        SpecRegs regs;
+#pragma unroll
+        for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
+        regs.v[13] = lr2;
+        const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
+#pragma unroll
+        for (int b = 0; b < FITROWS_BANDS; ++b)
+            if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_band[b] - dop, sp_tab) + geom;
+    };
+
+#ifdef VAG_SERIES_STAMPS  // developer aid: cycles of one wavefront per part of a step
+    long long c_pro = 0, c_node = 0, c_scan = 0, c_bnd = 0, c_int = 0, c_mark = __builtin_readcyclecounter();
+    int n_bnd = 0;
+#define VAG_FR_MARK(acc_) do { __builtin_amdgcn_s_waitcnt(0); const long long now_ = __builtin_readcyclecounter(); acc_ += now_ - c_mark; c_mark = now_; } while (0)
+#else
+#define VAG_FR_MARK(acc_) do { } while (0)
+#endif
+    double lt_a, dop_a, lr2_a, lt_b, dop_b, lr2_b;
+    node(k_first, lt_a, dop_a, lr2_a);
+    node(k_first + 1, lt_b, dop_b, lr2_b);
+    // the five EAT members of the node after next are requested a whole step before they are used
+    double nG = 1, nu_ = 0, nr = 0, nteng = 1, nlr2 = 0;
+    auto request = [&](int k) {
+        const int kk = k < K ? k : K - 1;
+        nG = row[VP_GAMMA * K + kk], nu_ = row[VP_U * K + kk], nr = row[VP_R * K + kk], nteng = row[VP_TENG * K + kk];
+        nlr2 = row[VP_LG2_R2 * K + kk];
+    };
+    request(k_first + 2);
+    // cursor into the sorted points: the first one at or beyond node 0 (a point equal to node 0 belongs to interval 0), or the
+    // first one beyond node k_first when the wavefront starts inside the lattice: bisection over the 64 slots (+inf beyond n)
+    int p = n;
+    if (valid) {
+        int lo = -1, hi = SERIES_THREADS;  // s_tp[lo] fails, s_tp[hi] passes
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {  // 65 candidates
+            const int mid = (lo + hi + 1) >> 1;
+            const double tm = s_tp[min(mid, SERIES_THREADS - 1)];
+            const bool pass = mid >= SERIES_THREADS || (k_first == 0 ? tm >= lt_a : tm > lt_a);
+            if (pass)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        p = min(hi, n);
+    }
+    double Bprev[FITROWS_BANDS] = {0, 0, 0, 0}, Bcur[FITROWS_BANDS] = {0, 0, 0, 0};
+    {
+        const bool need0 = p < n && s_tp[p] <= lt_b;  // the first interval holds a point: node k_first is one of its ends
+        if (__ballot(need0) != 0 && need0) boundary(k_first, dop_a, lr2_a, Bprev);
+    }
+    while (cut(seg + 1) <= k_first) flush(seg++);  // leading segments without an interval
+    VAG_FR_MARK(c_pro);
+    for (int k = k_first + 1; k <= k_last; ++k) {
+        // node k + 1, one step ahead: its time tells whether node k closes the interval before a point (beyond this wavefront's
+        // last node the next wavefront evaluates it as its own first)
+        double lt_c = -INFINITY, dop_c = 0, lr2_c = 0;
+        if (k + 1 <= k_last) {
+            lr2_c = nlr2;
+            eat(nG, nu_, nr, nteng, lt_c, dop_c);
+        }
+        request(k + 2);
+        VAG_FR_MARK(c_node);
+        // the lane's points inside (t[k-1], t[k]]: the next four at once (the times ascend, so the count is the number of
+        // leading ones that fit); more than four is rare
+        double tn[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) tn[q] = p + q < n ? s_tp[min(p + q, SERIES_THREADS - 1)] : INFINITY;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cnt += tn[q] <= lt_b ? 1 : 0;
+        int pe = p + cnt;
+        double t_next = cnt == 0 ? tn[0] : cnt == 1 ? tn[1] : cnt == 2 ? tn[2] : cnt == 3 ? tn[3] : tn[4];
+        if (cnt == 4) {
+            while (pe < n && s_tp[pe] <= lt_b) ++pe;
+            t_next = pe < n ? s_tp[pe] : INFINITY;
+        }
+        const bool need = pe > p || t_next <= lt_c;
+        VAG_FR_MARK(c_scan);
+        if (__ballot(need) != 0) {
+            if (need) boundary(k, dop_b, lr2_b, Bcur);
+#ifdef VAG_SERIES_STAMPS
+            ++n_bnd;
+#endif
+            VAG_FR_MARK(c_bnd);
+            if (__ballot(pe > p) != 0) {
+                const double inv_dt = 1.0 / (lt_b - lt_a);
+                // two points per turn: their interpolation chains (selects, slope, 2^x) are independent and interleave
+                for (int q = p; q < pe; q += 2) {
+                    const int q1 = min(q + 1, pe - 1);
+                    const int b0 = s_band_of[q], b1 = s_band_of[q1];
+                    const double t0 = s_tp[q], t1 = s_tp[q1];
+                    double lo0 = Bprev[0], hi0 = Bcur[0], lo1 = Bprev[0], hi1 = Bcur[0];
+#pragma unroll
+                    for (int bb = 1; bb < FITROWS_BANDS; ++bb) {
+                        lo0 = b0 == bb ? Bprev[bb] : lo0;
+                        hi0 = b0 == bb ? Bcur[bb] : hi0;
+                        lo1 = b1 == bb ? Bprev[bb] : lo1;
+                        hi1 = b1 == bb ? Bcur[bb] : hi1;
+                    }
+                    const double sl0 = (hi0 - lo0) * inv_dt, sl1 = (hi1 - lo1) * inv_dt;
+                    const double v0 = exp2_fast(lo0 + (t0 - lt_a) * sl0), v1 = exp2_fast(lo1 + (t1 - lt_a) * sl1);
+                    if (isfinite(sl0)) lds_add_f64(s_acc + q, v0);
+                    if (q + 1 < pe && isfinite(sl1)) lds_add_f64(s_acc + q + 1, v1);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < FITROWS_BANDS; ++b) Bprev[b] = Bcur[b];
+            VAG_FR_MARK(c_int);
+        }
+        p = pe;
+        lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
+        while (seg < seg_end && cut(seg + 1) <= k) flush(seg++);  // step k closes segment(s)
+    }
+#ifdef VAG_SERIES_STAMPS
+    if (m == 0 && vb == 0 && lane == 0 && wseg == 0)
+        printf("fit rows wave 0: K %d  cycles: prologue %lld  nodes %lld  scan %lld  boundary %lld (%d steps)  interp %lld\n", K, c_pro, c_node,
+               c_scan, c_bnd, n_bnd, c_int);
+#endif
+}
+
+}  // namespace vag
