@@ -27,10 +27,16 @@ constexpr int FITROWS_WAVES = 4;   // wavefronts per workgroup (they only share 
 constexpr int FITROWS_BANDS = 4;   // distinct frequencies handled (a fit with more goes through vag_flux_series_kernel)
 constexpr int FITROWS_ROWS = 64;   // rows per block = lanes of a wavefront
 constexpr int FITROWS_SEGS = 4;    // lattice segments per block: each (block, segment) is one partial sum of the model's tree
+#ifndef VAG_FITROWS_STRIPES
+#define VAG_FITROWS_STRIPES 4
+#endif
+constexpr int FITROWS_STRIPES = VAG_FITROWS_STRIPES;  // copies of a wavefront's per-point sums: lane L adds to copy L mod 4 (neighbouring
+                                                      // rows hit the same point in the same instruction; fewer collide per address)
 
 // bytes of LDS of one workgroup
 __host__ __device__ inline size_t fit_rows_lds_bytes() {
-    return sizeof(double) * (SP_LDS_DOUBLES + SERIES_THREADS + SERIES_MAX_BANDS + FITROWS_WAVES * SERIES_THREADS) + sizeof(int) * SERIES_THREADS;
+    return sizeof(double) * (SP_LDS_DOUBLES + SERIES_THREADS + SERIES_MAX_BANDS + FITROWS_WAVES * FITROWS_STRIPES * SERIES_THREADS) +
+           sizeof(int) * SERIES_THREADS;
 }
 
 #ifndef VAG_HOST_DEBUG
@@ -52,8 +58,8 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     if ((long long)blockIdx.x * blocks_per_wg * FITROWS_ROWS >= n_pairs) return;  // nothing of this model here (or model not evaluated)
     double* s_tp = s_sp + SP_LDS_DOUBLES;             // [64] log2 of the data points' times, ascending; +inf beyond n
     double* s_band = s_tp + SERIES_THREADS;           // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
-    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * SERIES_THREADS;  // this wavefront's per-point sums
-    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * SERIES_THREADS);  // [64] band of each point
+    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * FITROWS_STRIPES * SERIES_THREADS;  // this wavefront's per-point sums [stripe][64]
+    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * FITROWS_STRIPES * SERIES_THREADS);  // [64] band of each point
     const int n = a.n, NB = a.n_bands;
     const double lg2_1pz = Mp->lg2_1pz;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
@@ -62,7 +68,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         s_band_of[threadIdx.x] = (int)threadIdx.x < n ? a.band_idx[threadIdx.x] : 0;
     }
     if (threadIdx.x < NB) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]] + lg2_1pz;
-    s_acc[lane] = 0;
+#pragma unroll
+    for (int c = 0; c < FITROWS_STRIPES; ++c) s_acc[c * SERIES_THREADS + lane] = 0;
+    double* my_acc = s_acc + (lane % FITROWS_STRIPES) * SERIES_THREADS;  // the copy this lane adds to
     __syncthreads();  // the only workgroup-wide barrier
     // The lattice of a block is cut into FITROWS_SEGS segments, each with its own partial sum: the intervals between nodes are
     // independent, a segment starts from nothing but its first node.  W wavefronts share the block and take FITROWS_SEGS / W
@@ -84,8 +92,12 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     double* my_partial = a.partial + ((size_t)m * a.max_chunks + (size_t)vb * FITROWS_SEGS) * n;
     auto flush = [&](int s) {  // close segment s: its partial sum leaves, the accumulators start over
         wave_sync();
-        if (lane < n) my_partial[(size_t)s * n + lane] = s_acc[lane];
-        s_acc[lane] = 0;
+        double sum = s_acc[lane];
+#pragma unroll
+        for (int c = 1; c < FITROWS_STRIPES; ++c) sum += s_acc[c * SERIES_THREADS + lane];  // fixed order
+        if (lane < n) my_partial[(size_t)s * n + lane] = sum;
+#pragma unroll
+        for (int c = 0; c < FITROWS_STRIPES; ++c) s_acc[c * SERIES_THREADS + lane] = 0;
         wave_sync();
     };
     const int k_first = cut(seg), k_last = cut(seg_end);
@@ -219,8 +231,8 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
                     }
                     const double sl0 = (hi0 - lo0) * inv_dt, sl1 = (hi1 - lo1) * inv_dt;
                     const double v0 = exp2_fast(lo0 + (t0 - lt_a) * sl0), v1 = exp2_fast(lo1 + (t1 - lt_a) * sl1);
-                    if (isfinite(sl0)) lds_add_f64(s_acc + q, v0);
-                    if (q + 1 < pe && isfinite(sl1)) lds_add_f64(s_acc + q + 1, v1);
+                    if (isfinite(sl0)) lds_add_f64(my_acc + q, v0);
+                    if (q + 1 < pe && isfinite(sl1)) lds_add_f64(my_acc + q + 1, v1);
                 }
             }
 #pragma unroll
