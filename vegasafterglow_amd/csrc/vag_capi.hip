@@ -1418,7 +1418,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             // wavefronts per block of 64 rows: four while the batch leaves the GPU room (each walks a quarter of the lattice),
             // one when there are blocks enough to fill it (one prologue per block).  The partial sums are the same either way.
             const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
-            int wpb = blocks <= 4096 ? 4 : (blocks <= 8192 ? 2 : 1);
+            int wpb = blocks <= 2048 ? 4 : (blocks <= 4608 ? 2 : 1);  // measured: 1.6 k blocks 0.128 / 0.17 ms (4 / 1), 3.1 k 0.215 / 0.233 (2 / 1), 6.2 k 0.357 / 0.342
             if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
             a.grid_nt = wpb;
             const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
