@@ -19,6 +19,7 @@
 #include "vag_kernels.h"
 #include "vag_rs_kernels.h"
 #include "vag_fit_rows.h"
+#include "vag_grid_rows.h"
 
 using namespace vag;
 
@@ -950,6 +951,57 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, slots, d_out, mode, nnu, nt);
     if (slots > FLUX_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_MAX_SLOTS);
+    // Small grids of large batches: a (theta, phi) row per lane (vag_grid_rows.h).  A lone model would walk its lattice as one
+    // sequential chain there, so the batch must bring blocks of 64 rows enough to fill the GPU; models of a few rows (on-axis
+    // top hats: 32 rows) would leave lanes empty.
+    {
+        const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
+        if (mode != FLUX_FUSED && !(c->batch_flags & VAG_FLAG_SPREADING) && !c->count_work && slots <= GRIDROWS_MAX_SLOTS &&
+            nnu <= GRIDROWS_BANDS && nt <= GRIDROWS_MAX_NT && blocks >= 4096 && c->total_pairs >= 128LL * nb && c->n_rows > 0 &&
+            !std::getenv("VAG_GRID_ROW_PER_WORKGROUP")) {
+            const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
+            if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
+            SeriesArgs a{};
+            a.params = d_params;
+            a.meta = c->d_meta.as<VagGridMeta>();
+            a.geo_th = c->d_geo_th.as<double>();
+            a.geo_ph = c->d_geo_ph.as<double>();
+            a.g_rep_of = c->d_rep_of.as<int>();
+            a.lay = Layout{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
+            a.cellpar = c->d_cellpar.as<double>();
+            a.lg2_t_obs = d_lg2t;
+            a.lg2_nu_obs = d_lg2nu;
+            a.n = slots;
+            a.grid_nt = nt;
+            a.n_bands = nnu;
+            a.max_chunks = max_blocks;
+            a.partial = c->d_partial.as<double>();
+            a.sp_table = c->d_sptab.as<double>();
+            a.cellq = c->d_cellq.as<double>();
+            a.ictab = c->d_ictab.as<double>();
+            a.ic_status = c->d_icstatus.as<int>();
+            c->plan.spec_evals += c->eat_cells * nnu;
+            c->plan.interps += c->total_pairs * (long long)nt * nnu;
+            c->plan.flux_blocks = max_blocks * nb;
+            c->plan.pairs_per_block = FITROWS_ROWS;
+            const dim3 g((max_blocks + GRIDROWS_WAVES - 1) / GRIDROWS_WAVES, nb), b(SERIES_THREADS * GRIDROWS_WAVES);
+            const size_t lds = grid_rows_lds_bytes(slots);
+            if (mode == FLUX_SYN_IC)
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN_IC>), g, b, lds, st, a);
+            else if (mode == FLUX_SSC)
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SSC>), g, b, lds, st, a);
+            else
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN>), g, b, lds, st, a);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[4], st));
+            const int out_slots = d_bandw ? nt : slots;
+            hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
+                               c->d_partial.as<double>(), max_blocks, FITROWS_ROWS, nt, nnu, d_bandw, d_out);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[5], st));
+            return VAG_OK;
+        }
+    }
     const int ppb = choose_pairs_per_block(c);
     const int max_blocks = std::max(1, (c->max_pairs + ppb - 1) / ppb);
     if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;

@@ -1,0 +1,200 @@
+// vag_grid_rows.h -- small (nu, t) grids of large batches with ONE (theta, phi) ROW PER LANE (the grid-request counterpart of
+// vag_fit_rows.h).
+//
+// vag_flux_grid_kernel gives a row to a 256-lane workgroup: at four frequencies and a hundred times a row fills 22-78 % of the
+// lanes per phase and pays two workgroup barriers, and the row skeleton (EAT logs, bracket search, barriers) has come to outweigh
+// the spectra (~10 of 17-23 ms per pass on the C5 shape).  Here a wavefront takes 64 consecutive rows, one per
+// lane, and all lanes walk the lattice nodes together: node times one node ahead, a cursor into the ascending requested times,
+// the node's boundary values for the request's frequencies where a lane has times next to it, log-log interpolation of the
+// lane's times in the interval (Observer::specific_flux, observer.h:355-445: t_row[k] <= t < t_row[k+1]), added to the
+// wavefront's (nu, t) sums in LDS with ds_add_f64.  No staged rows, no barriers after the tables are loaded.
+//
+// Used when the batch has blocks of 64 rows enough to fill the GPU (a lone model would walk its lattice as one sequential chain)
+// and the grid has at most 512 (nu, t) slots in at most four frequencies; everything else stays with vag_flux_grid_kernel.
+#pragma once
+#include "vag_fit_rows.h"
+#include "vag_ic_kernels.h"
+
+namespace vag {
+
+constexpr int GRIDROWS_WAVES = 4;
+constexpr int GRIDROWS_BANDS = 4;     // frequencies
+constexpr int GRIDROWS_MAX_NT = 128;  // requested times
+constexpr int GRIDROWS_MAX_SLOTS = 512;
+
+__host__ __device__ inline int grid_rows_stripes(int slots) { return slots <= 128 ? 4 : 2; }
+__host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
+    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * slots);
+}
+
+// a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
+// 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
+template <int MODE>
+__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES)
+vag_flux_grid_rows_kernel(SeriesArgs a) {
+    const int m = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;
+    const VagGridMeta* Mp = a.meta + m;
+    const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
+    if ((long long)blockIdx.x * GRIDROWS_WAVES * FITROWS_ROWS >= n_pairs) return;
+    const int nt = a.grid_nt, NB = a.n_bands, slots = a.n;
+    const int stripes = grid_rows_stripes(slots);
+    double* s_tobs = s_sp + SP_LDS_DOUBLES;           // [GRIDROWS_MAX_NT] log2 requested times, ascending; +inf beyond nt
+    double* s_nu = s_tobs + GRIDROWS_MAX_NT;          // [SERIES_MAX_BANDS] log2 nu (1 + z)
+    double* s_acc = s_nu + SERIES_MAX_BANDS + (size_t)wave * stripes * slots;  // this wavefront's sums [stripe][slots]
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
+    for (int i = threadIdx.x; i < GRIDROWS_MAX_NT; i += blockDim.x) s_tobs[i] = i < nt ? a.lg2_t_obs[i] : INFINITY;
+    if (threadIdx.x < NB) s_nu[threadIdx.x] = a.lg2_nu_obs[threadIdx.x] + Mp->lg2_1pz;
+    for (int i = lane; i < stripes * slots; i += SERIES_THREADS) s_acc[i] = 0;
+    double* my_acc = s_acc + (lane % stripes) * slots;
+    __syncthreads();  // the only workgroup-wide barrier
+    const int vb = blockIdx.x * GRIDROWS_WAVES + wave;
+    const int p0 = vb * FITROWS_ROWS;
+    if (p0 >= n_pairs) return;
+    const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
+    const int K = Mp->n_t, n_phi_eff = Mp->n_phi_eff;
+    const double one_plus_z = 1 + a.params[m].z;
+    SpecConst sc;
+    sc.init_fast(a.params[m].p, lg_tab);
+    int breach = 0;
+
+    // this lane's row
+    const bool valid = p0 + lane < n_pairs;
+    const int pair = valid ? p0 + lane : n_pairs - 1;
+    const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j];
+    const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * Mp->sin_obs + gth[j] * Mp->cos_obs;
+    const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+    const long long cell0 = a.lay.cell_off[m] + (long long)rep * K;
+    const double* row = a.cellpar + cell0 * VAG_NPAR;  // [VAG_NPAR][K]
+
+    auto eat = [&](double G, double u, double r, double teng, double& lt, double& dop) {
+        dop = -log2_tab(fma(-u, cos_v, G), lg_tab);
+        lt = log2_tab(fma(t_coeff, r, teng * one_plus_z), lg_tab);
+    };
+    auto node = [&](int k, double& lt, double& dop, double& lr2) {
+        lr2 = row[VP_LG2_R2 * K + k];
+        eat(row[VP_GAMMA * K + k], row[VP_U * K + k], row[VP_R * K + k], row[VP_TENG * K + k], lt, dop);
+    };
+    // boundary values B[l] = log2 I'(nu_l (1+z) / D_k) + log2(dOmega r^2 D^3) of node k
+    auto boundary = [&](int k, double dop, double lr2, double (&B)[GRIDROWS_BANDS]) {
+        const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
+        if constexpr (MODE == FLUX_SSC) {
+            const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
+            const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
+#pragma unroll
+            for (int b = 0; b < GRIDROWS_BANDS; ++b)
+                if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[b] - dop, &breach) + geom;
+        } else {
+            SpecRegs regs;
+#pragma unroll
+            for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
+            regs.v[13] = lr2;
+            if constexpr (MODE == FLUX_SYN_IC) {
+                const double* cq = a.cellq + cell0 * FLUX_NQ + k;
+                IcQ q;
+                q.head(cq, K);
+                bool any = false;
+#pragma unroll
+                for (int b = 0; b < GRIDROWS_BANDS; ++b) any = any || (b < NB && q.applies(s_nu[b] - dop));
+                if (any) q.rest(cq, K);
+#pragma unroll
+                for (int b = 0; b < GRIDROWS_BANDS; ++b)
+                    if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(s_nu[b] - dop), q, sc, s_nu[b] - dop, sp_tab) + geom;
+            } else {
+#pragma unroll
+                for (int b = 0; b < GRIDROWS_BANDS; ++b)
+                    if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_nu[b] - dop, sp_tab) + geom;
+            }
+        }
+    };
+
+    double lt_a, dop_a, lr2_a, lt_b, dop_b, lr2_b;
+    node(0, lt_a, dop_a, lr2_a);
+    node(1, lt_b, dop_b, lr2_b);
+    double nG = 1, nu_ = 0, nr = 0, nteng = 1, nlr2 = 0;  // the node after next, requested a step before it is used
+    auto request = [&](int k) {
+        const int kk = k < K ? k : K - 1;
+        nG = row[VP_GAMMA * K + kk], nu_ = row[VP_U * K + kk], nr = row[VP_R * K + kk], nteng = row[VP_TENG * K + kk];
+        nlr2 = row[VP_LG2_R2 * K + kk];
+    };
+    request(2);
+    // cursor into the ascending requested times: the first one at or beyond node 0 (bisection over the 128 slots, +inf beyond nt)
+    int p = nt;
+    if (valid) {
+        int lo = -1, hi = GRIDROWS_MAX_NT;  // s_tobs[lo] < lt_a <= s_tobs[hi]
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {  // 129 candidates
+            const int mid = (lo + hi + 1) >> 1;
+            const bool pass = mid >= GRIDROWS_MAX_NT || s_tobs[min(mid, GRIDROWS_MAX_NT - 1)] >= lt_a;
+            if (pass)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        p = min(hi, nt);
+    }
+    double Bprev[GRIDROWS_BANDS] = {0, 0, 0, 0}, Bcur[GRIDROWS_BANDS] = {0, 0, 0, 0};
+    {
+        const bool need0 = p < nt && s_tobs[p] < lt_b;  // the first interval holds a requested time
+        if (__ballot(need0) != 0 && need0) boundary(0, dop_a, lr2_a, Bprev);
+    }
+    for (int k = 1; k < K; ++k) {
+        double lt_c = -INFINITY, dop_c = 0, lr2_c = 0;
+        if (k + 1 < K) {
+            lr2_c = nlr2;
+            eat(nG, nu_, nr, nteng, lt_c, dop_c);
+        }
+        request(k + 2);
+        // the lane's requested times inside [t[k-1], t[k]): the next four at once, more is rare
+        double tn[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) tn[q] = p + q < nt ? s_tobs[min(p + q, GRIDROWS_MAX_NT - 1)] : INFINITY;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cnt += tn[q] < lt_b ? 1 : 0;
+        int pe = p + cnt;
+        double t_next = cnt == 0 ? tn[0] : cnt == 1 ? tn[1] : cnt == 2 ? tn[2] : cnt == 3 ? tn[3] : tn[4];
+        if (cnt == 4) {
+            while (pe < nt && s_tobs[pe] < lt_b) ++pe;
+            t_next = pe < nt ? s_tobs[pe] : INFINITY;
+        }
+        const bool need = pe > p || t_next < lt_c;
+        if (__ballot(need) != 0) {
+            if (need) boundary(k, dop_b, lr2_b, Bcur);
+            if (__ballot(pe > p) != 0) {
+                const double inv_dt = 1.0 / (lt_b - lt_a);
+                double d[GRIDROWS_BANDS];
+#pragma unroll
+                for (int b = 0; b < GRIDROWS_BANDS; ++b) d[b] = Bcur[b] - Bprev[b];  // slope finite <=> d finite (observer.h:422-426)
+                for (int q = p; q < pe; ++q) {
+                    const double w = (s_tobs[q] - lt_a) * inv_dt;  // position inside the interval, shared by the frequencies
+#pragma unroll
+                    for (int b = 0; b < GRIDROWS_BANDS; ++b)
+                        if (b < NB && isfinite(d[b])) lds_add_f64(my_acc + b * nt + q, exp2_fast(fma(d[b], w, Bprev[b])));
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < GRIDROWS_BANDS; ++b) Bprev[b] = Bcur[b];
+        }
+        p = pe;
+        lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
+    }
+    if constexpr (MODE == FLUX_SSC) {
+        if (breach) atomicOr(a.ic_status + m, 2);
+    }
+    wave_sync();
+    double* dst = a.partial + ((size_t)m * a.max_chunks + vb) * slots;
+    for (int s = lane; s < slots; s += SERIES_THREADS) {
+        double sum = s_acc[s];
+        for (int c = 1; c < stripes; ++c) sum += s_acc[c * slots + s];
+        dst[s] = sum;
+    }
+}
+
+}  // namespace vag
