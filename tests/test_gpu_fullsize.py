@@ -107,6 +107,48 @@ def test_fit_kernel_partial_sums_do_not_depend_on_the_launch_shape(eng, oracle):
     np.testing.assert_allclose(base[ok], other[ok], rtol=1e-13)
 
 
+@pytest.mark.parametrize("case", ["two_component_ssc", "gaussian_offaxis", "rs_ssc_kn"])
+def test_row_per_lane_grid_kernel_agrees_with_the_workgroup_kernel(eng, case):
+    """Large batches with small (nu, t) grids go through vag_flux_grid_rows_kernel (a (theta, phi) row per lane, per-slot sums by
+    LDS atomics in lane order); VAG_GRID_ROW_PER_WORKGROUP=1 keeps them on vag_flux_grid_kernel.  Same boundary values, same
+    interpolation arithmetic, another summation order: every component agrees to rounding, and the row-per-lane result is the
+    same bits from run to run."""
+    from ssc_ensemble import c3_batch, c5_batch
+    lib, h = eng
+    if case == "two_component_ssc":
+        prms = c5_batch(32)
+    elif case == "rs_ssc_kn":
+        prms = c3_batch(128)
+    else:
+        rng = np.random.default_rng(5)
+        prms = [_abi.make_params(**dict(configs.C2, E_iso=10 ** rng.uniform(51, 53), theta_obs=rng.uniform(0.1, 0.4))) for _ in range(80)]
+    t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
+    nb = len(prms)
+    arr = (_lib.ModelParams * nb)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+
+    def run():
+        comps = [np.empty((nb, nu.size, t.size)) for _ in range(4)]
+        out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+        _lib.check(lib.vag_flux_density_grid_components4_batch(h, arr, nb, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, out4))
+        pl = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(pl))
+        return comps, pl.total_pairs, pl.pairs_per_block
+    rows, pairs, ppb = run()
+    assert pairs >= 4096 * 64 and ppb == 64  # the batch is large enough for the row-per-lane kernel (vag_capi.hip: run_flux_grid)
+    again, _, _ = run()
+    os.environ["VAG_GRID_ROW_PER_WORKGROUP"] = "1"
+    try:
+        wg, _, _ = run()
+    finally:
+        del os.environ["VAG_GRID_ROW_PER_WORKGROUP"]
+    for a, a2, b in zip(rows, again, wg):
+        assert np.array_equal(a, a2)
+        assert np.all(np.isfinite(a))
+        m = b > 1e-12 * np.maximum(b.max(axis=(1, 2), keepdims=True), 1e-300)
+        assert np.all(np.abs(a - b)[m] <= 1e-11 * b[m])
+    assert rows[0].max() > 0
+
+
 def test_config4_two_component_ssc_ensemble_512_members(eng, oracle):
     """configs[4]: 512 members of the prior-predictive two-component SSC sweep (128 x 128 grids, 100 t x 4 nu incl. 2.4e26 Hz) in
     one call: sub-sample against the oracle per member, run-to-run determinism (bitwise), batch == sub-batch to rounding, exact
