@@ -19,6 +19,16 @@ dp = C.POINTER(C.c_double)
 sys.path.insert(0, os.path.join(_abi.ROOT, "profiles"))
 
 
+def gpu_series(eng, prms, t, nu):
+    lib, h = eng
+    arr = (_lib.ModelParams * len(prms))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    out = np.empty((len(prms), t.size))
+    _lib.check(lib.vag_flux_density_batch(h, arr, len(prms), t.ctypes.data_as(dp), nu.ctypes.data_as(dp), t.size, out.ctypes.data_as(dp)))
+    return out
+
+
 @pytest.fixture(scope="module")
 def eng():
     lib = _lib.load()
@@ -105,6 +115,31 @@ def test_fit_kernel_partial_sums_do_not_depend_on_the_launch_shape(eng, oracle):
     ok = np.isfinite(base)
     assert np.array_equal(np.isfinite(other), ok) and ok.sum() > 150
     np.testing.assert_allclose(base[ok], other[ok], rtol=1e-13)
+
+
+def test_fit_kernel_with_300_points_in_six_bands(eng, oracle):
+    """A larger data set than the C4 mock (300 points, six bands: the eight-band instantiation, several slots per lane in the
+    flush): the row-per-lane kernel against the row-per-wavefront kernel on 48 models, and against the oracle on two."""
+    lib, h = eng
+    rng = np.random.default_rng(11)
+    bands = np.array([1.4e9, 1e10, 4.6e14, 8e14, 2.4e17, 1.2e18])
+    t = np.sort(10 ** rng.uniform(3.5, 7.5, 300))
+    nu = bands[rng.integers(0, bands.size, t.size)]
+    prms = [_abi.make_params(**dict(configs.C4_TRUTH, jet="GaussianJet", E_iso=10 ** rng.uniform(51.5, 53), theta_obs=rng.uniform(0.0, 0.5),
+                                    theta_c=rng.uniform(0.04, 0.2))) for _ in range(48)]
+    got = gpu_series(eng, prms, t, nu)
+    again = gpu_series(eng, prms, t, nu)
+    assert np.array_equal(got, again) and np.all(np.isfinite(got)) and got.max() > 0
+    os.environ["VAG_SERIES_ROW_PER_WAVE"] = "1"
+    try:
+        other = gpu_series(eng, prms, t, nu)
+    finally:
+        del os.environ["VAG_SERIES_ROW_PER_WAVE"]
+    np.testing.assert_allclose(got, other, rtol=1e-12, atol=1e-300)
+    for i in (0, 47):
+        want = oracle.flux_density(prms[i], t, nu)
+        m = want > 1e-9 * want.max()
+        assert np.max(np.abs(got[i] - want)[m] / want[m]) < 5e-6
 
 
 @pytest.mark.parametrize("case", ["two_component_ssc", "gaussian_offaxis", "rs_ssc_kn"])

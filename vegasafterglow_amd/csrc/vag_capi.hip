@@ -279,8 +279,8 @@ struct vag_ctx {
     int grid_large_idle = 0;  // consecutive batches that would have fitted the small one
     std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
     DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
-    DevBuf d_bandidx;  // [64 band index per point | 8 first point of each band] for the shared-node series path
-    int h_bandbuf[64 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
+    DevBuf d_bandidx;  // [512 band index per point | 8 first point of each band] for the shared-node / row-per-lane series paths
+    int h_bandbuf[512 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
     int h_bands_n = -1;
     int pending_bands = 0;  // set by the host-pointer entry points that know the frequencies; consumed by the next series call
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_icunclamp, d_ssc;
@@ -1438,7 +1438,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
     // A fit's shape (plain synchrotron, <= 64 points in a few bands): the row-per-lane kernel (vag_fit_rows.h)
-    if (mode == FLUX_SYN && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= SERIES_THREADS && n_bands > 0 &&
+    if (mode == FLUX_SYN && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
         n_bands <= FITROWS_BANDS && !std::getenv("VAG_SERIES_ROW_PER_WAVE")) {
         const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
         if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * FITROWS_SEGS * n)) return VAG_E_HIP;
@@ -1461,7 +1461,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         a.sp_table = c->d_sptab.as<double>();
         a.n_bands = n_bands;
         a.band_idx = c->d_bandidx.as<int>();
-        a.band_first = c->d_bandidx.as<int>() + SERIES_THREADS;
+        a.band_first = c->d_bandidx.as<int>() + FITROWS_MAX_POINTS;
         c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
         c->plan.interps = c->total_pairs * (long long)n;
         c->plan.flux_blocks = max_blocks * nb;
@@ -1474,7 +1474,10 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
             a.grid_nt = wpb;
             const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
-            hipLaunchKernelGGL(vag_flux_fit_rows_kernel, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(), st, a);
+            if (n_bands <= 4)
+                hipLaunchKernelGGL(vag_flux_fit_rows_kernel<4>, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(n), st, a);
+            else
+                hipLaunchKernelGGL(vag_flux_fit_rows_kernel<8>, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(n), st, a);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[4], st));
@@ -1530,7 +1533,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     a.grid_nt = grid_nt;
     a.chunk = chunk;
     a.band_idx = c->d_bandidx.as<int>();
-    a.band_first = c->d_bandidx.as<int>() + SERIES_THREADS;
+    a.band_first = c->d_bandidx.as<int>() + FITROWS_MAX_POINTS;
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
     a.params = d_params;
     a.meta = c->d_meta.as<VagGridMeta>();
@@ -2168,8 +2171,8 @@ int vag_flux_components4_batch(vag_ctx* c, const vag_model_params* params, int n
 // and returns the number of bands, 0 when the shared-node path does not apply.
 static int upload_series_bands(vag_ctx* c, const double* nu, int n) {
     constexpr int MAXB = SERIES_MAX_BANDS;
-    if (n <= 0 || n > SERIES_THREADS) return 0;
-    int buf[SERIES_THREADS + MAXB] = {};
+    if (n <= 0 || n > FITROWS_MAX_POINTS) return 0;
+    int buf[FITROWS_MAX_POINTS + MAXB] = {};
     double vals[MAXB];
     int nbands = 0;
     for (int s = 0; s < n; ++s) {
@@ -2178,7 +2181,7 @@ static int upload_series_bands(vag_ctx* c, const double* nu, int n) {
         if (b == nbands) {
             if (nbands == MAXB) return 0;
             vals[nbands] = nu[s];
-            buf[SERIES_THREADS + nbands] = s;
+            buf[FITROWS_MAX_POINTS + nbands] = s;
             ++nbands;
         }
         buf[s] = b;

@@ -24,19 +24,22 @@
 namespace vag {
 
 constexpr int FITROWS_WAVES = 4;   // wavefronts per workgroup (they only share the tables and the data points)
-constexpr int FITROWS_BANDS = 4;   // distinct frequencies handled (a fit with more goes through vag_flux_series_kernel)
+constexpr int FITROWS_BANDS = 8;   // distinct frequencies handled (instantiations for <= 4 and <= 8; more: vag_flux_series_kernel)
+constexpr int FITROWS_MAX_POINTS = 512;  // data points of a pass (SERIES_THREADS * SERIES_MAX_SLOTS)
 constexpr int FITROWS_ROWS = 64;   // rows per block = lanes of a wavefront
 constexpr int FITROWS_SEGS = 4;    // lattice segments per block: each (block, segment) is one partial sum of the model's tree
 #ifndef VAG_FITROWS_STRIPES
 #define VAG_FITROWS_STRIPES 4
 #endif
-constexpr int FITROWS_STRIPES = VAG_FITROWS_STRIPES;  // copies of a wavefront's per-point sums: lane L adds to copy L mod 4 (neighbouring
-                                                      // rows hit the same point in the same instruction; fewer collide per address)
+constexpr int FITROWS_STRIPES = VAG_FITROWS_STRIPES;  // copies of a wavefront's per-point sums for short data sets: lane L adds to copy
+                                                      // L mod 4 (neighbouring rows hit the same point in the same instruction)
+__host__ __device__ inline int fit_rows_npad(int n) { return (n + SERIES_THREADS - 1) / SERIES_THREADS * SERIES_THREADS; }
+__host__ __device__ inline int fit_rows_stripes(int n) { return n <= 128 ? FITROWS_STRIPES : 1; }
 
-// bytes of LDS of one workgroup
-__host__ __device__ inline size_t fit_rows_lds_bytes() {
-    return sizeof(double) * (SP_LDS_DOUBLES + SERIES_THREADS + SERIES_MAX_BANDS + FITROWS_WAVES * FITROWS_STRIPES * SERIES_THREADS) +
-           sizeof(int) * SERIES_THREADS;
+// bytes of LDS of one workgroup: tables, the points' times and bands, per wavefront [stripes][n_pad] sums
+__host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
+    const int np = fit_rows_npad(n);
+    return sizeof(double) * (SP_LDS_DOUBLES + np + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * fit_rows_stripes(n) * np) + sizeof(int) * np;
 }
 
 #ifndef VAG_HOST_DEBUG
@@ -45,7 +48,9 @@ VAG_DEV void lds_add_f64(double* p, double v) {
 }
 #endif
 
-// a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.
+// a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
+// registers per node.
+template <int NBMAX>
 __global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES)
 vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -56,21 +61,20 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
     const int W = a.grid_nt, blocks_per_wg = FITROWS_WAVES / W;
     if ((long long)blockIdx.x * blocks_per_wg * FITROWS_ROWS >= n_pairs) return;  // nothing of this model here (or model not evaluated)
-    double* s_tp = s_sp + SP_LDS_DOUBLES;             // [64] log2 of the data points' times, ascending; +inf beyond n
-    double* s_band = s_tp + SERIES_THREADS;           // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
-    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * FITROWS_STRIPES * SERIES_THREADS;  // this wavefront's per-point sums [stripe][64]
-    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * FITROWS_STRIPES * SERIES_THREADS);  // [64] band of each point
-    const int n = a.n, NB = a.n_bands;
+    const int n = a.n, NB = a.n_bands, NP = fit_rows_npad(n), stripes = fit_rows_stripes(n);
+    double* s_tp = s_sp + SP_LDS_DOUBLES;             // [NP] log2 of the data points' times, ascending; +inf beyond n
+    double* s_band = s_tp + NP;                       // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
+    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * stripes * NP;  // this wavefront's per-point sums [stripe][NP]
+    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * stripes * NP);  // [NP] band of each point
     const double lg2_1pz = Mp->lg2_1pz;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
-    if (threadIdx.x < SERIES_THREADS) {
-        s_tp[threadIdx.x] = (int)threadIdx.x < n ? a.lg2_t_obs[threadIdx.x] : INFINITY;
-        s_band_of[threadIdx.x] = (int)threadIdx.x < n ? a.band_idx[threadIdx.x] : 0;
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        s_tp[i] = i < n ? a.lg2_t_obs[i] : INFINITY;
+        s_band_of[i] = i < n ? a.band_idx[i] : 0;
     }
     if (threadIdx.x < NB) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]] + lg2_1pz;
-#pragma unroll
-    for (int c = 0; c < FITROWS_STRIPES; ++c) s_acc[c * SERIES_THREADS + lane] = 0;
-    double* my_acc = s_acc + (lane % FITROWS_STRIPES) * SERIES_THREADS;  // the copy this lane adds to
+    for (int i = lane; i < stripes * NP; i += SERIES_THREADS) s_acc[i] = 0;
+    double* my_acc = s_acc + (lane % stripes) * NP;  // the copy this lane adds to
     __syncthreads();  // the only workgroup-wide barrier
     // The lattice of a block is cut into FITROWS_SEGS segments, each with its own partial sum: the intervals between nodes are
     // independent, a segment starts from nothing but its first node.  W wavefronts share the block and take FITROWS_SEGS / W
@@ -92,12 +96,12 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     double* my_partial = a.partial + ((size_t)m * a.max_chunks + (size_t)vb * FITROWS_SEGS) * n;
     auto flush = [&](int s) {  // close segment s: its partial sum leaves, the accumulators start over
         wave_sync();
-        double sum = s_acc[lane];
-#pragma unroll
-        for (int c = 1; c < FITROWS_STRIPES; ++c) sum += s_acc[c * SERIES_THREADS + lane];  // fixed order
-        if (lane < n) my_partial[(size_t)s * n + lane] = sum;
-#pragma unroll
-        for (int c = 0; c < FITROWS_STRIPES; ++c) s_acc[c * SERIES_THREADS + lane] = 0;
+        for (int q = lane; q < NP; q += SERIES_THREADS) {
+            double sum = s_acc[q];
+            for (int c = 1; c < stripes; ++c) sum += s_acc[c * NP + q];  // fixed order
+            if (q < n) my_partial[(size_t)s * n + q] = sum;
+            for (int c = 0; c < stripes; ++c) s_acc[c * NP + q] = 0;
+        }
         wave_sync();
     };
     const int k_first = cut(seg), k_last = cut(seg_end);
@@ -129,14 +133,14 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         eat(row[VP_GAMMA * K + k], row[VP_U * K + k], row[VP_R * K + k], row[VP_TENG * K + k], lt, dop);
     };
     // boundary values B[b] = log2 I'(nu_b (1+z) / D_k) + log2(dOmega r^2 D^3) of node k for the fit's bands
-    auto boundary = [&](int k, double dop, double lr2, double (&B)[FITROWS_BANDS]) {
+    auto boundary = [&](int k, double dop, double lr2, double (&B)[NBMAX]) {
         SpecRegs regs;
 #pragma unroll
         for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
         regs.v[13] = lr2;
         const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
 #pragma unroll
-        for (int b = 0; b < FITROWS_BANDS; ++b)
+        for (int b = 0; b < NBMAX; ++b)
             if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_band[b] - dop, sp_tab) + geom;
     };
 
@@ -162,20 +166,20 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     // first one beyond node k_first when the wavefront starts inside the lattice: bisection over the 64 slots (+inf beyond n)
     int p = n;
     if (valid) {
-        int lo = -1, hi = SERIES_THREADS;  // s_tp[lo] fails, s_tp[hi] passes
-#pragma unroll
-        for (int it = 0; it < 7; ++it) {  // 65 candidates
-            const int mid = (lo + hi + 1) >> 1;
-            const double tm = s_tp[min(mid, SERIES_THREADS - 1)];
-            const bool pass = mid >= SERIES_THREADS || (k_first == 0 ? tm >= lt_a : tm > lt_a);
-            if (pass)
+        int lo = -1, hi = NP;  // s_tp[lo] fails, s_tp[hi] passes
+        while (hi - lo > 1) {  // NP + 1 candidates
+            const int mid = (lo + hi) >> 1;
+            const double tm = s_tp[mid];
+            if (k_first == 0 ? tm >= lt_a : tm > lt_a)
                 hi = mid;
             else
                 lo = mid;
         }
         p = min(hi, n);
     }
-    double Bprev[FITROWS_BANDS] = {0, 0, 0, 0}, Bcur[FITROWS_BANDS] = {0, 0, 0, 0};
+    double Bprev[NBMAX], Bcur[NBMAX];
+#pragma unroll
+    for (int b = 0; b < NBMAX; ++b) Bprev[b] = Bcur[b] = 0;
     {
         const bool need0 = p < n && s_tp[p] <= lt_b;  // the first interval holds a point: node k_first is one of its ends
         if (__ballot(need0) != 0 && need0) boundary(k_first, dop_a, lr2_a, Bprev);
@@ -196,7 +200,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         // leading ones that fit); more than four is rare
         double tn[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) tn[q] = p + q < n ? s_tp[min(p + q, SERIES_THREADS - 1)] : INFINITY;
+        for (int q = 0; q < 5; ++q) tn[q] = p + q < n ? s_tp[min(p + q, NP - 1)] : INFINITY;
         int cnt = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) cnt += tn[q] <= lt_b ? 1 : 0;
@@ -223,7 +227,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
                     const double t0 = s_tp[q], t1 = s_tp[q1];
                     double lo0 = Bprev[0], hi0 = Bcur[0], lo1 = Bprev[0], hi1 = Bcur[0];
 #pragma unroll
-                    for (int bb = 1; bb < FITROWS_BANDS; ++bb) {
+                    for (int bb = 1; bb < NBMAX; ++bb) {
                         lo0 = b0 == bb ? Bprev[bb] : lo0;
                         hi0 = b0 == bb ? Bcur[bb] : hi0;
                         lo1 = b1 == bb ? Bprev[bb] : lo1;
@@ -236,7 +240,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
                 }
             }
 #pragma unroll
-            for (int b = 0; b < FITROWS_BANDS; ++b) Bprev[b] = Bcur[b];
+            for (int b = 0; b < NBMAX; ++b) Bprev[b] = Bcur[b];
             VAG_FR_MARK(c_int);
         }
         p = pe;
