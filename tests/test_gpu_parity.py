@@ -783,8 +783,8 @@ def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
     """A fit's few bands (host-pointer series call, n <= 64): the spectrum is evaluated once per (band, lattice node) and
     shared by the points (observer.h:447-538); the device-pointer entry does not know the frequencies and evaluates per
     point.  Same evaluator and interpolation arithmetic: the two must agree to the last bit where both run in
-    vag_flux_series_kernel; the plain synchrotron fit goes through vag_flux_fit_rows_kernel (a row per lane, another
-    summation order) and agrees to rounding."""
+    vag_flux_series_kernel (spreading jets); the other fits go through vag_flux_fit_rows_kernel (a row per lane, another
+    summation order) and agree to rounding."""
     import torch
     lib, h = eng
     t, nu = configs.c4_mock_data()
@@ -798,7 +798,7 @@ def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
     _lib.check(lib.vag_flux_density_batch_dev(h, d_p.data_ptr(), 1, d_t.data_ptr(), d_nu.data_ptr(), t.size, d_out.data_ptr()))
     _lib.check(lib.vag_ctx_synchronize(h))
     per_point = d_out.cpu().numpy()[0]
-    if "ssc" in kw or kw.get("spreading"):
+    if kw.get("spreading"):
         assert np.array_equal(shared, per_point)
     else:
         np.testing.assert_allclose(shared, per_point, rtol=1e-13)

@@ -1438,7 +1438,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
     // A fit's shape (plain synchrotron, <= 64 points in a few bands): the row-per-lane kernel (vag_fit_rows.h)
-    if (mode == FLUX_SYN && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
+    if (mode != FLUX_FUSED && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
         n_bands <= FITROWS_BANDS && !std::getenv("VAG_SERIES_ROW_PER_WAVE")) {
         const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
         if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * FITROWS_SEGS * n)) return VAG_E_HIP;
@@ -1462,6 +1462,9 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         a.n_bands = n_bands;
         a.band_idx = c->d_bandidx.as<int>();
         a.band_first = c->d_bandidx.as<int>() + FITROWS_MAX_POINTS;
+        a.cellq = c->d_cellq.as<double>();
+        a.ictab = c->d_ictab.as<double>();
+        a.ic_status = c->d_icstatus.as<int>();
         c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
         c->plan.interps = c->total_pairs * (long long)n;
         c->plan.flux_blocks = max_blocks * nb;
@@ -1474,10 +1477,22 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
             a.grid_nt = wpb;
             const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
-            if (n_bands <= 4)
-                hipLaunchKernelGGL(vag_flux_fit_rows_kernel<4>, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(n), st, a);
+            const dim3 g(wgs, nb), b(SERIES_THREADS * FITROWS_WAVES);
+            const size_t lds = fit_rows_lds_bytes(n);
+#define VAG_FIT_LAUNCH(M_)                                                                      \
+    do {                                                                                        \
+        if (n_bands <= 4)                                                                       \
+            hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 4>), g, b, lds, st, a);             \
+        else                                                                                    \
+            hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 8>), g, b, lds, st, a);             \
+    } while (0)
+            if (mode == FLUX_SYN_IC)
+                VAG_FIT_LAUNCH(FLUX_SYN_IC);
+            else if (mode == FLUX_SSC)
+                VAG_FIT_LAUNCH(FLUX_SSC);
             else
-                hipLaunchKernelGGL(vag_flux_fit_rows_kernel<8>, dim3(wgs, nb), dim3(SERIES_THREADS * FITROWS_WAVES), fit_rows_lds_bytes(n), st, a);
+                VAG_FIT_LAUNCH(FLUX_SYN);
+#undef VAG_FIT_LAUNCH
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[4], st));

@@ -19,6 +19,7 @@
 //
 // Reference: Observer::specific_flux_series (src/core/observer.h:447-538).
 #pragma once
+#include "vag_ic_kernels.h"
 #include "vag_kernels.h"
 
 namespace vag {
@@ -50,7 +51,7 @@ VAG_DEV void lds_add_f64(double* p, double v) {
 
 // a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
 // registers per node.
-template <int NBMAX>
+template <int MODE, int NBMAX>
 __global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES)
 vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
@@ -120,7 +121,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * Mp->sin_obs + gth[j] * Mp->cos_obs;
     const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
     const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-    const double* row = a.cellpar + (a.lay.cell_off[m] + (long long)rep * K) * VAG_NPAR;  // [VAG_NPAR][K]
+    const long long cell0 = a.lay.cell_off[m] + (long long)rep * K;
+    const double* row = a.cellpar + cell0 * VAG_NPAR;  // [VAG_NPAR][K]
+    int breach = 0;
 
     // EAT quantities of node k: log2 observer time, log2 Doppler factor, 2 log2 r
     // (explicit fma: a wavefront that starts at a node and one that arrives there must form these two sums the same way)
@@ -134,14 +137,35 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     };
     // boundary values B[b] = log2 I'(nu_b (1+z) / D_k) + log2(dOmega r^2 D^3) of node k for the fit's bands
     auto boundary = [&](int k, double dop, double lr2, double (&B)[NBMAX]) {
-        SpecRegs regs;
-#pragma unroll
-        for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
-        regs.v[13] = lr2;
         const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
+        if constexpr (MODE == FLUX_SSC) {  // SSC tables (vag_ic_kernels.h)
+            const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
+            const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
 #pragma unroll
-        for (int b = 0; b < NBMAX; ++b)
-            if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_band[b] - dop, sp_tab) + geom;
+            for (int b = 0; b < NBMAX; ++b)
+                if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_band[b] - dop, &breach) + geom;
+        } else {
+            SpecRegs regs;
+#pragma unroll
+            for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
+            regs.v[13] = lr2;
+            if constexpr (MODE == FLUX_SYN_IC) {  // synchrotron with the IC correction above the cooling break
+                const double* cq = a.cellq + cell0 * FLUX_NQ + k;
+                IcQ q;
+                q.head(cq, K);
+                bool any = false;
+#pragma unroll
+                for (int b = 0; b < NBMAX; ++b) any = any || (b < NB && q.applies(s_band[b] - dop));
+                if (any) q.rest(cq, K);
+#pragma unroll
+                for (int b = 0; b < NBMAX; ++b)
+                    if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(s_band[b] - dop), q, sc, s_band[b] - dop, sp_tab) + geom;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NBMAX; ++b)
+                    if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_band[b] - dop, sp_tab) + geom;
+            }
+        }
     };
 
 #ifdef VAG_SERIES_STAMPS  // developer aid: cycles of one wavefront per part of a step
@@ -246,6 +270,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         p = pe;
         lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
         while (seg < seg_end && cut(seg + 1) <= k) flush(seg++);  // step k closes segment(s)
+    }
+    if constexpr (MODE == FLUX_SSC) {
+        if (breach) atomicOr(a.ic_status + m, 2);
     }
 #ifdef VAG_SERIES_STAMPS
     if (m == 0 && vb == 0 && lane == 0 && wseg == 0)
