@@ -782,9 +782,8 @@ def test_non_axisymmetric_models_match_oracle(eng, oracle, name):
 def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
     """A fit's few bands (host-pointer series call, n <= 64): the spectrum is evaluated once per (band, lattice node) and
     shared by the points (observer.h:447-538); the device-pointer entry does not know the frequencies and evaluates per
-    point.  Same evaluator and interpolation arithmetic: the two must agree to the last bit where both run in
-    vag_flux_series_kernel (spreading jets); the other fits go through vag_flux_fit_rows_kernel (a row per lane, another
-    summation order) and agree to rounding."""
+    point in vag_flux_series_kernel.  The host-pointer call goes through vag_flux_fit_rows_kernel (a row per lane): same
+    evaluators and interpolation arithmetic, another summation order -- the two agree to rounding."""
     import torch
     lib, h = eng
     t, nu = configs.c4_mock_data()
@@ -798,10 +797,7 @@ def test_shared_node_series_path_is_bitwise_the_per_point_path(eng, oracle, kw):
     _lib.check(lib.vag_flux_density_batch_dev(h, d_p.data_ptr(), 1, d_t.data_ptr(), d_nu.data_ptr(), t.size, d_out.data_ptr()))
     _lib.check(lib.vag_ctx_synchronize(h))
     per_point = d_out.cpu().numpy()[0]
-    if kw.get("spreading"):
-        assert np.array_equal(shared, per_point)
-    else:
-        np.testing.assert_allclose(shared, per_point, rtol=1e-13)
+    np.testing.assert_allclose(shared, per_point, rtol=1e-13)
     assert shared.max() > 0
     assert_close(shared, oracle.flux_density(prm, t, nu), rtol=5e-6)
     # all-distinct frequencies: nothing to share, the call silently takes the per-point path

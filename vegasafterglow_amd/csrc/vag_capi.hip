@@ -1438,7 +1438,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     if (n > SERIES_THREADS * SERIES_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
     // A fit's shape (plain synchrotron, <= 64 points in a few bands): the row-per-lane kernel (vag_fit_rows.h)
-    if (mode != FLUX_FUSED && !(c->batch_flags & VAG_FLAG_SPREADING) && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
+    if (mode != FLUX_FUSED && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
         n_bands <= FITROWS_BANDS && !std::getenv("VAG_SERIES_ROW_PER_WAVE")) {
         const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
         if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * FITROWS_SEGS * n)) return VAG_E_HIP;
@@ -1479,9 +1479,15 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
             const dim3 g(wgs, nb), b(SERIES_THREADS * FITROWS_WAVES);
             const size_t lds = fit_rows_lds_bytes(n);
+            const bool spread = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
+            a.cellgeo = c->d_cellgeo.as<double>();
 #define VAG_FIT_LAUNCH(M_)                                                                      \
     do {                                                                                        \
-        if (n_bands <= 4)                                                                       \
+        if (spread && n_bands <= 4)                                                             \
+            hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 4, true>), g, b, lds, st, a);       \
+        else if (spread)                                                                        \
+            hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 8, true>), g, b, lds, st, a);       \
+        else if (n_bands <= 4)                                                                  \
             hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 4>), g, b, lds, st, a);             \
         else                                                                                    \
             hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 8>), g, b, lds, st, a);             \

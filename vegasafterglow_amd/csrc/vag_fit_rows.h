@@ -51,8 +51,10 @@ VAG_DEV void lds_add_f64(double* p, double v) {
 
 // a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
 // registers per node.
-template <int MODE, int NBMAX>
-__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES)
+// SPREAD: a spreading jet's polar angle evolves along the lattice, so the viewing cosine and the solid angle are per node
+// (calc_t_obs + calc_solid_angle, observer.cpp:51-141; a.cellgeo holds cos theta, sin theta, log2|dcos| per cell).
+template <int MODE, int NBMAX, bool SPREAD = false>
+__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, 3)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
 vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -118,26 +120,40 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
     const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j];
-    const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * Mp->sin_obs + gth[j] * Mp->cos_obs;
+    const double cos_phi = gph[i], lg2_dphi = gph[VAG_MAX_PHI + i];
+    const double cos_v = gth[VAG_MAX_THETA + j] * cos_phi * Mp->sin_obs + gth[j] * Mp->cos_obs;  // (non-spreading rows)
     const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + lg2_dphi;
     const long long cell0 = a.lay.cell_off[m] + (long long)rep * K;
     const double* row = a.cellpar + cell0 * VAG_NPAR;  // [VAG_NPAR][K]
+    const double* geo = SPREAD ? a.cellgeo + cell0 * 3 : nullptr;  // [3][K]
+    const double sin_obs = Mp->sin_obs, cos_obs = Mp->cos_obs;
     int breach = 0;
 
     // EAT quantities of node k: log2 observer time, log2 Doppler factor, 2 log2 r
-    // (explicit fma: a wavefront that starts at a node and one that arrives there must form these two sums the same way)
-    auto eat = [&](double G, double u, double r, double teng, double& lt, double& dop) {
-        dop = -log2_tab(fma(-u, cos_v, G), lg_tab);
-        lt = log2_tab(fma(t_coeff, r, teng * one_plus_z), lg_tab);
+    // EAT quantities of a node: log2 observer time, log2 Doppler factor, log2 solid angle (explicit fma: a wavefront that starts
+    // at a node and one that arrives there must form these sums the same way)
+    auto eat = [&](double G, double u, double r, double teng, double g_cos, double g_sin, double g_ldc, double& lt, double& dop,
+                   double& ldo) {
+        if constexpr (SPREAD) {
+            const double cv = fma(g_sin * cos_phi, sin_obs, g_cos * cos_obs);
+            dop = -log2_tab(fma(-u, cv, G), lg_tab);
+            lt = log2_tab(fma((1 - cv) * r, 1.0 / C_C, teng) * one_plus_z, lg_tab);
+            ldo = g_ldc + lg2_dphi;
+        } else {
+            dop = -log2_tab(fma(-u, cos_v, G), lg_tab);
+            lt = log2_tab(fma(t_coeff, r, teng * one_plus_z), lg_tab);
+            ldo = lg2_dOmega;
+        }
     };
-    auto node = [&](int k, double& lt, double& dop, double& lr2) {
+    auto node = [&](int k, double& lt, double& dop, double& lr2, double& ldo) {
         lr2 = row[VP_LG2_R2 * K + k];
-        eat(row[VP_GAMMA * K + k], row[VP_U * K + k], row[VP_R * K + k], row[VP_TENG * K + k], lt, dop);
+        const double gc = SPREAD ? geo[k] : 0, gs = SPREAD ? geo[K + k] : 0, gl = SPREAD ? geo[2 * K + k] : 0;
+        eat(row[VP_GAMMA * K + k], row[VP_U * K + k], row[VP_R * K + k], row[VP_TENG * K + k], gc, gs, gl, lt, dop, ldo);
     };
     // boundary values B[b] = log2 I'(nu_b (1+z) / D_k) + log2(dOmega r^2 D^3) of node k for the fit's bands
-    auto boundary = [&](int k, double dop, double lr2, double (&B)[NBMAX]) {
-        const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
+    auto boundary = [&](int k, double dop, double lr2, double ldo, double (&B)[NBMAX]) {
+        const double geom = ((SPREAD ? ldo : lg2_dOmega) + lr2) + 3.0 * dop;  // (non-spreading: the per-node copies stay dead)
         if constexpr (MODE == FLUX_SSC) {  // SSC tables (vag_ic_kernels.h)
             const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
             const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
@@ -175,15 +191,16 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
 #else
 #define VAG_FR_MARK(acc_) do { } while (0)
 #endif
-    double lt_a, dop_a, lr2_a, lt_b, dop_b, lr2_b;
-    node(k_first, lt_a, dop_a, lr2_a);
-    node(k_first + 1, lt_b, dop_b, lr2_b);
-    // the five EAT members of the node after next are requested a whole step before they are used
-    double nG = 1, nu_ = 0, nr = 0, nteng = 1, nlr2 = 0;
+    double lt_a, dop_a, lr2_a, ldo_a, lt_b, dop_b, lr2_b, ldo_b;
+    node(k_first, lt_a, dop_a, lr2_a, ldo_a);
+    node(k_first + 1, lt_b, dop_b, lr2_b, ldo_b);
+    // the EAT members of the node after next are requested a whole step before they are used
+    double nG = 1, nu_ = 0, nr = 0, nteng = 1, nlr2 = 0, ngc = 0, ngs = 0, ngl = 0;
     auto request = [&](int k) {
         const int kk = k < K ? k : K - 1;
         nG = row[VP_GAMMA * K + kk], nu_ = row[VP_U * K + kk], nr = row[VP_R * K + kk], nteng = row[VP_TENG * K + kk];
         nlr2 = row[VP_LG2_R2 * K + kk];
+        if constexpr (SPREAD) ngc = geo[kk], ngs = geo[K + kk], ngl = geo[2 * K + kk];
     };
     request(k_first + 2);
     // cursor into the sorted points: the first one at or beyond node 0 (a point equal to node 0 belongs to interval 0), or the
@@ -206,17 +223,17 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     for (int b = 0; b < NBMAX; ++b) Bprev[b] = Bcur[b] = 0;
     {
         const bool need0 = p < n && s_tp[p] <= lt_b;  // the first interval holds a point: node k_first is one of its ends
-        if (__ballot(need0) != 0 && need0) boundary(k_first, dop_a, lr2_a, Bprev);
+        if (__ballot(need0) != 0 && need0) boundary(k_first, dop_a, lr2_a, ldo_a, Bprev);
     }
     while (cut(seg + 1) <= k_first) flush(seg++);  // leading segments without an interval
     VAG_FR_MARK(c_pro);
     for (int k = k_first + 1; k <= k_last; ++k) {
         // node k + 1, one step ahead: its time tells whether node k closes the interval before a point (beyond this wavefront's
         // last node the next wavefront evaluates it as its own first)
-        double lt_c = -INFINITY, dop_c = 0, lr2_c = 0;
+        double lt_c = -INFINITY, dop_c = 0, lr2_c = 0, ldo_c = 0;
         if (k + 1 <= k_last) {
             lr2_c = nlr2;
-            eat(nG, nu_, nr, nteng, lt_c, dop_c);
+            eat(nG, nu_, nr, nteng, ngc, ngs, ngl, lt_c, dop_c, ldo_c);
         }
         request(k + 2);
         VAG_FR_MARK(c_node);
@@ -237,7 +254,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         const bool need = pe > p || t_next <= lt_c;
         VAG_FR_MARK(c_scan);
         if (__ballot(need) != 0) {
-            if (need) boundary(k, dop_b, lr2_b, Bcur);
+            if (need) boundary(k, dop_b, lr2_b, ldo_b, Bcur);
 #ifdef VAG_SERIES_STAMPS
             ++n_bnd;
 #endif
@@ -268,7 +285,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
             VAG_FR_MARK(c_int);
         }
         p = pe;
-        lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
+        lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c, ldo_b = ldo_c;
         while (seg < seg_end && cut(seg + 1) <= k) flush(seg++);  // step k closes segment(s)
     }
     if constexpr (MODE == FLUX_SSC) {

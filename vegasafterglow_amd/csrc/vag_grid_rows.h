@@ -30,7 +30,7 @@ __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
 // a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
 // 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
 template <int MODE>
-__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES)
+__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, 3)  // 168 VGPRs: three wavefronts per SIMD
 vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
