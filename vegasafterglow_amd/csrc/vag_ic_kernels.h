@@ -397,6 +397,14 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                      unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
                      int band_stride) {
     const long long c = blockIdx.x;
+#ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
+    long long c_t[8];
+    int c_n = 0;
+    c_t[c_n++] = __builtin_readcyclecounter();
+#define VAG_IC_MARK() do { __builtin_amdgcn_s_waitcnt(0); c_t[c_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VAG_IC_MARK() do { } while (0)
+#endif
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int lane = threadIdx.x;
     __shared__ IcShared sh;
@@ -481,6 +489,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     }
     for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_sat(lg2_g0 + step * (double)i);
     __syncthreads();
+    VAG_IC_MARK();  // 1: prologue
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 4) { tab[0] = 0; return; }  // prologue only: loads, lattice parameters, lattice nodes
 #endif
@@ -502,6 +511,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         sh.lg2fv[j] = f > 0 ? log2_fast(f) : -INFINITY;
     }
     __syncthreads();
+    VAG_IC_MARK();  // 2: sampled distributions
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 3) { tab[0] = 0; return; }  // ... + the sampled electron and seed distributions
 #endif
@@ -523,6 +533,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     suffix_scan(sh.ex, sh.cdf_th, nu_last, lane);
     __syncthreads();
+    VAG_IC_MARK();  // 3: Thomson CDF
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
 #endif
@@ -615,6 +626,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         T0 = c1 + term0;
         T1 = from_lane_below(c0) + term1;
     };
+    VAG_IC_MARK();  // 4: KN lattice, split indices
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 1) g_size = 0;
 #endif
@@ -658,6 +670,12 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             }
         }
     }
+    VAG_IC_MARK();  // 5: energy loop
+#ifdef VAG_IC_STAMPS
+    if (lane == 0 && (c % 70001) == 0)
+        printf("ic cell %lld: g %d nu %d out %d  cycles: prologue %lld  sampling %lld  thomson cdf %lld  kn lattice %lld  energies %lld\n", c, g_size,
+               nu_size, n_ic, c_t[1] - c_t[0], c_t[2] - c_t[1], c_t[3] - c_t[2], c_t[4] - c_t[3], c_t[5] - c_t[4]);
+#endif
     // log2 table on the output lattice, inverse-compton.h:595-606
     const double lg2_scale = log2(0.25 * C_SIGMAT);
 #pragma unroll
