@@ -275,6 +275,14 @@ struct SeriesOcc {
 };
 struct vag_ctx {
     int device = 0;
+    // Likelihood calls evaluate the walkers in descending order of the cost the SAME batch position had in the previous call
+    // (dispatch is in batch order: expensive walkers last leave the GPU draining, and neighbours of similar cost diverge less):
+    // d_order[cur] maps evaluation slot -> walker; ln L, costs and counters come back in walker order.  A walker's ln L does
+    // not depend on its slot, so the result is the same bits.
+    DevBuf d_order[2], d_cost_f;  // d_cost_f: per-slot cost of the last batch (written with the batch plan by the grid kernel)
+    int order_cur = 0, order_nb = 0;  // order_nb: batch size d_order[order_cur] was computed for (0: none)
+    bool order_next = false, order_active = false;  // the next / the last model-stage run is in evaluation-slot order
+    const int* last_order = nullptr;                // ... and the order it used
     bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > 320 theta / > 640 phi nodes)
     int grid_large_idle = 0;  // consecutive batches that would have fitted the small one
     std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
@@ -712,8 +720,11 @@ int dyn_rows_per_wave(int rows) {
 // Stage 1-3: adaptive grid -> blast-wave dynamics -> per-cell radiation, for nb models whose
 // parameters are already in HBM.  d_tminmax holds the observer-time extrema [s].
 int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool want_details) {
+    c->order_active = c->order_next;  // only a likelihood call that permuted its walkers sets order_next (vag_ctx::d_order)
+    c->order_next = false;
     hipStream_t st = c->stream;
     if (c->d_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
+    if (c->d_cost_f.ensure(sizeof(float) * nb)) return VAG_E_HIP;
     if (c->d_phi.ensure(sizeof(double) * (size_t)nb * VAG_MAX_PHI)) return VAG_E_HIP;
     if (c->d_theta.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
     if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
@@ -771,7 +782,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
                            c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
                            cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
-                           spec ? c->hint.dyn_class : 0);
+                           spec ? c->hint.dyn_class : 0, c->d_cost_f.as<float>());
     };
     launch_grid(c->grid_large);
     ps_grid.reset();
@@ -2323,12 +2334,28 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
 // The front of a likelihood call, one launch: bounds mask and ln prior (log_prob_batch, fitting/samplers.py:72-91), the
 // transformer of fitting/utils.py:110-135 (theta[nb][ndim] -> params[nb], 10^theta for log-scale parameters), A_V per walker,
 // and -- block 0 -- log2 of the point data's times / frequencies and their time extrema for the grid stage.
+// order_out[rank] = walker, ranks by descending cost of the walker in THIS call (cost[] is in evaluation-slot order: order_in maps
+// a slot back to its walker; null = identity).  Ranking by counting, one wavefront per slot: the lanes compare it with all others.
+__global__ void __launch_bounds__(256)
+vag_order_kernel(const float* __restrict__ cost, const int* __restrict__ order_in, int nb, int* __restrict__ order_out) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= nb) return;
+    const float mine = cost[m];
+    int rank = 0;
+    for (int i0 = 0; i0 < nb; i0 += 64) {
+        const int i = i0 + lane;
+        const float c = i < nb ? cost[i] : -1.0f;
+        rank += __popcll(__ballot(c > mine || (c == mine && i < m)));
+    }
+    if (lane == 0) order_out[rank] = order_in ? order_in[m] : m;
+}
+
 __global__ void __launch_bounds__(128)
 vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, int nb, int ndim, const double* __restrict__ prior,
                      int use_priors, double a_v_fixed, vag_model_params* __restrict__ out, double* __restrict__ a_v,
                      double* __restrict__ ln_prior, int* __restrict__ fitstat, const double* __restrict__ t, int n,
                      const double* __restrict__ nu, double* __restrict__ lg2_t, double* __restrict__ lg2_nu,
-                     double* __restrict__ tminmax) {
+                     double* __restrict__ tminmax, const int* __restrict__ order /* evaluation slot -> walker, or null */) {
     const int* slot = reinterpret_cast<const int*>(prior + 64);
     const int* is_log = slot + 16;
     const int* kind = slot + 32;
@@ -2349,8 +2376,9 @@ vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, in
     double* f = &out[b].theta_c;
     double av = a_v_fixed, lp = 0;
     bool inside = true;
+    const int walker = order ? order[b] : b;
     for (int d = 0; d < ndim; ++d) {
-        const double v = theta[(size_t)b * ndim + d];
+        const double v = theta[(size_t)walker * ndim + d];
         if (use_priors) {
             const double lo = prior[d], hi = prior[16 + d];
             inside = inside && (v >= lo) && (v <= hi);
@@ -2390,7 +2418,8 @@ vag_fit_back_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const 
                     const double* __restrict__ a_v, const VagGridMeta* __restrict__ meta, const int* __restrict__ row_status,
                     const int* __restrict__ row_off, const int* __restrict__ ic_status /* or null */, double* __restrict__ chi2,
                     int* __restrict__ valid, const double* __restrict__ ln_prior, int first, int last, double* __restrict__ out,
-                    int* __restrict__ fitstat /* [0] walkers scored -inf, [1] of those: SSC table failures */) {
+                    int* __restrict__ fitstat /* [0] walkers scored -inf, [1] of those: SSC table failures */,
+                    const int* __restrict__ order /* evaluation slot -> walker, or null */) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const double av = (ext != nullptr) ? a_v[m] : 0.0;
     const bool grid_ok = meta[m].status == 0;
@@ -2418,7 +2447,7 @@ vag_fit_back_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const 
         if (last) {
             const double lp = ln_prior[m];
             const bool fin = ok && isfinite(acc) && lp > -INFINITY;
-            out[m] = fin ? -0.5 * acc + lp : -INFINITY;
+            out[order ? order[m] : m] = fin ? -0.5 * acc + lp : -INFINITY;
             if (!fin) atomicAdd(fitstat, 1);
         }
     }
@@ -2441,10 +2470,23 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
     double* d = c->d_fit.as<double>();
     const double* d_prior = d + c->fit_prior_off;
     vag_model_params* d_params = c->d_params.as<vag_model_params>();
+    // evaluation order: by the costs of the previous call with this batch size (see vag_ctx::d_order)
+    const bool can_order = nb >= 64 && nb <= 8192 && !std::getenv("VAG_NO_ORDER");
+    const int* d_order = (can_order && c->order_nb == nb) ? c->d_order[c->order_cur].as<int>() : nullptr;
     hipLaunchKernelGGL(vag_fit_front_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, spec->base, d_theta, nb, ndim, d_prior,
                        spec->use_priors, spec->a_v_fixed, d_params, d_av, d_lp, c->d_fitstat.as<int>(), d, n, d + n,
-                       c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), c->d_tminmax.as<double>());
+                       c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), c->d_tminmax.as<double>(), d_order);
     HIPCHK(hipGetLastError());
+    bool order_made = false;
+    auto make_order = [&]() -> int {  // once per call, from the first pass's grids: the order the NEXT call evaluates in
+        if (!can_order || order_made) return VAG_OK;
+        order_made = true;
+        DevBuf& nxt = c->d_order[c->order_cur ^ 1];
+        if (nxt.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
+        hipLaunchKernelGGL(vag_order_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, c->d_cost_f.as<float>(), d_order, nb, nxt.as<int>());
+        HIPCHK(hipGetLastError());
+        return VAG_OK;
+    };
     const int n_pass = (n > 0 ? 1 : 0) + spec->n_bands;
     int pass = 0, n_cap = 0, n_inv = 0;  // per-pass rejection counts: the call reports the worst pass
     // the SSC tables of a pass report per-model failures in d_icstatus: in a fit they invalidate the walker, they do not raise
@@ -2453,8 +2495,9 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
         hipLaunchKernelGGL(vag_fit_back_kernel, dim3(nb), dim3(64), 0, st, flux, npts, lnf, lne, w, ext, d_av,
                            c->d_meta.as<VagGridMeta>(), c->d_row_status.as<int>(), c->d_row_off.as<int>(),
                            (ssc && c->d_icstatus.p) ? c->d_icstatus.as<int>() : nullptr, d_chi2, c->d_valid.as<int>(), d_lp,
-                           pass == 0 ? 1 : 0, pass == n_pass - 1 ? 1 : 0, d_out, c->d_fitstat.as<int>());
+                           pass == 0 ? 1 : 0, pass == n_pass - 1 ? 1 : 0, d_out, c->d_fitstat.as<int>(), d_order);
         HIPCHK(hipGetLastError());
+        if (int rco = make_order()) return rco;
         ++pass;
         n_cap = std::max(n_cap, c->plan.n_models_capacity);
         n_inv = std::max(n_inv, c->plan.n_models_invalid);
@@ -2464,6 +2507,8 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
     if (n > 0) {  // point data: one (t, nu) series per walker (fitter.py:510-522)
         if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * n)) return VAG_E_HIP;
         c->allow_spec = try_spec;
+        c->order_next = d_order != nullptr;
+        c->last_order = d_order;
         rc = run_model_stages(c, d_params, nb, false);
         c->allow_spec = false;
         if (rc == VAG_OK) rc = series_request(c, d_params, nb, n, c->d_series_flux.as<double>(), upload_series_bands(c, spec->nu, n));
@@ -2487,6 +2532,8 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
         if (c->d_series_flux.ensure(sizeof(double) * (size_t)nb * std::max(bd.n, n))) return VAG_E_HIP;
         double* db = d + off;
         off += 4 * (size_t)bd.n;
+        c->order_next = d_order != nullptr;
+        c->last_order = d_order;
         rc = band_request_dev(c, d_params, nb, db, bd.n, bd.nu_min, bd.nu_max, bd.num_points, c->d_series_flux.as<double>(), nullptr);
         if (rc == VAG_OK) rc = back(c->d_series_flux.as<double>(), bd.n, db + bd.n, db + 2 * (size_t)bd.n, db + 3 * (size_t)bd.n, nullptr);
     }
@@ -2494,6 +2541,12 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
     c->plan.n_models_capacity = n_cap;
     c->plan.n_models_invalid = n_inv;
     c->fit_stats_pending = true;
+    if (rc == VAG_OK && order_made) {  // the order computed from this call's grids serves the next call of this size
+        c->order_cur ^= 1;
+        c->order_nb = nb;
+    } else if (rc != VAG_OK) {
+        c->order_nb = 0;
+    }
     return rc;
 }
 
@@ -2508,18 +2561,20 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     return rc;
 }
 
-__global__ void vag_model_cost_kernel(const VagGridMeta* __restrict__ meta, int nb, double* __restrict__ cost) {
+__global__ void vag_model_cost_kernel(const VagGridMeta* __restrict__ meta, int nb, double* __restrict__ cost,
+                                      const int* __restrict__ order /* evaluation slot -> walker of the last batch, or null */) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= nb) return;
     const VagGridMeta M = meta[m];
-    cost[m] = M.status == 0 ? (double)M.n_theta * (double)M.n_phi_eff * (double)M.n_t : 0.0;
+    cost[order ? order[m] : m] = M.status == 0 ? (double)M.n_theta * (double)M.n_phi_eff * (double)M.n_t : 0.0;
 }
 
 int vag_last_model_costs_dev(vag_ctx* c, int nb, double* d_cost) {
     if (!c || !d_cost) return set_err(VAG_E_INVALID, "null context or buffer");
     if (nb <= 0 || nb != c->nb || !c->d_meta.p) return set_err(VAG_E_INVALID, "no batch of %d models has been evaluated on this context", nb);
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(vag_model_cost_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb, d_cost);
+    hipLaunchKernelGGL(vag_model_cost_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb, d_cost,
+                       c->order_active ? c->last_order : nullptr);
     HIPCHK(hipGetLastError());
     return VAG_OK;
 }

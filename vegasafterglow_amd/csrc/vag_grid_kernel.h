@@ -308,13 +308,15 @@ VAG_DEV void invert_cdf(const SH& sh, int num, bool midpoint, double* out) {
 // nothing; the host sees `overflow` at the end of the call and repeats it.
 VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off, long long* __restrict__ cell_off,
                             VagDevPlan* __restrict__ plan, VagDevPlan* host_plan /* pinned, host-mapped */, int seq, int cap_rows,
-                            long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn) {
+                            long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn,
+                            float* __restrict__ cost /* [nb]: (theta, phi, t) cells of each model, 0 for one not evaluated */) {
     const int t = threadIdx.x;
     const int per = (nb + WAVE - 1) / WAVE, m0 = min(nb, t * per), m1 = min(nb, m0 + per);
     long long cells = 0, pairs = 0, eat = 0;
     int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_inv = 0, n_cap = 0, first = -1, mixed = 0, dyn = 0;
     for (int m = m0; m < m1; ++m) {
         const VagGridMeta M = meta[m];
+        cost[m] = M.status == 0 ? (float)M.n_theta * (float)M.n_phi_eff * (float)M.n_t : 0.0f;
         if (M.status == 0) {
             rows += M.n_reps;
             cells += (long long)M.n_reps * M.n_t;
@@ -1025,7 +1027,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 double* __restrict__ g_geo_th, double* __restrict__ g_geo_ph, int* __restrict__ fail,
                 int* __restrict__ done_counter /* zero between launches */, int* __restrict__ row_off,
                 long long* __restrict__ cell_off, VagDevPlan* __restrict__ plan, VagDevPlan* host_plan, int seq, int cap_rows,
-                long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn) {
+                long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn, float* __restrict__ cost) {
     using Shared = typename std::conditional<LARGE, GridSharedT<VAG_MAX_THETA, VAG_MAX_PHI>, GridSharedT<VAG_GRID_THETA, VAG_GRID_PHI>>::type;
     __shared__ Shared sh;  // declared here, not in grid_model: LDS of a device function is charged to every kernel of the module
     if ((int)blockIdx.x < nb)
@@ -1038,7 +1040,7 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     if (!s_last) return;
     __threadfence();
     if (threadIdx.x == 0) *done_counter = 0;
-    plan_scan_wave(meta, nb, row_off, cell_off, plan, host_plan, seq, cap_rows, cap_cells, cap_k, cap_pairs, expect_flags, expect_dyn);
+    plan_scan_wave(meta, nb, row_off, cell_off, plan, host_plan, seq, cap_rows, cap_cells, cap_k, cap_pairs, expect_flags, expect_dyn, cost);
 }
 
 }  // namespace vag
