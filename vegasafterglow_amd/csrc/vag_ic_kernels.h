@@ -1,5 +1,7 @@
 // vag_ic_kernels.h -- kernels of the SSC / inverse-Compton tier.
 #pragma once
+#include <type_traits>
+
 #include "vag_ic.h"
 #include "vag_kernels.h"
 
@@ -388,6 +390,9 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 #ifndef VAG_IC_WAVES
 #define VAG_IC_WAVES 4
 #endif
+#ifndef VAG_IC_ONE_NODE_MAX
+#define VAG_IC_ONE_NODE_MAX 64  // seed lattices up to this size take one node per lane (developer builds: 0 = always two)
+#endif
 __global__ void __launch_bounds__(64, VAG_IC_WAVES)
 vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                      long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
@@ -443,7 +448,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double nu_ic_base = 4 * IC_X0 * nu_M * gamma_M * gamma_M;
     const double nu_ic_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
     double nu_IC_max = nu_ic_cut * 2.0;
-    const double theory_max = log2(nu_IC_max), theory_min = log2(nu_IC_min);
+    const double theory_max = log2_fast(nu_IC_max), theory_min = log2_fast(nu_IC_min);
     nu_IC_min = dmax(nu_IC_min, dmin(nu_eval_min / 4.0, nu_IC_max / 16.0));
     nu_IC_max = dmin(nu_IC_max, dmax(nu_eval_max * 4.0, nu_IC_min * 16.0));
     auto posfin = [](double x) { return isfinite(x) && x > 0; };
@@ -458,14 +463,14 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     }
     // initialize_grids, inverse-compton.h:340-369
     const double step = 2 * IC_Q;
-    const double lg2_nu0 = log2(nu_min), lg2_g0 = log2(gamma_min);
-    int nu_size = (int)ceil((log2(nu_max) - lg2_nu0) / step) + 1;
-    int g_size = (int)ceil((log2(gamma_max) - lg2_g0) / step) + 1;
+    const double lg2_nu0 = log2_fast(nu_min), lg2_g0 = log2_fast(gamma_min);  // wave-uniform, but VALU work all the same
+    int nu_size = (int)ceil((log2_fast(nu_max) - lg2_nu0) / step) + 1;
+    int g_size = (int)ceil((log2_fast(gamma_max) - lg2_g0) / step) + 1;
     if (nu_size < 2) nu_size = 2;
     if (g_size < 2) g_size = 2;
     const double phase = lg2_nu0 + 2 * lg2_g0 + log2(4 * IC_X0);
-    const long n_lo = (long)floor((log2(nu_IC_min) - phase) / step);
-    const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
+    const long n_lo = (long)floor((log2_fast(nu_IC_min) - phase) / step);
+    const long n_hi = (long)ceil((log2_fast(nu_IC_max) - phase) / step);
     const long span = n_hi - n_lo;
     const int n_ic = (int)(span > 1 ? span : 1) + 1;
     const long idx0 = n_lo * 2;
@@ -538,138 +543,165 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
 #endif
     // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527).
-    // Register-resident form: every lane keeps two seed nodes, in REVERSED lane order (j0 = 2 (63 - lane), j1 = j0 + 1),
-    // so the suffix sums of the scattering CDF are a prefix sum over lanes and the value at node j + 1 is the lane's own
-    // second node or the first node of lane - 1 (one wave_shr DPP move); the per-gamma KN CDF (build_cdf_KN, :432-481)
-    // never touches LDS.  Output node kk samples seed bin j = n_lo - 2 i + kk exactly at its lower edge (all lattice offsets are
-    // even), so its term is cdf[j+1] + 0.5 (f_j + f_j+1) dnu_j ratio_j, a per-bin quantity exchanged through one LDS row.
+    // Register-resident form: every lane keeps NB seed nodes, in REVERSED lane order (j_a = NB (63 - lane) + a), so the suffix
+    // sums of the scattering CDF are a prefix sum over lanes and the value at node j + 1 is the lane's own next node or the
+    // first node of lane - 1 (one wave_shr DPP move); the per-gamma KN CDF (build_cdf_KN, :432-481) never touches LDS.
+    // NB = 1 when the seed lattice fits one node per lane (the usual cell: ~50 nodes), else 2: with two nodes per lane a
+    // 50-node lattice would leave 38 lanes idle through every scattering CDF.  Output node kk samples seed bin
+    // j = n_lo - 2 i + kk exactly at its lower edge (all lattice offsets are even), so its term is
+    // cdf[j+1] + 0.5 (f_j + f_j+1) dnu_j ratio_j, a per-bin quantity exchanged through one LDS row.
     double I_acc[3] = {0, 0, 0};
-    const int j0 = 2 * (63 - lane), j1 = j0 + 1;
-    auto ld = [&](const double* a, int jj) { return jj <= nu_last ? a[jj] : 0.0; };
-    const double nu0 = ld(sh.nu, j0), nu1 = ld(sh.nu, j1);
-    const double fth0 = ld(sh.fv_th, j0), fth1 = ld(sh.fv_th, j1);
-    const double lth0 = ld(sh.lg2fv, j0), lth1 = ld(sh.lg2fv, j1);
-    const bool bin0 = j0 < nu_last, bin1 = j1 < nu_last;  // bins [j, j+1]
-    const double dnu0 = bin0 ? sh.dnu[j0] : 0.0, dnu1 = bin1 ? sh.dnu[j1] : 0.0;
-    const double lgr0 = bin0 ? sh.lg2r[j0] : 0.0, lgr1 = bin1 ? sh.lg2r[j1] : 0.0;
-    const double ilr0 = bin0 ? sh.inv_lg2r[j0] : 0.0, ilr1 = bin1 ? sh.inv_lg2r[j1] : 0.0;
-    const double cth0 = ld(sh.cdf_th, j0), cth1 = ld(sh.cdf_th, j1);
-    const double nuN0 = nu1;
-    const double nuN1 = from_lane_below(nu0);
-    const double rth0 = bin0 ? sh.ratio_th[j0] : 1.0, rth1 = bin1 ? sh.ratio_th[j1] : 1.0;
     const double cdf0_th = sh.cdf_th[0];
     const double lg2nu_first = sh.lg2nu[0];
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
     const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
     const double gam_first = sh.gam[0];
-    __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
-    if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
-        const double fN0 = fth1, fN1 = from_lane_below(fth0);
-        const double cN0 = cth1, cN1 = from_lane_below(cth0);
-        if (bin0) sh.T[0][j0] = cN0 + 0.5 * (fth0 + fN0) * dnu0 * rth0;  // one exchange row serves every energy
-        if (bin1) sh.T[0][j1] = cN1 + 0.5 * (fth1 + fN1) * dnu1 * rth1;
-        __syncthreads();
-    }
-    if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
-        const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
-        const double lg2_base = log2(gam_first) + lg2nu_first;
-        for (int q = lane; q < n_lat; q += 64)
-            compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
-        __syncthreads();
-    }
     const int n_lo_i = (int)n_lo;
-    int my_split = 0;
-    if (KN && lane < g_size) {
-        const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
-        // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
-        const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
-        int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) / step);
-        js = js < 0 ? 0 : (js > nu_last ? nu_last : js);
-        while (js > 0 && sh.nu[js - 1] >= nu_split) --js;
-        while (js < nu_last && sh.nu[js] < nu_split) ++js;
-        my_split = js;
-    }
-    // one electron energy: per-bin terms T_a = cdf[j_a + 1] + trap_a ratio_a of this lane's two bins, and cdf[0]
-    auto kn_terms = [&](int i, double& T0, double& T1, double& cdf0) {  // build_cdf_KN, inverse-compton.h:432-481
-        const int i_gamma = 2 * i;
-        const int j_split = __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i));
-        const bool kn0 = j0 >= j_split && j0 <= nu_last, kn1 = j1 >= j_split && j1 <= nu_last;
-        const double f0 = kn0 ? fth0 * sh.corr[i_gamma + 2 * j0] : fth0;
-        const double f1 = kn1 ? fth1 * sh.corr[i_gamma + 2 * j1] : fth1;
-        const double lf0 = kn0 ? lth0 + sh.lg2corr[i_gamma + 2 * j0] : 0.0;
-        const double lf1 = kn1 ? lth1 + sh.lg2corr[i_gamma + 2 * j1] : 0.0;
-        const double fN0 = f1, fN1 = from_lane_below(f0);
-        const double lfN0 = lf1, lfN1 = from_lane_below(lf0);
-        // bins below the split keep the Thomson ratio (but see the corrected f at their upper edge j_split)
-        const double trap0 = 0.5 * (f0 + fN0) * dnu0, trap1 = 0.5 * (f1 + fN1) * dnu1;
-        double ex0 = 0, ex1 = 0, term0 = trap0 * rth0, term1 = trap1 * rth1;
-        if (bin0 && j0 >= j_split) {
-            ex0 = power_law_bin_integral(f0, fN0, nu0, nuN0, lf0, lfN0, lgr0, ilr0, trap0);
-            term0 = ex0;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+    auto energies = [&](auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
+        int jn[NB];
+        bool bin[NB];  // bins [j, j+1]
+        double nu_a[NB], fth[NB], lth[NB], dnu[NB], lgr[NB], ilr[NB], cth[NB], rth[NB], nuN[NB];
+        auto ld = [&](const double* arr, int jj) { return jj <= nu_last ? arr[jj] : 0.0; };
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            jn[a] = NB * (63 - lane) + a;
+            bin[a] = jn[a] < nu_last;
+            nu_a[a] = ld(sh.nu, jn[a]);
+            fth[a] = ld(sh.fv_th, jn[a]);
+            lth[a] = ld(sh.lg2fv, jn[a]);
+            cth[a] = ld(sh.cdf_th, jn[a]);
+            dnu[a] = bin[a] ? sh.dnu[jn[a]] : 0.0;
+            lgr[a] = bin[a] ? sh.lg2r[jn[a]] : 0.0;
+            ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
+            rth[a] = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
         }
-        if (bin1 && j1 >= j_split) {
-            ex1 = power_law_bin_integral(f1, fN1, nu1, nuN1, lf1, lfN1, lgr1, ilr1, trap1);
-            term1 = ex1;
+        // value at node j_a + 1: the lane's own next node, or the first node of lane - 1
+        auto next_of = [&](const double (&v)[NB], int a) { return a + 1 < NB ? v[a + 1 < NB ? a + 1 : a] : from_lane_below(v[0]); };
+#pragma unroll
+        for (int a = 0; a < NB; ++a) nuN[a] = next_of(nu_a, a);
+        __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
+        if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const double fN = next_of(fth, a), cN = next_of(cth, a);
+                if (bin[a]) sh.T[0][jn[a]] = cN + 0.5 * (fth[a] + fN) * dnu[a] * rth[a];  // one exchange row serves every energy
+            }
+            __syncthreads();
         }
-        // suffix sums over the bins, c_a = sum_{m >= j_a} ex[m]: a prefix sum over the reversed lanes
-        const double S = wave_prefix_sum(ex0 + ex1);  // bins of this lane and of every lane below (= higher j)
-        double c1 = from_lane_below(S) + ex1;
-        double c0 = c1 + ex0;
-        if (j_split > 0) {  // below the split the Thomson CDF applies, shifted to join continuously
-            const double dsel = (j_split & 1) ? (c1 - cth1) : (c0 - cth0);
-            const double delta = read_lane(dsel, 63 - (j_split >> 1));
-            if (j0 < j_split) c0 = cth0 + delta;
-            if (j1 < j_split) c1 = cth1 + delta;
+        if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
+            const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
+            const double lg2_base = log2_fast(gam_first) + lg2nu_first;
+            for (int q = lane; q < n_lat; q += 64)
+                compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+            __syncthreads();
         }
-        cdf0 = read_lane(c0, 63);
-        T0 = c1 + term0;
-        T1 = from_lane_below(c0) + term1;
-    };
-    VAG_IC_MARK();  // 4: KN lattice, split indices
+        int my_split = 0;
+        if (KN && lane < g_size) {
+            const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
+            // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
+            const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
+            int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) / step);
+            js = js < 0 ? 0 : (js > nu_last ? nu_last : js);
+            while (js > 0 && sh.nu[js - 1] >= nu_split) --js;
+            while (js < nu_last && sh.nu[js] < nu_split) ++js;
+            my_split = js;
+        }
+        // one electron energy: per-bin terms T_a = cdf[j_a + 1] + trap_a ratio_a of this lane's bins, and cdf[0]
+        auto kn_terms = [&](int i, double (&T)[NB], double& cdf0) {  // build_cdf_KN, inverse-compton.h:432-481
+            const int i_gamma = 2 * i;
+            const int j_split = __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i));
+            double f[NB], lf[NB], ex[NB], term[NB], c[NB];
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const bool kn = jn[a] >= j_split && jn[a] <= nu_last;
+                f[a] = kn ? fth[a] * sh.corr[i_gamma + 2 * jn[a]] : fth[a];
+                lf[a] = kn ? lth[a] + sh.lg2corr[i_gamma + 2 * jn[a]] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const double fN = next_of(f, a), lfN = next_of(lf, a);
+                // bins below the split keep the Thomson ratio (but see the corrected f at their upper edge j_split)
+                const double trap = 0.5 * (f[a] + fN) * dnu[a];
+                ex[a] = 0;
+                term[a] = trap * rth[a];
+                if (bin[a] && jn[a] >= j_split) {
+                    ex[a] = power_law_bin_integral(f[a], fN, nu_a[a], nuN[a], lf[a], lfN, lgr[a], ilr[a], trap);
+                    term[a] = ex[a];  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                }
+            }
+            // suffix sums over the bins, c_a = sum_{m >= j_a} ex[m]: a prefix sum over the reversed lanes
+            if constexpr (NB == 1) {
+                c[0] = wave_prefix_sum(ex[0]);  // this lane's bin and those of every lane below (= higher j)
+            } else {
+                const double S = wave_prefix_sum(ex[0] + ex[1]);
+                c[1] = from_lane_below(S) + ex[1];
+                c[0] = c[1] + ex[0];
+            }
+            if (j_split > 0) {  // below the split the Thomson CDF applies, shifted to join continuously
+                double dsel = c[0] - cth[0];
+                if constexpr (NB == 2) dsel = (j_split & 1) ? (c[1] - cth[1]) : dsel;
+                const double delta = read_lane(dsel, 63 - j_split / NB);
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+                    if (jn[a] < j_split) c[a] = cth[a] + delta;
+            }
+            cdf0 = read_lane(c[0], 63);
+#pragma unroll
+            for (int a = 0; a < NB; ++a) T[a] = next_of(c, a) + term[a];
+        };
+        VAG_IC_MARK();  // 4: KN lattice, split indices
+        int g_run = g_size;
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 1) g_size = 0;
+        if (VAG_IC_ABLATE >= 1) g_run = 0;
 #endif
 #ifndef VAG_IC_U
 #define VAG_IC_U 3  // measured: 3 beats 4 (one exchange row less of LDS: 13 resident wavefronts per CU) and 2
 #endif
-    constexpr int U = VAG_IC_U;  // electron energies per exchange round: four independent dependency chains in flight
-    for (int ib = 0; ib < g_size; ib += U) {
-        double dNe_u[U], cdf0_u[U];
-        bool live[U];
-        if (KN) __syncthreads();  // the rows below are still being read by the previous round
+        constexpr int U = VAG_IC_U;  // electron energies per exchange round: independent dependency chains in flight
+        for (int ib = 0; ib < g_run; ib += U) {
+            double dNe_u[U], cdf0_u[U];
+            bool live[U];
+            if (KN) __syncthreads();  // the rows below are still being read by the previous round
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = ib + u;
-            dNe_u[u] = i < g_size ? read_lane(my_dNe, i) : 0.0;
-            live[u] = dNe_u[u] > 0;  // uniform
-            cdf0_u[u] = cdf0_th;
-            if (KN && live[u]) {
-                double T0, T1;
-                kn_terms(i, T0, T1, cdf0_u[u]);
-                if (bin0) sh.T[u][j0] = T0;
-                if (bin1) sh.T[u][j1] = T1;
+            for (int u = 0; u < U; ++u) {
+                const int i = ib + u;
+                dNe_u[u] = i < g_size ? read_lane(my_dNe, i) : 0.0;
+                live[u] = dNe_u[u] > 0;  // uniform
+                cdf0_u[u] = cdf0_th;
+                if (KN && live[u]) {
+                    double T[NB];
+                    kn_terms(i, T, cdf0_u[u]);
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+                        if (bin[a]) sh.T[u][jn[a]] = T[a];
+                }
             }
-        }
-        if (KN) __syncthreads();
+            if (KN) __syncthreads();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!live[u] || cdf0_u[u] <= 0) continue;  // uniform
-            const double* Trow = KN ? sh.T[u] : sh.T[0];
-            const int jb = n_lo_i - 2 * (ib + u) + lane;
+            for (int u = 0; u < U; ++u) {
+                if (!live[u] || cdf0_u[u] <= 0) continue;  // uniform
+                const double* Trow = KN ? sh.T[u] : sh.T[0];
+                const int jb = n_lo_i - 2 * (ib + u) + lane;
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const int kk = lane + 64 * s3;
-                const int jo = jb + 64 * s3;
-                if (kk < n_ic) {
-                    if (jo < 0)
-                        I_acc[s3] += dNe_u[u] * cdf0_u[u];
-                    else if (jo < nu_last)
-                        I_acc[s3] += dNe_u[u] * Trow[jo];
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const int kk = lane + 64 * s3;
+                    const int jo = jb + 64 * s3;
+                    if (kk < n_ic) {
+                        if (jo < 0)
+                            I_acc[s3] += dNe_u[u] * cdf0_u[u];
+                        else if (jo < nu_last)
+                            I_acc[s3] += dNe_u[u] * Trow[jo];
+                    }
                 }
             }
         }
-    }
+    };
+    if (nu_size <= VAG_IC_ONE_NODE_MAX)
+        energies(std::integral_constant<int, 1>{});
+    else
+        energies(std::integral_constant<int, 2>{});
     VAG_IC_MARK();  // 5: energy loop
 #ifdef VAG_IC_STAMPS
     if (lane == 0 && (c % 70001) == 0)
