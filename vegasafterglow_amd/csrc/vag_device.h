@@ -987,6 +987,10 @@ VAG_DEV double wave_prefix_sum(double x) {  // inclusive sum over lanes 0..lane 
     return x;
 }
 VAG_DEV double from_lane_below(double v) { return dpp_zero<0x138, 0xf>(v); }  // wave_shr:1: lane - 1's value, 0 into lane 0
+// *p += v on an LDS word without a return value (the hardware applies the lanes of one instruction in lane order)
+VAG_DEV void lds_add_f64(double* p, double v) {
+    asm volatile("ds_add_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double*)p), "v"(v) : "memory");
+}
 #endif
 
 // compute_log2_I_nu (smooth-power-law-syn.cpp:15-46,80-92,159-167) on the fast kernels above.

@@ -43,11 +43,6 @@ __host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
     return sizeof(double) * (SP_LDS_DOUBLES + np + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * fit_rows_stripes(n) * np) + sizeof(int) * np;
 }
 
-#ifndef VAG_HOST_DEBUG
-VAG_DEV void lds_add_f64(double* p, double v) {
-    asm volatile("ds_add_f64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) double*)p), "v"(v) : "memory");
-}
-#endif
 
 // a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
 // registers per node.

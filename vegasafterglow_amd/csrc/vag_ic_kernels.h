@@ -337,21 +337,17 @@ __global__ void vag_ic_unclamp_kernel(int* __restrict__ status, int* __restrict_
 // LDS of one wavefront (= one cell).  The setup arrays are dead once every lane holds its two seed nodes in registers, so
 // the accumulation loop's exchange rows and the KN-correction lattice reuse their memory: 13 KB instead of 21 KB per
 // wavefront, i.e. 12 resident wavefronts per CU instead of 7 for a kernel that lives on latency hiding.
-#ifdef VAG_IC_U
-#define VAG_IC_U_ROWS VAG_IC_U
-#else
-#define VAG_IC_U_ROWS 3
-#endif
+constexpr int IC_MAX_DIAG = 256;  // >= (IC_MAX_NU - 2) + 2 (IC_MAX_G - 1) + 1 = 253
 struct IcShared {
     double nu[IC_MAX_NU];  // live throughout
     union {
         struct {  // setup only
             double lg2nu[IC_MAX_NU], dnu[IC_MAX_NU], fv_th[IC_MAX_NU], lg2fv[IC_MAX_NU], lg2r[IC_MAX_NU], inv_lg2r[IC_MAX_NU],
-                cdf_th[IC_MAX_NU], ratio_th[IC_MAX_NU];
+                ratio_th[IC_MAX_NU];
             double gam[IC_MAX_G], dNe[IC_MAX_G], ex[IC_MAX_NU];
         };
         struct {  // accumulation loop
-            double T[VAG_IC_U_ROWS][IC_MAX_NU];  // per-bin terms of U electron energies (exchange rows of the accumulation loop)
+            double D[IC_MAX_DIAG], E[IC_MAX_DIAG];  // diagonal histograms of dNe ex and dNe term (d = seed bin + 2 electron index)
             double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
         };
     };
@@ -365,11 +361,11 @@ VAG_DEV double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, do
     return f_lo * nu_lo * lg2r * 0.6931471805599453;
 }
 
-// cdf[j] = sum_{m >= j} ex[m] for j < n (ex beyond n treated as 0), cdf[n] = 0.  Two elements per lane + shuffles.
-VAG_DEV void suffix_scan(const double* __restrict__ ex, double* __restrict__ cdf, int n, int lane) {
-    const int j0 = 2 * lane, j1 = j0 + 1;
-    const double a = j0 < n ? ex[j0] : 0.0, b = j1 < n ? ex[j1] : 0.0;
-    double S = a + b;
+// in place over IC_MAX_DIAG = 256 words: v[d] <- sum_{d' >= d} v[d'].  Four words per lane + shuffles.
+VAG_DEV void suffix_scan4(double* __restrict__ v, int lane) {
+    const int j = 4 * lane;
+    const double a = v[j], b = v[j + 1], c = v[j + 2], d = v[j + 3];
+    double S = (a + b) + (c + d);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const double t = __shfl_down(S, off, 64);
@@ -377,9 +373,11 @@ VAG_DEV void suffix_scan(const double* __restrict__ ex, double* __restrict__ cdf
     }
     double S_next = __shfl_down(S, 1, 64);
     if (lane == 63) S_next = 0;
-    const double c1 = S_next + b;
-    if (j1 <= n) cdf[j1] = j1 < n ? c1 : 0.0;
-    if (j0 <= n) cdf[j0] = j0 < n ? c1 + a : 0.0;
+    const double c3 = S_next + d, c2 = c3 + c, c1 = c2 + b;
+    v[j + 3] = c3;
+    v[j + 2] = c2;
+    v[j + 1] = c1;
+    v[j] = c1 + a;
 }
 
 VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
@@ -536,22 +534,23 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         sh.ratio_th[j] = trap > 0 ? exact / trap : 1;
     }
     __syncthreads();
-    suffix_scan(sh.ex, sh.cdf_th, nu_last, lane);
-    __syncthreads();
     VAG_IC_MARK();  // 3: Thomson CDF
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
 #endif
-    // accumulate over electron energies; lane owns output nodes kk = lane + 64 s  (accumulate_IC, inverse-compton.h:483-527).
-    // Register-resident form: every lane keeps NB seed nodes, in REVERSED lane order (j_a = NB (63 - lane) + a), so the suffix
-    // sums of the scattering CDF are a prefix sum over lanes and the value at node j + 1 is the lane's own next node or the
-    // first node of lane - 1 (one wave_shr DPP move); the per-gamma KN CDF (build_cdf_KN, :432-481) never touches LDS.
-    // NB = 1 when the seed lattice fits one node per lane (the usual cell: ~50 nodes), else 2: with two nodes per lane a
-    // 50-node lattice would leave 38 lanes idle through every scattering CDF.  Output node kk samples seed bin
-    // j = n_lo - 2 i + kk exactly at its lower edge (all lattice offsets are even), so its term is
-    // cdf[j+1] + 0.5 (f_j + f_j+1) dnu_j ratio_j, a per-bin quantity exchanged through one LDS row.
+    // accumulate over electron energies (accumulate_IC, inverse-compton.h:483-527; build_cdf_KN, :432-481).  For electron
+    // energy i the reference forms the scattering CDF over the seed bins, c_j(i) = sum_{m >= j} ex_m(i), and output node kk
+    // takes dNe_i (c_{j+1}(i) + term_j(i)) at j = n_lo - 2 i + kk (c_0(i) alone for j < 0, nothing past the last bin).  All
+    // lattice offsets are even, so the pairs (i, m) that reach node kk through the CDF are exactly those on the diagonals
+    // d = m + 2 i > n_lo + kk, and the pair behind term_j sits on d = n_lo + kk:
+    //     I[kk] = sum_{d > n_lo + kk} D[d] + E[n_lo + kk],   D[d] = sum_{m + 2 i = d} dNe_i ex_m(i),  E[d] = same with term_m(i).
+    // So the loop only forms ex and term of the lane's bins and adds them to two diagonal histograms in LDS (ds_add_f64, the
+    // lanes of one instruction hit different words); ONE suffix sum over D per cell replaces a 64-lane scan, the continuity
+    // shift below the KN split, the exchange row and the three-slot gather per electron energy (below the split the shifted
+    // Thomson CDF is the same as ex_m = the Thomson bin integral).  Every lane keeps NB seed nodes in REVERSED lane order
+    // (j_a = NB (63 - lane) + a): the value at node j + 1 is the lane's own next node or the first node of lane - 1 (one
+    // wave_shr DPP move).  NB = 1 when the seed lattice fits one node per lane (the usual cell: ~50 nodes), else 2.
     double I_acc[3] = {0, 0, 0};
-    const double cdf0_th = sh.cdf_th[0];
     const double lg2nu_first = sh.lg2nu[0];
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
@@ -562,7 +561,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         constexpr int NB = decltype(nb_tag)::value;
         int jn[NB];
         bool bin[NB];  // bins [j, j+1]
-        double nu_a[NB], fth[NB], lth[NB], dnu[NB], lgr[NB], ilr[NB], cth[NB], rth[NB], nuN[NB];
+        double nu_a[NB], fth[NB], lth[NB], dnu[NB], lgr[NB], ilr[NB], rth[NB], exth[NB], nuN[NB];
         auto ld = [&](const double* arr, int jj) { return jj <= nu_last ? arr[jj] : 0.0; };
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
@@ -571,33 +570,26 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             nu_a[a] = ld(sh.nu, jn[a]);
             fth[a] = ld(sh.fv_th, jn[a]);
             lth[a] = ld(sh.lg2fv, jn[a]);
-            cth[a] = ld(sh.cdf_th, jn[a]);
             dnu[a] = bin[a] ? sh.dnu[jn[a]] : 0.0;
             lgr[a] = bin[a] ? sh.lg2r[jn[a]] : 0.0;
             ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
             rth[a] = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
+            exth[a] = bin[a] ? sh.ex[jn[a]] : 0.0;  // Thomson bin integral (build_cdf_thomson)
         }
         // value at node j_a + 1: the lane's own next node, or the first node of lane - 1
         auto next_of = [&](const double (&v)[NB], int a) { return a + 1 < NB ? v[a + 1 < NB ? a + 1 : a] : from_lane_below(v[0]); };
 #pragma unroll
         for (int a = 0; a < NB; ++a) nuN[a] = next_of(nu_a, a);
-        __syncthreads();  // every setup array has been read: from here on their memory holds T / corr / lg2corr
-        if (!KN) {  // Thomson: the per-bin term cdf_th[j+1] + trap_th ratio_th is the same for every electron energy
-#pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                const double fN = next_of(fth, a), cN = next_of(cth, a);
-                if (bin[a]) sh.T[0][jn[a]] = cN + 0.5 * (fth[a] + fN) * dnu[a] * rth[a];  // one exchange row serves every energy
-            }
-            __syncthreads();
-        }
+        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / corr / lg2corr
+        for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
         if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
             const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
             const double lg2_base = log2_fast(gam_first) + lg2nu_first;
             for (int q = lane; q < n_lat; q += 64)
                 compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
-            __syncthreads();
         }
-        int my_split = 0;
+        __syncthreads();
+        int my_split = nu_size;  // Thomson: no bin lies at or above the split
         if (KN && lane < g_size) {
             const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
             // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
@@ -608,11 +600,18 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             while (js < nu_last && sh.nu[js] < nu_split) ++js;
             my_split = js;
         }
-        // one electron energy: per-bin terms T_a = cdf[j_a + 1] + trap_a ratio_a of this lane's bins, and cdf[0]
-        auto kn_terms = [&](int i, double (&T)[NB], double& cdf0) {  // build_cdf_KN, inverse-compton.h:432-481
+        VAG_IC_MARK();  // 4: KN lattice, split indices
+        int g_run = g_size;
+#ifdef VAG_IC_ABLATE
+        if (VAG_IC_ABLATE >= 1) g_run = 0;
+#endif
+#pragma unroll 2
+        for (int i = 0; i < g_run; ++i) {
+            const double dNe = read_lane(my_dNe, i);
+            if (!(dNe > 0)) continue;  // uniform
             const int i_gamma = 2 * i;
             const int j_split = __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i));
-            double f[NB], lf[NB], ex[NB], term[NB], c[NB];
+            double f[NB], lf[NB];
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
                 const bool kn = jn[a] >= j_split && jn[a] <= nu_last;
@@ -622,78 +621,16 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
                 const double fN = next_of(f, a), lfN = next_of(lf, a);
-                // bins below the split keep the Thomson ratio (but see the corrected f at their upper edge j_split)
+                // bins below the split keep the Thomson integral and ratio (but see the corrected f at their upper edge j_split)
                 const double trap = 0.5 * (f[a] + fN) * dnu[a];
-                ex[a] = 0;
-                term[a] = trap * rth[a];
+                double ex = exth[a], term = trap * rth[a];
                 if (bin[a] && jn[a] >= j_split) {
-                    ex[a] = power_law_bin_integral(f[a], fN, nu_a[a], nuN[a], lf[a], lfN, lgr[a], ilr[a], trap);
-                    term[a] = ex[a];  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                    ex = power_law_bin_integral(f[a], fN, nu_a[a], nuN[a], lf[a], lfN, lgr[a], ilr[a], trap);
+                    term = ex;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
                 }
-            }
-            // suffix sums over the bins, c_a = sum_{m >= j_a} ex[m]: a prefix sum over the reversed lanes
-            if constexpr (NB == 1) {
-                c[0] = wave_prefix_sum(ex[0]);  // this lane's bin and those of every lane below (= higher j)
-            } else {
-                const double S = wave_prefix_sum(ex[0] + ex[1]);
-                c[1] = from_lane_below(S) + ex[1];
-                c[0] = c[1] + ex[0];
-            }
-            if (j_split > 0) {  // below the split the Thomson CDF applies, shifted to join continuously
-                double dsel = c[0] - cth[0];
-                if constexpr (NB == 2) dsel = (j_split & 1) ? (c[1] - cth[1]) : dsel;
-                const double delta = read_lane(dsel, 63 - j_split / NB);
-#pragma unroll
-                for (int a = 0; a < NB; ++a)
-                    if (jn[a] < j_split) c[a] = cth[a] + delta;
-            }
-            cdf0 = read_lane(c[0], 63);
-#pragma unroll
-            for (int a = 0; a < NB; ++a) T[a] = next_of(c, a) + term[a];
-        };
-        VAG_IC_MARK();  // 4: KN lattice, split indices
-        int g_run = g_size;
-#ifdef VAG_IC_ABLATE
-        if (VAG_IC_ABLATE >= 1) g_run = 0;
-#endif
-#ifndef VAG_IC_U
-#define VAG_IC_U 3  // measured: 3 beats 4 (one exchange row less of LDS: 13 resident wavefronts per CU) and 2
-#endif
-        constexpr int U = VAG_IC_U;  // electron energies per exchange round: independent dependency chains in flight
-        for (int ib = 0; ib < g_run; ib += U) {
-            double dNe_u[U], cdf0_u[U];
-            bool live[U];
-            if (KN) __syncthreads();  // the rows below are still being read by the previous round
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = ib + u;
-                dNe_u[u] = i < g_size ? read_lane(my_dNe, i) : 0.0;
-                live[u] = dNe_u[u] > 0;  // uniform
-                cdf0_u[u] = cdf0_th;
-                if (KN && live[u]) {
-                    double T[NB];
-                    kn_terms(i, T, cdf0_u[u]);
-#pragma unroll
-                    for (int a = 0; a < NB; ++a)
-                        if (bin[a]) sh.T[u][jn[a]] = T[a];
-                }
-            }
-            if (KN) __syncthreads();
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!live[u] || cdf0_u[u] <= 0) continue;  // uniform
-                const double* Trow = KN ? sh.T[u] : sh.T[0];
-                const int jb = n_lo_i - 2 * (ib + u) + lane;
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-                    const int kk = lane + 64 * s3;
-                    const int jo = jb + 64 * s3;
-                    if (kk < n_ic) {
-                        if (jo < 0)
-                            I_acc[s3] += dNe_u[u] * cdf0_u[u];
-                        else if (jo < nu_last)
-                            I_acc[s3] += dNe_u[u] * Trow[jo];
-                    }
+                if (bin[a]) {
+                    lds_add_f64(&sh.D[i_gamma + jn[a]], dNe * ex);
+                    lds_add_f64(&sh.E[i_gamma + jn[a]], dNe * term);
                 }
             }
         }
@@ -702,6 +639,19 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         energies(std::integral_constant<int, 1>{});
     else
         energies(std::integral_constant<int, 2>{});
+    __syncthreads();
+    suffix_scan4(sh.D, lane);  // D[d] <- sum_{d' >= d} D[d']
+    __syncthreads();
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int kk = lane + 64 * s3;
+        if (kk < n_ic) {
+            const int d0 = n_lo_i + kk;
+            const double above = d0 + 1 <= 0 ? sh.D[0] : (d0 + 1 < IC_MAX_DIAG ? sh.D[d0 + 1] : 0.0);
+            const double at = d0 >= 0 && d0 < IC_MAX_DIAG ? sh.E[d0] : 0.0;
+            I_acc[s3] = above + at;
+        }
+    }
     VAG_IC_MARK();  // 5: energy loop
 #ifdef VAG_IC_STAMPS
     if (lane == 0 && (c % 70001) == 0)
