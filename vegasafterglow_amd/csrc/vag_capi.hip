@@ -312,7 +312,7 @@ struct vag_ctx {
     HostBuf h_meta, h_off, h_plan;
     DevBuf d_plan;                // VagDevPlan of the current batch (vag_plan_kernel)
     DevBuf d_chunk;               // staging of chunked requests
-    DevBuf d_icwork;              // work tallies of vag_ic_photon_kernel (vag_ctx_count_work)
+    DevBuf d_icwork;              // work tallies of the SSC tables (vag_ic_plan_kernel, vag_ctx_count_work)
     VagDevPlan hint{};            // the last plan the host read back: sizes the next call of the same batch size in advance
     int hint_nb = 0;
     bool hint_valid = false;
@@ -1178,11 +1178,15 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icwork.p, 0, 2 * sizeof(unsigned long long), st));
         }
+        hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
+                           c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
+                           c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
+                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride);
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
-                           c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_band.as<double>(), c->d_sptab.as<double>(),
-                           c->d_knlut.as<double>(), c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
-                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride);
+                           c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_sptab.as<double>(),
+                           c->d_knlut.as<double>(), c->d_ictab.as<double>());
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             unsigned long long h[2] = {0, 0};

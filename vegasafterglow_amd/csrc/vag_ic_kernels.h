@@ -391,26 +391,20 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 #ifndef VAG_IC_ONE_NODE_MAX
 #define VAG_IC_ONE_NODE_MAX 64  // seed lattices up to this size take one node per lane (developer builds: 0 = always two)
 #endif
-__global__ void __launch_bounds__(64, VAG_IC_WAVES)
-vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
-                     long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
-                     const double* __restrict__ cellpar, const double* __restrict__ cellq, const double* __restrict__ band,
-                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* __restrict__ ictab,
-                     int* __restrict__ ic_status,
-                     unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
-                     int band_stride) {
-    const long long c = blockIdx.x;
-#ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
-    long long c_t[8];
-    int c_n = 0;
-    c_t[c_n++] = __builtin_readcyclecounter();
-#define VAG_IC_MARK() do { __builtin_amdgcn_s_waitcnt(0); c_t[c_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define VAG_IC_MARK() do { } while (0)
-#endif
+// Lattice plan of every cell, one LANE per cell (compute_grid_params + the sizes of initialize_grids, inverse-compton.h:297-369).
+// These few hundred instructions are the same for all 64 lanes of the wavefront that builds the cell's spectrum, so they are
+// done here at 1/64 of the cost and handed over in the cell's own table row: the header words [0..4] are final, the words from
+// IC_HDR on carry the plan until vag_ic_photon_kernel replaces them by the table.  Cells that get no table (failed model,
+// degenerate or over-capacity lattice) are finished here: n = 0 and the theoretical range.
+enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_N };
+__global__ void __launch_bounds__(256)
+vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
+                   long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
+                   double* __restrict__ ictab, int* __restrict__ ic_status,
+                   unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
+                   int band_stride) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    const int lane = threadIdx.x;
-    __shared__ IcShared sh;
     int lo = 0, hi = nb;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -420,19 +414,14 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             hi = mid;
     }
     const int m = lo;
-    const VagGridMeta M = meta[m];
-    if (M.status != 0) return;
-    const int nt = M.n_t;
-    const long long local = c - lay.cell_off[m];
-    const int r = (int)(local / nt), k = (int)(local % nt);
-    const vag_model_params P = params[m];
-    const bool KN = (P.flags & VAG_FLAG_KN) != 0;
     double* tab = ictab + (size_t)c * IC_STRIDE;
-
+    tab[IC_HDR + ICP_RUN] = 0;
+    tab[0] = 0;
+    const int nt = meta[m].n_t;
+    if (meta[m].status != 0) return;
+    const int k = (int)((c - lay.cell_off[m]) % nt);
     const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
-    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c], column_den = det[VD_COLUMN_DEN * n_cells + c];
-    const double Y_c = det[VD_YC * n_cells + c];
-    const int regime = (int)det[VD_REGIME * n_cells + c];
+    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c];
     const double nu_m = det[VD_NU_M * n_cells + c], nu_a = det[VD_NU_A * n_cells + c], nu_M = det[VD_NU_MAX * n_cells + c];
     const double nu_eval_min = band[((size_t)m * 2 + 0) * band_stride + k];
     const double nu_eval_max = band[((size_t)m * 2 + 1) * band_stride + k];
@@ -446,45 +435,82 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double nu_ic_base = 4 * IC_X0 * nu_M * gamma_M * gamma_M;
     const double nu_ic_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
     double nu_IC_max = nu_ic_cut * 2.0;
-    const double theory_max = log2_fast(nu_IC_max), theory_min = log2_fast(nu_IC_min);
+    const double theory_max = log2(nu_IC_max), theory_min = log2(nu_IC_min);
     nu_IC_min = dmax(nu_IC_min, dmin(nu_eval_min / 4.0, nu_IC_max / 16.0));
     nu_IC_max = dmin(nu_IC_max, dmax(nu_eval_max * 4.0, nu_IC_min * 16.0));
+    tab[3] = theory_min;
+    tab[4] = theory_max;
     auto posfin = [](double x) { return isfinite(x) && x > 0; };
-    if (!(posfin(gamma_min) && posfin(gamma_max) && posfin(nu_min) && posfin(nu_max) && posfin(nu_IC_min) &&
-          posfin(nu_IC_max))) {
-        if (lane == 0) {
-            tab[0] = 0;
-            tab[3] = theory_min;
-            tab[4] = theory_max;
-        }
+    if (!(posfin(gamma_min) && posfin(gamma_max) && posfin(nu_min) && posfin(nu_max) && posfin(nu_IC_min) && posfin(nu_IC_max)))
         return;
-    }
     // initialize_grids, inverse-compton.h:340-369
     const double step = 2 * IC_Q;
-    const double lg2_nu0 = log2_fast(nu_min), lg2_g0 = log2_fast(gamma_min);  // wave-uniform, but VALU work all the same
-    int nu_size = (int)ceil((log2_fast(nu_max) - lg2_nu0) / step) + 1;
-    int g_size = (int)ceil((log2_fast(gamma_max) - lg2_g0) / step) + 1;
+    const double lg2_nu0 = log2(nu_min), lg2_g0 = log2(gamma_min);
+    int nu_size = (int)ceil((log2(nu_max) - lg2_nu0) / step) + 1;
+    int g_size = (int)ceil((log2(gamma_max) - lg2_g0) / step) + 1;
     if (nu_size < 2) nu_size = 2;
     if (g_size < 2) g_size = 2;
     const double phase = lg2_nu0 + 2 * lg2_g0 + log2(4 * IC_X0);
-    const long n_lo = (long)floor((log2_fast(nu_IC_min) - phase) / step);
-    const long n_hi = (long)ceil((log2_fast(nu_IC_max) - phase) / step);
+    const long n_lo = (long)floor((log2(nu_IC_min) - phase) / step);
+    const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
     const long span = n_hi - n_lo;
     const int n_ic = (int)(span > 1 ? span : 1) + 1;
-    const long idx0 = n_lo * 2;
     if (nu_size > IC_MAX_NU || g_size > IC_MAX_G || n_ic > IC_MAX_OUT) {
-        if (lane == 0) {
-            tab[0] = 0;
-            tab[3] = theory_min;
-            tab[4] = theory_max;
-            atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
-        }
+        atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
         return;
     }
-    if (work && lane == 0) {  // instrumentation: the unit of this kernel's work model (bench.py)
+    if (work) {  // instrumentation: the unit of vag_ic_photon_kernel's work model (bench.py)
         atomicAdd(work, (unsigned long long)g_size * (unsigned long long)nu_size);
         atomicAdd(work + 1, (unsigned long long)(g_size + nu_size + n_ic));
     }
+    tab[0] = (double)n_ic;
+    tab[1] = phase;
+    tab[2] = (double)(n_lo * 2);
+    tab[IC_HDR + ICP_RUN] = 1;
+    tab[IC_HDR + ICP_MODEL] = (double)m;
+    tab[IC_HDR + ICP_NU_SIZE] = (double)nu_size;
+    tab[IC_HDR + ICP_G_SIZE] = (double)g_size;
+    tab[IC_HDR + ICP_N_LO] = (double)n_lo;
+    tab[IC_HDR + ICP_LG2_NU0] = lg2_nu0;
+    tab[IC_HDR + ICP_LG2_G0] = lg2_g0;
+}
+
+__global__ void __launch_bounds__(64, VAG_IC_WAVES)
+vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
+                     long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
+                     const double* __restrict__ cellpar, const double* __restrict__ cellq,
+                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* ictab) {
+    const long long c = blockIdx.x;
+#ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
+    long long c_t[8];
+    int c_n = 0;
+    c_t[c_n++] = __builtin_readcyclecounter();
+#define VAG_IC_MARK() do { __builtin_amdgcn_s_waitcnt(0); c_t[c_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VAG_IC_MARK() do { } while (0)
+#endif
+    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
+    const int lane = threadIdx.x;
+    __shared__ IcShared sh;
+    double* tab = ictab + (size_t)c * IC_STRIDE;
+    if (tab[IC_HDR + ICP_RUN] == 0) return;  // vag_ic_plan_kernel finished this cell (uniform)
+    const int m = (int)tab[IC_HDR + ICP_MODEL];
+    int nu_size = (int)tab[IC_HDR + ICP_NU_SIZE], g_size = (int)tab[IC_HDR + ICP_G_SIZE];
+    const long n_lo = (long)tab[IC_HDR + ICP_N_LO];
+    const double lg2_nu0 = tab[IC_HDR + ICP_LG2_NU0], lg2_g0 = tab[IC_HDR + ICP_LG2_G0];
+    const int n_ic = (int)tab[0];
+    const double phase = tab[1];
+    const long idx0 = n_lo * 2;
+    const double step = 2 * IC_Q;
+    const int nt = meta[m].n_t;
+    const long long local = c - lay.cell_off[m];
+    const int r = (int)(local / nt), k = (int)(local % nt);
+    const vag_model_params P = params[m];
+    const bool KN = (P.flags & VAG_FLAG_KN) != 0;
+    const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
+    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c], column_den = det[VD_COLUMN_DEN * n_cells + c];
+    const double Y_c = det[VD_YC * n_cells + c];
+    const int regime = (int)det[VD_REGIME * n_cells + c];
     __syncthreads();
     for (int j = lane; j < nu_size; j += 64) {
         sh.lg2nu[j] = lg2_nu0 + step * (double)j;
@@ -664,13 +690,6 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     for (int s = 0; s < 3; ++s) {
         const int kk = lane + 64 * s;
         if (kk < n_ic) tab[IC_HDR + kk] = log2_fast(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
-    }
-    if (lane == 0) {
-        tab[0] = (double)n_ic;
-        tab[1] = phase;
-        tab[2] = (double)idx0;
-        tab[3] = theory_min;
-        tab[4] = theory_max;
     }
 }
 
