@@ -247,36 +247,32 @@ VAG_DEV double compton_ratio_from_x(double x) {
 constexpr int KN_LUT_N = 128;
 constexpr double KN_LG2_XMIN = -6.6438561897747247, KN_LG2_XMAX = 6.6438561897747247;
 // lut: [2][KN_LUT_N] = ratio, log2 ratio (ComptonSigmaLUT, inverse-compton.cpp:285-343), built on the host
-VAG_DEV void compton_correction_pair(double nu, const double* __restrict__ lut, double& corr, double& lg2_corr) {
-    const double x = C_H / (C_ME * C_C2) * nu;
-    if (!(x > 0)) {
-        corr = 0;
-        lg2_corr = -INFINITY;
-        return;
-    }
-    if (x <= 1e-2) {
+// compton_correction_pair (inverse-compton.cpp:356-385) at a node of a log-spaced lattice, given log2(nu): 1 - 2x below the
+// table, the asymptotic form above it, linear in log2 x inside.  Inside the table's range the position comes from the
+// logarithm directly (no exp2 -> log2 round trip per node), and the two tails are the closed forms written in log2(x):
+// ln(2x) = (log2 x + 1) ln 2, 1/x = 2^-log2 x.  One wavefront usually holds nodes of all three ranges, so every branch counts.
+VAG_DEV void compton_correction_pair_lg2(double lg2_nu, const double* __restrict__ lut, double& corr, double& lg2_corr) {
+    const double lg2_x = lg2_nu + log2(C_H / (C_ME * C_C2));
+    if (!(lg2_x > KN_LG2_XMIN)) {  // x <= 1e-2 (NaN lands here too)
+        const double x = exp2_sat(lg2_x);
+        if (!(x > 0)) {
+            corr = 0;
+            lg2_corr = -INFINITY;
+            return;
+        }
         corr = 1 - 2 * x;
         lg2_corr = -(2 * x + 2 * x * x) * 1.4426950408889634;
         return;
     }
-    if (x >= 1e2) {
-        corr = compton_ratio_from_x(x);
-        lg2_corr = log2(corr);
+    if (lg2_x >= KN_LG2_XMAX) {  // x >= 1e2: sigma/sigma_T = 3/8 (ln 2x + 1/2) / x
+        const double a = 0.375 * ((lg2_x + 1.0) * LN2 + 0.5);
+        corr = a * exp2_sat(-lg2_x);
+        lg2_corr = log2_fast(a) - lg2_x;
         return;
     }
     constexpr double inv_step = 1.0 / ((KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1));
-    const double pos = (log2_fast(x) - KN_LG2_XMIN) * inv_step;
-    if (pos <= 0) {
-        corr = lut[0];
-        lg2_corr = lut[KN_LUT_N];
-        return;
-    }
-    if (pos >= (double)(KN_LUT_N - 1)) {
-        corr = lut[KN_LUT_N - 1];
-        lg2_corr = lut[2 * KN_LUT_N - 1];
-        return;
-    }
-    const int idx = (int)pos;
+    const double pos = dmin((lg2_x - KN_LG2_XMIN) * inv_step, (double)(KN_LUT_N - 1));
+    const int idx = pos >= (double)(KN_LUT_N - 1) ? KN_LUT_N - 2 : (int)pos;
     const double frac = pos - (double)idx;
     corr = lut[idx] + (lut[idx + 1] - lut[idx]) * frac;
     lg2_corr = lut[KN_LUT_N + idx] + (lut[KN_LUT_N + idx + 1] - lut[KN_LUT_N + idx]) * frac;

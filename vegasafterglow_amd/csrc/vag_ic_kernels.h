@@ -396,7 +396,7 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 // done here at 1/64 of the cost and handed over in the cell's own table row: the header words [0..4] are final, the words from
 // IC_HDR on carry the plan until vag_ic_photon_kernel replaces them by the table.  Cells that get no table (failed model,
 // degenerate or over-capacity lattice) are finished here: n = 0 and the theoretical range.
-enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_N };
+enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX, ICP_N };
 __global__ void __launch_bounds__(256)
 vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
@@ -473,6 +473,9 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
     tab[IC_HDR + ICP_N_LO] = (double)n_lo;
     tab[IC_HDR + ICP_LG2_NU0] = lg2_nu0;
     tab[IC_HDR + ICP_LG2_G0] = lg2_g0;
+    tab[IC_HDR + ICP_LG2_GM] = log2(gamma_m);  // uniform factors of the electron distribution (sample_distributions)
+    tab[IC_HDR + ICP_INV_GM] = 1 / gamma_m;
+    tab[IC_HDR + ICP_INV_GMAX] = 1 / gamma_M;
 }
 
 __global__ void __launch_bounds__(64, VAG_IC_WAVES)
@@ -498,6 +501,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     int nu_size = (int)tab[IC_HDR + ICP_NU_SIZE], g_size = (int)tab[IC_HDR + ICP_G_SIZE];
     const long n_lo = (long)tab[IC_HDR + ICP_N_LO];
     const double lg2_nu0 = tab[IC_HDR + ICP_LG2_NU0], lg2_g0 = tab[IC_HDR + ICP_LG2_G0];
+    const double lg2_gm = tab[IC_HDR + ICP_LG2_GM], inv_gm = tab[IC_HDR + ICP_INV_GM], inv_gM = tab[IC_HDR + ICP_INV_GMAX];
     const int n_ic = (int)tab[0];
     const double phase = tab[1];
     const long idx0 = n_lo * 2;
@@ -508,7 +512,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const vag_model_params P = params[m];
     const bool KN = (P.flags & VAG_FLAG_KN) != 0;
     const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
-    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c], column_den = det[VD_COLUMN_DEN * n_cells + c];
+    const double column_den = det[VD_COLUMN_DEN * n_cells + c];
     const double Y_c = det[VD_YC * n_cells + c];
     const int regime = (int)det[VD_REGIME * n_cells + c];
     __syncthreads();
@@ -527,17 +531,29 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double* qv = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
     SpecConst sc;
     sc.init(P.p);
+    // SynElectrons::compute_column_den (synchrotron.cpp:261-309) / gamma^2 * dgamma at the lattice energies: log2(gamma) is the
+    // node's own exponent, the cell-uniform factors come from the plan, the two exponentials of a branch are one exp2
+    const bool slow = regime == 1 || regime == 2 || regime == 5, fast = regime == 3 || regime == 4 || regime == 6;
     for (int i = lane; i < g_size; i += 64) {
-        const double gi = sh.gam[i];
+        constexpr double LOG2E_ = 1.4426950408889634;
+        const double gi = sh.gam[i], rg = rcp_fast(gi), lg = lg2_g0 + step * (double)i;
         const double dgi = 0.5 * ((i + 1 < g_size ? sh.gam[i + 1] : gi) - (i > 0 ? sh.gam[i - 1] : gi));
-        const double Yg = exp2_sat(icy_lg2_Y(icy, n_cells, c, log2_fast(gi)));
-        sh.dNe[i] = electron_column_den(gi, gamma_m, gamma_c, gamma_M, P.p, regime, column_den, Y_c, Yg) / (gi * gi) * dgi;
+        double spec = 0;
+        if (slow)
+            spec = (P.p - 1) * inv_gm * exp2_sat((-gi * inv_gM - gamma_m * rg) * LOG2E_ - P.p * (lg - lg2_gm)) * gamma_c *
+                   rcp_fast(gi + gamma_c);
+        else if (fast)
+            spec = exp2_sat((-gi * inv_gM - gamma_c * rg) * LOG2E_) * gamma_c * rg * rg *
+                   rcp_fast(1.0 + exp2_sat(dmin((P.p - 1) * (lg - lg2_gm), 1000.0)));
+        double den = column_den * spec;
+        if (gi > gamma_c) den = den * (1 + Y_c) / (1 + exp2_sat(icy_lg2_Y(icy, n_cells, c, lg)));
+        sh.dNe[i] = den * rg * rg * dgi;
     }
-    for (int j = lane; j < nu_size; j += 64) {
-        const double I_seed = exp2_sat(log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table));
-        const double f = I_seed / (sh.nu[j] * sh.nu[j]);
+    for (int j = lane; j < nu_size; j += 64) {  // f = I_seed / nu^2 and its logarithm, from the logarithm
+        const double lf = log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table) - 2 * sh.lg2nu[j];
+        const double f = exp2_sat(lf);
         sh.fv_th[j] = f;
-        sh.lg2fv[j] = f > 0 ? log2_fast(f) : -INFINITY;
+        sh.lg2fv[j] = f > 0 ? lf : -INFINITY;
     }
     __syncthreads();
     VAG_IC_MARK();  // 2: sampled distributions
@@ -581,7 +597,6 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
     const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
-    const double gam_first = sh.gam[0];
     const int n_lo_i = (int)n_lo;
     auto energies = [&](auto nb_tag) {
         constexpr int NB = decltype(nb_tag)::value;
@@ -610,9 +625,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
         if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
             const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
-            const double lg2_base = log2_fast(gam_first) + lg2nu_first;
+            const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
             for (int q = lane; q < n_lat; q += 64)
-                compton_correction_pair(exp2_sat(lg2_base + IC_Q * (double)q), kn_lut, sh.corr[q], sh.lg2corr[q]);
+                compton_correction_pair_lg2(lg2_base + IC_Q * (double)q, kn_lut, sh.corr[q], sh.lg2corr[q]);
         }
         __syncthreads();
         int my_split = nu_size;  // Thomson: no bin lies at or above the split
@@ -631,7 +646,10 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #ifdef VAG_IC_ABLATE
         if (VAG_IC_ABLATE >= 1) g_run = 0;
 #endif
-#pragma unroll 2
+#ifndef VAG_IC_UNROLL
+#define VAG_IC_UNROLL 2
+#endif
+#pragma unroll VAG_IC_UNROLL
         for (int i = 0; i < g_run; ++i) {
             const double dNe = read_lane(my_dNe, i);
             if (!(dNe > 0)) continue;  // uniform
@@ -655,8 +673,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                     term = ex;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
                 }
                 if (bin[a]) {
-                    lds_add_f64(&sh.D[i_gamma + jn[a]], dNe * ex);
-                    lds_add_f64(&sh.E[i_gamma + jn[a]], dNe * term);
+                    // relaxed workgroup atomics on LDS words: ds_add_f64 without a return value, free to overlap the next energy's reads
+                    __hip_atomic_fetch_add(&sh.D[i_gamma + jn[a]], dNe * ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&sh.E[i_gamma + jn[a]], dNe * term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
