@@ -44,12 +44,15 @@ __host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
 }
 
 
+#ifndef VAG_ROWS_MIN_WG
+#define VAG_ROWS_MIN_WG 3  // workgroups per CU the row-per-lane kernels are compiled for (developer builds: 4 = 128 VGPRs)
+#endif
 // a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
 // registers per node.
 // SPREAD: a spreading jet's polar angle evolves along the lattice, so the viewing cosine and the solid angle are per node
 // (calc_t_obs + calc_solid_angle, observer.cpp:51-141; a.cellgeo holds cos theta, sin theta, log2|dcos| per cell).
 template <int MODE, int NBMAX, bool SPREAD = false>
-__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, 3)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
+__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, VAG_ROWS_MIN_WG)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
 vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

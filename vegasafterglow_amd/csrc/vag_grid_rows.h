@@ -30,7 +30,9 @@ __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
 // a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
 // 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
 template <int MODE>
-__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, 3)  // 168 VGPRs: three wavefronts per SIMD
+// 168 VGPRs: three wavefronts per SIMD; the SSC pass (a table look-up per band, no spectrum constants) fits 128 with 12 B of
+// scratch and gains 9 % from the fourth wavefront, the others would spill 100-200 B per lane and lose 70 %
+__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? 4 : VAG_ROWS_MIN_WG)
 vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
