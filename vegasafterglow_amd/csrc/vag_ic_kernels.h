@@ -25,7 +25,7 @@ enum {
 constexpr int IC_MAX_OUT = 192;  // three output nodes per lane; an unclamped table needs at most ~(IC_MAX_NU - 1) + (IC_MAX_G - 1) + 3
 constexpr int IC_HDR = 6;  // n_ic, phase, idx0, log2 theory min, log2 theory max, spare
 constexpr int IC_STRIDE = IC_HDR + IC_MAX_OUT;
-constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = 2 * (IC_MAX_G - 1) + 2 * (IC_MAX_NU - 1) + 1;
+constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = (IC_MAX_G - 1) + (IC_MAX_NU - 1) + 1;
 static_assert(VAG_NQ == FLUX_NQ && IC_STRIDE == FLUX_IC_STRIDE, "keep vag_kernels.h forward constants in sync");
 constexpr double IC_Q = 3.321928094887362 / 8;  // lattice_quantum
 constexpr double IC_X0 = 0.47140452079103166;
@@ -330,13 +330,14 @@ __global__ void vag_ic_unclamp_kernel(int* __restrict__ status, int* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // SSC spectrum of one cell (ICPhoton::generate_spectrum, inverse-compton.h:270-607): one wavefront per
-// representative cell.  Seed and electron lattices live in LDS; per electron energy the scattering CDF over the
-// seed lattice is a suffix scan done with wave shuffles (two seed bins per lane), the accumulation onto the
-// phase-locked output lattice is integer-indexed with one output node per lane (registers).
+// representative cell, after vag_ic_plan_kernel has laid out every cell's lattices one lane per cell.  Seed and
+// electron lattices live in LDS; the walk over electron energies keeps a lane's seed node(s) in registers and adds
+// each (energy, bin) term to two diagonal histograms in LDS, from which ONE suffix sum per cell gives the table on the
+// phase-locked output lattice (see the comment at the loop).
 // ------------------------------------------------------------------------------------------------
-// LDS of one wavefront (= one cell).  The setup arrays are dead once every lane holds its two seed nodes in registers, so
-// the accumulation loop's exchange rows and the KN-correction lattice reuse their memory: 13 KB instead of 21 KB per
-// wavefront, i.e. 12 resident wavefronts per CU instead of 7 for a kernel that lives on latency hiding.
+// LDS of one wavefront (= one cell).  The setup arrays are dead once every lane holds its seed nodes in registers, so
+// the histograms and the KN-correction lattice reuse their memory: 11 KB per wavefront, i.e. 13-14 resident wavefronts
+// per CU for a kernel that needs them to keep the VALU busy.
 constexpr int IC_MAX_DIAG = 256;  // >= (IC_MAX_NU - 2) + 2 (IC_MAX_G - 1) + 1 = 253
 struct IcShared {
     double nu[IC_MAX_NU];  // live throughout
@@ -623,11 +624,12 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         for (int a = 0; a < NB; ++a) nuN[a] = next_of(nu_a, a);
         __syncthreads();  // every setup array has been read: from here on their memory holds D / E / corr / lg2corr
         for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
-        if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574
-            const int n_lat = 2 * (g_size - 1) + 2 * (nu_size - 1) + 1;
+        if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by
+                   // two quanta, so only the even nodes of the reference's lattice are ever read: node q here is its node 2 q
+            const int n_lat = (g_size - 1) + (nu_size - 1) + 1;
             const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
             for (int q = lane; q < n_lat; q += 64)
-                compton_correction_pair_lg2(lg2_base + IC_Q * (double)q, kn_lut, sh.corr[q], sh.lg2corr[q]);
+                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, sh.corr[q], sh.lg2corr[q]);
         }
         __syncthreads();
         int my_split = nu_size;  // Thomson: no bin lies at or above the split
@@ -659,8 +661,8 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
                 const bool kn = jn[a] >= j_split && jn[a] <= nu_last;
-                f[a] = kn ? fth[a] * sh.corr[i_gamma + 2 * jn[a]] : fth[a];
-                lf[a] = kn ? lth[a] + sh.lg2corr[i_gamma + 2 * jn[a]] : 0.0;
+                f[a] = kn ? fth[a] * sh.corr[i + jn[a]] : fth[a];
+                lf[a] = kn ? lth[a] + sh.lg2corr[i + jn[a]] : 0.0;
             }
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
