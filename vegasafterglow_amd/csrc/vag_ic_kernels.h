@@ -358,7 +358,7 @@ VAG_DEV double power_law_bin_integral(double f_lo, double f_hi, double nu_lo, do
                                       double lg2r, double inv_lg2r, double trap) {
     if (!(f_lo > 0) || !(f_hi > 0)) return trap;
     const double s1 = 1 + (lg2f_hi - lg2f_lo) * inv_lg2r;
-    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) * rcp_fast(s1);  // 1e-3 < |s1| < inf: no IEEE division needed
+    if (fabs(s1) > 1e-3) return (f_hi * nu_hi - f_lo * nu_lo) * rcp_ode(s1);  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
     return f_lo * nu_lo * lg2r * 0.6931471805599453;
 }
 
@@ -612,7 +612,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             nu_a[a] = ld(sh.nu, jn[a]);
             fth[a] = ld(sh.fv_th, jn[a]);
             lth[a] = ld(sh.lg2fv, jn[a]);
-            dnu[a] = bin[a] ? sh.dnu[jn[a]] : 0.0;
+            dnu[a] = bin[a] ? 0.5 * sh.dnu[jn[a]] : 0.0;  // half the bin width: the trapezoid's factor
             lgr[a] = bin[a] ? sh.lg2r[jn[a]] : 0.0;
             ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
             rth[a] = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
@@ -668,7 +668,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             for (int a = 0; a < NB; ++a) {
                 const double fN = next_of(f, a), lfN = next_of(lf, a);
                 // bins below the split keep the Thomson integral and ratio (but see the corrected f at their upper edge j_split)
-                const double trap = 0.5 * (f[a] + fN) * dnu[a];
+                const double trap = (f[a] + fN) * dnu[a];
                 double ex = exth[a], term = trap * rth[a];
                 if (bin[a] && jn[a] >= j_split) {
                     ex = power_law_bin_integral(f[a], fN, nu_a[a], nuN[a], lf[a], lfN, lgr[a], ilr[a], trap);
