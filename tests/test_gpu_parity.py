@@ -407,6 +407,34 @@ def test_ssc_series_and_loglike(eng, oracle):
         assert abs(ll[w] - (-0.5 * chi2)) <= 1e-5 * max(1.0, abs(chi2)), (w, ll[w], -0.5 * chi2)
 
 
+def test_ssc_loglike_with_a_rejected_walker_between_valid_ones(eng, oracle):
+    """A walker outside the model's domain (theta_c < 0: the reference's eval_one returns -inf, samplers.py:61-70) in the middle
+    of an SSC batch: its cells get no lattice plan and no table (vag_ic_plan_kernel finishes them), the table memory still
+    holds a larger, earlier call's rows, and the walkers on either side must score exactly what they score alone."""
+    rng = np.random.default_rng(11)
+    t = np.sort(10 ** rng.uniform(3.0, 6.0, 40))
+    nu = 10 ** rng.choice([14.7, 17.5, 23.0], size=t.size)
+    f = fitting.Fitter(z=1.0, lumi_dist=1e28, jet="gaussian", medium="ism", fwd_ssc=True, kn=True)
+    truth = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True)
+    f_obs = oracle.flux_density(truth, t, nu) * (1 + 0.05 * rng.standard_normal(t.size))
+    f.add_flux_density(nu, t, f_obs, 0.05 * f_obs)
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e51, 1e53, S.log), P("Gamma0", 100, 500, S.log), P("theta_c", -1.0, 0.2, S.linear),
+            P("theta_v", 0.0, 0.4, S.linear), P("n_ism", 0.1, 10, S.log), P("p", 2.1, 2.6, S.linear),
+            P("eps_e", 0.03, 0.3, S.log), P("eps_B", 1e-3, 1e-1, S.log), P("xi_e", 1.0, 1.0, S.fixed, 1.0)]
+    lo = np.array([51, 2.0, 0.05, 0.0, -1, 2.1, np.log10(0.03), -3])
+    hi = np.array([53, np.log10(500), 0.2, 0.4, 1, 2.6, np.log10(0.3), -1])
+    big = lo + (hi - lo) * rng.random((12, 8))
+    assert np.all(np.isfinite(f.loglike_batch(big, defs)))  # leaves 12 walkers' tables behind
+    theta = big[:5].copy()
+    theta[2, 2] = -0.5  # theta_c < 0
+    ll = f.loglike_batch(theta, defs)
+    assert np.isneginf(ll[2]) and f.last_plan.n_walkers_rejected == 1
+    for w in (0, 1, 3, 4):
+        alone = f.loglike_batch(theta[w:w + 1], defs)
+        assert np.isfinite(alone[0]) and ll[w] == alone[0], (w, ll[w], alone[0])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Reverse-shock tier (SURVEY section 8(f) rank 2): Model(rvs_rad=Radiation(...))
 #
