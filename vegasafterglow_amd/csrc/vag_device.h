@@ -731,9 +731,9 @@ VAG_DEV double cool_after_crossing(double gamma_x, double gamma_m_x, double gamm
 }
 
 // `inj` = electrons frozen at the crossing cell for a relic cell of a reverse shock (cool_relic_electrons,
-// synchrotron.h:187-201), nullptr otherwise.
+// synchrotron.h:187-201), used when `relic` (by value: a pointer would put the caller's copy in scratch memory).
 VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double Gamma, double Gamma_th, double B,
-                      double N_p, double eps_e, double p, double xi_e, const ElecBasic* inj = nullptr) {
+                      double N_p, double eps_e, double p, double xi_e, bool relic = false, ElecBasic inj = ElecBasic{0, 1, 0}) {
     // --- electrons (synchrotron.cpp:315-360) ---
     const ElecBasic eb = syn_elec_basic(t_comv, Gamma_th, B, eps_e, p, xi_e);
     double gamma_M = eb.gamma_M;
@@ -744,9 +744,9 @@ VAG_DEV void syn_cell(CellOut& o, double t_eng, double t_comv, double r, double 
     const double column_den = N_e / (r * r);
     const double I_peak = syn_I_peak(B, column_den);
     double gamma_c = eb.gamma_c;
-    if (inj) {
-        gamma_c = cool_after_crossing(inj->gamma_c, inj->gamma_m, gamma_m);
-        gamma_M = cool_after_crossing(inj->gamma_M, inj->gamma_m, gamma_m);
+    if (relic) {
+        gamma_c = cool_after_crossing(inj.gamma_c, inj.gamma_m, gamma_m);
+        gamma_M = cool_after_crossing(inj.gamma_M, inj.gamma_m, gamma_m);
     }
     // compute_syn_gamma_a with no IC (ratio exactly 1), synchrotron.cpp:212-246
     double gamma_a;

@@ -439,7 +439,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
         raw_shock[VS_NP * n_cells + c] = c_Np;
     }
     CellOut o;
-    ElecBasic inj;
+    ElecBasic inj{0, 1, 0};
     bool relic = false;
     if (inj_idx) {  // Shock::is_relic, shock.h:56
         const int k_inj = inj_idx[lay.row_off[m] + r];
@@ -451,7 +451,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
         }
     }
     syn_cell(o, shock[VS_TENG * n_cells + c], shock[VS_TCOMV * n_cells + c], shock[VS_R * n_cells + c],
-             shock[VS_GAMMA * n_cells + c], c_Gth, c_B, c_Np, P.eps_e, P.p, P.xi_e, relic ? &inj : nullptr);
+             shock[VS_GAMMA * n_cells + c], c_Gth, c_B, c_Np, P.eps_e, P.p, P.xi_e, relic, inj);
     double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
 #pragma unroll
     for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];
