@@ -1,5 +1,7 @@
 """Ad-hoc robustness sweep: forward shock with SSC (Thomson and Klein-Nishina) on random draws of a wide box, both components
-against the checker.  usage: python profiles/debug/prior_sweep_ssc.py [n]"""
+against the checker.  usage: [SWEEP_MODE=spread|magnetar|nonaxi] python profiles/debug/prior_sweep_ssc.py [n]
+(SWEEP_MODE widens the jets: two-component / step-power-law / wing profiles with lateral spreading, a magnetar, or
+axisymmetric=False)"""
 import os, sys
 import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,6 +30,17 @@ for kn in (True, False):
             kw.update(n_ism=10 ** rng.uniform(-3, 2))
         if jet == "PowerLawJet":
             kw.update(k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+        mode = os.environ.get("SWEEP_MODE", "")
+        if mode == "spread":
+            kw["spreading"] = True
+            kw["jet"] = ["TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing"][i % 6]
+            if kw["jet"] in ("TwoComponentJet", "StepPowerLawJet", "PowerLawWing"):
+                kw.update(theta_w=kw["theta_c"] * rng.uniform(1.5, 3.0), E_iso_w=kw["E_iso"] * 10 ** rng.uniform(-2, -0.5),
+                          Gamma0_w=max(20.0, kw["Gamma0"] * rng.uniform(0.1, 0.5)), k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+        elif mode == "magnetar":
+            kw["magnetar"] = (10 ** rng.uniform(45, 48), 10 ** rng.uniform(2, 4), rng.uniform(1.5, 2.5))
+        elif mode == "nonaxi":
+            kw["axisymmetric"] = False
         prms.append(_abi.make_params(**kw))
     arr = (_lib.ModelParams * n)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
     s, c = np.empty((n, nu.size, t.size)), np.empty((n, nu.size, t.size))
