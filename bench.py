@@ -86,7 +86,7 @@ def cpu_rate(call, n_items, budget_s, unit, what, min_calls=2):
     return {"value": n / dt, "unit": unit, "cores": 1, "kind": lib_kind, "sample": f"{n} {what}, single thread, {dt:.1f} s"}
 
 
-def cpu_rate_all_cores(call, n_items, budget_s, unit, what):
+def cpu_rate_all_cores(call, n_items, budget_s, unit, what, counts=(8, 32, None)):
     """Same on many host cores, one model per thread (the reference's own scheme: ThreadPoolExecutor over walkers with the GIL
     released, fitting/samplers.py:59-91; ctypes drops the GIL too).  The box may expose more logical CPUs than its quota
     grants, so a few thread counts are tried and the best throughput is reported with the count that produced it."""
@@ -96,7 +96,7 @@ def cpu_rate_all_cores(call, n_items, budget_s, unit, what):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     best = None
-    for nthreads in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+    for nthreads in sorted({min(k or ncpu, ncpu) for k in counts}):
         deadline = time.perf_counter() + budget_s
 
         def worker(w):
@@ -221,7 +221,7 @@ def tophat_sweep(lib, h, _lib, dev, with_cpu):
     return out
 
 
-def ensemble_bench(lib, h, _lib, dev):
+def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=128):
     """BASELINE configs[2] and [4] as batched ensembles on one GPU: C3 = power-law jet in a wind, forward +
     reverse shock with SSC + Klein-Nishina on both (jittered parameters); C5 = prior-predictive sweep of two-component SSC
     jets, 1024 members.  100 times x 4 bands (incl. 2.4e26 Hz), device-resident inputs.  The flux passes' FP64 roofline uses the
@@ -232,7 +232,7 @@ def ensemble_bench(lib, h, _lib, dev):
     from ssc_ensemble import c3_batch, c5_batch
     t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
     out = {}
-    for name, prms, ref_ms in (("C3_fs_rs_ssc_kn", c3_batch(128), 1197.0), ("C5_two_component_ssc", c5_batch(1024), 1120.0)):
+    for name, prms in (("C3_fs_rs_ssc_kn", c3_batch(c3_models)), ("C5_two_component_ssc", c5_batch(1024))):
         nb = len(prms)
         call = _grid_call(lib, h, _lib, dev, prms, t, nu)
         call()
@@ -271,7 +271,14 @@ def ensemble_bench(lib, h, _lib, dev):
                                                   "achieved": (plan.ic_terms * F_IC_TERM + plan.ic_nodes * F_IC_NODE) / max(prof.ic_photons * 1e-3, 1e-12) / 1e12,
                                                   "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                                   "frac": (plan.ic_terms * F_IC_TERM + plan.ic_nodes * F_IC_NODE) / max(prof.ic_photons * 1e-3, 1e-12) / 1e12 / PEAK_FP64_TFLOPS},
-                     "reference_cpu_ms_per_model_survey": ref_ms}
+                     }
+        if with_cpu:  # the reference's own code on THIS box's host cores, same models, same request (about 1 s per model and core)
+            cpu, _ = _cpu_lib()
+            f = lambda i, prms=prms: cpu.flux_density_grid(prms[i], t, nu)
+            one = cpu_rate(f, 8, 3.0, "light-curves/s", "models of the timed batch", min_calls=3)
+            allc = cpu_rate_all_cores(f, 64, 4.0, "light-curves/s", "models", counts=(32, None))
+            out[name]["cpu_baseline"], out[name]["cpu_baseline_all_cores"] = one, allc
+            out[name]["speedup_vs_reference"] = {"vs_1_core": (nb / dt) / one["value"], "vs_all_cores": (nb / dt) / allc["value"]}
     return out
 
 
@@ -365,7 +372,10 @@ def walker_cpu_baseline(lib, h, _lib, budget_s=5.0):
         prms.append(_abi.make_params(**kw))
     order = np.argsort(t)
     ts, nus = np.ascontiguousarray(t[order]), np.ascontiguousarray(nu[order])
-    return cpu_rate(lambda i: cpu.flux_density(prms[i], ts, nus), 64, budget_s, "walker-steps/s", "prior draws of the C4 box (60 data points each)")
+    f = lambda i: cpu.flux_density(prms[i], ts, nus)
+    one = cpu_rate(f, 64, budget_s, "walker-steps/s", "prior draws of the C4 box (60 data points each)")
+    allc = cpu_rate_all_cores(f, 64, 2.0, "walker-steps/s", "prior draws of the C4 box")  # the reference's own scheme: a thread pool over walkers
+    return one, allc
 
 
 def main():
@@ -377,6 +387,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walkers", action="store_true", help="skip everything but the headline measurement")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line and nothing else: RCCL prints its version banner to the C stdout when a communicator is
+    # created, so fd 1 points at stderr while the bench runs and the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -437,9 +453,11 @@ def main():
     walkers = walker_bench(lib, h, _lib, dev, rank, world) if extra else None
     walkers_half = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=512) if extra else None
     walkers_queued = walker_bench(lib, h, _lib, dev, rank, world, host_consumes=False) if extra else None
-    # an ensemble sized to the node (1024 walkers per GPU): the weak-scaling counterpart of the 1024-walker run above
+    # an ensemble sized to the node (1024 walkers per GPU): the weak-scaling counterpart of the 1024-walker run above; and a
+    # 8192-walker ensemble over all ranks (what a nested sampler's live-point pool or a large emcee ensemble hands over)
     walkers_weak = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=1024 * world) if (world > 1 and extra) else None
-    shares = None
+    walkers_8192 = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=8192, steps=5) if (world > 1 and extra) else None
+    shares = sharded1 = None
     if extra and world == 1:  # what ONE rank of an 8-GPU run evaluates per call, measured here: the strong-scaling ceiling
         s128 = walker_bench(lib, h, _lib, dev, 0, 1, nwalkers=128)
         s64 = walker_bench(lib, h, _lib, dev, 0, 1, nwalkers=64)
@@ -448,9 +466,29 @@ def main():
                   "implied_8gpu_redblue_walker_steps_per_s": 512.0 / (s64["ms_per_step"] * 1e-3),
                   "implied_8gpu_speedup_over_1gpu": walkers["ms_per_step"] / s128["ms_per_step"],
                   "note": "per-rank block of a 1024-walker (512 red-blue) step at 8 GPUs, timed on one GPU without the all-gather"}
+        # The code an N-GPU run executes, timed on one GPU: a world-size-1 RCCL group makes WalkerSharder take its sharded branch
+        # (device-side deal, the rank's block, all_gather_into_tensor over RCCL, scatter) instead of the plain call above.
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        sk.close()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        try:
+            plain = {1024: walkers, 512: walkers_half, 128: s128, 64: s64}
+            sharded1 = {"note": "dist.WalkerSharder's sharded branch over a world-size-1 nccl (RCCL) group on this GPU vs the plain "
+                                "evaluator call; ln L read by the host after every call in both"}
+            for n in (1024, 512, 128, 64):
+                r = walker_bench(lib, h, _lib, dev, 0, 1, nwalkers=n)
+                sharded1[f"{n}_walkers"] = {"ms_per_step_sharded": r["ms_per_step"], "ms_per_step_plain": plain[n]["ms_per_step"],
+                                            "sharder_overhead_ms": r["ms_per_step"] - plain[n]["ms_per_step"],
+                                            "walker_steps_per_s_sharded": r["value"], "finite_walkers": r["finite_walkers"]}
+        finally:
+            dist.destroy_process_group()
     with_cpu = not args.no_cpu_baseline and world == 1
     tophat = tophat_sweep(lib, h, _lib, dev, with_cpu) if (extra and world == 1) else None
-    ensembles = ensemble_bench(lib, h, _lib, dev) if (extra and world == 1) else None
+    ensembles = ensemble_bench(lib, h, _lib, dev, with_cpu) if (extra and world == 1) else None
 
     if rank == 0:
         st = np.mean(np.array(flux_ms), axis=0)
@@ -485,7 +523,7 @@ def main():
         }
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh; FETCH_SIZE x2 per the gfx950 note, calibrated on a kernel with known bytes)
-        for tp in ("r02_traffic.json", "r01_traffic.json"):
+        for tp in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tp) and nb == 512 and world == 1:
                 out["roofline"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
@@ -497,6 +535,10 @@ def main():
             if walkers_weak:
                 walkers_weak["scaling"] = "weak"
                 out["walker_steps_1024_per_gpu"] = walkers_weak
+            if walkers_8192:
+                out["walker_steps_8192_total"] = walkers_8192
+            if sharded1:
+                out["walker_steps_sharded_branch_world1"] = sharded1
             if shares:
                 out["walker_steps_per_rank_share_of_8gpu"] = shares
         if tophat is not None:
@@ -513,14 +555,23 @@ def main():
             f = lambda i: cpu.flux_density_grid(arr[i], t_np, nu_np)
             out["cpu_baseline"] = cpu_rate(f, len(arr), 12.0, "light-curves/s", "models of the timed batch (C2: 200 t x 10 nu)")
             out["cpu_baseline_all_cores"] = cpu_rate_all_cores(f, len(arr), 4.0, "light-curves/s", "models")
+            # `vs_baseline` stays null: BASELINE.md holds no published number for this metric on this config (its table is a
+            # different protocol on an Apple M2).  The same-box ratio against the reference's own thread-pool scheme is this:
+            out["vs_reference_all_cores_same_box"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
+            out["vs_reference_1_core_same_box"] = out["value"] / out["cpu_baseline"]["value"]
             if walkers is not None:
-                wc = walker_cpu_baseline(lib, h, _lib)
+                wc, wall = walker_cpu_baseline(lib, h, _lib)
                 out["walker_steps"]["cpu_baseline"] = wc
+                out["walker_steps"]["cpu_baseline_all_cores"] = wall
                 out["walker_steps"]["speedup_vs_reference_1_core"] = walkers["value"] / wc["value"]
-        print(json.dumps(out))
+                out["walker_steps"]["speedup_vs_reference_all_cores"] = walkers["value"] / wall["value"]
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     lib.vag_ctx_destroy(h)
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)  # whatever C stdio still buffers goes to stderr too
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 8
+#define VAG_ABI_VERSION 9
 
 /* error codes */
 #define VAG_OK 0
@@ -159,6 +159,9 @@ void vag_ctx_destroy(vag_ctx* ctx);
  * (PyTorch's default `torch.cuda.current_stream()` IS that stream: its `.cuda_stream` is 0). */
 #define VAG_STREAM_LEGACY_DEFAULT ((void*)1)
 int vag_ctx_set_stream(vag_ctx* ctx, void* hip_stream);
+/* The value vag_ctx_set_stream would take to select the stream the context is on now (NULL = its own): lets a caller that
+ * borrows the context for one call on another stream put the previous one back (ABI v9). */
+int vag_ctx_get_stream(vag_ctx* ctx, void** out);
 int vag_ctx_synchronize(vag_ctx* ctx);
 
 /* Static per-model capacity limits of the device grids (rows/time nodes). */
@@ -311,6 +314,8 @@ typedef struct vag_fit_spec {
 #define VAG_PRIOR_GAUSSIAN 1    /* -(x - mu)^2 / (2 sigma^2) - ln(sigma sqrt(2 pi)) */
 #define VAG_PRIOR_LOG_UNIFORM 2 /* -ln(x ln(max / min)) for min <= x <= max, else -inf */
 #define VAG_PRIOR_NONE 3        /* 0 inside the bounds: the caller adds its own ln prior for this parameter */
+#define VAG_PRIOR_UNIFORM_RANGE 4 /* ABI v9: bilby Uniform(minimum = prior_a, maximum = prior_b) with its OWN support:
+                                   * -ln(max - min) for min <= x <= max, else -inf (narrower or wider than the bounds) */
 
 /* theta is [nb][ndim] (host); out is [nb] log-likelihoods (host).  Walkers whose
  * transformed parameters fail validation get -inf, like eval_one's except branch. */
@@ -328,6 +333,30 @@ int vag_loglike_batch_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* 
  * no host synchronisation.  A sharded sampler balances the next call's walker blocks with it: walker cost varies 8x over a
  * prior box because every walker builds its own adaptive grid (fitter.py:503-533). */
 int vag_last_model_costs_dev(vag_ctx* ctx, int nb, double* d_cost);
+
+/*
+ * ABI v9 -- one rank's share of a sharded log_prob_batch (the reference spreads eval_one over a thread pool,
+ * VegasAfterglow/fitting/samplers.py:72-91; here the walkers are spread over the GPUs of a node, one process per GPU).
+ * Every rank holds the SAME d_theta_all[nb_all][ndim] and calls, in this order and without any host work in between:
+ *
+ *   vag_loglike_shard_dev        deals the walkers on the device -- ranked by the cost the engine reported for them in the previous
+ *                                finished call of this size (stable, descending), position q = sweep * world + k goes to rank k on
+ *                                even sweeps and world-1-k on odd ones, so every rank gets ceil(nb_all / world) slots (`per`) of
+ *                                near-equal total cost --, evaluates this rank's walkers and writes d_block[per][2] =
+ *                                {ln L (+ ln prior with use_priors), cost}; padding slots carry {NaN, 0};
+ *   <the caller's all-gather>    d_gathered[world * per][2] = the ranks' blocks in rank order (RCCL / any transport);
+ *   vag_loglike_shard_finish_dev scatters d_gathered back into walker order, d_out[nb_all], and keeps the gathered costs for the
+ *                                next deal (a walker that was not evaluated, cost 0, is assumed average).
+ *
+ * The deal is a function of the gathered costs only, so all ranks compute the same one without talking.  Stream-ordered on the
+ * context stream like vag_loglike_batch_dev; rank / world are the caller's (no communicator is touched here).
+ */
+int vag_loglike_shard_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank,
+                          int world, double* d_block);
+int vag_loglike_shard_finish_dev(vag_ctx* ctx, const double* d_gathered, int nb_all, int world, double* d_out);
+/* For inspection (either pointer may be NULL): d_table[world * per] = walker of every (rank, slot) in the last deal, -1 = padding;
+ * d_cost[nb_all] = the gathered costs the NEXT deal will rank by (after a finished call). */
+int vag_loglike_shard_state_dev(vag_ctx* ctx, int nb_all, int world, int32_t* d_table, double* d_cost);
 
 /*
  * Model.details(t_min, t_max) intermediates for ONE model (pybind/pymodel.cpp:315-348):

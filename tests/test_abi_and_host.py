@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert lib.vag_abi_version() == 8
+    assert lib.vag_abi_version() == 9
     assert b"gfx950" in lib.vag_version()
 
 
@@ -197,6 +197,47 @@ def test_log_prob_batch_bounds_prior_and_nonfinite_handling():
     ln_prior = -np.log(4.0) - np.log(0.8)
     assert got[0] == -np.inf and got[1] == -np.inf and got[3] == -np.inf
     np.testing.assert_allclose(got[[2, 4]], np.array([-1.0, -2.0]) + ln_prior)
+
+
+def test_priors_are_kept_when_a_sharded_loglike_is_substituted():
+    """make_log_prob_batch(loglike_fn=..., priors=...) (the multi-GPU form): the reference's log_prob_batch always adds
+    prior_dict[name].ln_prob (samplers.py:72-91), so Gaussian / LogUniform / Uniform-with-own-support / object priors must all
+    reach the result, and a sample outside the bounds or a prior's support is never evaluated."""
+    f = fitting.Fitter(z=0.1, lumi_dist=1e27, jet="gaussian", medium="ism")
+    f.add_flux_density(1e9, np.array([1e4, 1e5]), np.array([1e-27, 2e-27]), np.array([1e-28, 2e-28]))
+    defs = [fitting.ParamDef("E_iso", 1e50, 1e54, fitting.Scale.log), fitting.ParamDef("theta_c", 0.02, 0.5),
+            fitting.ParamDef("p", 2.05, 2.9), fitting.ParamDef("eps_e", 1e-3, 0.5, fitting.Scale.log)]
+
+    class Triangle:  # an object the device does not know: only ln_prob
+        def ln_prob(self, x):
+            return np.log(np.clip(1 - np.abs(x - 2.5) / 0.5, 1e-300, None))
+
+    class Uniform:  # shaped like bilby.core.prior.Uniform, narrower than the ParamDef
+        minimum, maximum = -2.5, -0.7
+
+    priors = {"E_iso": ("gaussian", 52.0, 0.7), "theta_c": ("log_uniform", 0.01, 1.0), "p": Triangle(), "eps_e": Uniform()}
+    seen = []
+
+    def loglike(block):
+        seen.append(np.array(block))
+        return -0.5 * np.sum(block ** 2, axis=1)
+    lpb = f.make_log_prob_batch(defs, loglike_fn=loglike, priors=priors)
+    x = np.array([[52.3, 0.1, 2.4, -1.0], [49.0, 0.1, 2.4, -1.0], [52.3, 0.1, 2.4, -2.8], [51.0, 0.3, 2.7, -2.0]])
+    got = lpb(x)
+    ok = [0, 3]
+    assert np.all(got[[1, 2]] == -np.inf) and len(seen) == 1 and np.array_equal(seen[0], x[ok])  # out of bounds / support: not evaluated
+    want = (-0.5 * np.sum(x[ok] ** 2, axis=1)
+            + (-0.5 * ((x[ok, 0] - 52.0) / 0.7) ** 2 - np.log(0.7 * np.sqrt(2 * np.pi)))
+            + (-np.log(x[ok, 1] * np.log(1.0 / 0.01)))
+            + priors["p"].ln_prob(x[ok, 2])
+            + (-np.log(-0.7 + 2.5)))
+    np.testing.assert_allclose(got[ok], want, rtol=1e-14)
+    # the device spec carries the same kinds: Uniform-with-own-support is VAG_PRIOR_UNIFORM_RANGE, the object stays on the host
+    spec, _, _ = f.build_spec(defs, priors=priors, use_priors=True)
+    assert list(spec.prior_kind[:4]) == [_lib.PRIOR_GAUSSIAN, _lib.PRIOR_LOG_UNIFORM, _lib.PRIOR_NONE, _lib.PRIOR_UNIFORM_RANGE]
+    assert (spec.prior_a[3], spec.prior_b[3]) == (-2.5, -0.7) and [d for d, _ in f._host_priors] == [2]
+    with pytest.raises(ValueError, match="host-only priors"):
+        f.device_evaluator(defs, priors=priors, use_priors=True)
 
 
 def test_stretch_move_sampler_recovers_a_gaussian_posterior():

@@ -131,6 +131,47 @@ def test_balanced_assignment_equal_counts_near_equal_costs():
             assert sums.max() / sums.mean() <= by_count.max() / by_count.mean()
 
 
+def test_deal_is_the_boustrophedon_deal_of_the_cost_ranking():
+    """balanced_assignment / deal_positions (vectorised; what the device kernels and the torch path compute) against the plain
+    statement of the deal: units in order of decreasing cost, ranks 0..w-1, w-1..0, ... sweep by sweep."""
+    rng = np.random.default_rng(3)
+    for n, world in ((1, 1), (5, 1), (9, 2), (203, 8), (1024, 8), (3, 8), (64, 3)):
+        costs = np.round(np.exp(rng.uniform(0, 2, n)), 1)  # rounded: ties must keep their original order
+        per = -(-n // world)
+        want = np.full((world, per), -1, dtype=np.int64)
+        for pos, unit in enumerate(np.argsort(-costs, kind="stable")):
+            sweep, k = divmod(pos, world)
+            want[k if sweep % 2 == 0 else world - 1 - k, sweep] = unit
+        np.testing.assert_array_equal(vdist.balanced_assignment(costs, world), want)
+        q = vdist.deal_positions(n, world)
+        assert np.array_equal(np.sort(q[q >= 0]), np.arange(n))
+
+
+def test_sharder_makes_no_host_round_trip_per_call(monkeypatch):
+    """Nothing in WalkerSharder.__call__ may read a tensor back (the r02 sharder spent 0.7 ms per call in a Python deal and a
+    .cpu() of the costs): with a 1-rank gloo group and .cpu / .item / .numpy / .tolist disabled, two calls must still run."""
+    import torch
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        theta = torch.from_numpy(np.random.default_rng(0).random((37, 3)))
+        sharder = vdist.WalkerSharder(lambda th: (th.sum(1), 1.0 + th[:, 0]))
+        first = sharder(theta)  # builds the cached slot positions (host work, once per (nb, world))
+
+        def forbidden(*a, **k):
+            raise AssertionError("host read inside WalkerSharder.__call__")
+        for name in ("cpu", "item", "numpy", "tolist"):
+            monkeypatch.setattr(torch.Tensor, name, forbidden)
+        second = sharder(theta)
+        third = sharder(theta)
+        monkeypatch.undo()
+        assert torch.equal(first, theta.sum(1)) and torch.equal(second, first) and torch.equal(third, first)
+        np.testing.assert_array_equal(sharder.last_table[0], np.argsort(-(1.0 + theta[:, 0].numpy()), kind="stable"))
+    finally:
+        dist.destroy_process_group()
+
+
 def _sharder_worker(rank, world, port, samples, data, q):
     import torch
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -282,8 +282,16 @@ def test_sharded_evaluator_over_rccl_world_size_1(eng, oracle):
         got = sharder(d_theta)
         assert got.device.type == "cuda"
         assert np.array_equal(got.cpu().numpy(), want)
+        assert sharder.native is not None  # the engine's own deal / scatter (vag_loglike_shard_dev), not the torch statement of it
         got2 = sharder(d_theta)  # second call: dealt by the engine's cost report
         assert np.array_equal(got2.cpu().numpy(), want)
+        plain = f.device_evaluator(defs)
+        generic = WalkerSharder(lambda th: plain(th), device=dev)  # no .native: the same deal from torch operations
+        assert generic.native is None
+        for _ in range(2):
+            assert np.array_equal(generic(d_theta).cpu().numpy(), want)
+        assert np.array_equal(generic.last_table, sharder.last_table)
+        np.testing.assert_allclose(generic.costs, sharder.costs, rtol=1e-15)
         costs = sharder.costs_per_rank()
         assert costs is not None and costs.shape == (1,) and costs[0] > 0
         assert sharder.costs.min() > 0 and sharder.costs.max() / sharder.costs.min() > 1.5  # ragged grids: cost varies
@@ -306,3 +314,62 @@ def test_sharded_evaluator_over_rccl_world_size_1(eng, oracle):
         np.testing.assert_array_equal(full.cpu().numpy(), eval_dev(prms).cpu().numpy())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_native_shard_entry_points_reproduce_the_plain_call_for_every_world(eng, oracle, world):
+    """The N > 1 deal without N GPUs: vag_loglike_shard_dev is called once per (simulated) rank on this GPU, the blocks are
+    concatenated in rank order (what the all-gather does) and vag_loglike_shard_finish_dev scatters them.  ln L must be the bits
+    of one plain vag_loglike_batch_dev call whatever the deal; the device's table must be the numpy statement of the deal
+    (dist.balanced_assignment) on the gathered costs; the second deal balances the ranks' cost sums."""
+    import torch
+    from vegasafterglow_amd.dist import balanced_assignment, shard_range
+    lib, h = eng
+    f, defs = _c4_fitter(oracle)
+    spec, lo, hi = f.build_spec(defs)
+    nb, ndim = 203, len(defs)  # ragged: the last sweep has padding slots for every world here
+    samples = lo + (hi - lo) * np.random.default_rng(21).random((nb, ndim))
+    samples[7, 2] = -0.5  # invalid walker: -inf, cost 0 -> assumed average in the next deal
+    want = f.loglike_batch(samples, defs)
+    dev = torch.device("cuda", 0)
+    d_theta = torch.from_numpy(samples).to(dev)
+    per = -(-nb // world)
+    _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+    try:
+        prev_costs = np.ones(nb)
+        for call in range(3):
+            blocks, tables = [], []
+            for rank in range(world):
+                blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+                _lib.check(lib.vag_loglike_shard_dev(h, C.byref(spec), d_theta.data_ptr(), nb, ndim, rank, world, blk.data_ptr()))
+                tab = torch.empty((world * per,), dtype=torch.int32, device=dev)
+                _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, tab.data_ptr(), None))
+                blocks.append(blk)
+                tables.append(tab.cpu().numpy().reshape(world, per))
+            for tab in tables[1:]:
+                assert np.array_equal(tab, tables[0])  # every rank computes the same deal
+            assert np.array_equal(tables[0], balanced_assignment(prev_costs, world))
+            gathered = torch.cat(blocks, 0).contiguous()
+            out = torch.full((nb,), 123.0, dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr()))
+            cost = torch.empty((nb,), dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, None, cost.data_ptr()))
+            got, g = out.cpu().numpy(), gathered.cpu().numpy()
+            assert np.array_equal(got, want), call
+            pad = tables[0].reshape(-1) < 0
+            assert np.isnan(g[pad, 0]).all() and np.all(g[pad, 1] == 0) and pad.sum() == world * per - nb
+            raw = np.ones(nb)
+            raw[tables[0].reshape(-1)[~pad]] = g[~pad, 1]
+            assert raw[7] == 0 and (np.delete(raw, 7) > 0).all()
+            prev_costs = np.where(raw > 0, raw, raw[raw > 0].mean())
+            np.testing.assert_allclose(cost.cpu().numpy(), prev_costs, rtol=1e-15)
+            sums = np.array([prev_costs[row[row >= 0]].sum() for row in tables[0]])
+            if call >= 1:  # dealt by the previous call's costs: near-equal cost sums, better than blocks of equal count
+                by_count = np.array([prev_costs[a:b].sum() for a, b in (shard_range(nb, r, world) for r in range(world))])
+                assert sums.max() / sums.mean() < 1.03 and sums.max() / sums.mean() <= by_count.max() / by_count.mean()
+        # a finish without a matching shard call, and a rank outside the world, are refused
+        assert lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr()) == _lib.VAG_E_INVALID
+        assert lib.vag_loglike_shard_dev(h, C.byref(spec), d_theta.data_ptr(), nb, ndim, world, world, blk.data_ptr()) == _lib.VAG_E_INVALID
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_ctx_set_stream(h, None))

@@ -67,7 +67,7 @@ class FitSpec(C.Structure):
     ]
 
 
-PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_LOG_UNIFORM, PRIOR_NONE = 0, 1, 2, 3
+PRIOR_UNIFORM, PRIOR_GAUSSIAN, PRIOR_LOG_UNIFORM, PRIOR_NONE, PRIOR_UNIFORM_RANGE = 0, 1, 2, 3, 4
 
 
 class DetailsShape(C.Structure):
@@ -105,11 +105,11 @@ class Limits(C.Structure):
 
 EXPORTS = [
     "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
-    "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_synchronize",
+    "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_get_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_last_model_costs_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
 ]
 
 _lib = None
@@ -144,6 +144,7 @@ def load():
     lib.vag_ctx_destroy.argtypes = [v]
     lib.vag_ctx_destroy.restype = None
     lib.vag_ctx_set_stream.argtypes = [v, v]
+    lib.vag_ctx_get_stream.argtypes = [v, C.POINTER(v)]
     lib.vag_ctx_synchronize.argtypes = [v]
     lib.vag_get_limits.argtypes = [C.POINTER(Limits)]
     lib.vag_get_limits.restype = None
@@ -160,6 +161,9 @@ def load():
     lib.vag_loglike_batch.argtypes = [v, C.POINTER(FitSpec), _dp, C.c_int, C.c_int, _dp]
     lib.vag_loglike_batch_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, v]
     lib.vag_last_model_costs_dev.argtypes = [v, C.c_int, v]
+    lib.vag_loglike_shard_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, C.c_int, C.c_int, v]
+    lib.vag_loglike_shard_finish_dev.argtypes = [v, v, C.c_int, C.c_int, v]
+    lib.vag_loglike_shard_state_dev.argtypes = [v, C.c_int, C.c_int, v, v]
     lib.vag_ctx_profile.argtypes = [v, C.c_int]
     lib.vag_last_profile.argtypes = [v, C.POINTER(Profile)]
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]

@@ -281,6 +281,11 @@ struct vag_ctx {
     // not depend on its slot, so the result is the same bits.
     DevBuf d_order[2], d_cost_f;  // d_cost_f: per-slot cost of the last batch (written with the batch plan by the grid kernel)
     int order_cur = 0, order_nb = 0;  // order_nb: batch size d_order[order_cur] was computed for (0: none)
+    // sharded likelihood calls (vag_loglike_shard_dev): the gathered per-walker costs of the last finished call (what the next
+    // deal ranks by), the current deal (walker of every (rank, slot)), this rank's gathered theta rows / ln L
+    DevBuf d_shard_cost, d_shard_table, d_shard_theta, d_shard_ll;
+    int shard_nb = 0, shard_world = 0;      // what d_shard_cost was gathered for (0: no finished call yet)
+    int shard_cur_nb = 0, shard_cur_world = 0;  // the call between vag_loglike_shard_dev and its finish
     bool order_next = false, order_active = false;  // the next / the last model-stage run is in evaluation-slot order
     const int* last_order = nullptr;                // ... and the order it used
     bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > 320 theta / > 640 phi nodes)
@@ -537,6 +542,8 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
+    for (DevBuf* b : {&c->d_shard_cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f})
+        b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
@@ -550,6 +557,15 @@ int vag_ctx_set_stream(vag_ctx* c, void* s) {
         c->stream = nullptr;  // the legacy default stream
     else
         c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return VAG_OK;
+}
+
+int vag_ctx_get_stream(vag_ctx* c, void** out) {
+    if (!c || !out) return set_err(VAG_E_INVALID, "null context or pointer");
+    if (c->stream == c->own_stream)
+        *out = nullptr;
+    else
+        *out = c->stream ? reinterpret_cast<void*>(c->stream) : VAG_STREAM_LEGACY_DEFAULT;
     return VAG_OK;
 }
 
@@ -2258,7 +2274,8 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
         for (int d = 0; d < ndim; ++d) {
             if (!(spec->lower[d] < spec->upper[d])) return set_err(VAG_E_INVALID, "prior bounds of parameter %d: need lower < upper", d);
             const int k = spec->prior_kind[d];
-            if (k < VAG_PRIOR_UNIFORM || k > VAG_PRIOR_NONE) return set_err(VAG_E_INVALID, "unknown prior kind %d", k);
+            if (k < VAG_PRIOR_UNIFORM || k > VAG_PRIOR_UNIFORM_RANGE) return set_err(VAG_E_INVALID, "unknown prior kind %d", k);
+            if (k == VAG_PRIOR_UNIFORM_RANGE && !(spec->prior_b[d] > spec->prior_a[d])) return set_err(VAG_E_INVALID, "Uniform prior needs maximum > minimum");
             if (k == VAG_PRIOR_GAUSSIAN && !(spec->prior_b[d] > 0)) return set_err(VAG_E_INVALID, "Gaussian prior needs sigma > 0");
             if (k == VAG_PRIOR_LOG_UNIFORM && !(spec->prior_a[d] > 0 && spec->prior_b[d] > spec->prior_a[d]))
                 return set_err(VAG_E_INVALID, "LogUniform prior needs 0 < minimum < maximum");
@@ -2394,6 +2411,9 @@ vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, in
                 lp += (v >= mn && v <= mx) ? -log(v * log(mx / mn)) : -INFINITY;
             } else if (kind[d] == VAG_PRIOR_UNIFORM) {
                 lp += -log(hi - lo);
+            } else if (kind[d] == VAG_PRIOR_UNIFORM_RANGE) {
+                const double mn = prior[32 + d], mx = prior[48 + d];
+                lp += (v >= mn && v <= mx) ? -log(mx - mn) : -INFINITY;
             }
         }
         const double val = is_log[d] ? pow(10.0, v) : v;
@@ -2580,6 +2600,150 @@ int vag_last_model_costs_dev(vag_ctx* c, int nb, double* d_cost) {
     hipLaunchKernelGGL(vag_model_cost_kernel, dim3((nb + 127) / 128), dim3(128), 0, c->stream, c->d_meta.as<VagGridMeta>(), nb, d_cost,
                        c->order_active ? c->last_order : nullptr);
     HIPCHK(hipGetLastError());
+    return VAG_OK;
+}
+
+// ---- sharded log_prob_batch: the deal, this rank's block, the scatter after the caller's all-gather (ABI v9) ----
+
+// One wavefront per position-or-walker m.  m < nb_all: walker m's rank q by counting (stable, descending cost; without costs
+// every walker counts 1 and q = m), its (rank r, slot s) of the boustrophedon deal, table[r * per + s] = m, and -- when r is this
+// process's rank -- its theta row into the rank's compact block.  m >= nb_all: padding positions of the last sweep, table = -1.
+__global__ void __launch_bounds__(256)
+vag_shard_deal_kernel(const double* __restrict__ cost /* [nb_all] or null */, const double* __restrict__ theta_all, int nb_all,
+                      int ndim, int rank, int world, int per, int* __restrict__ table, double* __restrict__ theta_mine) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= world * per) return;
+    int q = m;
+    if (m < nb_all && cost) {
+        const double mine = cost[m];
+        q = 0;
+        for (int i0 = 0; i0 < nb_all; i0 += 64) {
+            const int i = i0 + lane;
+            const double c = i < nb_all ? cost[i] : -1.0;
+            q += __popcll(__ballot(c > mine || (c == mine && i < m)));
+        }
+    }
+    const int s = q / world, k = q - s * world;
+    const int r = (s & 1) ? world - 1 - k : k;
+    if (lane == 0) table[r * per + s] = m < nb_all ? m : -1;
+    if (m < nb_all && r == rank && lane < ndim) theta_mine[(size_t)s * ndim + lane] = theta_all[(size_t)m * ndim + lane];
+}
+
+// block[s] = {ln L, cost} of this rank's slot s (cost = the (theta, phi, t) cell count of vag_last_model_costs_dev), {NaN, 0} for padding
+__global__ void vag_shard_pack_kernel(const double* __restrict__ ll, const VagGridMeta* __restrict__ meta,
+                                      const int* __restrict__ order /* evaluation slot -> block slot, or null */, int n_mine, int per,
+                                      double* __restrict__ block) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= per) return;
+    if (s < n_mine) {
+        const VagGridMeta M = meta[s];
+        block[2 * (size_t)s] = ll[s];
+        block[2 * (size_t)(order ? order[s] : s) + 1] = M.status == 0 ? (double)M.n_theta * (double)M.n_phi_eff * (double)M.n_t : 0.0;
+    } else {
+        block[2 * (size_t)s] = NAN;
+        block[2 * (size_t)s + 1] = 0.0;
+    }
+}
+
+// One workgroup: ln L back into walker order, the gathered costs kept for the next deal (a walker that was not evaluated is
+// assumed average: the mean of the positive costs, or 1).
+__global__ void __launch_bounds__(1024)
+vag_shard_finish_kernel(const double* __restrict__ gathered, const int* __restrict__ table, int n_slots, double* __restrict__ out,
+                        double* __restrict__ cost) {
+    __shared__ double s_sum[16];
+    __shared__ double s_cnt[16];
+    double sum = 0, cnt = 0;
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        const int w = table[i];
+        if (w < 0) continue;
+        out[w] = gathered[2 * (size_t)i];
+        const double cw = gathered[2 * (size_t)i + 1];
+        if (cw > 0) sum += cw, cnt += 1;
+    }
+    sum = vag::wave_sum(sum);
+    cnt = vag::wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum, s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    sum = 0, cnt = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) sum += s_sum[i], cnt += s_cnt[i];
+    const double mean = cnt > 0 ? sum / cnt : 1.0;
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        const int w = table[i];
+        if (w < 0) continue;
+        const double cw = gathered[2 * (size_t)i + 1];
+        cost[w] = cw > 0 ? cw : mean;
+    }
+}
+
+int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
+                          double* d_block) {
+    if (!c || !spec || !d_theta_all || !d_block) return set_err(VAG_E_INVALID, "null context, spec or buffer");
+    if (nb_all <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
+    if (world <= 0 || rank < 0 || rank >= world) return set_err(VAG_E_INVALID, "rank %d outside a world of %d", rank, world);
+    if (ndim <= 0 || ndim > 16) return set_err(VAG_E_INVALID, "ndim must be 1..16");
+    HIPCHK(hipSetDevice(c->device));
+    const int per = (nb_all + world - 1) / world;
+    // slots of this rank that hold a walker: positions q = s * world + k(s) < nb_all
+    int n_mine = 0;
+    for (int s = 0; s < per; ++s) {
+        const int k = (s & 1) ? world - 1 - rank : rank;
+        if ((long long)s * world + k < nb_all) ++n_mine;
+    }
+    if (c->d_shard_table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
+    if (c->d_shard_theta.ensure(sizeof(double) * (size_t)per * ndim)) return VAG_E_HIP;
+    if (c->d_shard_ll.ensure(sizeof(double) * (size_t)per)) return VAG_E_HIP;
+    if (c->d_shard_cost.ensure(sizeof(double) * (size_t)nb_all)) return VAG_E_HIP;
+    // ranking by counting is O(nb_all^2 / 64) per call: beyond 16384 walkers the deal stays by position (equal counts)
+    const bool ranked = c->shard_nb == nb_all && c->shard_world == world && nb_all <= 16384;
+    hipLaunchKernelGGL(vag_shard_deal_kernel, dim3((world * per + 3) / 4), dim3(256), 0, c->stream,
+                       ranked ? c->d_shard_cost.as<double>() : nullptr, d_theta_all, nb_all, ndim, rank, world, per,
+                       c->d_shard_table.as<int>(), c->d_shard_theta.as<double>());
+    HIPCHK(hipGetLastError());
+    c->shard_cur_nb = nb_all;
+    c->shard_cur_world = world;
+    const int* d_order = nullptr;
+    if (n_mine > 0) {
+        int rc = upload_fit_spec(c, spec, ndim);
+        if (rc) return rc;
+        rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), !c->count_work);
+        if (rc == VAG_RETRY) rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), false);
+        if (rc) return rc;
+        d_order = c->order_active ? c->last_order : nullptr;
+    }
+    hipLaunchKernelGGL(vag_shard_pack_kernel, dim3((per + 127) / 128), dim3(128), 0, c->stream, c->d_shard_ll.as<double>(),
+                       c->d_meta.as<VagGridMeta>(), d_order, n_mine, per, d_block);
+    HIPCHK(hipGetLastError());
+    return VAG_OK;
+}
+
+int vag_loglike_shard_finish_dev(vag_ctx* c, const double* d_gathered, int nb_all, int world, double* d_out) {
+    if (!c || !d_gathered || !d_out) return set_err(VAG_E_INVALID, "null context or buffer");
+    if (nb_all != c->shard_cur_nb || world != c->shard_cur_world || nb_all <= 0)
+        return set_err(VAG_E_INVALID, "no vag_loglike_shard_dev call of %d walkers over %d ranks is waiting for its finish", nb_all, world);
+    HIPCHK(hipSetDevice(c->device));
+    const int per = (nb_all + world - 1) / world;
+    hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, c->d_shard_table.as<int>(), world * per,
+                       d_out, c->d_shard_cost.as<double>());
+    HIPCHK(hipGetLastError());
+    c->shard_nb = nb_all;
+    c->shard_world = world;
+    c->shard_cur_nb = c->shard_cur_world = 0;
+    return VAG_OK;
+}
+
+int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_table, double* d_cost) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    const int per = world > 0 ? (nb_all + world - 1) / world : 0;
+    if (nb_all <= 0 || world <= 0 || c->d_shard_table.cap < sizeof(int) * (size_t)world * per)
+        return set_err(VAG_E_INVALID, "no deal of %d walkers over %d ranks on this context", nb_all, world);
+    HIPCHK(hipSetDevice(c->device));
+    if (d_table)
+        HIPCHK(hipMemcpyAsync(d_table, c->d_shard_table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
+    if (d_cost) {
+        if (c->shard_nb != nb_all || c->shard_world != world)
+            return set_err(VAG_E_INVALID, "no finished sharded call of %d walkers over %d ranks on this context", nb_all, world);
+        HIPCHK(hipMemcpyAsync(d_cost, c->d_shard_cost.p, sizeof(double) * (size_t)nb_all, hipMemcpyDeviceToDevice, c->stream));
+    }
     return VAG_OK;
 }
 

@@ -22,26 +22,46 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def balanced_assignment(costs, world):
-    """Deal n units to `world` ranks, ceil(n / world) slots each (-1 = padding): units in order of decreasing cost, ranks in
-    boustrophedon order (0..w-1, w-1..0, ...), so every rank gets the same count and the cost sums differ by at most about one
-    unit's cost per sweep.  Deterministic for identical `costs` (ties keep the original order): every rank computes the same
-    table without talking.  Returns int64[world, per]."""
-    costs = np.asarray(costs, dtype=np.float64)
-    n = costs.size
+def deal_positions(n, world):
+    """The fixed part of the deal: position q (0 = most expensive unit) of every (rank, slot), int64[world, per] with -1 for
+    padding.  Sweep s hands positions s*world .. s*world + world-1 to the ranks in boustrophedon order (0..w-1, w-1..0, ...),
+    so every rank gets the same count and the cost sums differ by at most about one unit's cost per sweep."""
     per = (n + world - 1) // world
-    table = np.full((world, per), -1, dtype=np.int64)
+    s = np.arange(per, dtype=np.int64)[None, :]
+    r = np.arange(world, dtype=np.int64)[:, None]
+    q = s * world + np.where(s % 2 == 0, r, world - 1 - r)
+    return np.where(q < n, q, -1)
+
+
+def balanced_assignment(costs, world):
+    """Deal n units to `world` ranks, ceil(n / world) slots each (-1 = padding): units in order of decreasing cost (ties keep
+    the original order) onto ``deal_positions``.  Deterministic for identical `costs`: every rank computes the same table
+    without talking.  Returns int64[world, per].  Host (numpy) statement of the deal; the sharder does the same on the device."""
+    costs = np.asarray(costs, dtype=np.float64)
     order = np.argsort(-costs, kind="stable")
-    for pos, unit in enumerate(order):
-        sweep, k = divmod(pos, world)
-        table[k if sweep % 2 == 0 else world - 1 - k, sweep] = unit
-    return table
+    q = deal_positions(costs.size, world)
+    return np.where(q >= 0, order[np.maximum(q, 0)] if costs.size else q, -1)
 
 
 def _default_device(group):
     if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
+
+
+class _Deal:
+    """What is fixed for a (batch size, world): slot positions, the flat indices of the slots that hold a walker, buffers."""
+
+    def __init__(self, nb, world, rank, device):
+        q = deal_positions(nb, world)
+        self.per = q.shape[1]
+        self.n_mine = int((q[rank] >= 0).sum())
+        flat = q.reshape(-1)
+        self.pos = torch.from_numpy(np.maximum(flat, 0)).to(device)          # [world * per] position of every slot (padding: 0)
+        self.keep = torch.from_numpy(np.nonzero(flat >= 0)[0]).to(device)    # flat slots that hold a walker
+        self.pad = torch.from_numpy(flat < 0).to(device)
+        self.block = torch.empty((self.per, 2), dtype=torch.float64, device=device)
+        self.gathered = torch.empty((world * self.per, 2), dtype=torch.float64, device=device)  # rank-major concatenation
 
 
 class WalkerSharder:
@@ -52,29 +72,53 @@ class WalkerSharder:
     walker (None: unknown, the blocks then stay balanced by count).  Every rank calls the sharder with the SAME theta
     (samplers run replicated, or rank 0 broadcasts its proposals) and gets the full [nb] vector back, on the device.
     Without an initialised process group it is a plain call.
+
+    Nothing in a call touches the host beyond launching: the walkers are ranked by the previous call's gathered costs ON THE
+    DEVICE, the slot positions of a (batch size, world) are cached tensors, and there is no ``.cpu()`` / ``.item()`` anywhere.
+    An evaluator made by ``Fitter.device_evaluator`` carries ``eval_dev.native``: the deal, the rank's block and the scatter are
+    then three launches inside the engine (``vag_loglike_shard_dev`` / ``vag_loglike_shard_finish_dev``) around the one
+    all-gather; any other evaluator gets the same deal from a handful of torch operations.
     """
 
     def __init__(self, eval_dev, group=None, device=None):
         self.eval_dev, self.group = eval_dev, group
         self.device = device if device is not None else _default_device(group)
-        self.costs = None  # float64[nb] of the previous call with the same batch size (host copy: it only orders indices)
-        self._pending = None  # the last call's gathered costs, still on the device: read when the next call needs them
-        self.last_table = None
+        self.native = getattr(eval_dev, "native", None)
+        self._deals = {}
+        self._costs = None       # float64[nb] tensor on the device: gathered costs of the previous call (generic path)
+        self._table = None       # int64[world * per] tensor: walker of every (rank, slot) in the last call, -1 = padding
+        self._shape = None       # (nb, world, per) of the last call
 
-    def _take_pending_costs(self):
-        if self._pending is None:
-            return
-        nc = self._pending.cpu().numpy()  # finished long ago: the caller has consumed that call's ln L
-        self._pending = None
-        pos = nc > 0  # walkers that were not evaluated (invalid parameters: cost 0) are assumed average next time
-        self.costs = np.where(pos, nc, nc[pos].mean() if pos.any() else 1.0)
+    @property
+    def costs(self):
+        """Gathered per-walker costs the NEXT deal ranks by (numpy, diagnostic: synchronises)."""
+        if self.native is not None:
+            return None if self._shape is None else self.native.state(self._shape[0], self._shape[1], self._shape[2])[1]
+        return None if self._costs is None else self._costs.cpu().numpy()
+
+    @property
+    def last_table(self):
+        """int64[world, per] walker of every (rank, slot) in the last call, -1 = padding (numpy, diagnostic: synchronises)."""
+        if self._shape is None:
+            return None
+        nb, world, per = self._shape
+        if self.native is not None:
+            return self.native.state(nb, world, per)[0]
+        return self._table.cpu().numpy().reshape(world, per)
 
     def costs_per_rank(self):
         """Sum of the reported walker costs on every rank in the last call (how well the deal balanced the work)."""
-        self._take_pending_costs()
-        if self.last_table is None or self.costs is None:
+        table, costs = self.last_table, self.costs
+        if table is None or costs is None:
             return None
-        return np.array([self.costs[row[row >= 0]].sum() for row in self.last_table])
+        return np.array([costs[row[row >= 0]].sum() for row in table])
+
+    def _deal(self, nb, world, rank):
+        key = (nb, world, rank)
+        d = self._deals.get(key)
+        if d is None:
+            d = self._deals[key] = _Deal(nb, world, rank, self.device)
+        return d
 
     def __call__(self, theta):
         theta = torch.as_tensor(theta, dtype=torch.float64, device=self.device)
@@ -85,30 +129,36 @@ class WalkerSharder:
             values, _ = self.eval_dev(theta)
             return values
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-        self._take_pending_costs()
-        if self.costs is None or self.costs.size != nb:
-            self.costs = np.ones(nb)
-        table = balanced_assignment(self.costs, world)
-        per = table.shape[1]
-        mine = table[rank][table[rank] >= 0]
-        # [ln L | cost] per slot; padding slots carry NaN / 0 and are never read back
-        block = torch.full((per, 2), float("nan"), dtype=torch.float64, device=self.device)
-        block[:, 1] = 0.0
-        if mine.size:
-            idx = torch.as_tensor(mine, device=self.device)
-            values, costs = self.eval_dev(theta.index_select(0, idx))
-            block[: mine.size, 0] = values
-            block[: mine.size, 1] = costs if costs is not None else 1.0
-        gathered = torch.empty((world * per, 2), dtype=torch.float64, device=self.device)  # rank-major concatenation
-        dist.all_gather_into_tensor(gathered, block, group=self.group)  # the path's only collective: 16 B per walker
-        flat_idx = torch.as_tensor(table.reshape(-1), device=self.device)
-        keep = flat_idx >= 0
+        d = self._deal(nb, world, rank)
         out = torch.empty((nb,), dtype=torch.float64, device=self.device)
-        out[flat_idx[keep]] = gathered[..., 0].reshape(-1)[keep]
-        new_costs = torch.ones((nb,), dtype=torch.float64, device=self.device)
-        new_costs[flat_idx[keep]] = gathered[..., 1].reshape(-1)[keep]
-        self._pending = new_costs
-        self.last_table = table
+        self._shape = (nb, world, d.per)
+        if self.native is not None:
+            self.native.shard(theta.contiguous(), nb, rank, world, d.block)
+            dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
+            self.native.finish(d.gathered, nb, world, out)
+            return out
+        if self._costs is None or self._costs.shape[0] != nb:
+            self._costs = torch.ones((nb,), dtype=torch.float64, device=self.device)
+        order = torch.argsort(self._costs, descending=True, stable=True)  # position -> walker
+        table = order.index_select(0, d.pos).masked_fill(d.pad, -1)       # walker of every (rank, slot)
+        mine = table[rank * d.per: rank * d.per + d.n_mine]
+        # [ln L | cost] per slot; padding slots carry NaN / 0 and are never read back
+        d.block[:, 0] = float("nan")
+        d.block[:, 1] = 0.0
+        if d.n_mine:
+            values, costs = self.eval_dev(theta.index_select(0, mine))
+            d.block[: d.n_mine, 0] = values
+            d.block[: d.n_mine, 1] = costs if costs is not None else 1.0
+        dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)
+        walkers = table.index_select(0, d.keep)
+        got = d.gathered.index_select(0, d.keep)
+        out.index_copy_(0, walkers, got[:, 0])
+        nc = torch.ones((nb,), dtype=torch.float64, device=self.device).index_copy_(0, walkers, got[:, 1])
+        pos = nc > 0  # walkers that were not evaluated (invalid parameters: cost 0) are assumed average next time
+        npos = pos.sum()
+        mean = torch.where(npos > 0, (nc * pos).sum() / npos.clamp(min=1), torch.ones((), dtype=torch.float64, device=self.device))
+        self._costs = torch.where(pos, nc, mean)
+        self._table = table
         return out
 
 

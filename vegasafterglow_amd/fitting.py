@@ -78,13 +78,16 @@ _dp = C.POINTER(C.c_double)
 
 def _device_prior(prior):
     """(VAG_PRIOR_* kind, a, b) of a prior the device evaluates itself; PRIOR_NONE hands an unknown object's ln_prob to the host.
-    Recognised by shape, not by import: bilby.core.prior.Uniform(minimum, maximum) -- taken as the ParamDef's own Uniform --,
-    Gaussian(mu, sigma), LogUniform(minimum, maximum), or tuples ("uniform",), ("gaussian", mu, sigma), ("log_uniform", lo, hi)."""
+    Recognised by shape, not by import: bilby.core.prior.Uniform(minimum, maximum) (its own support: -ln(maximum - minimum)
+    inside, -inf outside), Gaussian(mu, sigma), LogUniform(minimum, maximum), or tuples ("uniform",) = the ParamDef's own
+    Uniform(lower, upper), ("uniform", lo, hi), ("gaussian", mu, sigma), ("log_uniform", lo, hi)."""
     if prior is None:
         return _lib.PRIOR_UNIFORM, 0.0, 0.0
     if isinstance(prior, (tuple, list)):
         name = str(prior[0]).lower()
         if name == "uniform":
+            if len(prior) >= 3:
+                return _lib.PRIOR_UNIFORM_RANGE, float(prior[1]), float(prior[2])
             return _lib.PRIOR_UNIFORM, 0.0, 0.0
         if name in ("gaussian", "normal"):
             return _lib.PRIOR_GAUSSIAN, float(prior[1]), float(prior[2])
@@ -96,9 +99,36 @@ def _device_prior(prior):
         return _lib.PRIOR_GAUSSIAN, float(prior.mu), float(prior.sigma)
     if cls == "LogUniform" and hasattr(prior, "minimum") and hasattr(prior, "maximum"):
         return _lib.PRIOR_LOG_UNIFORM, float(prior.minimum), float(prior.maximum)
+    if cls == "Uniform" and hasattr(prior, "minimum") and hasattr(prior, "maximum"):
+        return _lib.PRIOR_UNIFORM_RANGE, float(prior.minimum), float(prior.maximum)
     if not hasattr(prior, "ln_prob"):
         raise ValueError(f"prior {prior!r} has no ln_prob")
     return _lib.PRIOR_NONE, 0.0, 0.0
+
+
+def host_ln_prior(samples, lower, upper, prior_specs):
+    """sum_d ln prior_d(samples[:, d]) with the bounds mask of fitting/samplers.py:72-91 on the host: -inf outside
+    [lower, upper], else the closed forms of bilby's Uniform / Gaussian / LogUniform (the same expressions
+    vag_fit_front_kernel evaluates) or the prior object's own ln_prob.  prior_specs[d] = (kind, a, b, obj)."""
+    samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
+    lp = np.zeros(samples.shape[0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for d, (kind, a, b, obj) in enumerate(prior_specs):
+            x = samples[:, d]
+            if kind == _lib.PRIOR_UNIFORM:
+                lp += -np.log(upper[d] - lower[d])
+            elif kind == _lib.PRIOR_UNIFORM_RANGE:
+                lp += np.where((x >= a) & (x <= b), -np.log(b - a), -np.inf)
+            elif kind == _lib.PRIOR_GAUSSIAN:
+                lp += -0.5 * ((x - a) / b) ** 2 - np.log(b * 2.5066282746310002)
+            elif kind == _lib.PRIOR_LOG_UNIFORM:
+                lp += np.where((x >= a) & (x <= b), -np.log(x * np.log(b / a)), -np.inf)
+            else:
+                lp += np.asarray(obj.ln_prob(x), dtype=np.float64)
+    inside = np.all((samples >= lower) & (samples <= upper), axis=1)
+    lp[~inside] = -np.inf
+    lp[~np.isfinite(lp)] = -np.inf
+    return lp
 
 
 class Fitter:
@@ -137,6 +167,7 @@ class Fitter:
         self._point_t, self._point_nu, self._point_flux, self._point_err, self._point_weights = [], [], [], [], []
         self._band_obs = []
         self._ext_kernel = None
+        self._ext_z = float(z)
         self._all_t = None
 
     @staticmethod
@@ -244,6 +275,7 @@ class Fitter:
         self._all_log_err = np.ascontiguousarray(e / f)
         self._all_weights = np.ascontiguousarray(w)
         if self.extinction is not None:  # fitter.py:439-449: rest-frame wavelengths, kernel = 0.4 ln10 k(lambda)
+            self._ext_z = self.z
             lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self.z)
             self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
 
@@ -314,6 +346,11 @@ class Fitter:
                 spec.slot[d] = _lib.PARAM_SLOTS[pd.name]
             spec.is_log[d] = 1 if pd.scale is Scale.log else 0
         spec.a_v_fixed = float(fixed.get("A_V", 0.0))
+        if self.extinction is not None and self._all_t.size and float(fixed.get("z", self.z)) != self._ext_z:
+            # a fixed 'z' ParamDef overrides Fitter.z in the model: the rest-frame wavelengths of the law must follow it
+            self._ext_z = float(fixed["z"])
+            lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self._ext_z)
+            self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
         spec.ext_kernel = self._ext_kernel.ctypes.data_as(_dp) if self._ext_kernel is not None else None
         self._band_structs = (_lib.BandObs * max(len(self._band_obs), 1))()
         for g, bd in enumerate(self._band_obs):
@@ -332,13 +369,14 @@ class Fitter:
         # sampler-space bounds: log10 of the ParamDef bounds for LOG-scale parameters (fitting/params.py:196-201)
         lower = np.array([np.log10(pd.lower) if pd.scale is Scale.log else pd.lower for pd in free], dtype=np.float64)
         upper = np.array([np.log10(pd.upper) if pd.scale is Scale.log else pd.upper for pd in free], dtype=np.float64)
-        self._host_priors = []
+        self._host_priors, self._prior_specs = [], []
         spec.use_priors = 1 if use_priors else 0
         for d, pd in enumerate(free):
             spec.lower[d], spec.upper[d] = lower[d], upper[d]
             kind, a, b = _device_prior((priors or {}).get(pd.name))
             if kind == _lib.PRIOR_NONE:
                 self._host_priors.append((d, priors[pd.name]))
+            self._prior_specs.append((kind, a, b, (priors or {}).get(pd.name)))
             spec.prior_kind[d], spec.prior_a[d], spec.prior_b[d] = kind, a, b
         return spec, lower, upper
 
@@ -427,8 +465,10 @@ class Fitter:
         here (the device path must be self-contained)."""
         import torch
         spec, _, _ = self.build_spec(param_defs, priors=priors, use_priors=use_priors)
+        param_defs_free = [pd.name for pd in param_defs if pd.scale is not Scale.fixed]
         if self._host_priors:
-            raise ValueError("device_evaluator: priors must be Uniform / Gaussian / LogUniform (evaluated on the device)")
+            raise ValueError("device_evaluator: only Uniform / Gaussian / LogUniform priors (or their tuple forms) run on the device; "
+                             f"got host-only priors for {[param_defs_free[d] for d, _ in self._host_priors]}")
         lib = _lib.load()
         if context is None:
             h, lock = get_context(self.device)
@@ -437,17 +477,53 @@ class Fitter:
         dev = torch.device("cuda", self.device)
         keep = [spec]  # the spec's arrays are owned by this Fitter; the struct itself by this closure
 
+        def _on_current_stream(fn):
+            # the context follows torch's current stream for the duration of the call and then goes back to the stream it was on:
+            # a stream the caller destroys later must not stay bound to the (shared) context
+            with lock:
+                prev = C.c_void_p()
+                _lib.check(lib.vag_ctx_get_stream(h, C.byref(prev)))
+                _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+                try:
+                    return fn()
+                finally:
+                    lib.vag_ctx_set_stream(h, prev)
+
         def eval_dev(theta):
             theta = theta.contiguous()
             k = theta.shape[0]
             values = torch.empty((k,), dtype=torch.float64, device=dev)
             costs = torch.empty((k,), dtype=torch.float64, device=dev)
-            with lock:
-                _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+
+            def run():
                 _lib.check(lib.vag_loglike_batch_dev(h, C.byref(keep[0]), theta.data_ptr(), k, keep[0].ndim, values.data_ptr()))
                 _lib.check(lib.vag_last_model_costs_dev(h, k, costs.data_ptr()))
+            _on_current_stream(run)
             return values, costs
 
+        class _Native:
+            """The engine's own sharded call for dist.WalkerSharder: deal + this rank's block, then the scatter after the
+            all-gather (vag_loglike_shard_dev / vag_loglike_shard_finish_dev); no host work besides the launches."""
+            parts = (lib, h, lock, keep)
+            check = staticmethod(_lib.check)
+
+            @staticmethod
+            def shard(theta_all, nb, rank, world, block):
+                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_dev(
+                    h, C.byref(keep[0]), theta_all.data_ptr(), nb, keep[0].ndim, rank, world, block.data_ptr())))
+
+            @staticmethod
+            def finish(gathered, nb, world, out):
+                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr())))
+
+            @staticmethod
+            def state(nb, world, per):
+                tab = torch.empty((world * per,), dtype=torch.int32, device=dev)
+                cost = torch.empty((nb,), dtype=torch.float64, device=dev)
+                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, tab.data_ptr(), cost.data_ptr())))
+                return tab.cpu().numpy().astype(np.int64).reshape(world, per), cost.cpu().numpy()
+
+        eval_dev.native = _Native
         return eval_dev
 
     def _device_loglike(self, spec, samples):
@@ -487,22 +563,23 @@ class Fitter:
     def make_log_prob_batch(self, param_defs, loglike_fn=None, priors=None):
         """log_prob_batch(samples) of fitting/samplers.py:72-91: out-of-bounds -> -inf; otherwise ln L + sum ln prior, evaluated
         by the device in one call (Fitter.log_prob_batch).  ``loglike_fn`` substitutes an evaluator of ln L alone (e.g. one that
-        shards walkers over ranks); mask and uniform priors are then applied here on the host."""
+        shards walkers over ranks); the bounds mask and EVERY prior of ``priors`` are then applied here on the host
+        (host_ln_prior: the same closed forms as the device, or the prior object's ln_prob)."""
         if loglike_fn is None:
             return lambda samples: self.log_prob_batch(samples, param_defs, priors=priors)
-        _, lower, upper = self.build_spec(param_defs)
-        ln_prior = -np.sum(np.log(upper - lower))
+        _, lower, upper = self.build_spec(param_defs, priors=priors, use_priors=True)
+        prior_specs = list(self._prior_specs)
         fn = loglike_fn
 
         def log_prob_batch(samples):
             samples = np.atleast_2d(np.asarray(samples, dtype=np.float64))
-            in_bounds = np.all((samples >= lower) & (samples <= upper), axis=1)
+            ln_prior = host_ln_prior(samples, lower, upper, prior_specs)  # -inf outside the bounds or a prior's support
             log_probs = np.full(samples.shape[0], -np.inf)
-            idx = np.where(in_bounds)[0]
+            idx = np.where(ln_prior > -np.inf)[0]
             if idx.size:
                 ll = np.asarray(fn(samples[idx]), dtype=np.float64)
                 ll[~np.isfinite(ll)] = -np.inf
-                log_probs[idx] = ll + ln_prior
+                log_probs[idx] = ll + ln_prior[idx]
             return log_probs
 
         return log_prob_batch
