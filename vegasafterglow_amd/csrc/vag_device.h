@@ -871,9 +871,9 @@ VAG_DEV double sp_fast(double z, Tab tab) {
     return fma(0.5, z + a, p);  // max(z, 0) = (z + |z|) / 2, exact
 }
 
-// 2^x: round-to-nearest split + degree-12 Taylor in f on [-0.5, 0.5] (coefficients ln2^k/k!, max rel err
-// 3.3e-16) + ldexp.  Large |x| saturate through v_ldexp_f64 (0 / inf) exactly like exp2.  Horner: 12 dependent FMAs,
-// each `v_fma_f64 p, p, f, s[coef]` -- the Estrin form needed 15 + 5 accumulator copies.
+// 2^x: round-to-nearest split + degree-11 minimax polynomial in f on [-0.5, 0.5] (max rel err 2.1e-16) + ldexp.  Large |x|
+// saturate through v_ldexp_f64 (0 / inf) exactly like exp2.  Horner: 11 dependent FMAs, each `v_fma_f64 p, p, f, s[coef]` -- the
+// Estrin form (of the earlier degree-12 Taylor polynomial, kept behind VAG_EXP2_ESTRIN) needed 15 + 5 accumulator copies.
 #ifdef VAG_HOST_DEBUG
 VAG_DEV double fma3(double a, double b, double c) { return fma(a, b, c); }
 #else
@@ -881,7 +881,13 @@ VAG_DEV double fma3(double a, double b, double c) { return fma(a, b, c); }
 // v_fmac_f64 plus a register copy of the constant per Horner step.
 VAG_DEV double fma3(double a, double b, double c) {
     double r;
+#ifdef VAG_FMA3_VGPR_CONST
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+#else
+    // the constant as the instruction's one scalar operand: with a "v" constraint the compiler parks every coefficient in a VGPR
+    // pair for the whole kernel (22 VGPRs of the flux kernel's 128 for exp2_fast alone)
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+#endif
     return r;
 }
 #endif
@@ -900,16 +906,17 @@ VAG_DEV double exp2_fast(double x) {  // finite x only: +-inf would give inf - i
     const double q8c = fma(2.5678435993488206e-11, f4, q8b);
     const double p = fma(q8c, f8, q07);
 #else
-    double p = fma(2.5678435993488206e-11, f, 4.4455382718708116e-10);
-    p = fma3(p, f, 7.054911620801123e-09);
-    p = fma3(p, f, 1.01780860092397e-07);
-    p = fma3(p, f, 1.321548679014431e-06);
-    p = fma3(p, f, 1.5252733804059841e-05);
-    p = fma3(p, f, 0.0001540353039338161);
-    p = fma3(p, f, 0.0013333558146428443);
-    p = fma3(p, f, 0.009618129107628477);
-    p = fma3(p, f, 0.05550410866482158);
-    p = fma3(p, f, 0.24022650695910072);
+    // minimax q of degree 10 for (2^f - 1) / f on [-1/2, 1/2] (profiles/micro/exp2_minimax.py: Remez in 60-digit arithmetic;
+    // the rounded Horner form is within 2.1e-16 of 2^f, the degree-12 Taylor form it replaces was at 3.3e-16 with one step more)
+    double p = fma(4.4566755710138823e-10, f, 7.072586181346367e-09);
+    p = fma3(p, f, 1.0178051727399186e-07);
+    p = fma3(p, f, 1.321544258661287e-06);
+    p = fma3(p, f, 1.5252733853282354e-05);
+    p = fma3(p, f, 0.00015403530441738514);
+    p = fma3(p, f, 0.0013333558146396002);
+    p = fma3(p, f, 0.009618129107606887);
+    p = fma3(p, f, 0.05550410866482166);
+    p = fma3(p, f, 0.24022650695910097);
     p = fma3(p, f, 0.6931471805599453);
     p = fma(p, f, 1.0);
 #endif
@@ -953,10 +960,12 @@ VAG_DEV double log2_fast(double x) {
 // ln(1 + r) (truncation 2e-18).  17 instructions instead of the 40 of log2_fast; the table (1 KB) sits behind the
 // softplus table in LDS.  Zero, subnormal, negative, inf, NaN go to the library log2.
 constexpr int SP_LDS_DOUBLES = SP_TABLE_DOUBLES + LOG_TAB_DOUBLES;  // what a flux workgroup keeps in LDS
-VAG_DEV double log2_tab(double x, LdsTab tab) {
+// the table form without its fall-back branch (straight-line callers interleave several of these): `special` is set for an argument
+// the table does not serve (zero, subnormal, negative, inf, NaN) -- the caller then takes the library log2 for that value
+VAG_DEV double log2_tab_core(double x, LdsTab tab, bool& special) {
     const int hi = __double2hiint(x), lo = __double2loint(x);
     const int eb = hi >> 20;
-    if ((unsigned)(eb - 1) >= 2046u) return log2(x);
+    special = (unsigned)(eb - 1) >= 2046u;
     const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);  // mantissa in [1, 2)
     const vdouble2 t = tab[(hi >> 14) & (LOG_TAB_N - 1)];
     const double r = fma(m, t.x, -1.0);
@@ -967,6 +976,12 @@ VAG_DEV double log2_tab(double x, LdsTab tab) {
     q = fma(q, r, -0.5);
     const double ln_m = fma(q * r, r, r);
     return fma(ln_m, LOG2E, (double)(eb - 1023) + t.y);
+}
+VAG_DEV double log2_tab(double x, LdsTab tab) {
+    const int eb = __double2hiint(x) >> 20;
+    if ((unsigned)(eb - 1) >= 2046u) return log2(x);
+    bool special;
+    return log2_tab_core(x, tab, special);
 }
 
 #ifndef VAG_HOST_DEBUG
@@ -1010,6 +1025,51 @@ VAG_DEV double log2_I_nu_fast(const PtrT& c, int st, const SpecConst& sc, double
     const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
+}
+
+// The same evaluator for the TWO frequencies of a boundary work item as one straight-line block: no lane-divergent branches (the
+// +-20 softplus shortcuts, the far-thick cut and the nu_M cut-off become selects on the same values), so the two evaluations and
+// the independent softplus / exp2 chains inside each interleave.  Same arithmetic per taken path, hence the same bits as
+// log2_I_nu_fast.
+template <class Tab>
+VAG_DEV double sp_fast_sel(double z, Tab tab) {
+    const double a = fabs(z);
+    const double t = fma(a, (double)SP_PER_UNIT, SP_MAGIC);
+    const int idx = (int)min((unsigned)__double2loint(t), (unsigned)(SP_INTERVALS - 1));
+    const double tau = fma(a, (double)SP_PER_UNIT, -(t - SP_MAGIC));
+    const auto c2 = sp_row(tab, idx);
+    const vdouble2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
+    double p = fma(c45.y, tau, c45.x);
+    p = fma(p, tau, c23.y);
+    p = fma(p, tau, c23.x);
+    p = fma(p, tau, c01.y);
+    p = fma(p, tau, c01.x);
+    const double r = fma(0.5, z + a, p);
+    return a > 20.0 ? (z > 0 ? z : 0.0) : r;
+}
+template <class PtrT, class Tab>
+VAG_DEV void log2_I_nu_fast2(const PtrT& c, const SpecConst& sc, double xa, double xb, Tab sp, double& ba, double& bb) {
+    const double l_lo = c[VP_LG2_LO], l_hi = c[VP_LG2_HI];
+    double out[2];
+    const double xs[2] = {xa, xb};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const double lg2_nu = xs[e];
+        const double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast_sel(c[VP_DLO] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO] -
+                            sp_fast_sel(c[VP_DHI] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI];
+        const double lx = lg2_nu - c[VP_LG2_NUM];
+        const bool far = lx > sc.log2_x_far;
+        const double s = -sc.smooth_thick * exp2_fast(2. / 3 * (far ? 0.0 : lx));
+        const double th = 2.5 * lx;
+        const double thick = far ? th : th + sp_fast_sel(-0.5 * lx + s, sp);
+        const double lb = thick + c[VP_TNORM];
+        const double smooth_one = thin - sp_fast_sel(c[VP_SAB] * (thin - lb), sp) * c[VP_INV_SAB];
+        const double spec = c[VP_LG2_I] + (c[VP_INV_SLO] + smooth_one);
+        const bool below = lg2_nu - c[VP_LG2_NUMAX] < -20;
+        const double cut = spec - c[VP_INV_NUMAX] * exp2_fast(below ? 0.0 : lg2_nu);
+        out[e] = below ? spec : cut;
+    }
+    ba = out[0], bb = out[1];
 }
 
 }  // namespace vag

@@ -520,12 +520,37 @@ VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, dou
 constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
 constexpr int FLUX_IC_STRIDE = 198;  // == IC_STRIDE
 
+// Observation window of a row from the partial counts its EAT step leaves in LDS (WinCount below): the row is sorted, so
+// positions are counts (observed_window, observer.h:324-338):
+//   n_lt = #{k : t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)                (last k with t[k+1] < w_lo)
+//   n_le = #{k : t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)    (first node > w_hi)
+// A wavefront that evaluates the EAT logs of some nodes counts them with two ballots and its lane 0 stores the pair in its slot of
+// `win` ([waves][2] ints; every wavefront of the workgroup writes its slot, zeros when it had no node).
+struct WinCount {
+    int n_lt = 0, n_le = 0;
+    VAG_DEV void add(bool valid, double t, double w_lo, double w_hi) {
+#ifndef VAG_HOST_DEBUG
+        n_lt += __popcll(__ballot(valid && t < w_lo));
+        n_le += __popcll(__ballot(valid && t <= w_hi));
+#endif
+    }
+    VAG_DEV void store(int* win, int tid) const {
+        if ((tid & 63) == 0) {
+            win[2 * (tid >> 6)] = n_lt;
+            win[2 * (tid >> 6) + 1] = n_le;
+        }
+    }
+};
+
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
 // (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.  s_par holds the staged row as
-// [k][VAG_NPAR] blocks (144 B apart: conflict-free 16-byte LDS reads, one address per cell).
+// [k][VAG_NPAR] blocks (144 B apart: conflict-free 16-byte LDS reads, one address per cell).  win != null: also the row's
+// observation-window counts against [w_lo, w_hi] (WinCount).
 VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads, double cos_v,
                      double t_coeff, double one_plus_z, double lg2_dOmega, double* __restrict__ s_t,
-                     double* __restrict__ s_dop, double* __restrict__ s_geom, LdsTab lg) {
+                     double* __restrict__ s_dop, double* __restrict__ s_geom, LdsTab lg, int* win = nullptr, double w_lo = 0,
+                     double w_hi = 0) {
+    WinCount wc;
     for (int k = tid; k < K; k += nthreads) {
         const double* c = s_par + k * VAG_NPAR;
         const LdsTab c2 = lds_tab(c);
@@ -535,12 +560,15 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
         s_dop[k] = G, s_t[k] = 3.0 + 0.1 * k + u, s_geom[k] = r;
         continue;
 #endif
-        const double lg2_dop = -log2_tab(G - u * cos_v, lg);
-        const double time = rt.y * one_plus_z + t_coeff * r;
+        const double lg2_dop = -log2_tab(fma(-u, cos_v, G), lg);  // explicit roundings: the flux kernels form these in two places
+        const double time = fma(t_coeff, r, rt.y * one_plus_z);
+        const double lt = log2_tab(time, lg);
         s_dop[k] = lg2_dop;
-        s_t[k] = log2_tab(time, lg);
+        s_t[k] = lt;
         s_geom[k] = (lg2_dOmega + c[VP_LG2_R2]) + 3.0 * lg2_dop;
+        if (win) wc.add(true, lt, w_lo, w_hi);
     }
+    if (win) wc.store(win, tid);
 }
 
 // Same for a spreading jet (calc_t_obs + calc_solid_angle, observer.cpp:51-141): theta evolves along k, so the viewing
@@ -548,7 +576,9 @@ VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, i
 VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads,
                             const double* __restrict__ geo, double cos_phi, double sin_obs, double cos_obs, double lg2_dphi,
                             double one_plus_z, double* __restrict__ s_t, double* __restrict__ s_dop,
-                            double* __restrict__ s_geom, LdsTab lg, int GS /* stride of geo's three rows: the row's whole lattice */) {
+                            double* __restrict__ s_geom, LdsTab lg, int GS /* stride of geo's three rows: the row's whole lattice */,
+                            int* win = nullptr, double w_lo = 0, double w_hi = 0) {
+    WinCount wc;
     for (int k = tid; k < K; k += nthreads) {
         const double* c = s_par + k * VAG_NPAR;
         const LdsTab c2 = lds_tab(c);
@@ -557,10 +587,13 @@ VAG_DEV void eat_row_spread(const double* __restrict__ s_par, int KS, int K, int
         const double cos_v = geo[GS + k] * cos_phi * sin_obs + geo[k] * cos_obs;
         const double lg2_dop = -log2_tab(G - u * cos_v, lg);
         const double time = (rt.y + (1 - cos_v) * r / C_C) * one_plus_z;
+        const double lt = log2_tab(time, lg);
         s_dop[k] = lg2_dop;
-        s_t[k] = log2_tab(time, lg);
+        s_t[k] = lt;
         s_geom[k] = ((geo[2 * GS + k] + lg2_dphi) + c[VP_LG2_R2]) + 3.0 * lg2_dop;
+        if (win) wc.add(true, lt, w_lo, w_hi);
     }
+    if (win) wc.store(win, tid);
 }
 
 // Model.jet_E_iso / jet_Gamma0 / medium (pybind/pymodel.cpp:572-594): the engine's own profile functions on n abscissae.
@@ -662,10 +695,13 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_B2 = s_hdr + (MODE == FLUX_FUSED ? 6 * KS : 0);         // FLUX_FUSED: [nnu][KS] SSC boundary values
     double* s_acc2 = s_B2 + (MODE == FLUX_FUSED ? (size_t)KS * nnu : 0);  // FLUX_FUSED: [nnu*nt] SSC partial grid
     int* s_kidx = (int*)(s_acc2 + (MODE == FLUX_FUSED ? slots : 0));  // [nt]
+    constexpr int NW = THREADS / 64;
+    int* s_win = s_kidx + nt;                // [2][NW][2] observation-window counts of the row in either s_t buffer (WinCount)
     int breach = 0;
 
     const vag_model_params* Pp = a.params + m;
     const double one_plus_z = 1 + Pp->z;
+    const double opz_over_c = one_plus_z / C_C;  // (1 - cos) / c * (1 + z) of calc_eat_non_spreading with the division done once
     {
         const double lg2_1pz = Mp->lg2_1pz;
         for (int i = tid; i < nt; i += THREADS) s_tobs[i] = a.lg2_t_obs[i];
@@ -677,34 +713,59 @@ vag_flux_grid_kernel(FluxArgs a) {
     const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
-    // slot = l * nt + idx walks in steps of THREADS: (l, idx) advance by a fixed (dl, didx) with one carry -- no divisions
-    // or integer multiplies inside the per-row loops
-    const int slot_dl = THREADS / nt, slot_didx = THREADS - slot_dl * nt;
-    const int slot_l0 = tid / nt, slot_idx0 = tid - slot_l0 * nt;
+    // A lane owns the slots tid + r * THREADS (slot = l * nt + idx): always the same lane per slot, so the LDS accumulator needs no
+    // atomics and the sum order is fixed.  The interpolation phase takes them U at a time; the first U -- all of them for
+    // nt * nnu <= U * THREADS -- keep their (idx | l * KS << 16) in a register for the whole kernel (sign bit: no such slot, the fields then read slot 0's), later ones
+    // are worked out again per row.  l * KS < 32768: the boundary block [nnu][KS] has to fit LDS.
+    constexpr int U = MODE == FLUX_FUSED ? 2 : 4;
+    const float inv_nt = __builtin_amdgcn_rcpf((float)nt);
+    auto slot_desc = [&](int slot) -> int {
+        const int l = (int)(((float)slot + 0.5f) * inv_nt);  // slot / nt (exact: slot < 2^20)
+        return slot < slots ? ((slot - __mul24(l, nt)) | (__mul24(l, KS) << 16)) : (int)0x80000000;
+    };
+    int desc0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) desc0[u] = slot_desc(tid + u * THREADS);
 
     for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
-    for (int i = tid; i < nt; i += THREADS) s_kidx[i] = -1;  // no bracket hint yet
+    for (int i = tid; i < nt; i += THREADS) s_kidx[i] = 0;  // no bracket hint yet
     if constexpr (MODE == FLUX_FUSED)
         for (int s = tid; s < slots; s += THREADS) s_acc2[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
+#ifdef VAG_FLUX_STAMPS  // developer aid: cycles every wavefront of one workgroup spends per phase (profiles/flux_stamps.py)
+    long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_mark = __builtin_readcyclecounter();
+#define VAG_FLUX_MARK(i) do { const long long now_ = __builtin_readcyclecounter(); c_ph[i] += now_ - c_mark; c_mark = now_; } while (0)
+#else
+#define VAG_FLUX_MARK(i) do { } while (0)
+#endif
 
     // Software pipeline over the (theta, phi) rows of this workgroup, two barriers per row:
     //   interval 1:  bracket lookup + interval reciprocals + A1 (boundary spectra) of row p
     //   interval 2:  B (interpolate/accumulate) of row p  ||  A0 (EAT logs) of row p+1 into the other s_t buffer
     // A0 is latency bound (two log2 per node on < half of the lanes) and hides behind B's exp2 work.
+    // Measured and rejected (-DVAG_FLUX_ROTATE): the EAT logs of the next row on the OTHER half of the workgroup than the bracket
+    // lookup (which runs on the lanes tid < nt), so that the two latency-bound side jobs of a row land on different wavefronts:
+    // 23.97 vs 23.22 ms per 512 C2 models -- the waves that take the logs are then the last at the second barrier of every row.
+#ifdef VAG_FLUX_ROTATE
+    const int etid = (tid + THREADS / 2) & (THREADS - 1);
+#else
+    const int etid = tid;
+#endif
+    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
     auto stage_and_eat = [&](int pair, int buf) {
         const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
-        const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-        const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+        const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K_all) * 3 + k0;
-            eat_row_spread(s_par, KS, K, tid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
-                           s_t + buf * KS, s_dop, s_geom, lg_tab, K_all);
+            eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
+                           s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2 * NW, w_lo, w_hi);
         } else {
             const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
-            const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
+            const double t_coeff = (1 - cos_v) * opz_over_c;
             const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
-            eat_row(s_par, KS, K, tid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom, lg_tab);
+            eat_row(s_par, KS, K, etid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom, lg_tab,
+                    s_win + buf * 2 * NW, w_lo, w_hi);
         }
     };
     int staged_rep = -1;
@@ -746,13 +807,14 @@ vag_flux_grid_kernel(FluxArgs a) {
     K = min(KS, K_all - k0);
     if (piece > 0) {
         staged_rep = -1;
-        for (int i = tid; i < nt; i += THREADS) s_kidx[i] = -1;
+        for (int i = tid; i < nt; i += THREADS) s_kidx[i] = 0;
     }
     __syncthreads();
     stage_row(p0);
     __syncthreads();
     stage_and_eat(p0, 0);
     __syncthreads();
+    VAG_FLUX_MARK(7);
     for (int pair = p0; pair < p1; ++pair) {
         const int buf = (pair - p0) & 1;
         const double* s_tc = s_t + buf * KS;  // log2 observer times of the current row
@@ -761,43 +823,51 @@ vag_flux_grid_kernel(FluxArgs a) {
         const double row_t0 = s_tc[0], row_tN = s_tc[K - 1];
         for (int idx = tid; idx < nt; idx += THREADS) {
             const double tq = s_tobs[idx];
-            int kk = -1;
-            double w = 0;
+            // a requested time outside the row's lattice contributes nothing (observer.h:405-433): it keeps interval 0 and a NaN
+            // position, which makes the interpolated exponent non-finite like a non-finite slope does
+            int kk = 0;
+            double w = NAN;
 #if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 4)
             if (tq >= row_t0 && tq < row_tN) kk = min(idx, K - 2), w = 0.5;
             if (false) {
 #else
             if (tq >= row_t0 && tq < row_tN) {
 #endif
-                // invariant: s_tc[lo] <= tq < s_tc[hi].  Neighbouring rows shift the lattice only slightly, so the bracket is
-                // grown outwards from the previous row's interval (still in s_kidx) before it is bisected: two dependent
-                // LDS reads in the common case instead of log2(K).
+                // invariant: s_tc[lo] <= tq < s_tc[hi].  Neighbouring rows shift the lattice only slightly: the previous row's
+                // interval (still in s_kidx) and its two neighbours are requested together -- four reads in flight, one round
+                // trip in the common case -- and only a larger shift grows the bracket outwards and bisects it.
                 int lo = s_kidx[idx], hi;
-                lo = lo < 0 ? 0 : lo;  // first row of the workgroup, or a time the previous row did not cover
-                if (s_tc[lo] <= tq) {
-                    int step = 1;
-                    hi = lo + 1;
-                    while (hi < K - 1 && s_tc[hi] <= tq) {
-                        lo = hi;
-                        step <<= 1;
-                        hi = min(lo + step, K - 1);
-                    }
+                lo = min(max(lo, 1), K - 3);  // first row of the workgroup / a time the previous row did not cover: node 1
+                const double ta = s_tc[lo - 1], tb = s_tc[lo], tc = s_tc[lo + 1], td = s_tc[lo + 2];
+                if (K >= 4 && ta <= tq && tq < td) {
+                    lo = tq < tb ? lo - 1 : (tq < tc ? lo : lo + 1);
                 } else {
-                    int step = 1;
-                    hi = lo;
-                    lo = hi - 1;
-                    while (s_tc[lo] > tq) {  // ends at the latest at node 0: s_tc[0] = row_t0 <= tq
+                    lo = K >= 4 ? lo : 0;
+                    if (s_tc[lo] <= tq) {
+                        int step = 1;
+                        hi = lo + 1;
+                        while (hi < K - 1 && s_tc[hi] <= tq) {
+                            lo = hi;
+                            step <<= 1;
+                            hi = min(lo + step, K - 1);
+                        }
+                    } else {
+                        int step = 1;
                         hi = lo;
-                        step <<= 1;
-                        lo = max(hi - step, 0);
+                        lo = hi - 1;
+                        while (s_tc[lo] > tq) {  // ends at the latest at node 0: s_tc[0] = row_t0 <= tq
+                            hi = lo;
+                            step <<= 1;
+                            lo = max(hi - step, 0);
+                        }
                     }
-                }
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_tc[mid] <= tq)
-                        lo = mid;
-                    else
-                        hi = mid;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_tc[mid] <= tq)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
                 }
                 kk = lo;
                 const double t_lo = s_tc[lo];
@@ -806,24 +876,24 @@ vag_flux_grid_kernel(FluxArgs a) {
             s_kidx[idx] = kk;
             s_w[idx] = w;
         }
+        VAG_FLUX_MARK(0);
         const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         const bool in_window = !(row_tN < w_lo || row_t0 > w_hi);  // block-uniform
         if (in_window) {
-            // sorted row => positions by counting, one ballot per 64 nodes (no dependent LDS chain):
-            //   n_lt = #{k : t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)   (observed_window: last k with t[k+1] < w_lo)
-            //   n_le = #{k : t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)  (first node > w_hi)
+            // the window's node counts were left by the row's EAT step, one pair per wavefront (WinCount)
             const int lane = tid & 63;
             int n_lt = 0, n_le = 0;
 #if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 16)
             n_lt = 1, n_le = K;
-            if (false)
-#endif
-            for (int base = 0; base < K; base += 64) {
-                const int kk = base + lane;
-                const double v = kk < K ? s_tc[kk] : INFINITY;
-                n_lt += __popcll(__ballot(v < w_lo));
-                n_le += __popcll(__ballot(v <= w_hi));
+#else
+            {
+                const int* wn = s_win + buf * 2 * NW;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) n_lt += wn[2 * w], n_le += wn[2 * w + 1];
+                n_lt = __builtin_amdgcn_readfirstlane(n_lt);
+                n_le = __builtin_amdgcn_readfirstlane(n_le);
             }
+#endif
             const int k_lo = n_lt > 0 ? n_lt - 1 : 0;
             const int k_hi = min(max(n_le, k_lo + 1), K - 1);
             // ---- A1: boundary values B[l][k] = log2 I'(nu_l (1+z) / D_k) + geom_k for k in the window.
@@ -832,7 +902,7 @@ vag_flux_grid_kernel(FluxArgs a) {
             const int nk = k_hi - k_lo + 1;
             const int npair_nu = (nnu + 1) >> 1;
             const int total = nk * npair_nu;
-            const float inv_nk = 1.0f / (float)nk;
+            const float inv_nk = __builtin_amdgcn_rcpf((float)nk);  // tid / nk below is exact with it: (tid + 0.5) / nk is >= 1e-3 away from an integer
             if constexpr (COUNT) {  // instrumentation pass: exact unit counts for the roofline
                 int n_lt0 = 0, n_ltN = 0;
                 for (int base = 0; base < nt; base += 64) {
@@ -862,8 +932,12 @@ vag_flux_grid_kernel(FluxArgs a) {
 #endif
                 if constexpr (MODE == FLUX_SYN) {
                     const SpecRegs regs = load_spec_regs(lds_tab(s_par) + __mul24(k, VAG_NPAR / 2));
+#ifdef VAG_FLUX_DUAL_EVAL
+                    log2_I_nu_fast2(regs, sc, s_nu[l0] - dop, s_nu[l1] - dop, sp_tab, b0, b1);
+#else
                     b0 = log2_I_nu_fast(regs, 1, sc, s_nu[l0] - dop, sp_tab);
                     b1 = log2_I_nu_fast(regs, 1, sc, s_nu[l1] - dop, sp_tab);
+#endif
                 } else if constexpr (HAS_Q) {
                     const double* cq = a.cellq + (a.cell_off[m] + (long long)staged_rep * K_all) * FLUX_NQ + k0 + k;
                     log2_I_nu_ic_pair(cp, 1, cq, K_all, sc, s_nu[l0] - dop, s_nu[l1] - dop, sp_tab, b0, b1);
@@ -894,49 +968,174 @@ vag_flux_grid_kernel(FluxArgs a) {
                 }
             }
         }
+        VAG_FLUX_MARK(1);
         __syncthreads();
-        // ---- A0 of the next row (other s_t buffer; s_dop / s_geom are free once A1 is done).  A row that needs a
-        //      different photon block is staged after B instead (block-uniform rare path).
+        VAG_FLUX_MARK(2);
+        // ---- interval 2: B of this row and A0 of the next one (other s_t buffer; s_dop / s_geom are free once A1 is done).  A
+        //      row that needs a different photon block is staged after B instead (block-uniform rare path).
+        //      B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433), U slots of the lane at a time as
+        //      straight-line code: the U chains (bracket index -> boundary pair -> exp2 -> accumulator) are independent, and a
+        //      wavefront that holds lattice nodes of the next row carries that node's two EAT logarithms as a further chain in the
+        //      same block, so the LDS round trips and the Horner chains interleave instead of queueing (alone, one slot's chain
+        //      takes ~650 cycles for 27 instructions and a node's logs ~1500; profiles/r03_flux_phase_budget.txt).  A slot
+        //      without a finite slope adds exp2(-2000) = 0: the sums keep their order and their bits.
         const bool have_next = pair + 1 < p1;
         const bool same_rep = have_next && rep_of[(pair + 1) / n_phi_eff] == staged_rep;
-        if (same_rep) stage_and_eat(pair + 1, buf ^ 1);
-        // ---- B: interpolate in log2 t, exponentiate, accumulate (observer.h:405-433).  slot = l * nt + idx is
-        //      always visited by the same lane, so the LDS accumulator needs no atomics and the sum order is fixed.
+        // EAT logs inside the interpolation block: the first node of every lane (k = tid); further nodes of long lattices and the
+        // rows without an interpolation phase go through stage_and_eat
+#if defined(VAG_FLUX_NO_FUSE_EAT) || (defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 8))
+        const bool fuse_eat = false;
+#else
+        const bool fuse_eat = !SPREAD && same_rep && in_window;
+#endif
+        if (same_rep && !fuse_eat) stage_and_eat(pair + 1, buf ^ 1);
+        VAG_FLUX_MARK(3);
         if (in_window) {
-            int idx = slot_idx0, lKS = slot_l0 * KS;
+            auto interp_group = [&](const int (&dq)[U], int slot0, auto with_eat, auto u_begin, auto u_end) {
+                constexpr int UB = decltype(u_begin)::value, UE = decltype(u_end)::value;
+                // -- requests of the EAT chain
+                [[maybe_unused]] vdouble2 e_Gu, e_rt;
+                [[maybe_unused]] double e_r2 = 0, e_cos = 0, e_tc = 0, e_dom = 0;
+                [[maybe_unused]] const int ek = min(tid, K - 1);
+                if constexpr (decltype(with_eat)::value) {
+                    const int jn = (pair + 1) / n_phi_eff, in_ = (pair + 1) - jn * n_phi_eff;
+                    e_cos = gth[VAG_MAX_THETA + jn] * gph[in_] * sin_obs + gth[jn] * cos_obs;
+                    e_tc = (1 - e_cos) * opz_over_c;
+                    e_dom = gth[2 * VAG_MAX_THETA + jn] + gph[VAG_MAX_PHI + in_];
+                    const double* c = s_par + ek * VAG_NPAR;
+                    const LdsTab c2 = lds_tab(c);
+                    e_Gu = c2[VP_GAMMA / 2], e_rt = c2[VP_R / 2];
+                    e_r2 = c[VP_LG2_R2];
+                }
+                // -- the U slots (the descriptors are made opaque per row: the compiler would otherwise keep a dozen LDS addresses
+                //    derived from them in registers for the whole kernel, and the boundary-spectra loop has none to spare)
+                int dv[U];
+#pragma unroll
+                for (int u = UB; u < UE; ++u) {
+                    dv[u] = dq[u];
+#ifndef VAG_HOST_DEBUG
+                    asm volatile("" : "+v"(dv[u]));
+#endif
+                }
+                int kq[U], iq[U];
+                double lo[U], hi[U], wq[U], aq[U];
+                [[maybe_unused]] double lo2[U], hi2[U], aq2[U];
+#pragma unroll
+                for (int u = UB; u < UE; ++u) {
+                    iq[u] = dv[u] & 0xffff;
+                    kq[u] = s_kidx[iq[u]];
+                }
+#pragma unroll
+                for (int u = UB; u < UE; ++u) {
+                    const int kk = ((dv[u] >> 16) & 0x7fff) + kq[u];
+                    lo[u] = s_B[kk], hi[u] = s_B[kk + 1];
+                    wq[u] = s_w[iq[u]];
+                    aq[u] = s_acc[min(slot0 + u * THREADS, slots - 1)];
+                    if constexpr (MODE == FLUX_FUSED) {
+                        lo2[u] = s_B2[kk], hi2[u] = s_B2[kk + 1];
+                        aq2[u] = s_acc2[min(slot0 + u * THREADS, slots - 1)];
+                    }
+                }
+                [[maybe_unused]] bool sp_a = false, sp_b = false;
+                [[maybe_unused]] double e_dop = 0, e_lt = 0;
+                if constexpr (decltype(with_eat)::value) {
+                    e_dop = -log2_tab_core(fma(-e_Gu.y, e_cos, e_Gu.x), lg_tab, sp_a);  // eat_row's expressions, rounding for rounding
+                    e_lt = log2_tab_core(fma(e_tc, e_rt.x, e_rt.y * one_plus_z), lg_tab, sp_b);
+                }
+#pragma unroll
+                for (int u = UB; u < UE; ++u) {
+                    // the slope (hi - lo) / (t[k+1] - t[k]) is finite <=> hi - lo is (observer.h:422-426); with the position w in
+                    // [0, 1) -- or NaN for a time outside the row -- the exponent is finite exactly for the terms that count
+                    const double x = fma(hi[u] - lo[u], wq[u], lo[u]);
+                    aq[u] += exp2_fast(isfinite(x) ? x : -2000.0);
+                    if constexpr (MODE == FLUX_FUSED) {
+                        const double x2 = fma(hi2[u] - lo2[u], wq[u], lo2[u]);
+                        aq2[u] += exp2_fast(isfinite(x2) ? x2 : -2000.0);
+                    }
+                }
+#pragma unroll
+                for (int u = UB; u < UE; ++u)
+                    if (dv[u] >= 0) {
+                        s_acc[slot0 + u * THREADS] = aq[u];
+                        if constexpr (MODE == FLUX_FUSED) s_acc2[slot0 + u * THREADS] = aq2[u];
+                    }
+                if constexpr (decltype(with_eat)::value) {
+                    if (sp_a) e_dop = -log2(fma(-e_Gu.y, e_cos, e_Gu.x));  // never in practice: arguments the table does not serve
+                    if (sp_b) e_lt = log2(fma(e_tc, e_rt.x, e_rt.y * one_plus_z));
+                    WinCount wc;
+                    wc.add(tid < K, e_lt, w_lo, w_hi);
+                    wc.store(s_win + (buf ^ 1) * 2 * NW, tid);
+                    if (tid < K) {
+                        s_dop[ek] = e_dop;
+                        s_t[(buf ^ 1) * KS + ek] = e_lt;
+                        s_geom[ek] = (e_dom + e_r2) + 3.0 * e_dop;
+                    }
+                }
+            };
 #if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 2)
             if (false)
 #endif
-#pragma unroll 2
-            for (int slot = tid; slot < slots; slot += THREADS) {
-                const int k = s_kidx[idx];
-                if (k >= 0) {
-                    const double lo = s_B[lKS + k], hi = s_B[lKS + k + 1];
-                    const double d = hi - lo;  // slope finite <=> d finite (observer.h:422-426)
-                    if (isfinite(d)) s_acc[slot] += exp2_fast(fma(d, s_w[idx], lo));
-                    if constexpr (MODE == FLUX_FUSED) {
-                        const double lo2 = s_B2[lKS + k], hi2 = s_B2[lKS + k + 1];
-                        const double d2 = hi2 - lo2;
-                        if (isfinite(d2)) s_acc2[slot] += exp2_fast(fma(d2, s_w[idx], lo2));
-                    }
+            {
+                using I0 = std::integral_constant<int, 0>;
+                using IH = std::integral_constant<int, U / 2>;
+                using IU = std::integral_constant<int, U>;
+                if (fuse_eat && (tid & ~63) < K) {  // the node's chain next to half of the slots (registers), then the other half
+                    interp_group(desc0, tid, std::true_type{}, I0{}, IH{});
+                    interp_group(desc0, tid, std::false_type{}, IH{}, IU{});
+                } else {
+                    interp_group(desc0, tid, std::false_type{}, I0{}, IU{});
                 }
-                idx += slot_didx;
-                lKS += slot_dl * KS;
-                if (idx >= nt) {
-                    idx -= nt;
-                    lKS += KS;
+                for (int slot0 = tid + U * THREADS; slot0 - tid < slots; slot0 += U * THREADS) {  // block-uniform trip count
+                    int dq[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) dq[u] = slot_desc(slot0 + u * THREADS);
+                    interp_group(dq, slot0, std::false_type{}, I0{}, IU{});
+                }
+            }
+            if (fuse_eat) {
+                if ((tid & ~63) >= K) WinCount().store(s_win + (buf ^ 1) * 2 * NW, tid);  // wavefronts without a node: zero counts
+                if (THREADS < 512 && K > THREADS) {  // nodes beyond the first per lane (256-lane workgroups on long lattices); their counts join the first's
+                    const int jn = (pair + 1) / n_phi_eff, in_ = (pair + 1) - jn * n_phi_eff;
+                    const double cos_v = gth[VAG_MAX_THETA + jn] * gph[in_] * sin_obs + gth[jn] * cos_obs;
+                    const double t_coeff = (1 - cos_v) * opz_over_c;
+                    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + jn] + gph[VAG_MAX_PHI + in_];
+                    int* wn = s_win + (buf ^ 1) * 2 * NW;
+                    WinCount wc;
+                    for (int k = tid + THREADS; k < K; k += THREADS) {
+                        const double* c = s_par + k * VAG_NPAR;
+                        const LdsTab c2 = lds_tab(c);
+                        const vdouble2 Gu = c2[VP_GAMMA / 2], rt = c2[VP_R / 2];
+                        const double lg2_dop = -log2_tab(fma(-Gu.y, cos_v, Gu.x), lg_tab);
+                        const double lt = log2_tab(fma(t_coeff, rt.x, rt.y * one_plus_z), lg_tab);
+                        s_dop[k] = lg2_dop;
+                        s_t[(buf ^ 1) * KS + k] = lt;
+                        s_geom[k] = (lg2_dOmega + c[VP_LG2_R2]) + 3.0 * lg2_dop;
+                        wc.add(true, lt, w_lo, w_hi);
+                    }
+                    if ((tid & 63) == 0) {  // same lane as the first store: program order
+                        wn[2 * (tid >> 6)] += wc.n_lt;
+                        wn[2 * (tid >> 6) + 1] += wc.n_le;
+                    }
                 }
             }
         }
+        VAG_FLUX_MARK(4);
         __syncthreads();
+        VAG_FLUX_MARK(5);
         if (have_next && !same_rep) {
             stage_row(pair + 1);
             __syncthreads();
             stage_and_eat(pair + 1, buf ^ 1);
             __syncthreads();
+            VAG_FLUX_MARK(6);
         }
     }
     }  // pieces of the lattice
+#ifdef VAG_FLUX_STAMPS
+    if (blockIdx.y == 0 && blockIdx.x == 1 && (tid & 63) == 0)
+        printf("flux wave %d rows %d cycles: bracket+window %lld  A1 %lld  barrier1 %lld  A0next %lld  B %lld  barrier2 %lld  restage %lld  prologue %lld\n",
+               tid >> 6, p1 - p0, c_ph[0], c_ph[1], c_ph[2], c_ph[3], c_ph[4], c_ph[5], c_ph[6], c_ph[7]);
+#endif
     if constexpr (COUNT) {
         if (tid == 0) {
             atomicAdd(a.work_count, n_evals);
