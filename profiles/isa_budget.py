@@ -19,14 +19,18 @@ blocks, cur = [], None
 for l in lines[start + 1:end]:
     m = re.match(r"^(\.LBB\d+_\d+):", l)
     if m:
-        cur = {"label": m.group(1), "ins": []}
+        d = re.search(r"Depth=(\d+)", l)
+        cur = {"label": m.group(1), "ins": [], "depth": d.group(1) if d else "-"}
         blocks.append(cur)
         continue
     t = l.strip()
+    if cur is not None and cur["depth"] == "-" and "Depth=" in t and t.startswith(";"):
+        d = re.search(r"Depth=(\d+)", t)
+        cur["depth"] = d.group(1)
     if not t or t.startswith(";") or t.startswith("."):
         continue
     if cur is None:
-        cur = {"label": "entry", "ins": []}
+        cur = {"label": "entry", "ins": [], "depth": "0"}
         blocks.append(cur)
     cur["ins"].append(t.split(";")[0].strip())
 
@@ -57,7 +61,7 @@ def classify(op):
 
 print(name)
 keys = ["f64", "f64x", "valu", "lds", "vmem", "scratch", "salu", "wait", "barrier", "branch"]
-print(f"{'block':>12} " + " ".join(f"{k:>7}" for k in keys) + "   total  -> branch targets")
+print(f"{'block':>12} dep " + " ".join(f"{k:>7}" for k in keys) + "   total  -> branch targets")
 tot = {k: 0 for k in keys}
 for b in blocks:
     c = {k: 0 for k in keys}
@@ -72,5 +76,5 @@ for b in blocks:
             targets.append(ins.split()[-1])
     n = sum(c.values())
     if n:
-        print(f"{b['label']:>12} " + " ".join(f"{c[k]:7d}" for k in keys) + f" {n:7d}  {' '.join(targets)}")
-print(f"{'TOTAL':>12} " + " ".join(f"{tot[k]:7d}" for k in keys) + f" {sum(tot.values()):7d}")
+        print(f"{b['label']:>12} {b['depth']:>3} " + " ".join(f"{c[k]:7d}" for k in keys) + f" {n:7d}  {' '.join(targets)}")
+print(f"{'TOTAL':>12}     " + " ".join(f"{tot[k]:7d}" for k in keys) + f" {sum(tot.values()):7d}")

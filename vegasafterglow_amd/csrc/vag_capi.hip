@@ -955,7 +955,7 @@ static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
     const size_t slots = (size_t)nt * nnu;
     size_t d = (size_t)(VAG_NPAR + 4) * ks + (size_t)ks * nnu + 2 * (size_t)nt + nnu + SP_LDS_DOUBLES + slots;
     if (mode == FLUX_FUSED) d += 6 * (size_t)ks + (size_t)ks * nnu + slots;
-    return sizeof(double) * d + sizeof(int) * nt + 128;  // + s_win: [2][8][2] observation-window counts (WinCount)
+    return sizeof(double) * d + sizeof(int) * nt + 16;  // + s_win: [2][2] observation-window counts (WinCount)
 }
 
 // Stage 4-5 for a (t, nu) grid request: d_lg2t/d_lg2nu are log2 of code-unit times / frequencies.

@@ -524,8 +524,9 @@ constexpr int FLUX_IC_STRIDE = 198;  // == IC_STRIDE
 // positions are counts (observed_window, observer.h:324-338):
 //   n_lt = #{k : t[k] <  w_lo}  ->  k_lo = max(n_lt - 1, 0)                (last k with t[k+1] < w_lo)
 //   n_le = #{k : t[k] <= w_hi}  ->  k_hi = clamp(n_le, k_lo + 1, K - 1)    (first node > w_hi)
-// A wavefront that evaluates the EAT logs of some nodes counts them with two ballots and its lane 0 stores the pair in its slot of
-// `win` ([waves][2] ints; every wavefront of the workgroup writes its slot, zeros when it had no node).
+// A wavefront that evaluates the EAT logs of some nodes counts them with two ballots and its lane 0 adds the pair to the row's
+// two counters in LDS (`win`: integer LDS atomics, so the order does not matter); the counters of a buffer are cleared by the
+// flux kernel once every wavefront has read them.
 struct WinCount {
     int n_lt = 0, n_le = 0;
     VAG_DEV void add(bool valid, double t, double w_lo, double w_hi) {
@@ -535,17 +536,44 @@ struct WinCount {
 #endif
     }
     VAG_DEV void store(int* win, int tid) const {
-        if ((tid & 63) == 0) {
-            win[2 * (tid >> 6)] = n_lt;
-            win[2 * (tid >> 6) + 1] = n_le;
+#ifndef VAG_HOST_DEBUG
+        if ((tid & 63) == 0 && (n_lt | n_le) != 0) {
+            __hip_atomic_fetch_add(win, n_lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(win + 1, n_le, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#endif
     }
 };
+
+// Uniform values straight into scalar registers.  The compiler reads the per-row geometry with vector loads (it cannot prove that
+// the kernel's own global stores do not alias it): five 500-cycle round trips that every wavefront sat out at the start of each
+// row's second interval.  s_load through the scalar cache instead (the arrays were written by an earlier kernel).
+#ifndef VAG_HOST_DEBUG
+VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
+                    double& v2, double& v3, double& v4) {
+    asm volatile("s_load_dwordx2 %0, %5, 0x0\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %7, 0x0\n\ts_load_dwordx2 %3, %8, 0x0\n\t"
+                 "s_load_dwordx2 %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4)
+                 : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4)
+                 : "memory");
+}
+VAG_DEV int sload_i32(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
+    return v;
+}
+#else
+VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
+                    double& v2, double& v3, double& v4) {
+    v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
+}
+VAG_DEV int sload_i32(const int* p) { return *p; }
+#endif
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
 // (calc_eat_non_spreading + finalize_log_grids, observer.cpp:143-205,439-454) -> LDS.  s_par holds the staged row as
 // [k][VAG_NPAR] blocks (144 B apart: conflict-free 16-byte LDS reads, one address per cell).  win != null: also the row's
-// observation-window counts against [w_lo, w_hi] (WinCount).
+// observation-window counts against [w_lo, w_hi] (WinCount; the caller has cleared the two counters).
 VAG_DEV void eat_row(const double* __restrict__ s_par, int KS, int K, int tid, int nthreads, double cos_v,
                      double t_coeff, double one_plus_z, double lg2_dOmega, double* __restrict__ s_t,
                      double* __restrict__ s_dop, double* __restrict__ s_geom, LdsTab lg, int* win = nullptr, double w_lo = 0,
@@ -696,7 +724,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     double* s_acc2 = s_B2 + (MODE == FLUX_FUSED ? (size_t)KS * nnu : 0);  // FLUX_FUSED: [nnu*nt] SSC partial grid
     int* s_kidx = (int*)(s_acc2 + (MODE == FLUX_FUSED ? slots : 0));  // [nt]
     constexpr int NW = THREADS / 64;
-    int* s_win = s_kidx + nt;                // [2][NW][2] observation-window counts of the row in either s_t buffer (WinCount)
+    int* s_win = s_kidx + nt;                // [2][2] observation-window counts of the row in either s_t buffer (WinCount)
     int breach = 0;
 
     const vag_model_params* Pp = a.params + m;
@@ -729,6 +757,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 
     for (int s = tid; s < slots; s += THREADS) s_acc[s] = 0;
     for (int i = tid; i < nt; i += THREADS) s_kidx[i] = 0;  // no bracket hint yet
+    if (tid < 4) s_win[tid] = 0;
     if constexpr (MODE == FLUX_FUSED)
         for (int s = tid; s < slots; s += THREADS) s_acc2[s] = 0;
     unsigned long long n_evals = 0, n_interps = 0;  // block-uniform tallies (COUNT variant only)
@@ -753,24 +782,26 @@ vag_flux_grid_kernel(FluxArgs a) {
 #endif
     const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
     const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-    auto stage_and_eat = [&](int pair, int buf) {
-        const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
+    auto stage_and_eat = [&](int j, int i, int buf) {  // (theta, phi) indices of the row: walked with a carry, never divided out
         const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K_all) * 3 + k0;
             eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
-                           s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2 * NW, w_lo, w_hi);
+                           s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2, w_lo, w_hi);
         } else {
-            const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            double g_sin, g_cph, g_cos, g_dth, g_dph;
+            sload5(gth + VAG_MAX_THETA + j, gph + i, gth + j, gth + 2 * VAG_MAX_THETA + j, gph + VAG_MAX_PHI + i, g_sin, g_cph, g_cos, g_dth,
+                   g_dph);
+            const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
             const double t_coeff = (1 - cos_v) * opz_over_c;
-            const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+            const double lg2_dOmega = g_dth + g_dph;
             eat_row(s_par, KS, K, etid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom, lg_tab,
-                    s_win + buf * 2 * NW, w_lo, w_hi);
+                    s_win + buf * 2, w_lo, w_hi);
         }
     };
     int staged_rep = -1;
-    auto stage_row = [&](int pair) {  // block-uniform: (re)load the photon block when the representative row changes
-        const int rep = rep_of[pair / n_phi_eff];
+    auto stage_row = [&](int j) {  // block-uniform: (re)load the photon block when the representative row changes
+        const int rep = sload_i32(rep_of + j);
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K_all) * VAG_NPAR + k0;
 #pragma unroll 1
@@ -810,13 +841,15 @@ vag_flux_grid_kernel(FluxArgs a) {
         for (int i = tid; i < nt; i += THREADS) s_kidx[i] = 0;
     }
     __syncthreads();
-    stage_row(p0);
+    int jn = p0 / n_phi_eff, in_ = p0 - jn * n_phi_eff;  // (theta, phi) of the NEXT row while the loop runs
+    stage_row(jn);
     __syncthreads();
-    stage_and_eat(p0, 0);
+    stage_and_eat(jn, in_, 0);
     __syncthreads();
     VAG_FLUX_MARK(7);
     for (int pair = p0; pair < p1; ++pair) {
         const int buf = (pair - p0) & 1;
+        if (++in_ == n_phi_eff) in_ = 0, ++jn;
         const double* s_tc = s_t + buf * KS;  // log2 observer times of the current row
         // ---- bracket lookup: idx -> k with t_row[k] <= lg2 t_obs < t_row[k+1] (iterate_to, observer.h:309-313,
         //      405-433), interval reciprocals, and the observation window (observed_window, observer.h:324-338)
@@ -886,13 +919,8 @@ vag_flux_grid_kernel(FluxArgs a) {
 #if defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 16)
             n_lt = 1, n_le = K;
 #else
-            {
-                const int* wn = s_win + buf * 2 * NW;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) n_lt += wn[2 * w], n_le += wn[2 * w + 1];
-                n_lt = __builtin_amdgcn_readfirstlane(n_lt);
-                n_le = __builtin_amdgcn_readfirstlane(n_le);
-            }
+            n_lt = __builtin_amdgcn_readfirstlane(s_win[buf * 2]);
+            n_le = __builtin_amdgcn_readfirstlane(s_win[buf * 2 + 1]);
 #endif
             const int k_lo = n_lt > 0 ? n_lt - 1 : 0;
             const int k_hi = min(max(n_le, k_lo + 1), K - 1);
@@ -979,8 +1007,9 @@ vag_flux_grid_kernel(FluxArgs a) {
         //      same block, so the LDS round trips and the Horner chains interleave instead of queueing (alone, one slot's chain
         //      takes ~650 cycles for 27 instructions and a node's logs ~1500; profiles/r03_flux_phase_budget.txt).  A slot
         //      without a finite slope adds exp2(-2000) = 0: the sums keep their order and their bits.
+        if (tid == THREADS - 1) s_win[buf * 2] = 0, s_win[buf * 2 + 1] = 0;  // read by everyone before the barrier; the row after next adds again
         const bool have_next = pair + 1 < p1;
-        const bool same_rep = have_next && rep_of[(pair + 1) / n_phi_eff] == staged_rep;
+        const bool same_rep = have_next && sload_i32(rep_of + (have_next ? jn : 0)) == staged_rep;
         // EAT logs inside the interpolation block: the first node of every lane (k = tid); further nodes of long lattices and the
         // rows without an interpolation phase go through stage_and_eat
 #if defined(VAG_FLUX_NO_FUSE_EAT) || (defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 8))
@@ -988,7 +1017,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #else
         const bool fuse_eat = !SPREAD && same_rep && in_window;
 #endif
-        if (same_rep && !fuse_eat) stage_and_eat(pair + 1, buf ^ 1);
+        if (same_rep && !fuse_eat) stage_and_eat(jn, in_, buf ^ 1);
         VAG_FLUX_MARK(3);
         if (in_window) {
             auto interp_group = [&](const int (&dq)[U], int slot0, auto with_eat, auto u_begin, auto u_end) {
@@ -998,10 +1027,12 @@ vag_flux_grid_kernel(FluxArgs a) {
                 [[maybe_unused]] double e_r2 = 0, e_cos = 0, e_tc = 0, e_dom = 0;
                 [[maybe_unused]] const int ek = min(tid, K - 1);
                 if constexpr (decltype(with_eat)::value) {
-                    const int jn = (pair + 1) / n_phi_eff, in_ = (pair + 1) - jn * n_phi_eff;
-                    e_cos = gth[VAG_MAX_THETA + jn] * gph[in_] * sin_obs + gth[jn] * cos_obs;
+                    double g_sin, g_cph, g_cos, g_dth, g_dph;
+                    sload5(gth + VAG_MAX_THETA + jn, gph + in_, gth + jn, gth + 2 * VAG_MAX_THETA + jn, gph + VAG_MAX_PHI + in_, g_sin, g_cph,
+                           g_cos, g_dth, g_dph);
+                    e_cos = g_sin * g_cph * sin_obs + g_cos * cos_obs;
                     e_tc = (1 - e_cos) * opz_over_c;
-                    e_dom = gth[2 * VAG_MAX_THETA + jn] + gph[VAG_MAX_PHI + in_];
+                    e_dom = g_dth + g_dph;
                     const double* c = s_par + ek * VAG_NPAR;
                     const LdsTab c2 = lds_tab(c);
                     e_Gu = c2[VP_GAMMA / 2], e_rt = c2[VP_R / 2];
@@ -1064,7 +1095,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                     if (sp_b) e_lt = log2(fma(e_tc, e_rt.x, e_rt.y * one_plus_z));
                     WinCount wc;
                     wc.add(tid < K, e_lt, w_lo, w_hi);
-                    wc.store(s_win + (buf ^ 1) * 2 * NW, tid);
+                    wc.store(s_win + (buf ^ 1) * 2, tid);
                     if (tid < K) {
                         s_dop[ek] = e_dop;
                         s_t[(buf ^ 1) * KS + ek] = e_lt;
@@ -1093,13 +1124,13 @@ vag_flux_grid_kernel(FluxArgs a) {
                 }
             }
             if (fuse_eat) {
-                if ((tid & ~63) >= K) WinCount().store(s_win + (buf ^ 1) * 2 * NW, tid);  // wavefronts without a node: zero counts
                 if (THREADS < 512 && K > THREADS) {  // nodes beyond the first per lane (256-lane workgroups on long lattices); their counts join the first's
-                    const int jn = (pair + 1) / n_phi_eff, in_ = (pair + 1) - jn * n_phi_eff;
-                    const double cos_v = gth[VAG_MAX_THETA + jn] * gph[in_] * sin_obs + gth[jn] * cos_obs;
+                    double g_sin, g_cph, g_cos, g_dth, g_dph;
+                    sload5(gth + VAG_MAX_THETA + jn, gph + in_, gth + jn, gth + 2 * VAG_MAX_THETA + jn, gph + VAG_MAX_PHI + in_, g_sin, g_cph,
+                           g_cos, g_dth, g_dph);
+                    const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
                     const double t_coeff = (1 - cos_v) * opz_over_c;
-                    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + jn] + gph[VAG_MAX_PHI + in_];
-                    int* wn = s_win + (buf ^ 1) * 2 * NW;
+                    const double lg2_dOmega = g_dth + g_dph;
                     WinCount wc;
                     for (int k = tid + THREADS; k < K; k += THREADS) {
                         const double* c = s_par + k * VAG_NPAR;
@@ -1112,10 +1143,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                         s_geom[k] = (lg2_dOmega + c[VP_LG2_R2]) + 3.0 * lg2_dop;
                         wc.add(true, lt, w_lo, w_hi);
                     }
-                    if ((tid & 63) == 0) {  // same lane as the first store: program order
-                        wn[2 * (tid >> 6)] += wc.n_lt;
-                        wn[2 * (tid >> 6) + 1] += wc.n_le;
-                    }
+                    wc.store(s_win + (buf ^ 1) * 2, tid);
                 }
             }
         }
@@ -1123,9 +1151,9 @@ vag_flux_grid_kernel(FluxArgs a) {
         __syncthreads();
         VAG_FLUX_MARK(5);
         if (have_next && !same_rep) {
-            stage_row(pair + 1);
+            stage_row(jn);
             __syncthreads();
-            stage_and_eat(pair + 1, buf ^ 1);
+            stage_and_eat(jn, in_, buf ^ 1);
             __syncthreads();
             VAG_FLUX_MARK(6);
         }
