@@ -849,11 +849,21 @@ VAG_DEV SpecRegs load_spec_regs(LdsTab cell) {
 }
 
 // log2_softplus (src/util/fast-math.h:179-185) = max(z,0) + g(|z|) with the reference's +-20 shortcuts
+// max(z, 0) as ONE v_max_f64 (the compiler's form quiets a possible NaN first: a second v_max_f64 per call)
+VAG_DEV double relu_f64(double z) {
+#ifdef VAG_HOST_DEBUG
+    return z > 0 ? z : 0.0;
+#else
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(z));
+    return r;
+#endif
+}
 template <class Tab>
 VAG_DEV double sp_fast(double z, Tab tab) {
     const double a = fabs(z);
 #ifndef VAG_SP_BRANCHLESS
-    if (a > 20.0) return z > 0 ? z : 0.0;
+    if (a > 20.0) return relu_f64(z);
 #endif
     const double t = fma(a, (double)SP_PER_UNIT, SP_MAGIC);  // nearest node: integer in the low mantissa word
     const int idx = (int)min((unsigned)__double2loint(t), (unsigned)(SP_INTERVALS - 1));  // the clamp only acts on NaN

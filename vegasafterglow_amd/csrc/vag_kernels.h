@@ -1007,6 +1007,9 @@ vag_flux_grid_kernel(FluxArgs a) {
         //      same block, so the LDS round trips and the Horner chains interleave instead of queueing (alone, one slot's chain
         //      takes ~650 cycles for 27 instructions and a node's logs ~1500; profiles/r03_flux_phase_budget.txt).  A slot
         //      without a finite slope adds exp2(-2000) = 0: the sums keep their order and their bits.
+#ifdef VAG_FLUX_PRIO  // measured and rejected: the short latency-bound interval ahead of the other workgroup's boundary spectra
+        __builtin_amdgcn_s_setprio(VAG_FLUX_PRIO);  // (s_setprio 2 here, 0 before the barrier: 21.83 vs 21.65 ms per 512 C2 models)
+#endif
         if (tid == THREADS - 1) s_win[buf * 2] = 0, s_win[buf * 2 + 1] = 0;  // read by everyone before the barrier; the row after next adds again
         const bool have_next = pair + 1 < p1;
         const bool same_rep = have_next && sload_i32(rep_of + (have_next ? jn : 0)) == staged_rep;
@@ -1148,6 +1151,9 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
         }
         VAG_FLUX_MARK(4);
+#ifdef VAG_FLUX_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         VAG_FLUX_MARK(5);
         if (have_next && !same_rep) {
