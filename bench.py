@@ -221,9 +221,10 @@ def tophat_sweep(lib, h, _lib, dev, with_cpu):
     return out
 
 
-def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=128):
+def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=512):
     """BASELINE configs[2] and [4] as batched ensembles on one GPU: C3 = power-law jet in a wind, forward +
-    reverse shock with SSC + Klein-Nishina on both (jittered parameters); C5 = prior-predictive sweep of two-component SSC
+    reverse shock with SSC + Klein-Nishina on both (jittered parameters), 512 models per call (128 leave a third of a launch
+    to the tail: 9.7 k wavefronts are < 4 rounds of the chip); C5 = prior-predictive sweep of two-component SSC
     jets, 1024 members.  100 times x 4 bands (incl. 2.4e26 Hz), device-resident inputs.  The flux passes' FP64 roofline uses the
     kernels' own work tallies (one extra untimed pass with vag_ctx_count_work): spectrum evaluations x 210 (synchrotron) or
     x 30 (tabulated SSC spectrum) + interpolations x 26, over the flux stage's HIP-event time."""

@@ -357,8 +357,7 @@ def test_ssc_batch_band_model_api_and_loud_limits(eng, oracle):
     assert_close(fd.fwd.sync, o_sync)
     assert_close(fd.fwd.ssc, o_ssc)
     assert_close(fd.total, o_sync + o_ssc)
-    # mixed Radiation flags in one host-pointer batch: split inside the call (test_mixed_flag_batches_are_split_inside_the_call);
-    # a device-resident batch cannot be regrouped behind the caller's back and says so
+    # mixed Radiation flags in one batch: split inside the call (test_mixed_flag_batches_are_split_inside_the_call)
     import torch
     mixed = (_lib.ModelParams * 2)(_lib.ModelParams.from_buffer_copy(bytes(prm)),
                                    _lib.ModelParams.from_buffer_copy(bytes(_abi.make_params(jet="GaussianJet"))))
@@ -371,8 +370,10 @@ def test_ssc_batch_band_model_api_and_loud_limits(eng, oracle):
     d_t, d_nu = torch.from_numpy(SSC_T).to(dev), torch.from_numpy(SSC_NU).to(dev)
     d_o = torch.empty((2, SSC_NU.size, SSC_T.size), dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    rc = lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), 2, d_t.data_ptr(), SSC_T.size, d_nu.data_ptr(), SSC_NU.size, d_o.data_ptr())
-    assert rc == _lib.VAG_E_UNSUPPORTED and b"split it by flags" in lib.vag_last_error()
+    # the device-pointer entry point regroups such a batch by flags itself (test_mixed_flag_batches_on_the_device_pointer_entry_points)
+    _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), 2, d_t.data_ptr(), SSC_T.size, d_nu.data_ptr(), SSC_NU.size, d_o.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_o.cpu().numpy(), out)
 
 
 def test_ssc_series_and_loglike(eng, oracle):
@@ -1460,3 +1461,58 @@ def test_mixed_flag_batches_are_split_inside_the_call(eng, oracle):
     comps = gpu_components4(eng, prms, t, nu)
     assert comps[1][0].max() == 0 and comps[1][1].max() > 0 and comps[2][3].max() > 0 and comps[2][0].max() == 0
     np.testing.assert_allclose(comps[0] + comps[1] + comps[2] + comps[3], mixed, rtol=1e-12)
+
+
+def test_mixed_flag_batches_on_the_device_pointer_entry_points(eng):
+    """vag_flux_density_grid_batch_dev / vag_flux_density_batch_dev with parameters, times and outputs resident in HBM and five
+    different flag sets in one batch (what dist.sharded_flux_density_grid and the bench hand over): the models are sorted by flags on
+    the way in and scattered back, each one bitwise as in a device call of its own flag group; the plan counts the whole batch."""
+    import torch
+    lib, h = eng
+    t, nu = np.logspace(3, 7, 12), np.array([1e9, 4.84e14, 1e18])
+    kws = [dict(jet="GaussianJet", theta_obs=0.2), dict(jet="TophatJet", theta_obs=0.05, ssc=True),
+           dict(jet="GaussianJet", theta_obs=0.3, n_ism=0.3), dict(jet="TophatJet", theta_obs=0.1, duration=50.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+           dict(jet="TophatJet", theta_obs=0.05, ssc=True, kn=True), dict(jet="GaussianJet", theta_obs=0.15, spreading=True),
+           dict(jet="TophatJet", theta_obs=0.05, ssc=True, eps_e=0.05), dict(jet="GaussianJet", theta_c=-1.0)]  # the last one is invalid
+    prms = [_abi.make_params(**kw) for kw in kws]
+    dev = torch.device("cuda", 0)
+    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
+    ts, nus = np.repeat(t, 3), np.tile(nu, t.size)
+    d_ts, d_nus = torch.from_numpy(ts).to(dev), torch.from_numpy(nus).to(dev)
+
+    def dev_params(ps):
+        arr = (_lib.ModelParams * len(ps))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in ps])
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    def grid(ps):
+        d_p = dev_params(ps)
+        d_o = torch.full((len(ps), nu.size, t.size), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), len(ps), d_t.data_ptr(), t.size, d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+        _lib.check(lib.vag_ctx_synchronize(h))
+        return d_o.cpu().numpy()
+
+    def series(ps):
+        d_p = dev_params(ps)
+        d_o = torch.full((len(ps), ts.size), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_flux_density_batch_dev(h, d_p.data_ptr(), len(ps), d_ts.data_ptr(), d_nus.data_ptr(), ts.size, d_o.data_ptr()))
+        _lib.check(lib.vag_ctx_synchronize(h))
+        return d_o.cpu().numpy()
+
+    mixed = grid(prms)
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_ok == len(prms) - 1 and pl.n_models_invalid == 1
+    assert np.isnan(mixed[-1]).all() and np.isfinite(mixed[:-1]).all() and mixed[:-1].min() >= 0
+    mixed_s = series(prms)
+    groups = {}
+    for i, p in enumerate(prms):
+        groups.setdefault(p.flags, []).append(i)
+    assert len(groups) == 5
+    for idx in groups.values():
+        own, own_s = grid([prms[i] for i in idx]), series([prms[i] for i in idx])
+        for q, i in enumerate(idx):
+            assert np.array_equal(mixed[i], own[q], equal_nan=True), i
+            assert np.array_equal(mixed_s[i], own_s[q], equal_nan=True), i
+    assert np.array_equal(grid(prms), mixed, equal_nan=True)  # run to run

@@ -286,6 +286,9 @@ struct vag_ctx {
     DevBuf d_shard_cost, d_shard_table, d_shard_theta, d_shard_ll;
     int shard_nb = 0, shard_world = 0;      // what d_shard_cost was gathered for (0: no finished call yet)
     int shard_cur_nb = 0, shard_cur_world = 0;  // the call between vag_loglike_shard_dev and its finish
+    // device-resident batches whose models differ in their Radiation / shock flags: regrouped by flags (flux_dev_by_flags)
+    bool mixed_flags_seen = false;  // the last grid pass stopped on such a batch
+    DevBuf d_mix_flags, d_mix_perm, d_mix_params, d_mix_out;
     bool order_next = false, order_active = false;  // the next / the last model-stage run is in evaluation-slot order
     const int* last_order = nullptr;                // ... and the order it used
     bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > 320 theta / > 640 phi nodes)
@@ -542,7 +545,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
-    for (DevBuf* b : {&c->d_shard_cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f})
+    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->d_shard_cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -825,9 +828,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             c->grid_large_idle = 0;
         }
         if (hp->n_capacity > 0) c->grid_large_idle = 0;
+        c->mixed_flags_seen = hp->flags_mixed != 0;
         if (hp->flags_mixed)
             return set_err(VAG_E_UNSUPPORTED, "models with different Radiation / shock flags in one device-resident batch: split it by flags "
-                                              "(the host-pointer entry points do that themselves)");
+                                              "(the flux entry points do that themselves)");
         rows = hp->rows, cells = hp->cells, pairs = hp->pairs, eat = hp->eat, max_k = hp->max_k, max_pairs = hp->max_pairs;
         n_ok = hp->n_ok, n_invalid = hp->n_invalid, n_capacity = hp->n_capacity, dyn_class = hp->dyn_class;
         flags = hp->flags_first < 0 ? 0 : hp->flags_first;
@@ -1858,11 +1862,81 @@ static int run_flag_groups(const vag_model_params* params, int nb, const std::ve
 
 extern "C" {
 
-int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt,
-                                    const double* d_nu, int nnu, double* d_out) {
-    if (!c) return set_err(VAG_E_INVALID, "null context");
-    if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
-    HIPCHK(hipSetDevice(c->device));
+}  // extern "C"
+
+// ---- device-resident batches with mixed Radiation / shock flags (samplers.py:59-91 evaluates any mix of models side by side) ----
+__global__ void vag_flags_kernel(const vag_model_params* __restrict__ params, int nb, int* __restrict__ flags) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nb) flags[m] = params[m].flags;
+}
+__global__ void vag_gather_params_kernel(const vag_model_params* __restrict__ params, const int* __restrict__ perm, int nb,
+                                         vag_model_params* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) out[i] = params[perm[i]];
+}
+__global__ void vag_scatter_rows_kernel(const double* __restrict__ src, const int* __restrict__ perm, int nb, size_t stride,
+                                        double* __restrict__ dst) {
+    const int i = blockIdx.y;
+    if (i >= nb) return;
+    const double* s = src + (size_t)i * stride;
+    double* d = dst + (size_t)perm[i] * stride;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < stride; q += (size_t)gridDim.x * blockDim.x) d[q] = s[q];
+}
+
+// A batch the grid pass refused for its mixed flags: sort the models by flags (stable: the flags travel to the host, 4 bytes per
+// model, the permutation comes back), run every group as a batch of its own on the gathered parameters -- each model then comes
+// out bitwise as in a call of its own group -- and scatter the rows back into the caller's order.  `body(d_params, n, d_out)` is
+// the single-flag path of the entry point.
+template <class Body>
+static int flux_dev_by_flags(vag_ctx* c, const vag_model_params* d_params, int nb, size_t stride, double* d_out, Body body) {
+    if (c->d_mix_flags.ensure(sizeof(int) * (size_t)nb) || c->d_mix_perm.ensure(sizeof(int) * (size_t)nb) ||
+        c->d_mix_params.ensure(sizeof(vag_model_params) * (size_t)nb) || c->d_mix_out.ensure(sizeof(double) * (size_t)nb * stride))
+        return VAG_E_HIP;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(vag_flags_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, d_params, nb, c->d_mix_flags.as<int>());
+    HIPCHK(hipGetLastError());
+    std::vector<int> flags(nb), perm;
+    HIPCHK(hipMemcpyAsync(flags.data(), c->d_mix_flags.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> keys;
+    std::vector<std::vector<int>> groups;
+    for (int m = 0; m < nb; ++m) {
+        size_t g = 0;
+        while (g < keys.size() && keys[g] != flags[m]) ++g;
+        if (g == keys.size()) {
+            keys.push_back(flags[m]);
+            groups.emplace_back();
+        }
+        groups[g].push_back(m);
+    }
+    perm.reserve(nb);
+    for (const auto& g : groups) perm.insert(perm.end(), g.begin(), g.end());
+    HIPCHK(hipMemcpyAsync(c->d_mix_perm.p, perm.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // perm is a local: the copy must have left it
+    hipLaunchKernelGGL(vag_gather_params_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, d_params, c->d_mix_perm.as<int>(), nb,
+                       c->d_mix_params.as<vag_model_params>());
+    HIPCHK(hipGetLastError());
+    size_t off = 0;
+    int n_ok = 0, n_inv = 0, n_cap = 0;
+    for (const auto& g : groups) {
+        const int ng = (int)g.size();
+        const int rc = body(c->d_mix_params.as<vag_model_params>() + off, ng, c->d_mix_out.as<double>() + off * stride);
+        if (rc) return rc;
+        n_ok += c->plan.n_models_ok, n_inv += c->plan.n_models_invalid, n_cap += c->plan.n_models_capacity;
+        off += (size_t)ng;
+    }
+    c->plan.n_models_ok = n_ok, c->plan.n_models_invalid = n_inv, c->plan.n_models_capacity = n_cap;  // the batch's, not the last group's
+    const unsigned gx = (unsigned)std::min<size_t>((stride + 255) / 256, 64);
+    hipLaunchKernelGGL(vag_scatter_rows_kernel, dim3(gx, nb), dim3(256), 0, st, c->d_mix_out.as<double>(), c->d_mix_perm.as<int>(), nb, stride,
+                       d_out);
+    HIPCHK(hipGetLastError());
+    return VAG_OK;
+}
+
+extern "C" {
+
+static int grid_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt, const double* d_nu, int nnu,
+                         double* d_out) {
     int rc = VAG_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {  // planned ahead from the previous call's summary, verified at the end
         rc = prep_times(c, d_t, nt, d_nu, nnu);
@@ -1881,6 +1955,20 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
         rc = finish_speculation(c);
         if (rc != VAG_RETRY) break;
     }
+    return rc;
+}
+
+int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt,
+                                    const double* d_nu, int nnu, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
+    HIPCHK(hipSetDevice(c->device));
+    c->mixed_flags_seen = false;
+    int rc = grid_dev_body(c, d_params, nb, d_t, nt, d_nu, nnu, d_out);
+    if (rc == VAG_E_UNSUPPORTED && c->mixed_flags_seen)
+        rc = flux_dev_by_flags(c, d_params, nb, (size_t)nnu * nt, d_out, [&](const vag_model_params* gp, int ng, double* o) {
+            return grid_dev_body(c, gp, ng, d_t, nt, d_nu, nnu, o);
+        });
     return rc;
 }
 
@@ -1908,13 +1996,8 @@ static int series_request(vag_ctx* c, const vag_model_params* d_params, int nb, 
     return rc;
 }
 
-int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
-                               const double* d_nu, int n, double* d_out) {
-    if (!c) return set_err(VAG_E_INVALID, "null context");
-    if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
-    HIPCHK(hipSetDevice(c->device));
-    const int n_bands = c->pending_bands;  // only the host-pointer wrapper below knows the frequencies
-    c->pending_bands = 0;
+static int series_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, const double* d_nu, int n,
+                           double* d_out, int n_bands) {
     int rc = VAG_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         rc = prep_times(c, d_t, n, d_nu, n);  // the grid sees the extrema of ALL requested times
@@ -1933,6 +2016,22 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
         rc = finish_speculation(c);
         if (rc != VAG_RETRY) break;
     }
+    return rc;
+}
+
+int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
+                               const double* d_nu, int n, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
+    HIPCHK(hipSetDevice(c->device));
+    const int n_bands = c->pending_bands;  // only the host-pointer wrapper below knows the frequencies
+    c->pending_bands = 0;
+    c->mixed_flags_seen = false;
+    int rc = series_dev_body(c, d_params, nb, d_t, d_nu, n, d_out, n_bands);
+    if (rc == VAG_E_UNSUPPORTED && c->mixed_flags_seen)
+        rc = flux_dev_by_flags(c, d_params, nb, (size_t)n, d_out, [&](const vag_model_params* gp, int ng, double* o) {
+            return series_dev_body(c, gp, ng, d_t, d_nu, n, o, n_bands);
+        });
     return rc;
 }
 
