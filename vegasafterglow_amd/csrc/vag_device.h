@@ -287,6 +287,9 @@ struct Dopri5 {
     double xo[N], dxo[N];        // previous state / derivative
     double k3[N], k4[N], k5[N], k6[N];
     double t, t_old, dt, eps;
+#ifdef VAG_PAIR_STAMPS
+    int n_att = 0;  // developer aid: step attempts made (accepted + rejected)
+#endif
 
     template <class F>
     VAG_DEV void init(const double* x0, double t0, double dt0, double tol, F& f) {
@@ -314,6 +317,9 @@ struct Dopri5 {
         for (int fails = 0; fails < 500; ++fails) {
             double xt[N], k2[N], xn[N], k7[N];
             const double h = dt;
+#ifdef VAG_PAIR_STAMPS
+            ++n_att;
+#endif
 #pragma unroll
             for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b21) * dx[i];
             f(xt, k2, t + h * a2);

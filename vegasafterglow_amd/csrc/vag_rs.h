@@ -50,7 +50,7 @@ struct CrossLattice {
             const int q = kk - n_pre + 1;  // node q of the second segment (its node 0 is t_refine, already emitted)
             lg = (n_post > 1 && q == n_post - 1) ? l3 : lr + step2 * (double)q;
         }
-        return pow(10.0, lg);
+        return exp2_fast(lg * 3.321928094887362347870319429489390175865);  // 10^lg like TimeLattice::node
     }
 };
 
@@ -106,6 +106,39 @@ VAG_DEV double sound_speed(double G) {  // compute_sound_speed, shock-physics.h:
     return sqrt(dmax(ad * (ad - 1) * (G - 1) / (1 + (G - 1) * ad), 0.0)) * C_C;
 }
 
+// ---- the same closed forms for the ODE right-hand side: hardware reciprocal / reciprocal square root + one Newton step (2e-15 /
+//      4e-15, vag_dyn_fast.h) instead of the IEEE division (~25 instructions) and square-root (~30) sequences.  The right-hand side
+//      of FRShockEqn holds 22 divisions and 8 square roots; the states are integrated to 1e-6.  profiles/r03_pair_stamps.txt: a
+//      step attempt of vag_dynamics_pair_kernel took 50 k cycles with the library forms, two thirds of them these sequences. ----
+VAG_DEV double rcp1(double x) {  // 1/x, x finite, non-zero, normal
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+VAG_DEV double sqrt1(double x) {  // sqrt(x) with sqrt(0) = 0 kept; x >= 0
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y;
+    const double s = fma(fma(-s0, s0, x), 0.5 * y, s0);
+    return x > 0 ? s : 0.0;
+}
+VAG_DEV double rel_Gamma_f(double g1, double g2) {
+    const double u1u2 = sqrt1(dmax((g1 - 1) * (g1 + 1) * (g2 - 1) * (g2 + 1), 0.0));
+    const double d = g1 - g2;
+    const double denom = g1 * g2 - 1 + u1u2;
+    return denom <= 0 ? 1 : 1 + d * d * rcp1(denom);
+}
+VAG_DEV double jump_4vel_f(double gamma_rel, double sigma) {  // sigma == 0: the hydrodynamic jump; else the exact cubic
+    if (sigma > SIGMA_CUT) return jump_4vel(gamma_rel, sigma);
+    const double ad = 4.0 / 3.0 + rcp1(3 * gamma_rel);
+    const double gm1 = gamma_rel - 1, adm2 = ad - 2, adm1 = ad - 1;
+    const double u_down = sqrt1(dmax(gm1 * adm1 * adm1 * rcp1(-ad * adm2 * gm1 + 2), 0.0));
+    const double u_up = sqrt1((1 + u_down * u_down) * dmax(gm1 * (gamma_rel + 1), 0.0)) + u_down * gamma_rel;
+    return (u_down == 0.) ? 4 * gamma_rel : u_up * rcp1(u_down);
+}
+VAG_DEV double sound_speed_f(double G) {
+    const double ad = 4.0 / 3.0 + rcp1(3 * G);
+    return sqrt1(dmax(ad * (ad - 1) * (G - 1) * rcp1(1 + (G - 1) * ad), 0.0)) * C_C;
+}
+
 VAG_DEV double downstr_B(double eps_B, double rho_up, double B_up, double Gamma_th, double comp) {  // shock-physics.h:354-360
     const double e_th = (Gamma_th - 1) * (rho_up * comp) * C_C2;
     return sqrt(8 * C_PI * eps_B * e_th) + B_up * comp;
@@ -141,15 +174,132 @@ struct PairShock {
     double beta4;
     double inj_L, inj_t0, inj_q;                        // magnetar injection (0 when off / outside theta_c), cf. FwdShock
 
+    VAG_DEV double inject_weight(double t) const {  // smoothstep(1.5 T0, 0.5 T0, t) with the edge difference's reciprocal at hand
+        double w = (t - 1.5 * T0) * (-1.0 / T0);
+        w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
+        return w * w * (3.0 - 2.0 * w);
+    }
     VAG_DEV double shell_sigma(const double* s) const {
         const double sigma = s[RS_EPS4] / (Gamma4 * s[RS_M4] * C_C2) - 1;
         return (sigma > SIGMA_CUT) ? sigma : 0;
     }
     VAG_DEV bool crossing_complete(const double* s, double t) const {  // reverse-shock.tpp:46-58
         if (s[RS_M3] < 0.999 * s[RS_M4]) return false;
-        return !(smoothstep(T0 * 1.5, T0 * 0.5, t) > 1e-6);
+        return !(inject_weight(t) > 1e-6);
     }
+#ifdef VAG_PAIR_EXACT_MATH
+    VAG_DEV void operator()(const double* raw, double* d, double t) const { rhs_exact(raw, d, t); }
+#else
+    // FRShockEqn::operator() (reverse-shock.tpp:60-293), same statements and guards as rhs_exact below, on rcp1 / sqrt1
     VAG_DEV void operator()(const double* raw, double* d, double t) const {
+        const double Gamma = dmin(dmax(raw[RS_GAMMA], 1.0), Gamma4);
+        const double m4 = raw[RS_M4];
+        const double m3 = dmin(dmax(raw[RS_M3], 0.0), dmax(m4, 0.0));
+        const double x3 = dmax(raw[RS_X3], 0.0), U3 = dmax(raw[RS_U3], 0.0);
+        const double x4 = raw[RS_X4], m2 = raw[RS_M2], U2 = raw[RS_U2], r = raw[RS_R], t_comv = raw[RS_TCOMV];
+        const double u3 = sqrt1((Gamma - 1) * (Gamma + 1));
+        const double dr = u3 * (Gamma + u3) * C_C;
+        const double dtc = Gamma + u3;
+        d[RS_R] = dr;
+        d[RS_TCOMV] = dtc;
+        const double rho = med.type == VAG_MEDIUM_ISM ? med.rho_ism : (med.generic ? medium_rho(med, r) : fma(med.A, rcp1(fma(r, r, med.r02)), med.rho_ism));
+        const double dm2 = r * r * rho * dr;
+        d[RS_M2] = dm2;
+        const double inject_w = inject_weight(t);
+        const double deps_inj = (inj_L != 0) ? inj_L * exp2_sat(-inj_q * log2_fast(1 + t * inj_t0)) : 0.0;
+        const double deps4 = ((inject_w > 1e-6) ? inject_w * deps0_dt : 0) + deps_inj;
+        const double dm4 = (inject_w > 1e-6) ? inject_w * dm0_dt : 0;
+        d[RS_EPS4] = deps4;
+        d[RS_M4] = dm4;
+        const double Gamma34 = rel_Gamma_f(Gamma4, Gamma);
+        const double inv_m4 = rcp1(m4);  // m4 > 0 along a row (seeded by dm0_dt dt); the m4 <= 0 guards below keep the reference's
+        double sigma = raw[RS_EPS4] * inv_m4 * (1.0 / (Gamma4 * C_C2)) - 1;
+        sigma = (sigma > SIGMA_CUT) ? sigma : 0;
+        const double comp_ratio = jump_4vel_f(Gamma34, sigma);
+        const double f = (dm0_dt > 0 && dm4 > 0) ? dmin(dm4 * rcp1(dm0_dt), 1.0) : 0.0;
+        const double cs34 = sound_speed_f(Gamma34);
+        const double inv_G = rcp1(Gamma);
+        {
+            const double se = cs4 * dtc;
+            d[RS_X4] = (f > 1e-6) ? f * u4 + (1 - f) * se : se;
+        }
+        double dx3;
+        {
+            const double se = cs34 * dtc;
+            dx3 = se;
+            if (!(m4 <= 0)) {
+                const double remaining = dmax(m4 - m3, 0.0);
+                const double crossing_w = f + (1.0 - f) * remaining * inv_m4;
+                const double penetration = Gamma * comp_ratio * (1.0 / Gamma4) - 1;
+                if (!(crossing_w < 1e-6) && !(penetration <= 0)) {
+                    const double beta3 = u3 * inv_G;
+                    const double dx3dt = (Gamma4 - Gamma) * (Gamma4 + Gamma) * (1 + beta3) * C_C *
+                                         rcp1(Gamma4 * Gamma4 * (beta3 + beta4) * penetration);
+                    double crossing = fabs(dx3dt * Gamma);
+                    if (penetration < 1) {
+                        const double va2 = sigma * rcp1(1 + sigma);
+                        const double cs2 = cs34 * cs34 * (1.0 / (C_C * C_C));
+                        crossing = dmin(crossing, sqrt1(va2 + cs2 * (1 - va2)) * C_C * dtc);
+                    }
+                    dx3 = crossing_w * crossing + (1.0 - crossing_w) * se;
+                }
+            }
+            d[RS_X3] = dx3;
+        }
+        const double inv_x4 = rcp1(x4);
+        double dm3 = 0.;
+        if (!(m4 <= 0)) {
+            const double remaining = dmax(m4 - m3, 0.0);
+            if (!(remaining <= 0 && f < 1e-6)) {
+                const double eff_mass = f * m4 + (1.0 - f) * remaining;
+                const double dm3dt = (eff_mass * comp_ratio * inv_x4) * dx3;
+                if (f > 1e-6) {
+                    double cw = m3 * inv_m4;  // smoothstep(0, 1, m3 / m4)
+                    cw = cw < 0.0 ? 0.0 : (cw > 1.0 ? 1.0 : cw);
+                    const double cap_w = cw * cw * (3.0 - 2.0 * cw);
+                    dm3 = (1.0 - cap_w) * dm3dt + cap_w * dmin(dm3dt, dm4);
+                } else {
+                    dm3 = dm3dt;
+                }
+            }
+        }
+        d[RS_M3] = dm3;
+        const double ad2 = 4.0 / 3.0 + inv_G * (1.0 / 3.0), ad3 = 4.0 / 3.0 + rcp1(3 * Gamma34);
+        const double inv_r = rcp1(r);
+        double dU2, dU3;
+        {
+            const double e_th = (Gamma - 1) * 4 * Gamma * rho * C_C2;
+            double eps_rad = 0;  // RadiativeEfficiency, shock-physics.h:247-288
+            if (eps_e_eff != 0) {
+                const double gamma_m = gamma_m_coeff * (Gamma - 1) + 1;
+                const double gamma_bar = gamma_c_coeff * rcp1(e_th * t_comv);
+                const double gamma_c = 0.5 * (gamma_bar + sqrt1(gamma_bar * gamma_bar + 4));
+                const double ratio = gamma_m * rcp1(gamma_c);
+                eps_rad = (ratio < 1 && p > 2) ? eps_e_eff * exp2_sat((p - 2) * log2_fast(ratio)) : eps_e_eff;
+            }
+            double dlnv = 2 * dr * inv_r;
+            if (x4 > 0) dlnv += d[RS_X4] * inv_x4;
+            dU2 = (1 - eps_rad) * (dm2 * (Gamma - 1) * C_C2) + (-(ad2 - 1) * dlnv * U2);
+        }
+        {
+            double dlnv = 2 * dr * inv_r;
+            if (x3 > 0) dlnv += dx3 * rcp1(x3);
+            dU3 = dm3 * (Gamma34 - 1) * C_C2 + (-(ad3 - 1) * dlnv * U3);
+        }
+        d[RS_U2] = dU2;
+        d[RS_U3] = dU3;
+        {
+            const double G2 = Gamma * Gamma, inv_G2 = inv_G * inv_G;
+            const double Geff2 = (ad2 * G2 - ad2 + 1) * inv_G, Geff3 = (ad3 * G2 - ad3 + 1) * inv_G;
+            const double dGeff2 = (ad2 * G2 + ad2 - 1) * inv_G2, dGeff3 = (ad3 * G2 + ad3 - 1) * inv_G2;
+            const double a = (Gamma - 1) * C_C2 * dm2 + (Gamma - Gamma4) * C_C2 * dm3 + Geff2 * dU2 + Geff3 * dU3 - deps_inj;
+            const double b = (m2 + m3) * C_C2 + dGeff2 * U2 + dGeff3 * U3;
+            const double q = -a * rcp1(b);
+            d[RS_GAMMA] = (b == 0 || isnan(q) || isinf(q)) ? 0 : q;
+        }
+    }
+#endif
+    VAG_DEV void rhs_exact(const double* raw, double* d, double t) const {
         const double Gamma = dmin(dmax(raw[RS_GAMMA], 1.0), Gamma4);
         const double m4 = raw[RS_M4];
         const double m3 = dmin(dmax(raw[RS_M3], 0.0), dmax(m4, 0.0));

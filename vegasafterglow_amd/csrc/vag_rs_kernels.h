@@ -90,22 +90,24 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
         {   // save_fwd_shock_state (forward-shock.tpp:151-173): region 2
             const double comp = compression_fwd(q[RS_GAMMA]);
             const double rho = medium_rho(eq.med, q[RS_R]);
-            const double Gth = Gamma_therm(q[RS_U2], q[RS_M2], false);
-            put(F, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth, downstr_B(P.eps_B, rho, 0, Gth, comp), q[RS_M2] / C_MP);
+            const double Gth = q[RS_M2] == 0 ? 1.0 : q[RS_U2] * rcp_fast(q[RS_M2] * C_C2) + 1;  // Gamma_therm without the limiter
+            const double e_th = (Gth - 1) * (rho * comp) * C_C2;
+            put(F, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth, sqrt_fast(8 * C_PI * P.eps_B * e_th), q[RS_M2] / C_MP);
         }
+        const double Gth3 = q[RS_M3] == 0 ? 1.0 : q[RS_U3] * rcp_fast(q[RS_M3] * C_C2) + 1;
         if (k <= inj) {  // save_rvs_shock_state (reverse-shock.tpp:393-426): still crossing
             const double sigma4 = eq.shell_sigma(q);
-            const double comp34 = jump_4vel(rel_Gamma(eq.Gamma4, q[RS_GAMMA]), sigma4);
-            const double rho4 = q[RS_M4] / (q[RS_R] * q[RS_R] * q[RS_X4]);
-            const double Gth = Gamma_therm(q[RS_U3], q[RS_M3], true);
-            const double B4 = sqrt((4 * C_PI * C_C2) * sigma4 * rho4);
-            put(R, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth, downstr_B(P.rvs_eps_B, rho4, B4, Gth, comp34),
-                q[RS_M3] / C_MP);
+            const double comp34 = jump_4vel_f(rel_Gamma_f(eq.Gamma4, q[RS_GAMMA]), sigma4);
+            const double rho4 = q[RS_M4] * rcp_fast(q[RS_R] * q[RS_R] * q[RS_X4]);
+            const double Gth = Gth3 < GAMMA_CUT ? 1.0 : Gth3;  // the limiter of compute_Gamma_therm
+            const double B4 = sigma4 > 0 ? sqrt_fast((4 * C_PI * C_C2) * sigma4 * rho4) : 0.0;
+            const double e_th = (Gth - 1) * (rho4 * comp34) * C_C2;
+            put(R, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth, sqrt_fast(8 * C_PI * P.rvs_eps_B * e_th) + B4 * comp34, q[RS_M3] / C_MP);
         } else {  // after the crossing: frozen shell expanding adiabatically
             const double V3_comv = q[RS_R] * q[RS_R] * q[RS_X3];
-            const double comp = V3_comv_x / V3_comv;
-            const double Gth = Gamma_therm(q[RS_U3], q[RS_M3], false);
-            put(R, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth, downstr_B(P.rvs_eps_B, rho3_x, B3_ordered_x, Gth, comp),
+            const double comp = V3_comv_x * rcp_fast(V3_comv);
+            const double e_th = (Gth3 - 1) * (rho3_x * comp) * C_C2;
+            put(R, k, t_k, q[RS_TCOMV], q[RS_R], q[RS_GAMMA], Gth3, sqrt_fast(8 * C_PI * P.rvs_eps_B * e_th) + B3_ordered_x * comp,
                 q[RS_M3] / C_MP);
         }
     };
@@ -142,7 +144,18 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     bool crossing = true, pending = false;
     double t_cross = 0, t_step_start = t0;
     int status = 0;
+#ifdef VAG_PAIR_STAMPS  // developer aid: where one row's cycles go
+    long long c_step = 0, c_bis = 0, c_save = 0, c_mark = __builtin_readcyclecounter();
+    const long long c_begin = c_mark;
+    int n_steps = 0, n_waves_att = 0;
+#define VAG_PAIR_MARK(acc) do { const long long now_ = __builtin_readcyclecounter(); acc += now_ - c_mark; c_mark = now_; } while (0)
+#else
+#define VAG_PAIR_MARK(acc) do { } while (0)
+#endif
     for (int steps = 0; st.t <= t_last;) {
+#ifdef VAG_PAIR_STAMPS
+        ++n_waves_att;
+#endif
         if (!st.step(eq)) {
             status = 1;
             break;
@@ -155,6 +168,10 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
             status = 3;
             break;
         }
+        VAG_PAIR_MARK(c_step);
+#ifdef VAG_PAIR_STAMPS
+        ++n_steps;
+#endif
         if (crossing && eq.crossing_complete(st.x, st.t)) {  // locate_crossing_time, reverse-shock.tpp:484-497
             double t_lo = t_step_start, t_hi = st.t;
             double q[RS_N];
@@ -179,6 +196,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
             crossing = false;
             pending = true;
         }
+        VAG_PAIR_MARK(c_bis);
         t_step_start = st.t;
         while (k < nt && st.t > t_k) {
             double q[RS_N];
@@ -191,7 +209,13 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
             ++k;
             if (k < nt) t_k = node(k);
         }
+        VAG_PAIR_MARK(c_save);
     }
+#ifdef VAG_PAIR_STAMPS
+    if (row % 997 == 0)
+        printf("pair row %d: accepted %d attempts %d (own) loop trips %d  cycles: total %lld stepping %lld bisection %lld saving %lld\n", row, n_steps,
+               st.n_att, n_waves_att, (long long)__builtin_readcyclecounter() - c_begin, c_step, c_bis, c_save);
+#endif
     for (; k < nt; ++k) {  // unreached nodes keep the Shock constructor's defaults (shock.cpp:12-24)
         const double tk = node(k);
         put(F, k, tk, 0, 0, 1, 1, 0, 0);
