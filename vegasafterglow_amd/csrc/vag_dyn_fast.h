@@ -238,7 +238,7 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
         if (false) {
 #else
         if (__any(accepted)) {  // publish the step
-#endif: the saver interpolates it at the lattice nodes it passed
+#endif  // the saver interpolates it at the lattice nodes it passed
             const int slot = head & (DYN_NSLOT - 1);
             {   // ring full?  (the saver is normally far ahead)
 #if defined(VAG_DYN_STAMPS) && VAG_DYN_STAMPS > 1
