@@ -1,5 +1,6 @@
-"""Developer aid (GPU box): the C2 bench batch through two builds of the library (VAG_LIB_A, VAG_LIB_B): the fluxes must be the same
-bits when a change only re-schedules the flux kernel (same boundary values, same sum order).  Each library runs in its own process."""
+"""Developer aid (GPU box): the C2 bench batch through two builds of the library (VAG_LIB_A, VAG_LIB_B) or two settings of one
+(VAG_ENV_A / VAG_ENV_B = "NAME=value ..."): the fluxes must be the same bits when a change only re-schedules the flux kernel (same
+boundary values, same sum order).  Each side runs in its own process."""
 import os
 import subprocess
 import sys
@@ -29,7 +30,12 @@ nb = sys.argv[1] if len(sys.argv) > 1 else "64"
 outs = []
 for tag in ("A", "B"):
     path = f"/tmp/flux_bits_{tag}.npy"
-    env = dict(os.environ, VAG_LIB_PATH=os.environ[f"VAG_LIB_{tag}"])
+    env = dict(os.environ)
+    if os.environ.get(f"VAG_LIB_{tag}"):
+        env["VAG_LIB_PATH"] = os.environ[f"VAG_LIB_{tag}"]
+    for kv in os.environ.get(f"VAG_ENV_{tag}", "").split():  # e.g. VAG_ENV_A="VAG_FLUX_NO_WIDE=1": a switch of the same library
+        k, v = kv.split("=", 1)
+        env[k] = v
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", path, nb], env=env)
     outs.append(np.load(path))
 a, b = outs

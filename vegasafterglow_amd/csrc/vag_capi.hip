@@ -1094,6 +1094,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
                          ppb, small ? 256 : FLUX_THREADS, lds, occ);
         }
         const bool pieces = c->max_k > ks;  // some lattice is longer than the staged row: the instantiations with the piece loop
+        // (Measured and rejected, profiles/rejected/vag_flux_wide.h: ONE 1024-lane workgroup per CU sharing the staged row and tables, a
+        // second boundary block in the LDS that frees, one barrier per row and balanced slot ownership -- bitwise the same fluxes,
+        // 27.0-27.7 ms against 21.7 per 512 C2 models: sixteen wavefronts in lockstep lose the overlap two independent workgroups have.)
         if (pieces) {
             a.work_count = nullptr;  // the tallying instantiation has no piece loop: the plan keeps the upper bounds
             const dim3 g(max_blocks, nb), b(FLUX_THREADS);
