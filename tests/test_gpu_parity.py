@@ -799,8 +799,16 @@ def test_non_axisymmetric_models_match_oracle(eng, oracle, name):
         assert d["shape"] == {k: o["shape"][k] for k in d["shape"]} and not d["shape"]["phi_mirrored"]
         np.testing.assert_allclose(d["phi"], o["phi"], rtol=2e-6)
         assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)
+        # a spreading jet takes (phi, theta) pair rows (test_non_axisymmetric_spreading_jets_match_the_reference); only the
+        # combination with a reverse shock is refused, by the mirror and by the engine
         with pytest.raises(NotImplementedError):
-            gpu_grid(eng, _abi.make_params(spreading=True, axisymmetric=False), t, nu)
+            gpu_grid(eng, _abi.make_params(spreading=True, axisymmetric=False, duration=50.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)), t, nu)
+        with pytest.raises(NotImplementedError):
+            va.Model(va.TophatJet(0.1, 1e52, 300, spreading=True, duration=50.0), va.ISM(1.0), va.Observer(1e28, 1.0, 0.1),
+                     va.Radiation(0.1, 0.01, 2.3), rvs_rad=va.Radiation(0.1, 0.01, 2.3), axisymmetric=False)
+        m3 = va.Model(va.GaussianJet(0.1, 1e52, 300, spreading=True), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2), va.Radiation(0.1, 0.01, 2.3),
+                      axisymmetric=False)
+        assert np.all(np.isfinite(m3.flux_density_grid(t, nu).total))
 
 
 @pytest.mark.parametrize("kw", [dict(configs.C4_TRUTH, jet="GaussianJet"),
@@ -1516,3 +1524,52 @@ def test_mixed_flag_batches_on_the_device_pointer_entry_points(eng):
             assert np.array_equal(mixed[i], own[q], equal_nan=True), i
             assert np.array_equal(mixed_s[i], own_s[q], equal_nan=True), i
     assert np.array_equal(grid(prms), mixed, equal_nan=True)  # run to run
+
+
+NONAXI_SPREAD = np.load(os.path.join(_abi.ROOT, "tests", "golden", "reference_nonaxi_spread.npz"))
+
+
+@pytest.mark.parametrize("case", ["gauss_offaxis", "tophat_offaxis", "gauss_onaxis", "powerlaw_wind_ssc", "two_component_fine"])
+def test_non_axisymmetric_spreading_jets_match_the_reference(eng, case):
+    """Model(axisymmetric=False) with a spreading jet: one time lattice and one blast-wave solve per (phi, theta) node
+    (grid-refinement.h:619-625, observer.cpp:51-141) -- the ODE rows are (phi, theta) pairs here.  Checked against vectors from the
+    reference's own build (tests/golden/make_nonaxi_spread_fixture.py; the C restatement does not cover this combination): grid
+    components, the paired series and the band integral, and the grid shape."""
+    lib, h = eng
+    fx = NONAXI_SPREAD
+    meta = json.loads(str(fx["meta"]))[case]
+    kw = dict(meta["kw"])
+    if "resolutions" in kw:
+        kw["resolutions"] = tuple(kw["resolutions"])
+    prm = _abi.make_params(**kw)
+    t, nu = fx["t"], fx["nu"]
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    sync, ssc = np.empty((1, nu.size, t.size)), np.empty((1, nu.size, t.size))
+    _lib.check(lib.vag_flux_density_grid_components_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size,
+                                                          sync.ctypes.data_as(dp), ssc.ctypes.data_as(dp)))
+    sh = _lib.DetailsShape()
+    _lib.check(lib.vag_details(h, arr, float(t.min()), float(t.max()), C.byref(sh), None))
+    want_sh = meta["shape"]
+    assert (sh.n_phi, sh.n_theta, sh.n_t, sh.n_reps) == (want_sh["n_phi"], want_sh["n_theta"], want_sh["n_t"], want_sh["n_reps"])
+
+    def close(got, want, tol):
+        m = want > 1e-9 * want.max()
+        assert np.all(np.isfinite(got)) and m.any()
+        err = np.max(np.abs(got - want)[m] / want[m])
+        assert err < tol, err
+
+    close(sync[0], fx[f"{case}__sync"], 2e-5)
+    if kw.get("ssc"):
+        close(ssc[0], fx[f"{case}__ssc"], 2e-5)
+    else:
+        assert np.all(ssc == 0)
+    ts, nus = np.repeat(t, 3), np.tile(nu, t.size)
+    close(gpu_series(eng, prm, ts, nus)[0], fx[f"{case}__series"], 2e-5)
+    band = np.empty((1, t.size))
+    _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e14, 1e15, 8, band.ctypes.data_as(dp)))
+    close(band[0], fx[f"{case}__band"], 2e-5)
+    # a batch of such models next to each other, and next to an axisymmetric spreading one, equals the single calls bit for bit
+    other = _abi.make_params(**dict(kw, theta_obs=kw["theta_obs"] + 0.05))
+    both = gpu_grid(eng, [prm, other], t, nu)
+    assert np.array_equal(both[0], gpu_grid(eng, prm, t, nu)[0]) and np.array_equal(both[1], gpu_grid(eng, other, t, nu)[0])
+    np.testing.assert_allclose(both[0], sync[0] + ssc[0], rtol=1e-12)

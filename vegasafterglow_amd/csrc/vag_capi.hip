@@ -845,10 +845,10 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         c->spec_pending = true;
     }
     c->batch_flags = flags;
-    // a spreading jet under axisymmetric=False would need one time lattice and one ODE solve per (phi, theta) node
-    // (grid-refinement.h:619-625); not built -- see DESIGN.md "out of scope"
-    if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING))
-        return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet is not supported");
+    // A spreading jet under axisymmetric=False has one time lattice and one ODE solve per (phi, theta) node (grid-refinement.h:619-625):
+    // the ODE rows are (phi, theta) pairs (VagGridMeta::rep_phi_stride).  The coupled forward + reverse solver does not take them.
+    if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING) && (c->batch_flags & VAG_FLAG_RVS))
+        return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet AND a reverse shock is not supported");
     c->nb = nb;
     c->n_rows = rows;
     c->n_cells = cells;
@@ -904,7 +904,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         hipLaunchKernelGGL(kern, dim3((rows + rpw - 1) / rpw), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                            c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
                            c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>(), rpw,
-                           c->d_fail.as<int>());
+                           c->d_fail.as<int>(), c->d_phi.as<double>(), c->d_tminmax.as<double>());
     }
     HIPCHK(hipGetLastError());
     if (spreading) {  // per-cell viewing geometry from the evolved theta (both shocks ride the same contact discontinuity)
@@ -2888,7 +2888,7 @@ static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min
     shape->n_phi = M.n_phi;
     shape->n_theta = M.n_theta;
     shape->n_t = M.n_t;
-    shape->n_reps = M.n_reps;
+    shape->n_reps = M.rep_phi_stride ? M.n_theta : M.n_reps;  // ((phi, theta) pair rows: the arrays below are the phi[0] slice)
     shape->symmetry = M.symmetry;
     shape->phi_mirrored = M.phi_mirrored;
     if (!out) return VAG_OK;

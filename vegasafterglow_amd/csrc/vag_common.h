@@ -35,7 +35,8 @@ struct VagGridMeta {
     int32_t flags;        // VAG_FLAG_* of the model (the host checks they are uniform over a batch)
     int32_t t_num_base;   // lattice nodes a forward-only run would use (post-crossing density of a reverse-shock run)
     int32_t dyn_class;    // 0: vag_dynamics_fast_kernel applies (ISM / analytic Wind, no spreading, no injection, no reverse shock)
-    int32_t pad_;
+    int32_t rep_phi_stride;  // 0, or n_theta for Model(axisymmetric=False) with a spreading jet: the ODE rows are (phi, theta) PAIRS,
+                             // row of (theta j, phi i) = rep_of[j] + i * rep_phi_stride (one lattice and one solve per pair, grid-refinement.h:619-625)
     double t_early;  // engine frame, code units
     double t_start;  // min_t_start
     double t_end;    // 1.01 t_max / (1+z)

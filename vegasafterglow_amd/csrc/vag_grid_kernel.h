@@ -403,6 +403,19 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
     }
 }
 
+// First regular lattice node and early node of the row (theta, phi) of a structured (spreading) grid: TimeScanResult::t_start /
+// early_t (grid-refinement.h:462-469,497-498).  t_min = 0.99-scaled first requested time is applied here; cut = the row's start
+// cut-off (min(0.01 t_dec, 0.01 s) [, 0.01 T0]).  Used by the grid kernel for the phi = phi[0] slice it stores per theta row and by
+// the dynamics / geometry kernels for the (phi, theta) pair rows of Model(axisymmetric=False).
+VAG_DEV void row_time_start(double beta0, double cos_th, double sin_th, double cos_phi, double cos_tv, double sin_tv, double t_min, double z,
+                            double cut, double& t_start, double& t_early, double& ts_raw) {
+    const double cos_a = cos_th * cos_tv + sin_th * sin_tv * cos_phi;
+    const double ts = 0.99 * t_min * (1 - beta0) / (1 - cos_a * beta0) / (1 + z);
+    ts_raw = ts;
+    t_start = dmax(ts, cut);
+    t_early = 0.99 * dmin(ts, cut);
+}
+
 // The adaptive grid of model m = blockIdx.x, by one wavefront.
 // tminmax[0..1]: min / max of the requested observer times [s] (device memory).
 template <class SH>
@@ -436,7 +449,7 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
     M.flags = P.flags;
     M.t_num_base = 0;
     M.dyn_class = (med.generic || (P.flags & (VAG_FLAG_SPREADING | VAG_FLAG_MAGNETAR | VAG_FLAG_RVS))) ? 1 : 0;
-    M.pad_ = 0;
+    M.rep_phi_stride = 0;
 #ifdef VAG_GRID_STAMPS
     long long stamps_[10] = {};
 #endif
@@ -907,8 +920,6 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
         for (int j = lane; j < n_theta; j += WAVE) {
             const double th = sh.theta[j];
             const double b = gamma_to_beta(jet_Gamma0(jet, th));
-            const double cos_a = cos(th) * cos_tv + sin(th) * sin_tv * cos_phi0;
-            const double ts = 0.99 * t_min * (1 - b) / (1 - cos_a * b) / (1 + z);
             const double td = estimate_t_dec(jet, med, th);
             sh.tdec[j] = td;
             double cut = dmin(0.01 * td, 1e-2 * U_SEC);
@@ -918,17 +929,19 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             }
             // TimeScanResult::t_start / early_t (grid-refinement.h:462-469,497-498), used per row by structured (spreading)
             // grids; symmetric grids overwrite them below with the shared start / early node
-            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = dmax(ts, cut);
-            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = 0.99 * dmin(ts, cut);
+            double ts, t_start_row, t_early_row;
+            row_time_start(b, cos(th), sin(th), cos_phi0, cos_tv, sin_tv, t_min, z, cut, t_start_row, t_early_row, ts);
+            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = t_start_row;
+            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = t_early_row;
             min_raw = dmin(min_raw, ts);
-            min_guarded = dmin(min_guarded, dmax(ts, cut));
+            min_guarded = dmin(min_guarded, t_start_row);
             min_cut = dmin(min_cut, cut);
             if (P.flags & VAG_FLAG_NON_AXISYMMETRIC)  // phi_size = |phi|: the global bounds scan every phi node (:484-507)
                 for (int i = 1; i < n_phi; ++i) {
-                    const double cos_ai = cos(th) * cos_tv + sin(th) * sin_tv * cos(sh.phi[i]);
-                    const double tsi = 0.99 * t_min * (1 - b) / (1 - cos_ai * b) / (1 + z);
+                    double tsi, tsg, tse;
+                    row_time_start(b, cos(th), sin(th), cos(sh.phi[i]), cos_tv, sin_tv, t_min, z, cut, tsg, tse, tsi);
                     min_raw = dmin(min_raw, tsi);
-                    min_guarded = dmin(min_guarded, dmax(tsi, cut));
+                    min_guarded = dmin(min_guarded, tsg);
                 }
         }
         min_raw = wave_min(min_raw);
@@ -950,6 +963,12 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
         M.t_early = min_raw;
         M.t_start = min_guarded;
         M.t_end = t_end;
+    }
+    // Model(axisymmetric=False) with a spreading jet: Symmetry::structured with phi_size = |phi| -- every (phi, theta) node has its own
+    // lattice start (the viewing cosine enters it) and its own solve (grid-refinement.h:619-625, forward-shock.tpp:175-208)
+    if (spreading && (P.flags & VAG_FLAG_NON_AXISYMMETRIC) && n_phi > 1) {
+        M.rep_phi_stride = n_theta;
+        n_reps = n_phi * n_theta;
     }
     M.n_phi = n_phi;
     M.n_theta = n_theta;

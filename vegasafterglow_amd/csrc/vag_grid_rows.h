@@ -68,7 +68,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
     const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
     const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-    const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j];
+    const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j] + i * Mp->rep_phi_stride;
     const double cos_v = gth[VAG_MAX_THETA + j] * gph[i] * Mp->sin_obs + gth[j] * Mp->cos_obs;
     const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
     const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];

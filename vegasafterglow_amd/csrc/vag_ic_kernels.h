@@ -300,6 +300,18 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
     }
     for (int k = lane; k < nt; k += 64) {
         double dmin_k = INFINITY, dmax_k = -INFINITY;
+        if (M.rep_phi_stride) {  // (phi, theta) pair rows (non-axisymmetric spreading jet): every pair's own cell at node k
+            for (int j = 0; j < M.n_theta; ++j)
+                for (int i = 0; i < M.n_phi_eff; ++i) {
+                    const long long rr = rep_of[j] + (long long)i * M.rep_phi_stride;
+                    const double* par = cellpar + (cell_off[m] + rr * nt) * VAG_NPAR;
+                    const double* geo = cellgeo + (cell_off[m] + rr * nt) * 3;
+                    const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];
+                    const double lg = -log2(G - u * (geo[nt + k] * gph[i] * sin_obs + geo[k] * cos_obs));
+                    dmax_k = fmax(dmax_k, lg);
+                    dmin_k = fmin(dmin_k, lg);
+                }
+        } else
         for (int j = 0; j < M.n_theta; ++j) {
             const double* par = cellpar + (cell_off[m] + (long long)rep_of[j] * nt) * VAG_NPAR;
             const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];

@@ -36,7 +36,8 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
                     const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                     const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
                     long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave,
-                    int* __restrict__ fail /* [4]: rows per non-zero status, zeroed by vag_grid_kernel */) {
+                    int* __restrict__ fail /* [4]: rows per non-zero status, zeroed by vag_grid_kernel */,
+                    const double* __restrict__ g_phi /* (phi, theta) pair rows only */, const double* __restrict__ tminmax) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];  // log2_tab's table for the right-hand sides
     for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
     __syncthreads();
@@ -48,7 +49,9 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     const int r = row - lay.row_off[m];
-    const int j = g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+    // rows are representative theta rows, or -- Model(axisymmetric=False) with a spreading jet -- (phi i, theta j) pairs
+    const int i_phi = M.rep_phi_stride ? r / M.rep_phi_stride : 0;
+    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * VAG_MAX_THETA + r];
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
@@ -57,8 +60,13 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
     const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
-    const double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
-    const double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
+    double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    if (M.rep_phi_stride) {  // the pair's own lattice start: the viewing cosine of (phi_i, theta_j) (grid-refinement.h:462-469,619-625)
+        double ts_raw;
+        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * VAG_MAX_PHI + i_phi]),
+                       M.cos_obs, M.sin_obs, tminmax[0] * U_SEC, P.z, dmin(0.01 * t_dec, 1e-2 * U_SEC), t_start_row, t_early_row, ts_raw);
+    }
     const int nt = M.n_t;
     double* o_teng = shock + VS_TENG * n_cells + lay.cell_off[m] + (long long)r * nt;
     double* o_tcomv = shock + VS_TCOMV * n_cells + lay.cell_off[m] + (long long)r * nt;
@@ -360,10 +368,12 @@ vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, 
     if (M.status != 0) return;
     const int nt = M.n_t;
     const long long local = c - lay.cell_off[m];
-    const int j = (int)(local / nt), k = (int)(local % nt);  // structured symmetry: row index == theta index
+    const int row = (int)(local / nt), k = (int)(local % nt);  // structured symmetry: row index == theta index ...
+    const int j = M.rep_phi_stride ? row % M.rep_phi_stride : row;  // ... within the row's phi slice ((phi, theta) pair rows)
     const int last = M.n_theta - 1;
-    const double* teng = shock + VS_TENG * n_cells + lay.cell_off[m];
-    const double* theta = shock + VS_THETA * n_cells + lay.cell_off[m];
+    // the neighbours j - 1, j + 1 belong to the same phi slice (calc_solid_angle, observer.cpp:103-131): offset the slice's rows
+    const double* teng = shock + VS_TENG * n_cells + lay.cell_off[m] + (long long)(row - j) * nt;
+    const double* theta = shock + VS_THETA * n_cells + lay.cell_off[m] + (long long)(row - j) * nt;
     const double th = theta[(long long)j * nt + k];
     const double t_target = teng[(long long)j * nt + k];
     auto interp_theta = [&](int j_nb) {  // theta of row j_nb at engine time t_target (the reference walks a hint forward)
@@ -386,7 +396,7 @@ vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, 
     };
     const double th_lo = (j == 0) ? th : 0.5 * (th + interp_theta(j - 1));
     const double th_hi = (j == last) ? th : 0.5 * (th + interp_theta(j + 1));
-    double* dst = cellgeo + (lay.cell_off[m] + (long long)j * nt) * 3 + k;
+    double* dst = cellgeo + (lay.cell_off[m] + (long long)row * nt) * 3 + k;
     dst[0] = cos(th);
     dst[(long long)nt] = sin(th);
     dst[2LL * nt] = log2(fabs(cos(th_hi) - cos(th_lo)));
@@ -660,11 +670,12 @@ vag_eat_details_kernel(const vag_model_params* __restrict__ params, const VagGri
     const int k = (int)(q % K), j = (int)((q / K) % nth), i = (int)(q / ((long long)K * nth));
     const vag_model_params P = params[0];
     const double one_plus_z = 1 + P.z, cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
-    const double* par = cellpar + (long long)rep_of[j] * K * VAG_NPAR;
+    const int rep = rep_of[j] + i * M.rep_phi_stride;  // ((phi, theta) pair rows of a non-axisymmetric spreading jet)
+    const double* par = cellpar + (long long)rep * K * VAG_NPAR;
     const double G = par[VP_GAMMA * K + k], u = par[VP_U * K + k], r = par[VP_R * K + k], teng = par[VP_TENG * K + k];
     double cos_v, time;
     if (cellgeo) {
-        const double* geo = cellgeo + (long long)rep_of[j] * K * 3;
+        const double* geo = cellgeo + (long long)rep * K * 3;
         cos_v = geo[K + k] * geo_ph[i] * sin_obs + geo[k] * cos_obs;
         time = (teng + (1 - cos_v) * r / C_C) * one_plus_z;
     } else {
@@ -740,6 +751,8 @@ vag_flux_grid_kernel(FluxArgs a) {
     sc.init(Pp->p);
     const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int rep_stride = Mp->rep_phi_stride;  // (phi, theta) pair rows of a non-axisymmetric spreading jet: row = rep_of[j] + i * stride
+    auto rep_at = [&](int j, int i) { return sload_i32(rep_of + j) + i * rep_stride; };
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     // A lane owns the slots tid + r * THREADS (slot = l * nt + idx): always the same lane per slot, so the LDS accumulator needs no
     // atomics and the sum order is fixed.  The interpolation phase takes them U at a time; the first U -- all of them for
@@ -785,7 +798,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     auto stage_and_eat = [&](int j, int i, int buf) {  // (theta, phi) indices of the row: walked with a carry, never divided out
         const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         if constexpr (SPREAD) {
-            const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_of[j] * K_all) * 3 + k0;
+            const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_at(j, i) * K_all) * 3 + k0;
             eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
                            s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2, w_lo, w_hi);
         } else {
@@ -800,8 +813,8 @@ vag_flux_grid_kernel(FluxArgs a) {
         }
     };
     int staged_rep = -1;
-    auto stage_row = [&](int j) {  // block-uniform: (re)load the photon block when the representative row changes
-        const int rep = sload_i32(rep_of + j);
+    auto stage_row = [&](int j, int i) {  // block-uniform: (re)load the photon block when the representative row changes
+        const int rep = rep_at(j, i);
         if (rep != staged_rep) {
             const double* src = a.cellpar + (a.cell_off[m] + (long long)rep * K_all) * VAG_NPAR + k0;
 #pragma unroll 1
@@ -842,7 +855,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     }
     __syncthreads();
     int jn = p0 / n_phi_eff, in_ = p0 - jn * n_phi_eff;  // (theta, phi) of the NEXT row while the loop runs
-    stage_row(jn);
+    stage_row(jn, in_);
     __syncthreads();
     stage_and_eat(jn, in_, 0);
     __syncthreads();
@@ -1012,7 +1025,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #endif
         if (tid == THREADS - 1) s_win[buf * 2] = 0, s_win[buf * 2 + 1] = 0;  // read by everyone before the barrier; the row after next adds again
         const bool have_next = pair + 1 < p1;
-        const bool same_rep = have_next && sload_i32(rep_of + (have_next ? jn : 0)) == staged_rep;
+        const bool same_rep = have_next && rep_at(have_next ? jn : 0, have_next ? in_ : 0) == staged_rep;
         // EAT logs inside the interpolation block: the first node of every lane (k = tid); further nodes of long lattices and the
         // rows without an interpolation phase go through stage_and_eat
 #if defined(VAG_FLUX_NO_FUSE_EAT) || (defined(VAG_FLUX_ABLATE) && (VAG_FLUX_ABLATE & 8))
@@ -1157,7 +1170,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         __syncthreads();
         VAG_FLUX_MARK(5);
         if (have_next && !same_rep) {
-            stage_row(jn);
+            stage_row(jn, in_);
             __syncthreads();
             stage_and_eat(jn, in_, buf ^ 1);
             __syncthreads();
@@ -1373,7 +1386,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     auto load_row_geometry = [&](int base) {
         const int pr = min(base + tid, p1 - 1);
         const int j = pr / n_phi_eff, i = pr - j * n_phi_eff;
-        g_rep = rep_of[j];
+        g_rep = rep_of[j] + i * M.rep_phi_stride;  // ((phi, theta) pair rows of a non-axisymmetric spreading jet)
         if constexpr (SPREAD) {
             g_a = gph[i];
             g_c = gph[VAG_MAX_PHI + i];
