@@ -39,7 +39,7 @@ extern "C" {
 #define VAG_E_INVALID (-1)   /* bad argument: the reference raises ValueError (pybind/error_handling.h:31-69) */
 #define VAG_E_NO_DEVICE (-2) /* no HIP device / HIP runtime failure at context creation */
 #define VAG_E_HIP (-3)       /* a HIP call failed; message carries hipGetErrorString */
-#define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (today: a non-axisymmetric spreading jet WITH a reverse shock) */
+#define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (today: a likelihood batch whose models differ in their flags) */
 #define VAG_E_CAPACITY (-5)  /* grid larger than the engine's static limits */
 #define VAG_E_NUMERIC (-6)   /* an ODE row could not find a step size (the reference throws odeint's step_adjustment_error) */
 

@@ -20,6 +20,10 @@ CASES = {
     "gauss_onaxis": dict(jet="GaussianJet", theta_obs=0.0, spreading=True, axisymmetric=False),
     "powerlaw_wind_ssc": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.25, spreading=True, axisymmetric=False,
                               ssc=True, resolutions=(0.1, 0.3, 8.0)),
+    "tophat_rs": dict(jet="TophatJet", theta_obs=0.1, duration=100.0, spreading=True, axisymmetric=False,
+                      rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)),
+    "gauss_rs_ssc": dict(jet="GaussianJet", theta_obs=0.25, duration=30.0, spreading=True, axisymmetric=False, ssc=True,
+                         rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True)),
     "two_component_fine": dict(jet="TwoComponentJet", theta_c=0.05, theta_w=0.3, theta_obs=0.1, spreading=True, axisymmetric=False,
                                resolutions=(0.15, 0.3, 10.0)),
 }
@@ -34,14 +38,14 @@ def main():
     out, meta = {"t": T, "nu": NU}, {}
     for name, kw in CASES.items():
         prm = _abi.make_params(**kw)
-        sync, ssc = ref.flux_components(prm, T, NU)
-        out[f"{name}__sync"], out[f"{name}__ssc"] = sync, ssc
+        sync, ssc, rsync, rssc = ref.flux_components4(prm, T, NU)
+        out[f"{name}__sync"], out[f"{name}__ssc"], out[f"{name}__rvs_sync"], out[f"{name}__rvs_ssc"] = sync, ssc, rsync, rssc
         ts, nus = np.repeat(T, 3), np.tile(NU, T.size)
         out[f"{name}__series"] = ref.flux_density(prm, ts, nus)
         out[f"{name}__band"] = ref.flux(prm, T, 1e14, 1e15, 8)
         d = ref.details(prm, T.min(), T.max())
         meta[name] = dict(kw=json.loads(json.dumps(kw, default=list)), shape=d["shape"])
-        print(name, d["shape"], "peak", sync.max())
+        print(name, d["shape"], "peak", sync.max(), rsync.max())
     out["meta"] = json.dumps(meta)
     path = os.path.join(HERE, "reference_nonaxi_spread.npz")
     np.savez_compressed(path, **out)

@@ -112,8 +112,6 @@ def test_constructor_validation_matches_reference_error_types():
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, rtol=1.0)
     with pytest.raises(ValueError):
         va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, resolutions=(0.0, 0.15, 6))
-    with pytest.raises(NotImplementedError):  # the one combination left out fails loudly instead of silently degrading
-        va.Model(va.TophatJet(0.1, 1e52, 300, spreading=True, duration=10.0), va.ISM(1.0), obs, rad, rvs_rad=rad, axisymmetric=False)
     msp = va.Model(va.TophatJet(0.1, 1e52, 300, spreading=True), va.ISM(1.0), obs, rad, axisymmetric=False)
     assert msp.params.flags == 128 | 32  # (phi, theta) pair rows on the device
     m3d = va.Model(va.TophatJet(0.1, 1e52, 300), va.ISM(1.0), obs, rad, axisymmetric=False)

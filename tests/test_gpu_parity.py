@@ -799,13 +799,7 @@ def test_non_axisymmetric_models_match_oracle(eng, oracle, name):
         assert d["shape"] == {k: o["shape"][k] for k in d["shape"]} and not d["shape"]["phi_mirrored"]
         np.testing.assert_allclose(d["phi"], o["phi"], rtol=2e-6)
         assert_close(m.flux_density_grid(t, nu).total, want[0], rtol=5e-6)
-        # a spreading jet takes (phi, theta) pair rows (test_non_axisymmetric_spreading_jets_match_the_reference); only the
-        # combination with a reverse shock is refused, by the mirror and by the engine
-        with pytest.raises(NotImplementedError):
-            gpu_grid(eng, _abi.make_params(spreading=True, axisymmetric=False, duration=50.0, rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3)), t, nu)
-        with pytest.raises(NotImplementedError):
-            va.Model(va.TophatJet(0.1, 1e52, 300, spreading=True, duration=50.0), va.ISM(1.0), va.Observer(1e28, 1.0, 0.1),
-                     va.Radiation(0.1, 0.01, 2.3), rvs_rad=va.Radiation(0.1, 0.01, 2.3), axisymmetric=False)
+        # a spreading jet takes (phi, theta) pair rows, with or without a reverse shock (test_non_axisymmetric_spreading_jets_match_the_reference)
         m3 = va.Model(va.GaussianJet(0.1, 1e52, 300, spreading=True), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2), va.Radiation(0.1, 0.01, 2.3),
                       axisymmetric=False)
         assert np.all(np.isfinite(m3.flux_density_grid(t, nu).total))
@@ -1529,7 +1523,8 @@ def test_mixed_flag_batches_on_the_device_pointer_entry_points(eng):
 NONAXI_SPREAD = np.load(os.path.join(_abi.ROOT, "tests", "golden", "reference_nonaxi_spread.npz"))
 
 
-@pytest.mark.parametrize("case", ["gauss_offaxis", "tophat_offaxis", "gauss_onaxis", "powerlaw_wind_ssc", "two_component_fine"])
+@pytest.mark.parametrize("case", ["gauss_offaxis", "tophat_offaxis", "gauss_onaxis", "powerlaw_wind_ssc", "two_component_fine", "tophat_rs",
+                                  "gauss_rs_ssc"])
 def test_non_axisymmetric_spreading_jets_match_the_reference(eng, case):
     """Model(axisymmetric=False) with a spreading jet: one time lattice and one blast-wave solve per (phi, theta) node
     (grid-refinement.h:619-625, observer.cpp:51-141) -- the ODE rows are (phi, theta) pairs here.  Checked against vectors from the
@@ -1544,9 +1539,9 @@ def test_non_axisymmetric_spreading_jets_match_the_reference(eng, case):
     prm = _abi.make_params(**kw)
     t, nu = fx["t"], fx["nu"]
     arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
-    sync, ssc = np.empty((1, nu.size, t.size)), np.empty((1, nu.size, t.size))
-    _lib.check(lib.vag_flux_density_grid_components_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size,
-                                                          sync.ctypes.data_as(dp), ssc.ctypes.data_as(dp)))
+    comps = [np.empty((1, nu.size, t.size)) for _ in range(4)]
+    out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+    _lib.check(lib.vag_flux_density_grid_components4_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, out4))
     sh = _lib.DetailsShape()
     _lib.check(lib.vag_details(h, arr, float(t.min()), float(t.max()), C.byref(sh), None))
     want_sh = meta["shape"]
@@ -1558,16 +1553,23 @@ def test_non_axisymmetric_spreading_jets_match_the_reference(eng, case):
         err = np.max(np.abs(got - want)[m] / want[m])
         assert err < tol, err
 
-    close(sync[0], fx[f"{case}__sync"], 2e-5)
-    if kw.get("ssc"):
-        close(ssc[0], fx[f"{case}__ssc"], 2e-5)
-    else:
-        assert np.all(ssc == 0)
+    for got, name in zip(comps, ("sync", "ssc", "rvs_sync", "rvs_ssc")):
+        want = fx[f"{case}__{name}"]
+        if want.max() == 0:
+            assert np.all(got == 0), name
+        elif name.startswith("rvs") and kw["jet"] == "GaussianJet":
+            # the reverse shock of a structured jet: low-Gamma wing rows of the coupled solver amplify last-bit differences -- the
+            # reference's own two builds differ by 7e-3 there (DESIGN.md parity note 1) -- so the reference's golden contract applies
+            assert np.all(np.abs(got[0] - want) <= 2e-3 * np.abs(want) + 1e-2 * want.max()), name
+        else:  # measured: forward solver 2e-11 ... 1e-8, coupled solver 1e-9 (top hat) ... 6e-6 (Gaussian)
+            close(got[0], want, 2e-5 if kw.get("rvs") else 1e-6)
+    sync, ssc = comps[0] + comps[2], comps[1] + comps[3]
     ts, nus = np.repeat(t, 3), np.tile(nu, t.size)
-    close(gpu_series(eng, prm, ts, nus)[0], fx[f"{case}__series"], 2e-5)
+    tol_sum = 2e-4 if (kw.get("rvs") and kw["jet"] == "GaussianJet") else 2e-5  # (sums that hold the structured-jet reverse shock)
+    close(gpu_series(eng, prm, ts, nus)[0], fx[f"{case}__series"], tol_sum)
     band = np.empty((1, t.size))
     _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e14, 1e15, 8, band.ctypes.data_as(dp)))
-    close(band[0], fx[f"{case}__band"], 2e-5)
+    close(band[0], fx[f"{case}__band"], tol_sum)
     # a batch of such models next to each other, and next to an axisymmetric spreading one, equals the single calls bit for bit
     other = _abi.make_params(**dict(kw, theta_obs=kw["theta_obs"] + 0.05))
     both = gpu_grid(eng, [prm, other], t, nu)

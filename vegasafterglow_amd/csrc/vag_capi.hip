@@ -845,10 +845,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         c->spec_pending = true;
     }
     c->batch_flags = flags;
-    // A spreading jet under axisymmetric=False has one time lattice and one ODE solve per (phi, theta) node (grid-refinement.h:619-625):
-    // the ODE rows are (phi, theta) pairs (VagGridMeta::rep_phi_stride).  The coupled forward + reverse solver does not take them.
-    if ((c->batch_flags & VAG_FLAG_NON_AXISYMMETRIC) && (c->batch_flags & VAG_FLAG_SPREADING) && (c->batch_flags & VAG_FLAG_RVS))
-        return set_err(VAG_E_UNSUPPORTED, "axisymmetric=False with a spreading jet AND a reverse shock is not supported");
+    // (A spreading jet under axisymmetric=False has one time lattice and one ODE solve per (phi, theta) node, grid-refinement.h:619-625:
+    // the ODE rows are (phi, theta) pairs, VagGridMeta::rep_phi_stride.)
     c->nb = nb;
     c->n_rows = rows;
     c->n_cells = cells;
@@ -888,7 +886,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         hipLaunchKernelGGL(vag_dynamics_pair_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
-                           c->d_inj.as<int>(), c->d_row_status.as<int>(), c->d_fail.as<int>());
+                           c->d_inj.as<int>(), c->d_row_status.as<int>(), c->d_fail.as<int>(), c->d_phi.as<double>(),
+                           c->d_tminmax.as<double>());
     } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
         const int rpw = dyn_rows_per_wave(rows);

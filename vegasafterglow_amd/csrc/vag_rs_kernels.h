@@ -31,14 +31,17 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
                          const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock_fwd,
                          double* __restrict__ shock_rvs, long long n_cells, int* __restrict__ inj_idx,
-                         int* __restrict__ row_status, int* __restrict__ fail) {
+                         int* __restrict__ row_status, int* __restrict__ fail,
+                         const double* __restrict__ g_phi /* (phi, theta) pair rows only */, const double* __restrict__ tminmax) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows || row >= lay.row_off[nb]) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     const int r = row - lay.row_off[m];
-    const int j = g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+    // rows are representative theta rows, or -- Model(axisymmetric=False) with a spreading jet -- (phi i, theta j) pairs
+    const int i_phi = M.rep_phi_stride ? r / M.rep_phi_stride : 0;
+    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * VAG_MAX_THETA + r];
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
@@ -46,8 +49,14 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     medium_init(eq.med, P);
     const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
     const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
-    const double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
-    const double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
+    double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    if (M.rep_phi_stride) {  // the pair's own lattice start (grid-refinement.h:462-469,619-625; the reverse-shock cut of :489-491)
+        double ts_raw;
+        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * VAG_MAX_PHI + i_phi]),
+                       M.cos_obs, M.sin_obs, tminmax[0] * U_SEC, P.z, dmin(dmin(0.01 * t_dec, 1e-2 * U_SEC), 0.01 * P.duration * U_SEC),
+                       t_start_row, t_early_row, ts_raw);
+    }
     const int nt = M.n_t;
     const long long c0 = lay.cell_off[m] + (long long)r * nt;
     double* F = shock_fwd + c0;

@@ -307,9 +307,6 @@ class Model:
             raise TypeError("rvs_rad must be a Radiation")
         if fwd_rad.kn and not fwd_rad.ssc:
             pass  # Klein-Nishina corrections only act through the IC cooling enabled by ssc (pymodel.h:567-577)
-        if not axisymmetric and getattr(jet, "spreading", False) and rvs_rad is not None:
-            raise NotImplementedError("axisymmetric=False with a spreading jet AND a reverse shock: the coupled solver does not take "
-                                      "(phi, theta) pair rows")
         _req(math.isfinite(rtol) and 0 < rtol < 1, f"rtol must be in (0, 1), got {rtol}")
         # forward-only runs default to the coarser calibrated grid, reverse-shock runs to the denser one (pymodel.h:630-637)
         default_res = (0.06, 0.2, 10.0) if rvs_rad is not None else (0.06, 0.15, 6.0)
