@@ -112,12 +112,23 @@ VAG_DEV double sound_speed(double G) {  // compute_sound_speed, shock-physics.h:
 //      step attempt of vag_dynamics_pair_kernel took 50 k cycles with the library forms, two thirds of them these sequences. ----
 VAG_DEV double rcp1(double x) {  // 1/x, x finite, non-zero, normal
     const double r = __builtin_amdgcn_rcp(x);
+#ifdef VAG_PAIR_NEWTON2  // experiment: a second Newton step (<= 1 ulp) -- profiles/r03_rs_structured_diagnostic.txt
+    const double r1 = fma(r, fma(-x, r, 1.0), r);
+    return fma(r1, fma(-x, r1, 1.0), r1);
+#else
     return fma(r, fma(-x, r, 1.0), r);
+#endif
 }
 VAG_DEV double sqrt1(double x) {  // sqrt(x) with sqrt(0) = 0 kept; x >= 0
     const double y = __builtin_amdgcn_rsq(x);
     const double s0 = x * y;
+#ifdef VAG_PAIR_NEWTON2
+    const double h = 0.5 * y;
+    const double s1 = fma(fma(-s0, s0, x), h, s0);
+    const double s = fma(fma(-s1, s1, x), h, s1);
+#else
     const double s = fma(fma(-s0, s0, x), 0.5 * y, s0);
+#endif
     return x > 0 ? s : 0.0;
 }
 VAG_DEV double rel_Gamma_f(double g1, double g2) {
