@@ -203,21 +203,29 @@ VAG_DEV double ic_thin_correction(const IcQ& q, double lg2_nu, Tab sp) {
     return q.l1pyc - (0.5 * (z + a) + g);
 }
 
-// IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92) given the thin-branch correction
-template <class P1, class Tab>
+// IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92) given the thin-branch correction.
+// STRAIGHT: the +-20 softplus shortcuts as selects (sp_fast_sel) -- same values; for a caller whose table sits in global memory, so
+// that the three independent table reads of an evaluation are in flight together instead of one per branch.
+template <bool STRAIGHT = false, class P1, class Tab>
 VAG_DEV double log2_I_nu_ic_core(const P1 c, int st, bool corrected, const IcQ& q, const SpecConst& sc, double lg2_nu, Tab sp) {
+    auto sp_ = [&](double z) { return STRAIGHT ? sp_fast_sel(z, sp) : sp_fast(z, sp); };
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
-    double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_fast(c[VP_DLO * st] * (lg2_nu - l_lo), sp) * c[VP_INV_SLO * st] -
-                  sp_fast(c[VP_DHI * st] * (lg2_nu - l_hi), sp) * c[VP_INV_SHI * st];
+    double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_(c[VP_DLO * st] * (lg2_nu - l_lo)) * c[VP_INV_SLO * st] -
+                  sp_(c[VP_DHI * st] * (lg2_nu - l_hi)) * c[VP_INV_SHI * st];
     if (corrected) thin += ic_thin_correction(q, lg2_nu, sp);
     const double lx = lg2_nu - c[VP_LG2_NUM * st];
     double thick = 2.5 * lx;
-    if (!(lx > sc.log2_x_far)) {
+    if (STRAIGHT) {
+        const bool far = lx > sc.log2_x_far;
+        const double s = -sc.smooth_thick * exp2_fast(2. / 3 * (far ? 0.0 : lx));
+        const double add = sp_(-0.5 * lx + s);
+        thick += far ? 0.0 : add;
+    } else if (!(lx > sc.log2_x_far)) {
         const double s = -sc.smooth_thick * exp2_fast(2. / 3 * lx);
-        thick += sp_fast(-0.5 * lx + s, sp);
+        thick += sp_(-0.5 * lx + s);
     }
     const double lb = thick + c[VP_TNORM * st];
-    const double smooth_one = thin - sp_fast(c[VP_SAB * st] * (thin - lb), sp) * c[VP_INV_SAB * st];
+    const double smooth_one = thin - sp_(c[VP_SAB * st] * (thin - lb)) * c[VP_INV_SAB * st];
     const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
@@ -231,6 +239,13 @@ VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const Spec
     const bool corrected = q.applies(lg2_nu);
     if (corrected) q.rest(qv, qst);
     return log2_I_nu_ic_core(c, st, corrected, q, sc, lg2_nu, sp);
+}
+template <class P1, class P2, class Tab>
+VAG_DEV double log2_I_nu_ic_straight(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double lg2_nu, Tab sp) {
+    IcQ q;
+    q.head(qv, qst);
+    q.rest(qv, qst);
+    return log2_I_nu_ic_core<true>(c, st, q.applies(lg2_nu), q, sc, lg2_nu, sp);
 }
 
 // two frequencies on one cell (a work item of the grid flux kernel): the constants are loaded once for both
@@ -361,7 +376,7 @@ struct IcShared {
         };
         struct {  // accumulation loop
             double D[IC_MAX_DIAG], E[IC_MAX_DIAG];  // diagonal histograms of dNe ex and dNe term (d = seed bin + 2 electron index)
-            double corr[IC_MAX_LAT], lg2corr[IC_MAX_LAT];
+            double corr[IC_MAX_LAT], dlc[IC_MAX_LAT];  // KN correction per lattice node, forward difference of its log2
         };
     };
 };
@@ -498,7 +513,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                      const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* ictab) {
     const long long c = blockIdx.x;
 #ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
-    long long c_t[8];
+    long long c_t[10];
     int c_n = 0;
     c_t[c_n++] = __builtin_readcyclecounter();
 #define VAG_IC_MARK() do { __builtin_amdgcn_s_waitcnt(0); c_t[c_n++] = __builtin_readcyclecounter(); } while (0)
@@ -528,25 +543,56 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double column_den = det[VD_COLUMN_DEN * n_cells + c];
     const double Y_c = det[VD_YC * n_cells + c];
     const int regime = (int)det[VD_REGIME * n_cells + c];
+    // Every constant of the cell the two sampling loops below use, requested HERE by ONE vector load (lane l fetches constant l)
+    // and handed round through LDS: left to the evaluators they are fetched where they are used -- behind lane-divergent
+    // branches, i.e. as vector loads, one memory round trip after the other inside the loops (a dozen per pass; the loops then
+    // took 40 % of this kernel's time); as scalar loads up front they overflow the scalar registers.
+    constexpr int CST_Q = VAG_NPAR, CST_Y = VAG_NPAR + VAG_NQ, CST_N = VAG_NPAR + VAG_NQ + VAG_NICY;
+    static_assert(CST_N <= 64, "one constant per lane");
+    double my_cst;
+    {
+        const long long row0 = lay.cell_off[m] + (long long)r * nt;
+        const double* src = cellpar + row0 * VAG_NPAR + k;  // lanes past the list re-read the first word
+        if (lane < CST_Q)
+            src += (long long)lane * nt;
+        else if (lane < CST_Y)
+            src = cellq + row0 * VAG_NQ + k + (long long)(lane - CST_Q) * nt;
+        else if (lane < CST_N)
+            src = icy + c + (long long)(lane - CST_Y) * n_cells;
+        my_cst = *src;
+    }
     __syncthreads();
     for (int j = lane; j < nu_size; j += 64) {
         sh.lg2nu[j] = lg2_nu0 + step * (double)j;
         sh.nu[j] = exp2_sat(sh.lg2nu[j]);
     }
     for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_sat(lg2_g0 + step * (double)i);
+    sh.ex[lane] = my_cst;  // `ex` is not written before the Thomson CDF
     __syncthreads();
+    double cp[VAG_NPAR];
+    for (int q : {VP_LG2_LO, VP_LG2_HI, VP_DLO, VP_INV_SLO, VP_DHI, VP_INV_SHI, VP_LG2_NUM, VP_TNORM, VP_SAB, VP_INV_SAB, VP_LG2_I,
+                  VP_LG2_NUMAX, VP_INV_NUMAX})
+        cp[q] = sh.ex[q];
+    IcQ icq;
+    icq.head(sh.ex + CST_Q, 1);
+    icq.rest(sh.ex + CST_Q, 1);
+    const bool y_any = sh.ex[CST_Y + VY_NSEG] != 0;
+    const double yS0 = sh.ex[CST_Y + VY_S0], yC0 = sh.ex[CST_Y + VY_C0];
+    const double yL1 = sh.ex[CST_Y + VY_L1], yS1 = sh.ex[CST_Y + VY_S1], yC1 = sh.ex[CST_Y + VY_C1];
+    const double yL2 = sh.ex[CST_Y + VY_L2], yS2 = sh.ex[CST_Y + VY_S2], yC2 = sh.ex[CST_Y + VY_C2];
     VAG_IC_MARK();  // 1: prologue
 #ifdef VAG_IC_ABLATE
     if (VAG_IC_ABLATE >= 4) { tab[0] = 0; return; }  // prologue only: loads, lattice parameters, lattice nodes
 #endif
     // sample_distributions, inverse-compton.h:371-399
-    const double* par = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
-    const double* qv = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
     SpecConst sc;
     sc.init(P.p);
     // SynElectrons::compute_column_den (synchrotron.cpp:261-309) / gamma^2 * dgamma at the lattice energies: log2(gamma) is the
     // node's own exponent, the cell-uniform factors come from the plan, the two exponentials of a branch are one exp2
     const bool slow = regime == 1 || regime == 2 || regime == 5, fast = regime == 3 || regime == 4 || regime == 6;
+#ifdef VAG_IC_STAMPS
+    VAG_IC_MARK();  // 2a: spectrum constants
+#endif
     for (int i = lane; i < g_size; i += 64) {
         constexpr double LOG2E_ = 1.4426950408889634;
         const double gi = sh.gam[i], rg = rcp_fast(gi), lg = lg2_g0 + step * (double)i;
@@ -559,11 +605,20 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             spec = exp2_sat((-gi * inv_gM - gamma_c * rg) * LOG2E_) * gamma_c * rg * rg *
                    rcp_fast(1.0 + exp2_sat(dmin((P.p - 1) * (lg - lg2_gm), 1000.0)));
         double den = column_den * spec;
-        if (gi > gamma_c) den = den * (1 + Y_c) / (1 + exp2_sat(icy_lg2_Y(icy, n_cells, c, lg)));
+        if (gi > gamma_c) {  // icy_lg2_Y on the constants at hand: the last segment whose lower edge lg reaches (unused ones: +inf)
+            double z = fma(yS0, lg, yC0);
+            z = lg >= yL1 ? fma(yS1, lg, yC1) : z;
+            z = lg >= yL2 ? fma(yS2, lg, yC2) : z;
+            den = den * (1 + Y_c) * rcp_fast(1 + (y_any ? exp2_sat(z) : 0.0));
+        }
         sh.dNe[i] = den * rg * rg * dgi;
     }
+#ifdef VAG_IC_STAMPS
+    VAG_IC_MARK();  // 2b: electron distribution
+#endif
     for (int j = lane; j < nu_size; j += 64) {  // f = I_seed / nu^2 and its logarithm, from the logarithm
-        const double lf = log2_I_nu_ic(par, nt, qv, nt, sc, sh.lg2nu[j], sp_table) - 2 * sh.lg2nu[j];
+        const double x = sh.lg2nu[j];
+        const double lf = log2_I_nu_ic_core<true>(cp, 1, icq.applies(x), icq, sc, x, sp_table) - 2 * x;
         const double f = exp2_sat(lf);
         sh.fv_th[j] = f;
         sh.lg2fv[j] = f > 0 ? lf : -INFINITY;
@@ -611,37 +666,69 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
     const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
     const int n_lo_i = (int)n_lo;
-    auto energies = [&](auto nb_tag) {
+    auto energies = [&](auto nb_tag, auto kn_tag) {
         constexpr int NB = decltype(nb_tag)::value;
+        constexpr bool WITH_KN = decltype(kn_tag)::value;  // Thomson cells: every bin keeps its two constants, no lattice
+        // Per bin [j, j+1] of the lane, everything of ex / term that does not depend on the electron energy is folded into
+        // constants here, so that an energy costs the lane one lattice read and ~10 FP64 instructions:
+        //   above the split     f nu = (f_th nu) corr,  s1 = 1 + (lf_N - lf) / lg2r = s_th + (lg2corr_N - lg2corr) / lg2r
+        //                       ex = term = (A_N corr_N - A corr) / s1           (|s1| > 1e-3;  A corr lg2r ln 2 otherwise)
+        //   seeds not both > 0  ex = term = the trapezoid (f + f_N) dnu / 2 = A_N corr_N + A corr with A := f_th dnu / 2 instead
+        //   bin below the split ex = the Thomson integral, term = trap ratio_th: constants -- except the bin right below it, whose
+        //                       upper edge carries the corrected f: term = K0 + K1 corr_N
         int jn[NB];
-        bool bin[NB];  // bins [j, j+1]
-        double nu_a[NB], fth[NB], lth[NB], dnu[NB], lgr[NB], ilr[NB], rth[NB], exth[NB], nuN[NB];
-        auto ld = [&](const double* arr, int jj) { return jj <= nu_last ? arr[jj] : 0.0; };
+        bool bin[NB], pos[NB];
+        double A[NB], AN[NB], s_th[NB], ilr[NB], Lr[NB], exth[NB], termth[NB], K0[NB], K1[NB];
+        {
+            double nu_a[NB], fth[NB], lth[NB];
+            auto ld = [&](const double* arr, int jj) { return jj <= nu_last ? arr[jj] : 0.0; };
 #pragma unroll
-        for (int a = 0; a < NB; ++a) {
-            jn[a] = NB * (63 - lane) + a;
-            bin[a] = jn[a] < nu_last;
-            nu_a[a] = ld(sh.nu, jn[a]);
-            fth[a] = ld(sh.fv_th, jn[a]);
-            lth[a] = ld(sh.lg2fv, jn[a]);
-            dnu[a] = bin[a] ? 0.5 * sh.dnu[jn[a]] : 0.0;  // half the bin width: the trapezoid's factor
-            lgr[a] = bin[a] ? sh.lg2r[jn[a]] : 0.0;
-            ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
-            rth[a] = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
-            exth[a] = bin[a] ? sh.ex[jn[a]] : 0.0;  // Thomson bin integral (build_cdf_thomson)
+            for (int a = 0; a < NB; ++a) {
+                jn[a] = NB * (63 - lane) + a;
+                bin[a] = jn[a] < nu_last;
+                nu_a[a] = ld(sh.nu, jn[a]);
+                fth[a] = ld(sh.fv_th, jn[a]);
+                lth[a] = ld(sh.lg2fv, jn[a]);
+            }
+            // value at node j_a + 1: the lane's own next node, or the first node of lane - 1
+            auto next_of = [&](const double (&v)[NB], int a) { return a + 1 < NB ? v[a + 1 < NB ? a + 1 : a] : from_lane_below(v[0]); };
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const double nuN = next_of(nu_a, a), fthN = next_of(fth, a), lthN = next_of(lth, a);
+                const double hd = bin[a] ? 0.5 * sh.dnu[jn[a]] : 0.0;  // half the bin width: the trapezoid's factor
+                const double lgr = bin[a] ? sh.lg2r[jn[a]] : 0.0;
+                const double rth = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
+                ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
+                exth[a] = bin[a] ? sh.ex[jn[a]] : 0.0;  // Thomson bin integral (build_cdf_thomson)
+                pos[a] = fth[a] > 0 && fthN > 0;
+                A[a] = pos[a] ? fth[a] * nu_a[a] : fth[a] * hd;
+                AN[a] = pos[a] ? fthN * nuN : fthN * hd;
+                s_th[a] = pos[a] ? 1 + (lthN - lth[a]) * ilr[a] : 1.0;
+                Lr[a] = lgr * 0.6931471805599453;
+                K0[a] = fth[a] * hd * rth;
+                K1[a] = fthN * hd * rth;
+                termth[a] = (fth[a] + fthN) * hd * rth;
+            }
         }
-        // value at node j_a + 1: the lane's own next node, or the first node of lane - 1
-        auto next_of = [&](const double (&v)[NB], int a) { return a + 1 < NB ? v[a + 1 < NB ? a + 1 : a] : from_lane_below(v[0]); };
-#pragma unroll
-        for (int a = 0; a < NB; ++a) nuN[a] = next_of(nu_a, a);
-        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / corr / lg2corr
+        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / corr / dlc
         for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
         if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by
                    // two quanta, so only the even nodes of the reference's lattice are ever read: node q here is its node 2 q
             const int n_lat = (g_size - 1) + (nu_size - 1) + 1;
             const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
             for (int q = lane; q < n_lat; q += 64)
-                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, sh.corr[q], sh.lg2corr[q]);
+                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, sh.corr[q], sh.dlc[q]);
+            __syncthreads();
+            double d3[3];  // log2 corr -> its forward difference, in place (IC_MAX_LAT <= 192: three nodes per lane)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int q = lane + 64 * s3;
+                d3[s3] = q + 1 < n_lat ? sh.dlc[q + 1] - sh.dlc[q] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+                if (lane + 64 * s3 < n_lat) sh.dlc[lane + 64 * s3] = d3[s3];
         }
         __syncthreads();
         int my_split = nu_size;  // Thomson: no bin lies at or above the split
@@ -663,41 +750,75 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #ifndef VAG_IC_UNROLL
 #define VAG_IC_UNROLL 2
 #endif
-#pragma unroll VAG_IC_UNROLL
-        for (int i = 0; i < g_run; ++i) {
-            const double dNe = read_lane(my_dNe, i);
-            if (!(dNe > 0)) continue;  // uniform
-            const int i_gamma = 2 * i;
-            const int j_split = __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i));
-            double f[NB], lf[NB];
+        // The lattice words of every lane, used or not, are read one energy ahead (an LDS instruction costs the same under any
+        // mask; read inside the branches they would go out one by one, each with its own wait).  Garbage where the cell has no
+        // lattice or the index runs past it (still inside this wavefront's LDS): those lanes never use them.  Two energies per
+        // trip, so that the words read ahead alternate between two register sets instead of being moved.
+        struct Lat {
+            double c[NB], cN[NB], dl[NB];
+        };
+        auto read_lat = [&](Lat& w, int i) {
+            if constexpr (WITH_KN) {
 #pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                const bool kn = jn[a] >= j_split && jn[a] <= nu_last;
-                f[a] = kn ? fth[a] * sh.corr[i + jn[a]] : fth[a];
-                lf[a] = kn ? lth[a] + sh.lg2corr[i + jn[a]] : 0.0;
+                for (int a = 0; a < NB; ++a) w.c[a] = sh.corr[i + jn[a]], w.cN[a] = sh.corr[i + 1 + jn[a]], w.dl[a] = sh.dlc[i + jn[a]];
             }
+        };
+        // `asm volatile("")` inside a branch: keep it a branch under the exec mask (scalar instructions) -- if-converted, the
+        // three-way choice costs ten v_cndmask per energy on the pipe this loop is bound by
+        auto energy = [&](int i, const Lat& w) {
+            const double dNe = read_lane(my_dNe, i);
+            if (!(dNe > 0)) return;  // uniform
+            const int i_gamma = 2 * i;
+            const int j_split = WITH_KN ? __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i)) : 0;
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
-                const double fN = next_of(f, a), lfN = next_of(lf, a);
-                // bins below the split keep the Thomson integral and ratio (but see the corrected f at their upper edge j_split)
-                const double trap = (f[a] + fN) * dnu[a];
-                double ex = exth[a], term = trap * rth[a];
-                if (bin[a] && jn[a] >= j_split) {
-                    ex = power_law_bin_integral(f[a], fN, nu_a[a], nuN[a], lf[a], lfN, lgr[a], ilr[a], trap);
-                    term = ex;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                double ve = exth[a], vt = termth[a];
+                if (WITH_KN && bin[a] && jn[a] >= j_split - 1) {  // at or right below the split: the bin sees the lattice
+                    asm volatile("");
+                    if (jn[a] >= j_split) {
+                        asm volatile("");
+                        const double u = A[a] * w.c[a];
+                        if (pos[a]) {
+                            asm volatile("");
+                            const double s1 = fma(w.dl[a], ilr[a], s_th[a]);
+                            ve = u * Lr[a];
+                            if (fabs(s1) > 1e-3) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
+                                asm volatile("");
+                                ve = fma(AN[a], w.cN[a], -u) * rcp_ode(s1);
+                            }
+                        } else
+                            ve = fma(AN[a], w.cN[a], u);
+                        vt = ve;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                    } else
+                        vt = fma(K1[a], w.cN[a], K0[a]);
                 }
                 if (bin[a]) {
                     // relaxed workgroup atomics on LDS words: ds_add_f64 without a return value, free to overlap the next energy's reads
-                    __hip_atomic_fetch_add(&sh.D[i_gamma + jn[a]], dNe * ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&sh.E[i_gamma + jn[a]], dNe * term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&sh.D[i_gamma + jn[a]], dNe * ve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&sh.E[i_gamma + jn[a]], dNe * vt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+        };
+        Lat w0, w1;
+        read_lat(w0, 0);
+        for (int i = 0; i < g_run; i += 2) {
+            read_lat(w1, i + 1);
+            energy(i, w0);
+            read_lat(w0, i + 2);
+            if (i + 1 < g_run) energy(i + 1, w1);
         }
     };
-    if (nu_size <= VAG_IC_ONE_NODE_MAX)
-        energies(std::integral_constant<int, 1>{});
-    else
-        energies(std::integral_constant<int, 2>{});
+    if (nu_size <= VAG_IC_ONE_NODE_MAX) {
+        if (KN)
+            energies(std::integral_constant<int, 1>{}, std::true_type{});
+        else
+            energies(std::integral_constant<int, 1>{}, std::false_type{});
+    } else {
+        if (KN)
+            energies(std::integral_constant<int, 2>{}, std::true_type{});
+        else
+            energies(std::integral_constant<int, 2>{}, std::false_type{});
+    }
     __syncthreads();
     suffix_scan4(sh.D, lane);  // D[d] <- sum_{d' >= d} D[d']
     __syncthreads();
@@ -714,8 +835,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     VAG_IC_MARK();  // 5: energy loop
 #ifdef VAG_IC_STAMPS
     if (lane == 0 && (c % 70001) == 0)
-        printf("ic cell %lld: g %d nu %d out %d  cycles: prologue %lld  sampling %lld  thomson cdf %lld  kn lattice %lld  energies %lld\n", c, g_size,
-               nu_size, n_ic, c_t[1] - c_t[0], c_t[2] - c_t[1], c_t[3] - c_t[2], c_t[4] - c_t[3], c_t[5] - c_t[4]);
+        printf("ic cell %lld: g %d nu %d out %d  cycles: prologue %lld  constants %lld  electrons %lld  seeds %lld  thomson cdf %lld  kn lattice %lld  energies %lld\n",
+               c, g_size, nu_size, n_ic, c_t[1] - c_t[0], c_t[2] - c_t[1], c_t[3] - c_t[2], c_t[4] - c_t[3], c_t[5] - c_t[4], c_t[6] - c_t[5],
+               c_t[7] - c_t[6]);
 #endif
     // log2 table on the output lattice, inverse-compton.h:595-606
     const double lg2_scale = log2(0.25 * C_SIGMAT);
