@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(256) kern(double* out, int iters, double a, do
     lds[threadIdx.x] = x0;
     __syncthreads();
     unsigned la = (threadIdx.x * 16) & 8191;
+    const unsigned la8 = threadIdx.x * 8, la_dup = (threadIdx.x >> 3) * 8;  // contiguous words; eight lanes per word
     for (int it = 0; it < iters; ++it) {
 #define OP8(INS) \
     { REP8(asm volatile(INS : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), \
@@ -85,6 +86,22 @@ __global__ void __launch_bounds__(256) kern(double* out, int iters, double a, do
             REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:16\n ds_read_b64 %3, %4 offset:24\n s_waitcnt lgkmcnt(0)"
                               : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(la) : "memory");)
         }
+        if constexpr (KIND == 29) {  // ds_add_f64 without return, all lanes on different words
+            REP8(asm volatile("ds_add_f64 %0, %1\n ds_add_f64 %0, %2 offset:2048\n ds_add_f64 %0, %3 offset:4096\n ds_add_f64 %0, %4 offset:6144\n s_waitcnt lgkmcnt(0)"
+                              : : "v"(la8), "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "memory");)
+        }
+        if constexpr (KIND == 30) {  // ds_add_f64, half of the lanes masked off
+            REP8(asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0x00000000ffffffff\n ds_add_f64 %0, %1\n ds_add_f64 %0, %2 offset:2048\n ds_add_f64 %0, %3 offset:4096\n ds_add_f64 %0, %4 offset:6144\n s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, s[20:21]"
+                              : : "v"(la8), "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "memory", "s20", "s21");)
+        }
+        if constexpr (KIND == 31) {  // ds_read2_b64 of two neighbouring words per lane (lanes overlap their neighbours' words)
+            REP8(asm volatile("ds_read2_b64 %0, %4 offset1:1\n ds_read2_b64 %1, %4 offset0:2 offset1:3\n ds_read2_b64 %2, %4 offset0:4 offset1:5\n ds_read2_b64 %3, %4 offset0:6 offset1:7\n s_waitcnt lgkmcnt(0)"
+                              : "=v"(*(double2*)&x0), "=v"(*(double2*)&x2), "=v"(*(double2*)&x4), "=v"(*(double2*)&x6) : "v"(la8) : "memory");)
+        }
+        if constexpr (KIND == 32) {  // ds_add_f64 with eight lanes per word (same-address serialisation)
+            REP8(asm volatile("ds_add_f64 %0, %1\n ds_add_f64 %0, %2 offset:2048\n ds_add_f64 %0, %3 offset:4096\n ds_add_f64 %0, %4 offset:6144\n s_waitcnt lgkmcnt(0)"
+                              : : "v"(la_dup), "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "memory");)
+        }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
 }
@@ -147,5 +164,9 @@ int main() {
     run<28>("v_fma_f64 sgpr addend", 64);
     run<19>("ds_read_b128", 32);
     run<20>("ds_read_b64", 32);
+    run<31>("ds_read2_b64 (q, q+1)", 32);
+    run<29>("ds_add_f64", 32);
+    run<30>("ds_add_f64 half exec", 32);
+    run<32>("ds_add_f64 8 lanes/word", 32);
     return 0;
 }

@@ -376,7 +376,9 @@ struct IcShared {
         };
         struct {  // accumulation loop
             double D[IC_MAX_DIAG], E[IC_MAX_DIAG];  // diagonal histograms of dNe ex and dNe term (d = seed bin + 2 electron index)
-            double corr[IC_MAX_LAT], dlc[IC_MAX_LAT];  // KN correction per lattice node, forward difference of its log2
+            vdouble2 lat[IC_MAX_LAT];  // per lattice node: KN correction, its log2
+            double dNe_i[IC_MAX_G];    // per electron energy, for the lanes of the tail pass (each at its own energy)
+            int split_i[IC_MAX_G];
         };
     };
 };
@@ -657,80 +659,73 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     // So the loop only forms ex and term of the lane's bins and adds them to two diagonal histograms in LDS (ds_add_f64, the
     // lanes of one instruction hit different words); ONE suffix sum over D per cell replaces a 64-lane scan, the continuity
     // shift below the KN split, the exchange row and the three-slot gather per electron energy (below the split the shifted
-    // Thomson CDF is the same as ex_m = the Thomson bin integral).  Every lane keeps NB seed nodes in REVERSED lane order
-    // (j_a = NB (63 - lane) + a): the value at node j + 1 is the lane's own next node or the first node of lane - 1 (one
-    // wave_shr DPP move).  NB = 1 when the seed lattice fits one node per lane (the usual cell: ~50 nodes), else 2.
+    // Thomson CDF is the same as ex_m = the Thomson bin integral).  Lane l owns bin l through all energies; a seed lattice
+    // with more than 64 bins (one cell in five) hands its bins 64.. to a second, PACKED pass: W = 8 ... 64 lanes per tail bin
+    // set, 64 / W energy chunks side by side, so that eight tail bins cost g / 8 trips instead of doubling every trip.
     double I_acc[3] = {0, 0, 0};
     const double lg2nu_first = sh.lg2nu[0];
     // lane L keeps what electron energy i = L needs (read back with v_readlane, no LDS): gamma, dNe and the KN split index
     const double my_dNe = lane < g_size ? sh.dNe[lane] : 0.0;
     const double my_gam = lane < g_size ? sh.gam[lane] : 1.0;
     const int n_lo_i = (int)n_lo;
-    auto energies = [&](auto nb_tag, auto kn_tag) {
-        constexpr int NB = decltype(nb_tag)::value;
+    auto energies = [&](auto kn_tag) {
         constexpr bool WITH_KN = decltype(kn_tag)::value;  // Thomson cells: every bin keeps its two constants, no lattice
-        // Per bin [j, j+1] of the lane, everything of ex / term that does not depend on the electron energy is folded into
-        // constants here, so that an energy costs the lane one lattice read and ~10 FP64 instructions:
+        // Per bin [j, j+1], everything of ex / term that does not depend on the electron energy is folded into constants, so
+        // that an energy costs the lane one lattice read and ~10 FP64 instructions:
         //   above the split     f nu = (f_th nu) corr,  s1 = 1 + (lf_N - lf) / lg2r = s_th + (lg2corr_N - lg2corr) / lg2r
         //                       ex = term = (A_N corr_N - A corr) / s1           (|s1| > 1e-3;  A corr lg2r ln 2 otherwise)
         //   seeds not both > 0  ex = term = the trapezoid (f + f_N) dnu / 2 = A_N corr_N + A corr with A := f_th dnu / 2 instead
         //   bin below the split ex = the Thomson integral, term = trap ratio_th: constants -- except the bin right below it, whose
         //                       upper edge carries the corrected f: term = K0 + K1 corr_N
-        int jn[NB];
-        bool bin[NB], pos[NB];
-        double A[NB], AN[NB], s_th[NB], ilr[NB], Lr[NB], exth[NB], termth[NB], K0[NB], K1[NB];
-        {
-            double nu_a[NB], fth[NB], lth[NB];
-            auto ld = [&](const double* arr, int jj) { return jj <= nu_last ? arr[jj] : 0.0; };
-#pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                jn[a] = NB * (63 - lane) + a;
-                bin[a] = jn[a] < nu_last;
-                nu_a[a] = ld(sh.nu, jn[a]);
-                fth[a] = ld(sh.fv_th, jn[a]);
-                lth[a] = ld(sh.lg2fv, jn[a]);
-            }
-            // value at node j_a + 1: the lane's own next node, or the first node of lane - 1
-            auto next_of = [&](const double (&v)[NB], int a) { return a + 1 < NB ? v[a + 1 < NB ? a + 1 : a] : from_lane_below(v[0]); };
-#pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                const double nuN = next_of(nu_a, a), fthN = next_of(fth, a), lthN = next_of(lth, a);
-                const double hd = bin[a] ? 0.5 * sh.dnu[jn[a]] : 0.0;  // half the bin width: the trapezoid's factor
-                const double lgr = bin[a] ? sh.lg2r[jn[a]] : 0.0;
-                const double rth = bin[a] ? sh.ratio_th[jn[a]] : 1.0;
-                ilr[a] = bin[a] ? sh.inv_lg2r[jn[a]] : 0.0;
-                exth[a] = bin[a] ? sh.ex[jn[a]] : 0.0;  // Thomson bin integral (build_cdf_thomson)
-                pos[a] = fth[a] > 0 && fthN > 0;
-                A[a] = pos[a] ? fth[a] * nu_a[a] : fth[a] * hd;
-                AN[a] = pos[a] ? fthN * nuN : fthN * hd;
-                s_th[a] = pos[a] ? 1 + (lthN - lth[a]) * ilr[a] : 1.0;
-                Lr[a] = lgr * 0.6931471805599453;
-                K0[a] = fth[a] * hd * rth;
-                K1[a] = fthN * hd * rth;
-                termth[a] = (fth[a] + fthN) * hd * rth;
-            }
-        }
-        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / corr / dlc
+        struct Bin {
+            int j;
+            bool bin, pos;
+            double A, AN, s_th, ilr, Lr, exth, termth, K0, K1;
+        };
+        auto bin_constants = [&](int j) {
+            Bin b;
+            b.j = j;
+            b.bin = j < nu_last;
+            const int jj = b.bin ? j : 0;
+            const double nu_a = sh.nu[jj], nuN = sh.nu[jj + 1], fth = sh.fv_th[jj], fthN = sh.fv_th[jj + 1];
+            const double lth = sh.lg2fv[jj], lthN = sh.lg2fv[jj + 1];
+            const double hd = 0.5 * sh.dnu[jj];  // half the bin width: the trapezoid's factor
+            const double rth = sh.ratio_th[jj];
+            b.ilr = sh.inv_lg2r[jj];
+            b.exth = sh.ex[jj];  // Thomson bin integral (build_cdf_thomson)
+            b.pos = fth > 0 && fthN > 0;
+            b.A = b.pos ? fth * nu_a : fth * hd;
+            b.AN = b.pos ? fthN * nuN : fthN * hd;
+            b.s_th = b.pos ? 1 + (lthN - lth) * b.ilr : 1.0;
+            b.Lr = sh.lg2r[jj] * 0.6931471805599453;
+            b.K0 = fth * hd * rth;
+            b.K1 = fthN * hd * rth;
+            b.termth = (fth + fthN) * hd * rth;
+            return b;
+        };
+        const Bin bm = bin_constants(lane);
+        // the tail pass: W lanes side by side for the bins 64 .. nu_last - 1, 64 / W chunks of T consecutive energies
+        const int n_tail = nu_last > 64 ? nu_last - 64 : 0;
+        int lgW = 3;
+        while ((1 << lgW) < n_tail) ++lgW;
+        const int W = 1 << lgW, T = (g_size * W + 63) >> 6;
+        const int i_tail0 = (lane >> lgW) * T;
+        Bin bt = bm;
+        if (n_tail > 0) bt = bin_constants(64 + (lane & (W - 1)));
+        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / lat / dNe_i / split_i
         for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
         if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by
-                   // two quanta, so only the even nodes of the reference's lattice are ever read: node q here is its node 2 q
+                   // two quanta, so only the even nodes of the reference's lattice are ever read: node q here is its node 2 q.
+                   // (The nodes below min_i (i + split(i)) - 1, a third of them, are never read; skipping them was measured and
+                   // costs more -- a wave-wide minimum and two barriers before the fill -- than the partial second pass it saves.)
             const int n_lat = (g_size - 1) + (nu_size - 1) + 1;
             const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
-            for (int q = lane; q < n_lat; q += 64)
-                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, sh.corr[q], sh.dlc[q]);
-            __syncthreads();
-            double d3[3];  // log2 corr -> its forward difference, in place (IC_MAX_LAT <= 192: three nodes per lane)
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const int q = lane + 64 * s3;
-                d3[s3] = q + 1 < n_lat ? sh.dlc[q + 1] - sh.dlc[q] : 0.0;
+            for (int q = lane; q < n_lat; q += 64) {
+                double cq, lq;
+                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, cq, lq);
+                sh.lat[q] = vdouble2{cq, lq};
             }
-            __syncthreads();
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3)
-                if (lane + 64 * s3 < n_lat) sh.dlc[lane + 64 * s3] = d3[s3];
         }
-        __syncthreads();
         int my_split = nu_size;  // Thomson: no bin lies at or above the split
         if (KN && lane < g_size) {
             const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
@@ -742,83 +737,82 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             while (js < nu_last && sh.nu[js] < nu_split) ++js;
             my_split = js;
         }
+        if (n_tail > 0) sh.dNe_i[lane] = my_dNe, sh.split_i[lane] = my_split;
+        __syncthreads();
         VAG_IC_MARK();  // 4: KN lattice, split indices
         int g_run = g_size;
 #ifdef VAG_IC_ABLATE
         if (VAG_IC_ABLATE >= 1) g_run = 0;
 #endif
-#ifndef VAG_IC_UNROLL
-#define VAG_IC_UNROLL 2
-#endif
-        // The lattice words of every lane, used or not, are read one energy ahead (an LDS instruction costs the same under any
-        // mask; read inside the branches they would go out one by one, each with its own wait).  Garbage where the cell has no
-        // lattice or the index runs past it (still inside this wavefront's LDS): those lanes never use them.  Two energies per
-        // trip, so that the words read ahead alternate between two register sets instead of being moved.
-        struct Lat {
-            double c[NB], cN[NB], dl[NB];
-        };
-        auto read_lat = [&](Lat& w, int i) {
-            if constexpr (WITH_KN) {
-#pragma unroll
-                for (int a = 0; a < NB; ++a) w.c[a] = sh.corr[i + jn[a]], w.cN[a] = sh.corr[i + 1 + jn[a]], w.dl[a] = sh.dlc[i + jn[a]];
-            }
-        };
-        // `asm volatile("")` inside a branch: keep it a branch under the exec mask (scalar instructions) -- if-converted, the
-        // three-way choice costs ten v_cndmask per energy on the pipe this loop is bound by
-        auto energy = [&](int i, const Lat& w) {
-            const double dNe = read_lane(my_dNe, i);
-            if (!(dNe > 0)) return;  // uniform
-            const int i_gamma = 2 * i;
-            const int j_split = WITH_KN ? __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i)) : 0;
-#pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                double ve = exth[a], vt = termth[a];
-                if (WITH_KN && bin[a] && jn[a] >= j_split - 1) {  // at or right below the split: the bin sees the lattice
+        // ex and term of one (energy, bin) pair, added to the diagonal histograms.  `asm volatile("")` inside a branch: keep it
+        // a branch under the exec mask (scalar instructions) -- if-converted, the three-way choice costs ten v_cndmask per pair
+        auto pair = [&](int i, double dNe, int j_split, const Bin& b, const vdouble2& nd0, const vdouble2& nd1) {
+            double ve = b.exth, vt = b.termth;
+            if (WITH_KN && b.bin && b.j >= j_split - 1) {  // at or right below the split: the bin sees the lattice
+                asm volatile("");
+                const double cN = nd1.x;
+                if (b.j >= j_split) {
                     asm volatile("");
-                    if (jn[a] >= j_split) {
+                    const double u = b.A * nd0.x;
+                    if (b.pos) {
                         asm volatile("");
-                        const double u = A[a] * w.c[a];
-                        if (pos[a]) {
+                        const double s1 = fma(nd1.y - nd0.y, b.ilr, b.s_th);
+                        ve = u * b.Lr;
+                        if (fabs(s1) > 1e-3) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
                             asm volatile("");
-                            const double s1 = fma(w.dl[a], ilr[a], s_th[a]);
-                            ve = u * Lr[a];
-                            if (fabs(s1) > 1e-3) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
-                                asm volatile("");
-                                ve = fma(AN[a], w.cN[a], -u) * rcp_ode(s1);
-                            }
-                        } else
-                            ve = fma(AN[a], w.cN[a], u);
-                        vt = ve;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                            ve = fma(b.AN, cN, -u) * rcp_ode(s1);
+                        }
                     } else
-                        vt = fma(K1[a], w.cN[a], K0[a]);
-                }
-                if (bin[a]) {
-                    // relaxed workgroup atomics on LDS words: ds_add_f64 without a return value, free to overlap the next energy's reads
-                    __hip_atomic_fetch_add(&sh.D[i_gamma + jn[a]], dNe * ve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&sh.E[i_gamma + jn[a]], dNe * vt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                        ve = fma(b.AN, cN, u);
+                    vt = ve;  // trap * (exact / trap); exact == trap == 0 when the bin is empty
+                } else
+                    vt = fma(b.K1, cN, b.K0);
+            }
+            if (b.bin) {
+                // relaxed workgroup atomics on LDS words: ds_add_f64 without a return value, free to overlap the next pair's reads
+                __hip_atomic_fetch_add(&sh.D[2 * i + b.j], dNe * ve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sh.E[2 * i + b.j], dNe * vt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
-        Lat w0, w1;
-        read_lat(w0, 0);
-        for (int i = 0; i < g_run; i += 2) {
-            read_lat(w1, i + 1);
-            energy(i, w0);
-            read_lat(w0, i + 2);
-            if (i + 1 < g_run) energy(i + 1, w1);
+        // Main pass.  Energy i needs the lattice nodes i + j, i + j + 1 of the lane's bin -- the nodes of energy i - 1 moved up by
+        // one.  So ONE node (16 bytes: correction and its log2) is read per energy, a step ahead of its use, into a ring of three
+        // slots; the loop is unrolled over the ring so that the slots are fixed registers.  (This loop is bound by the LDS pipe as
+        // much as by the VALU -- profiles/micro/valu_throughput.hip: a ds_add_f64 or a two-word read holds it for 8 cycles -- so
+        // the words are not re-read.)  Every lane reads, used or not: an LDS instruction costs the same under any mask; garbage
+        // where the cell has no lattice or the index runs past it (still inside this wavefront's LDS), and those lanes never use it.
+        constexpr int R = 3;
+        vdouble2 ring[R];
+        if constexpr (WITH_KN) ring[0] = sh.lat[lane], ring[1] = sh.lat[lane + 1];
+        for (int i0 = 0; i0 < g_run; i0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = i0 + u;
+                if constexpr (WITH_KN) ring[(u + 2) % R] = sh.lat[i + 2 + lane];  // for energy i + 1
+                if (i < g_run) {
+                    const double dNe = read_lane(my_dNe, i);
+                    if (dNe > 0)  // uniform
+                        pair(i, dNe, WITH_KN ? __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i)) : 0, bm, ring[u % R],
+                             ring[(u + 1) % R]);
+                }
+            }
+        }
+        // Tail pass: lane (chunk c, bin 64 + w) walks the energies c T .. c T + T - 1
+        if (n_tail > 0 && g_run > 0) {
+            for (int t = 0; t < T; ++t) {
+                const int i = i_tail0 + t;
+                const bool live = i < g_size;
+                const int ii = live ? i : 0;
+                const double dNe = live ? sh.dNe_i[ii] : 0.0;
+                vdouble2 nd0 = {0, 0}, nd1 = {0, 0};
+                if constexpr (WITH_KN) nd0 = sh.lat[ii + bt.j], nd1 = sh.lat[ii + bt.j + 1];
+                if (dNe > 0) pair(ii, dNe, WITH_KN ? sh.split_i[ii] : 0, bt, nd0, nd1);
+            }
         }
     };
-    if (nu_size <= VAG_IC_ONE_NODE_MAX) {
-        if (KN)
-            energies(std::integral_constant<int, 1>{}, std::true_type{});
-        else
-            energies(std::integral_constant<int, 1>{}, std::false_type{});
-    } else {
-        if (KN)
-            energies(std::integral_constant<int, 2>{}, std::true_type{});
-        else
-            energies(std::integral_constant<int, 2>{}, std::false_type{});
-    }
+    if (KN)
+        energies(std::true_type{});
+    else
+        energies(std::false_type{});
     __syncthreads();
     suffix_scan4(sh.D, lane);  // D[d] <- sum_{d' >= d} D[d']
     __syncthreads();
