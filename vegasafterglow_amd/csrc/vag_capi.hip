@@ -693,14 +693,14 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
             StageScope ps(c, PS_COOLING);
             hipLaunchKernelGGL(vag_ic_cooling_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_rad_params, nb,
                                c->d_meta.as<VagGridMeta>(), lay, rows, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                               c->d_icy.as<double>(), d_inj);
+                               d_inj);
         }
         HIPCHK(hipGetLastError());
         {
             StageScope ps(c, PS_SYN_PHOTONS);
             hipLaunchKernelGGL(vag_photons_ic_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
                                c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_celldet.as<double>(),
-                               c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>());
+                               c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>(), d_inj);
         }
         HIPCHK(hipGetLastError());
     }

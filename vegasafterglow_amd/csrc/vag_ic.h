@@ -10,20 +10,28 @@ constexpr double C_H = 6.63e-27 * U_ERG * U_SEC;  // con::h, src/util/macros.h:9
 
 // ---- BrokenPowerLaw<5> restricted to the three segments build_segments() can create for regimes 0-2
 //      (src/util/utilities.h:21-78, inverse-compton.cpp:112-131) ----
+// The fixed points of vag_ic_cooling_kernel walk a row cell by cell on ONE lane: their instruction count is their latency.  So the
+// pieces they iterate -- Y_T, the cooling breaks, the segments of Y(gamma), gamma_c -- run on the fast kernels of vag_device.h
+// (log2_fast / exp2_sat: ~1 ulp, the library forms behind them for zeros, infinities and NaN) and on reciprocal / square-root
+// estimates + Newton steps, with the library division and square root kept where an operand may be 0 or inf (B = 0 cells).
+VAG_DEV double ic_pow(double a, double b) { return exp2_sat(b * log2_fast(a)); }  // fast_pow (fast-math.h:138-140)
+VAG_DEV double ic_rcp(double x) { return (isfinite(x) && x != 0) ? rcp_fast(x) : 1.0 / x; }
+VAG_DEV double ic_sqrt(double x) { return (isfinite(x) && x > 0) ? sqrt_fast(x) : sqrt(x); }
+
 struct Bpl {
     int size;
     double slope[3], lg2_lower[3], lg2_const[3];
     VAG_DEV void first(double norm, double lower, double sl) {
         size = 1;
-        const double ll = log2(lower);
+        const double ll = log2_fast(lower);
         slope[0] = sl;
         lg2_lower[0] = ll;
-        lg2_const[0] = log2(norm) - sl * ll;
+        lg2_const[0] = log2_fast(norm) - sl * ll;
     }
     // (constant indices throughout: with a running index the three small arrays live in scratch memory, 168 B per lane of
     // vag_ic_cooling_kernel, and every evaluation of Y(gamma) in its fixed-point loops went through it)
     VAG_DEV void add(double lower, double sl) {
-        const double ll = log2(lower);
+        const double ll = log2_fast(lower);
         if (size == 1) {
             const double val = lg2_const[0] + slope[0] * ll;
             slope[1] = sl;
@@ -38,10 +46,10 @@ struct Bpl {
         ++size;
     }
     VAG_DEV double eval(double x) const {
-        const double lx = log2(x);
-        if (size > 2 && lx >= lg2_lower[2]) return exp2(lg2_const[2] + slope[2] * lx);
-        if (size > 1 && lx >= lg2_lower[1]) return exp2(lg2_const[1] + slope[1] * lx);
-        return size > 0 ? exp2(lg2_const[0] + slope[0] * lx) : 0.0;
+        const double lx = log2_fast(x);
+        if (size > 2 && lx >= lg2_lower[2]) return exp2_sat(lg2_const[2] + slope[2] * lx);
+        if (size > 1 && lx >= lg2_lower[1]) return exp2_sat(lg2_const[1] + slope[1] * lx);
+        return size > 0 ? exp2_sat(lg2_const[0] + slope[0] * lx) : 0.0;
     }
 };
 
@@ -49,7 +57,7 @@ struct Bpl {
 struct IcY {
     double gamma_m_hat, gamma_c_hat, gamma_self, gamma0, Y_T;
     int regime;
-    double gamma_m_, B_, p_, gamma_self3;
+    double gamma_m_, inv_gamma_m_, B_, p_, gamma_self3;
     Bpl seg;
 
     VAG_DEV void set_default() {
@@ -60,12 +68,13 @@ struct IcY {
         Y_T = 0.0;
         regime = 0;
         gamma_m_ = 1;
+        inv_gamma_m_ = 1;
         B_ = 0;
         p_ = 2.3;
         gamma_self3 = 1;
         seg.size = 0;
     }
-    VAG_DEV double gamma_hat(double g) const { return dmax(gamma_self3 / (g * g), 1.0); }
+    VAG_DEV double gamma_hat(double g) const { return dmax(gamma_self3 * ic_rcp(g * g), 1.0); }
     VAG_DEV double gamma_spectrum(double g) const { return seg.eval(g); }
     VAG_DEV void build_segments() {
         seg.first(Y_T, 1.0, 0.0);
@@ -83,15 +92,15 @@ struct IcY {
             return;
         }
         if (gamma_m_ < gamma_c) {
-            gamma0 = fast_pow(Y_T, 2.0 / (3.0 - p_)) * gamma_c_hat;
+            gamma0 = ic_pow(Y_T, 2.0 / (3.0 - p_)) * gamma_c_hat;
             if (gamma0 > gamma_m_hat)
-                gamma0 = gamma_m_hat * fast_pow(Y_T, 3.0 / 4.0) * fast_pow(gamma_c / gamma_m_, 0.75 * (p_ - 3.0));
+                gamma0 = gamma_m_hat * ic_pow(Y_T, 3.0 / 4.0) * ic_pow(gamma_c * inv_gamma_m_, 0.75 * (p_ - 3.0));
         } else {
             gamma0 = Y_T * Y_T * gamma_m_hat;
             if (gamma_m_ < gamma_m_hat) {
-                if (gamma0 > gamma_c_hat) gamma0 = fast_pow(Y_T * gamma_c / gamma_m_, 3.0 / 4.0) * gamma_c_hat;
+                if (gamma0 > gamma_c_hat) gamma0 = ic_pow(Y_T * gamma_c * inv_gamma_m_, 3.0 / 4.0) * gamma_c_hat;
             } else {
-                if (gamma0 > gamma_self) gamma0 = sqrt(Y_T * gamma_m_ * gamma_m_hat);
+                if (gamma0 > gamma_self) gamma0 = ic_sqrt(Y_T * gamma_m_ * gamma_m_hat);
             }
         }
     }
@@ -105,11 +114,12 @@ struct IcY {
     VAG_DEV void init(double gamma_m, double gamma_c, double p, double B, double YT, bool is_KN) {
         set_default();
         const double nu_m = syn_freq(gamma_m, B);
-        gamma_m_hat = dmax(C_ME * C_C2 / C_H / nu_m, 1.0);
-        gamma_self = fast_pow(gamma_m_hat * gamma_m * gamma_m, 1.0 / 3.0);
+        gamma_m_hat = dmax((C_ME * C_C2 / C_H) * ic_rcp(nu_m), 1.0);
+        gamma_self = ic_pow(gamma_m_hat * gamma_m * gamma_m, 1.0 / 3.0);
         gamma_self3 = gamma_self * gamma_self * gamma_self;
         B_ = B;
         gamma_m_ = gamma_m;
+        inv_gamma_m_ = ic_rcp(gamma_m);
         p_ = p;
         if (is_KN) {
             update_cooling_breaks(gamma_c, YT);
@@ -125,14 +135,14 @@ struct IcY {
 VAG_DEV double syn_gamma(double nu, double B) { return sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu / B)); }
 VAG_DEV double icy_nu_spectrum(const IcY& y, double nu) { return y.gamma_spectrum(syn_gamma(nu, y.B_)); }
 
-VAG_DEV double thomson_Y(double eps_e, double eps_B, double p, double gamma_m, double gamma_c) {
-    const double eta_e = (gamma_c < gamma_m) ? 1 : fast_pow(gamma_c / gamma_m, 2 - p);
-    const double b = eta_e * eps_e / eps_B;
-    return 0.5 * (sqrt(1. + 4. * b) - 1.);
+// `e_over_B` = eps_e / eps_B and `inv_gamma_m` are the same for every iteration of a cell's fixed point
+VAG_DEV double thomson_Y(double e_over_B, double p, double gamma_m, double inv_gamma_m, double gamma_c) {
+    const double eta_e = (gamma_c < gamma_m) ? 1 : ic_pow(gamma_c * inv_gamma_m, 2 - p);
+    return 0.5 * (ic_sqrt(fma(4. * e_over_B, eta_e, 1.)) - 1.);
 }
 VAG_DEV double gamma_c_of(double t_comv, double B, double Y) {
-    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) / (B * B * (1 + Y) * t_comv) * 1;
-    return (gamma_bar + sqrt(gamma_bar * gamma_bar + 4)) / 2;
+    const double gamma_bar = (6 * C_PI * C_ME * C_C / C_SIGMAT) * ic_rcp(B * B * (1 + Y) * t_comv);
+    return (gamma_bar + ic_sqrt(gamma_bar * gamma_bar + 4)) * 0.5;
 }
 VAG_DEV double gamma_M_of(double B, double Y) {
     if (B == 0) return INFINITY;

@@ -31,15 +31,29 @@ constexpr double IC_Q = 3.321928094887362 / 8;  // lattice_quantum
 constexpr double IC_X0 = 0.47140452079103166;
 
 // ------------------------------------------------------------------------------------------------
-// IC cooling: one lane per representative row, sequential in k because each cell's iteration starts from the
-// previous cell's cooled gamma_c (IC_cooling, inverse-compton.h:729-768; update_gamma_c_Thomson/_KN and
-// update_gamma_M, inverse-compton.cpp:192-251).  Updates the electron detail arrays in place and stores
-// InverseComptonY per cell.
+// IC cooling (IC_cooling, inverse-compton.h:729-768; update_gamma_c_Thomson/_KN and update_gamma_M,
+// inverse-compton.cpp:192-251) in two kernels.  Cells of a row are tied together by ONE number: each cell's gamma_c fixed point
+// starts from the previous cell's cooled gamma_c (and stops on a relative step, so the start value decides the iterate it stops
+// at).  vag_ic_cooling_kernel walks that chain, one lane per representative row -- a pure latency chain, so it carries nothing
+// else: per cell it leaves gamma_c, the gamma_c its last Y(gamma) was built for and the Thomson Y of that iteration.  Everything
+// that follows from them per cell -- Y(gamma) itself, gamma_M's fixed point, Y_c, gamma_a, the regime, the stored segments --
+// is done one lane per CELL at the head of vag_photons_ic_kernel.
 // ------------------------------------------------------------------------------------------------
+// gamma_M's fixed point of one cell (update_gamma_M, inverse-compton.cpp:236-251)
+VAG_DEV double ic_gamma_M(double B, double gM, const IcY& Ys) {
+    if (B == 0) return INFINITY;
+    double gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
+    for (int guard = 0; fabs((gM - gM_new) / gM_new) > 1e-3 && guard < 10000; ++guard) {
+        gM = gM_new;
+        gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
+    }
+    return gM;
+}
+
 __global__ void __launch_bounds__(64)
 vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                       Layout lay, int n_rows, const double* __restrict__ shock, long long n_cells,
-                      double* __restrict__ det, double* __restrict__ icy,
+                      double* __restrict__ det,
                       const int* __restrict__ inj_idx /* optional: reverse shock's injection cutoff per row */) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows || row >= lay.row_off[nb]) return;
@@ -48,81 +62,78 @@ vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const
     if (M.status != 0) return;
     const vag_model_params P = params[m];
     const bool kn = (P.flags & VAG_FLAG_KN) != 0;
+    const double e_over_B = P.eps_e / P.eps_B;
     const int nt = M.n_t;
     const long long c0 = lay.cell_off[m] + (long long)(row - lay.row_off[m]) * nt;
     double gamma_c_last = det[VD_GAMMA_C * n_cells + c0];
     const int k_inj = inj_idx ? inj_idx[row] : nt;
     double inj_gc = 0, inj_gm = 1, inj_gM = 0;  // cooled electrons of the crossing cell k_inj - 1
+    // the cell's inputs one cell ahead of the chain
+    double n_t_com = shock[VS_TCOMV * n_cells + c0], n_B = shock[VS_B * n_cells + c0];
+    double n_gm = det[VD_GAMMA_M * n_cells + c0], n_gc = gamma_c_last;
     for (int k = 0; k < nt; ++k) {
         const long long c = c0 + k;
-        const double t_com = shock[VS_TCOMV * n_cells + c], B = shock[VS_B * n_cells + c];
-        const double gm = det[VD_GAMMA_M * n_cells + c];
-        double gc = det[VD_GAMMA_C * n_cells + c];
-        double gM = det[VD_GAMMA_MAX * n_cells + c];
-        const double cd = det[VD_COLUMN_DEN * n_cells + c];
+        const double t_com = n_t_com, B = n_B, gm = n_gm;
+        double gc = n_gc;
+        if (k + 1 < nt) {
+            n_t_com = shock[VS_TCOMV * n_cells + c + 1], n_B = shock[VS_B * n_cells + c + 1];
+            n_gm = det[VD_GAMMA_M * n_cells + c + 1], n_gc = det[VD_GAMMA_C * n_cells + c + 1];
+        }
+        const double inv_gm = ic_rcp(gm);
+        double gc_used, Y_T;  // what the cell's Y(gamma) is built from
         IcY Ys;
         if (kn) {
             double gc_new = gamma_c_last;
-            double Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc_new);
+            Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc_new);
             Ys.init(gm, gc_new, P.p, B, Y_T, true);
             int iter = 0;
             do {
                 gc = gc_new;
-                Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+                Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
                 Ys.update_cooling_breaks(gc, Y_T);
                 gc_new = gamma_c_of(t_com, B, Ys.gamma_spectrum(gc));
                 iter++;
             } while (fabs((gc_new - gc) / gc) > 1e-3 && iter < 100);
+            gc_used = gc;
             gc = gc_new;
         } else {
-            double Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+            Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
             double gc_new = gamma_c_last;
             for (int guard = 0; fabs((gc_new - gc) / gc) > 1e-3 && guard < 10000; ++guard) {
                 gc = gc_new;
-                Y_T = thomson_Y(P.eps_e, P.eps_B, P.p, gm, gc);
+                Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
                 gc_new = gamma_c_of(t_com, B, Y_T);
             }
             gc = gc_new;
-            Ys.init(gm, gc, P.p, B, Y_T, false);
-        }
-        if (B == 0) {
-            gM = INFINITY;
-        } else {
-            double gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
-            for (int guard = 0; fabs((gM - gM_new) / gM_new) > 1e-3 && guard < 10000; ++guard) {
-                gM = gM_new;
-                gM_new = gamma_M_of(B, Ys.gamma_spectrum(gM));
-            }
+            gc_used = gc;
         }
         if (k >= k_inj) {  // cool_relic_electrons inside IC_cooling, inverse-compton.h:752
             gc = cool_after_crossing(inj_gc, inj_gm, gm);
-            gM = cool_after_crossing(inj_gM, inj_gm, gm);
+            det[VD_GAMMA_MAX * n_cells + c] = cool_after_crossing(inj_gM, inj_gm, gm);
         }
-        if (k == k_inj - 1) {
+        if (k == k_inj - 1) {  // the crossing cell's own gamma_M is what the relic cells scale
+            if (!kn) Ys.init(gm, gc_used, P.p, B, Y_T, false);
             inj_gc = gc;
             inj_gm = gm;
-            inj_gM = gM;
+            inj_gM = ic_gamma_M(B, det[VD_GAMMA_MAX * n_cells + c], Ys);
         }
-        const double Y_c = Ys.gamma_spectrum(gc);
-        const double ga = syn_gamma_a_ic(B, syn_I_peak(B, cd), gm, gc, P.p, Ys, Y_c);
         det[VD_GAMMA_C * n_cells + c] = gc;
-        det[VD_GAMMA_MAX * n_cells + c] = gM;
-        det[VD_GAMMA_A * n_cells + c] = ga;
-        det[VD_YC * n_cells + c] = Y_c;
-        det[VD_REGIME * n_cells + c] = (double)determine_regime(ga, gc, gm);
-        icy_store(Ys, icy, n_cells, c);
+        det[VD_GAMMA_A * n_cells + c] = gc_used;  // } until vag_photons_ic_kernel puts gamma_a and Y_c there
+        det[VD_YC * n_cells + c] = Y_T;           // }
         gamma_c_last = gc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Photons from the (cooled) electrons, one lane per cell: generate_syn_photons + build, plus the constants of
-// the IC correction of the thin branch (inverse_compton_correction, inverse-compton.h:781-792).
+// One lane per cell: the rest of IC_cooling from what the chain left (see above), then the photons from the cooled electrons
+// (generate_syn_photons + build) and the constants of the IC correction of the thin branch (inverse_compton_correction,
+// inverse-compton.h:781-792).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                       Layout lay, const double* __restrict__ shock, long long n_cells, double* __restrict__ det,
-                      const double* __restrict__ icy, double* __restrict__ cellpar, double* __restrict__ cellq) {
+                      double* __restrict__ icy, double* __restrict__ cellpar, double* __restrict__ cellq,
+                      const int* __restrict__ inj_idx /* optional: reverse shock's injection cutoff per row */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     int lo = 0, hi = nb;
@@ -141,10 +152,22 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
     const int r = (int)(local / nt), k = (int)(local % nt);
     const vag_model_params P = params[m];
     const double B = shock[VS_B * n_cells + c];
+    const double gm = det[VD_GAMMA_M * n_cells + c], gc = det[VD_GAMMA_C * n_cells + c], cd = det[VD_COLUMN_DEN * n_cells + c];
+    IcY Ys;
+    Ys.init(gm, det[VD_GAMMA_A * n_cells + c], P.p, B, det[VD_YC * n_cells + c], (P.flags & VAG_FLAG_KN) != 0);
+    const int k_inj = inj_idx ? inj_idx[lay.row_off[m] + r] : nt;
+    double gM = det[VD_GAMMA_MAX * n_cells + c];  // relic cells: already the crossing cell's, scaled by the chain
+    if (k < k_inj) gM = ic_gamma_M(B, gM, Ys);
+    const double Y_c = Ys.gamma_spectrum(gc);
+    const double ga = syn_gamma_a_ic(B, syn_I_peak(B, cd), gm, gc, P.p, Ys, Y_c);
+    det[VD_GAMMA_MAX * n_cells + c] = gM;
+    det[VD_GAMMA_A * n_cells + c] = ga;
+    det[VD_YC * n_cells + c] = Y_c;
+    det[VD_REGIME * n_cells + c] = (double)determine_regime(ga, gc, gm);
+    icy_store(Ys, icy, n_cells, c);
     CellOut o;
-    syn_photons_build(o, det[VD_GAMMA_M * n_cells + c], det[VD_GAMMA_C * n_cells + c], det[VD_GAMMA_A * n_cells + c],
-                      det[VD_GAMMA_MAX * n_cells + c], det[VD_COLUMN_DEN * n_cells + c], det[VD_N_E * n_cells + c], B, P.p,
-                      shock[VS_GAMMA * n_cells + c], shock[VS_R * n_cells + c], shock[VS_TENG * n_cells + c]);
+    syn_photons_build(o, gm, gc, ga, gM, cd, det[VD_N_E * n_cells + c], B, P.p, shock[VS_GAMMA * n_cells + c],
+                      shock[VS_R * n_cells + c], shock[VS_TENG * n_cells + c]);
     double* dst = cellpar + (lay.cell_off[m] + (long long)r * nt) * VAG_NPAR + k;
 #pragma unroll
     for (int q = 0; q < VAG_NPAR; ++q) dst[(long long)q * nt] = o.par[q];
@@ -153,15 +176,19 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
     det[VD_NU_A * n_cells + c] = o.nu_a;
     det[VD_NU_MAX * n_cells + c] = o.nu_M;
     det[VD_I_NU_MAX * n_cells + c] = o.I_nu_max;
-    const double Y_c = det[VD_YC * n_cells + c], Y_T = icy[VY_YT * n_cells + c];
+    const double Y_T = Ys.Y_T;
     double* q = cellq + (lay.cell_off[m] + (long long)r * nt) * VAG_NQ + k;
     q[(long long)VQ_LG2_NUC * nt] = log2(o.nu_c);
     q[(long long)VQ_L1PYC * nt] = log2(1. + Y_c);
     q[(long long)VQ_HASIC * nt] = (Y_c > 0 || Y_T > 0) ? 1.0 : 0.0;
     q[(long long)VQ_LG2_KB * nt] = log2(4 * C_PI * C_ME * C_C / (3 * C_E)) - log2(B);
-    q[(long long)VQ_NSEG * nt] = icy[VY_NSEG * n_cells + c];
+    q[(long long)VQ_NSEG * nt] = (double)Ys.seg.size;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) q[(long long)(VQ_S0 + s) * nt] = icy[(VY_S0 + s) * n_cells + c];
+    for (int s = 0; s < 3; ++s) {  // as icy_store lays them out
+        q[(long long)(VQ_S0 + 3 * s) * nt] = s < Ys.seg.size ? Ys.seg.slope[s] : 0;
+        q[(long long)(VQ_S0 + 3 * s + 1) * nt] = s < Ys.seg.size ? Ys.seg.lg2_lower[s] : INFINITY;
+        q[(long long)(VQ_S0 + 3 * s + 2) * nt] = s < Ys.seg.size ? Ys.seg.lg2_const[s] : 0;
+    }
 }
 
 // IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92).  `c`/`st` address the
