@@ -18,20 +18,20 @@ VAG_DEV double ic_pow(double a, double b) { return exp2_sat(b * log2_fast(a)); }
 VAG_DEV double ic_rcp(double x) { return (isfinite(x) && x != 0) ? rcp_fast(x) : 1.0 / x; }
 VAG_DEV double ic_sqrt(double x) { return (isfinite(x) && x > 0) ? sqrt_fast(x) : sqrt(x); }
 
+// Everything below is carried in log2: the segments are stored that way, and a cell's fixed point needs two logarithms per
+// iteration (of gamma_c and of Y_T) instead of the seven its pieces would each take on their own.
 struct Bpl {
     int size;
     double slope[3], lg2_lower[3], lg2_const[3];
-    VAG_DEV void first(double norm, double lower, double sl) {
+    VAG_DEV void first_lg(double lg2_norm) {  // first_segment(norm, 1, 0)
         size = 1;
-        const double ll = log2_fast(lower);
-        slope[0] = sl;
-        lg2_lower[0] = ll;
-        lg2_const[0] = log2_fast(norm) - sl * ll;
+        slope[0] = 0;
+        lg2_lower[0] = 0;
+        lg2_const[0] = lg2_norm;
     }
     // (constant indices throughout: with a running index the three small arrays live in scratch memory, 168 B per lane of
     // vag_ic_cooling_kernel, and every evaluation of Y(gamma) in its fixed-point loops went through it)
-    VAG_DEV void add(double lower, double sl) {
-        const double ll = log2_fast(lower);
+    VAG_DEV void add_lg(double ll, double sl) {  // add_segment(lower, slope) given log2(lower)
         if (size == 1) {
             const double val = lg2_const[0] + slope[0] * ll;
             slope[1] = sl;
@@ -45,89 +45,73 @@ struct Bpl {
         }
         ++size;
     }
-    VAG_DEV double eval(double x) const {
-        const double lx = log2_fast(x);
+    VAG_DEV double eval_lg(double lx) const {
         if (size > 2 && lx >= lg2_lower[2]) return exp2_sat(lg2_const[2] + slope[2] * lx);
         if (size > 1 && lx >= lg2_lower[1]) return exp2_sat(lg2_const[1] + slope[1] * lx);
         return size > 0 ? exp2_sat(lg2_const[0] + slope[0] * lx) : 0.0;
     }
+    VAG_DEV double eval(double x) const { return eval_lg(log2_fast(x)); }
 };
 
 // ---- InverseComptonY (inverse-compton.h:28-76, inverse-compton.cpp:18-187) ----
+// (Its gamma0 -- update_gamma0, inverse-compton.cpp:51-93 -- is only read by code the reference has commented out, :101-114, and
+// is not formed here.)
 struct IcY {
-    double gamma_m_hat, gamma_c_hat, gamma_self, gamma0, Y_T;
+    double gamma_m_hat, gamma_c_hat, gamma_self, Y_T;
     int regime;
-    double gamma_m_, inv_gamma_m_, B_, p_, gamma_self3;
+    double gamma_m_, B_, p_, gamma_self3;
+    double lg2_gamma_m, lg2_gamma_m_hat, lg2_gamma_self3;
     Bpl seg;
 
-    VAG_DEV void set_default() {
-        gamma_m_hat = 1.0;
-        gamma_c_hat = 1.0;
-        gamma_self = 1;
-        gamma0 = 1;
-        Y_T = 0.0;
-        regime = 0;
-        gamma_m_ = 1;
-        inv_gamma_m_ = 1;
-        B_ = 0;
-        p_ = 2.3;
-        gamma_self3 = 1;
-        seg.size = 0;
-    }
     VAG_DEV double gamma_hat(double g) const { return dmax(gamma_self3 * ic_rcp(g * g), 1.0); }
     VAG_DEV double gamma_spectrum(double g) const { return seg.eval(g); }
-    VAG_DEV void build_segments() {
-        seg.first(Y_T, 1.0, 0.0);
+    VAG_DEV double gamma_spectrum_lg(double lg2_g) const { return seg.eval_lg(lg2_g); }
+    VAG_DEV void build_segments(double lg2_gamma_c_hat) {
+        seg.first_lg(log2_fast(Y_T));
         if (regime == 1) {
-            seg.add(gamma_c_hat, 0.5 * (p_ - 3.0));
-            seg.add(gamma_m_hat, -4.0 / 3.0);
+            seg.add_lg(lg2_gamma_c_hat, 0.5 * (p_ - 3.0));
+            seg.add_lg(lg2_gamma_m_hat, -4.0 / 3.0);
         } else if (regime == 2) {
-            seg.add(gamma_m_hat, -0.5);
-            seg.add(gamma_c_hat, -4.0 / 3.0);
+            seg.add_lg(lg2_gamma_m_hat, -0.5);
+            seg.add_lg(lg2_gamma_c_hat, -4.0 / 3.0);
         }
     }
-    VAG_DEV void update_gamma0(double gamma_c) {
-        if (Y_T < 1) {
-            gamma0 = 0.0;
-            return;
-        }
-        if (gamma_m_ < gamma_c) {
-            gamma0 = ic_pow(Y_T, 2.0 / (3.0 - p_)) * gamma_c_hat;
-            if (gamma0 > gamma_m_hat)
-                gamma0 = gamma_m_hat * ic_pow(Y_T, 3.0 / 4.0) * ic_pow(gamma_c * inv_gamma_m_, 0.75 * (p_ - 3.0));
-        } else {
-            gamma0 = Y_T * Y_T * gamma_m_hat;
-            if (gamma_m_ < gamma_m_hat) {
-                if (gamma0 > gamma_c_hat) gamma0 = ic_pow(Y_T * gamma_c * inv_gamma_m_, 3.0 / 4.0) * gamma_c_hat;
-            } else {
-                if (gamma0 > gamma_self) gamma0 = ic_sqrt(Y_T * gamma_m_ * gamma_m_hat);
-            }
-        }
-    }
-    VAG_DEV void update_cooling_breaks(double gamma_c, double YT) {
+    VAG_DEV double lg2_gamma_hat(double lg2_g) const { return dmax(lg2_gamma_self3 - 2 * lg2_g, 0.0); }
+    // update_cooling_breaks(gamma_c, Y_T) given log2(gamma_c)
+    VAG_DEV void update_cooling_breaks_lg(double gamma_c, double lg2_gamma_c, double YT) {
         gamma_c_hat = gamma_hat(gamma_c);
         Y_T = YT;
-        update_gamma0(gamma_c);
         regime = (gamma_m_ < gamma_c) ? 1 : 2;
-        build_segments();
+        build_segments(lg2_gamma_hat(lg2_gamma_c));
     }
-    VAG_DEV void init(double gamma_m, double gamma_c, double p, double B, double YT, bool is_KN) {
-        set_default();
+    VAG_DEV void update_cooling_breaks(double gamma_c, double YT) { update_cooling_breaks_lg(gamma_c, log2_fast(gamma_c), YT); }
+    // the part of the constructor that does not depend on gamma_c
+    VAG_DEV void init_base(double gamma_m, double p, double B) {
         const double nu_m = syn_freq(gamma_m, B);
         gamma_m_hat = dmax((C_ME * C_C2 / C_H) * ic_rcp(nu_m), 1.0);
-        gamma_self = ic_pow(gamma_m_hat * gamma_m * gamma_m, 1.0 / 3.0);
+        lg2_gamma_m = log2_fast(gamma_m);
+        lg2_gamma_m_hat = log2_fast(gamma_m_hat);
+        const double lg2_self = (lg2_gamma_m_hat + 2 * lg2_gamma_m) * (1.0 / 3.0);  // (gamma_m_hat gamma_m^2)^(1/3)
+        gamma_self = exp2_sat(lg2_self);
         gamma_self3 = gamma_self * gamma_self * gamma_self;
+        lg2_gamma_self3 = 3 * lg2_self;
         B_ = B;
         gamma_m_ = gamma_m;
-        inv_gamma_m_ = ic_rcp(gamma_m);
         p_ = p;
+        gamma_c_hat = 1.0;
+        Y_T = 0.0;
+        regime = 0;
+        seg.size = 0;
+    }
+    VAG_DEV void init(double gamma_m, double gamma_c, double p, double B, double YT, bool is_KN) {
+        init_base(gamma_m, p, B);
         if (is_KN) {
             update_cooling_breaks(gamma_c, YT);
         } else {
             gamma_c_hat = gamma_hat(gamma_c);
             Y_T = YT;
             regime = 0;
-            build_segments();
+            build_segments(0.0);
         }
     }
 };
@@ -135,9 +119,9 @@ struct IcY {
 VAG_DEV double syn_gamma(double nu, double B) { return sqrt((4 * C_PI * C_ME * C_C / (3 * C_E)) * (nu / B)); }
 VAG_DEV double icy_nu_spectrum(const IcY& y, double nu) { return y.gamma_spectrum(syn_gamma(nu, y.B_)); }
 
-// `e_over_B` = eps_e / eps_B and `inv_gamma_m` are the same for every iteration of a cell's fixed point
-VAG_DEV double thomson_Y(double e_over_B, double p, double gamma_m, double inv_gamma_m, double gamma_c) {
-    const double eta_e = (gamma_c < gamma_m) ? 1 : ic_pow(gamma_c * inv_gamma_m, 2 - p);
+// compute_Thomson_Y (inverse-compton.cpp:192-198) given log2(gamma_c / gamma_m); `e_over_B` = eps_e / eps_B
+VAG_DEV double thomson_Y_lg(double e_over_B, double p, bool below_gamma_m, double lg2_gc_over_gm) {
+    const double eta_e = below_gamma_m ? 1 : exp2_sat((2 - p) * lg2_gc_over_gm);
     return 0.5 * (ic_sqrt(fma(4. * e_over_B, eta_e, 1.)) - 1.);
 }
 VAG_DEV double gamma_c_of(double t_comv, double B, double Y) {

@@ -79,29 +79,29 @@ vag_ic_cooling_kernel(const vag_model_params* __restrict__ params, int nb, const
             n_t_com = shock[VS_TCOMV * n_cells + c + 1], n_B = shock[VS_B * n_cells + c + 1];
             n_gm = det[VD_GAMMA_M * n_cells + c + 1], n_gc = det[VD_GAMMA_C * n_cells + c + 1];
         }
-        const double inv_gm = ic_rcp(gm);
         double gc_used, Y_T;  // what the cell's Y(gamma) is built from
         IcY Ys;
+        Ys.init_base(gm, P.p, B);
+        const double lg2_gm = Ys.lg2_gamma_m;
         if (kn) {
-            double gc_new = gamma_c_last;
-            Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc_new);
-            Ys.init(gm, gc_new, P.p, B, Y_T, true);
+            double gc_new = gamma_c_last;  // (the constructor's own update with this start value is overwritten by the first pass)
             int iter = 0;
             do {
                 gc = gc_new;
-                Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
-                Ys.update_cooling_breaks(gc, Y_T);
-                gc_new = gamma_c_of(t_com, B, Ys.gamma_spectrum(gc));
+                const double lg2_gc = log2_fast(gc);
+                Y_T = thomson_Y_lg(e_over_B, P.p, gc < gm, lg2_gc - lg2_gm);
+                Ys.update_cooling_breaks_lg(gc, lg2_gc, Y_T);
+                gc_new = gamma_c_of(t_com, B, Ys.gamma_spectrum_lg(lg2_gc));
                 iter++;
             } while (fabs((gc_new - gc) / gc) > 1e-3 && iter < 100);
             gc_used = gc;
             gc = gc_new;
         } else {
-            Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
+            Y_T = thomson_Y_lg(e_over_B, P.p, gc < gm, log2_fast(gc) - lg2_gm);
             double gc_new = gamma_c_last;
             for (int guard = 0; fabs((gc_new - gc) / gc) > 1e-3 && guard < 10000; ++guard) {
                 gc = gc_new;
-                Y_T = thomson_Y(e_over_B, P.p, gm, inv_gm, gc);
+                Y_T = thomson_Y_lg(e_over_B, P.p, gc < gm, log2_fast(gc) - lg2_gm);
                 gc_new = gamma_c_of(t_com, B, Y_T);
             }
             gc = gc_new;
