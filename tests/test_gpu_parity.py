@@ -436,6 +436,34 @@ def test_ssc_loglike_with_a_rejected_walker_between_valid_ones(eng, oracle):
         assert np.isfinite(alone[0]) and ll[w] == alone[0], (w, ll[w], alone[0])
 
 
+@pytest.mark.parametrize("jet,medium,kn", [("gaussian", "ism", True), ("tophat", "wind", True), ("powerlaw", "ism", False)])
+def test_no_walker_of_a_wide_ssc_box_leaves_its_clamped_table_band(eng, jet, medium, kn):
+    """Inside a likelihood call a walker whose SSC flux pass asks for a frequency outside its cells' clamped table band (but inside the
+    theoretical range) is not rebuilt unclamped as Model's entry points and the reference do (inverse-compton.h:626-635): it scores
+    -inf and is counted in n_walkers_ssc_failed.  The band is the extrema of the rows' Doppler factors widened by two octaves either
+    way (pymodel.h:896-909), the row-per-lane kernels' table logarithms are good to 1e-15, so no walker should ever get there: 512
+    draws of a wide box, data from radio to TeV over five decades of time, none fails and every ln L is finite."""
+    rng = np.random.default_rng(2024)
+    t = np.sort(10 ** rng.uniform(2.0, 7.0, 48))
+    nu = 10 ** rng.choice([9.0, 11.0, 14.7, 17.5, 20.0, 23.0, 26.0], size=t.size)
+    f = fitting.Fitter(z=0.5, lumi_dist=8e27, jet=jet, medium=medium, fwd_ssc=True, kn=kn)
+    f.add_flux_density(nu, t, np.full(t.size, 1e-28), np.full(t.size, 1e-29))
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e50, 1e54, S.log), P("Gamma0", 30, 800, S.log), P("theta_c", 0.03, 0.3, S.linear),
+            P("theta_v", 0.0, 0.6, S.linear), P("p", 2.05, 2.9, S.linear), P("eps_e", 3e-3, 0.4, S.log), P("eps_B", 1e-6, 1e-1, S.log),
+            P("xi_e", 1.0, 1.0, S.fixed, 1.0)]
+    defs.append(P("A_star", 1e-2, 3, S.log) if medium == "wind" else P("n_ism", 1e-3, 100, S.log))
+    if jet == "powerlaw":
+        defs += [P("k_e", 2.0, 2.0, S.fixed, 2.0), P("k_g", 2.0, 2.0, S.fixed, 2.0)]
+    free = [d for d in defs if d.scale is not S.fixed]
+    lo = np.array([np.log10(d.lower) if d.scale is S.log else d.lower for d in free])
+    hi = np.array([np.log10(d.upper) if d.scale is S.log else d.upper for d in free])
+    theta = lo + (hi - lo) * rng.random((512, len(free)))
+    ll = f.loglike_batch(theta, defs)
+    assert f.last_plan.n_walkers_ssc_failed == 0 and f.last_plan.n_walkers_rejected == 0
+    assert np.all(np.isfinite(ll))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Reverse-shock tier (SURVEY section 8(f) rank 2): Model(rvs_rad=Radiation(...))
 #

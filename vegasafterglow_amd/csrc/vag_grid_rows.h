@@ -95,7 +95,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         } else {
             SpecRegs regs;
 #pragma unroll
+#ifdef VAG_ROWS_ABLATE_LOADS  // timing experiment only: the node's constants without their memory round trip
+            for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K] + 1e-300 * k;
+#else
             for (int w = 0; w < 13; ++w) regs.v[w] = row[w * K + k];
+#endif
             regs.v[13] = lr2;
             if constexpr (MODE == FLUX_SYN_IC) {
                 const double* cq = a.cellq + cell0 * FLUX_NQ + k;
@@ -178,7 +182,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
                     const double w = (s_tobs[q] - lt_a) * inv_dt;  // position inside the interval, shared by the frequencies
 #pragma unroll
                     for (int b = 0; b < GRIDROWS_BANDS; ++b)
+#ifdef VAG_ROWS_ABLATE_ATOMICS  // timing experiment only: the sums kept in a register
+                        if (b < NB && isfinite(d[b])) Bcur[b] += 1e-300 * exp2_fast(fma(d[b], w, Bprev[b]));
+#else
                         if (b < NB && isfinite(d[b])) lds_add_f64(my_acc + b * nt + q, exp2_fast(fma(d[b], w, Bprev[b])));
+#endif
                 }
             }
 #pragma unroll
