@@ -730,15 +730,24 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
             b.termth = (fth + fthN) * hd * rth;
             return b;
         };
-        const Bin bm = bin_constants(lane);
-        // the tail pass: W lanes side by side for the bins 64 .. nu_last - 1, 64 / W chunks of T consecutive energies
-        const int n_tail = nu_last > 64 ? nu_last - 64 : 0;
+#ifndef VAG_IC_MAIN_BINS
+#define VAG_IC_MAIN_BINS 64  // bins of the main pass (test builds: 24 sends most bins of an ordinary cell through the tail pass)
+#endif
+        constexpr int MAIN = VAG_IC_MAIN_BINS;
+        static_assert(MAIN <= 64, "one main bin per lane");
+#if VAG_IC_MAIN_BINS < 64
+        if (nu_last - MAIN > 64) __builtin_trap();  // test builds: the tail pass holds at most 64 bins
+#endif
+        Bin bm = bin_constants(lane);
+        if (MAIN < 64 && lane >= MAIN) bm.bin = false;
+        // the tail pass: W lanes side by side for the bins MAIN .. nu_last - 1, 64 / W chunks of T consecutive energies
+        const int n_tail = nu_last > MAIN ? nu_last - MAIN : 0;
         int lgW = 3;
-        while ((1 << lgW) < n_tail) ++lgW;
+        while ((1 << lgW) < n_tail && lgW < 6) ++lgW;
         const int W = 1 << lgW, T = (g_size * W + 63) >> 6;
         const int i_tail0 = (lane >> lgW) * T;
         Bin bt = bm;
-        if (n_tail > 0) bt = bin_constants(64 + (lane & (W - 1)));
+        if (n_tail > 0) bt = bin_constants(MAIN + (lane & (W - 1)));
         __syncthreads();  // every setup array has been read: from here on their memory holds D / E / lat / dNe_i / split_i
         for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
         if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by
@@ -823,7 +832,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                 }
             }
         }
-        // Tail pass: lane (chunk c, bin 64 + w) walks the energies c T .. c T + T - 1
+        // Tail pass: lane (chunk c, bin MAIN + w) walks the energies c T .. c T + T - 1
         if (n_tail > 0 && g_run > 0) {
             for (int t = 0; t < T; ++t) {
                 const int i = i_tail0 + t;
