@@ -572,12 +572,25 @@ VAG_DEV int sload_i32(const int* p) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
     return v;
 }
+// The five geometry words of row (theta j, phi i) from a model's geo_th [3][VAG_MAX_THETA] and geo_ph [2][VAG_MAX_PHI]: TWO
+// addresses and the planes as immediate offsets -- five separate pointers cost the flux kernel ten scalar registers it does not have
+// (they were spilled to a VGPR and read back lane by lane, with a 64-bit add each, once per row and wavefront).
+VAG_DEV void sload_geo(const double* th_j, const double* ph_i, double& g_sin, double& g_cph, double& g_cos, double& g_dth, double& g_dph) {
+    asm volatile("s_load_dwordx2 %0, %5, %7\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %5, 0x0\n\ts_load_dwordx2 %3, %5, %8\n\t"
+                 "s_load_dwordx2 %4, %6, %9\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(g_sin), "=&s"(g_cph), "=&s"(g_cos), "=&s"(g_dth), "=&s"(g_dph)
+                 : "s"(th_j), "s"(ph_i), "i"(VAG_MAX_THETA * 8), "i"(2 * VAG_MAX_THETA * 8), "i"(VAG_MAX_PHI * 8)
+                 : "memory");
+}
 #else
 VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
                     double& v2, double& v3, double& v4) {
     v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
 }
 VAG_DEV int sload_i32(const int* p) { return *p; }
+VAG_DEV void sload_geo(const double* th_j, const double* ph_i, double& g_sin, double& g_cph, double& g_cos, double& g_dth, double& g_dph) {
+    g_sin = th_j[VAG_MAX_THETA], g_cph = ph_i[0], g_cos = th_j[0], g_dth = th_j[2 * VAG_MAX_THETA], g_dph = ph_i[VAG_MAX_PHI];
+}
 #endif
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
@@ -803,8 +816,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                            s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2, w_lo, w_hi);
         } else {
             double g_sin, g_cph, g_cos, g_dth, g_dph;
-            sload5(gth + VAG_MAX_THETA + j, gph + i, gth + j, gth + 2 * VAG_MAX_THETA + j, gph + VAG_MAX_PHI + i, g_sin, g_cph, g_cos, g_dth,
-                   g_dph);
+            sload_geo(gth + j, gph + i, g_sin, g_cph, g_cos, g_dth, g_dph);
             const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
             const double t_coeff = (1 - cos_v) * opz_over_c;
             const double lg2_dOmega = g_dth + g_dph;
@@ -1044,8 +1056,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                 [[maybe_unused]] const int ek = min(tid, K - 1);
                 if constexpr (decltype(with_eat)::value) {
                     double g_sin, g_cph, g_cos, g_dth, g_dph;
-                    sload5(gth + VAG_MAX_THETA + jn, gph + in_, gth + jn, gth + 2 * VAG_MAX_THETA + jn, gph + VAG_MAX_PHI + in_, g_sin, g_cph,
-                           g_cos, g_dth, g_dph);
+                    sload_geo(gth + jn, gph + in_, g_sin, g_cph, g_cos, g_dth, g_dph);
                     e_cos = g_sin * g_cph * sin_obs + g_cos * cos_obs;
                     e_tc = (1 - e_cos) * opz_over_c;
                     e_dom = g_dth + g_dph;
@@ -1142,8 +1153,7 @@ vag_flux_grid_kernel(FluxArgs a) {
             if (fuse_eat) {
                 if (THREADS < 512 && K > THREADS) {  // nodes beyond the first per lane (256-lane workgroups on long lattices); their counts join the first's
                     double g_sin, g_cph, g_cos, g_dth, g_dph;
-                    sload5(gth + VAG_MAX_THETA + jn, gph + in_, gth + jn, gth + 2 * VAG_MAX_THETA + jn, gph + VAG_MAX_PHI + in_, g_sin, g_cph,
-                           g_cos, g_dth, g_dph);
+                    sload_geo(gth + jn, gph + in_, g_sin, g_cph, g_cos, g_dth, g_dph);
                     const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
                     const double t_coeff = (1 - cos_v) * opz_over_c;
                     const double lg2_dOmega = g_dth + g_dph;
