@@ -1045,7 +1045,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #else
         const bool fuse_eat = !SPREAD && same_rep && in_window;
 #endif
-        if (same_rep && !fuse_eat) stage_and_eat(jn, in_, buf ^ 1);
+        if (__builtin_expect(same_rep && !fuse_eat, 0)) stage_and_eat(jn, in_, buf ^ 1);  // rare: keep its scalars out of the hot path's registers
         VAG_FLUX_MARK(3);
         if (in_window) {
             auto interp_group = [&](const int (&dq)[U], int slot0, auto with_eat, auto u_begin, auto u_end) {
@@ -1119,7 +1119,7 @@ vag_flux_grid_kernel(FluxArgs a) {
                     }
                 if constexpr (decltype(with_eat)::value) {
                     if (sp_a) e_dop = -log2(fma(-e_Gu.y, e_cos, e_Gu.x));  // never in practice: arguments the table does not serve
-                    if (sp_b) e_lt = log2(fma(e_tc, e_rt.x, e_rt.y * one_plus_z));
+                    if (__builtin_expect(sp_b, 0)) e_lt = log2(fma(e_tc, e_rt.x, e_rt.y * one_plus_z));
                     WinCount wc;
                     wc.add(tid < K, e_lt, w_lo, w_hi);
                     wc.store(s_win + (buf ^ 1) * 2, tid);
@@ -1179,7 +1179,7 @@ vag_flux_grid_kernel(FluxArgs a) {
 #endif
         __syncthreads();
         VAG_FLUX_MARK(5);
-        if (have_next && !same_rep) {
+        if (__builtin_expect(have_next && !same_rep, 0)) {  // once per theta row
             stage_row(jn, in_);
             __syncthreads();
             stage_and_eat(jn, in_, buf ^ 1);
