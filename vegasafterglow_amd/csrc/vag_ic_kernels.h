@@ -453,7 +453,8 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 // done here at 1/64 of the cost and handed over in the cell's own table row: the header words [0..4] are final, the words from
 // IC_HDR on carry the plan until vag_ic_photon_kernel replaces them by the table.  Cells that get no table (failed model,
 // degenerate or over-capacity lattice) are finished here: n = 0 and the theoretical range.
-enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX, ICP_N };
+enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX,
+       ICP_SMOOTH_THICK, ICP_LOG2_X_FAR /* SpecConst of the model's p: a division and a library log2 per wavefront otherwise */, ICP_N };
 __global__ void __launch_bounds__(256)
 vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
@@ -533,6 +534,10 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
     tab[IC_HDR + ICP_LG2_GM] = log2(gamma_m);  // uniform factors of the electron distribution (sample_distributions)
     tab[IC_HDR + ICP_INV_GM] = 1 / gamma_m;
     tab[IC_HDR + ICP_INV_GMAX] = 1 / gamma_M;
+    SpecConst sc;
+    sc.init(params[m].p);
+    tab[IC_HDR + ICP_SMOOTH_THICK] = sc.smooth_thick;
+    tab[IC_HDR + ICP_LOG2_X_FAR] = sc.log2_x_far;
 }
 
 __global__ void __launch_bounds__(64, VAG_IC_WAVES)
@@ -615,7 +620,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #endif
     // sample_distributions, inverse-compton.h:371-399
     SpecConst sc;
-    sc.init(P.p);
+    sc.smooth_thick = tab[IC_HDR + ICP_SMOOTH_THICK], sc.log2_x_far = tab[IC_HDR + ICP_LOG2_X_FAR];  // sc.init(P.p), done by the plan kernel
     // SynElectrons::compute_column_den (synchrotron.cpp:261-309) / gamma^2 * dgamma at the lattice energies: log2(gamma) is the
     // node's own exponent, the cell-uniform factors come from the plan, the two exponentials of a branch are one exp2
     const bool slow = regime == 1 || regime == 2 || regime == 5, fast = regime == 3 || regime == 4 || regime == 6;
