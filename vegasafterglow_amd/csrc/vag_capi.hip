@@ -328,6 +328,9 @@ struct vag_ctx {
     bool spec_pending = false;    // the current call was planned from the hint and has not been verified yet
     VagDevPlan* d_hplan = nullptr;  // device address of h_plan
     int plan_seq = 0;
+    bool layout_large = false;  // vag_grid_kernel's layout of the batch at hand
+    DevBuf d_rowgeo;            // row-geometry records of the flux grid kernel (vag_rowgeo_kernel), filled once per batch
+    int rowgeo_seq = -1, rowgeo_stride = 0;
     bool plan_counter_ready = false;
     // named-stage profiler (vag_ctx_profile): spans of (stage id, begin event, end event) recorded during a call
     bool prof_on = false;
@@ -794,6 +797,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     HIPCHK(hipEventRecord(c->ev[0], st));
     std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
     auto launch_grid = [&](bool large) {
+        c->layout_large = large;  // the layout THIS batch is laid out with (c->grid_large may change below for the next one)
         auto kern = large ? vag_grid_kernel<true> : vag_grid_kernel<false>;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                            c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
@@ -1063,6 +1067,21 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.ic_status = c->d_icstatus.as<int>();
     a.cellgeo = c->d_cellgeo.as<double>();
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
+    a.rowgeo = nullptr;
+    a.rowgeo_stride = 0;
+    if (!spreading) {  // the model's row-geometry records (once per laid-out batch, whatever passes follow)
+        const int stride = ROWGEO_HDR + 2 * (c->layout_large ? VAG_MAX_PHI : VAG_GRID_PHI) + 4 * (c->layout_large ? VAG_MAX_THETA : VAG_GRID_THETA);
+        if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * stride)) return VAG_E_HIP;
+        if (c->rowgeo_seq != c->plan_seq || c->rowgeo_stride != stride) {
+            hipLaunchKernelGGL(vag_rowgeo_kernel, dim3(nb), dim3(256), 0, st, c->d_meta.as<VagGridMeta>(), c->d_geo_th.as<double>(),
+                               c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(), c->d_rowgeo.as<double>(), stride);
+            HIPCHK(hipGetLastError());
+            c->rowgeo_seq = c->plan_seq;
+            c->rowgeo_stride = stride;
+        }
+        a.rowgeo = c->d_rowgeo.as<double>();
+        a.rowgeo_stride = stride;
+    }
     if (c->count_work && mode == FLUX_SYN && !spreading) {
         if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
         HIPCHK(hipMemsetAsync(c->d_workcount.p, 0, 2 * sizeof(unsigned long long), st));

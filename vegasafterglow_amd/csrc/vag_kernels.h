@@ -511,7 +511,45 @@ struct FluxArgs {
     const double* ictab;   // [cells][IC_STRIDE] SSC tables (MODE 2)
     int* ic_status;        // [nb] bit 2: band-contract breach seen by the SSC flux pass
     const double* cellgeo; // [rows][3][n_t] per-cell cos(theta), sin(theta), log2|dcos| of a spreading jet (SPREAD kernels)
+    const double* rowgeo;  // [nb][rowgeo_stride] row-geometry records of vag_rowgeo_kernel (non-spreading kernels)
+    int rowgeo_stride;
 };
+
+// Row-geometry records of one model, for the flux grid kernel's scalar loads: everything a (theta j, phi i) row needs sits behind
+// ONE base address -- header {cos theta_obs, sin theta_obs, byte offset of the theta records, -}, phi records {cos phi, log2 dphi}
+// from double 4 on, theta records {cos theta, sin theta, log2 |dcos theta|, representative row (int)} behind them.  The kernel is out
+// of scalar registers: five base pointers, two observer constants and the rep_of pointer were ten spilled registers read back
+// lane by lane once per row and wavefront.
+constexpr int ROWGEO_HDR = 4;
+__global__ void __launch_bounds__(256)
+vag_rowgeo_kernel(const VagGridMeta* __restrict__ meta, const double* __restrict__ geo_th, const double* __restrict__ geo_ph,
+                  const int* __restrict__ g_rep_of, double* __restrict__ rowgeo, int stride) {
+    const int m = blockIdx.x;
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) return;
+    double* rg = rowgeo + (size_t)m * stride;
+    const double* gth = geo_th + (size_t)m * 3 * VAG_MAX_THETA;
+    const double* gph = geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int th_off = ROWGEO_HDR + 2 * M.n_phi_eff;  // doubles
+    if (threadIdx.x == 0) {
+        rg[0] = M.cos_obs;
+        rg[1] = M.sin_obs;
+        rg[2] = __hiloint2double(0, th_off * 8);
+        rg[3] = 0;
+    }
+    for (int i = threadIdx.x; i < M.n_phi_eff; i += blockDim.x) {
+        rg[ROWGEO_HDR + 2 * i] = gph[i];
+        rg[ROWGEO_HDR + 2 * i + 1] = gph[VAG_MAX_PHI + i];
+    }
+    for (int j = threadIdx.x; j < M.n_theta; j += blockDim.x) {
+        double* r = rg + th_off + 4 * j;
+        r[0] = gth[j];
+        r[1] = gth[VAG_MAX_THETA + j];
+        r[2] = gth[2 * VAG_MAX_THETA + j];
+        r[3] = __hiloint2double(0, rep_of[j]);
+    }
+}
 
 // photon source of the flux kernels
 constexpr int FLUX_SYN = 0;     // synchrotron, no inverse-Compton cooling
@@ -582,7 +620,48 @@ VAG_DEV void sload_geo(const double* th_j, const double* ph_i, double& g_sin, do
                  : "s"(th_j), "s"(ph_i), "i"(VAG_MAX_THETA * 8), "i"(2 * VAG_MAX_THETA * 8), "i"(VAG_MAX_PHI * 8)
                  : "memory");
 }
+typedef int vag_v8i __attribute__((ext_vector_type(8)));
+typedef int vag_v4i __attribute__((ext_vector_type(4)));
+struct RowGeo {
+    double cos_th, sin_th, dth, cph, dph, cos_obs, sin_obs;
+    int rep;
+    // cos of the angle to the line of sight, sin th cos ph sin th_obs + cos th cos th_obs (observer.cpp:143-160), with its roundings
+    // spelled out: left to the compiler's contraction the instantiations of the flux kernel round it differently, and a model's
+    // fluxes must not depend on which of them served it
+    VAG_DEV double cos_view() const { return fma(cos_th, cos_obs, (sin_th * cph) * sin_obs); }
+};
+// row (theta j, phi i) from the model's records: three scalar loads behind one base (offsets in scalar registers)
+VAG_DEV RowGeo sload_rowgeo(const double* rg, int th_byte, int j, int i) {
+    vag_v8i t;
+    vag_v4i p, h;
+    asm volatile("s_load_dwordx8 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx4 %2, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t), "=&s"(p), "=&s"(h)
+                 : "s"(rg), "s"(th_byte + 32 * j), "s"(ROWGEO_HDR * 8 + 16 * i)
+                 : "memory");
+    RowGeo g;
+    g.cos_th = __hiloint2double(t[1], t[0]), g.sin_th = __hiloint2double(t[3], t[2]), g.dth = __hiloint2double(t[5], t[4]);
+    g.rep = t[6];
+    g.cph = __hiloint2double(p[1], p[0]), g.dph = __hiloint2double(p[3], p[2]);
+    g.cos_obs = __hiloint2double(h[1], h[0]), g.sin_obs = __hiloint2double(h[3], h[2]);
+    return g;
+}
 #else
+struct RowGeo {
+    double cos_th, sin_th, dth, cph, dph, cos_obs, sin_obs;
+    int rep;
+    // cos of the angle to the line of sight, sin th cos ph sin th_obs + cos th cos th_obs (observer.cpp:143-160), with its roundings
+    // spelled out: left to the compiler's contraction the instantiations of the flux kernel round it differently, and a model's
+    // fluxes must not depend on which of them served it
+    VAG_DEV double cos_view() const { return fma(cos_th, cos_obs, (sin_th * cph) * sin_obs); }
+};
+VAG_DEV RowGeo sload_rowgeo(const double* rg, int th_byte, int j, int i) {
+    const double* t = rg + th_byte / 8 + 4 * j;
+    const double* p = rg + ROWGEO_HDR + 2 * i;
+    RowGeo g;
+    g.cos_th = t[0], g.sin_th = t[1], g.dth = t[2], g.rep = __double2loint(t[3]);
+    g.cph = p[0], g.dph = p[1], g.cos_obs = rg[0], g.sin_obs = rg[1];
+    return g;
+}
 VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
                     double& v2, double& v3, double& v4) {
     v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
@@ -762,10 +841,18 @@ vag_flux_grid_kernel(FluxArgs a) {
     }
     SpecConst sc;
     sc.init(Pp->p);
-    const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;
+    const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;  // (SPREAD kernels; the others read them with the row's record)
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const int rep_stride = Mp->rep_phi_stride;  // (phi, theta) pair rows of a non-axisymmetric spreading jet: row = rep_of[j] + i * stride
-    auto rep_at = [&](int j, int i) { return sload_i32(rep_of + j) + i * rep_stride; };
+    // non-spreading kernels: the model's row-geometry records (vag_rowgeo_kernel), one base address for everything a row needs
+    const double* rg = a.rowgeo + (size_t)m * a.rowgeo_stride;
+    const int rg_th = SPREAD ? 0 : sload_i32(reinterpret_cast<const int*>(rg + 2));  // byte offset of the theta records
+    auto rep_at = [&](int j, int i) {
+        if constexpr (SPREAD)
+            return sload_i32(rep_of + j) + i * rep_stride;
+        else
+            return sload_i32(reinterpret_cast<const int*>(reinterpret_cast<const char*>(rg) + rg_th + 32 * j + 24));
+    };
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     // A lane owns the slots tid + r * THREADS (slot = l * nt + idx): always the same lane per slot, so the LDS accumulator needs no
     // atomics and the sum order is fixed.  The interpolation phase takes them U at a time; the first U -- all of them for
@@ -815,11 +902,10 @@ vag_flux_grid_kernel(FluxArgs a) {
             eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
                            s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2, w_lo, w_hi);
         } else {
-            double g_sin, g_cph, g_cos, g_dth, g_dph;
-            sload_geo(gth + j, gph + i, g_sin, g_cph, g_cos, g_dth, g_dph);
-            const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
+            const RowGeo g = sload_rowgeo(rg, rg_th, j, i);
+            const double cos_v = g.cos_view();
             const double t_coeff = (1 - cos_v) * opz_over_c;
-            const double lg2_dOmega = g_dth + g_dph;
+            const double lg2_dOmega = g.dth + g.dph;
             eat_row(s_par, KS, K, etid, THREADS, cos_v, t_coeff, one_plus_z, lg2_dOmega, s_t + buf * KS, s_dop, s_geom, lg_tab,
                     s_win + buf * 2, w_lo, w_hi);
         }
@@ -1055,11 +1141,10 @@ vag_flux_grid_kernel(FluxArgs a) {
                 [[maybe_unused]] double e_r2 = 0, e_cos = 0, e_tc = 0, e_dom = 0;
                 [[maybe_unused]] const int ek = min(tid, K - 1);
                 if constexpr (decltype(with_eat)::value) {
-                    double g_sin, g_cph, g_cos, g_dth, g_dph;
-                    sload_geo(gth + jn, gph + in_, g_sin, g_cph, g_cos, g_dth, g_dph);
-                    e_cos = g_sin * g_cph * sin_obs + g_cos * cos_obs;
+                    const RowGeo g = sload_rowgeo(rg, rg_th, jn, in_);
+                    e_cos = g.cos_view();
                     e_tc = (1 - e_cos) * opz_over_c;
-                    e_dom = g_dth + g_dph;
+                    e_dom = g.dth + g.dph;
                     const double* c = s_par + ek * VAG_NPAR;
                     const LdsTab c2 = lds_tab(c);
                     e_Gu = c2[VP_GAMMA / 2], e_rt = c2[VP_R / 2];
@@ -1152,11 +1237,10 @@ vag_flux_grid_kernel(FluxArgs a) {
             }
             if (fuse_eat) {
                 if (THREADS < 512 && K > THREADS) {  // nodes beyond the first per lane (256-lane workgroups on long lattices); their counts join the first's
-                    double g_sin, g_cph, g_cos, g_dth, g_dph;
-                    sload_geo(gth + jn, gph + in_, g_sin, g_cph, g_cos, g_dth, g_dph);
-                    const double cos_v = g_sin * g_cph * sin_obs + g_cos * cos_obs;
+                    const RowGeo g = sload_rowgeo(rg, rg_th, jn, in_);
+                    const double cos_v = g.cos_view();
                     const double t_coeff = (1 - cos_v) * opz_over_c;
-                    const double lg2_dOmega = g_dth + g_dph;
+                    const double lg2_dOmega = g.dth + g.dph;
                     WinCount wc;
                     for (int k = tid + THREADS; k < K; k += THREADS) {
                         const double* c = s_par + k * VAG_NPAR;
