@@ -594,31 +594,13 @@ struct WinCount {
 };
 
 // Uniform values straight into scalar registers.  The compiler reads the per-row geometry with vector loads (it cannot prove that
-// the kernel's own global stores do not alias it): five 500-cycle round trips that every wavefront sat out at the start of each
-// row's second interval.  s_load through the scalar cache instead (the arrays were written by an earlier kernel).
+// the kernel's own global stores do not alias it): 500-cycle round trips that every wavefront sat out at the start of each
+// row's second interval.  s_load through the scalar cache instead (the records were written by an earlier kernel).
 #ifndef VAG_HOST_DEBUG
-VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
-                    double& v2, double& v3, double& v4) {
-    asm volatile("s_load_dwordx2 %0, %5, 0x0\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %7, 0x0\n\ts_load_dwordx2 %3, %8, 0x0\n\t"
-                 "s_load_dwordx2 %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4)
-                 : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4)
-                 : "memory");
-}
 VAG_DEV int sload_i32(const int* p) {
     int v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p) : "memory");
     return v;
-}
-// The five geometry words of row (theta j, phi i) from a model's geo_th [3][VAG_MAX_THETA] and geo_ph [2][VAG_MAX_PHI]: TWO
-// addresses and the planes as immediate offsets -- five separate pointers cost the flux kernel ten scalar registers it does not have
-// (they were spilled to a VGPR and read back lane by lane, with a 64-bit add each, once per row and wavefront).
-VAG_DEV void sload_geo(const double* th_j, const double* ph_i, double& g_sin, double& g_cph, double& g_cos, double& g_dth, double& g_dph) {
-    asm volatile("s_load_dwordx2 %0, %5, %7\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %5, 0x0\n\ts_load_dwordx2 %3, %5, %8\n\t"
-                 "s_load_dwordx2 %4, %6, %9\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(g_sin), "=&s"(g_cph), "=&s"(g_cos), "=&s"(g_dth), "=&s"(g_dph)
-                 : "s"(th_j), "s"(ph_i), "i"(VAG_MAX_THETA * 8), "i"(2 * VAG_MAX_THETA * 8), "i"(VAG_MAX_PHI * 8)
-                 : "memory");
 }
 typedef int vag_v8i __attribute__((ext_vector_type(8)));
 typedef int vag_v4i __attribute__((ext_vector_type(4)));
@@ -662,14 +644,7 @@ VAG_DEV RowGeo sload_rowgeo(const double* rg, int th_byte, int j, int i) {
     g.cph = p[0], g.dph = p[1], g.cos_obs = rg[0], g.sin_obs = rg[1];
     return g;
 }
-VAG_DEV void sload5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, double& v0, double& v1,
-                    double& v2, double& v3, double& v4) {
-    v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
-}
 VAG_DEV int sload_i32(const int* p) { return *p; }
-VAG_DEV void sload_geo(const double* th_j, const double* ph_i, double& g_sin, double& g_cph, double& g_cos, double& g_dth, double& g_dph) {
-    g_sin = th_j[VAG_MAX_THETA], g_cph = ph_i[0], g_cos = th_j[0], g_dth = th_j[2 * VAG_MAX_THETA], g_dph = ph_i[VAG_MAX_PHI];
-}
 #endif
 
 // EAT quantities of one (theta j, phi i) row: Doppler, observer time and geometry logs
