@@ -472,10 +472,17 @@ def main():
         import socket
         sk = socket.socket()
         sk.bind(("127.0.0.1", 0))
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        port = sk.getsockname()[1]
         sk.close()
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        # a private tcp:// rendezvous; under torch.distributed.run (N = 1 launched through it) c10d would otherwise connect to the
+        # launcher's store as a client -- on a port nobody serves -- and wait for its timeout
+        agent_store = os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        finally:
+            if agent_store is not None:
+                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = agent_store
         try:
             plain = {1024: walkers, 512: walkers_half, 128: s128, 64: s64}
             sharded1 = {"note": "dist.WalkerSharder's sharded branch over a world-size-1 nccl (RCCL) group on this GPU vs the plain "
