@@ -795,11 +795,11 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                 if (b.j >= j_split) {
                     asm volatile("");
                     const double u = b.A * nd0.x;
-                    if (b.pos) {
+                    if (__builtin_expect(b.pos, 1)) {
                         asm volatile("");
                         const double s1 = fma(nd1.y - nd0.y, b.ilr, b.s_th);
                         ve = u * b.Lr;
-                        if (fabs(s1) > 1e-3) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
+                        if (__builtin_expect(fabs(s1) > 1e-3, 1)) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
                             asm volatile("");
                             ve = fma(b.AN, cN, -u) * rcp_ode(s1);
                         }
