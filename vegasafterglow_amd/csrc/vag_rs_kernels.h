@@ -165,15 +165,15 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
 #ifdef VAG_PAIR_STAMPS
         ++n_waves_att;
 #endif
-        if (!st.step(eq)) {
+        if (__builtin_expect(!st.step(eq), 0)) {
             status = 1;
             break;
         }
-        if (++steps > 100000) {
+        if (__builtin_expect(++steps > 100000, 0)) {
             status = 2;
             break;
         }
-        if (st.t + st.dt == st.t) {  // dt below one ulp of t: the reference gives up on this row
+        if (__builtin_expect(st.t + st.dt == st.t, 0)) {  // dt below one ulp of t: the reference gives up on this row
             status = 3;
             break;
         }
@@ -181,7 +181,7 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
 #ifdef VAG_PAIR_STAMPS
         ++n_steps;
 #endif
-        if (crossing && eq.crossing_complete(st.x, st.t)) {  // locate_crossing_time, reverse-shock.tpp:484-497
+        if (__builtin_expect(crossing && eq.crossing_complete(st.x, st.t), 0)) {  // locate_crossing_time, reverse-shock.tpp:484-497
             double t_lo = t_step_start, t_hi = st.t;
             double q[RS_N];
             for (int iter = 0; iter < 100 && (t_hi - t_lo) > 1e-12 * t_hi; ++iter) {
