@@ -45,6 +45,10 @@ int set_err(int code, const char* fmt, ...) {
     } while (0)
 
 // grow-only device buffer
+static int rowgeo_stride(bool large) {  // doubles per model of the row-geometry records (vag_grid_kernel.h)
+    return VAG_ROWGEO_HDR + 2 * (large ? VAG_MAX_PHI : VAG_GRID_PHI) + 4 * (large ? VAG_MAX_THETA : VAG_GRID_THETA);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -329,8 +333,7 @@ struct vag_ctx {
     VagDevPlan* d_hplan = nullptr;  // device address of h_plan
     int plan_seq = 0;
     bool layout_large = false;  // vag_grid_kernel's layout of the batch at hand
-    DevBuf d_rowgeo;            // row-geometry records of the flux grid kernel (vag_rowgeo_kernel), filled once per batch
-    int rowgeo_seq = -1, rowgeo_stride = 0;
+    DevBuf d_rowgeo;            // row-geometry records for the flux grid kernel, written by the grid kernel
     bool plan_counter_ready = false;
     // named-stage profiler (vag_ctx_profile): spans of (stage id, begin event, end event) recorded during a call
     bool prof_on = false;
@@ -796,6 +799,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->prof_used = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
     std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
+    if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(c->grid_large))) return VAG_E_HIP;
     auto launch_grid = [&](bool large) {
         c->layout_large = large;  // the layout THIS batch is laid out with (c->grid_large may change below for the next one)
         auto kern = large ? vag_grid_kernel<true> : vag_grid_kernel<false>;
@@ -805,7 +809,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
                            c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
                            cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
-                           spec ? c->hint.dyn_class : 0, c->d_cost_f.as<float>());
+                           spec ? c->hint.dyn_class : 0, c->d_cost_f.as<float>(), c->d_rowgeo.as<double>());
     };
     launch_grid(c->grid_large);
     ps_grid.reset();
@@ -821,6 +825,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             // some model's angular grid outgrew the small layout of the grid kernel: lay the batch out again with the large one
             // (the same grids for every model that fitted), and keep using it while the caller keeps sending such models
             c->grid_large = true;
+            if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(true))) return VAG_E_HIP;
             if (std::getenv("VAG_DEBUG_LAUNCH"))
                 std::fprintf(stderr, "[vag] grid: %d of %d models over the small layout's capacity, laying the batch out again\n", hp->n_capacity, nb);
             launch_grid(true);
@@ -1069,18 +1074,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
     a.rowgeo = nullptr;
     a.rowgeo_stride = 0;
-    if (!spreading) {  // the model's row-geometry records (once per laid-out batch, whatever passes follow)
-        const int stride = ROWGEO_HDR + 2 * (c->layout_large ? VAG_MAX_PHI : VAG_GRID_PHI) + 4 * (c->layout_large ? VAG_MAX_THETA : VAG_GRID_THETA);
-        if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * stride)) return VAG_E_HIP;
-        if (c->rowgeo_seq != c->plan_seq || c->rowgeo_stride != stride) {
-            hipLaunchKernelGGL(vag_rowgeo_kernel, dim3(nb), dim3(256), 0, st, c->d_meta.as<VagGridMeta>(), c->d_geo_th.as<double>(),
-                               c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(), c->d_rowgeo.as<double>(), stride);
-            HIPCHK(hipGetLastError());
-            c->rowgeo_seq = c->plan_seq;
-            c->rowgeo_stride = stride;
-        }
+    if (!spreading) {  // the models' row-geometry records, written by the grid kernel with the layout it ran with
         a.rowgeo = c->d_rowgeo.as<double>();
-        a.rowgeo_stride = stride;
+        a.rowgeo_stride = rowgeo_stride(c->layout_large);
     }
     if (c->count_work && mode == FLUX_SYN && !spreading) {
         if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;

@@ -10,6 +10,7 @@
 #define VAG_MAX_PHI 2560    // phi nodes per model
 #define VAG_GRID_THETA 320  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
 #define VAG_GRID_PHI 640    //   with the large layout (vag_grid_kernel<true>)
+#define VAG_ROWGEO_HDR 4    // doubles ahead of a model's row-geometry records (vag_grid_kernel.h writes them, the flux grid kernel reads them)
 #define VAG_MAX_TIME 8192   // time-lattice nodes per row (the flux kernels stage at most 512 at a time and take longer lattices in pieces)
 #define VAG_MAX_NU 64       // frequencies per grid call
 #define VAG_MAX_JUMPS 16

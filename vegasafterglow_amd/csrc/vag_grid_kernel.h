@@ -425,7 +425,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
                 double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
                 double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */,
-                int* __restrict__ fail /* [4] ODE-row failure counters of the dynamics stage, reset here */) {
+                int* __restrict__ fail /* [4] ODE-row failure counters of the dynamics stage, reset here */,
+                double* __restrict__ g_rowgeo /* [nb][VAG_ROWGEO_HDR + 2 SH::max_phi + 4 SH::max_theta]: the same geometry as records */) {
     const int m = blockIdx.x;
     const int lane = threadIdx.x;
     if (m == 0 && lane < 4) fail[lane] = 0;
@@ -993,20 +994,38 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
     // Geometry factors of the equal-arrival-time step that depend on the angular grid only
     // (calc_eat_non_spreading + compute_dphi, src/core/observer.cpp:17-37,143-188): computed once per model
     // here instead of once per (theta, phi) row in the flux kernel.
+    M.cos_obs = cos(theta_v);
+    M.sin_obs = sin(theta_v);
     {
         double* gth = g_geo_th + (size_t)m * 3 * VAG_MAX_THETA;
         double* gph = g_geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+        // The same numbers once more as ROW-GEOMETRY RECORDS behind one base address per model, for the workgroup flux kernel's
+        // scalar loads (it is out of scalar registers for five plane pointers, the rep_of pointer and the observer constants):
+        // header {cos theta_obs, sin theta_obs, byte offset of the theta records, -}, phi records {cos phi, log2 dphi} from
+        // double VAG_ROWGEO_HDR on, theta records {cos theta, sin theta, log2 |dcos theta|, representative row (int)} behind them.
+        double* rg = g_rowgeo + (size_t)m * (VAG_ROWGEO_HDR + 2 * SH::max_phi + 4 * SH::max_theta);
+        const int npe = M.n_phi_eff;
+        const int rg_th = VAG_ROWGEO_HDR + 2 * npe;
+        const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;  // written above, a barrier ago
+        if (lane == 0) {
+            rg[0] = M.cos_obs;
+            rg[1] = M.sin_obs;
+            rg[2] = __hiloint2double(0, rg_th * 8);
+            rg[3] = 0;
+        }
         const int last = n_theta - 1;
         for (int j = lane; j < n_theta; j += WAVE) {
             const double th = sh.theta[j];
             const double ct = cos(th);
             const double cos_lo = (j == 0) ? ct : cos(0.5 * (sh.theta[j - 1] + th));
             const double cos_hi = (j == last) ? ct : cos(0.5 * (th + sh.theta[j + 1]));
+            const double st = sin(th), ld = log2(fabs(cos_hi - cos_lo));
             gth[j] = ct;
-            gth[VAG_MAX_THETA + j] = sin(th);
-            gth[2 * VAG_MAX_THETA + j] = log2(fabs(cos_hi - cos_lo));
+            gth[VAG_MAX_THETA + j] = st;
+            gth[2 * VAG_MAX_THETA + j] = ld;
+            double* r = rg + rg_th + 4 * j;
+            r[0] = ct, r[1] = st, r[2] = ld, r[3] = __hiloint2double(0, rep_of[j]);
         }
-        const int npe = M.n_phi_eff;
         for (int i = lane; i < npe; i += WAVE) {
             double dphi;
             if (npe == 1) {
@@ -1018,12 +1037,13 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             } else {
                 dphi = 0.5 * (sh.phi[min(i + 1, npe - 1)] - sh.phi[i > 0 ? i - 1 : 0]);
             }
-            gph[i] = cos(sh.phi[i]);
-            gph[VAG_MAX_PHI + i] = log2(fabs(dphi));
+            const double cp = cos(sh.phi[i]), ldp = log2(fabs(dphi));
+            gph[i] = cp;
+            gph[VAG_MAX_PHI + i] = ldp;
+            rg[VAG_ROWGEO_HDR + 2 * i] = cp;
+            rg[VAG_ROWGEO_HDR + 2 * i + 1] = ldp;
         }
     }
-    M.cos_obs = cos(theta_v);
-    M.sin_obs = sin(theta_v);
     M.lg2_1pz = log2(1 + z);
     if (lane == 0) meta[m] = M;
     VAG_GRID_STAMP(8);
@@ -1046,11 +1066,12 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 double* __restrict__ g_geo_th, double* __restrict__ g_geo_ph, int* __restrict__ fail,
                 int* __restrict__ done_counter /* zero between launches */, int* __restrict__ row_off,
                 long long* __restrict__ cell_off, VagDevPlan* __restrict__ plan, VagDevPlan* host_plan, int seq, int cap_rows,
-                long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn, float* __restrict__ cost) {
+                long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn, float* __restrict__ cost,
+                double* __restrict__ g_rowgeo) {
     using Shared = typename std::conditional<LARGE, GridSharedT<VAG_MAX_THETA, VAG_MAX_PHI>, GridSharedT<VAG_GRID_THETA, VAG_GRID_PHI>>::type;
     __shared__ Shared sh;  // declared here, not in grid_model: LDS of a device function is charged to every kernel of the module
     if ((int)blockIdx.x < nb)
-        grid_model<Shared>(sh, params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail);
+        grid_model<Shared>(sh, params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail, g_rowgeo);
     __shared__ int s_last;
     __threadfence();  // this model's results are visible device-wide before the ticket is taken
     __syncthreads();

@@ -511,45 +511,11 @@ struct FluxArgs {
     const double* ictab;   // [cells][IC_STRIDE] SSC tables (MODE 2)
     int* ic_status;        // [nb] bit 2: band-contract breach seen by the SSC flux pass
     const double* cellgeo; // [rows][3][n_t] per-cell cos(theta), sin(theta), log2|dcos| of a spreading jet (SPREAD kernels)
-    const double* rowgeo;  // [nb][rowgeo_stride] row-geometry records of vag_rowgeo_kernel (non-spreading kernels)
+    const double* rowgeo;  // [nb][rowgeo_stride] row-geometry records written by vag_grid_kernel (read by the non-spreading kernels)
     int rowgeo_stride;
 };
 
-// Row-geometry records of one model, for the flux grid kernel's scalar loads: everything a (theta j, phi i) row needs sits behind
-// ONE base address -- header {cos theta_obs, sin theta_obs, byte offset of the theta records, -}, phi records {cos phi, log2 dphi}
-// from double 4 on, theta records {cos theta, sin theta, log2 |dcos theta|, representative row (int)} behind them.  The kernel is out
-// of scalar registers: five base pointers, two observer constants and the rep_of pointer were ten spilled registers read back
-// lane by lane once per row and wavefront.
-constexpr int ROWGEO_HDR = 4;
-__global__ void __launch_bounds__(256)
-vag_rowgeo_kernel(const VagGridMeta* __restrict__ meta, const double* __restrict__ geo_th, const double* __restrict__ geo_ph,
-                  const int* __restrict__ g_rep_of, double* __restrict__ rowgeo, int stride) {
-    const int m = blockIdx.x;
-    const VagGridMeta M = meta[m];
-    if (M.status != 0) return;
-    double* rg = rowgeo + (size_t)m * stride;
-    const double* gth = geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-    const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
-    const int th_off = ROWGEO_HDR + 2 * M.n_phi_eff;  // doubles
-    if (threadIdx.x == 0) {
-        rg[0] = M.cos_obs;
-        rg[1] = M.sin_obs;
-        rg[2] = __hiloint2double(0, th_off * 8);
-        rg[3] = 0;
-    }
-    for (int i = threadIdx.x; i < M.n_phi_eff; i += blockDim.x) {
-        rg[ROWGEO_HDR + 2 * i] = gph[i];
-        rg[ROWGEO_HDR + 2 * i + 1] = gph[VAG_MAX_PHI + i];
-    }
-    for (int j = threadIdx.x; j < M.n_theta; j += blockDim.x) {
-        double* r = rg + th_off + 4 * j;
-        r[0] = gth[j];
-        r[1] = gth[VAG_MAX_THETA + j];
-        r[2] = gth[2 * VAG_MAX_THETA + j];
-        r[3] = __hiloint2double(0, rep_of[j]);
-    }
-}
+constexpr int ROWGEO_HDR = VAG_ROWGEO_HDR;  // row-geometry records of a model: written by vag_grid_kernel (vag_grid_kernel.h), layout there
 
 // photon source of the flux kernels
 constexpr int FLUX_SYN = 0;     // synchrotron, no inverse-Compton cooling
