@@ -785,7 +785,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;  // (SPREAD kernels; the others read them with the row's record)
     const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
     const int rep_stride = Mp->rep_phi_stride;  // (phi, theta) pair rows of a non-axisymmetric spreading jet: row = rep_of[j] + i * stride
-    // non-spreading kernels: the model's row-geometry records (vag_rowgeo_kernel), one base address for everything a row needs
+    // non-spreading kernels: the model's row-geometry records (written by vag_grid_kernel), one base address for everything a row needs
     const double* rg = a.rowgeo + (size_t)m * a.rowgeo_stride;
     const int rg_th = SPREAD ? 0 : sload_i32(reinterpret_cast<const int*>(rg + 2));  // byte offset of the theta records
     auto rep_at = [&](int j, int i) {
