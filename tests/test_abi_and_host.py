@@ -432,6 +432,34 @@ def test_custom_extinction_callables_in_either_signature():
         needs._k_lambda(lam)
 
 
+def test_extinction_kernel_follows_a_fixed_z_and_outlives_later_specs():
+    """A fixed 'z' ParamDef moves the law's rest-frame wavelengths; a later spec WITHOUT a fixed z goes back to Fitter.z (no
+    KeyError), every spec keeps pointing at a live array of its own z, and a free 'z' next to an extinction law is refused."""
+    from vegasafterglow_amd import fitting
+    P, S = fitting.ParamDef, fitting.Scale
+    f = fitting.Fitter(z=0.5, lumi_dist=1e28, jet="tophat", medium="ism", extinction=lambda l: 5.5e-5 / l)
+    nu = np.array([3e14, 5e14, 8e14])
+    f.add_flux_density(nu, np.array([1e4, 1e5, 1e6]), np.array([1e-26, 1e-27, 1e-28]), np.array([1e-27, 1e-28, 1e-29]))
+    free = [P("E_iso", 1e50, 1e54, S.log), P("A_V", 0.0, 1.0, S.linear)]
+    kern = lambda z: 0.4 * np.log(10.0) * 5.5e-5 / ((2.99792458e10 / nu) / (1.0 + z))
+    read = lambda spec: np.array([spec.ext_kernel[i] for i in range(3)])
+    s_own, _, _ = f.build_spec(free)
+    np.testing.assert_allclose(read(s_own), kern(0.5), rtol=1e-15)
+    s_fix, _, _ = f.build_spec(free + [P("z", 1.5, 1.5, S.fixed)])
+    np.testing.assert_allclose(read(s_fix), kern(1.5), rtol=1e-15)
+    assert s_fix.base.z == 1.5
+    s_back, _, _ = f.build_spec(free)            # used to raise KeyError('z')
+    np.testing.assert_allclose(read(s_back), kern(0.5), rtol=1e-15)
+    s_other, _, _ = f.build_spec(free + [P("z", 2.5, 2.5, S.fixed)])
+    import gc
+    gc.collect()
+    np.testing.assert_allclose(read(s_fix), kern(1.5), rtol=1e-15)   # earlier specs still read THEIR kernel
+    np.testing.assert_allclose(read(s_own), kern(0.5), rtol=1e-15)
+    np.testing.assert_allclose(read(s_other), kern(2.5), rtol=1e-15)
+    with pytest.raises(ValueError, match="free 'z'"):
+        f.build_spec(free + [P("z", 0.1, 2.0, S.linear)])
+
+
 def _toy_fitter():
     f = fitting.Fitter(z=0.1, lumi_dist=1e27, jet="tophat", medium="ism")
     f.add_flux_density(5e14, np.array([1e4, 1e5, 1e6]), np.array([1e-26, 1e-27, 1e-28]), np.array([1e-27, 1e-28, 1e-29]))

@@ -272,3 +272,61 @@ def test_bench_multi_rank_timing_contract_under_gloo():
     assert c0 == c1 == {"steps": 7, "recorded": 5}  # 2 warm-up + exactly 5 timed
     assert e0 == e1 and e0 >= 5 * 0.02  # the MAX over ranks (the slow rank's 5 x 20 ms), identical on both
     np.testing.assert_array_equal(g0, [0, 0, 0, 0, 1, 1, 1, 1])
+
+
+def _ensemble_leg_worker(rank, world, port, q):
+    """bench.py's configs[4] leg (sharded_ensemble_leg over dist.sharded_flux_density_grid) on CPU: a list of member ids stands
+    in for the resident parameter structs, a sleep + closed form for the rank's GPU."""
+    import time
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, _abi.ROOT)
+    import bench
+    dev = torch.device("cpu")
+    members = list(range(11))  # ragged over two ranks: 6 + 5
+    calls = []
+
+    def eval_dev(block):
+        calls.append(list(block))
+        time.sleep(0.005 * (1 + rank))
+        return torch.tensor([[[float(m), 2.0 * m, 3.0 * m]] * 2 for m in block], dtype=torch.float64).reshape(len(block), 2, 3)
+
+    sync, barrier, max_over_ranks = bench._dist_helpers(world, dev)
+    out = {}
+    for gather in (True, False):
+        calls.clear()
+        res, got = bench.sharded_ensemble_leg(members, eval_dev, (2, 3), world, dev, 4, 1, gather, sync, barrier, max_over_ranks)
+        out[gather] = (res, got if gather else (got[0], got[1], got[2].numpy().copy()), [list(c) for c in calls])
+    q.put((rank, out[True][0], out[True][1].numpy().copy(), out[True][2], out[False][0], out[False][1], out[False][2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_sharded_ensemble_leg_contract_under_gloo():
+    """The leg the N > 1 bench prints for BASELINE configs[4]: every rank evaluates ONLY its contiguous block, exactly
+    warm-up + steps times; gather=True hands every rank the full ensemble in member order, gather=False its own block and no
+    collective; the rate counts ALL members over the MAX-over-ranks time."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ensemble_leg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.array([[[m, 2.0 * m, 3.0 * m]] * 2 for m in range(11)], dtype=np.float64)
+    blocks = {0: list(range(0, 6)), 1: list(range(6, 11))}
+    for rank, res_g, full, calls_g, res_n, (lo, hi, mine), calls_n in results:
+        assert res_g["members"] == res_n["members"] == 11 and res_g["members_per_rank"] == 6 and res_g["steps"] == 4
+        assert res_g["gather"] is True and res_n["gather"] is False and res_g["scaling"] == "strong"
+        np.testing.assert_array_equal(full, want)                       # every rank holds the whole ensemble, in member order
+        assert (lo, hi) == (blocks[rank][0], blocks[rank][-1] + 1)
+        np.testing.assert_array_equal(mine, want[lo:hi])                # gather=False: the rank's own block
+        assert calls_g == [blocks[rank]] * 5 and calls_n == [blocks[rank]] * 5  # 1 warm-up + exactly 4 timed, own block only
+        assert res_g["value"] == pytest.approx(11 * 4 / (res_g["ms_per_step"] * 4e-3))
+        assert res_g["ms_per_step"] >= 10.0 - 1e-9                      # the slow rank's 10 ms per step: MAX over ranks
+    assert results[0][1]["ms_per_step"] == results[1][1]["ms_per_step"]  # identical on both ranks

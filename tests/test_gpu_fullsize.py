@@ -406,3 +406,82 @@ def test_native_shard_entry_points_reproduce_the_plain_call_for_every_world(eng,
     finally:
         torch.cuda.synchronize()
         _lib.check(lib.vag_ctx_set_stream(h, None))
+
+
+def test_two_fitters_alternating_on_one_context_keep_their_own_cost_ranking(eng, oracle):
+    """The gathered costs a deal ranks by belong to (fit data, batch size, world): two fitters of equal batch size that take
+    turns on the shared context must each be dealt by THEIR OWN previous call, and a finish must belong to the shard call
+    before it.  (Second fitter: the same bands observed ten times later -> other lattices -> other per-walker costs.)"""
+    import torch
+    from vegasafterglow_amd.dist import balanced_assignment
+    lib, h = eng
+    fa, defs = _c4_fitter(oracle)
+    t, nu = configs.c4_mock_data()
+    truth = oracle.flux_density(_abi.make_params(**configs.C4_TRUTH), 10.0 * t, nu)
+    fb = fitting.Fitter(z=configs.C4_TRUTH["z"], lumi_dist=configs.C4_TRUTH["lumi_dist"], jet="gaussian", medium="ism")
+    for b in configs.C4_BANDS:
+        sel = nu == b
+        fb.add_flux_density(b, 10.0 * t[sel], truth[sel], 0.1 * truth[sel])
+    sa, lo, hi = fa.build_spec(defs)
+    sb, _, _ = fb.build_spec(defs)
+    nb, ndim, world = 96, len(defs), 2
+    per = nb // world
+    samples = lo + (hi - lo) * np.random.default_rng(33).random((nb, ndim))
+    want = {"a": fa.loglike_batch(samples, defs), "b": fb.loglike_batch(samples, defs)}
+    dev = torch.device("cuda", 0)
+    d_theta = torch.from_numpy(samples).to(dev)
+    _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+
+    def sharded_call(spec):
+        blocks = []
+        for rank in range(world):
+            blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_dev(h, C.byref(spec), d_theta.data_ptr(), nb, ndim, rank, world, blk.data_ptr()))
+            blocks.append(blk)
+        tab = torch.empty((world * per,), dtype=torch.int32, device=dev)
+        _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, tab.data_ptr(), None))
+        out = torch.empty((nb,), dtype=torch.float64, device=dev)
+        gathered = torch.cat(blocks, 0).contiguous()
+        _lib.check(lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr()))
+        cost = torch.empty((nb,), dtype=torch.float64, device=dev)
+        _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, None, cost.data_ptr()))
+        return out.cpu().numpy(), tab.cpu().numpy().reshape(world, per), cost.cpu().numpy()
+
+    try:
+        prev = {"a": np.ones(nb), "b": np.ones(nb)}
+        for turn, key in enumerate("ababab"):
+            got, table, cost = sharded_call(sa if key == "a" else sb)
+            assert np.array_equal(got, want[key]), (turn, key)
+            assert np.array_equal(table, balanced_assignment(prev[key], world)), (turn, key)  # ranked by ITS OWN last call
+            prev[key] = cost
+        assert not np.array_equal(prev["a"], prev["b"])  # the two problems do have different cost profiles
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_ctx_set_stream(h, None))
+
+
+def test_context_buffers_are_ordered_across_a_change_of_stream(eng, oracle):
+    """vag_ctx_set_stream chains the streams (event at the tail of the one it leaves, waited for by the one it takes): a
+    likelihood call queued on a torch side stream through the shared context and a grid request right behind it on the
+    context's own stream -- no host synchronisation in between -- both give the bits of the same calls made one at a time."""
+    import torch
+    import vegasafterglow_amd as va
+    f, defs = _c4_fitter(oracle)
+    _, lo, hi = f.build_spec(defs)
+    samples = lo + (hi - lo) * np.random.default_rng(5).random((1024, len(defs)))
+    want_ll = f.loglike_batch(samples, defs)
+    m = va.Model(va.GaussianJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.25), va.Radiation(0.1, 0.01, 2.3))
+    t, nu = np.logspace(3, 7, 40), np.array([1e9, 5e14, 1e18])
+    want_grid = m.flux_density_grid(t, nu).total
+    dev = torch.device("cuda", 0)
+    ev = f.device_evaluator(defs)
+    d_theta = torch.from_numpy(samples).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            ll, _ = ev(d_theta)                  # ~1.4 ms of kernels queued on the side stream; returns at once
+        got_grid = m.flux_density_grid(t, nu).total  # same context, its own stream, queued while those still run
+        side.synchronize()
+        assert np.array_equal(ll.cpu().numpy(), want_ll)
+        assert np.array_equal(got_grid, want_grid)

@@ -287,9 +287,20 @@ struct vag_ctx {
     int order_cur = 0, order_nb = 0;  // order_nb: batch size d_order[order_cur] was computed for (0: none)
     // sharded likelihood calls (vag_loglike_shard_dev): the gathered per-walker costs of the last finished call (what the next
     // deal ranks by), the current deal (walker of every (rank, slot)), this rank's gathered theta rows / ln L
-    DevBuf d_shard_cost, d_shard_table, d_shard_theta, d_shard_ll;
-    int shard_nb = 0, shard_world = 0;      // what d_shard_cost was gathered for (0: no finished call yet)
-    int shard_cur_nb = 0, shard_cur_world = 0;  // the call between vag_loglike_shard_dev and its finish
+    // The costs belong to a (fit data, batch size, world) triple: two fitters that alternate on one context must not rank each
+    // other's walkers, so a few of them are kept (least recently used is replaced), keyed by the fit spec's content hash.
+    struct ShardCosts {
+        DevBuf cost;
+        uint64_t hash = 0;
+        int nb = 0, world = 0;
+        bool valid = false;     // a call of this key has finished: `cost` holds its gathered costs
+        unsigned long long used = 0;
+    };
+    ShardCosts shard_costs[4];
+    unsigned long long shard_clock = 0;
+    int shard_last = -1;                    // entry of the last finished call (vag_loglike_shard_state_dev reports it)
+    DevBuf d_shard_table, d_shard_theta, d_shard_ll;
+    int shard_cur_nb = 0, shard_cur_world = 0, shard_cur_entry = -1;  // the call between vag_loglike_shard_dev and its finish
     // device-resident batches whose models differ in their Radiation / shock flags: regrouped by flags (flux_dev_by_flags)
     bool mixed_flags_seen = false;  // the last grid pass stopped on such a batch
     DevBuf d_mix_flags, d_mix_perm, d_mix_params, d_mix_out;
@@ -317,6 +328,7 @@ struct vag_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
+    hipEvent_t ev_handoff = nullptr;  // orders the context's buffers across a change of stream (vag_ctx_set_stream)
     // inputs
     DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
     // grid results
@@ -448,6 +460,7 @@ static int ctx_init(vag_ctx* c) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_handoff, hipEventDisableTiming));
     // allow the flux kernels the full 160 KiB LDS of a gfx950 CU
     for (const void* fn : {reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<true, FLUX_SYN>),
@@ -551,21 +564,35 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
-    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->d_shard_cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f})
+    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->ev_handoff) (void)hipEventDestroy(c->ev_handoff);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
 int vag_ctx_set_stream(vag_ctx* c, void* s) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    hipStream_t next;
     if (s == VAG_STREAM_LEGACY_DEFAULT)
-        c->stream = nullptr;  // the legacy default stream
+        next = nullptr;  // the legacy default stream
     else
-        c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+        next = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    if (next != c->stream) {
+        // The context's scratch buffers (parameters, grid results, shock arrays, deal tables ...) are reused by every call, so
+        // work queued on the stream the context leaves must be ordered before anything the next stream does with them: an event
+        // at the tail of the old stream, waited for by the new one.  No host synchronisation.  The old stream must still exist
+        // when it is handed back (a failure to record on it is ignored: nothing can be in flight on a destroyed stream).
+        (void)hipSetDevice(c->device);
+        if (hipEventRecord(c->ev_handoff, c->stream) == hipSuccess)
+            (void)hipStreamWaitEvent(next, c->ev_handoff, 0);
+        else
+            (void)hipGetLastError();
+        c->stream = next;
+    }
     return VAG_OK;
 }
 
@@ -1893,11 +1920,12 @@ __global__ void vag_gather_params_kernel(const vag_model_params* __restrict__ pa
 }
 __global__ void vag_scatter_rows_kernel(const double* __restrict__ src, const int* __restrict__ perm, int nb, size_t stride,
                                         double* __restrict__ dst) {
-    const int i = blockIdx.y;
-    if (i >= nb) return;
-    const double* s = src + (size_t)i * stride;
-    double* d = dst + (size_t)perm[i] * stride;
-    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < stride; q += (size_t)gridDim.x * blockDim.x) d[q] = s[q];
+    // gridDim.y is capped (65535): a workgroup row takes every gridDim.y-th model
+    for (int i = blockIdx.y; i < nb; i += gridDim.y) {
+        const double* s = src + (size_t)i * stride;
+        double* d = dst + (size_t)perm[i] * stride;
+        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < stride; q += (size_t)gridDim.x * blockDim.x) d[q] = s[q];
+    }
 }
 
 // A batch the grid pass refused for its mixed flags: sort the models by flags (stable: the flags travel to the host, 4 bytes per
@@ -1944,9 +1972,10 @@ static int flux_dev_by_flags(vag_ctx* c, const vag_model_params* d_params, int n
     }
     c->plan.n_models_ok = n_ok, c->plan.n_models_invalid = n_inv, c->plan.n_models_capacity = n_cap;  // the batch's, not the last group's
     const unsigned gx = (unsigned)std::min<size_t>((stride + 255) / 256, 64);
-    hipLaunchKernelGGL(vag_scatter_rows_kernel, dim3(gx, nb), dim3(256), 0, st, c->d_mix_out.as<double>(), c->d_mix_perm.as<int>(), nb, stride,
-                       d_out);
+    hipLaunchKernelGGL(vag_scatter_rows_kernel, dim3(gx, (unsigned)std::min(nb, 65535)), dim3(256), 0, st, c->d_mix_out.as<double>(),
+                       c->d_mix_perm.as<int>(), nb, stride, d_out);
     HIPCHK(hipGetLastError());
+    c->hint_valid = false;  // the hint is the LAST GROUP's plan: the next mixed batch of this size must not be planned from it
     return VAG_OK;
 }
 
@@ -2808,20 +2837,39 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     if (c->d_shard_table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
     if (c->d_shard_theta.ensure(sizeof(double) * (size_t)per * ndim)) return VAG_E_HIP;
     if (c->d_shard_ll.ensure(sizeof(double) * (size_t)per)) return VAG_E_HIP;
-    if (c->d_shard_cost.ensure(sizeof(double) * (size_t)nb_all)) return VAG_E_HIP;
+    // every rank needs the same deal, whether or not it holds a walker: the key of the costs is the spec's content hash
+    {
+        const int rc = upload_fit_spec(c, spec, ndim);
+        if (rc) return rc;
+    }
+    int entry = -1, victim = 0;
+    for (int i = 0; i < 4; ++i) {
+        const vag_ctx::ShardCosts& e = c->shard_costs[i];
+        if (e.nb == nb_all && e.world == world && e.hash == c->fit_hash) entry = i;
+        if (e.used < c->shard_costs[victim].used) victim = i;
+    }
+    if (entry < 0) {
+        entry = victim;
+        c->shard_costs[entry].nb = nb_all;
+        c->shard_costs[entry].world = world;
+        c->shard_costs[entry].hash = c->fit_hash;
+        c->shard_costs[entry].valid = false;  // until its first call finishes
+        if (c->shard_last == entry) c->shard_last = -1;
+    }
     // ranking by counting is O(nb_all^2 / 64) per call: beyond 16384 walkers the deal stays by position (equal counts)
-    const bool ranked = c->shard_nb == nb_all && c->shard_world == world && nb_all <= 16384;
+    const bool ranked = c->shard_costs[entry].valid && nb_all <= 16384;
+    c->shard_costs[entry].used = ++c->shard_clock;
+    if (c->shard_costs[entry].cost.ensure(sizeof(double) * (size_t)nb_all)) return VAG_E_HIP;
     hipLaunchKernelGGL(vag_shard_deal_kernel, dim3((world * per + 3) / 4), dim3(256), 0, c->stream,
-                       ranked ? c->d_shard_cost.as<double>() : nullptr, d_theta_all, nb_all, ndim, rank, world, per,
+                       ranked ? c->shard_costs[entry].cost.as<double>() : nullptr, d_theta_all, nb_all, ndim, rank, world, per,
                        c->d_shard_table.as<int>(), c->d_shard_theta.as<double>());
     HIPCHK(hipGetLastError());
     c->shard_cur_nb = nb_all;
     c->shard_cur_world = world;
+    c->shard_cur_entry = entry;
     const int* d_order = nullptr;
     if (n_mine > 0) {
-        int rc = upload_fit_spec(c, spec, ndim);
-        if (rc) return rc;
-        rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), !c->count_work);
+        int rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), !c->count_work);
         if (rc == VAG_RETRY) rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), false);
         if (rc) return rc;
         d_order = c->order_active ? c->last_order : nullptr;
@@ -2834,16 +2882,17 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
 
 int vag_loglike_shard_finish_dev(vag_ctx* c, const double* d_gathered, int nb_all, int world, double* d_out) {
     if (!c || !d_gathered || !d_out) return set_err(VAG_E_INVALID, "null context or buffer");
-    if (nb_all != c->shard_cur_nb || world != c->shard_cur_world || nb_all <= 0)
+    if (nb_all != c->shard_cur_nb || world != c->shard_cur_world || nb_all <= 0 || c->shard_cur_entry < 0)
         return set_err(VAG_E_INVALID, "no vag_loglike_shard_dev call of %d walkers over %d ranks is waiting for its finish", nb_all, world);
     HIPCHK(hipSetDevice(c->device));
     const int per = (nb_all + world - 1) / world;
     hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, c->d_shard_table.as<int>(), world * per,
-                       d_out, c->d_shard_cost.as<double>());
+                       d_out, c->shard_costs[c->shard_cur_entry].cost.as<double>());
     HIPCHK(hipGetLastError());
-    c->shard_nb = nb_all;
-    c->shard_world = world;
+    c->shard_costs[c->shard_cur_entry].valid = true;
+    c->shard_last = c->shard_cur_entry;
     c->shard_cur_nb = c->shard_cur_world = 0;
+    c->shard_cur_entry = -1;
     return VAG_OK;
 }
 
@@ -2856,9 +2905,9 @@ int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_ta
     if (d_table)
         HIPCHK(hipMemcpyAsync(d_table, c->d_shard_table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
     if (d_cost) {
-        if (c->shard_nb != nb_all || c->shard_world != world)
+        if (c->shard_last < 0 || !c->shard_costs[c->shard_last].valid || c->shard_costs[c->shard_last].nb != nb_all || c->shard_costs[c->shard_last].world != world)
             return set_err(VAG_E_INVALID, "no finished sharded call of %d walkers over %d ranks on this context", nb_all, world);
-        HIPCHK(hipMemcpyAsync(d_cost, c->d_shard_cost.p, sizeof(double) * (size_t)nb_all, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_cost, c->shard_costs[c->shard_last].cost.p, sizeof(double) * (size_t)nb_all, hipMemcpyDeviceToDevice, c->stream));
     }
     return VAG_OK;
 }

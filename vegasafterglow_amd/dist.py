@@ -133,9 +133,12 @@ class WalkerSharder:
         out = torch.empty((nb,), dtype=torch.float64, device=self.device)
         self._shape = (nb, world, d.per)
         if self.native is not None:
-            self.native.shard(theta.contiguous(), nb, rank, world, d.block)
-            dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
-            self.native.finish(d.gathered, nb, world, out)
+            # the deal table of the call lives on the (per-device, shared) engine context between shard and finish: the context's
+            # lock is held across the three steps so that another sharder on this device cannot deal in between
+            with self.native.lock:
+                self.native.shard(theta.contiguous(), nb, rank, world, d.block)
+                dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
+                self.native.finish(d.gathered, nb, world, out)
             return out
         if self._costs is None or self._costs.shape[0] != nb:
             self._costs = torch.ones((nb,), dtype=torch.float64, device=self.device)

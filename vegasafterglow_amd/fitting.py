@@ -167,6 +167,7 @@ class Fitter:
         self._point_t, self._point_nu, self._point_flux, self._point_err, self._point_weights = [], [], [], [], []
         self._band_obs = []
         self._ext_kernel = None
+        self._ext_kernels = {}  # z -> 0.4 ln10 k(lambda_rest) over the consolidated point data
         self._ext_z = float(z)
         self._all_t = None
 
@@ -278,6 +279,7 @@ class Fitter:
             self._ext_z = self.z
             lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self.z)
             self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
+            self._ext_kernels = {self._ext_z: self._ext_kernel}
 
     def _k_lambda(self, lam_rest_cm):
         """k(lambda) of the configured law.  The reference hands custom callables (lam_rest_cm, params) (fitter.py:445-449);
@@ -346,11 +348,18 @@ class Fitter:
                 spec.slot[d] = _lib.PARAM_SLOTS[pd.name]
             spec.is_log[d] = 1 if pd.scale is Scale.log else 0
         spec.a_v_fixed = float(fixed.get("A_V", 0.0))
-        if self.extinction is not None and self._all_t.size and float(fixed.get("z", self.z)) != self._ext_z:
-            # a fixed 'z' ParamDef overrides Fitter.z in the model: the rest-frame wavelengths of the law must follow it
-            self._ext_z = float(fixed["z"])
-            lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + self._ext_z)
-            self._ext_kernel = np.ascontiguousarray(0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
+        if self.extinction is not None and any(pd.name == "z" for pd in free):
+            raise ValueError("a free 'z' cannot be combined with Fitter(extinction=...): the law's rest-frame wavelengths are fixed per fit")
+        z_eff = float(fixed.get("z", self.z))
+        if self.extinction is not None and self._all_t.size and z_eff != self._ext_z:
+            # a fixed 'z' ParamDef overrides Fitter.z in the model: the rest-frame wavelengths of the law must follow it.  One
+            # kernel per z, all kept for the Fitter's lifetime: earlier specs (a device_evaluator's closure) still point at theirs
+            ext = self._ext_kernels.get(z_eff)
+            if ext is None:
+                lam_rest_cm = (2.99792458e10 / self._all_nu) / (1.0 + z_eff)
+                ext = self._ext_kernels[z_eff] = np.ascontiguousarray(
+                    0.4 * np.log(10.0) * np.asarray(self._k_lambda(lam_rest_cm), dtype=np.float64))
+            self._ext_z, self._ext_kernel = z_eff, ext
         spec.ext_kernel = self._ext_kernel.ctypes.data_as(_dp) if self._ext_kernel is not None else None
         self._band_structs = (_lib.BandObs * max(len(self._band_obs), 1))()
         for g, bd in enumerate(self._band_obs):
@@ -366,6 +375,10 @@ class Fitter:
         spec.ln_flux = self._all_log_flux.ctypes.data_as(_dp)
         spec.ln_err = self._all_log_err.ctypes.data_as(_dp)
         spec.weight = self._all_weights.ctypes.data_as(_dp)
+        # the struct holds raw pointers: what they point at lives as long as the spec (a device_evaluator closure keeps its spec
+        # while the Fitter may consolidate new data or another z)
+        spec._keep_alive = (self._ext_kernel, self._band_structs, list(self._band_obs), self._all_t, self._all_nu,
+                            self._all_log_flux, self._all_log_err, self._all_weights)
         # sampler-space bounds: log10 of the ParamDef bounds for LOG-scale parameters (fitting/params.py:196-201)
         lower = np.array([np.log10(pd.lower) if pd.scale is Scale.log else pd.lower for pd in free], dtype=np.float64)
         upper = np.array([np.log10(pd.upper) if pd.scale is Scale.log else pd.upper for pd in free], dtype=np.float64)
@@ -505,6 +518,7 @@ class Fitter:
             """The engine's own sharded call for dist.WalkerSharder: deal + this rank's block, then the scatter after the
             all-gather (vag_loglike_shard_dev / vag_loglike_shard_finish_dev); no host work besides the launches."""
             parts = (lib, h, lock, keep)
+            lock = lock  # dist.WalkerSharder holds it across shard -> all-gather -> finish: the deal table lives on the context
             check = staticmethod(_lib.check)
 
             @staticmethod

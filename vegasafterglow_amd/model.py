@@ -279,7 +279,7 @@ def get_context(device=0):
         if device not in _ctx:
             h = C.c_void_p()
             _lib.check(lib.vag_ctx_create(device, C.byref(h)))
-            _ctx[device] = (h, threading.Lock())
+            _ctx[device] = (h, threading.RLock())  # re-entrant: a sharded call holds it across deal, all-gather and scatter
         return _ctx[device]
 
 
