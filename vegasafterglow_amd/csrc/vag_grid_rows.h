@@ -32,7 +32,10 @@ __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
 template <int MODE>
 // 168 VGPRs: three wavefronts per SIMD; the SSC pass (a table look-up per band, no spectrum constants) fits 128 with 12 B of
 // scratch and gains 9 % from the fourth wavefront, the others would spill 100-200 B per lane and lose 70 %
-__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? 4 : VAG_ROWS_MIN_WG)
+#ifndef VAG_ROWS_SSC_WG
+#define VAG_ROWS_SSC_WG 4
+#endif
+__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? VAG_ROWS_SSC_WG : VAG_ROWS_MIN_WG)
 vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int m = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -86,7 +89,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     // boundary values B[l] = log2 I'(nu_l (1+z) / D_k) + log2(dOmega r^2 D^3) of node k
     auto boundary = [&](int k, double dop, double lr2, double (&B)[GRIDROWS_BANDS]) {
         const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
-        if constexpr (MODE == FLUX_SSC) {
+        if constexpr (MODE == FLUX_SSC) {  // (only node 0: the loop below keeps the later nodes' look-ups in flight a node ahead)
             const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
             const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
 #pragma unroll
@@ -130,6 +133,38 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         nlr2 = row[VP_LG2_R2 * K + kk];
     };
     request(2);
+    // FLUX_SSC: a tabulated spectrum is a header read and a gather whose address depends on the node's Doppler factor -- two
+    // dependent trips to L2 per node, which three or four wavefronts per SIMD cannot hide (r03: 54 % VALU busy).  Both are taken
+    // off the chain: node k + 2's header is requested with its shock state, node k + 1's gathers are issued as soon as its
+    // Doppler factor exists (one iteration before the values are used), for every lane whether or not it will need the node.
+    [[maybe_unused]] double hq_n = 0, hq_first = 0, hq_last = 0, hq_tmin = 0, hq_tmax = 0;  // header of the node the next issue serves
+    // a pending look-up is its position inside the table interval (NaN where the reference returns -inf: no table, or beyond
+    // the last node -- either makes the interval's slope non-finite, which is all the sum asks) and the gathered pair
+    [[maybe_unused]] double pfrac[GRIDROWS_BANDS];
+    [[maybe_unused]] vdouble2_a8 pI[GRIDROWS_BANDS];
+    [[maybe_unused]] const double* tab_row = nullptr;
+    [[maybe_unused]] auto request_hdr = [&](int k) {
+        const double* tab = tab_row + (size_t)(k < K ? k : K - 1) * FLUX_IC_STRIDE;
+        hq_n = tab[0], hq_first = tab[1], hq_last = tab[2], hq_tmin = tab[3], hq_tmax = tab[4];
+    };
+    [[maybe_unused]] int p_breach = 0;  // band-contract breach of the pending look-ups: counts only if the node is then used
+    [[maybe_unused]] auto issue = [&](int k, double dop) {  // node k's look-ups from the header at hand
+        const double* tab = tab_row + (size_t)(k < K ? k : K - 1) * FLUX_IC_STRIDE;
+        p_breach = 0;
+#pragma unroll
+        for (int b = 0; b < GRIDROWS_BANDS; ++b)
+            if (b < NB) {
+                const IcTabQuery q = ic_table_query(hq_n, hq_first, hq_last, hq_tmin, hq_tmax, s_nu[b] - dop, &p_breach);
+                pI[b] = ic_table_gather(tab, q.idx);
+                pfrac[b] = q.none ? NAN : q.frac;
+            }
+    };
+    if constexpr (MODE == FLUX_SSC) {
+        tab_row = a.ictab + (size_t)cell0 * FLUX_IC_STRIDE;
+        request_hdr(1);
+        issue(1, dop_b);
+        request_hdr(2);
+    }
     // cursor into the ascending requested times: the first one at or beyond node 0 (bisection over the 128 slots, +inf beyond nt)
     int p = nt;
     if (valid) {
@@ -171,8 +206,21 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
             t_next = pe < nt ? s_tobs[pe] : INFINITY;
         }
         const bool need = pe > p || t_next < lt_c;
+        if constexpr (MODE == FLUX_SSC) {
+            // node k's tabulated values from the gathers issued an iteration ago, then node k + 1's look-ups take their place
+            // (past the last node: a repeat of it, never used) and node k + 2's header is requested
+            const double geom = (lg2_dOmega + lr2_b) + 3.0 * dop_b;
+#pragma unroll
+            for (int b = 0; b < GRIDROWS_BANDS; ++b)
+                if (b < NB) Bcur[b] = need ? fma(pfrac[b], pI[b].y - pI[b].x, pI[b].x) + geom : Bcur[b];
+            if (need && p_breach) breach = 1;
+            issue(k + 1, dop_c);
+            request_hdr(k + 2);
+        }
         if (__ballot(need) != 0) {
-            if (need) boundary(k, dop_b, lr2_b, Bcur);
+            if constexpr (MODE != FLUX_SSC) {
+                if (need) boundary(k, dop_b, lr2_b, Bcur);
+            }
             if (__ballot(pe > p) != 0) {
                 const double inv_dt = 1.0 / (lt_b - lt_a);
                 double d[GRIDROWS_BANDS];

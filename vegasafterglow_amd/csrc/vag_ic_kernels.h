@@ -23,7 +23,7 @@ enum {
 
 // SSC table of one cell: header + log2 I on the phase-locked output lattice (inverse-compton.h:354-369,595-606)
 constexpr int IC_MAX_OUT = 192;  // three output nodes per lane; an unclamped table needs at most ~(IC_MAX_NU - 1) + (IC_MAX_G - 1) + 3
-constexpr int IC_HDR = 6;  // n_ic, phase, idx0, log2 theory min, log2 theory max, spare
+constexpr int IC_HDR = 6;  // n_ic, first node, last node, log2 theory min, log2 theory max, spare
 constexpr int IC_STRIDE = IC_HDR + IC_MAX_OUT;
 constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = (IC_MAX_G - 1) + (IC_MAX_NU - 1) + 1;
 static_assert(VAG_NQ == FLUX_NQ && IC_STRIDE == FLUX_IC_STRIDE, "keep vag_kernels.h forward constants in sync");
@@ -454,7 +454,11 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 // IC_HDR on carry the plan until vag_ic_photon_kernel replaces them by the table.  Cells that get no table (failed model,
 // degenerate or over-capacity lattice) are finished here: n = 0 and the theoretical range.
 enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX,
-       ICP_SMOOTH_THICK, ICP_LOG2_X_FAR /* SpecConst of the model's p: a division and a library log2 per wavefront otherwise */, ICP_N };
+       ICP_SMOOTH_THICK, ICP_LOG2_X_FAR /* SpecConst of the model's p: a division and a library log2 per wavefront otherwise */,
+       ICP_PHASE, ICP_N };
+// output lattice node q of a table: phase + IC_Q (idx0 + 2 q), idx0 + 2 q an integer far below 2^53 formed in double -- exactly the
+// value the reference converts from its integer (log2_nu_IC, inverse-compton.h:595-606)
+VAG_DEV double ic_out_node(double phase, double idx0, int q) { return phase + IC_Q * (idx0 + 2.0 * (double)q); }
 __global__ void __launch_bounds__(256)
 vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
@@ -522,8 +526,9 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         atomicAdd(work + 1, (unsigned long long)(g_size + nu_size + n_ic));
     }
     tab[0] = (double)n_ic;
-    tab[1] = phase;
-    tab[2] = (double)(n_lo * 2);
+    tab[1] = ic_out_node(phase, (double)(n_lo * 2), 0);         // first and last node of the output lattice: what the flux passes'
+    tab[2] = ic_out_node(phase, (double)(n_lo * 2), n_ic - 1);  // evaluator needs of it (ic_table_eval_hdr)
+    tab[IC_HDR + ICP_PHASE] = phase;
     tab[IC_HDR + ICP_RUN] = 1;
     tab[IC_HDR + ICP_MODEL] = (double)m;
     tab[IC_HDR + ICP_NU_SIZE] = (double)nu_size;
@@ -565,7 +570,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double lg2_nu0 = tab[IC_HDR + ICP_LG2_NU0], lg2_g0 = tab[IC_HDR + ICP_LG2_G0];
     const double lg2_gm = tab[IC_HDR + ICP_LG2_GM], inv_gm = tab[IC_HDR + ICP_INV_GM], inv_gM = tab[IC_HDR + ICP_INV_GMAX];
     const int n_ic = (int)tab[0];
-    const double phase = tab[1];
+    const double phase = tab[IC_HDR + ICP_PHASE];
     const long idx0 = n_lo * 2;
     const double step = 2 * IC_Q;
     const int nt = meta[m].n_t;
@@ -883,38 +888,46 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     }
 }
 
-// ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table.  A query outside the clamped band but
-// inside the theoretical range would make the reference rebuild the cell's spectrum; here it raises `*breach`.
-VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
-                                 double th_max, double x, int* breach);
+// ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table: header {n, first node, last node, log2 of the
+// theoretical minimum / maximum, spare}, then the n values log2 I on the lattice first + 2 IC_Q q.  A query outside the clamped
+// band but inside the theoretical range would make the reference rebuild the cell's spectrum; here it raises `*breach`.
+//
+// The reference scans forward to the largest node <= x (clamped to [0, n - 2]) and adds (x - node) * slope with the slope it stored
+// per interval.  The lattice being uniform, that interval is floor((x - first) / step) and the interpolant Ilo + frac (Ihi - Ilo)
+// with frac = (x - first) / step - interval: the same piecewise-linear function (continuous at the nodes, extrapolating with the end
+// intervals' slopes), evaluated with ~2e-14 of rounding in log2 I instead of reproducing the scan's last bit -- 15 instructions and
+// ONE 16-byte gather {Ilo, Ihi} where the node-exact form took 45 and two dependent 8-byte gathers (r04: this evaluator is the
+// tabulated-SSC flux pass, a third of a configs[4] call).
+typedef double vdouble2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+constexpr double IC_INV_STEP = 1.0 / (2 * IC_Q);
+struct IcTabQuery {  // the look-up split at its memory access, for callers that issue the gather ahead of its use
+    double frac;
+    int idx;
+    bool none;  // no table, or x beyond the last node: -inf (compute_log2_I_nu's early return)
+};
+VAG_DEV IcTabQuery ic_table_query(double h_n, double first, double last, double th_min, double th_max, double x, int* breach) {
+    IcTabQuery q;
+    const bool empty = h_n < 2.0, above = x > last;
+    if (!empty && ((above && x < th_max) || (x < first && x > th_min))) *breach = 1;
+    const double u = (x - first) * IC_INV_STEP;
+    const double fl = __builtin_fmin(__builtin_fmax(floor(u), 0.0), __builtin_fmax(h_n - 2.0, 0.0));  // v_max_f64 / v_min_f64, no selects
+    q.idx = (int)fl;
+    q.frac = u - fl;
+    q.none = empty || above;
+    return q;
+}
+VAG_DEV vdouble2_a8 ic_table_gather(const double* __restrict__ tab, int idx) {
+    return *reinterpret_cast<const vdouble2_a8*>(tab + IC_HDR + idx);
+}
+VAG_DEV double ic_table_finish(const IcTabQuery& q, vdouble2_a8 I) { return q.none ? -INFINITY : fma(q.frac, I.y - I.x, I.x); }
+
+VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double first, double last, double th_min,
+                                 double th_max, double x, int* breach) {
+    const IcTabQuery q = ic_table_query(h_n, first, last, th_min, th_max, x, breach);
+    return ic_table_finish(q, ic_table_gather(tab, q.idx));
+}
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach) {
     return ic_table_eval_hdr(tab, tab[0], tab[1], tab[2], tab[3], tab[4], x, breach);
-}
-// the same with the five header words already at hand (the grid flux kernel keeps them in its LDS-staged row)
-VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
-                                 double th_max, double x, int* breach) {
-    const int n = (int)h_n;
-    // lattice node q = phase + IC_Q * (idx0 + 2 q): idx0 + 2 q is an integer far below 2^53, so it is formed in double
-    // (exactly the value the reference converts from its integer) -- no 64-bit integer conversions in this hot evaluator
-    auto node = [&](int q) { return phase + IC_Q * (h_idx0 + 2.0 * (double)q); };
-    const double first = node(0), last = node(n - 1);
-    const bool empty = n < 2;
-    if (!empty && ((x > last && x < th_max) || (x < first && x > th_min))) *breach = 1;
-    // Straight-line from here (no early return before the table reads): the reads of the evaluations a work item makes are
-    // in flight together, which is what this L2-latency-bound evaluator lives on (C5 SSC pass 22.9 -> 17.8 ms per 256 models).
-    int idx = (int)floor((x - first) * (1.0 / (2 * IC_Q)));
-    const int top = n - 2 > 0 ? n - 2 : 0;
-    idx = idx < 0 ? 0 : (idx > top ? top : idx);
-    // settle exactly where the reference's forward scan stops (the largest node <= x): the estimate is off by at most one node
-    // (the lattice is exact to rounding), so one step each way does it
-    idx += (idx + 2 < n && node(idx + 1) <= x) ? 1 : 0;
-    idx -= (idx > 0 && node(idx) > x) ? 1 : 0;
-    const double Ilo = tab[IC_HDR + idx], Ihi = tab[IC_HDR + idx + 1];
-    const double n_lo = node(idx);
-    const double dl = node(idx + 1) - n_lo;
-    const double slope = dl != 0 ? (Ihi - Ilo) * rcp_fast(dl) : 0;  // dl ~ 2 IC_Q: finite, normal
-    const double v = Ilo + (x - n_lo) * slope;
-    return (empty || x > last) ? -INFINITY : v;
 }
 
 }  // namespace vag

@@ -518,7 +518,6 @@ class Fitter:
             """The engine's own sharded call for dist.WalkerSharder: deal + this rank's block, then the scatter after the
             all-gather (vag_loglike_shard_dev / vag_loglike_shard_finish_dev); no host work besides the launches."""
             parts = (lib, h, lock, keep)
-            lock = lock  # dist.WalkerSharder holds it across shard -> all-gather -> finish: the deal table lives on the context
             check = staticmethod(_lib.check)
 
             @staticmethod
@@ -537,6 +536,7 @@ class Fitter:
                 _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, tab.data_ptr(), cost.data_ptr())))
                 return tab.cpu().numpy().astype(np.int64).reshape(world, per), cost.cpu().numpy()
 
+        _Native.lock = lock  # dist.WalkerSharder holds it across shard -> all-gather -> finish: the deal table lives on the context
         eval_dev.native = _Native
         return eval_dev
 
