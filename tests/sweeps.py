@@ -1,0 +1,47 @@
+"""Seeded random draws of wide parameter boxes for the randomised parity tests (tests/test_gpu_parity.py) and for the script that
+measures what the reference itself demonstrates on them (tests/golden/make_sweep_fixture.py).  The streams are those of
+profiles/debug/prior_sweep_ssc.py and prior_sweep_rs_ssc.py, so draw #i here is draw #i of the sweeps recorded under profiles/."""
+import numpy as np
+
+import _abi
+
+SSC_T, SSC_NU = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
+RS_T, RS_NU = np.logspace(1.5, 7.5, 36), np.array([1e9, 4.84e14, 1e18, 2.4e24])
+
+
+def ssc_draws(n, kn):
+    """Forward shock with SSC: the n Klein-Nishina draws (kn=True) or the n Thomson draws that follow them in the stream."""
+    rng = np.random.default_rng(4242)
+    sets = {}
+    for flag in (True, False):
+        prms = []
+        for i in range(n):
+            jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]
+            kw = dict(jet=jet, E_iso=10 ** rng.uniform(50.5, 54), Gamma0=10 ** rng.uniform(1.5, 2.9), theta_c=rng.uniform(0.03, 0.3),
+                      theta_obs=rng.uniform(0, 0.5), p=rng.uniform(2.05, 2.9), eps_e=10 ** rng.uniform(-2.5, -0.5),
+                      eps_B=10 ** rng.uniform(-6, -1), ssc=True, kn=flag)
+            if i % 2:
+                kw.update(medium="Wind", A_star=10 ** rng.uniform(-2, 0.5))
+            else:
+                kw.update(n_ism=10 ** rng.uniform(-3, 2))
+            if jet == "PowerLawJet":
+                kw.update(k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+            prms.append(_abi.make_params(**kw))
+        sets[flag] = prms
+    return sets[bool(kn)]
+
+
+def rs_ssc_draws(n):
+    """Forward + reverse shock, SSC with Klein-Nishina on both."""
+    rng = np.random.default_rng(777)
+    prms = []
+    for i in range(n):
+        jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]
+        kw = dict(jet=jet, E_iso=10 ** rng.uniform(51, 53.5), Gamma0=10 ** rng.uniform(1.7, 2.7), theta_c=rng.uniform(0.04, 0.2),
+                  theta_obs=rng.uniform(0, 0.3), n_ism=10 ** rng.uniform(-2, 1), p=rng.uniform(2.1, 2.7), eps_e=10 ** rng.uniform(-2, -0.7),
+                  eps_B=10 ** rng.uniform(-4, -1.5), duration=10 ** rng.uniform(0, 3), ssc=True, kn=True,
+                  rvs=dict(eps_e=10 ** rng.uniform(-2, -0.7), eps_B=10 ** rng.uniform(-3, -1), p=rng.uniform(2.1, 2.7), ssc=True, kn=True))
+        if jet == "PowerLawJet":
+            kw.update(k_e=2.0, k_g=2.0)
+        prms.append(_abi.make_params(**kw))
+    return prms

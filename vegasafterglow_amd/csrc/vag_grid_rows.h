@@ -17,14 +17,27 @@
 
 namespace vag {
 
-constexpr int GRIDROWS_WAVES = 4;
+#ifndef VAG_GRIDROWS_WAVES
+#define VAG_GRIDROWS_WAVES 4
+#endif
+constexpr int GRIDROWS_WAVES = VAG_GRIDROWS_WAVES;
 constexpr int GRIDROWS_BANDS = 4;     // frequencies
 constexpr int GRIDROWS_MAX_NT = 128;  // requested times
 constexpr int GRIDROWS_MAX_SLOTS = 512;
 
+// The interpolation work of a wavefront goes through a RING of items in LDS: a lane pushes {the four exponents of one requested
+// time inside its current lattice interval, the time's index}, and whenever 64 items have gathered ALL 64 lanes pop one each and do
+// the exp2 + accumulate.  Walking the lattice, the lanes of a wavefront meet their requested times at different nodes (0, 1 or 2 per
+// interval, 0.9 on average on the C5 shape), so the interpolation done in place ran at the trip count of the busiest lane with
+// ~45 % of the lanes active: 22 of the SSC pass's 31 ms and 23 of the synchrotron pass's 52 ms per 1024 C5 members
+// (profiles/r04_rows_ablation.txt).  A push is ~15 instructions under that mask; the expensive part now always runs on full lanes.
+constexpr int GRIDROWS_RING = 128;  // items: a push pass adds at most 64 to at most 63 left over
+constexpr int GRIDROWS_RING_BYTES = GRIDROWS_RING * (2 * 16 + 4);  // {x0, x1}, {x2, x3}, time index
+
 __host__ __device__ inline int grid_rows_stripes(int slots) { return slots <= 128 ? 4 : 2; }
 __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
-    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * slots);
+    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * slots) +
+           (size_t)GRIDROWS_WAVES * GRIDROWS_RING_BYTES;
 }
 
 // a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
@@ -54,6 +67,12 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     if (threadIdx.x < NB) s_nu[threadIdx.x] = a.lg2_nu_obs[threadIdx.x] + Mp->lg2_1pz;
     for (int i = lane; i < stripes * slots; i += SERIES_THREADS) s_acc[i] = 0;
     double* my_acc = s_acc + (lane % stripes) * slots;
+    // this wavefront's ring (behind every wavefront's sums; 16-byte aligned: the doubles before it are an even count)
+    char* ring_base = reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * slots) + (size_t)wave * GRIDROWS_RING_BYTES;
+    vdouble2* ring_x01 = reinterpret_cast<vdouble2*>(ring_base);
+    vdouble2* ring_x23 = ring_x01 + GRIDROWS_RING;
+    int* ring_q = reinterpret_cast<int*>(ring_x23 + GRIDROWS_RING);
+    int ring_tail = 0, ring_count = 0;  // wavefront-uniform
     __syncthreads();  // the only workgroup-wide barrier
     const int vb = blockIdx.x * GRIDROWS_WAVES + wave;
     const int p0 = vb * FITROWS_ROWS;
@@ -123,6 +142,27 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         }
     };
 
+    // n_take (wavefront-uniform) items leave the ring, one per lane: exp2 and the sums (observer.h:405-433).  An item whose
+    // interval has no finite slope carries a non-finite exponent and adds nothing (observer.h:422-426).
+    auto ring_pop = [&](int n_take) {
+        wave_sync();  // the pushes of this wavefront are in LDS (same wavefront: program order; the fence is for the compiler)
+        const int idx = (ring_tail + lane) & (GRIDROWS_RING - 1);
+        const vdouble2 a01 = ring_x01[idx], a23 = ring_x23[idx];
+        const int q = ring_q[idx];
+        if (lane < n_take) {
+            const double xs[GRIDROWS_BANDS] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+            for (int b = 0; b < GRIDROWS_BANDS; ++b)
+#ifdef VAG_ROWS_ABLATE_ATOMICS  // timing experiment only: the sums kept in a register
+                if (b < NB && isfinite(xs[b])) breach += exp2_fast(xs[b]) > 1e300 ? 1 : 0;
+#else
+                if (b < NB && isfinite(xs[b])) lds_add_f64(my_acc + b * nt + q, exp2_fast(xs[b]));
+#endif
+        }
+        ring_tail = (ring_tail + n_take) & (GRIDROWS_RING - 1);
+        ring_count -= n_take;
+        wave_sync();  // the slots may be written again
+    };
     double lt_a, dop_a, lr2_a, lt_b, dop_b, lr2_b;
     node(0, lt_a, dop_a, lr2_a);
     node(1, lt_b, dop_b, lr2_b);
@@ -214,27 +254,42 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
             for (int b = 0; b < GRIDROWS_BANDS; ++b)
                 if (b < NB) Bcur[b] = need ? fma(pfrac[b], pI[b].y - pI[b].x, pI[b].x) + geom : Bcur[b];
             if (need && p_breach) breach = 1;
+#ifndef VAG_ROWS_ABLATE_EVAL  // timing experiment only: no table look-ups
             issue(k + 1, dop_c);
             request_hdr(k + 2);
+#endif
         }
         if (__ballot(need) != 0) {
             if constexpr (MODE != FLUX_SSC) {
                 if (need) boundary(k, dop_b, lr2_b, Bcur);
             }
+#ifdef VAG_ROWS_ABLATE_INTERP  // timing experiment only: no interpolation / accumulation at all
+            if (false) {
+#else
             if (__ballot(pe > p) != 0) {
+#endif
                 const double inv_dt = 1.0 / (lt_b - lt_a);
                 double d[GRIDROWS_BANDS];
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b) d[b] = Bcur[b] - Bprev[b];  // slope finite <=> d finite (observer.h:422-426)
-                for (int q = p; q < pe; ++q) {
-                    const double w = (s_tobs[q] - lt_a) * inv_dt;  // position inside the interval, shared by the frequencies
+                // push the lane's times inside the interval, one per pass (the passes are short: the trip count of the busiest
+                // lane no longer multiplies the exp2 work); 64 gathered items are worked off at once
+                for (int q = p; __ballot(q < pe) != 0; ++q) {
+                    const bool has = q < pe;
+                    const double w = (s_tobs[min(q, GRIDROWS_MAX_NT - 1)] - lt_a) * inv_dt;  // position inside the interval, shared by the frequencies
+                    double x[GRIDROWS_BANDS];
 #pragma unroll
-                    for (int b = 0; b < GRIDROWS_BANDS; ++b)
-#ifdef VAG_ROWS_ABLATE_ATOMICS  // timing experiment only: the sums kept in a register
-                        if (b < NB && isfinite(d[b])) Bcur[b] += 1e-300 * exp2_fast(fma(d[b], w, Bprev[b]));
-#else
-                        if (b < NB && isfinite(d[b])) lds_add_f64(my_acc + b * nt + q, exp2_fast(fma(d[b], w, Bprev[b])));
-#endif
+                    for (int b = 0; b < GRIDROWS_BANDS; ++b) x[b] = b < NB ? fma(d[b], w, Bprev[b]) : NAN;
+                    const unsigned long long mask = __ballot(has);
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    if (has) {
+                        const int idx = (ring_tail + ring_count + pos) & (GRIDROWS_RING - 1);
+                        ring_x01[idx] = vdouble2{x[0], x[1]};
+                        ring_x23[idx] = vdouble2{x[2], x[3]};
+                        ring_q[idx] = q;
+                    }
+                    ring_count += __popcll(mask);
+                    if (ring_count >= 64) ring_pop(64);
                 }
             }
 #pragma unroll
@@ -243,6 +298,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         p = pe;
         lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
     }
+    if (ring_count > 0) ring_pop(ring_count);
     if constexpr (MODE == FLUX_SSC) {
         if (breach) atomicOr(a.ic_status + m, 2);
     }
