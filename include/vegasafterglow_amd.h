@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 9
+#define VAG_ABI_VERSION 10  /* v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream */
 
 /* error codes */
 #define VAG_OK 0
@@ -42,6 +42,7 @@ extern "C" {
 #define VAG_E_UNSUPPORTED (-4) /* configuration outside the accelerated path (today: a likelihood batch whose models differ in their flags) */
 #define VAG_E_CAPACITY (-5)  /* grid larger than the engine's static limits */
 #define VAG_E_NUMERIC (-6)   /* an ODE row could not find a step size (the reference throws odeint's step_adjustment_error) */
+#define VAG_E_INTERNAL (-7)  /* an invariant of the engine failed (a defect, reported instead of a silently wrong flux) */
 
 /* jet profiles: src/environment/jet.h:84-259 (TophatJet, GaussianJet, PowerLawJet),
  * math::two_component jet.h:421-437 via PyTwoComponentJet pybind/pymodel.cpp:130-146 */

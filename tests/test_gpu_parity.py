@@ -923,6 +923,55 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     assert np.array_equal(band_f, band_t)
 
 
+@pytest.mark.parametrize("case", ["grid", "series", "fused", "rows_batch"])
+def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
+    """The reference builds a cell's SSC spectrum on its first query (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620); the
+    engine gives a table to the cells some (theta, phi) row's observation window touches (vag_ic_band_kernel: ~80 % of the cells of
+    the configs[2] shape) and leaves the others without.  (1) The fluxes are the bits of a pass that builds every table
+    (VAG_IC_ALL_CELLS=1), on every kernel family.  (2) A query of a skipped cell is an engine fault that is reported, not a silent
+    zero: VAG_DEBUG_IC_NEED_SHRINK cuts the window short so that the flux pass meets such cells, and the call must fail loudly."""
+    lib, h = eng
+    kw = dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.3, duration=50.0, ssc=True, kn=True,
+              rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True))
+    t, nu = np.logspace(3, 6, 24), np.array([1e9, 1e15, 1e18, 1e24])  # a window well inside the lattice: cells at both ends unqueried
+    prms = [_abi.make_params(**kw)]
+    if case == "rows_batch":  # enough rows for the row-per-lane grid kernels (>= 4096 blocks of 64 rows)
+        prms = [_abi.make_params(**dict(kw, E_iso=1e52 * (1 + 0.01 * i), resolutions=(0.3, 1.0, 10.0))) for i in range(48)]
+
+    def run():
+        if case == "series":
+            tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+            comps = [np.empty((len(prms), tt.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            arr = (_lib.ModelParams * len(prms))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+            _lib.check(lib.vag_flux_density_components4_batch(h, arr, len(prms), tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
+            return comps
+        if case == "grid":
+            os.environ["VAG_NO_FUSED"] = "1"
+        try:
+            return gpu_components4(eng, prms, t, nu)
+        finally:
+            os.environ.pop("VAG_NO_FUSED", None)
+
+    got = run()
+    os.environ["VAG_IC_ALL_CELLS"] = "1"
+    try:
+        want = run()
+    finally:
+        os.environ.pop("VAG_IC_ALL_CELLS")
+    assert want[1].max() > 0 and want[3].max() > 0
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    os.environ["VAG_DEBUG_IC_NEED_SHRINK"] = "1e-2"
+    try:
+        with pytest.raises(RuntimeError, match="queried an SSC cell that was given no table"):
+            run()
+    finally:
+        os.environ.pop("VAG_DEBUG_IC_NEED_SHRINK")
+    for g, w in zip(run(), want):  # and the context is in order afterwards
+        assert np.array_equal(g, w)
+
+
 @pytest.mark.parametrize("case", ["grid", "series", "fused"])
 def test_ssc_band_breach_rebuilds_the_tables_unclamped(eng, case):
     """ICPhoton::compute_log2_I_nu drops a cell's band clamp and rebuilds its spectrum when a query falls outside the clamped

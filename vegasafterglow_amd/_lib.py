@@ -13,7 +13,7 @@ JET_TOPHAT, JET_GAUSSIAN, JET_POWERLAW, JET_TWO_COMPONENT, JET_MAGNETIZED_TOPHAT
 JET_STEP_POWERLAW, JET_POWERLAW_WING = 5, 6
 MEDIUM_ISM, MEDIUM_WIND = 0, 1
 
-VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY, VAG_E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
+VAG_OK, VAG_E_INVALID, VAG_E_NO_DEVICE, VAG_E_HIP, VAG_E_UNSUPPORTED, VAG_E_CAPACITY, VAG_E_NUMERIC, VAG_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 FLAG_SSC, FLAG_KN, FLAG_RVS, FLAG_RVS_SSC, FLAG_RVS_KN, FLAG_SPREADING, FLAG_MAGNETAR = 1, 2, 4, 8, 16, 32, 64  # VAG_FLAG_* of include/vegasafterglow_amd.h
 FLAG_NON_AXISYMMETRIC = 128
 
@@ -204,4 +204,6 @@ def check(rc):
         raise NotImplementedError(msg)
     if rc == VAG_E_NUMERIC:
         raise RuntimeError("ODE integration failed: " + msg)  # odeint's step_adjustment_error surfaces as RuntimeError
+    if rc == VAG_E_INTERNAL:
+        raise RuntimeError("vegasafterglow_amd internal error (please report): " + msg)
     raise RuntimeError(f"vegasafterglow_amd error {rc}: {msg}")

@@ -315,6 +315,7 @@ struct vag_ctx {
     int h_bands_n = -1;
     int pending_bands = 0;  // set by the host-pointer entry points that know the frequencies; consumed by the next series call
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_icunclamp, d_ssc;
+    DevBuf d_icneed;  // [cells] bytes: 1 = some (theta, phi) row's observation window touches the cell (vag_ic_band_kernel)
     bool count_work = false;
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
@@ -564,7 +565,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
-    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo})
+    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo, &c->d_icneed})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1232,11 +1233,21 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
         double narrow = 1.0;  // test hook: VAG_DEBUG_IC_NARROW=<factor> shrinks the clamp so that the flux pass breaches it
         if (const char* e = std::getenv("VAG_DEBUG_IC_NARROW")) narrow = std::atof(e);
+        // tables only for the cells some row's observation window touches (the reference builds a cell's spectrum on its first
+        // query); VAG_IC_ALL_CELLS=1 builds every cell's table (developer aid: A/B timing, and the loud-fault test)
+        unsigned char* d_need = nullptr;
+        double need_shrink = 1.0;  // test hook: VAG_DEBUG_IC_NEED_SHRINK=<factor> cuts the window short, so that a flux pass meets a skipped cell
+        if (const char* e = std::getenv("VAG_DEBUG_IC_NEED_SHRINK")) need_shrink = std::atof(e);
+        if (!std::getenv("VAG_IC_ALL_CELLS") && c->d_tminmax.p) {
+            if (c->d_icneed.ensure((size_t)std::max<long long>(c->n_cells, 1))) return VAG_E_HIP;
+            HIPCHK(hipMemsetAsync(c->d_icneed.p, 0, (size_t)std::max<long long>(c->n_cells, 1), st));
+            d_need = c->d_icneed.as<unsigned char>();
+        }
         hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
                            c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
                            c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
                            (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr,
-                           c->d_icunclamp.as<int>(), narrow, band_stride);
+                           c->d_icunclamp.as<int>(), narrow, band_stride, c->d_tminmax.as<double>(), d_need, need_shrink);
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
@@ -1245,7 +1256,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
                            c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
-                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride);
+                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
@@ -1274,6 +1285,7 @@ int check_ic_status(vag_ctx* c, int nb) {
     bool breach = false;
     for (int m = 0; m < nb; ++m) {
         if (h[m] & 1) return set_err(VAG_E_CAPACITY, "model %d: SSC lattices exceed the engine limits", m);
+        if (h[m] & 4) return set_err(VAG_E_INTERNAL, "model %d: a flux pass queried an SSC cell that was given no table", m);
         if (h[m] & 2) {
             breach = true;
             ++c->plan.n_models_ssc_rebuilt;

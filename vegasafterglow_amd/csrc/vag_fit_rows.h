@@ -287,7 +287,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         while (seg < seg_end && cut(seg + 1) <= k) flush(seg++);  // step k closes segment(s)
     }
     if constexpr (MODE == FLUX_SSC) {
-        if (breach) atomicOr(a.ic_status + m, 2);
+        if (breach) atomicOr(a.ic_status + m, ic_breach_status(breach));
     }
 #ifdef VAG_SERIES_STAMPS
     if (m == 0 && vb == 0 && lane == 0 && wseg == 0)

@@ -31,8 +31,11 @@ constexpr int GRIDROWS_MAX_SLOTS = 512;
 // interval, 0.9 on average on the C5 shape), so the interpolation done in place ran at the trip count of the busiest lane with
 // ~45 % of the lanes active: 22 of the SSC pass's 31 ms and 23 of the synchrotron pass's 52 ms per 1024 C5 members
 // (profiles/r04_rows_ablation.txt).  A push is ~15 instructions under that mask; the expensive part now always runs on full lanes.
+#ifndef VAG_ROWS_RING
+#define VAG_ROWS_RING 0  // measured SLOWER (C5: 71 / 39 ms per pass against 52 / 31): see DESIGN.md 4h; kept as a build option
+#endif
 constexpr int GRIDROWS_RING = 128;  // items: a push pass adds at most 64 to at most 63 left over
-constexpr int GRIDROWS_RING_BYTES = GRIDROWS_RING * (2 * 16 + 4);  // {x0, x1}, {x2, x3}, time index
+constexpr int GRIDROWS_RING_BYTES = VAG_ROWS_RING ? GRIDROWS_RING * (2 * 16 + 4) : 0;  // {x0, x1}, {x2, x3}, time index
 
 __host__ __device__ inline int grid_rows_stripes(int slots) { return slots <= 128 ? 4 : 2; }
 __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
@@ -46,7 +49,7 @@ template <int MODE>
 // 168 VGPRs: three wavefronts per SIMD; the SSC pass (a table look-up per band, no spectrum constants) fits 128 with 12 B of
 // scratch and gains 9 % from the fourth wavefront, the others would spill 100-200 B per lane and lose 70 %
 #ifndef VAG_ROWS_SSC_WG
-#define VAG_ROWS_SSC_WG 4
+#define VAG_ROWS_SSC_WG 3  // three workgroups per CU (168 VGPRs, no scratch): the look-ups in flight a node ahead need the registers, 4 spills 92-160 B
 #endif
 __global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? VAG_ROWS_SSC_WG : VAG_ROWS_MIN_WG)
 vag_flux_grid_rows_kernel(SeriesArgs a) {
@@ -78,6 +81,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int p0 = vb * FITROWS_ROWS;
     if (p0 >= n_pairs) return;
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
+    // log2 nu (1 + z) of the request's frequencies, wavefront-uniform: scalar loads into scalar registers (read back from LDS they
+    // cost the node loop four round trips with a wait each)
+    double nu_b[GRIDROWS_BANDS];
+#pragma unroll
+    for (int b = 0; b < GRIDROWS_BANDS; ++b) nu_b[b] = a.lg2_nu_obs[b < NB ? b : 0] + Mp->lg2_1pz;
     const int K = Mp->n_t, n_phi_eff = Mp->n_phi_eff;
     const double one_plus_z = 1 + a.params[m].z;
     SpecConst sc;
@@ -113,7 +121,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
             const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
 #pragma unroll
             for (int b = 0; b < GRIDROWS_BANDS; ++b)
-                if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[b] - dop, &breach) + geom;
+                if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, nu_b[b] - dop, &breach) + geom;
         } else {
             SpecRegs regs;
 #pragma unroll
@@ -129,15 +137,15 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
                 q.head(cq, K);
                 bool any = false;
 #pragma unroll
-                for (int b = 0; b < GRIDROWS_BANDS; ++b) any = any || (b < NB && q.applies(s_nu[b] - dop));
+                for (int b = 0; b < GRIDROWS_BANDS; ++b) any = any || (b < NB && q.applies(nu_b[b] - dop));
                 if (any) q.rest(cq, K);
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b)
-                    if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(s_nu[b] - dop), q, sc, s_nu[b] - dop, sp_tab) + geom;
+                    if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(nu_b[b] - dop), q, sc, nu_b[b] - dop, sp_tab) + geom;
             } else {
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b)
-                    if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_nu[b] - dop, sp_tab) + geom;
+                    if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, nu_b[b] - dop, sp_tab) + geom;
             }
         }
     };
@@ -182,28 +190,27 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     // the last node -- either makes the interval's slope non-finite, which is all the sum asks) and the gathered pair
     [[maybe_unused]] double pfrac[GRIDROWS_BANDS];
     [[maybe_unused]] vdouble2_a8 pI[GRIDROWS_BANDS];
-    [[maybe_unused]] const double* tab_row = nullptr;
-    [[maybe_unused]] auto request_hdr = [&](int k) {
-        const double* tab = tab_row + (size_t)(k < K ? k : K - 1) * FLUX_IC_STRIDE;
+    [[maybe_unused]] const double* tab_next = nullptr;  // table of node min(k + 1, K - 1) while iteration k runs: walked, never multiplied out
+    [[maybe_unused]] auto request_hdr = [&](const double* tab) {
         hq_n = tab[0], hq_first = tab[1], hq_last = tab[2], hq_tmin = tab[3], hq_tmax = tab[4];
     };
     [[maybe_unused]] int p_breach = 0;  // band-contract breach of the pending look-ups: counts only if the node is then used
-    [[maybe_unused]] auto issue = [&](int k, double dop) {  // node k's look-ups from the header at hand
-        const double* tab = tab_row + (size_t)(k < K ? k : K - 1) * FLUX_IC_STRIDE;
+    [[maybe_unused]] auto issue = [&](const double* tab, double dop) {  // a node's look-ups from the header at hand
         p_breach = 0;
 #pragma unroll
         for (int b = 0; b < GRIDROWS_BANDS; ++b)
             if (b < NB) {
-                const IcTabQuery q = ic_table_query(hq_n, hq_first, hq_last, hq_tmin, hq_tmax, s_nu[b] - dop, &p_breach);
+                const IcTabQuery q = ic_table_query(hq_n, hq_first, hq_last, hq_tmin, hq_tmax, nu_b[b] - dop, &p_breach);
                 pI[b] = ic_table_gather(tab, q.idx);
                 pfrac[b] = q.none ? NAN : q.frac;
             }
     };
     if constexpr (MODE == FLUX_SSC) {
-        tab_row = a.ictab + (size_t)cell0 * FLUX_IC_STRIDE;
-        request_hdr(1);
-        issue(1, dop_b);
-        request_hdr(2);
+        tab_next = a.ictab + (size_t)(cell0 + 1) * FLUX_IC_STRIDE;  // (K >= 2: a lattice has at least two nodes)
+        request_hdr(tab_next);
+        issue(tab_next, dop_b);
+        tab_next += 2 < K ? FLUX_IC_STRIDE : 0;
+        request_hdr(tab_next);
     }
     // cursor into the ascending requested times: the first one at or beyond node 0 (bisection over the 128 slots, +inf beyond nt)
     int p = nt;
@@ -253,10 +260,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
 #pragma unroll
             for (int b = 0; b < GRIDROWS_BANDS; ++b)
                 if (b < NB) Bcur[b] = need ? fma(pfrac[b], pI[b].y - pI[b].x, pI[b].x) + geom : Bcur[b];
-            if (need && p_breach) breach = 1;
+            breach |= need ? p_breach : 0;
 #ifndef VAG_ROWS_ABLATE_EVAL  // timing experiment only: no table look-ups
-            issue(k + 1, dop_c);
-            request_hdr(k + 2);
+            issue(tab_next, dop_c);
+            tab_next += k + 2 < K ? FLUX_IC_STRIDE : 0;
+            request_hdr(tab_next);
 #endif
         }
         if (__ballot(need) != 0) {
@@ -272,6 +280,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
                 double d[GRIDROWS_BANDS];
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b) d[b] = Bcur[b] - Bprev[b];  // slope finite <=> d finite (observer.h:422-426)
+#if VAG_ROWS_RING
                 // push the lane's times inside the interval, one per pass (the passes are short: the trip count of the busiest
                 // lane no longer multiplies the exp2 work); 64 gathered items are worked off at once
                 for (int q = p; __ballot(q < pe) != 0; ++q) {
@@ -291,6 +300,22 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
                     ring_count += __popcll(mask);
                     if (ring_count >= 64) ring_pop(64);
                 }
+#else
+                // (Measured and rejected, r04: the four frequencies' exponentials as one straight-line block so that their Horner
+                // chains interleave -- 168 VGPRs with 12-20 B of scratch, C5 53.7 / 30.4 ms per pass against 51.7 / 31.0.)
+                for (int q = p; q < pe; ++q) {
+                    const double w = (s_tobs[q] - lt_a) * inv_dt;  // position inside the interval, shared by the frequencies
+#pragma unroll
+                    for (int b = 0; b < GRIDROWS_BANDS; ++b)
+#ifdef VAG_ROWS_ABLATE_ATOMICS  // timing experiment only: the sums kept in a register
+                        if (b < NB && isfinite(d[b])) Bcur[b] += 1e-300 * exp2_fast(fma(d[b], w, Bprev[b]));
+#elif defined(VAG_ROWS_ABLATE_EXP2)  // timing experiment only: the accumulate without the exponential
+                        if (b < NB && isfinite(d[b])) lds_add_f64(my_acc + b * nt + q, fma(d[b], w, Bprev[b]));
+#else
+                        if (b < NB && isfinite(d[b])) lds_add_f64(my_acc + b * nt + q, exp2_fast(fma(d[b], w, Bprev[b])));
+#endif
+                }
+#endif
             }
 #pragma unroll
             for (int b = 0; b < GRIDROWS_BANDS; ++b) Bprev[b] = Bcur[b];
@@ -298,9 +323,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         p = pe;
         lt_a = lt_b, lt_b = lt_c, dop_b = dop_c, lr2_b = lr2_c;
     }
+#if VAG_ROWS_RING
     if (ring_count > 0) ring_pop(ring_count);
+#endif
     if constexpr (MODE == FLUX_SSC) {
-        if (breach) atomicOr(a.ic_status + m, 2);
+        if (breach) atomicOr(a.ic_status + m, ic_breach_status(breach));
     }
     wave_sync();
     double* dst = a.partial + ((size_t)m * a.max_chunks + vb) * slots;

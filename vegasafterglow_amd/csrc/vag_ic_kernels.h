@@ -300,7 +300,10 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
                    const double* __restrict__ cellgeo /* spreading jets: [rows][3][n_t], else nullptr */,
                    const int* __restrict__ unclamp /* [nb]: the model's tables span the full theoretical range */,
                    double debug_narrow /* 1, or a test's factor on the upper band edge (forces a band breach) */,
-                   int band_stride /* >= the longest lattice of the batch */) {
+                   int band_stride /* >= the longest lattice of the batch */,
+                   const double* __restrict__ tminmax /* [2] extrema of the requested observer times [s] */,
+                   unsigned char* __restrict__ need /* [cells], cleared by the caller, or nullptr: every cell gets a table */,
+                   double debug_need_shrink /* 1, or a test's factor on the window's upper end (forces a query of a skipped cell) */) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -309,6 +312,8 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
             band[((size_t)m * 2 + 0) * band_stride + k] = 0.0;
             band[((size_t)m * 2 + 1) * band_stride + k] = INFINITY;
         }
+        if (need)  // (a rebuilt model keeps every table: the rebuild is the rare path)
+            for (long long q = cell_off[m] + lane; q < cell_off[m + 1]; q += 64) need[q] = 1;
         return;
     }
     __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
@@ -340,8 +345,21 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
         cphi_max = fmax(cphi_max, gph[ii]);
         cphi_min = fmin(cphi_min, gph[ii]);
     }
+    // Which cells does the flux integration query at all?  The reference builds a cell's spectrum on its first query
+    // (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620): a boundary value at node k is asked for only when the interval before
+    // or after it holds a requested time for some (theta, phi) row of the cell (observer.h:355-445).  The test here is the range form
+    // of that -- for some row, t_obs(k - 1) <= t_max and t_obs(k + 1) >= t_min of the request, with the rows' extreme viewing
+    // cosines standing for the phi rows and a 1e-9 margin for the roundings of the flux kernels' log2 times -- a superset of the
+    // queried cells (C3: 0.794 of the cells against 0.791 queried exactly; profiles/debug/ssc_needed_cells.py).  A cell that is
+    // skipped and queried nevertheless answers loudly (header n = -1, status bit 4).
+    const double one_plus_z = 1 + P.z;
+    const double t_req_min = need ? tminmax[0] * U_SEC * (1 - 1e-9) : 0, t_req_max = need ? tminmax[1] * U_SEC * (1 + 1e-9) * debug_need_shrink : 0;
+    auto t_obs = [&](const double* par, int kk, double cv) {  // calc_eat_non_spreading / calc_t_obs, observer.cpp:51-205
+        return (par[(long long)VP_TENG * nt + kk] + (1 - cv) * par[(long long)VP_R * nt + kk] / C_C) * one_plus_z;
+    };
     for (int k = lane; k < nt; k += 64) {
         double dmin_k = INFINITY, dmax_k = -INFINITY;
+        const int k_prev = k > 0 ? k - 1 : 0, k_next = k + 1 < nt ? k + 1 : nt - 1;
         if (M.rep_phi_stride) {  // (phi, theta) pair rows (non-axisymmetric spreading jet): every pair's own cell at node k
             for (int j = 0; j < M.n_theta; ++j)
                 for (int i = 0; i < M.n_phi_eff; ++i) {
@@ -352,20 +370,31 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
                     const double lg = -log2(G - u * (geo[nt + k] * gph[i] * sin_obs + geo[k] * cos_obs));
                     dmax_k = fmax(dmax_k, lg);
                     dmin_k = fmin(dmin_k, lg);
+                    if (need) {
+                        const double cv_p = geo[nt + k_prev] * gph[i] * sin_obs + geo[k_prev] * cos_obs;
+                        const double cv_n = geo[nt + k_next] * gph[i] * sin_obs + geo[k_next] * cos_obs;
+                        if (t_obs(par, k_prev, cv_p) <= t_req_max && t_obs(par, k_next, cv_n) >= t_req_min) need[cell_off[m] + rr * nt + k] = 1;
+                    }
                 }
         } else
         for (int j = 0; j < M.n_theta; ++j) {
             const double* par = cellpar + (cell_off[m] + (long long)rep_of[j] * nt) * VAG_NPAR;
             const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];
             double cvmax = s_cvmax[j], cvmin = s_cvmin[j];
+            double cvmax_p = cvmax, cvmin_n = cvmin;  // the earliest-arriving row at node k - 1, the latest at node k + 1
             if (cellgeo) {  // theta evolves: the extrema over phi of cos_v = sin th cos phi sin_obs + cos th cos_obs per cell
                 const double* geo = cellgeo + (cell_off[m] + (long long)rep_of[j] * nt) * 3;
                 const double ct = geo[k], st = geo[nt + k];
                 cvmax = st * cphi_max * sin_obs + ct * cos_obs;
                 cvmin = st * cphi_min * sin_obs + ct * cos_obs;
+                cvmax_p = geo[nt + k_prev] * cphi_max * sin_obs + geo[k_prev] * cos_obs;
+                cvmin_n = geo[nt + k_next] * cphi_min * sin_obs + geo[k_next] * cos_obs;
             }
             dmax_k = fmax(dmax_k, -log2(G - u * cvmax));
             dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
+            // (several theta rows may share the cell: every writer stores the same 1)
+            if (need && t_obs(par, k_prev, cvmax_p) <= t_req_max && t_obs(par, k_next, cvmin_n) >= t_req_min)
+                need[cell_off[m] + (long long)rep_of[j] * nt + k] = 1;
         }
         band[((size_t)m * 2 + 0) * band_stride + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
         band[((size_t)m * 2 + 1) * band_stride + k] = exp2((nu_hi + lg2_1pz) - dmin_k) * debug_narrow;  // nu_eval_max_k
@@ -464,7 +493,7 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
                    double* __restrict__ ictab, int* __restrict__ ic_status,
                    unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
-                   int band_stride) {
+                   int band_stride, const unsigned char* __restrict__ need /* [cells] or nullptr (vag_ic_band_kernel) */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     int lo = 0, hi = nb;
@@ -481,6 +510,10 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
     tab[0] = 0;
     const int nt = meta[m].n_t;
     if (meta[m].status != 0) return;
+    if (need && !need[c]) {  // no (theta, phi) row queries this cell: no table, and a query would be an engine fault (status bit 4)
+        tab[0] = -1;
+        return;
+    }
     const int k = (int)((c - lay.cell_off[m]) % nt);
     const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
     const double gamma_M = det[VD_GAMMA_MAX * n_cells + c];
@@ -898,6 +931,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 // intervals' slopes), evaluated with ~2e-14 of rounding in log2 I instead of reproducing the scan's last bit -- 15 instructions and
 // ONE 16-byte gather {Ilo, Ihi} where the node-exact form took 45 and two dependent 8-byte gathers (r04: this evaluator is the
 // tabulated-SSC flux pass, a third of a configs[4] call).
+// `breach` of the evaluators below -> bits of the model's status word: 2 = a query outside the clamped band but inside the
+// theoretical range (the tables are rebuilt unclamped), 4 = a query of a cell that was given no table
+VAG_DEV int ic_breach_status(int breach) { return ((breach & 1) << 1) | (breach & 4); }
 typedef double vdouble2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 constexpr double IC_INV_STEP = 1.0 / (2 * IC_Q);
 struct IcTabQuery {  // the look-up split at its memory access, for callers that issue the gather ahead of its use
@@ -908,7 +944,9 @@ struct IcTabQuery {  // the look-up split at its memory access, for callers that
 VAG_DEV IcTabQuery ic_table_query(double h_n, double first, double last, double th_min, double th_max, double x, int* breach) {
     IcTabQuery q;
     const bool empty = h_n < 2.0, above = x > last;
-    if (!empty && ((above && x < th_max) || (x < first && x > th_min))) *breach = 1;
+    // (bitwise on purpose: four compares and three scalar mask operations, no branches around single compares)
+    *breach |= (!empty & ((above & (x < th_max)) | ((x < first) & (x > th_min)))) ? 1 : 0;
+    *breach |= h_n < 0 ? 4 : 0;  // a cell vag_ic_band_kernel declared outside every row's observation window: must not happen
     const double u = (x - first) * IC_INV_STEP;
     const double fl = __builtin_fmin(__builtin_fmax(floor(u), 0.0), __builtin_fmax(h_n - 2.0, 0.0));  // v_max_f64 / v_min_f64, no selects
     q.idx = (int)fl;

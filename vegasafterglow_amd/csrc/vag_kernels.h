@@ -529,8 +529,9 @@ template <class P1, class P2, class Tab>
 VAG_DEV void log2_I_nu_ic_pair(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double x0, double x1, Tab sp, double& b0,
                                double& b1);
 VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
-VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double phase, double h_idx0, double th_min,
+VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double first, double last, double th_min,
                                  double th_max, double x, int* breach);
+VAG_DEV int ic_breach_status(int breach);
 constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
 constexpr int FLUX_IC_STRIDE = 198;  // == IC_STRIDE
 
@@ -1225,7 +1226,7 @@ vag_flux_grid_kernel(FluxArgs a) {
         }
     }
     if constexpr (MODE == FLUX_SSC || MODE == FLUX_FUSED) {
-        if (breach) atomicOr(a.ic_status + m, 2);
+        if (breach) atomicOr(a.ic_status + m, ic_breach_status(breach));
     }
     __syncthreads();
     // partial grid of this workgroup, stored [l][idx] like the reference's F_nu (nu outer)
@@ -1666,7 +1667,7 @@ vag_flux_series_kernel(SeriesArgs a) {
     if (m == 0 && vb == 0 && tid == 0)
         printf("series wave 0: rows %d K %d  cycles: staging %lld  eat %lld  bracket %lld  items %lld  interp+rest %lld\n", p1 - p0, K, c_stage, c_eat, c_brk, c_items, c_pts);
 #endif
-    if (MODE == FLUX_SSC && breach) atomicOr(a.ic_status + m, 2);
+    if (MODE == FLUX_SSC && breach) atomicOr(a.ic_status + m, ic_breach_status(breach));
 }
 
 // chi^2 / log-likelihood of Fitter._evaluate (VegasAfterglow/fitting/fitter.py:497-533,
