@@ -825,6 +825,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #endif
         // ex and term of one (energy, bin) pair, added to the diagonal histograms.  `asm volatile("")` inside a branch: keep it
         // a branch under the exec mask (scalar instructions) -- if-converted, the three-way choice costs ten v_cndmask per pair
+        // (Measured and rejected, r04: the second histogram kept as E - D -- above the split and below it the edge term repeats the
+        // bin integral, so only the bin right below the split feeds it and every other pair needs ONE ds_add_f64: 20.33 against
+        // 19.87 ms per launch on the configs[2] batch; the branch around the rare second add costs more than the add.)
         auto pair = [&](int i, double dNe, int j_split, const Bin& b, const vdouble2& nd0, const vdouble2& nd1) {
             double ve = b.exth, vt = b.termth;
             if (WITH_KN && b.bin && b.j >= j_split - 1) {  // at or right below the split: the bin sees the lattice
