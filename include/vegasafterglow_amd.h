@@ -458,6 +458,9 @@ typedef struct vag_plan {
      * clamped band (ICPhoton::compute_log2_I_nu's self-healing path, inverse-compton.h:626-635); the pass was then repeated */
     int32_t n_models_ssc_rebuilt;
     int32_t pad_plan;
+    /* ABI v10: bytes of the pool that holds the SSC tables of one shock of the batch (each table as long as its own output lattice;
+     * cells no (theta, phi) row queries have none) -- the largest table build of the last call */
+    int64_t ic_pool_bytes;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -96,7 +96,8 @@ class Plan(C.Structure):
                 ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32),
                 ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32),
                 ("n_walkers_rejected", C.c_int32), ("n_walkers_ssc_failed", C.c_int32),
-                ("ic_terms", C.c_int64), ("ic_nodes", C.c_int64), ("n_models_ssc_rebuilt", C.c_int32), ("pad_plan", C.c_int32)]
+                ("ic_terms", C.c_int64), ("ic_nodes", C.c_int64), ("n_models_ssc_rebuilt", C.c_int32), ("pad_plan", C.c_int32),
+                ("ic_pool_bytes", C.c_int64)]
 
 
 class Limits(C.Structure):

@@ -314,7 +314,10 @@ struct vag_ctx {
     int h_bandbuf[512 + 8] = {};  // host mirror of d_bandidx (skips the upload while a fit keeps its data)
     int h_bands_n = -1;
     int pending_bands = 0;  // set by the host-pointer entry points that know the frequencies; consumed by the next series call
-    DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_ictab, d_icstatus, d_icunclamp, d_ssc;
+    DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_icstatus, d_icunclamp, d_ssc;
+    // SSC tables: a header per cell, the lattice plan between the plan and the spectrum kernel, and the pool of tables (each as long
+    // as its own output lattice; offsets handed out by vag_ic_plan_kernel, d_icused counts the doubles in use)
+    DevBuf d_ichdr, d_icplan, d_icpool, d_icused;
     DevBuf d_icneed;  // [cells] bytes: 1 = some (theta, phi) row's observation window touches the cell (vag_ic_band_kernel)
     bool count_work = false;
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
@@ -550,7 +553,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ictab,
+    for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
@@ -1045,7 +1048,8 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
             a.partial = c->d_partial.as<double>();
             a.sp_table = c->d_sptab.as<double>();
             a.cellq = c->d_cellq.as<double>();
-            a.ictab = c->d_ictab.as<double>();
+            a.ichdr = c->d_ichdr.as<double>();
+            a.icpool = c->d_icpool.as<double>();
             a.ic_status = c->d_icstatus.as<int>();
             c->plan.spec_evals += c->eat_cells * nnu;
             c->plan.interps += c->total_pairs * (long long)nt * nnu;
@@ -1096,7 +1100,8 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     a.sp_table = c->d_sptab.as<double>();
     a.work_count = nullptr;
     a.cellq = c->d_cellq.as<double>();
-    a.ictab = c->d_ictab.as<double>();
+    a.ichdr = c->d_ichdr.as<double>();
+    a.icpool = c->d_icpool.as<double>();
     a.ic_status = c->d_icstatus.as<int>();
     a.cellgeo = c->d_cellgeo.as<double>();
     const bool spreading = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
@@ -1217,7 +1222,10 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     StageScope ps(c, PS_IC_PHOTONS);
     const int band_stride = std::max(c->max_k, 1);  // [nb][2][band_stride]
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * band_stride)) return VAG_E_HIP;
-    if (c->d_ictab.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_STRIDE)) return VAG_E_HIP;
+    if (c->d_ichdr.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_HDR)) return VAG_E_HIP;
+    if (c->d_icplan.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_PLAN)) return VAG_E_HIP;
+    if (c->d_icused.ensure(sizeof(unsigned long long))) return VAG_E_HIP;
+    if (c->d_icpool.ensure(sizeof(double) * 1024)) return VAG_E_HIP;  // (never null: the empty tables point at its first words)
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
     if (c->d_icunclamp.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
     if (rebuild) {
@@ -1253,15 +1261,25 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icwork.p, 0, 2 * sizeof(unsigned long long), st));
         }
+        const unsigned long long pool_first = 2;  // the pool's first two words serve the gathers of the cells without a table
+        HIPCHK(hipMemcpyAsync(c->d_icused.p, &pool_first, sizeof pool_first, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
-                           c->d_ictab.as<double>(), c->d_icstatus.as<int>(),
-                           c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need);
+                           c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icused.as<unsigned long long>(),
+                           c->d_icstatus.as<int>(), c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need);
         HIPCHK(hipGetLastError());
+        // The pool grows to what the plan handed out (grow-only: in a sampler's loop it stops growing after a few calls).  The host has
+        // to see the total before the spectrum kernel may write: one 8-byte copy and a wait per table build (~20 us against the
+        // milliseconds of the build; an SSC pass ends with such a wait anyway, check_ic_status).
+        unsigned long long pool_used = 0;
+        HIPCHK(hipMemcpyAsync(&pool_used, c->d_icused.p, sizeof pool_used, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (c->d_icpool.ensure(sizeof(double) * (size_t)(pool_used + pool_used / 16 + 1024))) return VAG_E_HIP;
+        c->plan.ic_pool_bytes = std::max<long long>(c->plan.ic_pool_bytes, (long long)(sizeof(double) * pool_used));
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
                            c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_sptab.as<double>(),
-                           c->d_knlut.as<double>(), c->d_ictab.as<double>());
+                           c->d_knlut.as<double>(), c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icpool.as<double>());
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             unsigned long long h[2] = {0, 0};
@@ -1554,7 +1572,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         a.band_idx = c->d_bandidx.as<int>();
         a.band_first = c->d_bandidx.as<int>() + FITROWS_MAX_POINTS;
         a.cellq = c->d_cellq.as<double>();
-        a.ictab = c->d_ictab.as<double>();
+        a.ichdr = c->d_ichdr.as<double>();
+        a.icpool = c->d_icpool.as<double>();
         a.ic_status = c->d_icstatus.as<int>();
         c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
         c->plan.interps = c->total_pairs * (long long)n;
@@ -1638,7 +1657,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     }
     SeriesArgs a;
     a.cellq = c->d_cellq.as<double>();
-    a.ictab = c->d_ictab.as<double>();
+    a.ichdr = c->d_ichdr.as<double>();
+    a.icpool = c->d_icpool.as<double>();
     a.ic_status = c->d_icstatus.as<int>();
     a.cellgeo = c->d_cellgeo.as<double>();
     a.n_bands = n_bands;

@@ -153,8 +153,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     auto boundary = [&](int k, double dop, double lr2, double ldo, double (&B)[NBMAX]) {
         const double geom = ((SPREAD ? ldo : lg2_dOmega) + lr2) + 3.0 * dop;  // (non-spreading: the per-node copies stay dead)
         if constexpr (MODE == FLUX_SSC) {  // SSC tables (vag_ic_kernels.h)
-            const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
-            const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
+            const double* hdr = a.ichdr + (size_t)(cell0 + k) * FLUX_IC_HDR;
+            const double h0 = hdr[0], h1 = hdr[1], h2 = hdr[2], h3 = hdr[3], h4 = hdr[4];
+            const double* tab = a.icpool + (unsigned long long)hdr[5];
 #pragma unroll
             for (int b = 0; b < NBMAX; ++b)
                 if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_band[b] - dop, &breach) + geom;

@@ -117,8 +117,9 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     auto boundary = [&](int k, double dop, double lr2, double (&B)[GRIDROWS_BANDS]) {
         const double geom = (lg2_dOmega + lr2) + 3.0 * dop;
         if constexpr (MODE == FLUX_SSC) {  // (only node 0: the loop below keeps the later nodes' look-ups in flight a node ahead)
-            const double* tab = a.ictab + (size_t)(cell0 + k) * FLUX_IC_STRIDE;
-            const double h0 = tab[0], h1 = tab[1], h2 = tab[2], h3 = tab[3], h4 = tab[4];
+            const double* hdr = a.ichdr + (size_t)(cell0 + k) * FLUX_IC_HDR;
+            const double h0 = hdr[0], h1 = hdr[1], h2 = hdr[2], h3 = hdr[3], h4 = hdr[4];
+            const double* tab = a.icpool + (unsigned long long)hdr[5];
 #pragma unroll
             for (int b = 0; b < GRIDROWS_BANDS; ++b)
                 if (b < NB) B[b] = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, nu_b[b] - dop, &breach) + geom;
@@ -185,17 +186,18 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     // dependent trips to L2 per node, which three or four wavefronts per SIMD cannot hide (r03: 54 % VALU busy).  Both are taken
     // off the chain: node k + 2's header is requested with its shock state, node k + 1's gathers are issued as soon as its
     // Doppler factor exists (one iteration before the values are used), for every lane whether or not it will need the node.
-    [[maybe_unused]] double hq_n = 0, hq_first = 0, hq_last = 0, hq_tmin = 0, hq_tmax = 0;  // header of the node the next issue serves
+    [[maybe_unused]] double hq_n = 0, hq_first = 0, hq_last = 0, hq_tmin = 0, hq_tmax = 0, hq_off = 0;  // header of the node the next issue serves
     // a pending look-up is its position inside the table interval (NaN where the reference returns -inf: no table, or beyond
     // the last node -- either makes the interval's slope non-finite, which is all the sum asks) and the gathered pair
     [[maybe_unused]] double pfrac[GRIDROWS_BANDS];
     [[maybe_unused]] vdouble2_a8 pI[GRIDROWS_BANDS];
-    [[maybe_unused]] const double* tab_next = nullptr;  // table of node min(k + 1, K - 1) while iteration k runs: walked, never multiplied out
-    [[maybe_unused]] auto request_hdr = [&](const double* tab) {
-        hq_n = tab[0], hq_first = tab[1], hq_last = tab[2], hq_tmin = tab[3], hq_tmax = tab[4];
+    [[maybe_unused]] const double* hdr_next = nullptr;  // header of node min(k + 2, K - 1) while iteration k runs: walked, never multiplied out
+    [[maybe_unused]] auto request_hdr = [&](const double* hdr) {
+        hq_n = hdr[0], hq_first = hdr[1], hq_last = hdr[2], hq_tmin = hdr[3], hq_tmax = hdr[4], hq_off = hdr[5];
     };
     [[maybe_unused]] int p_breach = 0;  // band-contract breach of the pending look-ups: counts only if the node is then used
-    [[maybe_unused]] auto issue = [&](const double* tab, double dop) {  // a node's look-ups from the header at hand
+    [[maybe_unused]] auto issue = [&](double dop) {  // a node's look-ups from the header at hand
+        const double* tab = a.icpool + (unsigned long long)hq_off;
         p_breach = 0;
 #pragma unroll
         for (int b = 0; b < GRIDROWS_BANDS; ++b)
@@ -206,11 +208,11 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
             }
     };
     if constexpr (MODE == FLUX_SSC) {
-        tab_next = a.ictab + (size_t)(cell0 + 1) * FLUX_IC_STRIDE;  // (K >= 2: a lattice has at least two nodes)
-        request_hdr(tab_next);
-        issue(tab_next, dop_b);
-        tab_next += 2 < K ? FLUX_IC_STRIDE : 0;
-        request_hdr(tab_next);
+        hdr_next = a.ichdr + (size_t)(cell0 + 1) * FLUX_IC_HDR;  // (K >= 2: a lattice has at least two nodes)
+        request_hdr(hdr_next);
+        issue(dop_b);
+        hdr_next += 2 < K ? FLUX_IC_HDR : 0;
+        request_hdr(hdr_next);
     }
     // cursor into the ascending requested times: the first one at or beyond node 0 (bisection over the 128 slots, +inf beyond nt)
     int p = nt;
@@ -262,9 +264,9 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
                 if (b < NB) Bcur[b] = need ? fma(pfrac[b], pI[b].y - pI[b].x, pI[b].x) + geom : Bcur[b];
             breach |= need ? p_breach : 0;
 #ifndef VAG_ROWS_ABLATE_EVAL  // timing experiment only: no table look-ups
-            issue(tab_next, dop_c);
-            tab_next += k + 2 < K ? FLUX_IC_STRIDE : 0;
-            request_hdr(tab_next);
+            issue(dop_c);
+            hdr_next += k + 2 < K ? FLUX_IC_HDR : 0;
+            request_hdr(hdr_next);
 #endif
         }
         if (__ballot(need) != 0) {

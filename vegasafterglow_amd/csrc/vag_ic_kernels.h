@@ -23,10 +23,15 @@ enum {
 
 // SSC table of one cell: header + log2 I on the phase-locked output lattice (inverse-compton.h:354-369,595-606)
 constexpr int IC_MAX_OUT = 192;  // three output nodes per lane; an unclamped table needs at most ~(IC_MAX_NU - 1) + (IC_MAX_G - 1) + 3
-constexpr int IC_HDR = 6;  // n_ic, first node, last node, log2 theory min, log2 theory max, spare
-constexpr int IC_STRIDE = IC_HDR + IC_MAX_OUT;
+// SSC tables in HBM (r04): a header per cell -- {n (0: no table, -1: cell never queried), first node, last node, log2 of the theoretical
+// minimum / maximum, offset of the table in the pool [doubles], 2 spare} -- and ONE pool that holds the tables back to back, each as
+// long as its own output lattice (~70 nodes where the fixed layout reserved 192, none for the cells no row queries: 9 GB -> ~3 GB on
+// the 512-model configs[2] batch).  The offsets are handed out by vag_ic_plan_kernel (one atomic reservation per workgroup).
+constexpr int IC_HDR = 8;
+enum { ICH_N = 0, ICH_FIRST, ICH_LAST, ICH_TMIN, ICH_TMAX, ICH_OFF };
+constexpr int IC_PLAN = 16;  // per-cell lattice plan between vag_ic_plan_kernel and vag_ic_photon_kernel (ICP_* words)
 constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = (IC_MAX_G - 1) + (IC_MAX_NU - 1) + 1;
-static_assert(VAG_NQ == FLUX_NQ && IC_STRIDE == FLUX_IC_STRIDE, "keep vag_kernels.h forward constants in sync");
+static_assert(VAG_NQ == FLUX_NQ && IC_HDR == FLUX_IC_HDR, "keep vag_kernels.h forward constants in sync");
 constexpr double IC_Q = 3.321928094887362 / 8;  // lattice_quantum
 constexpr double IC_X0 = 0.47140452079103166;
 
@@ -479,110 +484,145 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 #endif
 // Lattice plan of every cell, one LANE per cell (compute_grid_params + the sizes of initialize_grids, inverse-compton.h:297-369).
 // These few hundred instructions are the same for all 64 lanes of the wavefront that builds the cell's spectrum, so they are
-// done here at 1/64 of the cost and handed over in the cell's own table row: the header words [0..4] are final, the words from
-// IC_HDR on carry the plan until vag_ic_photon_kernel replaces them by the table.  Cells that get no table (failed model,
-// degenerate or over-capacity lattice) are finished here: n = 0 and the theoretical range.
+// done here at 1/64 of the cost and handed over in the cell's plan row (ICP_* words); the cell's header is final here, including
+// the place of its table in the pool: the lanes of a workgroup add up their table lengths and ONE atomic per workgroup reserves the
+// block (the order of the blocks in the pool follows the scheduler; the values in them do not depend on it).  Cells that get no
+// table (failed model, degenerate or over-capacity lattice: n = 0 and the theoretical range; a cell no row queries: n = -1) are
+// finished here.
 enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX,
        ICP_SMOOTH_THICK, ICP_LOG2_X_FAR /* SpecConst of the model's p: a division and a library log2 per wavefront otherwise */,
        ICP_PHASE, ICP_N };
+static_assert(ICP_N <= IC_PLAN, "plan row");
 // output lattice node q of a table: phase + IC_Q (idx0 + 2 q), idx0 + 2 q an integer far below 2^53 formed in double -- exactly the
 // value the reference converts from its integer (log2_nu_IC, inverse-compton.h:595-606)
 VAG_DEV double ic_out_node(double phase, double idx0, int q) { return phase + IC_Q * (idx0 + 2.0 * (double)q); }
 __global__ void __launch_bounds__(256)
 vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
-                   double* __restrict__ ictab, int* __restrict__ ic_status,
+                   double* __restrict__ ichdr /* [cells][IC_HDR] */, double* __restrict__ icplan /* [cells][IC_PLAN] */,
+                   unsigned long long* __restrict__ pool_used /* doubles handed out so far (starts at 2: slot 0 serves the empty tables) */,
+                   int* __restrict__ ic_status,
                    unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
                    int band_stride, const unsigned char* __restrict__ need /* [cells] or nullptr (vag_ic_band_kernel) */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    int lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (lay.cell_off[mid] <= c)
-            lo = mid;
-        else
-            hi = mid;
+    const bool live = c < n_cells && c < lay.cell_off[nb];  // n_cells is the arrays' stride (>= the batch's cell count)
+    double* hdr = ichdr + (size_t)(live ? c : 0) * IC_HDR;
+    double* plan = icplan + (size_t)(live ? c : 0) * IC_PLAN;
+    // the cell's plan; returns the length of its table (0: none)
+    auto plan_cell = [&]() -> int {
+        int lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (lay.cell_off[mid] <= c)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int m = lo;
+        plan[ICP_RUN] = 0;
+        hdr[ICH_N] = 0;
+        hdr[ICH_OFF] = 0;
+        const int nt = meta[m].n_t;
+        if (meta[m].status != 0) return 0;
+        if (need && !need[c]) {  // no (theta, phi) row queries this cell: no table, and a query would be an engine fault (status bit 4)
+            hdr[ICH_N] = -1;
+            return 0;
+        }
+        const int k = (int)((c - lay.cell_off[m]) % nt);
+        const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
+        const double gamma_M = det[VD_GAMMA_MAX * n_cells + c];
+        const double nu_m = det[VD_NU_M * n_cells + c], nu_a = det[VD_NU_A * n_cells + c], nu_M = det[VD_NU_MAX * n_cells + c];
+        const double nu_eval_min = band[((size_t)m * 2 + 0) * band_stride + k];
+        const double nu_eval_max = band[((size_t)m * 2 + 1) * band_stride + k];
+        // compute_grid_params, inverse-compton.h:297-338
+        const double tail_factor = dmax(-log(1e-2), 5.0);
+        const double gamma_min = dmin(gamma_m, gamma_c) / 30;
+        const double gamma_max = dmax(gamma_M * tail_factor, gamma_min);
+        const double nu_min = dmin(nu_a, nu_m) / 10;
+        const double nu_max = dmax(nu_M * tail_factor, nu_min);
+        double nu_IC_min = 4 * IC_X0 * nu_min * gamma_min * gamma_min;
+        const double nu_ic_base = 4 * IC_X0 * nu_M * gamma_M * gamma_M;
+        const double nu_ic_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
+        double nu_IC_max = nu_ic_cut * 2.0;
+        const double theory_max = log2(nu_IC_max), theory_min = log2(nu_IC_min);
+        nu_IC_min = dmax(nu_IC_min, dmin(nu_eval_min / 4.0, nu_IC_max / 16.0));
+        nu_IC_max = dmin(nu_IC_max, dmax(nu_eval_max * 4.0, nu_IC_min * 16.0));
+        hdr[ICH_TMIN] = theory_min;
+        hdr[ICH_TMAX] = theory_max;
+        auto posfin = [](double x) { return isfinite(x) && x > 0; };
+        if (!(posfin(gamma_min) && posfin(gamma_max) && posfin(nu_min) && posfin(nu_max) && posfin(nu_IC_min) && posfin(nu_IC_max)))
+            return 0;
+        // initialize_grids, inverse-compton.h:340-369
+        const double step = 2 * IC_Q;
+        const double lg2_nu0 = log2(nu_min), lg2_g0 = log2(gamma_min);
+        int nu_size = (int)ceil((log2(nu_max) - lg2_nu0) / step) + 1;
+        int g_size = (int)ceil((log2(gamma_max) - lg2_g0) / step) + 1;
+        if (nu_size < 2) nu_size = 2;
+        if (g_size < 2) g_size = 2;
+        const double phase = lg2_nu0 + 2 * lg2_g0 + log2(4 * IC_X0);
+        const long n_lo = (long)floor((log2(nu_IC_min) - phase) / step);
+        const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
+        const long span = n_hi - n_lo;
+        const int n_ic = (int)(span > 1 ? span : 1) + 1;
+        if (nu_size > IC_MAX_NU || g_size > IC_MAX_G || n_ic > IC_MAX_OUT) {
+            atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
+            return 0;
+        }
+        if (work) {  // instrumentation: the unit of vag_ic_photon_kernel's work model (bench.py)
+            atomicAdd(work, (unsigned long long)g_size * (unsigned long long)nu_size);
+            atomicAdd(work + 1, (unsigned long long)(g_size + nu_size + n_ic));
+        }
+        hdr[ICH_N] = (double)n_ic;
+        hdr[ICH_FIRST] = ic_out_node(phase, (double)(n_lo * 2), 0);         // first and last node of the output lattice: what the flux
+        hdr[ICH_LAST] = ic_out_node(phase, (double)(n_lo * 2), n_ic - 1);   // passes' evaluator needs of it (ic_table_eval_hdr)
+        plan[ICP_PHASE] = phase;
+        plan[ICP_RUN] = 1;
+        plan[ICP_MODEL] = (double)m;
+        plan[ICP_NU_SIZE] = (double)nu_size;
+        plan[ICP_G_SIZE] = (double)g_size;
+        plan[ICP_N_LO] = (double)n_lo;
+        plan[ICP_LG2_NU0] = lg2_nu0;
+        plan[ICP_LG2_G0] = lg2_g0;
+        plan[ICP_LG2_GM] = log2(gamma_m);  // uniform factors of the electron distribution (sample_distributions)
+        plan[ICP_INV_GM] = 1 / gamma_m;
+        plan[ICP_INV_GMAX] = 1 / gamma_M;
+        SpecConst sc;
+        sc.init(params[m].p);
+        plan[ICP_SMOOTH_THICK] = sc.smooth_thick;
+        plan[ICP_LOG2_X_FAR] = sc.log2_x_far;
+        return n_ic;
+    };
+    const int len = live ? plan_cell() : 0;
+    // place of the table: exclusive sum over the workgroup's lanes + the workgroup's reservation
+    __shared__ unsigned long long s_base;
+    __shared__ int s_wave[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    const int m = lo;
-    double* tab = ictab + (size_t)c * IC_STRIDE;
-    tab[IC_HDR + ICP_RUN] = 0;
-    tab[0] = 0;
-    const int nt = meta[m].n_t;
-    if (meta[m].status != 0) return;
-    if (need && !need[c]) {  // no (theta, phi) row queries this cell: no table, and a query would be an engine fault (status bit 4)
-        tab[0] = -1;
-        return;
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total > 0 ? atomicAdd(pool_used, (unsigned long long)total) : 0ull;
     }
-    const int k = (int)((c - lay.cell_off[m]) % nt);
-    const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
-    const double gamma_M = det[VD_GAMMA_MAX * n_cells + c];
-    const double nu_m = det[VD_NU_M * n_cells + c], nu_a = det[VD_NU_A * n_cells + c], nu_M = det[VD_NU_MAX * n_cells + c];
-    const double nu_eval_min = band[((size_t)m * 2 + 0) * band_stride + k];
-    const double nu_eval_max = band[((size_t)m * 2 + 1) * band_stride + k];
-    // compute_grid_params, inverse-compton.h:297-338
-    const double tail_factor = dmax(-log(1e-2), 5.0);
-    const double gamma_min = dmin(gamma_m, gamma_c) / 30;
-    const double gamma_max = dmax(gamma_M * tail_factor, gamma_min);
-    const double nu_min = dmin(nu_a, nu_m) / 10;
-    const double nu_max = dmax(nu_M * tail_factor, nu_min);
-    double nu_IC_min = 4 * IC_X0 * nu_min * gamma_min * gamma_min;
-    const double nu_ic_base = 4 * IC_X0 * nu_M * gamma_M * gamma_M;
-    const double nu_ic_cut = dmax(nu_ic_base * tail_factor * tail_factor, nu_ic_base * tail_factor);
-    double nu_IC_max = nu_ic_cut * 2.0;
-    const double theory_max = log2(nu_IC_max), theory_min = log2(nu_IC_min);
-    nu_IC_min = dmax(nu_IC_min, dmin(nu_eval_min / 4.0, nu_IC_max / 16.0));
-    nu_IC_max = dmin(nu_IC_max, dmax(nu_eval_max * 4.0, nu_IC_min * 16.0));
-    tab[3] = theory_min;
-    tab[4] = theory_max;
-    auto posfin = [](double x) { return isfinite(x) && x > 0; };
-    if (!(posfin(gamma_min) && posfin(gamma_max) && posfin(nu_min) && posfin(nu_max) && posfin(nu_IC_min) && posfin(nu_IC_max)))
-        return;
-    // initialize_grids, inverse-compton.h:340-369
-    const double step = 2 * IC_Q;
-    const double lg2_nu0 = log2(nu_min), lg2_g0 = log2(gamma_min);
-    int nu_size = (int)ceil((log2(nu_max) - lg2_nu0) / step) + 1;
-    int g_size = (int)ceil((log2(gamma_max) - lg2_g0) / step) + 1;
-    if (nu_size < 2) nu_size = 2;
-    if (g_size < 2) g_size = 2;
-    const double phase = lg2_nu0 + 2 * lg2_g0 + log2(4 * IC_X0);
-    const long n_lo = (long)floor((log2(nu_IC_min) - phase) / step);
-    const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
-    const long span = n_hi - n_lo;
-    const int n_ic = (int)(span > 1 ? span : 1) + 1;
-    if (nu_size > IC_MAX_NU || g_size > IC_MAX_G || n_ic > IC_MAX_OUT) {
-        atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
-        return;
+    __syncthreads();
+    if (len > 0) {
+        int before = incl - len;
+        for (int q = 0; q < w; ++q) before += s_wave[q];
+        hdr[ICH_OFF] = (double)(s_base + (unsigned long long)before);  // < 2^53: exact
     }
-    if (work) {  // instrumentation: the unit of vag_ic_photon_kernel's work model (bench.py)
-        atomicAdd(work, (unsigned long long)g_size * (unsigned long long)nu_size);
-        atomicAdd(work + 1, (unsigned long long)(g_size + nu_size + n_ic));
-    }
-    tab[0] = (double)n_ic;
-    tab[1] = ic_out_node(phase, (double)(n_lo * 2), 0);         // first and last node of the output lattice: what the flux passes'
-    tab[2] = ic_out_node(phase, (double)(n_lo * 2), n_ic - 1);  // evaluator needs of it (ic_table_eval_hdr)
-    tab[IC_HDR + ICP_PHASE] = phase;
-    tab[IC_HDR + ICP_RUN] = 1;
-    tab[IC_HDR + ICP_MODEL] = (double)m;
-    tab[IC_HDR + ICP_NU_SIZE] = (double)nu_size;
-    tab[IC_HDR + ICP_G_SIZE] = (double)g_size;
-    tab[IC_HDR + ICP_N_LO] = (double)n_lo;
-    tab[IC_HDR + ICP_LG2_NU0] = lg2_nu0;
-    tab[IC_HDR + ICP_LG2_G0] = lg2_g0;
-    tab[IC_HDR + ICP_LG2_GM] = log2(gamma_m);  // uniform factors of the electron distribution (sample_distributions)
-    tab[IC_HDR + ICP_INV_GM] = 1 / gamma_m;
-    tab[IC_HDR + ICP_INV_GMAX] = 1 / gamma_M;
-    SpecConst sc;
-    sc.init(params[m].p);
-    tab[IC_HDR + ICP_SMOOTH_THICK] = sc.smooth_thick;
-    tab[IC_HDR + ICP_LOG2_X_FAR] = sc.log2_x_far;
 }
 
 __global__ void __launch_bounds__(64, VAG_IC_WAVES)
 vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                      long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
                      const double* __restrict__ cellpar, const double* __restrict__ cellq,
-                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, double* ictab) {
+                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, const double* __restrict__ ichdr,
+                     const double* __restrict__ icplan, double* __restrict__ icpool) {
     const long long c = blockIdx.x;
 #ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
     long long c_t[10];
@@ -595,15 +635,17 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int lane = threadIdx.x;
     __shared__ IcShared sh;
-    double* tab = ictab + (size_t)c * IC_STRIDE;
-    if (tab[IC_HDR + ICP_RUN] == 0) return;  // vag_ic_plan_kernel finished this cell (uniform)
-    const int m = (int)tab[IC_HDR + ICP_MODEL];
-    int nu_size = (int)tab[IC_HDR + ICP_NU_SIZE], g_size = (int)tab[IC_HDR + ICP_G_SIZE];
-    const long n_lo = (long)tab[IC_HDR + ICP_N_LO];
-    const double lg2_nu0 = tab[IC_HDR + ICP_LG2_NU0], lg2_g0 = tab[IC_HDR + ICP_LG2_G0];
-    const double lg2_gm = tab[IC_HDR + ICP_LG2_GM], inv_gm = tab[IC_HDR + ICP_INV_GM], inv_gM = tab[IC_HDR + ICP_INV_GMAX];
-    const int n_ic = (int)tab[0];
-    const double phase = tab[IC_HDR + ICP_PHASE];
+    const double* plan = icplan + (size_t)c * IC_PLAN;
+    if (plan[ICP_RUN] == 0) return;  // vag_ic_plan_kernel finished this cell (uniform)
+    const double* hdr = ichdr + (size_t)c * IC_HDR;
+    double* tab = icpool + (unsigned long long)hdr[ICH_OFF];  // this cell's table in the pool
+    const int m = (int)plan[ICP_MODEL];
+    int nu_size = (int)plan[ICP_NU_SIZE], g_size = (int)plan[ICP_G_SIZE];
+    const long n_lo = (long)plan[ICP_N_LO];
+    const double lg2_nu0 = plan[ICP_LG2_NU0], lg2_g0 = plan[ICP_LG2_G0];
+    const double lg2_gm = plan[ICP_LG2_GM], inv_gm = plan[ICP_INV_GM], inv_gM = plan[ICP_INV_GMAX];
+    const int n_ic = (int)hdr[ICH_N];
+    const double phase = plan[ICP_PHASE];
     const long idx0 = n_lo * 2;
     const double step = 2 * IC_Q;
     const int nt = meta[m].n_t;
@@ -654,11 +696,11 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double yL2 = sh.ex[CST_Y + VY_L2], yS2 = sh.ex[CST_Y + VY_S2], yC2 = sh.ex[CST_Y + VY_C2];
     VAG_IC_MARK();  // 1: prologue
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 4) { tab[0] = 0; return; }  // prologue only: loads, lattice parameters, lattice nodes
+    if (VAG_IC_ABLATE >= 4) return;  // prologue only: loads, lattice parameters, lattice nodes
 #endif
     // sample_distributions, inverse-compton.h:371-399
     SpecConst sc;
-    sc.smooth_thick = tab[IC_HDR + ICP_SMOOTH_THICK], sc.log2_x_far = tab[IC_HDR + ICP_LOG2_X_FAR];  // sc.init(P.p), done by the plan kernel
+    sc.smooth_thick = plan[ICP_SMOOTH_THICK], sc.log2_x_far = plan[ICP_LOG2_X_FAR];  // sc.init(P.p), done by the plan kernel
     // SynElectrons::compute_column_den (synchrotron.cpp:261-309) / gamma^2 * dgamma at the lattice energies: log2(gamma) is the
     // node's own exponent, the cell-uniform factors come from the plan, the two exponentials of a branch are one exp2
     const bool slow = regime == 1 || regime == 2 || regime == 5, fast = regime == 3 || regime == 4 || regime == 6;
@@ -698,7 +740,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     VAG_IC_MARK();  // 2: sampled distributions
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 3) { tab[0] = 0; return; }  // ... + the sampled electron and seed distributions
+    if (VAG_IC_ABLATE >= 3) return;  // ... + the sampled electron and seed distributions
 #endif
     const int nu_last = nu_size - 1;
     for (int j = lane; j < nu_last; j += 64) {
@@ -718,7 +760,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     __syncthreads();
     VAG_IC_MARK();  // 3: Thomson CDF
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 2) { tab[0] = 0; return; }
+    if (VAG_IC_ABLATE >= 2) return;
 #endif
     // accumulate over electron energies (accumulate_IC, inverse-compton.h:483-527; build_cdf_KN, :432-481).  For electron
     // energy i the reference forms the scattering CDF over the seed bins, c_j(i) = sum_{m >= j} ex_m(i), and output node kk
@@ -920,12 +962,12 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int kk = lane + 64 * s;
-        if (kk < n_ic) tab[IC_HDR + kk] = log2_fast(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
+        if (kk < n_ic) tab[kk] = log2_fast(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
     }
 }
 
-// ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table: header {n, first node, last node, log2 of the
-// theoretical minimum / maximum, spare}, then the n values log2 I on the lattice first + 2 IC_Q q.  A query outside the clamped
+// ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table: the cell's header {n, first node, last node, log2 of the
+// theoretical minimum / maximum, offset} and its n values log2 I on the lattice first + 2 IC_Q q in the pool.  A query outside the clamped
 // band but inside the theoretical range would make the reference rebuild the cell's spectrum; here it raises `*breach`.
 //
 // The reference scans forward to the largest node <= x (clamped to [0, n - 2]) and adds (x - node) * slope with the slope it stored
@@ -957,8 +999,8 @@ VAG_DEV IcTabQuery ic_table_query(double h_n, double first, double last, double 
     q.none = empty || above;
     return q;
 }
-VAG_DEV vdouble2_a8 ic_table_gather(const double* __restrict__ tab, int idx) {
-    return *reinterpret_cast<const vdouble2_a8*>(tab + IC_HDR + idx);
+VAG_DEV vdouble2_a8 ic_table_gather(const double* __restrict__ tab /* the cell's table in the pool */, int idx) {
+    return *reinterpret_cast<const vdouble2_a8*>(tab + idx);
 }
 VAG_DEV double ic_table_finish(const IcTabQuery& q, vdouble2_a8 I) { return q.none ? -INFINITY : fma(q.frac, I.y - I.x, I.x); }
 
@@ -967,8 +1009,9 @@ VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, dou
     const IcTabQuery q = ic_table_query(h_n, first, last, th_min, th_max, x, breach);
     return ic_table_finish(q, ic_table_gather(tab, q.idx));
 }
-VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach) {
-    return ic_table_eval_hdr(tab, tab[0], tab[1], tab[2], tab[3], tab[4], x, breach);
+VAG_DEV double ic_table_eval(const double* __restrict__ hdr, const double* __restrict__ pool, double x, int* breach) {
+    return ic_table_eval_hdr(pool + (unsigned long long)hdr[ICH_OFF], hdr[ICH_N], hdr[ICH_FIRST], hdr[ICH_LAST], hdr[ICH_TMIN], hdr[ICH_TMAX],
+                             x, breach);
 }
 
 }  // namespace vag

@@ -508,7 +508,8 @@ struct FluxArgs {
     unsigned long long* work_count;  // optional [2]: exact spectrum evaluations / interpolations done (instrumentation)
     // SSC tier (vag_ic_kernels.h)
     const double* cellq;   // [rows][VAG_NQ][n_t] IC-correction constants of the synchrotron spectrum (MODE 1)
-    const double* ictab;   // [cells][IC_STRIDE] SSC tables (MODE 2)
+    const double* ichdr;   // [cells][IC_HDR] SSC table headers (MODE 2)
+    const double* icpool;  // the tables, back to back (a header holds its table's offset)
     int* ic_status;        // [nb] bit 2: band-contract breach seen by the SSC flux pass
     const double* cellgeo; // [rows][3][n_t] per-cell cos(theta), sin(theta), log2|dcos| of a spreading jet (SPREAD kernels)
     const double* rowgeo;  // [nb][rowgeo_stride] row-geometry records written by vag_grid_kernel (read by the non-spreading kernels)
@@ -528,12 +529,12 @@ VAG_DEV double log2_I_nu_ic(const P1 c, int st, const P2 qv, int qst, const Spec
 template <class P1, class P2, class Tab>
 VAG_DEV void log2_I_nu_ic_pair(const P1 c, int st, const P2 qv, int qst, const SpecConst& sc, double x0, double x1, Tab sp, double& b0,
                                double& b1);
-VAG_DEV double ic_table_eval(const double* __restrict__ tab, double x, int* breach);
+VAG_DEV double ic_table_eval(const double* __restrict__ hdr, const double* __restrict__ pool, double x, int* breach);
 VAG_DEV double ic_table_eval_hdr(const double* __restrict__ tab, double h_n, double first, double last, double th_min,
                                  double th_max, double x, int* breach);
 VAG_DEV int ic_breach_status(int breach);
 constexpr int FLUX_NQ = 14;          // == VAG_NQ (vag_ic_kernels.h)
-constexpr int FLUX_IC_STRIDE = 198;  // == IC_STRIDE
+constexpr int FLUX_IC_HDR = 8;       // == IC_HDR: doubles per cell header {n, first, last, theory min / max, pool offset, 2 spare}
 
 // Observation window of a row from the partial counts its EAT step leaves in LDS (WinCount below): the row is sorted, so
 // positions are counts (observed_window, observer.h:324-338):
@@ -863,22 +864,22 @@ vag_flux_grid_kernel(FluxArgs a) {
                 s_par[(q - par * K) * VAG_NPAR + par] = src[(size_t)par * K_all + (q - par * K)];
             }
             if constexpr (MODE == FLUX_SSC) {
-                // the SSC pass never evaluates the synchrotron block: its first five rows carry the table headers
-                // (n, phase, idx0, theory_min, theory_max) instead, saving a dependent global round trip per evaluation
+                // the SSC pass never evaluates the synchrotron block: its first six rows carry the table headers
+                // (n, first node, last node, theory_min, theory_max, pool offset) instead, saving a dependent global round trip per evaluation
                 __syncthreads();
-                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_STRIDE;
+                const double* hdr0 = a.ichdr + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_HDR;
 #pragma unroll 1
-                for (int q = tid; q < 5 * K; q += THREADS) {
-                    const int kk = q / 5, w = q - kk * 5;
-                    s_par[kk * VAG_NPAR + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
+                for (int q = tid; q < 6 * K; q += THREADS) {
+                    const int kk = q / 6, w = q - kk * 6;
+                    s_par[kk * VAG_NPAR + w] = hdr0[(size_t)kk * FLUX_IC_HDR + w];
                 }
             }
             if constexpr (MODE == FLUX_FUSED) {
-                const double* tab0 = a.ictab + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_STRIDE;
+                const double* hdr0 = a.ichdr + (size_t)(a.cell_off[m] + (long long)rep * K_all + k0) * FLUX_IC_HDR;
 #pragma unroll 1
-                for (int q = tid; q < 5 * K; q += THREADS) {
-                    const int kk = q / 5, w = q - kk * 5;
-                    s_hdr[kk * 6 + w] = tab0[(size_t)kk * FLUX_IC_STRIDE + w];
+                for (int q = tid; q < 6 * K; q += THREADS) {
+                    const int kk = q / 6, w = q - kk * 6;
+                    s_hdr[kk * 6 + w] = hdr0[(size_t)kk * FLUX_IC_HDR + w];
                 }
             }
             staged_rep = rep;
@@ -1023,17 +1024,17 @@ vag_flux_grid_kernel(FluxArgs a) {
                     const double* cq = a.cellq + (a.cell_off[m] + (long long)staged_rep * K_all) * FLUX_NQ + k0 + k;
                     log2_I_nu_ic_pair(cp, 1, cq, K_all, sc, s_nu[l0] - dop, s_nu[l1] - dop, sp_tab, b0, b1);
                     if constexpr (MODE == FLUX_FUSED) {
-                        const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                         const double* hp = s_hdr + __mul24(k, 6);
                         const double h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
+                        const double* tab = a.icpool + (unsigned long long)hp[5];
                         const double c0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
                         const double c1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
                         s_B2[bofs + k] = c0 + geom;
                         s_B2[min(bofs + KS, top) + k] = c1 + geom;
                     }
                 } else {
-                    const double* tab = a.ictab + (size_t)(a.cell_off[m] + (long long)staged_rep * K_all + k0 + k) * FLUX_IC_STRIDE;
                     const double h0 = cp[0], h1 = cp[1], h2 = cp[2], h3 = cp[3], h4 = cp[4];
+                    const double* tab = a.icpool + (unsigned long long)cp[5];
                     b0 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l0] - dop, &breach);
                     b1 = ic_table_eval_hdr(tab, h0, h1, h2, h3, h4, s_nu[l1] - dop, &breach);
                 }
@@ -1314,7 +1315,8 @@ struct SeriesArgs {
     double* partial; // [nb][max_chunks][n]
     const double* sp_table;
     const double* cellq;  // FLUX_SYN_IC: [cells][FLUX_NQ]
-    const double* ictab;  // FLUX_SSC: [cells][FLUX_IC_STRIDE]
+    const double* ichdr;  // FLUX_SSC: [cells][FLUX_IC_HDR] table headers
+    const double* icpool; // FLUX_SSC: the tables, back to back
     int* ic_status;       // FLUX_SSC: per-model breach flag
     const double* cellgeo; // SPREAD: [rows][3][n_t] per-cell polar geometry
     // few distinct frequencies (a fit's bands), n <= 64: point s observes band band_idx[s], whose log2 nu is
@@ -1560,8 +1562,8 @@ vag_flux_series_kernel(SeriesArgs a) {
                     } else if (MODE == FLUX_SYN_IC) {
                         v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, cq_row + kk, K_all, sc, x, sp_tab);
                     } else {
-                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
-                        v = ic_table_eval(tab, x, &breach);
+                        const double* hdr = a.ichdr + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_HDR;
+                        v = ic_table_eval(hdr, a.icpool, x, &breach);
                     }
                     s_Bw[b * KS + kk] = v + s_geom[kk];
                 }
@@ -1607,8 +1609,8 @@ vag_flux_series_kernel(SeriesArgs a) {
                         } else if (MODE == FLUX_SYN_IC) {
                             v = log2_I_nu_ic(s_par + kk * VAG_NPAR, 1, cq_row + kk, K_all, sc, x, sp_tab);
                         } else {
-                            const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_STRIDE;
-                            v = ic_table_eval(tab, x, &breach);
+                            const double* hdr = a.ichdr + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + kk) * FLUX_IC_HDR;
+                            v = ic_table_eval(hdr, a.icpool, x, &breach);
                         }
                         s_Bw[b * KS + kk] = v + s_geom[kk];
                     }
@@ -1641,9 +1643,9 @@ vag_flux_series_kernel(SeriesArgs a) {
                         bhi = log2_I_nu_ic(s_par + (k + 1) * VAG_NPAR, 1, cq_row + (k + 1), K_all, sc, nuq[q] - s_dop[k + 1],
                                            sp_tab);
                     } else {
-                        const double* tab = a.ictab + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + k) * FLUX_IC_STRIDE;
-                        blo = ic_table_eval(tab, nuq[q] - s_dop[k], &breach);
-                        bhi = ic_table_eval(tab + FLUX_IC_STRIDE, nuq[q] - s_dop[k + 1], &breach);
+                        const double* hdr = a.ichdr + (a.lay.cell_off[m] + (long long)rep * K_all + k0 + k) * FLUX_IC_HDR;
+                        blo = ic_table_eval(hdr, a.icpool, nuq[q] - s_dop[k], &breach);
+                        bhi = ic_table_eval(hdr + FLUX_IC_HDR, a.icpool, nuq[q] - s_dop[k + 1], &breach);
                     }
                     blo += s_geom[k];
                     bhi += s_geom[k + 1];
