@@ -263,6 +263,8 @@ def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=512):
         flops = plan.spec_evals * 0.5 * (F_SPEC + F_TABLE) + plan.interps * F_INTERP
         out[name] = {"batch": nb, "ms_per_batch": 1e3 * dt, "light_curves_per_s": nb / dt,
                      "finite": bool(torch.isfinite(call.out).all()), "ode_rows": plan.n_rows, "cells": plan.n_cells,
+                     "ssc_table_pool_mb": plan.ic_pool_bytes / 1e6,  # per shock; the fixed 192-node layout took cells x 1584 B
+                     "ssc_table_pool_mb_fixed_192_node_layout": plan.n_cells * 198 * 8 / 1e6,
                      "stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "cells_cooling_tables": st.cells_ms,
                                   "flux_passes": st.flux_ms, "reduce": st.reduce_ms},
                      "stage_ms_reference_names": {n: getattr(prof, n) for n, _ in _lib.Profile._fields_},

@@ -1,14 +1,17 @@
 /*
  * vag_oracle.c -- TEST INFRASTRUCTURE: the CPU parity checker (see vag_oracle.h).
  *
- * A scalar, single-threaded C11 restatement of VegasAfterglow's forward-shock
- * synchrotron light-curve path.  Every function cites the reference file:line it
- * follows (paths relative to the VegasAfterglow tree).  Written from the algorithm,
- * with flat arrays instead of xtensor containers; arithmetic order follows the
- * reference so that results agree to libm/contraction noise (measured <= ~1e-8 rel.;
- * see tests/test_oracle_vs_ref.py).  Scope: axisymmetric, non-spreading named jets
- * (TophatJet, GaussianJet, PowerLawJet, TwoComponentJet), ISM / Wind(k=2) media,
- * forward shock, synchrotron with self-absorption, no SSC / reverse shock.
+ * A scalar, single-threaded C11 restatement of VegasAfterglow's light-curve path.
+ * Every function cites the reference file:line it follows (paths relative to the
+ * VegasAfterglow tree).  Written from the algorithm, with flat arrays instead of xtensor
+ * containers; arithmetic order follows the reference: bit-identical to a strict-FP build of
+ * the reference's own sources (oracle/_ref/libvag_ref_strict.so) on the configurations
+ * tests/test_oracle.py pins, within ~2e-6 of its -O3 -ffp-contract=fast build.  Scope: every
+ * closed-form jet and medium of the reference's registry, lateral spreading, magnetar
+ * injection, Model(axisymmetric=False) (with a spreading jet: one lattice and one solve per
+ * (phi, theta) node, coord_t::phi_size), forward and reverse shock, synchrotron with
+ * self-absorption, SSC with Thomson / Klein-Nishina cooling, grid / series / band / exposure
+ * requests, Model.details and the fitter's log-likelihood.
  */
 #include "vag_oracle.h"
 
@@ -397,14 +400,18 @@ enum { SYM_STRUCTURED = 0, SYM_PHI_SYMMETRIC = 1, SYM_PIECEWISE = 2, SYM_ISOTROP
 
 typedef struct {
     int n_phi, n_theta, n_t, n_reps;
+    int phi_size; /* phi slices of t / Shock / electrons / photons that are kept: 1, or n_phi for Model(axisymmetric=False) with a
+                   * SPREADING jet, whose lattices start per (phi, theta) node (grid-refinement.h:462-469,619-625).  A "row" below is
+                   * (slice i, theta j) -> i * n_theta + j; with one slice it is the theta index. */
     double* phi;
     double* theta;
-    double* t; /* [n_theta][n_t] engine-frame lattice (phi slice 0) */
-    int* reps; /* representative theta indices */
+    double* t; /* [phi_size * n_theta][n_t] engine-frame lattice */
+    int* reps; /* representative rows */
     int symmetry, phi_mirrored;
     int spreading; /* Coord::spreading, mesh.h:92 */
     int jet_3d;    /* Model(axisymmetric=False) with more than one phi node: Observer::jet_3d, observer.cpp:215. The named
-                    * jets are phi-independent, so every phi slice of t / Shock equals slice 0 and only slice 0 is kept. */
+                    * jets are phi-independent, so without spreading every phi slice of t / Shock equals slice 0 and only slice 0
+                    * is kept (phi_size = 1). */
     double theta_view;
 } coord_t;
 
@@ -810,11 +817,11 @@ static void logspace_with_band_refinement(double ts, double t_end, double b_lo, 
 
 /* Coord::detect_symmetry, src/core/mesh.h:121-187 (isotropic medium) */
 static void detect_symmetry(coord_t* c, const jet_t* jet) {
-    c->reps = malloc(sizeof(int) * c->n_theta);
+    c->reps = malloc(sizeof(int) * c->phi_size * c->n_theta);
     c->n_reps = 0;
     c->spreading = jet->spreading;
     if (jet->spreading) { /* every row evolves on its own: Symmetry::structured */
-        for (int j = 0; j < c->n_theta; ++j) c->reps[c->n_reps++] = j;
+        for (int j = 0; j < c->phi_size * c->n_theta; ++j) c->reps[c->n_reps++] = j;
         c->symmetry = SYM_STRUCTURED;
         return;
     }
@@ -866,10 +873,10 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     const double cos_tv = cos(c->theta_view), sin_tv = sin(c->theta_view);
     double min_raw = t_end, min_guarded = t_end, min_cut = t_end, max_ref = 0;
     double* t_dec = malloc(sizeof(double) * nth);
-    double* t_start_row = malloc(sizeof(double) * nth); /* TimeScanResult::t_start / early_t, grid-refinement.h:462-469 */
-    double* early_t_row = malloc(sizeof(double) * nth);
+    double* t_start_row = malloc(sizeof(double) * c->phi_size * nth); /* TimeScanResult::t_start / early_t, grid-refinement.h:462-469 */
+    double* early_t_row = malloc(sizeof(double) * c->phi_size * nth);
     /* phi_size = |phi| for Model(axisymmetric=False): the global bounds then scan every phi node (:484-507); the per-row
-     * caches keep phi slice 0, the only one the (non-spreading) lattices below read */
+     * caches keep the slices the lattices below read (slice 0, or every slice of a spreading jet) */
     const int phi_size = is_axisymmetric ? 1 : c->n_phi;
     for (int i = 0; i < phi_size; ++i)
         for (int j = 0; j < nth; ++j) {
@@ -883,9 +890,9 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
                 cut = dmin(cut, 0.01 * jet->T0);
                 max_ref = dmax(max_ref, 10.0 * dmax(td, jet->T0));
             }
-            if (i == 0) {
-                t_start_row[j] = dmax(ts, cut);
-                early_t_row[j] = 0.99 * dmin(ts, cut);
+            if (i < c->phi_size) {
+                t_start_row[i * nth + j] = dmax(ts, cut);
+                early_t_row[i * nth + j] = 0.99 * dmin(ts, cut);
             }
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, dmax(ts, cut));
@@ -902,22 +909,22 @@ static void build_time_grid(coord_t* c, const jet_t* jet, const medium_t* med, d
     const size_t t_num_tot = t_num_base + t_num_rvs_extra;
     const size_t t_num = t_num_tot + (has_early ? 1 : 0);
     c->n_t = (int)t_num;
-    c->t = calloc((size_t)nth * t_num, sizeof(double));
+    c->t = calloc((size_t)c->phi_size * nth * t_num, sizeof(double));
     double* grid = malloc(sizeof(double) * (t_num_tot > 0 ? t_num_tot : 1));
     for (int r = 0; r < c->n_reps; ++r) {
         const int j_rep = c->reps[r];
         const int j_end = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
         if (c->symmetry < SYM_PHI_SYMMETRIC) { /* structured: every row has its own start and early point (:619-625) */
-            const int j = j_rep;
+            const int R = j_rep, j = R % nth; /* row (phi slice, theta j) */
             if (is_rvs) {
                 const double t_cross_limit = dmax(t_dec[j], jet->T0);
-                logspace_with_cross_refinement(t_start_row[j], t_end, 10 * t_cross_limit, t_num_tot, t_num_base, grid);
+                logspace_with_cross_refinement(t_start_row[R], t_end, 10 * t_cross_limit, t_num_tot, t_num_base, grid);
             } else {
-                logspace_with_band_refinement(t_start_row[j], t_end, t_dec[j] / 3, 3 * t_dec[j], t_num_tot, 3.0, grid);
+                logspace_with_band_refinement(t_start_row[R], t_end, t_dec[j] / 3, 3 * t_dec[j], t_num_tot, 3.0, grid);
             }
-            double* row = c->t + (size_t)j * t_num;
+            double* row = c->t + (size_t)R * t_num;
             if (has_early) {
-                row[0] = early_t_row[j];
+                row[0] = early_t_row[R];
                 for (size_t k = 0; k < t_num_tot; ++k) row[1 + k] = grid[k];
             } else {
                 for (size_t k = 0; k < t_num_tot; ++k) row[k] = grid[k];
@@ -997,6 +1004,7 @@ static int auto_grid(coord_t* c, const jet_t* jet, const medium_t* med, double t
         }
     }
     c->jet_3d = !is_axisymmetric && c->n_phi > 1;
+    c->phi_size = (!is_axisymmetric && jet->spreading) ? c->n_phi : 1;
     detect_symmetry(c, jet);
     build_time_grid(c, jet, med, t_obs_min, t_obs_max, z, t_resol, is_rvs, is_axisymmetric);
     return 0;
@@ -1272,14 +1280,15 @@ static double jet_spreading_edge(const jet_t* jet, double theta_min, double thet
 
 static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med, const jet_t* jet,
                               const vag_model_params* p) {
-    shock_alloc(sh, c->n_theta, c->n_t);
+    const int n_rows = c->phi_size * c->n_theta;
+    shock_alloc(sh, n_rows, c->n_t);
     const double theta_s = jet->spreading ? jet_spreading_edge(jet, c->theta[0], c->theta[c->n_theta - 1]) : 0;
     for (int r = 0; r < c->n_reps; ++r) {
-        const int j = c->reps[r];
+        const int j = c->reps[r]; /* row */
         fwd_eqn_t e;
         e.med = med;
         e.jet = jet;
-        e.theta0 = c->theta[j];
+        e.theta0 = c->theta[j % c->n_theta];
         e.theta_s = theta_s;
         e.m_jet0 = jet_eps_k(jet, e.theta0) / jet_Gamma0(jet, e.theta0) / C_C2;
         if (jet_is_ejecta(jet)) e.m_jet0 /= 1 + jet->sigma0;
@@ -1296,13 +1305,13 @@ static int generate_fwd_shock(shock_t* sh, const coord_t* c, const medium_t* med
     const int nt = c->n_t;
     for (int r = 0; r < c->n_reps; ++r) {
         const int j0 = c->reps[r];
-        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : n_rows;
         for (int j = j0 + 1; j < j1; ++j) {
             for (int k = 0; k < nt; ++k) {
                 const size_t o = (size_t)j * nt + k, s = (size_t)j0 * nt + k;
                 sh->t_comv[o] = sh->t_comv[s];
                 sh->r[o] = sh->r[s];
-                sh->theta[o] = c->theta[j];
+                sh->theta[o] = c->theta[j % c->n_theta];
                 sh->Gamma[o] = sh->Gamma[s];
                 sh->Gamma_th[o] = sh->Gamma_th[s];
                 sh->B[o] = sh->B[s];
@@ -1765,14 +1774,14 @@ static void broadcast_shock_groups(shock_t* sh, const coord_t* c) { /* Shock::br
     const int nt = c->n_t;
     for (int r = 0; r < c->n_reps; ++r) {
         const int j0 = c->reps[r];
-        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->phi_size * c->n_theta;
         for (int j = j0 + 1; j < j1; ++j) {
             sh->injection_idx[j] = sh->injection_idx[j0];
             for (int k = 0; k < nt; ++k) {
                 const size_t o = (size_t)j * nt + k, s = (size_t)j0 * nt + k;
                 sh->t_comv[o] = sh->t_comv[s];
                 sh->r[o] = sh->r[s];
-                sh->theta[o] = c->theta[j];
+                sh->theta[o] = c->theta[j % c->n_theta];
                 sh->Gamma[o] = sh->Gamma[s];
                 sh->Gamma_th[o] = sh->Gamma_th[s];
                 sh->B[o] = sh->B[s];
@@ -1785,15 +1794,15 @@ static void broadcast_shock_groups(shock_t* sh, const coord_t* c) { /* Shock::br
 /* generate_shock_pair, reverse-shock.tpp:592-614 */
 static int generate_shock_pair(shock_t* fwd, shock_t* rvs, const coord_t* c, const medium_t* med, const jet_t* jet,
                                const vag_model_params* p) {
-    shock_alloc(fwd, c->n_theta, c->n_t);
-    shock_alloc(rvs, c->n_theta, c->n_t);
+    shock_alloc(fwd, c->phi_size * c->n_theta, c->n_t);
+    shock_alloc(rvs, c->phi_size * c->n_theta, c->n_t);
     for (int r = 0; r < c->n_reps; ++r) {
-        const int j = c->reps[r];
+        const int j = c->reps[r]; /* row */
         rvs_eqn_t e;
         memset(&e, 0, sizeof e);
         e.med = med;
         e.jet = jet;
-        e.theta0 = c->theta[j];
+        e.theta0 = c->theta[j % c->n_theta];
         e.T0 = jet->T0;
         e.Gamma4 = jet_Gamma0(jet, e.theta0);
         e.deps0_dt = jet_eps_k(jet, e.theta0) / jet->T0;
@@ -1823,6 +1832,7 @@ static int generate_shock_pair(shock_t* fwd, shock_t* rvs, const coord_t* c, con
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     int n_phi_eff, n_theta, n_t;
+    int phi_size; /* phi slices of the cells (coord_t::phi_size): cell row of (phi i, theta j) = (phi_size > 1 ? i : 0) * n_theta + j */
     double *lg2_t, *lg2_doppler, *lg2_geom; /* [n_phi_eff][n_theta][n_t] */
     double one_plus_z, lumi_dist;
 } eat_t;
@@ -1838,6 +1848,7 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
     const int nth = c->n_theta, nt = c->n_t;
     const int eff_phi = (c->theta_view == 0 && !c->jet_3d) ? 1 : c->n_phi;
     o->n_phi_eff = eff_phi;
+    o->phi_size = c->phi_size;
     o->n_theta = nth;
     o->n_t = nt;
     o->one_plus_z = 1 + z;
@@ -1865,17 +1876,20 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
     }
     if (c->spreading) { /* calc_t_obs + calc_solid_angle + finalize_log_grids (geometry not pre-logged), observer.cpp:51-141,439-454 */
         const int last = nth - 1;
-        double* dcos = malloc(sizeof(double) * (size_t)nth * nt);
+        const int n_slice = c->phi_size; /* shock.theta.shape(0): the theta neighbours of a cell are those of its own phi slice */
+        double* dcos = malloc(sizeof(double) * (size_t)n_slice * nth * nt);
+        for (int is = 0; is < n_slice; ++is)
         for (int j = 0; j < nth; ++j) {
             const int j_p1 = (j == last) ? last : j + 1;
+            const size_t R = (size_t)is * nth + j;
             int k_hint_lo = 0, k_hint_hi = 0;
             for (int k = 0; k < nt; ++k) {
-                const double t_target = c->t[(size_t)j * nt + k];
+                const double t_target = c->t[R * nt + k];
                 double th_lo, th_hi;
 #define INTERP_THETA_(j_nb, hint, out)                                                                          \
     do {                                                                                                        \
-        const double* tn = c->t + (size_t)(j_nb) * nt;                                                          \
-        const double* thn = sh->theta + (size_t)(j_nb) * nt;                                                    \
+        const double* tn = c->t + ((size_t)is * nth + (j_nb)) * nt;                                             \
+        const double* thn = sh->theta + ((size_t)is * nth + (j_nb)) * nt;                                       \
         while ((hint) + 1 < nt && tn[(hint) + 1] < t_target) (hint)++;                                          \
         if ((hint) + 1 >= nt) {                                                                                 \
             (out) = thn[nt - 1];                                                                                \
@@ -1884,7 +1898,7 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
             (out) = thn[hint] + w * (thn[(hint) + 1] - thn[hint]);                                              \
         }                                                                                                       \
     } while (0)
-                const double th_jk = sh->theta[(size_t)j * nt + k];
+                const double th_jk = sh->theta[R * nt + k];
                 if (j == 0) {
                     th_lo = th_jk;
                 } else {
@@ -1900,14 +1914,15 @@ static void observe(eat_t* o, const coord_t* c, const shock_t* sh, double lumi_d
                     th_hi = 0.5 * (th_jk + nb);
                 }
 #undef INTERP_THETA_
-                dcos[(size_t)j * nt + k] = cos(th_hi) - cos(th_lo);
+                dcos[R * nt + k] = cos(th_hi) - cos(th_lo);
             }
         }
         for (int i = 0; i < eff_phi; ++i) {
             const double cos_phi = cos(c->phi[i] - 0.0);
+            const int i_eff = n_slice > 1 ? i : 0; /* i * jet_3d on the slices that are kept */
             for (int j = 0; j < nth; ++j)
                 for (int k = 0; k < nt; ++k) {
-                    const size_t s = (size_t)j * nt + k;
+                    const size_t s = ((size_t)i_eff * nth + j) * nt + k;
                     const size_t q = ((size_t)i * nth + j) * nt + k;
                     const double gamma_ = sh->Gamma[s], r = sh->r[s];
                     const double cos_v = sin(sh->theta[s]) * cos_phi * sin_obs + cos(sh->theta[s]) * cos_obs;
@@ -2369,7 +2384,7 @@ static void generate_syn(electrons_t* el, photons_t* ph, const shock_t* sh, cons
     const int ssc = (p->flags & VAG_FLAG_SSC) != 0, kn = (p->flags & VAG_FLAG_KN) != 0;
     for (int r = 0; r < c->n_reps; ++r) {
         const int j0 = c->reps[r];
-        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->n_theta;
+        const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : c->phi_size * c->n_theta;
         for (int k = 0; k < nt; ++k) {
             const size_t o = (size_t)j0 * nt + k;
             const int k_inj = sh->injection_idx[j0];
@@ -2858,14 +2873,15 @@ static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const d
     for (int i = 0; i < o->n_phi_eff; ++i) {
         for (int j = 0; j < o->n_theta; ++j) {
             const size_t row = ((size_t)i * o->n_theta + j) * t_grid;
+            const int cell_row = (o->phi_size > 1 ? i : 0) * o->n_theta + j; /* photons: eff_i = i * jet_3d, observer.h:365 */
             const double* t_row = o->lg2_t + row;
             const double* dop_row = o->lg2_doppler + row;
             const double* geom_row = o->lg2_geom + row;
-            int k_lo, k_hi; /* photons: eff_i = 0, one phi slice */
+            int k_lo, k_hi;
             if (!observed_window(t_row, t_grid, lg2_t_obs[0], lg2_t_obs[nt_obs - 1], &k_lo, &k_hi)) continue;
             for (int k = k_lo; k <= k_hi; ++k)
                 for (int l = 0; l < nnu; ++l)
-                    boundary[(size_t)k * nnu + l] = eval(grid, j, k, t_grid, lg2_nu_src[l] - dop_row[k]) + geom_row[k];
+                    boundary[(size_t)k * nnu + l] = eval(grid, cell_row, k, t_grid, lg2_nu_src[l] - dop_row[k]) + geom_row[k];
 
             int t_idx = 0;
             iterate_to(t_row[0], lg2_t_obs, nt_obs, &t_idx);
@@ -2918,6 +2934,7 @@ static void specific_flux_series(const eat_t* o, cell_eval_fn eval, void* grid, 
     for (int i = 0; i < o->n_phi_eff; ++i) {
         for (int j = 0; j < o->n_theta; ++j) {
             const size_t row = ((size_t)i * o->n_theta + j) * t_grid;
+            const int cell_row = (o->phi_size > 1 ? i : 0) * o->n_theta + j;
             const double* t_row = o->lg2_t + row;
             const double* dop_row = o->lg2_doppler + row;
             const double* geom_row = o->lg2_geom + row;
@@ -2940,8 +2957,8 @@ static void specific_flux_series(const eat_t* o, cell_eval_fn eval, void* grid, 
                         hi = prev_hi;
                     } else {
                         const int carried = (s == block_first && carry_k == k && carry_nu == lg2_nu);
-                        lo = carried ? carry_val : eval(grid, j, k, t_grid, lg2_nu - dop_row[k]) + geom_row[k];
-                        hi = eval(grid, j, k + 1, t_grid, lg2_nu - dop_row[k + 1]) + geom_row[k + 1];
+                        lo = carried ? carry_val : eval(grid, cell_row, k, t_grid, lg2_nu - dop_row[k]) + geom_row[k];
+                        hi = eval(grid, cell_row, k + 1, t_grid, lg2_nu - dop_row[k + 1]) + geom_row[k + 1];
                         prev_nu = lg2_nu;
                         prev_lo = lo;
                         prev_hi = hi;
@@ -3125,8 +3142,6 @@ static void pipeline_free(pipeline_t* pl) {
 static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_min, double t_obs_max) {
     memset(pl, 0, sizeof *pl);
     if (vag_oracle_params_validate(p) != 0) return -1;
-    if ((p->flags & VAG_FLAG_NON_AXISYMMETRIC) && (p->flags & VAG_FLAG_SPREADING)) /* per-phi lattices: not restated */
-        return fail("axisymmetric=False with a spreading jet is not supported");
     jet_init(&pl->jet, p);
     medium_init(&pl->med, p);
     pl->has_rvs = (p->flags & VAG_FLAG_RVS) != 0;
@@ -3139,7 +3154,7 @@ static int run_pipeline(pipeline_t* pl, const vag_model_params* p, double t_obs_
         return -1;
     }
     observe(&pl->eat, &pl->coord, &pl->shock, p->lumi_dist * U_CM, p->z);
-    const size_t n = (size_t)pl->coord.n_theta * pl->coord.n_t;
+    const size_t n = (size_t)pl->coord.phi_size * pl->coord.n_theta * pl->coord.n_t;
     pl->el = calloc(n, sizeof(electrons_t));
     pl->ph = calloc(n, sizeof(photons_t));
     generate_syn(pl->el, pl->ph, &pl->shock, &pl->coord, p);
@@ -3172,7 +3187,8 @@ static icphoton_t* make_ic_photons(pipeline_t* pl, const emitter_t* em, const do
     }
     const double lg2_1pz = log2(o->one_plus_z);
     const double lg2_nu_lo = log2(nu_lo) + lg2_1pz, lg2_nu_hi = log2(nu_hi) + lg2_1pz;
-    icphoton_t* ic = calloc((size_t)nth * nt, sizeof(icphoton_t));
+    const int n_rows = c->phi_size * nth;
+    icphoton_t* ic = calloc((size_t)n_rows * nt, sizeof(icphoton_t));
     for (int k = 0; k < nt; ++k) {
         double dmin_k = INFINITY, dmax_k = -INFINITY;
         for (int i = 0; i < o->n_phi_eff; ++i)
@@ -3184,7 +3200,7 @@ static icphoton_t* make_ic_photons(pipeline_t* pl, const emitter_t* em, const do
         const double nu_eval_min = exp2(lg2_nu_lo - dmax_k), nu_eval_max = exp2(lg2_nu_hi - dmin_k);
         for (int r = 0; r < c->n_reps; ++r) {
             const int j0 = c->reps[r];
-            const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : nth;
+            const int j1 = (r + 1 < c->n_reps) ? c->reps[r + 1] : n_rows;
             icphoton_t* q = &ic[(size_t)j0 * nt + k];
             q->electrons = em->el[(size_t)j0 * nt + k];
             q->photons = em->ph[(size_t)j0 * nt + k];
@@ -3250,7 +3266,7 @@ int vag_oracle_flux_density_grid_components4(const vag_model_params* p, const do
                 for (size_t q = 0; q < nout; ++q) sync[q] = sync[q] / U_FLUX_DEN_CGS;
             }
             if (ssc && em[e].ssc) {
-                const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+                const size_t ncell = (size_t)pl.coord.phi_size * pl.coord.n_theta * pl.coord.n_t;
                 icphoton_t* ic = make_ic_photons(&pl, &em[e], nu_obs, nnu);
                 specific_flux(&pl.eat, eval_ic_cell, ic, t_obs, nt, nu_obs, nnu, ssc);
                 for (size_t q = 0; q < nout; ++q) ssc[q] = ssc[q] / U_FLUX_DEN_CGS;
@@ -3311,7 +3327,7 @@ int vag_oracle_flux_density(const vag_model_params* p, const double* t, const do
             else
                 for (int i = 0; i < n; ++i) out[i] += tmp[i] / U_FLUX_DEN_CGS;
             if (em[e].ssc) {
-                const size_t ncell = (size_t)pl.coord.n_theta * pl.coord.n_t;
+                const size_t ncell = (size_t)pl.coord.phi_size * pl.coord.n_theta * pl.coord.n_t;
                 icphoton_t* ic = make_ic_photons(&pl, &em[e], nu_obs, n);
                 specific_flux_series(&pl.eat, eval_ic_cell, ic, t_obs, nu_obs, n, tmp);
                 for (int i = 0; i < n; ++i) out[i] += tmp[i] / U_FLUX_DEN_CGS;
@@ -3414,7 +3430,7 @@ int vag_oracle_flux(const vag_model_params* p, const double* t, int nt, double n
                     for (int j = 0; j < nt; ++j) out[j] = band[j] / U_FLUX_CGS;
                 else
                     for (int j = 0; j < nt; ++j) out[j] += band[j] / U_FLUX_CGS;
-                if (ic) free_ic_photons(ic, (size_t)pl.coord.n_theta * pl.coord.n_t);
+                if (ic) free_ic_photons(ic, (size_t)pl.coord.phi_size * pl.coord.n_theta * pl.coord.n_t);
             }
         }
         free(band);
@@ -3444,7 +3460,7 @@ static int details_impl(const vag_model_params* p, double t_min, double t_max, v
     shape->n_phi = c->n_phi;
     shape->n_theta = nth;
     shape->n_t = nt;
-    shape->n_reps = c->n_reps;
+    shape->n_reps = c->n_reps / c->phi_size; /* Coord::theta_reps: representatives per phi slice */
     shape->symmetry = c->symmetry;
     shape->phi_mirrored = c->phi_mirrored;
     if (n_phi_eff) *n_phi_eff = pl.eat.n_phi_eff;

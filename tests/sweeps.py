@@ -45,3 +45,27 @@ def rs_ssc_draws(n):
             kw.update(k_e=2.0, k_g=2.0)
         prms.append(_abi.make_params(**kw))
     return prms
+
+
+NONAXI_T, NONAXI_NU = np.logspace(2.5, 7.5, 28), np.array([1e9, 4.84e14, 1e18])
+
+
+def nonaxi_spread_draws(n):
+    """Model(axisymmetric=False) with a spreading jet -- one lattice and one blast-wave solve per (phi, theta) node -- over the jet
+    profiles; every fourth draw carries a reverse shock."""
+    rng = np.random.default_rng(2024)
+    prms = []
+    for i in range(n):
+        jet = ["TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet"][i % 4]
+        kw = dict(jet=jet, E_iso=10 ** rng.uniform(51, 53.5), Gamma0=10 ** rng.uniform(1.7, 2.7), theta_c=rng.uniform(0.05, 0.2),
+                  theta_obs=rng.uniform(0, 0.4), n_ism=10 ** rng.uniform(-2, 1), p=rng.uniform(2.1, 2.8), eps_e=10 ** rng.uniform(-2, -0.7),
+                  eps_B=10 ** rng.uniform(-4, -1.5), spreading=True, axisymmetric=False)
+        if jet == "PowerLawJet":
+            kw.update(k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+        if jet == "TwoComponentJet":
+            kw.update(theta_w=kw["theta_c"] * rng.uniform(1.5, 3.0), E_iso_w=kw["E_iso"] * 10 ** rng.uniform(-2, -0.5),
+                      Gamma0_w=max(20.0, kw["Gamma0"] * rng.uniform(0.1, 0.5)))
+        if i % 4 == 3:
+            kw.update(duration=10 ** rng.uniform(0.5, 2.5), rvs=dict(eps_e=10 ** rng.uniform(-2, -0.7), eps_B=10 ** rng.uniform(-3, -1), p=rng.uniform(2.1, 2.7)))
+        prms.append(_abi.make_params(**kw))
+    return prms
