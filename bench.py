@@ -18,7 +18,13 @@ The same JSON line carries what BASELINE.json's north_star asks for, each next t
   tophat_config0    configs[0] (the >= 100x target): single-call latency and batched throughput, on-axis and theta_obs = 0.05,
                     with the reference on 1 core and on all host cores;
   ensembles         configs[2] (FS + RS + SSC + KN) and configs[4] (two-component SSC ensemble, 1024 members) with tallied
-                    FP64 rooflines of their flux passes.
+                    FP64 rooflines of their flux passes;
+  ensemble_c5_4096  configs[4] at its full 4096 members through dist.sharded_flux_density_grid, with and without the all-gather
+                    of the fluxes, at EVERY N (N = 1: also the 512-member share of one rank of eight and the ratio it implies);
+  walker_steps_8192_total / walker_steps_1024_per_gpu   the strong- and weak-scaling walker legs, at every N as well, so that the
+                    driver's N = 1, 2, 4, 8 lines give each curve its origin;
+  single_model_latency   one model per call (the reference's own protocol) for configs[1] / [2] / [4] beside the reference's
+                    one-core time.
 Prints ONE JSON line (see DESIGN.md for the roofline conventions).
 """
 import argparse

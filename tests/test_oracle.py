@@ -462,8 +462,8 @@ def test_oracle_pair_row_mode_matches_the_committed_reference_vectors(oracle, ca
             continue
         m = want > 1e-2 * want.max()
         err = float(np.max(np.abs(g - want)[m] / want[m]))
-        tol = max(2e-6, 3 * dem[case][name.replace("rvs_", "rvs.").replace("sync", "sync") if name.startswith("rvs") else "fwd." + name]) \
-            if case == "gauss_rs_ssc" else (2e-5 if case == "tophat_rs" else 2e-6)
+        comp = name.replace("rvs_", "rvs.") if name.startswith("rvs") else "fwd." + name
+        tol = max(2e-6, 3 * dem[case][comp]) if case == "gauss_rs_ssc" else (2e-5 if case == "tophat_rs" else 2e-6)
         assert err <= tol, (name, err, tol)
     ts, nus = np.repeat(t, 3), np.tile(nu, t.size)
     series, band = oracle.flux_density(prm, ts, nus), oracle.flux(prm, t, 1e14, 1e15, 8)
