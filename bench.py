@@ -274,7 +274,11 @@ def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=512):
                      "stage_ms": {"grid": st.grid_ms, "dynamics": st.dynamics_ms, "cells_cooling_tables": st.cells_ms,
                                   "flux_passes": st.flux_ms, "reduce": st.reduce_ms},
                      "stage_ms_reference_names": {n: getattr(prof, n) for n, _ in _lib.Profile._fields_},
-                     "roofline_fp64_flux_passes": {"spec_evals": plan.spec_evals, "interps": plan.interps,
+                     "roofline_fp64_flux_passes": {"tally_note": "unit counts from one extra UNTIMED pass with vag_ctx_count_work, which runs the workgroup "
+                                                                 "flux kernel (the row-per-lane kernels that serve the timed passes carry no tallies); "
+                                                                 "the counts -- window-clamped evaluations and interpolations -- do not depend on the kernel",
+                                                   "valu_busy_see": "valu_busy_from_pmc (vag_flux_grid_rows_kernel<1> / <2>)",
+                                                   "spec_evals": plan.spec_evals, "interps": plan.interps,
                                                    "achieved": flops / (st.flux_ms * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": flops / (st.flux_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
                      "roofline_fp64_ic_photons": {"kernel": "vag_ic_photon_kernel (+ seed band)", "ic_terms": plan.ic_terms, "ic_nodes": plan.ic_nodes,
