@@ -28,6 +28,21 @@ if p:
 else:
     print("kernel_stats.csv not found")
 
+# The stats table averages a kernel over ALL its launches; the bench line also launches the headline instantiation for its single-model
+# latency leg (a 1-model grid, ~0.06 ms), so the launches are listed per launch shape from the kernel trace: the batch launches are the
+# ones bench.py's roofline.ms_per_launch refers to.
+p = find("stats", "*kernel_trace.csv")
+if p:
+    shapes = defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if "vag_flux_grid_kernel<false, 0, false, 512" in r["Kernel_Name"]:
+            shapes[(int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]))].append(
+                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    print("\n== vag_flux_grid_kernel<false, 0, false, 512, false> by launch shape (workgroups x models): launches, average ms, min - max ==")
+    for shape, d in sorted(shapes.items(), reverse=True):
+        print(f"   {shape[0]:>6d} x {shape[1]:<5d} {len(d):>4d} launches  avg {sum(d) / len(d):8.3f} ms   {min(d):.3f} - {max(d):.3f}"
+              + ("   (all but the first, which pays the cold caches: avg %.3f ms)" % (sum(d[1:]) / (len(d) - 1)) if len(d) > 2 else ""))
+
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     p = find(sub, "*counter_collection.csv")
     print(f"\n== PMC pass {sub} ==")
