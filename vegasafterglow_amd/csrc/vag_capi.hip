@@ -781,13 +781,16 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     hipStream_t st = c->stream;
     if (c->d_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
     if (c->d_cost_f.ensure(sizeof(float) * nb)) return VAG_E_HIP;
-    if (c->d_phi.ensure(sizeof(double) * (size_t)nb * VAG_MAX_PHI)) return VAG_E_HIP;
-    if (c->d_theta.ensure(sizeof(double) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->d_tdec.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->d_geo_th.ensure(sizeof(double) * (size_t)nb * 3 * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * VAG_MAX_PHI)) return VAG_E_HIP;
-    if (c->d_rep_of.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
-    if (c->d_rep_start.ensure(sizeof(int) * (size_t)nb * VAG_MAX_THETA)) return VAG_E_HIP;
+    // per-model angular arrays at the stride of the layout the grid kernel runs with (VagGridMeta::th_stride / ph_stride): 35 KB per
+    // model for default-resolution batches (320 theta / 640 phi slots), 140 KB when a batch needed the large layout
+    auto ensure_angular = [&](bool large) -> bool {
+        const size_t ts = large ? VAG_MAX_THETA : VAG_GRID_THETA, ps = large ? VAG_MAX_PHI : VAG_GRID_PHI;
+        return c->d_phi.ensure(sizeof(double) * (size_t)nb * ps) || c->d_theta.ensure(sizeof(double) * (size_t)nb * ts) ||
+               c->d_tdec.ensure(sizeof(double) * (size_t)nb * 3 * ts) || c->d_geo_th.ensure(sizeof(double) * (size_t)nb * 3 * ts) ||
+               c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * ps) || c->d_rep_of.ensure(sizeof(int) * (size_t)nb * ts) ||
+               c->d_rep_start.ensure(sizeof(int) * (size_t)nb * ts) || c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(large));
+    };
+    if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
@@ -830,7 +833,6 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->prof_used = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
     std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
-    if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(c->grid_large))) return VAG_E_HIP;
     auto launch_grid = [&](bool large) {
         c->layout_large = large;  // the layout THIS batch is laid out with (c->grid_large may change below for the next one)
         auto kern = large ? vag_grid_kernel<true> : vag_grid_kernel<false>;
@@ -856,7 +858,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             // some model's angular grid outgrew the small layout of the grid kernel: lay the batch out again with the large one
             // (the same grids for every model that fitted), and keep using it while the caller keeps sending such models
             c->grid_large = true;
-            if (c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(true))) return VAG_E_HIP;
+            HIPCHK(hipStreamSynchronize(st));  // (the arrays are about to be re-allocated at the large stride; nothing may still write them)
+            if (ensure_angular(true)) return VAG_E_HIP;
             if (std::getenv("VAG_DEBUG_LAUNCH"))
                 std::fprintf(stderr, "[vag] grid: %d of %d models over the small layout's capacity, laying the batch out again\n", hp->n_capacity, nb);
             launch_grid(true);

@@ -6,7 +6,7 @@
 
 // Static per-model capacities of the adaptive grid (src/core/grid-refinement.h:639-706 decides
 // the actual sizes at run time; these bound them).
-#define VAG_MAX_THETA 1280  // theta nodes per model: stride of the per-model angular arrays in HBM
+#define VAG_MAX_THETA 1280  // theta nodes per model (the large layout of the grid kernel; VagGridMeta::th_stride is the HBM stride of a batch)
 #define VAG_MAX_PHI 2560    // phi nodes per model
 #define VAG_GRID_THETA 320  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
 #define VAG_GRID_PHI 640    //   with the large layout (vag_grid_kernel<true>)
@@ -38,6 +38,8 @@ struct VagGridMeta {
     int32_t dyn_class;    // 0: vag_dynamics_fast_kernel applies (ISM / analytic Wind, no spreading, no injection, no reverse shock)
     int32_t rep_phi_stride;  // 0, or n_theta for Model(axisymmetric=False) with a spreading jet: the ODE rows are (phi, theta) PAIRS,
                              // row of (theta j, phi i) = rep_of[j] + i * rep_phi_stride (one lattice and one solve per pair, grid-refinement.h:619-625)
+    int32_t th_stride, ph_stride;  // stride of the per-model angular arrays in HBM (theta / rep_of / tdec / geo_th; phi / geo_ph): what the
+                                   // layout the batch was laid out with holds (VAG_GRID_* by default, VAG_MAX_* for the large one)
     double t_early;  // engine frame, code units
     double t_start;  // min_t_start
     double t_end;    // 1.01 t_max / (1+z)

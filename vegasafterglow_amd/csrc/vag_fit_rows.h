@@ -115,13 +115,13 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     const bool valid = p0 + lane < n_pairs;
     const int pair = valid ? p0 + lane : n_pairs - 1;
     const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
-    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-    const int rep = a.g_rep_of[(size_t)m * VAG_MAX_THETA + j] + i * Mp->rep_phi_stride;  // ((phi, theta) pair rows: non-axisymmetric spreading jet)
-    const double cos_phi = gph[i], lg2_dphi = gph[VAG_MAX_PHI + i];
-    const double cos_v = gth[VAG_MAX_THETA + j] * cos_phi * Mp->sin_obs + gth[j] * Mp->cos_obs;  // (non-spreading rows)
+    const double* gth = a.geo_th + (size_t)m * 3 * Mp->th_stride;
+    const double* gph = a.geo_ph + (size_t)m * 2 * Mp->ph_stride;
+    const int rep = a.g_rep_of[(size_t)m * Mp->th_stride + j] + i * Mp->rep_phi_stride;  // ((phi, theta) pair rows: non-axisymmetric spreading jet)
+    const double cos_phi = gph[i], lg2_dphi = gph[Mp->ph_stride + i];
+    const double cos_v = gth[Mp->th_stride + j] * cos_phi * Mp->sin_obs + gth[j] * Mp->cos_obs;  // (non-spreading rows)
     const double t_coeff = (1 - cos_v) / C_C * one_plus_z;
-    const double lg2_dOmega = gth[2 * VAG_MAX_THETA + j] + lg2_dphi;
+    const double lg2_dOmega = gth[2 * Mp->th_stride + j] + lg2_dphi;
     const long long cell0 = a.lay.cell_off[m] + (long long)rep * K;
     const double* row = a.cellpar + cell0 * VAG_NPAR;  // [VAG_NPAR][K]
     const double* geo = SPREAD ? a.cellgeo + cell0 * 3 : nullptr;  // [3][K]

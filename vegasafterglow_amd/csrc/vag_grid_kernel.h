@@ -451,6 +451,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
     M.t_num_base = 0;
     M.dyn_class = (med.generic || (P.flags & (VAG_FLAG_SPREADING | VAG_FLAG_MAGNETAR | VAG_FLAG_RVS))) ? 1 : 0;
     M.rep_phi_stride = 0;
+    M.th_stride = SH::max_theta;
+    M.ph_stride = SH::max_phi;
 #ifdef VAG_GRID_STAMPS
     long long stamps_[10] = {};
 #endif
@@ -887,8 +889,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             sh.flag[j] = differs;
         }
         __syncthreads();
-        int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
-        int* rep_start = g_rep_start + (size_t)m * VAG_MAX_THETA;
+        int* rep_of = g_rep_of + (size_t)m * SH::max_theta;
+        int* rep_start = g_rep_start + (size_t)m * SH::max_theta;
         // group index of row j = (number of group starts in [0, j]) - 1: ballot prefix counts, 64 rows per round
         for (int base = 0; base < n_theta; base += WAVE) {
             const int j = base + lane;
@@ -932,8 +934,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             // grids; symmetric grids overwrite them below with the shared start / early node
             double ts, t_start_row, t_early_row;
             row_time_start(b, cos(th), sin(th), cos_phi0, cos_tv, sin_tv, t_min, z, cut, t_start_row, t_early_row, ts);
-            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = t_start_row;
-            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = t_early_row;
+            g_tdec[((size_t)m * 3 + 1) * SH::max_theta + j] = t_start_row;
+            g_tdec[((size_t)m * 3 + 2) * SH::max_theta + j] = t_early_row;
             min_raw = dmin(min_raw, ts);
             min_guarded = dmin(min_guarded, t_start_row);
             min_cut = dmin(min_cut, cut);
@@ -979,15 +981,15 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
     // Observer::build_time_grid, observer.cpp:215-222 (jet_3d = non-axisymmetric model with more than one phi node)
     M.n_phi_eff = (theta_v == 0 && !((P.flags & VAG_FLAG_NON_AXISYMMETRIC) && n_phi > 1)) ? 1 : n_phi;
     __syncthreads();
-    for (int i = lane; i < n_phi; i += WAVE) g_phi[(size_t)m * VAG_MAX_PHI + i] = sh.phi[i];
+    for (int i = lane; i < n_phi; i += WAVE) g_phi[(size_t)m * SH::max_phi + i] = sh.phi[i];
     for (int j = lane; j < n_theta; j += WAVE) {
-        g_theta[(size_t)m * VAG_MAX_THETA + j] = sh.theta[j];
+        g_theta[(size_t)m * SH::max_theta + j] = sh.theta[j];
         // lattice scalars per row: [0] t_dec, [1] first regular node, [2] early node.  Symmetric grids share the global
         // start / early point (build_time_grid, grid-refinement.h:609-626)
-        g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j] = sh.tdec[j];
+        g_tdec[((size_t)m * 3 + 0) * SH::max_theta + j] = sh.tdec[j];
         if (!spreading) {
-            g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j] = M.t_start;
-            g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j] = M.t_early;
+            g_tdec[((size_t)m * 3 + 1) * SH::max_theta + j] = M.t_start;
+            g_tdec[((size_t)m * 3 + 2) * SH::max_theta + j] = M.t_early;
         }
     }
     VAG_GRID_STAMP(7);
@@ -997,8 +999,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
     M.cos_obs = cos(theta_v);
     M.sin_obs = sin(theta_v);
     {
-        double* gth = g_geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-        double* gph = g_geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+        double* gth = g_geo_th + (size_t)m * 3 * SH::max_theta;
+        double* gph = g_geo_ph + (size_t)m * 2 * SH::max_phi;
         // The same numbers once more as ROW-GEOMETRY RECORDS behind one base address per model, for the workgroup flux kernel's
         // scalar loads (it is out of scalar registers for five plane pointers, the rep_of pointer and the observer constants):
         // header {cos theta_obs, sin theta_obs, byte offset of the theta records, -}, phi records {cos phi, log2 dphi} from
@@ -1006,7 +1008,7 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
         double* rg = g_rowgeo + (size_t)m * (VAG_ROWGEO_HDR + 2 * SH::max_phi + 4 * SH::max_theta);
         const int npe = M.n_phi_eff;
         const int rg_th = VAG_ROWGEO_HDR + 2 * npe;
-        const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;  // written above, a barrier ago
+        const int* rep_of = g_rep_of + (size_t)m * SH::max_theta;  // written above, a barrier ago
         if (lane == 0) {
             rg[0] = M.cos_obs;
             rg[1] = M.sin_obs;
@@ -1021,8 +1023,8 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             const double cos_hi = (j == last) ? ct : cos(0.5 * (th + sh.theta[j + 1]));
             const double st = sin(th), ld = log2(fabs(cos_hi - cos_lo));
             gth[j] = ct;
-            gth[VAG_MAX_THETA + j] = st;
-            gth[2 * VAG_MAX_THETA + j] = ld;
+            gth[SH::max_theta + j] = st;
+            gth[2 * SH::max_theta + j] = ld;
             double* r = rg + rg_th + 4 * j;
             r[0] = ct, r[1] = st, r[2] = ld, r[3] = __hiloint2double(0, rep_of[j]);
         }
@@ -1039,7 +1041,7 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
             }
             const double cp = cos(sh.phi[i]), ldp = log2(fabs(dphi));
             gph[i] = cp;
-            gph[VAG_MAX_PHI + i] = ldp;
+            gph[SH::max_phi + i] = ldp;
             rg[VAG_ROWGEO_HDR + 2 * i] = cp;
             rg[VAG_ROWGEO_HDR + 2 * i + 1] = ldp;
         }

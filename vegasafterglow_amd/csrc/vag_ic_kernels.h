@@ -324,12 +324,12 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
     __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
     const vag_model_params P = params[m];
     const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
-    const double* gth = geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    const double* gth = geo_th + (size_t)m * 3 * M.th_stride;
+    const double* gph = geo_ph + (size_t)m * 2 * M.ph_stride;
     for (int j = lane; j < M.n_theta; j += 64) {
         double lo = INFINITY, hi = -INFINITY;
         for (int i = 0; i < M.n_phi_eff; ++i) {
-            const double cv = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            const double cv = gth[M.th_stride + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             lo = fmin(lo, cv);
             hi = fmax(hi, cv);
         }
@@ -344,7 +344,7 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
     }
     const double lg2_1pz = log2(1 + P.z);
     const int nt = M.n_t;
-    const int* rep_of = g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int* rep_of = g_rep_of + (size_t)m * M.th_stride;
     double cphi_max = -INFINITY, cphi_min = INFINITY;
     for (int ii = 0; ii < M.n_phi_eff; ++ii) {
         cphi_max = fmax(cphi_max, gph[ii]);

@@ -51,20 +51,20 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     const int r = row - lay.row_off[m];
     // rows are representative theta rows, or -- Model(axisymmetric=False) with a spreading jet -- (phi i, theta j) pairs
     const int i_phi = M.rep_phi_stride ? r / M.rep_phi_stride : 0;
-    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * M.th_stride + r];
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
     FwdShock<SPREAD, INJECT> eq;
     eq.lg_tab = lds_tab(s_lg);
     medium_init(eq.med, P);
-    const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
-    const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
-    double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
-    double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    const double theta0 = g_theta[(size_t)m * M.th_stride + j];
+    const double t_dec = g_tdec[((size_t)m * 3 + 0) * M.th_stride + j];
+    double t_start_row = g_tdec[((size_t)m * 3 + 1) * M.th_stride + j];
+    double t_early_row = g_tdec[((size_t)m * 3 + 2) * M.th_stride + j];
     if (M.rep_phi_stride) {  // the pair's own lattice start: the viewing cosine of (phi_i, theta_j) (grid-refinement.h:462-469,619-625)
         double ts_raw;
-        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * VAG_MAX_PHI + i_phi]),
+        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * M.ph_stride + i_phi]),
                        M.cos_obs, M.sin_obs, tminmax[0] * U_SEC, P.z, dmin(0.01 * t_dec, 1e-2 * U_SEC), t_start_row, t_early_row, ts_raw);
     }
     const int nt = M.n_t;
@@ -95,7 +95,7 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     eq.inj_q = P.mag_q;
     constexpr int NS = 5 + (SPREAD ? 1 : 0) + (INJECT ? 1 : 0);
     if constexpr (SPREAD) {  // jet_spreading_edge over [theta.front(), theta.back()], grid-refinement.h:113-135
-        const double th_min = g_theta[(size_t)m * VAG_MAX_THETA], th_max = g_theta[(size_t)m * VAG_MAX_THETA + M.n_theta - 1];
+        const double th_min = g_theta[(size_t)m * M.th_stride], th_max = g_theta[(size_t)m * M.th_stride + M.n_theta - 1];
         const double step = (th_max - th_min) / 256;
         double theta_s = th_min, dp_min = 0;
         for (double th = th_min; th <= th_max; th += step) {
@@ -245,16 +245,16 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
     bool stopped = false;
     if (active) {
         const int r = row - lay.row_off[m];
-        const int j = g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+        const int j = g_rep_start[(size_t)m * M.th_stride + r];
         const vag_model_params P = params[m];
         Jet jet;
         jet_init(jet, P);
         Medium med;
         medium_init(med, P);
-        const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
-        const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
-        t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
-        t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+        const double theta0 = g_theta[(size_t)m * M.th_stride + j];
+        const double t_dec = g_tdec[((size_t)m * 3 + 0) * M.th_stride + j];
+        t_start_row = g_tdec[((size_t)m * 3 + 1) * M.th_stride + j];
+        t_early_row = g_tdec[((size_t)m * 3 + 2) * M.th_stride + j];
         const long long c0 = lay.cell_off[m] + (long long)r * nt;
         o_teng = shock + VS_TENG * n_cells + c0;
         o_tcomv = shock + VS_TCOMV * n_cells + c0;
@@ -714,7 +714,7 @@ vag_eat_details_kernel(const vag_model_params* __restrict__ params, const VagGri
         cos_v = geo[K + k] * geo_ph[i] * sin_obs + geo[k] * cos_obs;
         time = (teng + (1 - cos_v) * r / C_C) * one_plus_z;
     } else {
-        cos_v = geo_th[VAG_MAX_THETA + j] * geo_ph[i] * sin_obs + geo_th[j] * cos_obs;
+        cos_v = geo_th[M.th_stride + j] * geo_ph[i] * sin_obs + geo_th[j] * cos_obs;
         time = teng * one_plus_z + (1 - cos_v) / C_C * one_plus_z * r;
     }
     out_t[q] = time / U_SEC;
@@ -785,7 +785,7 @@ vag_flux_grid_kernel(FluxArgs a) {
     SpecConst sc;
     sc.init(Pp->p);
     const double cos_obs = Mp->cos_obs, sin_obs = Mp->sin_obs;  // (SPREAD kernels; the others read them with the row's record)
-    const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const int* rep_of = a.g_rep_of + (size_t)m * Mp->th_stride;
     const int rep_stride = Mp->rep_phi_stride;  // (phi, theta) pair rows of a non-axisymmetric spreading jet: row = rep_of[j] + i * stride
     // non-spreading kernels: the model's row-geometry records (written by vag_grid_kernel), one base address for everything a row needs
     const double* rg = a.rowgeo + (size_t)m * a.rowgeo_stride;
@@ -836,13 +836,13 @@ vag_flux_grid_kernel(FluxArgs a) {
 #else
     const int etid = tid;
 #endif
-    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
+    const double* gth = a.geo_th + (size_t)m * 3 * Mp->th_stride;
+    const double* gph = a.geo_ph + (size_t)m * 2 * Mp->ph_stride;
     auto stage_and_eat = [&](int j, int i, int buf) {  // (theta, phi) indices of the row: walked with a carry, never divided out
         const double w_lo = s_tobs[0], w_hi = s_tobs[nt - 1];
         if constexpr (SPREAD) {
             const double* geo = a.cellgeo + (a.cell_off[m] + (long long)rep_at(j, i) * K_all) * 3 + k0;
-            eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[VAG_MAX_PHI + i], one_plus_z,
+            eat_row_spread(s_par, KS, K, etid, THREADS, geo, gph[i], sin_obs, cos_obs, gph[Mp->ph_stride + i], one_plus_z,
                            s_t + buf * KS, s_dop, s_geom, lg_tab, K_all, s_win + buf * 2, w_lo, w_hi);
         } else {
             const RowGeo g = sload_rowgeo(rg, rg_th, j, i);
@@ -1411,9 +1411,9 @@ vag_flux_series_kernel(SeriesArgs a) {
     SpecConst sc;
     sc.init_fast(a.params[m].p, lg_tab);
     const double cos_obs = M.cos_obs, sin_obs = M.sin_obs;
-    const double* gth = a.geo_th + (size_t)m * 3 * VAG_MAX_THETA;
-    const double* gph = a.geo_ph + (size_t)m * 2 * VAG_MAX_PHI;
-    const int* rep_of = a.g_rep_of + (size_t)m * VAG_MAX_THETA;
+    const double* gth = a.geo_th + (size_t)m * 3 * M.th_stride;
+    const double* gph = a.geo_ph + (size_t)m * 2 * M.ph_stride;
+    const int* rep_of = a.g_rep_of + (size_t)m * M.th_stride;
     const int n_phi_eff = M.n_phi_eff;
     // Row geometry of the next 64 (theta, phi) rows, one row per lane, read back with v_readlane when the row's turn comes: the
     // five dependent global loads and the index division of a row leave its critical path (a wavefront works alone: nothing
@@ -1427,11 +1427,11 @@ vag_flux_series_kernel(SeriesArgs a) {
         g_rep = rep_of[j] + i * M.rep_phi_stride;  // ((phi, theta) pair rows of a non-axisymmetric spreading jet)
         if constexpr (SPREAD) {
             g_a = gph[i];
-            g_c = gph[VAG_MAX_PHI + i];
+            g_c = gph[M.ph_stride + i];
         } else {
-            g_a = gth[VAG_MAX_THETA + j] * gph[i] * sin_obs + gth[j] * cos_obs;
+            g_a = gth[M.th_stride + j] * gph[i] * sin_obs + gth[j] * cos_obs;
             g_b = (1 - g_a) / C_C * one_plus_z;
-            g_c = gth[2 * VAG_MAX_THETA + j] + gph[VAG_MAX_PHI + i];
+            g_c = gth[2 * M.th_stride + j] + gph[M.ph_stride + i];
         }
     };
     auto lane_value = [&](double v, int l) {

@@ -41,19 +41,19 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
     const int r = row - lay.row_off[m];
     // rows are representative theta rows, or -- Model(axisymmetric=False) with a spreading jet -- (phi i, theta j) pairs
     const int i_phi = M.rep_phi_stride ? r / M.rep_phi_stride : 0;
-    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * VAG_MAX_THETA + r];
+    const int j = M.rep_phi_stride ? r - i_phi * M.rep_phi_stride : g_rep_start[(size_t)m * M.th_stride + r];
     const vag_model_params P = params[m];
     Jet jet;
     jet_init(jet, P);
     PairShock eq;
     medium_init(eq.med, P);
-    const double theta0 = g_theta[(size_t)m * VAG_MAX_THETA + j];
-    const double t_dec = g_tdec[((size_t)m * 3 + 0) * VAG_MAX_THETA + j];
-    double t_start_row = g_tdec[((size_t)m * 3 + 1) * VAG_MAX_THETA + j];
-    double t_early_row = g_tdec[((size_t)m * 3 + 2) * VAG_MAX_THETA + j];
+    const double theta0 = g_theta[(size_t)m * M.th_stride + j];
+    const double t_dec = g_tdec[((size_t)m * 3 + 0) * M.th_stride + j];
+    double t_start_row = g_tdec[((size_t)m * 3 + 1) * M.th_stride + j];
+    double t_early_row = g_tdec[((size_t)m * 3 + 2) * M.th_stride + j];
     if (M.rep_phi_stride) {  // the pair's own lattice start (grid-refinement.h:462-469,619-625; the reverse-shock cut of :489-491)
         double ts_raw;
-        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * VAG_MAX_PHI + i_phi]),
+        row_time_start(gamma_to_beta(jet_Gamma0(jet, theta0)), cos(theta0), sin(theta0), cos(g_phi[(size_t)m * M.ph_stride + i_phi]),
                        M.cos_obs, M.sin_obs, tminmax[0] * U_SEC, P.z, dmin(dmin(0.01 * t_dec, 1e-2 * U_SEC), 0.01 * P.duration * U_SEC),
                        t_start_row, t_early_row, ts_raw);
     }
