@@ -12,7 +12,7 @@ import sys
 
 src, pat = sys.argv[1], sys.argv[2]
 lines = open(src).read().split("\n")
-start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:", l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:.*", l))
 name = lines[start][:-1]
 end = next(i for i in range(start, len(lines)) if lines[i].startswith("\t.section") or lines[i].startswith(".Lfunc_end"))
 blocks, cur = [], None

@@ -764,6 +764,21 @@ int wait_plan(vag_ctx* c) {
 // ODE rows per wavefront of the dynamics kernels (one lane integrates one row).  Measured (profiles/r02_rpw.txt): fewer
 // rows per wavefront do NOT pay for the general kernel -- at 256 VGPRs only one wavefront fits a SIMD and the dispatcher
 // does not spread single-wavefront workgroups evenly -- so full wavefronts stay the default; the knob remains for tuning.
+// The coupled forward + reverse shock solver keeps its retry loop inside the step (a wavefront repeats an attempt while ANY of its
+// lanes rejects) and one wavefront fills a SIMD (256 VGPRs): fewer rows per wavefront mean fewer repeated attempts and -- while the
+// batch has fewer wavefronts than the chip has SIMDs -- more SIMDs at work.  VAG_PAIR_RPW overrides (tuning).
+int pair_rows_per_wave(int rows) {
+    if (const char* e = std::getenv("VAG_PAIR_RPW")) {
+        const int v = std::atoi(e);
+        if (v > 0) return std::min(v, 64);
+    }
+    // Measured (profiles/debug/pair_rpw_probe.py, one configs[2] model = 65 rows / 512 models = 33 k rows; same bits): 64 rows per
+    // wavefront 3.18 / 3.48 ms, 32: 2.83 / 5.35, 16: 2.68 / 5.89, 8: 2.32 / 16.3 -- fewer rows pay while the wavefronts stay well below the
+    // number of SIMDs (1024), and cost dearly beyond it (a 256-VGPR wavefront owns its SIMD; the dispatcher does not pack them evenly).
+    for (int rpw = 8; rpw < 64; rpw *= 2)
+        if ((rows + rpw - 1) / rpw <= 512) return rpw;
+    return 64;
+}
 int dyn_rows_per_wave(int rows) {
     (void)rows;
     if (const char* e = std::getenv("VAG_DYN_RPW")) {
@@ -926,11 +941,12 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         if (c->d_params_rvs.ensure(sizeof(vag_model_params) * (size_t)nb)) return VAG_E_HIP;
         hipLaunchKernelGGL(vag_rvs_params_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, d_params, nb,
                            c->d_params_rvs.as<vag_model_params>());
-        hipLaunchKernelGGL(vag_dynamics_pair_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_params, nb,
+        const int prw = pair_rows_per_wave(rows);
+        hipLaunchKernelGGL(vag_dynamics_pair_kernel, dim3((rows + prw - 1) / prw), dim3(64), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
                            c->d_inj.as<int>(), c->d_row_status.as<int>(), c->d_fail.as<int>(), c->d_phi.as<double>(),
-                           c->d_tminmax.as<double>());
+                           c->d_tminmax.as<double>(), prw);
     } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
         const int rpw = dyn_rows_per_wave(rows);

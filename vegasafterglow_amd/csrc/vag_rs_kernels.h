@@ -32,9 +32,10 @@ vag_dynamics_pair_kernel(const vag_model_params* __restrict__ params, int nb, co
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock_fwd,
                          double* __restrict__ shock_rvs, long long n_cells, int* __restrict__ inj_idx,
                          int* __restrict__ row_status, int* __restrict__ fail,
-                         const double* __restrict__ g_phi /* (phi, theta) pair rows only */, const double* __restrict__ tminmax) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows || row >= lay.row_off[nb]) return;
+                         const double* __restrict__ g_phi /* (phi, theta) pair rows only */, const double* __restrict__ tminmax,
+                         int rows_per_wave /* rows a wavefront carries (pair_rows_per_wave): its lanes pay for each other's rejected steps */) {
+    const int row = blockIdx.x * rows_per_wave + threadIdx.x;
+    if ((int)threadIdx.x >= rows_per_wave || row >= n_rows || row >= lay.row_off[nb]) return;
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
