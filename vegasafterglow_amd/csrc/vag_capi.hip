@@ -767,16 +767,18 @@ int wait_plan(vag_ctx* c) {
 // The coupled forward + reverse shock solver keeps its retry loop inside the step (a wavefront repeats an attempt while ANY of its
 // lanes rejects) and one wavefront fills a SIMD (256 VGPRs): fewer rows per wavefront mean fewer repeated attempts and -- while the
 // batch has fewer wavefronts than the chip has SIMDs -- more SIMDs at work.  VAG_PAIR_RPW overrides (tuning).
-int pair_rows_per_wave(int rows) {
-    if (const char* e = std::getenv("VAG_PAIR_RPW")) {
+int pair_rows_per_wave(int rows, const char* env = "VAG_PAIR_RPW") {
+    if (const char* e = std::getenv(env)) {
         const int v = std::atoi(e);
         if (v > 0) return std::min(v, 64);
     }
-    // Measured (profiles/debug/pair_rpw_probe.py, one configs[2] model = 65 rows / 512 models = 33 k rows; same bits): 64 rows per
-    // wavefront 3.18 / 3.48 ms, 32: 2.83 / 5.35, 16: 2.68 / 5.89, 8: 2.32 / 16.3 -- fewer rows pay while the wavefronts stay well below the
-    // number of SIMDs (1024), and cost dearly beyond it (a 256-VGPR wavefront owns its SIMD; the dispatcher does not pack them evenly).
+    // Measured (profiles/debug/pair_rpw_probe.py: one configs[2] model = 65 rows / 512 models = 33 k rows; general_rpw_probe.py: one
+    // spreading Gaussian jet = 49 rows / 256 of them = 12.5 k rows; same bits whatever the choice): 64 rows per wavefront 3.18 / 3.48 ms
+    // and 1.85 / 1.98 ms, 32: 2.83 / 5.35 and 1.57 / 2.28, 16: 2.68 / 5.89 and 1.77 / 2.30, 8: 2.32 / 16.3 and 1.41 / 4.36 -- fewer rows pay
+    // for a handful of models and cost as soon as there are a few hundred wavefronts (a 256-VGPR wavefront owns its SIMD and the
+    // dispatcher does not spread them evenly), so only small batches are split up.
     for (int rpw = 8; rpw < 64; rpw *= 2)
-        if ((rows + rpw - 1) / rpw <= 512) return rpw;
+        if ((rows + rpw - 1) / rpw <= 64) return rpw;
     return 64;
 }
 int dyn_rows_per_wave(int rows) {
@@ -958,7 +960,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         const bool inject = (c->batch_flags & VAG_FLAG_MAGNETAR) != 0;
         auto kern = spreading ? (inject ? vag_dynamics_kernel<true, true> : vag_dynamics_kernel<true, false>)
                               : (inject ? vag_dynamics_kernel<false, true> : vag_dynamics_kernel<false, false>);
-        const int rpw = dyn_rows_per_wave(rows);
+        const int rpw = pair_rows_per_wave(rows, "VAG_DYN_RPW");  // (the general solver retries inside the step like the pair solver)
         hipLaunchKernelGGL(kern, dim3((rows + rpw - 1) / rpw), dim3(64), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                            c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows,
                            c->d_shock.as<double>(), cells, c->d_row_status.as<int>(), c->d_sptab.as<double>(), rpw,
