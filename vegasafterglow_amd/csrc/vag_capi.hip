@@ -1026,6 +1026,20 @@ static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
 int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, const double* d_lg2nu, int n,
                     double* d_out, int mode = FLUX_SYN, int n_bands = 0, int grid_nt = 0);
 
+// fixed-order sum of a flux pass's workgroup partials + normalisation: plain grids through the grouped kernel, band-weighted
+// requests through the serial one
+static void launch_reduce(hipStream_t st, const vag_model_params* d_params, const VagGridMeta* meta, const double* partial, int max_blocks,
+                          int ppb, int nt, int nnu, const double* d_bandw, double* d_out, int nb) {
+    if (d_bandw) {
+        hipLaunchKernelGGL(vag_reduce_kernel, dim3((nt + 255) / 256, nb), dim3(256), 0, st, d_params, meta, partial, max_blocks, ppb, nt, nnu,
+                           d_bandw, d_out);
+    } else {
+        const int slots = nt * nnu;
+        hipLaunchKernelGGL(vag_reduce_grid_kernel, dim3((slots + REDUCE_SLOTS - 1) / REDUCE_SLOTS, nb), dim3(REDUCE_GROUPS * REDUCE_SLOTS), 0, st,
+                           d_params, meta, partial, max_blocks, ppb, slots, d_out);
+    }
+}
+
 int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt,
                   const double* d_lg2nu, int nnu, const double* d_bandw, double* d_out, int mode = FLUX_SYN,
                   double* d_out2 = nullptr /* FLUX_FUSED: the SSC component */) {
@@ -1086,9 +1100,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
                 hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN>), g, b, lds, st, a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[4], st));
-            const int out_slots = d_bandw ? nt : slots;
-            hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
-                               c->d_partial.as<double>(), max_blocks, FITROWS_ROWS, nt, nnu, d_bandw, d_out);
+            launch_reduce(st, d_params, c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, FITROWS_ROWS, nt, nnu, d_bandw, d_out, nb);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));
             return VAG_OK;
@@ -1220,12 +1232,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         c->plan.spec_evals += (long long)h[0] - c->eat_cells * nnu;
         c->plan.interps += (long long)h[1] - c->total_pairs * (long long)nt * nnu;
     }
-    const int out_slots = d_bandw ? nt : slots;
-    hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
-                       c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out);
+    launch_reduce(st, d_params, c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out, nb);
     if (mode == FLUX_FUSED)
-        hipLaunchKernelGGL(vag_reduce_kernel, dim3((out_slots + 255) / 256, nb), dim3(256), 0, st, d_params,
-                           c->d_meta.as<VagGridMeta>(), c->d_partial2.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out2);
+        launch_reduce(st, d_params, c->d_meta.as<VagGridMeta>(), c->d_partial2.as<double>(), max_blocks, ppb, nt, nnu, d_bandw, d_out2, nb);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[5], st));
     return VAG_OK;
