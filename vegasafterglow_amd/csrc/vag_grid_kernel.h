@@ -15,7 +15,9 @@ namespace vag {
 constexpr int WAVE = 64;
 constexpr int N_SCAN = 512;      // find_jet_jumps / find_theta_range scans
 constexpr int N_SAMPLES = 200;   // defaults::sampling::theta_samples
-constexpr int QUAD_REC = 96;     // accepted CDF-quadrature steps buffered before their samples are interpolated
+constexpr int QUAD_REC = 24;     // accepted CDF-quadrature steps buffered before their samples are interpolated (a quadrature takes 23-33 steps: one or
+                                 // two flushes).  With this and 16-bit merge flags the small layout is 27.0 KB: SIX models resident per CU instead of
+                                 // four (33 KB at 96 records) -- the grid stage of batches larger than the chip holds at once
 
 #ifdef VAG_GRID_STAMPS  // developer aid: cycle stamps of model 0 at the section boundaries, printed by lane 0
 #define VAG_GRID_STAMP(i) do { if (m == 0 && lane == 0) stamps_[i] = __builtin_readcyclecounter(); } while (0)
@@ -75,7 +77,7 @@ struct GridSharedT {
     };
     double theta[MAXTH + 64];
     double phi[MAXPH];
-    int flag[MAXTH];
+    short flag[MAXTH];  // merge bookkeeping: node indices < MAXTH, -1; group-start marks
     double rec[9][QUAD_REC];          // accepted quadrature steps awaiting their dense-output pass (integrate_cdf)
     double jumps[VAG_MAX_JUMPS];      // find_jet_jumps results (dynamically indexed: LDS, not scratch)
     double feat[3 * VAG_MAX_JUMPS];   // jump_refinement_grid nodes
@@ -1060,8 +1062,11 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
 
 // One wavefront (blockDim.x == 64) per model; the last wavefront to finish also lays the batch out (plan_scan_wave): no
 // separate launch, no host round trip between the grids and the stages that depend on their sizes.
+// Two wavefronts per SIMD (second launch bound): left alone the compiler allocates 208 VGPRs + 49 AGPRs = 257 registers -- ONE more than
+// two resident wavefronts allow -- and a batch larger than the chip's 1024 SIMDs then runs its models one per SIMD, round after round
+// (4096 top-hat models: 0.52 ms of grid stage at 0.87 resident wavefronts per SIMD, profiles/debug/grid_occupancy.sh).
 template <bool LARGE>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE, LARGE ? 1 : 2)
 vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
