@@ -33,14 +33,44 @@ constexpr int FITROWS_SEGS = 4;    // lattice segments per block: each (block, s
 #define VAG_FITROWS_STRIPES 4
 #endif
 constexpr int FITROWS_STRIPES = VAG_FITROWS_STRIPES;  // copies of a wavefront's per-point sums for short data sets: lane L adds to copy
-                                                      // L mod 4 (neighbouring rows hit the same point in the same instruction)
+                                                      // L mod 4 (rows near each other hit the same point in the same instruction)
 __host__ __device__ inline int fit_rows_npad(int n) { return (n + SERIES_THREADS - 1) / SERIES_THREADS * SERIES_THREADS; }
 __host__ __device__ inline int fit_rows_stripes(int n) { return n <= 128 ? FITROWS_STRIPES : 1; }
 
-// bytes of LDS of one workgroup: tables, the points' times and bands, per wavefront [stripes][n_pad] sums
+// How the LDS applies a wave64 ds_add_f64 (profiles/micro/lds_atomic.hip, MI355X): sixteen lanes at a time; lanes of such a group
+// that hit one address take turns at ~3 cycles each (8.4 cycles per instruction without collisions, 44 with four lanes per address
+// in every group, 191 with all sixteen), lanes that hit different addresses of one bank (32 banks of 4 B: doubles 16 apart) at ~2.
+// Neighbouring rows reach the same requested time in the same instruction, so
+//   * the copies ("stripes") of a wavefront's sums lie 16 / stripes doubles apart modulo 16 (the same slot of two copies in different
+//     banks: with a stride that is a multiple of 16 -- 64 points, 4 x 100 slots -- the copies bought nothing), and
+//   * lane L takes row 4 (L mod 16) + L / 16 of the wavefront's 64: the sixteen lanes the LDS serves together are rows four apart,
+//     and rows next to each other are in different groups.
+#ifndef VAG_ROWS_BANK_STRIDE
+#define VAG_ROWS_BANK_STRIDE 1
+#endif
+#ifndef VAG_ROWS_PERMUTE
+#define VAG_ROWS_PERMUTE 1
+#endif
+__host__ __device__ inline int rows_acc_stride(int n, int stripes) {
+#if VAG_ROWS_BANK_STRIDE
+    const int want = (16 / stripes) & 15;
+    return n + ((want - n) & 15);
+#else
+    return n;
+#endif
+}
+__host__ __device__ inline int rows_lane_row(int lane) {
+#if VAG_ROWS_PERMUTE
+    return ((lane & 15) << 2) | (lane >> 4);
+#else
+    return lane;
+#endif
+}
+
+// bytes of LDS of one workgroup: tables, the points' times and bands, per wavefront [stripes][stride] sums
 __host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
-    const int np = fit_rows_npad(n);
-    return sizeof(double) * (SP_LDS_DOUBLES + np + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * fit_rows_stripes(n) * np) + sizeof(int) * np;
+    const int np = fit_rows_npad(n), st = fit_rows_stripes(n);
+    return sizeof(double) * (SP_LDS_DOUBLES + np + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * st * rows_acc_stride(np, st)) + sizeof(int) * np;
 }
 
 
@@ -62,11 +92,11 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
     const int W = a.grid_nt, blocks_per_wg = FITROWS_WAVES / W;
     if ((long long)blockIdx.x * blocks_per_wg * FITROWS_ROWS >= n_pairs) return;  // nothing of this model here (or model not evaluated)
-    const int n = a.n, NB = a.n_bands, NP = fit_rows_npad(n), stripes = fit_rows_stripes(n);
+    const int n = a.n, NB = a.n_bands, NP = fit_rows_npad(n), stripes = fit_rows_stripes(n), NS = rows_acc_stride(NP, stripes);
     double* s_tp = s_sp + SP_LDS_DOUBLES;             // [NP] log2 of the data points' times, ascending; +inf beyond n
     double* s_band = s_tp + NP;                       // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
-    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * stripes * NP;  // this wavefront's per-point sums [stripe][NP]
-    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * stripes * NP);  // [NP] band of each point
+    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * stripes * NS;  // this wavefront's per-point sums [stripe][NS]
+    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * stripes * NS);  // [NP] band of each point
     const double lg2_1pz = Mp->lg2_1pz;
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     for (int i = threadIdx.x; i < NP; i += blockDim.x) {
@@ -74,8 +104,8 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         s_band_of[i] = i < n ? a.band_idx[i] : 0;
     }
     if (threadIdx.x < NB) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]] + lg2_1pz;
-    for (int i = lane; i < stripes * NP; i += SERIES_THREADS) s_acc[i] = 0;
-    double* my_acc = s_acc + (lane % stripes) * NP;  // the copy this lane adds to
+    for (int i = lane; i < stripes * NS; i += SERIES_THREADS) s_acc[i] = 0;
+    double* my_acc = s_acc + (lane % stripes) * NS;  // the copy this lane adds to
     __syncthreads();  // the only workgroup-wide barrier
     // The lattice of a block is cut into FITROWS_SEGS segments, each with its own partial sum: the intervals between nodes are
     // independent, a segment starts from nothing but its first node.  W wavefronts share the block and take FITROWS_SEGS / W
@@ -99,9 +129,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         wave_sync();
         for (int q = lane; q < NP; q += SERIES_THREADS) {
             double sum = s_acc[q];
-            for (int c = 1; c < stripes; ++c) sum += s_acc[c * NP + q];  // fixed order
+            for (int c = 1; c < stripes; ++c) sum += s_acc[c * NS + q];  // fixed order
             if (q < n) my_partial[(size_t)s * n + q] = sum;
-            for (int c = 0; c < stripes; ++c) s_acc[c * NP + q] = 0;
+            for (int c = 0; c < stripes; ++c) s_acc[c * NS + q] = 0;
         }
         wave_sync();
     };
@@ -112,8 +142,8 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     }
 
     // this lane's row
-    const bool valid = p0 + lane < n_pairs;
-    const int pair = valid ? p0 + lane : n_pairs - 1;
+    const bool valid = p0 + rows_lane_row(lane) < n_pairs;
+    const int pair = valid ? p0 + rows_lane_row(lane) : n_pairs - 1;
     const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
     const double* gth = a.geo_th + (size_t)m * 3 * Mp->th_stride;
     const double* gph = a.geo_ph + (size_t)m * 2 * Mp->ph_stride;

@@ -39,7 +39,8 @@ constexpr int GRIDROWS_RING_BYTES = VAG_ROWS_RING ? GRIDROWS_RING * (2 * 16 + 4)
 
 __host__ __device__ inline int grid_rows_stripes(int slots) { return slots <= 128 ? 4 : 2; }
 __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
-    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * slots) +
+    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS +
+                             (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * rows_acc_stride(slots, grid_rows_stripes(slots))) +
            (size_t)GRIDROWS_WAVES * GRIDROWS_RING_BYTES;
 }
 
@@ -61,17 +62,17 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
     if ((long long)blockIdx.x * GRIDROWS_WAVES * FITROWS_ROWS >= n_pairs) return;
     const int nt = a.grid_nt, NB = a.n_bands, slots = a.n;
-    const int stripes = grid_rows_stripes(slots);
+    const int stripes = grid_rows_stripes(slots), SS = rows_acc_stride(slots, stripes);  // (the copies' stride: vag_fit_rows.h)
     double* s_tobs = s_sp + SP_LDS_DOUBLES;           // [GRIDROWS_MAX_NT] log2 requested times, ascending; +inf beyond nt
     double* s_nu = s_tobs + GRIDROWS_MAX_NT;          // [SERIES_MAX_BANDS] log2 nu (1 + z)
-    double* s_acc = s_nu + SERIES_MAX_BANDS + (size_t)wave * stripes * slots;  // this wavefront's sums [stripe][slots]
+    double* s_acc = s_nu + SERIES_MAX_BANDS + (size_t)wave * stripes * SS;  // this wavefront's sums [stripe][SS]
     for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
     for (int i = threadIdx.x; i < GRIDROWS_MAX_NT; i += blockDim.x) s_tobs[i] = i < nt ? a.lg2_t_obs[i] : INFINITY;
     if (threadIdx.x < NB) s_nu[threadIdx.x] = a.lg2_nu_obs[threadIdx.x] + Mp->lg2_1pz;
-    for (int i = lane; i < stripes * slots; i += SERIES_THREADS) s_acc[i] = 0;
-    double* my_acc = s_acc + (lane % stripes) * slots;
+    for (int i = lane; i < stripes * SS; i += SERIES_THREADS) s_acc[i] = 0;
+    double* my_acc = s_acc + (lane % stripes) * SS;
     // this wavefront's ring (behind every wavefront's sums; 16-byte aligned: the doubles before it are an even count)
-    char* ring_base = reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * slots) + (size_t)wave * GRIDROWS_RING_BYTES;
+    char* ring_base = reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * SS) + (size_t)wave * GRIDROWS_RING_BYTES;
     vdouble2* ring_x01 = reinterpret_cast<vdouble2*>(ring_base);
     vdouble2* ring_x23 = ring_x01 + GRIDROWS_RING;
     int* ring_q = reinterpret_cast<int*>(ring_x23 + GRIDROWS_RING);
@@ -93,8 +94,8 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     int breach = 0;
 
     // this lane's row
-    const bool valid = p0 + lane < n_pairs;
-    const int pair = valid ? p0 + lane : n_pairs - 1;
+    const bool valid = p0 + rows_lane_row(lane) < n_pairs;
+    const int pair = valid ? p0 + rows_lane_row(lane) : n_pairs - 1;
     const int j = pair / n_phi_eff, i = pair - j * n_phi_eff;
     const double* gth = a.geo_th + (size_t)m * 3 * Mp->th_stride;
     const double* gph = a.geo_ph + (size_t)m * 2 * Mp->ph_stride;
@@ -335,7 +336,7 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
     double* dst = a.partial + ((size_t)m * a.max_chunks + vb) * slots;
     for (int s = lane; s < slots; s += SERIES_THREADS) {
         double sum = s_acc[s];
-        for (int c = 1; c < stripes; ++c) sum += s_acc[c * slots + s];
+        for (int c = 1; c < stripes; ++c) sum += s_acc[c * SS + s];
         dst[s] = sum;
     }
 }
