@@ -37,12 +37,20 @@ constexpr int GRIDROWS_MAX_SLOTS = 512;
 constexpr int GRIDROWS_RING = 128;  // items: a push pass adds at most 64 to at most 63 left over
 constexpr int GRIDROWS_RING_BYTES = VAG_ROWS_RING ? GRIDROWS_RING * (2 * 16 + 4) : 0;  // {x0, x1}, {x2, x3}, time index
 
-__host__ __device__ inline int grid_rows_stripes(int slots) { return slots <= 128 ? 4 : 2; }
-__host__ __device__ inline size_t grid_rows_lds_bytes(int slots) {
-    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS +
-                             (size_t)GRIDROWS_WAVES * grid_rows_stripes(slots) * rows_acc_stride(slots, grid_rows_stripes(slots))) +
+// copies of a wavefront's sums (vag_fit_rows.h: why, and how they are laid out): four for short requests, else three where three
+// workgroups per CU still fit the 160 KB with them (C5's 4 x 100 slots: 24.3 against 25.2 ms per tabulated-SSC pass with two), else two
+__host__ __device__ inline size_t grid_rows_lds_bytes_with(int slots, int stripes) {
+    return sizeof(double) * (SP_LDS_DOUBLES + GRIDROWS_MAX_NT + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * rows_acc_stride(slots, stripes)) +
            (size_t)GRIDROWS_WAVES * GRIDROWS_RING_BYTES;
 }
+__host__ __device__ inline int grid_rows_stripes(int slots) {
+#ifdef VAG_GRIDROWS_STRIPES_BIG
+    return slots <= 128 ? 4 : VAG_GRIDROWS_STRIPES_BIG;
+#else
+    return slots <= 128 ? 4 : (3 * grid_rows_lds_bytes_with(slots, 3) <= 160 * 1024 ? 3 : 2);
+#endif
+}
+__host__ __device__ inline size_t grid_rows_lds_bytes(int slots) { return grid_rows_lds_bytes_with(slots, grid_rows_stripes(slots)); }
 
 // a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
 // 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
