@@ -351,6 +351,7 @@ struct vag_ctx {
     bool layout_large = false;  // vag_grid_kernel's layout of the batch at hand
     DevBuf d_rowgeo;            // row-geometry records for the flux grid kernel, written by the grid kernel
     bool plan_counter_ready = false;
+    int n_cus = 256;              // compute units of the device (persistent launches size themselves by it)
     // named-stage profiler (vag_ctx_profile): spans of (stage id, begin event, end event) recorded during a call
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -465,6 +466,7 @@ static int ctx_init(vag_ctx* c) {
     c->stream = c->own_stream;
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventCreateWithFlags(&c->ev_handoff, hipEventDisableTiming));
+    HIPCHK(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, c->device));
     // allow the flux kernels the full 160 KiB LDS of a gfx950 CU
     for (const void* fn : {reinterpret_cast<const void*>(vag_flux_grid_kernel<false, FLUX_SYN>),
                            reinterpret_cast<const void*>(vag_flux_grid_kernel<true, FLUX_SYN>),
@@ -808,7 +810,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                c->d_rep_start.ensure(sizeof(int) * (size_t)nb * ts) || c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(large));
     };
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
-    if (c->d_row_off.ensure(sizeof(int) * (size_t)(nb + 1))) return VAG_E_HIP;
+    if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
     if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
 
@@ -1013,6 +1015,10 @@ static int flux_ks(const vag_ctx* c) {
     if (const char* e = std::getenv("VAG_FLUX_K_CAP")) cap = std::max(4, std::atoi(e));
     return std::max(2, std::min(c->max_k, cap));
 }
+
+// the work-item counter of a persistent launch (SeriesArgs::work), in the zeroed words behind the device plan: the kernel behind every
+// such launch puts it back to zero, and kernels of one context run on one stream
+static int* work_counters(vag_ctx* c) { return reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)) + 4; }
 
 // dynamic LDS of vag_flux_grid_kernel (layout at the top of the kernel)
 static size_t flux_grid_lds_bytes(int mode, int ks, int nt, int nnu) {
@@ -1527,9 +1533,11 @@ int grid_request_chunked(vag_ctx* c, const vag_model_params* d_params, int nb, i
 __global__ void __launch_bounds__(256)
 vag_series_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                          const double* __restrict__ partial, int max_blocks, int pairs_per_block, int n,
-                         double* __restrict__ out, int parts /* partial sums per block of rows */) {
+                         double* __restrict__ out, int parts /* partial sums per block of rows */,
+                         int* __restrict__ work_counter = nullptr /* of the persistent launch before this one: back to zero */) {
     __shared__ double s_part[4][64];
     const int m = blockIdx.y;
+    if (work_counter && blockIdx.x == 0 && m == 0 && threadIdx.x == 0) *work_counter = 0;
     const VagGridMeta M = meta[m];
     const vag_model_params P = params[m];
     const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block * parts : 0;
@@ -1613,11 +1621,15 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             // wavefronts per block of 64 rows: four while the batch leaves the GPU room (each walks a quarter of the lattice),
             // one when there are blocks enough to fill it (one prologue per block).  The partial sums are the same either way.
             const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
-            int wpb = blocks <= 2048 ? 4 : (blocks <= 4608 ? 2 : 1);  // measured: 1.6 k blocks 0.128 / 0.17 ms (4 / 1), 3.1 k 0.215 / 0.233 (2 / 1), 6.2 k 0.357 / 0.342
+            int wpb = blocks <= 1024 ? 4 : (blocks <= 4608 ? 2 : 1);  // measured (persistent launch, 4 / 2 / 1): 0.8 k blocks 0.072 / 0.088 / 0.140 ms, 1.6 k 0.115 / 0.105 / 0.142, 6.2 k 0.333 / 0.267 / 0.269
             if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
             a.grid_nt = wpb;
-            const int wgs = (max_blocks * wpb + FITROWS_WAVES - 1) / FITROWS_WAVES;
-            const dim3 g(wgs, nb), b(SERIES_THREADS * FITROWS_WAVES);
+            a.nb = nb;
+            a.work = work_counters(c);
+            // persistent workgroups: as many as the GPU holds (three per CU), fewer when there are fewer items (blocks x wavefronts per block)
+            const long long items = (blocks + nb) * wpb;  // (total_pairs may be the previous call's: every model can own one block more)
+            const int wgs = (int)std::max<long long>(1, std::min<long long>((items + FITROWS_WAVES - 1) / FITROWS_WAVES, 3LL * c->n_cus));
+            const dim3 g(wgs), b(SERIES_THREADS * FITROWS_WAVES);
             const size_t lds = fit_rows_lds_bytes(n);
             const bool spread = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
             a.cellgeo = c->d_cellgeo.as<double>();
@@ -1643,7 +1655,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         }
         HIPCHK(hipEventRecord(c->ev[4], st));
         hipLaunchKernelGGL(vag_series_reduce_kernel, dim3((n + 63) / 64, nb), dim3(256), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
-                           c->d_partial.as<double>(), max_blocks * FITROWS_SEGS, FITROWS_ROWS, n, d_out, FITROWS_SEGS);
+                           c->d_partial.as<double>(), max_blocks * FITROWS_SEGS, FITROWS_ROWS, n, d_out, FITROWS_SEGS, work_counters(c));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev[5], st));
         return VAG_OK;

@@ -67,55 +67,47 @@ __host__ __device__ inline int rows_lane_row(int lane) {
 #endif
 }
 
-// bytes of LDS of one workgroup: tables, the points' times and bands, per wavefront [stripes][stride] sums
+// bytes of LDS of one workgroup: tables, the points' times and bands, per wavefront the bands' frequencies and [stripes][stride] sums
 __host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
     const int np = fit_rows_npad(n), st = fit_rows_stripes(n);
-    return sizeof(double) * (SP_LDS_DOUBLES + np + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * st * rows_acc_stride(np, st)) + sizeof(int) * np;
+    return sizeof(double) * (SP_LDS_DOUBLES + np + FITROWS_WAVES * SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * st * rows_acc_stride(np, st)) + sizeof(int) * np;
 }
 
 
 #ifndef VAG_ROWS_MIN_WG
 #define VAG_ROWS_MIN_WG 3  // workgroups per CU the row-per-lane kernels are compiled for (developer builds: 4 = 128 VGPRs)
 #endif
-// a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
-// registers per node.
-// SPREAD: a spreading jet's polar angle evolves along the lattice, so the viewing cosine and the solid angle are per node
-// (calc_t_obs + calc_solid_angle, observer.cpp:51-141; a.cellgeo holds cos theta, sin theta, log2|dcos| per cell).
-template <int MODE, int NBMAX, bool SPREAD = false>
-__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, VAG_ROWS_MIN_WG)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
-vag_flux_fit_rows_kernel(SeriesArgs a) {
-    const int m = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* s_sp = lds;
+// LDS of a workgroup as the items see it (the tables and the data points are the launch's, the rest is the wavefront's own)
+struct FitRowsLds {
+    const double* s_sp;   // softplus + log2 tables
+    const double* s_tp;   // [NP] log2 of the data points' times, ascending; +inf beyond n
+    const int* s_band_of; // [NP] band of each point
+    double* s_band;       // this wavefront's [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands for the model at hand
+    double* s_acc;        // this wavefront's per-point sums [stripe][NS]
+};
+
+// One work item of the fit: segment(s) wseg (of W) of the lattice walk of block vb (64 rows) of model m, by one wavefront.
+template <int MODE, int NBMAX, bool SPREAD>
+VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int vb, int wseg, int W, int lane) {
     const VagGridMeta* Mp = a.meta + m;
-    const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
-    const int W = a.grid_nt, blocks_per_wg = FITROWS_WAVES / W;
-    if ((long long)blockIdx.x * blocks_per_wg * FITROWS_ROWS >= n_pairs) return;  // nothing of this model here (or model not evaluated)
+    const int n_pairs = Mp->n_theta * Mp->n_phi_eff;
     const int n = a.n, NB = a.n_bands, NP = fit_rows_npad(n), stripes = fit_rows_stripes(n), NS = rows_acc_stride(NP, stripes);
-    double* s_tp = s_sp + SP_LDS_DOUBLES;             // [NP] log2 of the data points' times, ascending; +inf beyond n
-    double* s_band = s_tp + NP;                       // [SERIES_MAX_BANDS] log2 nu (1 + z) of the fit's bands
-    double* s_acc = s_band + SERIES_MAX_BANDS + (size_t)wave * stripes * NS;  // this wavefront's per-point sums [stripe][NS]
-    int* s_band_of = (int*)(s_band + SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * stripes * NS);  // [NP] band of each point
-    const double lg2_1pz = Mp->lg2_1pz;
-    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
-    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-        s_tp[i] = i < n ? a.lg2_t_obs[i] : INFINITY;
-        s_band_of[i] = i < n ? a.band_idx[i] : 0;
-    }
-    if (threadIdx.x < NB) s_band[threadIdx.x] = a.lg2_nu_obs[a.band_first[threadIdx.x]] + lg2_1pz;
-    for (int i = lane; i < stripes * NS; i += SERIES_THREADS) s_acc[i] = 0;
+    const double* s_sp = L.s_sp;
+    const double* s_tp = L.s_tp;
+    const int* s_band_of = L.s_band_of;
+    double* s_band = L.s_band;
+    double* s_acc = L.s_acc;
     double* my_acc = s_acc + (lane % stripes) * NS;  // the copy this lane adds to
-    __syncthreads();  // the only workgroup-wide barrier
+    wave_sync();  // (the previous item's reads of s_band are done)
+    if (lane < NB) s_band[lane] = a.lg2_nu_obs[a.band_first[lane]] + Mp->lg2_1pz;
+    wave_sync();
     // The lattice of a block is cut into FITROWS_SEGS segments, each with its own partial sum: the intervals between nodes are
     // independent, a segment starts from nothing but its first node.  W wavefronts share the block and take FITROWS_SEGS / W
     // consecutive segments each; one that walks several in a row flushes its accumulators at the cuts, and its running state
     // at a cut (cursor, the cut node's boundary values) is bit for bit what a wavefront starting there computes.  So the
     // partial sums do not depend on W: the host picks W = 4 for small batches (the longest sequential chain of the pass is a
     // quarter as long) and W = 1 for large ones (one prologue per block instead of four).
-    const int vb = blockIdx.x * blocks_per_wg + wave / W, wseg = wave % W;
     const int p0 = vb * FITROWS_ROWS;
-    if (p0 >= n_pairs) return;
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     const int K = Mp->n_t, n_phi_eff = Mp->n_phi_eff;
     const double one_plus_z = 1 + a.params[m].z;
@@ -325,6 +317,62 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
         printf("fit rows wave 0: K %d  cycles: prologue %lld  nodes %lld  scan %lld  boundary %lld (%d steps)  interp %lld\n", K, c_pro, c_node,
                c_scan, c_bnd, n_bnd, c_int);
 #endif
+}
+
+// Persistent workgroups: the launch fills the GPU once (or holds as many wavefronts as there are items, if fewer) and every wavefront
+// takes items -- (model, block of 64 rows, lattice segment) in the batch's order, most expensive models first -- until none is left.  A grid of one workgroup per four blocks had a workgroup's four wavefront slots wait for a successor every ~100 us of work
+// (2.1-2.4 of 3 wavefronts per SIMD resident, `profiles/debug/uniform_pmc.sh`), and launched max-blocks-of-any-model workgroups for every
+// model (two thirds of them empty on a ragged walker batch).  Which wavefront serves an item does not enter its partial sum.
+// a.grid_nt carries W = wavefronts per block of 64 rows (1, 2 or 4), the launch's choice.  NBMAX = 4 or 8 bounds the bands held in
+// registers per node.
+// SPREAD: a spreading jet's polar angle evolves along the lattice, so the viewing cosine and the solid angle are per node
+// (calc_t_obs + calc_solid_angle, observer.cpp:51-141; a.cellgeo holds cos theta, sin theta, log2|dcos| per cell).
+template <int MODE, int NBMAX, bool SPREAD = false>
+__global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, VAG_ROWS_MIN_WG)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
+vag_flux_fit_rows_kernel(SeriesArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;
+    const int n = a.n, NP = fit_rows_npad(n), stripes = fit_rows_stripes(n), NS = rows_acc_stride(NP, stripes);
+    double* s_tp = s_sp + SP_LDS_DOUBLES;
+    double* s_band = s_tp + NP;  // [FITROWS_WAVES][SERIES_MAX_BANDS]
+    double* s_acc = s_band + FITROWS_WAVES * SERIES_MAX_BANDS + (size_t)wave * stripes * NS;
+    int* s_band_of = (int*)(s_band + FITROWS_WAVES * SERIES_MAX_BANDS + (size_t)FITROWS_WAVES * stripes * NS);
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        s_tp[i] = i < n ? a.lg2_t_obs[i] : INFINITY;
+        s_band_of[i] = i < n ? a.band_idx[i] : 0;
+    }
+    for (int i = lane; i < stripes * NS; i += SERIES_THREADS) s_acc[i] = 0;
+    __syncthreads();  // the only workgroup-wide barrier
+    const FitRowsLds L{s_sp, s_tp, s_band_of, s_band + wave * SERIES_MAX_BANDS, s_acc};
+    const int W = a.grid_nt, nb = a.nb;
+    const int* __restrict__ blk_off = a.lay.row_off + nb + 1;  // [nb + 1] first block of every model (vag_grid_kernel's plan scan)
+    const int total_items = blk_off[nb] * W;
+    int m_lo = 0;  // a wavefront's items ascend
+    // the first item of a wavefront is its own number, the later ones come from the counter (one device-wide atomic per item: ~7 ns
+    // each on one address, so the 3072 simultaneous first fetches of a launch were 25 us of a 128-walker call); a launch with no more
+    // items than wavefronts never touches it
+    const int n_waves = (int)gridDim.x * FITROWS_WAVES;
+    int item = (int)blockIdx.x * FITROWS_WAVES + wave;
+    for (;; ) {
+        if (item >= total_items) break;
+        const int blk = item / W, wseg = item - blk * W;
+        int lo = m_lo, hi = nb;  // blk_off[lo] <= blk < blk_off[hi]: the model is the last one that starts at or before the block
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (blk_off[mid] <= blk)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        m_lo = lo;
+        fit_rows_item<MODE, NBMAX, SPREAD>(a, L, lo, blk - blk_off[lo], wseg, W, lane);
+        if (total_items <= n_waves) break;
+        if (lane == 0) item = n_waves + __hip_atomic_fetch_add(a.work, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+    }
+    // (the counter is put back to zero by the reduction kernel that follows every launch of this one)
 }
 
 }  // namespace vag

@@ -303,7 +303,8 @@ VAG_DEV void invert_cdf(const SH& sh, int num, bool midpoint, double* out) {
 }
 
 // Compact layout of a batch from its grid results, by ONE wavefront (the last one of vag_grid_kernel to finish): exclusive
-// scans of rows (n_reps) and cells (n_reps x n_t) over the models -> row_off / cell_off [nb + 1], and the totals / maxima /
+// scans of rows (n_reps) and cells (n_reps x n_t) over the models -> row_off / cell_off [nb + 1], of the blocks of 64 (theta, phi)
+// rows the row-per-lane flux kernels deal out (row_off[nb + 1 ...]: a second [nb + 1] array behind the first), and the totals / maxima /
 // flag summary the host plans the later stages with (VagDevPlan).  When a total exceeds the capacity the host sized its
 // buffers and launches for (it plans ahead from the previous call of the same batch size instead of waiting for this
 // summary), every model is marked VAG_E_CAPACITY and the offsets are zeroed: the later kernels find no work and write
@@ -315,7 +316,7 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
     const int t = threadIdx.x;
     const int per = (nb + WAVE - 1) / WAVE, m0 = min(nb, t * per), m1 = min(nb, m0 + per);
     long long cells = 0, pairs = 0, eat = 0;
-    int rows = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_inv = 0, n_cap = 0, first = -1, mixed = 0, dyn = 0;
+    int rows = 0, blks = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_inv = 0, n_cap = 0, first = -1, mixed = 0, dyn = 0;
     for (int m = m0; m < m1; ++m) {
         const VagGridMeta M = meta[m];
         cost[m] = M.status == 0 ? (float)M.n_theta * (float)M.n_phi_eff * (float)M.n_t : 0.0f;
@@ -326,6 +327,7 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
             const int pr = M.n_theta * M.n_phi_eff;
             max_pairs = max(max_pairs, pr);
             pairs += pr;
+            blks += (pr + 63) >> 6;
             eat += (long long)pr * M.n_t;
             dyn |= M.dyn_class;
             if (first < 0) first = M.flags;
@@ -338,18 +340,19 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
         }
     }
     // inclusive scans of rows / cells over the lanes, totals and summaries by butterflies
-    int r_inc = rows;
+    int r_inc = rows, b_inc = blks;
     long long c_inc = cells;
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {
-        const int ro = __shfl_up(r_inc, off, WAVE);
+        const int ro = __shfl_up(r_inc, off, WAVE), bo = __shfl_up(b_inc, off, WAVE);
         const long long co = __shfl_up(c_inc, off, WAVE);
         if (t >= off) {
             r_inc += ro;
+            b_inc += bo;
             c_inc += co;
         }
     }
-    const int tot_rows = __shfl(r_inc, WAVE - 1, WAVE);
+    const int tot_rows = __shfl(r_inc, WAVE - 1, WAVE), tot_blks = __shfl(b_inc, WAVE - 1, WAVE);
     const long long tot_cells = __shfl(c_inc, WAVE - 1, WAVE);
     int first_all = first < 0 ? INT32_MAX : t;  // lane of the first valid model
 #pragma unroll
@@ -387,20 +390,24 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
         __hip_atomic_store(&host_plan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();  // push the number itself out of the L2: nothing else in this kernel would
     }
-    int r = r_inc - rows;  // exclusive prefixes of this lane's chunk
+    int r = r_inc - rows, b = b_inc - blks;  // exclusive prefixes of this lane's chunk
     long long c = c_inc - cells;
+    int* __restrict__ blk_off = row_off + nb + 1;
     for (int m = m0; m < m1; ++m) {
         row_off[m] = overflow ? 0 : r;
+        blk_off[m] = overflow ? 0 : b;
         cell_off[m] = overflow ? 0 : c;
         const VagGridMeta M = meta[m];
         if (M.status == 0) {
             r += M.n_reps;
+            b += (M.n_theta * M.n_phi_eff + 63) >> 6;
             c += (long long)M.n_reps * M.n_t;
             if (overflow) meta[m].status = VAG_E_CAPACITY;
         }
     }
     if (t == 0) {
         row_off[nb] = overflow ? 0 : tot_rows;
+        blk_off[nb] = overflow ? 0 : tot_blks;
         cell_off[nb] = overflow ? 0 : tot_cells;
     }
 }

@@ -1358,6 +1358,10 @@ struct SeriesArgs {
     // A small (nu, t) GRID served by this kernel (grid_nt > 0): point s = l * grid_nt + idx observes frequency lg2_nu_obs[l] at
     // time lg2_t_obs[idx]; n = n_bands * grid_nt; band_idx / band_first are not read.
     int grid_nt;
+    // persistent launches (vag_flux_fit_rows_kernel): the batch size and the work-item counter in device memory, zero between launches
+    // (the reduction kernel behind the launch resets it); the items' model offsets are lay.row_off[nb + 1 ...] (the grid kernel's plan scan)
+    int nb;
+    int* work;
 };
 
 // Series kernels: k with s_t[k] < t <= s_t[k+1] (t == s_t[0] -> 0), grown outwards from `hint` (the interval of the same
