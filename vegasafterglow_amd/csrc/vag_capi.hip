@@ -1035,14 +1035,15 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
 // fixed-order sum of a flux pass's workgroup partials + normalisation: plain grids through the grouped kernel, band-weighted
 // requests through the serial one
 static void launch_reduce(hipStream_t st, const vag_model_params* d_params, const VagGridMeta* meta, const double* partial, int max_blocks,
-                          int ppb, int nt, int nnu, const double* d_bandw, double* d_out, int nb) {
+                          int ppb, int nt, int nnu, const double* d_bandw, double* d_out, int nb,
+                          int* work_counter = nullptr /* of a persistent flux launch before this one: the reduction puts it back to zero */) {
     if (d_bandw) {
         hipLaunchKernelGGL(vag_reduce_kernel, dim3((nt + 255) / 256, nb), dim3(256), 0, st, d_params, meta, partial, max_blocks, ppb, nt, nnu,
-                           d_bandw, d_out);
+                           d_bandw, d_out, work_counter);
     } else {
         const int slots = nt * nnu;
         hipLaunchKernelGGL(vag_reduce_grid_kernel, dim3((slots + REDUCE_SLOTS - 1) / REDUCE_SLOTS, nb), dim3(REDUCE_GROUPS * REDUCE_SLOTS), 0, st,
-                           d_params, meta, partial, max_blocks, ppb, slots, d_out);
+                           d_params, meta, partial, max_blocks, ppb, slots, d_out, work_counter);
     }
 }
 
@@ -1096,6 +1097,9 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
             c->plan.interps += c->total_pairs * (long long)nt * nnu;
             c->plan.flux_blocks = max_blocks * nb;
             c->plan.pairs_per_block = FITROWS_ROWS;
+            // (Measured and rejected, r04: this kernel as persistent workgroups like vag_flux_fit_rows_kernel.  Its launches have no empty
+            // workgroups and its wavefronts live ~0.5 ms, so there was 9 % to gain at most -- and the loop around the items costs the
+            // synchrotron instantiation, which sits at 167 of 168 VGPRs, 120-170 B of scratch per lane: 61 against 47 ms per 1024 C5 members.)
             const dim3 g((max_blocks + GRIDROWS_WAVES - 1) / GRIDROWS_WAVES, nb), b(SERIES_THREADS * GRIDROWS_WAVES);
             const size_t lds = grid_rows_lds_bytes(slots);
             if (mode == FLUX_SYN_IC)

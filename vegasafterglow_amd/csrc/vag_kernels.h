@@ -1245,8 +1245,10 @@ vag_flux_grid_kernel(FluxArgs a) {
 __global__ void __launch_bounds__(256)
 vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                   const double* __restrict__ partial, int max_blocks, int pairs_per_block, int nt, int nnu,
-                  const double* __restrict__ band_w /* NULL or [nnu] */, double* __restrict__ out) {
+                  const double* __restrict__ band_w /* NULL or [nnu] */, double* __restrict__ out,
+                  int* __restrict__ work_counter = nullptr /* of a persistent launch before this one: back to zero */) {
     const int m = blockIdx.y;
+    if (work_counter && blockIdx.x == 0 && m == 0 && threadIdx.x == 0) *work_counter = 0;
     const VagGridMeta M = meta[m];
     const vag_model_params P = params[m];
     const int slots = nt * nnu;
@@ -1281,8 +1283,10 @@ vag_reduce_kernel(const vag_model_params* __restrict__ params, const VagGridMeta
 constexpr int REDUCE_GROUPS = 8, REDUCE_SLOTS = 64;
 __global__ void __launch_bounds__(REDUCE_GROUPS * REDUCE_SLOTS)
 vag_reduce_grid_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
-                       const double* __restrict__ partial, int max_blocks, int pairs_per_block, int slots, double* __restrict__ out) {
+                       const double* __restrict__ partial, int max_blocks, int pairs_per_block, int slots, double* __restrict__ out,
+                       int* __restrict__ work_counter = nullptr /* of a persistent launch before this one: back to zero */) {
     const int m = blockIdx.y;
+    if (work_counter && blockIdx.x == 0 && m == 0 && threadIdx.x == 0) *work_counter = 0;
     const VagGridMeta M = meta[m];
     const int nblk = (M.status == 0) ? (M.n_theta * M.n_phi_eff + pairs_per_block - 1) / pairs_per_block : 0;
     const int sx = threadIdx.x % REDUCE_SLOTS, g = threadIdx.x / REDUCE_SLOTS;
