@@ -306,7 +306,7 @@ struct vag_ctx {
     DevBuf d_mix_flags, d_mix_perm, d_mix_params, d_mix_out;
     bool order_next = false, order_active = false;  // the next / the last model-stage run is in evaluation-slot order
     const int* last_order = nullptr;                // ... and the order it used
-    bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > 320 theta / > 640 phi nodes)
+    bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > VAG_GRID_THETA theta / > VAG_GRID_PHI phi nodes)
     int grid_large_idle = 0;  // consecutive batches that would have fitted the small one
     std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
     DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
@@ -800,8 +800,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     hipStream_t st = c->stream;
     if (c->d_meta.ensure(sizeof(VagGridMeta) * nb)) return VAG_E_HIP;
     if (c->d_cost_f.ensure(sizeof(float) * nb)) return VAG_E_HIP;
-    // per-model angular arrays at the stride of the layout the grid kernel runs with (VagGridMeta::th_stride / ph_stride): 35 KB per
-    // model for default-resolution batches (320 theta / 640 phi slots), 140 KB when a batch needed the large layout
+    // per-model angular arrays at the stride of the layout the grid kernel runs with (VagGridMeta::th_stride / ph_stride): 17 KB per
+    // model for default-resolution batches (256 theta / 208 phi slots), 140 KB when a batch needed the large layout
     auto ensure_angular = [&](bool large) -> bool {
         const size_t ts = large ? VAG_MAX_THETA : VAG_GRID_THETA, ps = large ? VAG_MAX_PHI : VAG_GRID_PHI;
         return c->d_phi.ensure(sizeof(double) * (size_t)nb * ps) || c->d_theta.ensure(sizeof(double) * (size_t)nb * ts) ||

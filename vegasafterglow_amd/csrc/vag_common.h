@@ -8,8 +8,9 @@
 // the actual sizes at run time; these bound them).
 #define VAG_MAX_THETA 1280  // theta nodes per model (the large layout of the grid kernel; VagGridMeta::th_stride is the HBM stride of a batch)
 #define VAG_MAX_PHI 2560    // phi nodes per model
-#define VAG_GRID_THETA 320  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
-#define VAG_GRID_PHI 640    //   with the large layout (vag_grid_kernel<true>)
+#define VAG_GRID_THETA 256  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
+#define VAG_GRID_PHI 208    //   with the large layout (vag_grid_kernel<true>).  256 / 208 is 20 420 B of LDS: eight models per CU, as many
+                            //   as the kernel's 206 VGPRs allow (320 / 640 was 27 KB: five; the configs' ensembles reach 177 / 191)
 #define VAG_ROWGEO_HDR 4    // doubles ahead of a model's row-geometry records (vag_grid_kernel.h writes them, the flux grid kernel reads them)
 #define VAG_MAX_TIME 8192   // time-lattice nodes per row (the flux kernels stage at most 512 at a time and take longer lattices in pieces)
 #define VAG_MAX_NU 64       // frequencies per grid call

@@ -48,20 +48,19 @@ VAG_DEV double linspace_at(double start, double stop, int n, int i) {
     return (n > 1 && i == n - 1) ? stop : start + step * (double)i;
 }
 
-// LDS of one wavefront (= one model).  Arrays with disjoint lifetimes share memory (25.6 KB instead of 38.9 KB: six
-// resident models per CU instead of four when a batch is larger than the chip):
+// LDS of one wavefront (= one model).  Arrays with disjoint lifetimes share memory (what decides how many models a CU holds when a
+// batch is larger than the chip):
 //   profile scans + theta quantiles (find_jet_jumps ... merge_grids)   |  phi-weight constants (adaptive_phi_grid)
 //   CDF samples (both inverse_CFD_sampling calls)                       |  t_dec per row (build_time_grid, after the phi grid)
-// The wavefront's scratch arrays.  Two sizes exist: the angular grids of every default-resolution model fit (320, 640) -- 32 KB,
-// several models resident per CU --, and a batch in which some model asks for more is laid out again with (MAXTH,
-// MAXPH) -- 100 KB, one model per CU.  The arrays in HBM are strided by the large size either way.
+// The wavefront's scratch arrays.  Two sizes exist: the angular grids of every default-resolution model fit (VAG_GRID_THETA,
+// VAG_GRID_PHI) = (256, 208) -- 20 KB, eight models resident per CU --, and a batch in which some model asks for more is laid out
+// again with (VAG_MAX_THETA, VAG_MAX_PHI) -- 97 KB, one model per CU.  The arrays in HBM are strided by the layout in use.
 template <int MAXTH, int MAXPH>
 struct GridSharedT {
     static constexpr int max_theta = MAXTH, max_phi = MAXPH;
     union {
         struct {
-            double scan_th[N_SCAN + 8];  // scan abscissae (find_theta_range accumulates them sequentially)
-            double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae
+            double scan_g[N_SCAN + 8];   // Gamma0 at the scan abscissae (find_jet_jumps)
             double base[MAXTH];  // theta quantiles before the jump nodes are merged in
         };
         struct {  // per-theta constants of the phi weight (adaptive_phi_grid, grid-refinement.h:296-331)
