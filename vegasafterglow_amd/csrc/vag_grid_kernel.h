@@ -1092,7 +1092,8 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (threadIdx.x == 0) *done_counter = 0;
+    if (threadIdx.x == 0) *done_counter = 0, done_counter[4] = 0;  // (+4: the work-item counter of the persistent flux launches -- a call that
+                                                                    //  died half-way must not leave its count to the next one)
     plan_scan_wave(meta, nb, row_off, cell_off, plan, host_plan, seq, cap_rows, cap_cells, cap_k, cap_pairs, expect_flags, expect_dyn, cost);
 }
 
