@@ -316,26 +316,45 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
     const int per = (nb + WAVE - 1) / WAVE, m0 = min(nb, t * per), m1 = min(nb, m0 + per);
     long long cells = 0, pairs = 0, eat = 0;
     int rows = 0, blks = 0, max_k = 2, max_pairs = 0, n_ok = 0, n_inv = 0, n_cap = 0, first = -1, mixed = 0, dyn = 0;
-    for (int m = m0; m < m1; ++m) {
-        const VagGridMeta M = meta[m];
-        cost[m] = M.status == 0 ? (float)M.n_theta * (float)M.n_phi_eff * (float)M.n_t : 0.0f;
-        if (M.status == 0) {
-            rows += M.n_reps;
-            cells += (long long)M.n_reps * M.n_t;
-            max_k = max(max_k, M.n_t);
-            const int pr = M.n_theta * M.n_phi_eff;
-            max_pairs = max(max_pairs, pr);
-            pairs += pr;
-            blks += (pr + 63) >> 6;
-            eat += (long long)pr * M.n_t;
-            dyn |= M.dyn_class;
-            if (first < 0) first = M.flags;
-            mixed |= (M.flags != first) ? 1 : 0;
-            ++n_ok;
-        } else if (M.status == VAG_E_CAPACITY) {
-            ++n_cap;
-        } else {
-            ++n_inv;
+    // a lane's models four at a time: their records are requested together (one trip to memory per four models instead of one per
+    // model -- this wavefront runs after every other one of the launch has left, so its chain of trips is pure latency of the call:
+    // ~1 us per model and lane, i.e. 16 / 128 trips per lane at 1024 / 8192 models)
+    struct MetaHead {  // the leading members of VagGridMeta the scan reads
+        int32_t status, n_phi, n_theta, n_t, n_reps, symmetry, phi_mirrored, n_phi_eff, t_num_tot, has_early, flags, t_num_base, dyn_class;
+    };
+    static_assert(offsetof(VagGridMeta, dyn_class) == offsetof(MetaHead, dyn_class), "MetaHead mirrors the head of VagGridMeta");
+    constexpr int SCAN_U = 4;
+    auto load_heads = [&](int m, MetaHead (&H)[SCAN_U]) {
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) H[u] = *reinterpret_cast<const MetaHead*>(meta + min(m + u, nb - 1));
+    };
+    for (int mb = m0; mb < m1; mb += SCAN_U) {
+        MetaHead H[SCAN_U];
+        load_heads(mb, H);
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) {
+            const int m = mb + u;
+            if (m >= m1) break;
+            const MetaHead& M = H[u];
+            cost[m] = M.status == 0 ? (float)M.n_theta * (float)M.n_phi_eff * (float)M.n_t : 0.0f;
+            if (M.status == 0) {
+                rows += M.n_reps;
+                cells += (long long)M.n_reps * M.n_t;
+                max_k = max(max_k, M.n_t);
+                const int pr = M.n_theta * M.n_phi_eff;
+                max_pairs = max(max_pairs, pr);
+                pairs += pr;
+                blks += (pr + 63) >> 6;
+                eat += (long long)pr * M.n_t;
+                dyn |= M.dyn_class;
+                if (first < 0) first = M.flags;
+                mixed |= (M.flags != first) ? 1 : 0;
+                ++n_ok;
+            } else if (M.status == VAG_E_CAPACITY) {
+                ++n_cap;
+            } else {
+                ++n_inv;
+            }
         }
     }
     // inclusive scans of rows / cells over the lanes, totals and summaries by butterflies
@@ -392,16 +411,23 @@ VAG_DEV void plan_scan_wave(VagGridMeta* meta, int nb, int* __restrict__ row_off
     int r = r_inc - rows, b = b_inc - blks;  // exclusive prefixes of this lane's chunk
     long long c = c_inc - cells;
     int* __restrict__ blk_off = row_off + nb + 1;
-    for (int m = m0; m < m1; ++m) {
-        row_off[m] = overflow ? 0 : r;
-        blk_off[m] = overflow ? 0 : b;
-        cell_off[m] = overflow ? 0 : c;
-        const VagGridMeta M = meta[m];
-        if (M.status == 0) {
-            r += M.n_reps;
-            b += (M.n_theta * M.n_phi_eff + 63) >> 6;
-            c += (long long)M.n_reps * M.n_t;
-            if (overflow) meta[m].status = VAG_E_CAPACITY;
+    for (int mb = m0; mb < m1; mb += SCAN_U) {
+        MetaHead H[SCAN_U];
+        load_heads(mb, H);
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) {
+            const int m = mb + u;
+            if (m >= m1) break;
+            const MetaHead& M = H[u];
+            row_off[m] = overflow ? 0 : r;
+            blk_off[m] = overflow ? 0 : b;
+            cell_off[m] = overflow ? 0 : c;
+            if (M.status == 0) {
+                r += M.n_reps;
+                b += (M.n_theta * M.n_phi_eff + 63) >> 6;
+                c += (long long)M.n_reps * M.n_t;
+                if (overflow) meta[m].status = VAG_E_CAPACITY;
+            }
         }
     }
     if (t == 0) {
