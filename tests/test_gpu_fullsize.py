@@ -117,6 +117,25 @@ def test_fit_kernel_partial_sums_do_not_depend_on_the_launch_shape(eng, oracle):
     np.testing.assert_allclose(base[ok], other[ok], rtol=1e-13)
 
 
+def test_fit_kernel_items_beyond_the_first_come_from_the_counter_and_change_nothing(eng, oracle):
+    """The likelihood's flux pass is a persistent launch: at most three workgroups per CU, every wavefront takes (model, block of 64
+    rows, lattice segment) items -- its own number first, then from a device-wide counter -- until none is left.  4096 walkers are
+    ~50 k items for ~3 k wavefronts, so nearly all of them come from the counter, in an order that differs from run to run: ln L must
+    not (an item's partial sum does not depend on who serves it), and must be the bits the same walkers get in a batch small enough
+    that no wavefront takes a second item.  The counter is back at zero after every call (a smaller batch right behind a larger one)."""
+    f, defs = _c4_fitter(oracle)
+    _, lo, hi = f.build_spec(defs)
+    samples = lo + (hi - lo) * np.random.default_rng(11).random((4096, len(defs)))
+    samples[100, 2] = -0.1  # a rejected walker in the middle: a model without blocks
+    big = f.loglike_batch(samples, defs)
+    assert big[100] == -np.inf and np.isfinite(np.delete(big, 100)).all()
+    for _ in range(2):
+        assert np.array_equal(f.loglike_batch(samples, defs), big)
+    for a, b in ((0, 64), (90, 130), (4000, 4096)):
+        assert np.array_equal(f.loglike_batch(samples[a:b], defs), big[a:b]), (a, b)
+    assert np.array_equal(f.loglike_batch(samples, defs), big)
+
+
 def test_fit_kernel_with_300_points_in_six_bands(eng, oracle):
     """A larger data set than the C4 mock (300 points, six bands: the eight-band instantiation, several slots per lane in the
     flush): the row-per-lane kernel against the row-per-wavefront kernel on 48 models, and against the oracle on two."""
