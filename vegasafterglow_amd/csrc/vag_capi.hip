@@ -1701,7 +1701,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         std::fprintf(stderr, "[vag] series launch: n=%d bands=%d max_k=%d rows/wave=%lld waves/wg=%d lds=%zu B grid=(%u,%u) wg/CU=%d\n", n,
                      n_bands, ks, ppb, waves, lds, sgrid.x, sgrid.y, occ);
     }
-    SeriesArgs a;
+    SeriesArgs a{};
     a.cellq = c->d_cellq.as<double>();
     a.ichdr = c->d_ichdr.as<double>();
     a.icpool = c->d_icpool.as<double>();
