@@ -923,6 +923,26 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     assert np.array_equal(band_f, band_t)
 
 
+def test_spreading_jet_whose_arrival_times_do_not_ascend_keeps_every_ssc_table(eng, oracle):
+    """A spreading jet's polar angle evolves along the lattice: a row that swings towards the line of sight reaches the observer EARLIER
+    from a later node, and the flux kernels place the observation window by counting nodes like the reference (observed_window,
+    observer.h:324-338) -- so which cells a request queries is not the range test of the non-spreading case.  Draw 13 of the random
+    sweep of spreading SSC jets (profiles/debug/prior_sweep_ssc.py, SWEEP_MODE=spread: a Gaussian jet in a dense wind seen from
+    outside the core) queried cells that test had skipped and failed loudly (status bit 4) in round 4; spreading jets keep every
+    table now.  Against the checker, both components."""
+    kw = dict(jet="GaussianJet", E_iso=5.439833428348364e+50, Gamma0=387.31924795103055, theta_c=0.16449474595309396,
+              theta_obs=0.4047201203232014, p=2.5802629713712104, eps_e=0.06605189948979821, eps_B=0.08481166776782337, ssc=True, kn=True,
+              medium="Wind", A_star=2.3251434233117934, spreading=True)  # (n_ism stays at make_params' 1.0: the draw's wind has that floor)
+    t, nu = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
+    prm = _abi.make_params(**kw)
+    got = gpu_components4(eng, [prm], t, nu)
+    want = oracle.flux_components(prm, t, nu)
+    for g, w in zip((got[0][0], got[1][0]), want):
+        assert np.all(np.isfinite(g)) and w.max() > 0
+        m = w > 1e-3 * w.max()
+        assert np.max(np.abs(g - w)[m] / w[m]) <= 2e-6  # (measured 1e-10)
+
+
 @pytest.mark.parametrize("case", ["grid", "series", "fused", "rows_batch"])
 def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     """The reference builds a cell's SSC spectrum on its first query (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620); the

@@ -321,6 +321,14 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
             for (long long q = cell_off[m] + lane; q < cell_off[m + 1]; q += 64) need[q] = 1;
         return;
     }
+    // A spreading jet keeps every table: its polar angle evolves along the lattice, so a row's observer times need not ascend with k
+    // (a row swinging towards the line of sight arrives EARLIER at a later node), while the flux kernels place the observation window
+    // by counting nodes as the reference does (observed_window, observer.h:324-338) -- the range test below would skip cells they
+    // then query (found by the random sweep of spreading SSC jets, profiles/r04_sweep_final.txt; the loud status bit 4 caught it).
+    if (need && cellgeo) {
+        for (long long q = cell_off[m] + lane; q < cell_off[m + 1]; q += 64) need[q] = 1;
+        need = nullptr;
+    }
     __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
     const vag_model_params P = params[m];
     const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
@@ -350,7 +358,7 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
         cphi_max = fmax(cphi_max, gph[ii]);
         cphi_min = fmin(cphi_min, gph[ii]);
     }
-    // Which cells does the flux integration query at all?  The reference builds a cell's spectrum on its first query
+    // Which cells does the flux integration query at all (non-spreading jets)?  The reference builds a cell's spectrum on its first query
     // (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620): a boundary value at node k is asked for only when the interval before
     // or after it holds a requested time for some (theta, phi) row of the cell (observer.h:355-445).  The test here is the range form
     // of that -- for some row, t_obs(k - 1) <= t_max and t_obs(k + 1) >= t_min of the request, with the rows' extreme viewing
@@ -375,30 +383,23 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
                     const double lg = -log2(G - u * (geo[nt + k] * gph[i] * sin_obs + geo[k] * cos_obs));
                     dmax_k = fmax(dmax_k, lg);
                     dmin_k = fmin(dmin_k, lg);
-                    if (need) {
-                        const double cv_p = geo[nt + k_prev] * gph[i] * sin_obs + geo[k_prev] * cos_obs;
-                        const double cv_n = geo[nt + k_next] * gph[i] * sin_obs + geo[k_next] * cos_obs;
-                        if (t_obs(par, k_prev, cv_p) <= t_req_max && t_obs(par, k_next, cv_n) >= t_req_min) need[cell_off[m] + rr * nt + k] = 1;
-                    }
                 }
         } else
         for (int j = 0; j < M.n_theta; ++j) {
             const double* par = cellpar + (cell_off[m] + (long long)rep_of[j] * nt) * VAG_NPAR;
             const double G = par[(long long)VP_GAMMA * nt + k], u = par[(long long)VP_U * nt + k];
             double cvmax = s_cvmax[j], cvmin = s_cvmin[j];
-            double cvmax_p = cvmax, cvmin_n = cvmin;  // the earliest-arriving row at node k - 1, the latest at node k + 1
             if (cellgeo) {  // theta evolves: the extrema over phi of cos_v = sin th cos phi sin_obs + cos th cos_obs per cell
                 const double* geo = cellgeo + (cell_off[m] + (long long)rep_of[j] * nt) * 3;
                 const double ct = geo[k], st = geo[nt + k];
                 cvmax = st * cphi_max * sin_obs + ct * cos_obs;
                 cvmin = st * cphi_min * sin_obs + ct * cos_obs;
-                cvmax_p = geo[nt + k_prev] * cphi_max * sin_obs + geo[k_prev] * cos_obs;
-                cvmin_n = geo[nt + k_next] * cphi_min * sin_obs + geo[k_next] * cos_obs;
             }
             dmax_k = fmax(dmax_k, -log2(G - u * cvmax));
             dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
-            // (several theta rows may share the cell: every writer stores the same 1)
-            if (need && t_obs(par, k_prev, cvmax_p) <= t_req_max && t_obs(par, k_next, cvmin_n) >= t_req_min)
+            // non-spreading rows: the earliest-arriving row at node k - 1 is the one with the largest viewing cosine, the latest at node
+            // k + 1 the one with the smallest (several theta rows may share the cell: every writer stores the same 1)
+            if (need && t_obs(par, k_prev, cvmax) <= t_req_max && t_obs(par, k_next, cvmin) >= t_req_min)
                 need[cell_off[m] + (long long)rep_of[j] * nt + k] = 1;
         }
         band[((size_t)m * 2 + 0) * band_stride + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
