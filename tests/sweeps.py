@@ -69,3 +69,29 @@ def nonaxi_spread_draws(n):
             kw.update(duration=10 ** rng.uniform(0.5, 2.5), rvs=dict(eps_e=10 ** rng.uniform(-2, -0.7), eps_B=10 ** rng.uniform(-3, -1), p=rng.uniform(2.1, 2.7)))
         prms.append(_abi.make_params(**kw))
     return prms
+
+
+def spread_ssc_draws(n):
+    """Axisymmetric jets with lateral spreading and SSC (Klein-Nishina) over all six jet profiles: the first n draws of
+    `SWEEP_MODE=spread python profiles/debug/prior_sweep_ssc.py n` (draw 13 of the 30-draw stream is the Gaussian jet in a dense wind
+    whose rows arrive earlier from later nodes: tests/test_gpu_parity.py pins it by name as well)."""
+    rng = np.random.default_rng(4242)
+    prms = []
+    for i in range(n):
+        jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]
+        kw = dict(jet=jet, E_iso=10 ** rng.uniform(50.5, 54), Gamma0=10 ** rng.uniform(1.5, 2.9), theta_c=rng.uniform(0.03, 0.3),
+                  theta_obs=rng.uniform(0, 0.5), p=rng.uniform(2.05, 2.9), eps_e=10 ** rng.uniform(-2.5, -0.5),
+                  eps_B=10 ** rng.uniform(-6, -1), ssc=True, kn=True)
+        if i % 2:
+            kw.update(medium="Wind", A_star=10 ** rng.uniform(-2, 0.5))
+        else:
+            kw.update(n_ism=10 ** rng.uniform(-3, 2))
+        if jet == "PowerLawJet":
+            kw.update(k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+        kw["spreading"] = True
+        kw["jet"] = ["TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing"][i % 6]
+        if kw["jet"] in ("TwoComponentJet", "StepPowerLawJet", "PowerLawWing"):
+            kw.update(theta_w=kw["theta_c"] * rng.uniform(1.5, 3.0), E_iso_w=kw["E_iso"] * 10 ** rng.uniform(-2, -0.5),
+                      Gamma0_w=max(20.0, kw["Gamma0"] * rng.uniform(0.1, 0.5)), k_e=rng.uniform(1.5, 3.0), k_g=rng.uniform(1.5, 3.0))
+        prms.append(_abi.make_params(**kw))
+    return prms

@@ -943,6 +943,26 @@ def test_spreading_jet_whose_arrival_times_do_not_ascend_keeps_every_ssc_table(e
         assert np.max(np.abs(g - w)[m] / w[m]) <= 2e-6  # (measured 1e-10)
 
 
+def test_rows_whose_state_goes_non_finite_keep_their_ssc_tables(eng, oracle):
+    """A Gaussian jet with a magnetar in a dense wind, seen almost on axis: the blast wave of the outermost theta row leaves the solver's
+    range and its state -- observer times included -- is NaN from node 13 on (in the reference as well: those intervals have no finite
+    slope and add nothing).  The flux kernels still visit the cells, because they count the nodes before the window like the reference;
+    the test that decides which cells get an SSC table compared NaN times and skipped them (draw 19 of the Thomson half of
+    `SWEEP_MODE=magnetar profiles/debug/prior_sweep_ssc.py 30`: status bit 4, loudly, in round 4).  It is written as "not excluded"
+    now.  Against the checker, both components."""
+    kw = dict(jet="GaussianJet", E_iso=4.460426649397416e+51, Gamma0=427.30930019677726, theta_c=0.07602877048106377,
+              theta_obs=0.015165954752948074, p=2.1137269063496933, eps_e=0.06343644661487786, eps_B=0.0024324771035933146, ssc=True,
+              kn=False, medium="Wind", A_star=1.865321778529919, magnetar=(4.722996518123433e+46, 669.4503306793644, 2.0487730053290845))
+    t, nu = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
+    prm = _abi.make_params(**kw)
+    got = gpu_components4(eng, [prm], t, nu)
+    want = oracle.flux_components(prm, t, nu)
+    for g, w in zip((got[0][0], got[1][0]), want):
+        assert np.all(np.isfinite(g)) and w.max() > 0
+        m = w > 1e-3 * w.max()
+        assert np.max(np.abs(g - w)[m] / w[m]) <= 2e-6
+
+
 @pytest.mark.parametrize("case", ["grid", "series", "fused", "rows_batch"])
 def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     """The reference builds a cell's SSC spectrum on its first query (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620); the
@@ -1755,6 +1775,27 @@ def test_random_forward_reverse_shock_ssc_draws_match_the_checker(eng, oracle):
     worst = max(report)
     assert worst[0] <= 1.0, f"draw {worst[3]} {worst[4]}: rel. err {worst[1]:.2e} > gate {worst[2]:.2e}"
     assert np.median([r[1] for r in report]) < 1e-6
+
+
+def test_random_spreading_ssc_draws_match_the_checker(eng, oracle):
+    """Spreading jets of all six profiles with SSC + Klein-Nishina: the first 24 draws of `SWEEP_MODE=spread
+    profiles/debug/prior_sweep_ssc.py` (draw 13: rows whose observer times do not ascend along the lattice; draw 22: the spreading
+    StepPowerLawJet with eps_B = 2e-6 on which the reference's own two builds differ by 4e-5 and one ulp of Gamma0 moves it by 4e-4),
+    both components, each draw held to max(2e-6, 3 x what the reference demonstrates on it)."""
+    import sweeps
+    prms = sweeps.spread_ssc_draws(24)
+    gate = _sweep_gate("sweep_spread_ssc")
+    sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
+    report = []
+    for i, p in enumerate(prms):
+        want = oracle.flux_components(p, sweeps.SSC_T, sweeps.SSC_NU)
+        for name, g, w in (("fwd.sync", sync[i], want[0]), ("fwd.ssc", ssc[i], want[1])):
+            assert np.all(np.isfinite(g)) and w.max() > 0, (i, name)
+            err, tol = _sweep_err(g, w), max(2e-6, 3 * gate[str(i)][name])
+            report.append((err / tol, err, tol, i, name))
+    worst = max(report)
+    assert worst[0] <= 1.0, f"draw {worst[3]} {worst[4]}: rel. err {worst[1]:.2e} > gate {worst[2]:.2e}"
+    assert np.median([r[1] for r in report]) < 1e-7
 
 
 def test_random_non_axisymmetric_spreading_draws_match_the_checker(eng, oracle):

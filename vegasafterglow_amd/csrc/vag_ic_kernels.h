@@ -399,7 +399,10 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
             dmin_k = fmin(dmin_k, -log2(G - u * cvmin));
             // non-spreading rows: the earliest-arriving row at node k - 1 is the one with the largest viewing cosine, the latest at node
             // k + 1 the one with the smallest (several theta rows may share the cell: every writer stores the same 1)
-            if (need && t_obs(par, k_prev, cvmax) <= t_req_max && t_obs(par, k_next, cvmin) >= t_req_min)
+            // The test is written as "not excluded": a row whose state went non-finite (the outermost rows of a Gaussian jet with a
+            // magnetar in a dense wind: NaN observer times from some node on) fails every comparison, and the flux kernels -- which
+            // count the nodes before the window like the reference -- do visit those cells.
+            if (need && !(t_obs(par, k_prev, cvmax) > t_req_max || t_obs(par, k_next, cvmin) < t_req_min))
                 need[cell_off[m] + (long long)rep_of[j] * nt + k] = 1;
         }
         band[((size_t)m * 2 + 0) * band_stride + k] = exp2((nu_lo + lg2_1pz) - dmax_k);  // nu_eval_min_k
