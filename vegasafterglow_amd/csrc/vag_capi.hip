@@ -1286,7 +1286,10 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         unsigned char* d_need = nullptr;
         double need_shrink = 1.0;  // test hook: VAG_DEBUG_IC_NEED_SHRINK=<factor> cuts the window short, so that a flux pass meets a skipped cell
         if (const char* e = std::getenv("VAG_DEBUG_IC_NEED_SHRINK")) need_shrink = std::atof(e);
-        if (!std::getenv("VAG_IC_ALL_CELLS") && c->d_tminmax.p) {
+        // (A likelihood call keeps every table: there a model's SSC status folds into the walker's score -- ic_soft_fail, -inf -- so a cell
+        // wrongly left without a table would be a silent wrong answer instead of VAG_E_INTERNAL; round 4's sweeps found two such holes
+        // in the range test, both on grid requests, both loud.)
+        if (!std::getenv("VAG_IC_ALL_CELLS") && c->d_tminmax.p && !c->ic_soft_fail) {
             if (c->d_icneed.ensure((size_t)std::max<long long>(c->n_cells, 1))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icneed.p, 0, (size_t)std::max<long long>(c->n_cells, 1), st));
             d_need = c->d_icneed.as<unsigned char>();
