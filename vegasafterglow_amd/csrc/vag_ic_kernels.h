@@ -141,15 +141,7 @@ vag_photons_ic_kernel(const vag_model_params* __restrict__ params, int nb, const
                       const int* __restrict__ inj_idx /* optional: reverse shock's injection cutoff per row */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    int lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (lay.cell_off[mid] <= c)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const int m = lo;
+    const int m = cell_model(lay.cell_off, nb, c);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     const int nt = M.n_t;
@@ -514,15 +506,7 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
     double* plan = icplan + (size_t)(live ? c : 0) * IC_PLAN;
     // the cell's plan; returns the length of its table (0: none)
     auto plan_cell = [&]() -> int {
-        int lo = 0, hi = nb;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (lay.cell_off[mid] <= c)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int m = lo;
+        const int m = cell_model(lay.cell_off, nb, c);
         plan[ICP_RUN] = 0;
         hdr[ICH_N] = 0;
         hdr[ICH_OFF] = 0;

@@ -25,6 +25,28 @@ VAG_DEV int find_model(const int* off, int nb, int idx) {  // largest m with off
     return lo;
 }
 
+// Model of cell c (largest m with cell_off[m] <= c) for kernels whose lanes hold CONSECUTIVE cells: the first live lane's cell is looked up
+// by bisection on the scalar unit (one chain of scalar-cache loads for the wavefront instead of one chain of vector loads per lane --
+// 10-13 dependent trips were a fifth of a wavefront's life in vag_cells_kernel), then each lane steps forward from that model: 64
+// consecutive cells span one or two models, rarely more.  Safe under any lane mask (the first live lane holds the smallest cell).
+VAG_DEV int cell_model(const long long* __restrict__ cell_off, int nb, long long c) {
+#ifndef VAG_HOST_DEBUG
+    const long long c_first = ((long long)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+#else
+    const long long c_first = c;
+#endif
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cell_off[mid] <= c_first)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    while (lo + 1 < nb && cell_off[lo + 1] <= c) ++lo;
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dynamics: one lane per representative (model, theta) row.  grid_solve_fwd_shock
 // (src/dynamics/forward-shock.tpp:175-208) with the lattice generated on the fly, state saved through
@@ -355,15 +377,7 @@ vag_spread_geo_kernel(int nb, const VagGridMeta* __restrict__ meta, Layout lay, 
                       long long n_cells, double* __restrict__ cellgeo) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    int lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (lay.cell_off[mid] <= c)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const int m = lo;
+    const int m = cell_model(lay.cell_off, nb, c);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     const int nt = M.n_t;
@@ -414,24 +428,7 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
                  double* raw_shock /* = shock when vag_dynamics_fast_kernel left (U2_th, m2) to be finished */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    // the cell's model: the wavefront's FIRST cell is looked up by bisection on the scalar unit (one chain of scalar-cache loads for the
-    // wavefront instead of one chain of vector loads per lane: 10-13 dependent trips were a fifth of a wavefront's life here), then each
-    // lane steps forward from that model -- 64 consecutive cells span one or two models, rarely more
-#ifndef VAG_HOST_DEBUG  // (the first live lane's cell: lanes hold consecutive cells, and a lane beyond the batch has left with all behind it)
-    const long long c_first = ((long long)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-#else
-    const long long c_first = c;
-#endif
-    int lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (lay.cell_off[mid] <= c_first)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    int m = lo;
-    while (m + 1 < nb && lay.cell_off[m + 1] <= c) ++m;
+    const int m = cell_model(lay.cell_off, nb, c);
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
     const int nt = M.n_t;
