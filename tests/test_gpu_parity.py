@@ -963,6 +963,51 @@ def test_rows_whose_state_goes_non_finite_keep_their_ssc_tables(eng, oracle):
         assert np.max(np.abs(g - w)[m] / w[m]) <= 2e-6
 
 
+def test_lazily_built_ssc_tables_are_the_bits_of_every_table_on_random_narrow_windows(eng):
+    """Property test of the table-per-queried-cell logic (vag_ic_band_kernel's range test): 48 SSC models of every kind -- six jet
+    profiles, ISM / wind, KN / Thomson, reverse shocks, magnetars, spreading, axisymmetric=False, one ragged mixed-flag batch -- times 24
+    random NARROW request windows (1 ... 12 times inside 0.05 ... 2 decades anywhere between 30 s and 3e8 s: the requests that leave
+    80-90 % of the cells without a table), grid and series requests alternating.  Each is evaluated with the lazy tables and with every
+    table (VAG_IC_ALL_CELLS=1): the four components must be the same bits, and no call may meet a cell without a table (that would
+    raise).  The two holes round 4's oracle sweeps found in that logic would both have failed here."""
+    import sweeps
+    lib, h = eng
+    prms, tags = sweeps.ssc_window_models(48)
+    n, nu = len(prms), sweeps.WINDOW_NU
+    arr = (_lib.ModelParams * n)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+
+    def run(t, series):
+        if series:
+            tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+            comps = [np.empty((n, tt.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            _lib.check(lib.vag_flux_density_components4_batch(h, arr, n, tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
+        else:
+            comps = [np.empty((n, nu.size, t.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            _lib.check(lib.vag_flux_density_grid_components4_batch(h, arr, n, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, out4))
+        return comps
+
+    lazy_bytes = all_bytes = 0
+    for w, t in enumerate(sweeps.narrow_windows(24)):
+        series = w % 3 == 2
+        got = run(t, series)
+        pl = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(pl))
+        lazy_bytes += pl.ic_pool_bytes
+        os.environ["VAG_IC_ALL_CELLS"] = "1"
+        try:
+            want = run(t, series)
+        finally:
+            os.environ.pop("VAG_IC_ALL_CELLS")
+        lib.vag_last_plan(h, C.byref(pl))
+        all_bytes += pl.ic_pool_bytes
+        for c, (g, x) in enumerate(zip(got, want)):
+            bad = [i for i in range(n) if not np.array_equal(g[i], x[i], equal_nan=True)]
+            assert not bad, (w, c, [tags[i] for i in bad[:4]])
+    assert lazy_bytes < 0.6 * all_bytes  # (the windows do leave most cells without a table: the property is exercised)
+
+
 @pytest.mark.parametrize("case", ["grid", "series", "fused", "rows_batch"])
 def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     """The reference builds a cell's SSC spectrum on its first query (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620); the
