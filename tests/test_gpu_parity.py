@@ -963,6 +963,48 @@ def test_rows_whose_state_goes_non_finite_keep_their_ssc_tables(eng, oracle):
         assert np.max(np.abs(g - w)[m] / w[m]) <= 2e-6
 
 
+def test_the_grid_kernels_two_layouts_give_the_same_bits(eng):
+    """vag_grid_kernel has a small LDS layout (256 theta / 208 phi nodes, eight models per CU) and a large one (1280 / 2560, one per CU); a
+    batch in which some model outgrows the small one is laid out again with the large one, and every array downstream is strided by the
+    layout in use (VagGridMeta::th_stride / ph_stride).  The layout must not enter the numbers: 48 mixed models (all jet profiles, reverse
+    shocks, SSC, spreading, axisymmetric=False) on a grid and on a series request, with the layout their sizes call for and with the large
+    one forced (VAG_GRID_FORCE_LARGE) -- same bits; and back again afterwards."""
+    import sweeps
+    lib, h = eng
+    prms, tags = sweeps.ssc_window_models(48, seed=2718)
+    n, nu = len(prms), sweeps.WINDOW_NU
+    arr = (_lib.ModelParams * n)(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    t = np.logspace(2.5, 7, 14)
+
+    def run(series):
+        if series:
+            tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+            comps = [np.empty((n, tt.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            _lib.check(lib.vag_flux_density_components4_batch(h, arr, n, tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
+        else:
+            comps = [np.empty((n, nu.size, t.size)) for _ in range(4)]
+            out4 = (dp * 4)(*[a.ctypes.data_as(dp) for a in comps])
+            _lib.check(lib.vag_flux_density_grid_components4_batch(h, arr, n, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, out4))
+        return comps
+
+    for series in (False, True):
+        small = run(series)
+        os.environ["VAG_GRID_FORCE_LARGE"] = "1"
+        try:
+            large = run(series)
+        finally:
+            os.environ.pop("VAG_GRID_FORCE_LARGE")
+        for c, (a, b) in enumerate(zip(small, large)):
+            bad = [i for i in range(n) if not np.array_equal(a[i], b[i], equal_nan=True)]
+            assert not bad, (series, c, [tags[i] for i in bad[:4]])
+        assert max(float(np.nanmax(x)) for x in small) > 0
+    for _ in range(9):  # eight fitting batches in a row take the context back to the small layout
+        again = run(False)
+    for a, b in zip(again, run(False)):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_lazily_built_ssc_tables_are_the_bits_of_every_table_on_random_narrow_windows(eng):
     """Property test of the table-per-queried-cell logic (vag_ic_band_kernel's range test): 48 SSC models of every kind -- six jet
     profiles, ISM / wind, KN / Thomson, reverse shocks, magnetars, spreading, axisymmetric=False, one ragged mixed-flag batch -- times 24

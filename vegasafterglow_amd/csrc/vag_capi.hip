@@ -809,6 +809,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * ps) || c->d_rep_of.ensure(sizeof(int) * (size_t)nb * ts) ||
                c->d_rep_start.ensure(sizeof(int) * (size_t)nb * ts) || c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(large));
     };
+    if (std::getenv("VAG_GRID_FORCE_LARGE")) c->grid_large = true, c->grid_large_idle = 0;  // test hook: the large layout for batches that fit the small one
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
