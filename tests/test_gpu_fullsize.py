@@ -136,6 +136,27 @@ def test_fit_kernel_items_beyond_the_first_come_from_the_counter_and_change_noth
     assert np.array_equal(f.loglike_batch(samples, defs), big)
 
 
+def test_cost_ordering_of_the_walkers_changes_no_bit(eng, oracle):
+    """A likelihood call evaluates its walkers in descending order of the cost the same batch position had in the previous call
+    (vag_order_kernel; VAG_NO_ORDER switches it off): theta is gathered, ln L scattered back.  Walkers are independent units, so ln L
+    must be the same bits ordered or not, from the first call (no ranking yet) through calls ranked by a DIFFERENT batch's costs."""
+    f, defs = _c4_fitter(oracle)
+    _, lo, hi = f.build_spec(defs)
+    rng = np.random.default_rng(23)
+    a = lo + (hi - lo) * rng.random((512, len(defs)))
+    b = lo + (hi - lo) * rng.random((512, len(defs)))
+    os.environ["VAG_NO_ORDER"] = "1"
+    try:
+        want_a, want_b = f.loglike_batch(a, defs), f.loglike_batch(b, defs)
+    finally:
+        os.environ.pop("VAG_NO_ORDER")
+    assert np.isfinite(want_a).sum() > 400
+    for _ in range(2):  # first call of a batch size, then ranked by the other batch's costs, then by its own
+        assert np.array_equal(f.loglike_batch(a, defs), want_a)
+        assert np.array_equal(f.loglike_batch(b, defs), want_b)
+        assert np.array_equal(f.loglike_batch(b, defs), want_b)
+
+
 def test_fit_kernel_with_300_points_in_six_bands(eng, oracle):
     """A larger data set than the C4 mock (300 points, six bands: the eight-band instantiation, several slots per lane in the
     flush): the row-per-lane kernel against the row-per-wavefront kernel on 48 models, and against the oracle on two."""
