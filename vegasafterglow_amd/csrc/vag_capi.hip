@@ -1098,20 +1098,26 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
             c->plan.interps += c->total_pairs * (long long)nt * nnu;
             c->plan.flux_blocks = max_blocks * nb;
             c->plan.pairs_per_block = FITROWS_ROWS;
-            // (Measured and rejected, r04: this kernel as persistent workgroups like vag_flux_fit_rows_kernel.  Its launches have no empty
-            // workgroups and its wavefronts live ~0.5 ms, so there was 9 % to gain at most -- and the loop around the items costs the
-            // synchrotron instantiation, which sits at 167 of 168 VGPRs, 120-170 B of scratch per lane: 61 against 47 ms per 1024 C5 members.)
-            const dim3 g((max_blocks + GRIDROWS_WAVES - 1) / GRIDROWS_WAVES, nb), b(SERIES_THREADS * GRIDROWS_WAVES);
+            // The plain-synchrotron pass is a persistent launch like vag_flux_fit_rows_kernel (three workgroups per CU that take blocks
+            // until none is left: vag_grid_rows.h); the IC-corrected and the tabulated-SSC pass keep one workgroup per four blocks (the
+            // first has no registers for the loop -- 61 against 47 ms per 1024 C5 members, measured -- the second nothing to gain).
+            const bool persistent = mode != FLUX_SYN_IC && mode != FLUX_SSC;
+            a.nb = nb;
+            a.work = work_counters(c);
+            const long long wg_need = (blocks + nb + GRIDROWS_WAVES - 1) / GRIDROWS_WAVES;  // (total_pairs may be the previous call's)
+            const dim3 g_all((max_blocks + GRIDROWS_WAVES - 1) / GRIDROWS_WAVES, nb), b(SERIES_THREADS * GRIDROWS_WAVES);
+            const dim3 g_pers((unsigned)std::max<long long>(1, std::min<long long>(wg_need, 3LL * c->n_cus)));
             const size_t lds = grid_rows_lds_bytes(slots);
             if (mode == FLUX_SYN_IC)
-                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN_IC>), g, b, lds, st, a);
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN_IC>), g_all, b, lds, st, a);
             else if (mode == FLUX_SSC)
-                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SSC>), g, b, lds, st, a);
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SSC>), g_all, b, lds, st, a);
             else
-                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN>), g, b, lds, st, a);
+                hipLaunchKernelGGL((vag_flux_grid_rows_kernel<FLUX_SYN>), g_pers, b, lds, st, a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[4], st));
-            launch_reduce(st, d_params, c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, FITROWS_ROWS, nt, nnu, d_bandw, d_out, nb);
+            launch_reduce(st, d_params, c->d_meta.as<VagGridMeta>(), c->d_partial.as<double>(), max_blocks, FITROWS_ROWS, nt, nnu, d_bandw, d_out, nb,
+                          persistent ? work_counters(c) : nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));
             return VAG_OK;

@@ -52,43 +52,33 @@ __host__ __device__ inline int grid_rows_stripes(int slots) {
 }
 __host__ __device__ inline size_t grid_rows_lds_bytes(int slots) { return grid_rows_lds_bytes_with(slots, grid_rows_stripes(slots)); }
 
-// a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
-// 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
+// LDS of a workgroup as a block of rows sees it
+struct GridRowsLds {
+    const double* s_sp;    // softplus + log2 tables
+    const double* s_tobs;  // [GRIDROWS_MAX_NT] log2 requested times, ascending; +inf beyond nt
+    double* s_acc;         // this wavefront's sums [stripe][SS]
+    char* ring_base;       // this wavefront's ring (VAG_ROWS_RING builds)
+};
+
+// One block of 64 rows (block vb of model m), by one wavefront.
 template <int MODE>
-// 168 VGPRs: three wavefronts per SIMD; the SSC pass (a table look-up per band, no spectrum constants) fits 128 with 12 B of
-// scratch and gains 9 % from the fourth wavefront, the others would spill 100-200 B per lane and lose 70 %
-#ifndef VAG_ROWS_SSC_WG
-#define VAG_ROWS_SSC_WG 3  // three workgroups per CU (168 VGPRs, no scratch): the look-ups in flight a node ahead need the registers, 4 spills 92-160 B
-#endif
-__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? VAG_ROWS_SSC_WG : VAG_ROWS_MIN_WG)
-vag_flux_grid_rows_kernel(SeriesArgs a) {
-    const int m = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* s_sp = lds;
+VAG_DEV void grid_rows_item(const SeriesArgs& a, const GridRowsLds& L, int m, int vb, int lane) {
     const VagGridMeta* Mp = a.meta + m;
-    const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
-    if ((long long)blockIdx.x * GRIDROWS_WAVES * FITROWS_ROWS >= n_pairs) return;
+    const int n_pairs = Mp->n_theta * Mp->n_phi_eff;
     const int nt = a.grid_nt, NB = a.n_bands, slots = a.n;
     const int stripes = grid_rows_stripes(slots), SS = rows_acc_stride(slots, stripes);  // (the copies' stride: vag_fit_rows.h)
-    double* s_tobs = s_sp + SP_LDS_DOUBLES;           // [GRIDROWS_MAX_NT] log2 requested times, ascending; +inf beyond nt
-    double* s_nu = s_tobs + GRIDROWS_MAX_NT;          // [SERIES_MAX_BANDS] log2 nu (1 + z)
-    double* s_acc = s_nu + SERIES_MAX_BANDS + (size_t)wave * stripes * SS;  // this wavefront's sums [stripe][SS]
-    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
-    for (int i = threadIdx.x; i < GRIDROWS_MAX_NT; i += blockDim.x) s_tobs[i] = i < nt ? a.lg2_t_obs[i] : INFINITY;
-    if (threadIdx.x < NB) s_nu[threadIdx.x] = a.lg2_nu_obs[threadIdx.x] + Mp->lg2_1pz;
-    for (int i = lane; i < stripes * SS; i += SERIES_THREADS) s_acc[i] = 0;
+    const double* s_sp = L.s_sp;
+    const double* s_tobs = L.s_tobs;
+    double* s_acc = L.s_acc;
     double* my_acc = s_acc + (lane % stripes) * SS;
-    // this wavefront's ring (behind every wavefront's sums; 16-byte aligned: the doubles before it are an even count)
-    char* ring_base = reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * SS) + (size_t)wave * GRIDROWS_RING_BYTES;
-    vdouble2* ring_x01 = reinterpret_cast<vdouble2*>(ring_base);
-    vdouble2* ring_x23 = ring_x01 + GRIDROWS_RING;
-    int* ring_q = reinterpret_cast<int*>(ring_x23 + GRIDROWS_RING);
-    int ring_tail = 0, ring_count = 0;  // wavefront-uniform
-    __syncthreads();  // the only workgroup-wide barrier
-    const int vb = blockIdx.x * GRIDROWS_WAVES + wave;
+    [[maybe_unused]] vdouble2* ring_x01 = reinterpret_cast<vdouble2*>(L.ring_base);
+    [[maybe_unused]] vdouble2* ring_x23 = ring_x01 + GRIDROWS_RING;
+    [[maybe_unused]] int* ring_q = reinterpret_cast<int*>(ring_x23 + GRIDROWS_RING);
+    [[maybe_unused]] int ring_tail = 0, ring_count = 0;  // wavefront-uniform
+    wave_sync();  // (a previous block's sums have been read)
+    for (int i = lane; i < stripes * SS; i += SERIES_THREADS) s_acc[i] = 0;
+    wave_sync();
     const int p0 = vb * FITROWS_ROWS;
-    if (p0 >= n_pairs) return;
     const LdsTab sp_tab = lds_tab(s_sp), lg_tab = lds_tab(s_sp + SP_TABLE_DOUBLES);
     // log2 nu (1 + z) of the request's frequencies, wavefront-uniform: scalar loads into scalar registers (read back from LDS they
     // cost the node loop four round trips with a wait each)
@@ -346,6 +336,96 @@ vag_flux_grid_rows_kernel(SeriesArgs a) {
         double sum = s_acc[s];
         for (int c = 1; c < stripes; ++c) sum += s_acc[c * SS + s];
         dst[s] = sum;
+    }
+}
+
+// The kernel's arguments read again from the kernel-argument segment (constant address space: scalar loads), the pointer hidden from
+// the optimiser first: a loop that calls this per turn re-reads the arguments per turn instead of keeping all of them in scalar
+// registers across the loop (where they overflow into VGPR lanes, and those into scratch).
+#ifndef VAG_HOST_DEBUG
+typedef const SeriesArgs __attribute__((address_space(4))) KernargSeriesArgs;
+VAG_DEV SeriesArgs load_series_args() {
+    KernargSeriesArgs* p = (KernargSeriesArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    SeriesArgs a;
+    __builtin_memcpy(&a, p, sizeof(SeriesArgs));
+    return a;
+}
+#endif
+
+// a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
+// 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
+// FLUX_SYN is a PERSISTENT launch like vag_flux_fit_rows_kernel (the launch fills the GPU once, every wavefront takes blocks -- its own
+// number first, then from the counter -- until none is left): plain-synchrotron batches are the ragged ones with short wavefront lives
+// (4096 off-axis top hats: 2.3-2.4 of 3 wavefronts per SIMD resident with a workgroup per four blocks), and this instantiation has the
+// registers for the loop (144 of 168 VGPRs).  The IC-corrected pass sits at 167 of 168 and pays 120-170 B of scratch for it (61 against
+// 47 ms per 1024 C5 members, measured), the tabulated-SSC pass gains nothing: both keep one workgroup per four blocks.
+template <int MODE>
+// 168 VGPRs: three wavefronts per SIMD; the SSC pass (a table look-up per band, no spectrum constants) fits 128 with 12 B of
+// scratch and gains 9 % from the fourth wavefront, the others would spill 100-200 B per lane and lose 70 %
+#ifndef VAG_ROWS_SSC_WG
+#define VAG_ROWS_SSC_WG 3  // three workgroups per CU (168 VGPRs, no scratch): the look-ups in flight a node ahead need the registers, 4 spills 92-160 B
+#endif
+__global__ void __launch_bounds__(SERIES_THREADS * GRIDROWS_WAVES, MODE == FLUX_SSC ? VAG_ROWS_SSC_WG : VAG_ROWS_MIN_WG)
+vag_flux_grid_rows_kernel(SeriesArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* s_sp = lds;
+    if constexpr (MODE != FLUX_SYN) {
+        const VagGridMeta* Mp = a.meta + blockIdx.y;
+        const int n_pairs = Mp->status == 0 ? Mp->n_theta * Mp->n_phi_eff : 0;
+        if ((long long)blockIdx.x * GRIDROWS_WAVES * FITROWS_ROWS >= n_pairs) return;
+    }
+    const int nt = a.grid_nt, slots = a.n;
+    const int stripes = grid_rows_stripes(slots), SS = rows_acc_stride(slots, stripes);
+    double* s_tobs = s_sp + SP_LDS_DOUBLES;           // [GRIDROWS_MAX_NT] log2 requested times, ascending; +inf beyond nt
+    double* s_nu = s_tobs + GRIDROWS_MAX_NT;          // [SERIES_MAX_BANDS] (the frequencies live in scalar registers)
+    for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_sp[i] = a.sp_table[i];
+    for (int i = threadIdx.x; i < GRIDROWS_MAX_NT; i += blockDim.x) s_tobs[i] = i < nt ? a.lg2_t_obs[i] : INFINITY;
+    __syncthreads();  // the only workgroup-wide barrier
+    if constexpr (MODE != FLUX_SYN) {
+        const int m = blockIdx.y, vb = blockIdx.x * GRIDROWS_WAVES + wave;
+        const VagGridMeta* Mp = a.meta + m;
+        if (vb * FITROWS_ROWS >= Mp->n_theta * Mp->n_phi_eff) return;
+        // this wavefront's sums, and its ring behind every wavefront's sums (16-byte aligned: the doubles before it are an even count)
+        const GridRowsLds L{s_sp, s_tobs, s_nu + SERIES_MAX_BANDS + (size_t)wave * stripes * SS,
+                            reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * SS) + (size_t)wave * GRIDROWS_RING_BYTES};
+        grid_rows_item<MODE>(a, L, m, vb, lane);
+    } else {
+        // The loop keeps nothing alive but the block number: a turn re-reads the arguments and makes the lane / wavefront numbers opaque,
+        // so that what a block derives from them is formed inside the turn instead of being held in registers across the loop.
+        int item = (int)blockIdx.x * GRIDROWS_WAVES + wave;
+        for (;;) {
+#ifndef VAG_HOST_DEBUG
+            const SeriesArgs A = load_series_args();
+            int lane_i = threadIdx.x & 63, wave_i = threadIdx.x >> 6;
+            asm volatile("" : "+v"(lane_i), "+v"(wave_i));
+            wave_i = __builtin_amdgcn_readfirstlane(wave_i);
+#else
+            const SeriesArgs& A = a;
+            const int lane_i = lane, wave_i = wave;
+#endif
+            const int nb = A.nb;
+            const int* __restrict__ blk_off = A.lay.row_off + nb + 1;  // [nb + 1] first block of every model (vag_grid_kernel's plan scan)
+            const int total_items = blk_off[nb];
+            if (item >= total_items) break;
+            int lo = 0, hi = nb;  // blk_off[lo] <= item < blk_off[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (blk_off[mid] <= item)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const GridRowsLds L{s_sp, s_tobs, s_nu + SERIES_MAX_BANDS + (size_t)wave_i * stripes * SS,
+                                reinterpret_cast<char*>(s_nu + SERIES_MAX_BANDS + (size_t)GRIDROWS_WAVES * stripes * SS) + (size_t)wave_i * GRIDROWS_RING_BYTES};
+            grid_rows_item<MODE>(A, L, lo, item - blk_off[lo], lane_i);
+            const int n_waves = (int)gridDim.x * GRIDROWS_WAVES;
+            if (total_items <= n_waves) break;
+            if (lane_i == 0) item = n_waves + __hip_atomic_fetch_add(A.work, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
+        // (the counter is put back to zero by the reduction kernel that follows every launch of this one)
     }
 }
 
