@@ -14,8 +14,9 @@
 //   * each of the lane's points in the interval is interpolated log-log (observer.h:405-433) and added to the wavefront's
 //     per-point accumulator in LDS (ds_add_f64: lanes of one instruction are applied in lane order, so the sum is reproducible).
 // No staged rows, no per-row LDS arrays, no phase barriers: every lane is busy on every step, and the only LDS besides the
-// evaluator's tables is 64 accumulators per wavefront.  A wavefront's 64 rows and their order depend on the model alone, and it
-// writes one partial sum per data point, so a walker's ln L does not depend on what else is in the batch.
+// evaluator's tables is a few copies of 64 accumulators per wavefront.  A block's 64 rows and their order depend on the model alone,
+// and a block writes one partial sum per data point and lattice segment, so a walker's ln L does not depend on what else is in the
+// batch -- nor on which wavefront of the PERSISTENT launch served the block (round 4: workgroups that take items until none is left).
 //
 // Reference: Observer::specific_flux_series (src/core/observer.h:447-538).
 #pragma once

@@ -25,7 +25,8 @@ constexpr int GRIDROWS_BANDS = 4;     // frequencies
 constexpr int GRIDROWS_MAX_NT = 128;  // requested times
 constexpr int GRIDROWS_MAX_SLOTS = 512;
 
-// The interpolation work of a wavefront goes through a RING of items in LDS: a lane pushes {the four exponents of one requested
+// (Build option VAG_ROWS_RING=1, measured slower and off by default -- DESIGN.md 4h.)  With it the interpolation work of a wavefront
+// goes through a RING of items in LDS: a lane pushes {the four exponents of one requested
 // time inside its current lattice interval, the time's index}, and whenever 64 items have gathered ALL 64 lanes pop one each and do
 // the exp2 + accumulate.  Walking the lattice, the lanes of a wavefront meet their requested times at different nodes (0, 1 or 2 per
 // interval, 0.9 on average on the C5 shape), so the interpolation done in place ran at the trip count of the busiest lane with
