@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 10  /* v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream */
+#define VAG_ABI_VERSION 11  /* v11: vag_plan.ode_rhs; a likelihood call's work tallies under vag_ctx_count_work (v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream) */
 
 /* error codes */
 #define VAG_OK 0
@@ -159,6 +159,10 @@ void vag_ctx_destroy(vag_ctx* ctx);
  * The legacy default stream has the handle 0 and cannot be told apart from NULL: pass VAG_STREAM_LEGACY_DEFAULT for it
  * (PyTorch's default `torch.cuda.current_stream()` IS that stream: its `.cuda_stream` is 0). */
 #define VAG_STREAM_LEGACY_DEFAULT ((void*)1)
+/* Stream lifetime (ABI v11): a caller-owned stream must stay alive for the duration of every engine call made on it; it may be destroyed
+ * between calls, before it is handed back -- the engine never touches the stream it leaves (the hand-off event that orders the
+ * context's scratch buffers across streams is recorded at the end of each device-resident call, while the stream is known to be
+ * alive).  VAG_E_HIP if the new stream cannot be made to wait for that event. */
 int vag_ctx_set_stream(vag_ctx* ctx, void* hip_stream);
 /* The value vag_ctx_set_stream would take to select the stream the context is on now (NULL = its own): lets a caller that
  * borrows the context for one call on another stream put the previous one back (ABI v9). */
@@ -351,6 +355,9 @@ int vag_last_model_costs_dev(vag_ctx* ctx, int nb, double* d_cost);
  *
  * The deal is a function of the gathered costs only, so all ranks compute the same one without talking.  Stream-ordered on the
  * context stream like vag_loglike_batch_dev; rank / world are the caller's (no communicator is touched here).
+ * ABI v11: the deal of a call in flight is kept per (nb_all, world, spec content), so other sharded calls may run on the context between
+ * a call's two halves (up to four in flight; calls of equal shape finish in the order they were dealt) -- a caller need not, and should
+ * not, hold a process-local lock across its collective.
  */
 int vag_loglike_shard_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank,
                           int world, double* d_block);
@@ -457,15 +464,43 @@ typedef struct vag_plan {
     /* ABI v8: models whose SSC tables were rebuilt over their full theoretical range because a flux pass queried them outside the
      * clamped band (ICPhoton::compute_log2_I_nu's self-healing path, inverse-compton.h:626-635); the pass was then repeated */
     int32_t n_models_ssc_rebuilt;
-    int32_t pad_plan;
+    /* ABI v11 (the v8 padding word): SSC passes of the last call that had to be repeated with EVERY cell's table because a flux pass
+     * queried a cell the lazy selection (tables only for the cells a request's observation window touches) had skipped */
+    int32_t n_ssc_all_cell_fallbacks;
     /* ABI v10: bytes of the pool that holds the SSC tables of one shock of the batch (each table as long as its own output lattice;
      * cells no (theta, phi) row queries have none) -- the largest table build of the last call */
     int64_t ic_pool_bytes;
+    /* ABI v11, with vag_ctx_count_work(1): right-hand sides the forward-shock solver evaluated for the batch (ForwardShockEqn::operator(),
+     * forward-shock.tpp:10-118; FSAL: six per step attempt + one per row); 0 for the solvers that carry no tally (reverse shock,
+     * spreading, injection).  In the same mode a likelihood call's spec_evals / interps are tallied by the flux kernel itself
+     * (boundary-spectrum evaluations actually formed, data points inside a row's lattice) instead of the 2 / 1 per (row, point) bound. */
+    int64_t ode_rhs;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with
  * one atomic per workgroup and a host sync; leave disabled in timed runs. */
 int vag_ctx_count_work(vag_ctx* ctx, int enable);
+
+/*
+ * ABI v11 -- thread pools.  Every entry point that takes a context locks it for its own duration, so a context may be shared by the
+ * threads of a pool (the reference releases the GIL in every compute method and its samplers map eval_one over a ThreadPoolExecutor with
+ * one Model per thread, pybind/pybind.cpp:424-448, VegasAfterglow/fitting/samplers.py:59-70); calls are served one after the other.
+ * The *_coalesced forms take ONE model, block the calling thread, and serve the calls that wait at the same time with the same request
+ * (times, frequencies / band) as ONE batch call of the corresponding *_batch entry point: an unmodified thread-pool sampler gets batched
+ * throughput.  `out` receives the total ([nnu][nt] / [n] / [nt]); or, with out == NULL, out4[i] != NULL receive the components as in the
+ * *_components4_batch forms.  The caller's buffers must stay valid until its call returns; errors are per caller (a batch that fails as
+ * a whole is repeated member by member).  Results: the series and band forms are the bits of a single call (their summation tree does
+ * not depend on the batch); a grid call's fixed-order sums are laid out per batch, so its values may differ from a single call's in the
+ * last bits (~1e-15 relative).
+ */
+int vag_ctx_coalesce(vag_ctx* ctx, int max_batch /* default 64 */, int wait_us /* the first caller waits this long for company: default 50 */);
+int vag_ctx_coalesce_stats(vag_ctx* ctx, long long* calls, long long* batches); /* requests served / batch calls issued so far */
+int vag_flux_density_grid_coalesced(vag_ctx* ctx, const vag_model_params* p, const double* t, int nt, const double* nu, int nnu,
+                                    double* out, double* const* out4);
+int vag_flux_density_coalesced(vag_ctx* ctx, const vag_model_params* p, const double* t, const double* nu, int n, double* out,
+                               double* const* out4);
+int vag_flux_coalesced(vag_ctx* ctx, const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max, int num_nu,
+                       double* out, double* const* out4);
 
 #ifdef __cplusplus
 }

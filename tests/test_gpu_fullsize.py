@@ -526,3 +526,106 @@ def test_context_buffers_are_ordered_across_a_change_of_stream(eng, oracle):
         side.synchronize()
         assert np.array_equal(ll.cpu().numpy(), want_ll)
         assert np.array_equal(got_grid, want_grid)
+
+
+def _mixed_models(n):
+    """n Models of mixed jets / media / radiation switches (what a pool of threads holds in the reference's samplers: one Model each)."""
+    rng = np.random.default_rng(7)
+    out = []
+    for i in range(n):
+        th_c, E, G0 = rng.uniform(0.05, 0.15), 10 ** rng.uniform(51.5, 52.5), rng.uniform(150, 400)
+        obs = va.Observer(1e28, 1.0, rng.uniform(0.0, 0.3))
+        kind = i % 4
+        if kind == 0:
+            m = va.Model(va.TophatJet(th_c, E, G0), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3))
+        elif kind == 1:
+            m = va.Model(va.GaussianJet(th_c, E, G0), va.ISM(0.5), obs, va.Radiation(0.1, 0.01, 2.2))
+        elif kind == 2:
+            m = va.Model(va.PowerLawJet(th_c, E, G0, 2.0, 2.0), va.Wind(0.1), obs, va.Radiation(0.1, 0.01, 2.3, ssc=True))
+        else:
+            m = va.Model(va.GaussianJet(th_c, E, G0, duration=10.0), va.ISM(1.0), obs, va.Radiation(0.1, 0.01, 2.3),
+                         rvs_rad=va.Radiation(0.1, 0.01, 2.3))
+        out.append(m)
+    return out
+
+
+def _flux_parts(fd):
+    return [np.array(a) for a in (fd.total, fd.fwd.sync, fd.fwd.ssc, fd.rvs.sync, fd.rvs.ssc)]
+
+
+def test_models_driven_from_a_thread_pool_give_the_bits_of_their_single_threaded_calls(eng):
+    """The reference's calling pattern (pybind/pybind.cpp:424-448 releases the GIL in every compute method; fitting/samplers.py:59-70
+    maps eval_one over a ThreadPoolExecutor, one Model per thread): 8 threads x 16 Models of mixed jets call flux_density_grid,
+    flux_density and flux concurrently on the one per-device context.  The library serialises the calls itself (every entry point locks
+    the context); each result must be bit for bit what the same call returns single-threaded."""
+    from concurrent.futures import ThreadPoolExecutor
+    models = _mixed_models(128)
+    t, nu = np.logspace(3, 7, 24), np.array([1e9, 4.84e14, 1e18])
+    ts, nus = np.repeat(t, nu.size), np.tile(nu, t.size)
+
+    def work(m):
+        return (_flux_parts(m.flux_density_grid(t, nu)), _flux_parts(m.flux_density(ts, nus)), _flux_parts(m.flux(t, 1e17, 1e18, 5)))
+
+    want = [work(m) for m in models]
+    va.set_coalescing(False)
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(work, models))
+    for g, w in zip(got, want):
+        for gm, wm in zip(g, w):
+            for a, b in zip(gm, wm):
+                assert a.shape == b.shape and np.array_equal(a, b)
+    assert all(np.all(np.isfinite(w[0][0])) and w[0][0].max() > 0 for w in want)
+
+
+def test_coalesced_thread_pool_calls_are_served_as_batches_with_each_callers_own_result(eng):
+    """vag_*_coalesced (opt-in, va.set_coalescing): concurrent single-model calls with the same request run as one batch call.  32
+    threads x 128 mixed Models: far fewer batch calls than requests; flux_density / flux are the bits of the single calls (their
+    summation trees do not depend on the batch), flux_density_grid agrees to 1e-12 (its fixed-order sums are laid out per batch); a model
+    the engine rejects raises for its own caller only, and callers with a different request are not mixed in."""
+    from concurrent.futures import ThreadPoolExecutor
+    models = _mixed_models(128)
+    t, nu = np.logspace(3, 7, 24), np.array([1e9, 4.84e14, 1e18])
+    t2 = np.logspace(3.5, 6.5, 10)  # a second request in the same pool
+    ts, nus = np.repeat(t, nu.size), np.tile(nu, t.size)
+
+    def work(im):
+        i, m = im
+        tt = t2 if i % 5 == 0 else t
+        return (_flux_parts(m.flux_density_grid(tt, nu)), _flux_parts(m.flux_density(ts, nus)), _flux_parts(m.flux(tt, 1e17, 1e18, 5)))
+
+    va.set_coalescing(False)
+    want = [work(im) for im in enumerate(models)]
+    calls0, batches0 = va.coalescing_stats()
+    prev = va.set_coalescing(True, max_batch=64, wait_us=200)
+    try:
+        with ThreadPoolExecutor(32) as ex:
+            got = list(ex.map(work, enumerate(models)))
+        calls, batches = va.coalescing_stats()
+        assert calls - calls0 == 3 * len(models)
+        assert batches - batches0 < (calls - calls0) // 3  # batches did form
+        for g, w in zip(got, want):
+            for a, b in zip(g[0], w[0]):  # grid
+                assert a.shape == b.shape
+                if a.ndim:
+                    assert np.allclose(a, b, rtol=1e-12, atol=0)
+            for part in (1, 2):  # series, band: the same bits
+                for a, b in zip(g[part], w[part]):
+                    assert a.shape == b.shape and np.array_equal(a, b)
+        # an over-capacity grid among valid ones: its caller gets the error, the others their fluxes
+        bad = va.Model(va.GaussianJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2), va.Radiation(0.1, 0.01, 2.3),
+                       resolutions=(50.0, 50.0, 50.0))
+        mix = models[:15] + [bad] + models[15:30]
+
+        def guarded(m):
+            try:
+                return np.array(m.flux_density(ts, nus).total)
+            except Exception as e:  # noqa: BLE001
+                return e
+
+        with ThreadPoolExecutor(31) as ex:
+            res = list(ex.map(guarded, mix))
+        assert isinstance(res[15], Exception)
+        for r, im in zip(res[:15] + res[16:], list(range(15)) + list(range(15, 30))):
+            assert np.array_equal(r, want[im][1][0])
+    finally:
+        va.set_coalescing(prev)

@@ -1080,8 +1080,9 @@ def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     """The reference builds a cell's SSC spectrum on its first query (ICPhoton::compute_log2_I_nu, inverse-compton.h:614-620); the
     engine gives a table to the cells some (theta, phi) row's observation window touches (vag_ic_band_kernel: ~80 % of the cells of
     the configs[2] shape) and leaves the others without.  (1) The fluxes are the bits of a pass that builds every table
-    (VAG_IC_ALL_CELLS=1), on every kernel family.  (2) A query of a skipped cell is an engine fault that is reported, not a silent
-    zero: VAG_DEBUG_IC_NEED_SHRINK cuts the window short so that the flux pass meets such cells, and the call must fail loudly."""
+    (VAG_IC_ALL_CELLS=1), on every kernel family.  (2) A query of a skipped cell is never a silent zero: VAG_DEBUG_IC_NEED_SHRINK cuts
+    the window short so that the flux pass meets such cells; the engine then builds every table and repeats the pass (counted in
+    vag_plan.n_ssc_all_cell_fallbacks), and raises VAG_E_INTERNAL only if that cannot help."""
     lib, h = eng
     kw = dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.3, duration=50.0, ssc=True, kn=True,
               rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True))
@@ -1114,14 +1115,27 @@ def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     assert want[1].max() > 0 and want[3].max() > 0
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+    # (2) a hole in the selection: the pass is repeated with every cell's table -- the reference's answer, bit for bit -- and counted;
+    #     with the fallback switched off the fault is loud (what a second miss, on the all-cells pass, would raise)
     os.environ["VAG_DEBUG_IC_NEED_SHRINK"] = "1e-2"
     try:
+        got_fb = run()
+        plan = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(plan))
+        assert plan.n_ssc_all_cell_fallbacks >= 1
+        for g, w in zip(got_fb, want):
+            assert np.array_equal(g, w)
+        os.environ["VAG_DEBUG_IC_NO_FALLBACK"] = "1"
         with pytest.raises(RuntimeError, match="queried an SSC cell that was given no table"):
             run()
     finally:
         os.environ.pop("VAG_DEBUG_IC_NEED_SHRINK")
+        os.environ.pop("VAG_DEBUG_IC_NO_FALLBACK", None)
     for g, w in zip(run(), want):  # and the context is in order afterwards
         assert np.array_equal(g, w)
+    plan = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(plan))
+    assert plan.n_ssc_all_cell_fallbacks == 0
 
 
 @pytest.mark.parametrize("case", ["grid", "series", "fused"])

@@ -5,9 +5,9 @@ Drop-in names for the accelerated path of the reference's Python API
 """
 from . import _lib, extinction, units
 from .model import (ISM, Flux, FluxDict, GaussianJet, Magnetar, MagnetizedTophatJet, Model, Observer, PowerLawJet, PowerLawWing,
-                    Radiation, StepPowerLawJet, TophatJet, TwoComponentJet, Wind, get_context)
+                    Radiation, StepPowerLawJet, TophatJet, TwoComponentJet, Wind, coalescing_stats, get_context, set_coalescing)
 from .fitting import logscale_screen
 
 __all__ = ["ISM", "Wind", "TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing", "MagnetizedTophatJet", "Magnetar", "Observer", "Radiation",
-           "Model", "Flux", "FluxDict", "get_context", "logscale_screen", "extinction", "units"]
+           "Model", "Flux", "FluxDict", "get_context", "set_coalescing", "coalescing_stats", "logscale_screen", "extinction", "units"]
 __version__ = "0.1.0"

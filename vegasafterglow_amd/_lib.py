@@ -96,8 +96,8 @@ class Plan(C.Structure):
                 ("n_models_invalid", C.c_int32), ("n_models_capacity", C.c_int32),
                 ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32),
                 ("n_walkers_rejected", C.c_int32), ("n_walkers_ssc_failed", C.c_int32),
-                ("ic_terms", C.c_int64), ("ic_nodes", C.c_int64), ("n_models_ssc_rebuilt", C.c_int32), ("pad_plan", C.c_int32),
-                ("ic_pool_bytes", C.c_int64)]
+                ("ic_terms", C.c_int64), ("ic_nodes", C.c_int64), ("n_models_ssc_rebuilt", C.c_int32), ("n_ssc_all_cell_fallbacks", C.c_int32),
+                ("ic_pool_bytes", C.c_int64), ("ode_rhs", C.c_int64)]
 
 
 class Limits(C.Structure):
@@ -111,6 +111,7 @@ EXPORTS = [
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
     "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_ctx_coalesce", "vag_ctx_coalesce_stats", "vag_flux_density_grid_coalesced", "vag_flux_density_coalesced", "vag_flux_coalesced",
 ]
 
 _lib = None
@@ -156,6 +157,11 @@ def load():
     lib.vag_flux_components4_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]
     lib.vag_flux_density_batch.argtypes = [v, _pp, C.c_int, _dp, _dp, C.c_int, _dp]
     lib.vag_flux_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp]
+    lib.vag_ctx_coalesce.argtypes = [v, C.c_int, C.c_int]
+    lib.vag_ctx_coalesce_stats.argtypes = [v, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.vag_flux_density_grid_coalesced.argtypes = [v, _pp, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(_dp)]
+    lib.vag_flux_density_coalesced.argtypes = [v, _pp, _dp, _dp, C.c_int, _dp, C.POINTER(_dp)]
+    lib.vag_flux_coalesced.argtypes = [v, _pp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, C.POINTER(_dp)]
     lib.vag_flux_components_batch.argtypes = [v, _pp, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]
     lib.vag_flux_density_grid_batch_dev.argtypes = [v, v, C.c_int, v, C.c_int, v, C.c_int, v]
     lib.vag_flux_density_batch_dev.argtypes = [v, v, C.c_int, v, v, C.c_int, v]

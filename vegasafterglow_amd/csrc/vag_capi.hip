@@ -14,6 +14,8 @@
 #include <vector>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 
 #include "vag_ic_kernels.h"
 #include "vag_kernels.h"
@@ -277,8 +279,19 @@ struct SeriesOcc {
     size_t lds;
     int wg;
 };
+struct CoalesceRequest;
 struct vag_ctx {
     int device = 0;
+    // Every entry point that takes the context locks it for its duration (ApiLock): Model methods release the GIL and are called
+    // from thread pools, one Model per thread (pybind.cpp:424-448, samplers.py:59-70), so the library serialises GPU access itself.
+    std::recursive_mutex api_mutex;
+    // Concurrent single-model calls gathered into batch calls (vag_*_coalesced, opt-in): see the coalescer below
+    std::mutex co_mutex;
+    std::condition_variable co_cv;
+    std::vector<CoalesceRequest*> co_queue;
+    bool co_leader = false;
+    int co_max_batch = 64, co_wait_us = 50;
+    long long co_calls = 0, co_batches = 0;  // requests served / batch calls issued (vag_ctx_coalesce_stats)
     // Likelihood calls evaluate the walkers in descending order of the cost the SAME batch position had in the previous call
     // (dispatch is in batch order: expensive walkers last leave the GPU draining, and neighbours of similar cost diverge less):
     // d_order[cur] maps evaluation slot -> walker; ln L, costs and counters come back in walker order.  A walker's ln L does
@@ -291,16 +304,21 @@ struct vag_ctx {
     // other's walkers, so a few of them are kept (least recently used is replaced), keyed by the fit spec's content hash.
     struct ShardCosts {
         DevBuf cost;
+        DevBuf table;           // the deal of this key's call in flight (between vag_loglike_shard_dev and its finish), kept afterwards for inspection
         uint64_t hash = 0;
         int nb = 0, world = 0;
         bool valid = false;     // a call of this key has finished: `cost` holds its gathered costs
-        unsigned long long used = 0;
+        bool pending = false;   // a call of this key waits for its finish
+        unsigned long long used = 0, dealt = 0;  // clock of the last use / of the pending deal
     };
+    // Deals are kept per key (batch size, world, spec hash), so that other sharded calls on this context between one call's
+    // vag_loglike_shard_dev and its finish -- another sharder of the same process, around ITS all-gather -- leave that call's table
+    // alone (ABI v11; until v10 there was one table per context and the Python side held the context lock across the collective).
     ShardCosts shard_costs[4];
     unsigned long long shard_clock = 0;
     int shard_last = -1;                    // entry of the last finished call (vag_loglike_shard_state_dev reports it)
-    DevBuf d_shard_table, d_shard_theta, d_shard_ll;
-    int shard_cur_nb = 0, shard_cur_world = 0, shard_cur_entry = -1;  // the call between vag_loglike_shard_dev and its finish
+    int shard_last_dealt = -1;              // entry of the last deal
+    DevBuf d_shard_theta, d_shard_ll;
     // device-resident batches whose models differ in their Radiation / shock flags: regrouped by flags (flux_dev_by_flags)
     bool mixed_flags_seen = false;  // the last grid pass stopped on such a batch
     DevBuf d_mix_flags, d_mix_perm, d_mix_params, d_mix_out;
@@ -320,11 +338,12 @@ struct vag_ctx {
     DevBuf d_ichdr, d_icplan, d_icpool, d_icused;
     DevBuf d_icneed;  // [cells] bytes: 1 = some (theta, phi) row's observation window touches the cell (vag_ic_band_kernel)
     bool count_work = false;
+    bool ic_all_cells = false;    // this request's SSC tables are built for every cell (the lazy selection was caught with a hole, see check_ic_status)
     int batch_flags = 0;  // VAG_FLAG_* shared by every model of the current batch
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
     // flux passes always read d_shock, d_cellpar, ...; select_emitter() swaps the reverse shock's buffers in and out.
     DevBuf d_shock_r, d_cellpar_r, d_celldet_r, d_icy_r, d_cellq_r, d_params_rvs, d_inj, d_comp;
-    DevBuf d_fail;     // int[4]: ODE rows per status (1 step underflow, 2 step cap, 3 stalled), reset per batch
+    DevBuf d_fail;     // int[8]: ODE rows per status (1 step underflow, 2 step cap, 3 stalled), [4] right-hand sides evaluated (vag_ctx_count_work), reset per batch
     DevBuf d_cellgeo;  // spreading jets (VAG_FLAG_SPREADING): per-cell cos/sin(theta), log2|dcos|, shared by both shocks
     int cur_emitter = 0;                            // 0 forward, 1 reverse
     bool cur_ssc = false;                           // SSC switch of the selected emitter
@@ -333,6 +352,7 @@ struct vag_ctx {
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
     hipEvent_t ev_handoff = nullptr;  // orders the context's buffers across a change of stream (vag_ctx_set_stream)
+    bool handoff_ready = false;       // ev_handoff marks the tail of the work queued on the current (caller-owned) stream
     // inputs
     DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
     // grid results
@@ -406,6 +426,14 @@ struct StageScope {
 extern "C" {
 
 const char* vag_last_error(void) { return g_err.c_str(); }
+struct ApiLock {  // (a null context is rejected by the entry point itself)
+    std::recursive_mutex* m;
+    explicit ApiLock(vag_ctx* c);
+    ~ApiLock() {
+        if (m) m->unlock();
+    }
+    ApiLock(const ApiLock&) = delete;
+};
 const char* vag_version(void) { return "vegasafterglow_amd 0.1 (gfx950)"; }
 int vag_abi_version(void) { return VAG_ABI_VERSION; }
 
@@ -534,6 +562,10 @@ static int ctx_init(vag_ctx* c) {
 
 extern "C" {
 
+ApiLock::ApiLock(vag_ctx* c) : m(c ? &c->api_mutex : nullptr) {
+    if (m) m->lock();
+}
+
 int vag_ctx_create(int device, vag_ctx** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -570,7 +602,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
-    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->d_shard_table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo, &c->d_icneed})
+    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->shard_costs[0].table, &c->shard_costs[1].table, &c->shard_costs[2].table, &c->shard_costs[3].table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo, &c->d_icneed})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -581,6 +613,7 @@ void vag_ctx_destroy(vag_ctx* c) {
 }
 
 int vag_ctx_set_stream(vag_ctx* c, void* s) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     hipStream_t next;
     if (s == VAG_STREAM_LEGACY_DEFAULT)
@@ -590,19 +623,36 @@ int vag_ctx_set_stream(vag_ctx* c, void* s) {
     if (next != c->stream) {
         // The context's scratch buffers (parameters, grid results, shock arrays, deal tables ...) are reused by every call, so
         // work queued on the stream the context leaves must be ordered before anything the next stream does with them: an event
-        // at the tail of the old stream, waited for by the new one.  No host synchronisation.  The old stream must still exist
-        // when it is handed back (a failure to record on it is ignored: nothing can be in flight on a destroyed stream).
+        // at the tail of the old stream, waited for by the new one.  No host synchronisation.
         (void)hipSetDevice(c->device);
-        if (hipEventRecord(c->ev_handoff, c->stream) == hipSuccess)
-            (void)hipStreamWaitEvent(next, c->ev_handoff, 0);
-        else
-            (void)hipGetLastError();
+        const bool foreign = c->stream != nullptr && c->stream != c->own_stream;
+        if (!foreign) {  // the context's own stream / the legacy default stream: always alive, the event is recorded here
+            if (hipEventRecord(c->ev_handoff, c->stream) != hipSuccess) return set_err(VAG_E_HIP, "vag_ctx_set_stream: event record failed");
+            c->handoff_ready = true;
+        }
+        // a caller-owned stream may have been destroyed since its last call (legal: nothing can be in flight on it then), so it is
+        // never touched here: every device-resident entry point records the event at its own end, while the stream is known to be
+        // alive (HandoffScope), and the host-buffer entry points end with a synchronisation
+        if (c->handoff_ready && hipStreamWaitEvent(next, c->ev_handoff, 0) != hipSuccess)
+            return set_err(VAG_E_HIP, "vag_ctx_set_stream: the new stream cannot wait for the work queued on the old one");
+        c->handoff_ready = false;
         c->stream = next;
     }
     return VAG_OK;
 }
 
+// At the end of an entry point that leaves work in flight on a caller-owned stream: the hand-off event of vag_ctx_set_stream
+struct HandoffScope {
+    vag_ctx* c;
+    explicit HandoffScope(vag_ctx* ctx) : c(ctx) {}
+    ~HandoffScope() {
+        if (c && c->stream != nullptr && c->stream != c->own_stream)
+            c->handoff_ready = hipEventRecord(c->ev_handoff, c->stream) == hipSuccess;
+    }
+};
+
 int vag_ctx_get_stream(vag_ctx* c, void** out) {
+    ApiLock api_lock(c);
     if (!c || !out) return set_err(VAG_E_INVALID, "null context or pointer");
     if (c->stream == c->own_stream)
         *out = nullptr;
@@ -612,18 +662,20 @@ int vag_ctx_get_stream(vag_ctx* c, void** out) {
 }
 
 int vag_ctx_count_work(vag_ctx* c, int enable) {
+    ApiLock api_lock(c);
     c->count_work = enable != 0;
     return VAG_OK;
 }
 
 static int read_row_failures(vag_ctx* c) {
-    int f[4] = {0, 0, 0, 0};
+    int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c->d_fail.p && c->n_rows > 0) {
         HIPCHK(hipMemcpyAsync(f, c->d_fail.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     c->plan.n_rows_failed = f[1];
     c->plan.n_rows_gave_up = f[2] + f[3];
+    c->plan.ode_rhs = f[4];
     if (c->fit_stats_pending && c->d_fitstat.p) {  // the last likelihood call's tallies over ALL of its passes
         int fs[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(fs, c->d_fitstat.p, sizeof fs, hipMemcpyDeviceToHost, c->stream));
@@ -636,24 +688,28 @@ static int read_row_failures(vag_ctx* c) {
 }
 
 int vag_last_plan(vag_ctx* c, vag_plan* out) {
+    ApiLock api_lock(c);
     const int rc = read_row_failures(c);
     *out = c->plan;
     return rc;
 }
 
 int vag_ctx_synchronize(vag_ctx* c) {
+    ApiLock api_lock(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     return VAG_OK;
 }
 
 static int collect_times_fwd(vag_ctx* c);
 int vag_ctx_profile(vag_ctx* c, int enable) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     c->prof_on = enable != 0;
     return VAG_OK;
 }
 
 int vag_last_profile(vag_ctx* c, vag_profile* out) {
+    ApiLock api_lock(c);
     if (!c || !out) return set_err(VAG_E_INVALID, "null context or output");
     HIPCHK(hipStreamSynchronize(c->stream));
     double acc[PS_COUNT] = {0};
@@ -673,6 +729,7 @@ int vag_last_profile(vag_ctx* c, vag_profile* out) {
 }
 
 int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
+    ApiLock api_lock(c);
     // measured with HIP events recorded on the context stream around each kernel of the last batch call
     const int rc = collect_times_fwd(c);
     *out = c->times;
@@ -813,7 +870,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
-    if (c->d_fail.ensure(sizeof(int) * 4)) return VAG_E_HIP;
+    if (c->d_fail.ensure(sizeof(int) * 8)) return VAG_E_HIP;
 
     // Grid shapes decide the compact layout and the launch geometry of everything downstream.  The last wavefront of
     // vag_grid_kernel scans them on the device and publishes an 80-byte summary in pinned host memory; the host spins on its
@@ -955,8 +1012,8 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
         const int rpw = dyn_rows_per_wave(rows);
-        hipLaunchKernelGGL(vag_dynamics_fast_kernel, dim3((rows + rpw - 1) / rpw), dim3(128), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
+        hipLaunchKernelGGL(c->count_work ? vag_dynamics_fast_kernel<true> : vag_dynamics_fast_kernel<false>, dim3((rows + rpw - 1) / rpw),
+                           dim3(128), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>(),
                            c->d_sptab.as<double>(), rpw, c->d_fail.as<int>());
     } else {
@@ -1271,7 +1328,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * band_stride)) return VAG_E_HIP;
     if (c->d_ichdr.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_HDR)) return VAG_E_HIP;
     if (c->d_icplan.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_PLAN)) return VAG_E_HIP;
-    if (c->d_icused.ensure(sizeof(unsigned long long))) return VAG_E_HIP;
+    if (c->d_icused.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
     if (c->d_icpool.ensure(sizeof(double) * 1024)) return VAG_E_HIP;  // (never null: the empty tables point at its first words)
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
     if (c->d_icunclamp.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
@@ -1296,7 +1353,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         // (A likelihood call keeps every table: there a model's SSC status folds into the walker's score -- ic_soft_fail, -inf -- so a cell
         // wrongly left without a table would be a silent wrong answer instead of VAG_E_INTERNAL; round 4's sweeps found two such holes
         // in the range test, both on grid requests, both loud.)
-        if (!std::getenv("VAG_IC_ALL_CELLS") && c->d_tminmax.p && !c->ic_soft_fail) {
+        if (!std::getenv("VAG_IC_ALL_CELLS") && !c->ic_all_cells && c->d_tminmax.p && !c->ic_soft_fail) {
             if (c->d_icneed.ensure((size_t)std::max<long long>(c->n_cells, 1))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icneed.p, 0, (size_t)std::max<long long>(c->n_cells, 1), st));
             d_need = c->d_icneed.as<unsigned char>();
@@ -1311,25 +1368,46 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icwork.p, 0, 2 * sizeof(unsigned long long), st));
         }
-        const unsigned long long pool_first = 2;  // the pool's first two words serve the gathers of the cells without a table
-        HIPCHK(hipMemcpyAsync(c->d_icused.p, &pool_first, sizeof pool_first, hipMemcpyHostToDevice, st));
+        // {doubles of the pool in use: its first two words serve the gathers of the cells without a table; plan records written}
+        static const unsigned long long ic_counters_start[2] = {2, 0};
+        HIPCHK(hipMemcpyAsync(c->d_icused.p, ic_counters_start, sizeof ic_counters_start, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
                            c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icused.as<unsigned long long>(),
                            c->d_icstatus.as<int>(), c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need);
         HIPCHK(hipGetLastError());
         // The pool grows to what the plan handed out (grow-only: in a sampler's loop it stops growing after a few calls).  The host has
-        // to see the total before the spectrum kernel may write: one 8-byte copy and a wait per table build (~20 us against the
-        // milliseconds of the build; an SSC pass ends with such a wait anyway, check_ic_status).
-        unsigned long long pool_used = 0;
-        HIPCHK(hipMemcpyAsync(&pool_used, c->d_icused.p, sizeof pool_used, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (c->d_icpool.ensure(sizeof(double) * (size_t)(pool_used + pool_used / 16 + 1024))) return VAG_E_HIP;
-        c->plan.ic_pool_bytes = std::max<long long>(c->plan.ic_pool_bytes, (long long)(sizeof(double) * pool_used));
-        hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)c->n_cells), dim3(64), 0, st, d_params, nb,
-                           c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_icy.as<double>(),
-                           c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_sptab.as<double>(),
-                           c->d_knlut.as<double>(), c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icpool.as<double>());
+        // to see the total before the spectrum kernel may write: one 16-byte copy and a wait per table build (~20 us against the
+        // milliseconds of the build; a grid / series SSC pass ends with such a wait anyway, check_ic_status).  A LIKELIHOOD call has no
+        // host wait anywhere in its SSC stage (its table status folds into the walker's score on the device), so it does not get one
+        // here either: the pool is sized for the worst case -- every cell a table of IC_MAX_OUT nodes -- once, the launch covers every
+        // cell and the kernel reads the record count from HBM.  (Beyond 32 GB of worst case the wait is taken after all.)
+        const unsigned long long worst = (unsigned long long)std::max<long long>(c->n_cells, 1) * IC_MAX_OUT + 1024;
+        const bool no_wait = c->ic_soft_fail && worst * sizeof(double) <= (32ull << 30) && !std::getenv("VAG_IC_POOL_READBACK");
+        long long n_run = c->n_cells;  // launch size (an upper bound when the host has not seen the count)
+        if (no_wait) {
+            if (c->d_icpool.ensure(sizeof(double) * (size_t)worst)) return VAG_E_HIP;
+        } else {
+            unsigned long long ic_counters[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(ic_counters, c->d_icused.p, sizeof ic_counters, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const unsigned long long pool_used = ic_counters[0];
+            n_run = (long long)ic_counters[1];  // cells that get a table: one plan record each
+            if (c->d_icpool.ensure(sizeof(double) * (size_t)(pool_used + pool_used / 16 + 1024))) return VAG_E_HIP;
+            c->plan.ic_pool_bytes = std::max<long long>(c->plan.ic_pool_bytes, (long long)(sizeof(double) * pool_used));
+        }
+        // one wavefront per plan record (= per cell that gets a table); -DVAG_IC_PERSISTENT=1 developer builds: as many wavefronts as the
+        // device holds at the kernel's four per SIMD, each taking the records w, w + G, ...
+        long long ic_waves = n_run;
+#if VAG_IC_PERSISTENT
+        ic_waves = (long long)c->n_cus * 4 * VAG_IC_WAVES;
+        if (const char* e = std::getenv("VAG_IC_GRID")) ic_waves = std::max(1, std::atoi(e));  // developer aid
+#endif
+        if (n_run > 0)
+        hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)std::min<long long>(n_run, ic_waves)), dim3(64), 0, st,
+                           IcPhotonArgs{n_run, no_wait ? c->d_icused.as<unsigned long long>() + 1 : nullptr, c->n_cells, c->d_icy.as<double>(),
+                                        c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_sptab.as<double>(), c->d_knlut.as<double>(),
+                                        c->d_icplan.as<double>(), c->d_icpool.as<double>()});
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             unsigned long long h[2] = {0, 0};
@@ -1344,38 +1422,73 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
 
 // > 0: not an error code of the C-ABI -- a flux pass breached a clamped band, the caller rebuilds those tables unclamped and repeats
 constexpr int VAG_IC_REBUILD = 1000;
+// > 0 as well: a flux pass queried a cell the lazy selection (vag_ic_band_kernel's range test: a superset of the queried cells by
+// construction, but round 4's sweeps met two holes in it) had left without a table.  The caller builds EVERY cell's table and repeats the
+// pass -- the answer the reference gives -- and the event is counted (vag_plan.n_ssc_all_cell_fallbacks); VAG_E_INTERNAL only if the
+// all-cells pass reports a missing table too.
+constexpr int VAG_IC_REBUILD_ALL = 1001;
 int check_ic_status(vag_ctx* c, int nb) {
     if (c->ic_soft_fail) return VAG_OK;  // vag_fit_back_kernel folds d_icstatus into the walker's validity (-inf), samplers.py:61-70
     hipStream_t st = c->stream;
     std::vector<int> h(nb);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_icstatus.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    bool breach = false;
+    bool breach = false, hole = false;
     for (int m = 0; m < nb; ++m) {
         if (h[m] & 1) return set_err(VAG_E_CAPACITY, "model %d: SSC lattices exceed the engine limits", m);
-        if (h[m] & 4) return set_err(VAG_E_INTERNAL, "model %d: a flux pass queried an SSC cell that was given no table", m);
+        if (h[m] & 4) {
+            if (c->ic_all_cells) return set_err(VAG_E_INTERNAL, "model %d: a flux pass queried an SSC cell that was given no table", m);
+            hole = true;
+        }
+    }
+    if (hole) {
+        ++c->plan.n_ssc_all_cell_fallbacks;
+        if (std::getenv("VAG_DEBUG_IC_NO_FALLBACK"))  // test hook: the loud answer itself
+            return set_err(VAG_E_INTERNAL, "a flux pass queried an SSC cell that was given no table (fallback disabled)");
+        return VAG_IC_REBUILD_ALL;
+    }
+    for (int m = 0; m < nb; ++m)
         if (h[m] & 2) {
             breach = true;
             ++c->plan.n_models_ssc_rebuilt;
         }
-    }
     return breach ? VAG_IC_REBUILD : VAG_OK;
+}
+
+// The attempts of one SSC flux pass: lazily selected tables -> (a hole in the selection: every cell's table) -> (a breach of a
+// clamped band: those models' tables unclamped).  `pass(rebuild)` builds the tables and runs the flux pass; returns the C-ABI code.
+template <class Pass>
+int ssc_attempts(vag_ctx* c, int nb, Pass pass) {
+    struct Reset {
+        vag_ctx* c;
+        ~Reset() { c->ic_all_cells = false; }
+    } reset{c};
+    bool rebuild = false;
+    int rc = VAG_OK;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = pass(rebuild);
+        if (rc) return rc;
+        rc = check_ic_status(c, nb);
+        if (rc == VAG_IC_REBUILD_ALL) {
+            c->ic_all_cells = true;
+            rebuild = false;
+        } else if (rc == VAG_IC_REBUILD) {
+            rebuild = true;
+        } else {
+            return rc;
+        }
+    }
+    return set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
 }
 
 // d_lg2nu_all / nnu_all: every frequency of the request (the seed band is clamped over all of them, also when the
 // frequency axis is evaluated in chunks)
 int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
                  int nnu, const double* d_bandw, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
-    int rc = VAG_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, attempt > 0);
-        if (rc) return rc;
-        rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
-        if (rc) return rc;
-        rc = check_ic_status(c, nb);
-        if (rc != VAG_IC_REBUILD) return rc;
-    }
-    return set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
+    return ssc_attempts(c, nb, [&](bool rebuild) {
+        const int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, rebuild);
+        return rc ? rc : run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_ssc, FLUX_SSC);
+    });
 }
 
 // Synchrotron (IC-cooled) and SSC components of one emitter in ONE flux pass: the tables are built first, then both
@@ -1394,16 +1507,10 @@ static bool fused_fits(vag_ctx* c, int nt, int nnu) {
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
                    int nnu, const double* d_bandw, double* d_syn, double* d_ssc, const double* d_lg2nu_all, int nnu_all) {
-    int rc = VAG_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, attempt > 0);
-        if (rc) return rc;
-        rc = run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
-        if (rc) return rc;
-        rc = check_ic_status(c, nb);
-        if (rc != VAG_IC_REBUILD) return rc;
-    }
-    return set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
+    return ssc_attempts(c, nb, [&](bool rebuild) {
+        const int rc = build_ssc_tables(c, d_params, nb, d_lg2nu_all, nnu_all, rebuild);
+        return rc ? rc : run_flux_grid(c, d_params, nb, d_lg2t, nt, d_lg2nu, nnu, d_bandw, d_syn, FLUX_FUSED, d_ssc);
+    });
 }
 
 __global__ void vag_copy_kernel(double* __restrict__ out, const double* __restrict__ src, size_t n) {
@@ -1647,6 +1754,20 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             const size_t lds = fit_rows_lds_bytes(n);
             const bool spread = (c->batch_flags & VAG_FLAG_SPREADING) != 0;
             a.cellgeo = c->d_cellgeo.as<double>();
+            // vag_ctx_count_work: the tallying instantiation (plain synchrotron, <= 4 bands, no spreading: the walker metric's case)
+            const bool tally = c->count_work && mode == FLUX_SYN && !spread && n_bands <= 4;
+            if (tally) {
+                if (c->d_workcount.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
+                HIPCHK(hipMemsetAsync(c->d_workcount.p, 0, 2 * sizeof(unsigned long long), st));
+                a.tally = c->d_workcount.as<unsigned long long>();
+                hipLaunchKernelGGL((vag_flux_fit_rows_kernel<FLUX_SYN, 4, false, true>), g, b, lds, st, a);
+                HIPCHK(hipGetLastError());
+                unsigned long long hcount[2] = {0, 0};
+                HIPCHK(hipMemcpyAsync(hcount, c->d_workcount.p, sizeof hcount, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                c->plan.spec_evals = (long long)hcount[0];
+                c->plan.interps = (long long)hcount[1];
+            } else
 #define VAG_FIT_LAUNCH(M_)                                                                      \
     do {                                                                                        \
         if (spread && n_bands <= 4)                                                             \
@@ -1658,12 +1779,14 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         else                                                                                    \
             hipLaunchKernelGGL((vag_flux_fit_rows_kernel<M_, 8>), g, b, lds, st, a);             \
     } while (0)
+            {
             if (mode == FLUX_SYN_IC)
                 VAG_FIT_LAUNCH(FLUX_SYN_IC);
-            else if (mode == FLUX_SSC)
-                VAG_FIT_LAUNCH(FLUX_SSC);
-            else
+            else if (mode == FLUX_SYN)
                 VAG_FIT_LAUNCH(FLUX_SYN);
+            else
+                VAG_FIT_LAUNCH(FLUX_SSC);
+            }
 #undef VAG_FIT_LAUNCH
             HIPCHK(hipGetLastError());
         }
@@ -1813,13 +1936,10 @@ int series_chunk(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
             if (pass == 0) {
                 rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, c->cur_ssc ? FLUX_SYN_IC : FLUX_SYN, n_bands);
             } else {
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                    rc = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all, attempt > 0);
-                    if (rc == VAG_OK) rc = run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC, n_bands);
-                    if (rc == VAG_OK) rc = check_ic_status(c, nb);
-                    if (rc != VAG_IC_REBUILD) break;
-                }
-                if (rc == VAG_IC_REBUILD) rc = set_err(VAG_E_NUMERIC, "SSC query outside the band of an unclamped table");
+                rc = ssc_attempts(c, nb, [&](bool rebuild) {
+                    const int rb = build_ssc_tables(c, c->cur_params, nb, d_lg2nu_all, n_all, rebuild);
+                    return rb ? rb : run_flux_series(c, c->cur_params, nb, d_lg2t, d_lg2nu, n, dst, FLUX_SSC, n_bands);
+                });
             }
             if (rc) break;
             if (d_out) {
@@ -2094,6 +2214,8 @@ static int grid_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb, c
 
 int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t, int nt,
                                     const double* d_nu, int nnu, double* d_out) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
     HIPCHK(hipSetDevice(c->device));
@@ -2155,6 +2277,8 @@ static int series_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb,
 
 int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_t,
                                const double* d_nu, int n, double* d_out) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
     HIPCHK(hipSetDevice(c->device));
@@ -2171,6 +2295,7 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
 
 int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
                                 const double* nu, int nnu, double* out) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
     int rc = check_host_inputs(params, nb, t, nt);
@@ -2237,18 +2362,21 @@ static int grid_components_impl(vag_ctx* c, const vag_model_params* params, int 
 
 int vag_flux_density_grid_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
                                            const double* nu, int nnu, double* out_sync, double* out_ssc) {
+    ApiLock api_lock(c);
     double* out4[4] = {out_sync, out_ssc, nullptr, nullptr};
     return grid_components_impl(c, params, nb, t, nt, nu, nnu, out4);
 }
 
 int vag_flux_density_grid_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt,
                                             const double* nu, int nnu, double* const* out4) {
+    ApiLock api_lock(c);
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
     return grid_components_impl(c, params, nb, t, nt, nu, nnu, out4);
 }
 
 int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu, int n,
                            double* out) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     int rc = check_host_inputs(params, nb, t, n);
     if (rc) return rc;
@@ -2279,6 +2407,7 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
 // receives component i of {fwd.sync, fwd.ssc, rvs.sync, rvs.ssc} [nb][n]; disabled components come back as zeros.
 int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, const double* nu,
                                        int n, double* const* out4) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
     int rc = check_host_inputs(params, nb, t, n);
@@ -2437,17 +2566,20 @@ static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, co
 
 int vag_flux_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                    double nu_max, int num_nu, double* out) {
+    ApiLock api_lock(c);
     return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, out, nullptr);
 }
 
 int vag_flux_components_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                               double nu_max, int num_nu, double* out_sync, double* out_ssc) {
+    ApiLock api_lock(c);
     double* out4[4] = {out_sync, out_ssc, nullptr, nullptr};
     return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, nullptr, out4);
 }
 
 int vag_flux_components4_batch(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                                double nu_max, int num_nu, double* const* out4) {
+    ApiLock api_lock(c);
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
     return flux_band_impl(c, params, nb, t, nt, nu_min, nu_max, num_nu, nullptr, out4);
 }
@@ -2808,6 +2940,8 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
 }
 
 int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta, int nb, int ndim, double* d_out) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     HIPCHK(hipSetDevice(c->device));
@@ -2827,6 +2961,8 @@ __global__ void vag_model_cost_kernel(const VagGridMeta* __restrict__ meta, int 
 }
 
 int vag_last_model_costs_dev(vag_ctx* c, int nb, double* d_cost) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c || !d_cost) return set_err(VAG_E_INVALID, "null context or buffer");
     if (nb <= 0 || nb != c->nb || !c->d_meta.p) return set_err(VAG_E_INVALID, "no batch of %d models has been evaluated on this context", nb);
     HIPCHK(hipSetDevice(c->device));
@@ -2910,6 +3046,8 @@ vag_shard_finish_kernel(const double* __restrict__ gathered, const int* __restri
 
 int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
                           double* d_block) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c || !spec || !d_theta_all || !d_block) return set_err(VAG_E_INVALID, "null context, spec or buffer");
     if (nb_all <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     if (world <= 0 || rank < 0 || rank >= world) return set_err(VAG_E_INVALID, "rank %d outside a world of %d", rank, world);
@@ -2922,7 +3060,6 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
         const int k = (s & 1) ? world - 1 - rank : rank;
         if ((long long)s * world + k < nb_all) ++n_mine;
     }
-    if (c->d_shard_table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
     if (c->d_shard_theta.ensure(sizeof(double) * (size_t)per * ndim)) return VAG_E_HIP;
     if (c->d_shard_ll.ensure(sizeof(double) * (size_t)per)) return VAG_E_HIP;
     // every rank needs the same deal, whether or not it holds a walker: the key of the costs is the spec's content hash
@@ -2930,13 +3067,15 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
         const int rc = upload_fit_spec(c, spec, ndim);
         if (rc) return rc;
     }
-    int entry = -1, victim = 0;
+    int entry = -1, victim = -1;
     for (int i = 0; i < 4; ++i) {
         const vag_ctx::ShardCosts& e = c->shard_costs[i];
         if (e.nb == nb_all && e.world == world && e.hash == c->fit_hash) entry = i;
-        if (e.used < c->shard_costs[victim].used) victim = i;
+        if (!e.pending && (victim < 0 || e.used < c->shard_costs[victim].used)) victim = i;
     }
+    // (a key that is dealt again before its finish is simply dealt anew: the earlier block never went through a finish)
     if (entry < 0) {
+        if (victim < 0) return set_err(VAG_E_INVALID, "four sharded calls wait for their finish on this context");
         entry = victim;
         c->shard_costs[entry].nb = nb_all;
         c->shard_costs[entry].world = world;
@@ -2948,18 +3087,22 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     const bool ranked = c->shard_costs[entry].valid && nb_all <= 16384;
     c->shard_costs[entry].used = ++c->shard_clock;
     if (c->shard_costs[entry].cost.ensure(sizeof(double) * (size_t)nb_all)) return VAG_E_HIP;
+    if (c->shard_costs[entry].table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
     hipLaunchKernelGGL(vag_shard_deal_kernel, dim3((world * per + 3) / 4), dim3(256), 0, c->stream,
                        ranked ? c->shard_costs[entry].cost.as<double>() : nullptr, d_theta_all, nb_all, ndim, rank, world, per,
-                       c->d_shard_table.as<int>(), c->d_shard_theta.as<double>());
+                       c->shard_costs[entry].table.as<int>(), c->d_shard_theta.as<double>());
     HIPCHK(hipGetLastError());
-    c->shard_cur_nb = nb_all;
-    c->shard_cur_world = world;
-    c->shard_cur_entry = entry;
+    c->shard_costs[entry].pending = true;
+    c->shard_costs[entry].dealt = c->shard_clock;
+    c->shard_last_dealt = entry;
     const int* d_order = nullptr;
     if (n_mine > 0) {
         int rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), !c->count_work);
         if (rc == VAG_RETRY) rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), false);
-        if (rc) return rc;
+        if (rc) {
+            c->shard_costs[entry].pending = false;  // (no block went out: there is nothing to finish)
+            return rc;
+        }
         d_order = c->order_active ? c->last_order : nullptr;
     }
     hipLaunchKernelGGL(vag_shard_pack_kernel, dim3((per + 127) / 128), dim3(128), 0, c->stream, c->d_shard_ll.as<double>(),
@@ -2969,29 +3112,41 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
 }
 
 int vag_loglike_shard_finish_dev(vag_ctx* c, const double* d_gathered, int nb_all, int world, double* d_out) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c || !d_gathered || !d_out) return set_err(VAG_E_INVALID, "null context or buffer");
-    if (nb_all != c->shard_cur_nb || world != c->shard_cur_world || nb_all <= 0 || c->shard_cur_entry < 0)
+    // the oldest pending deal of this shape: calls of equal shape finish in the order they were dealt (their all-gathers must run in one
+    // order on every rank anyway)
+    int entry = -1;
+    for (int i = 0; i < 4 && nb_all > 0; ++i) {
+        const vag_ctx::ShardCosts& e = c->shard_costs[i];
+        if (e.pending && e.nb == nb_all && e.world == world && (entry < 0 || e.dealt < c->shard_costs[entry].dealt)) entry = i;
+    }
+    if (entry < 0)
         return set_err(VAG_E_INVALID, "no vag_loglike_shard_dev call of %d walkers over %d ranks is waiting for its finish", nb_all, world);
     HIPCHK(hipSetDevice(c->device));
     const int per = (nb_all + world - 1) / world;
-    hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, c->d_shard_table.as<int>(), world * per,
-                       d_out, c->shard_costs[c->shard_cur_entry].cost.as<double>());
+    hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, c->shard_costs[entry].table.as<int>(), world * per,
+                       d_out, c->shard_costs[entry].cost.as<double>());
     HIPCHK(hipGetLastError());
-    c->shard_costs[c->shard_cur_entry].valid = true;
-    c->shard_last = c->shard_cur_entry;
-    c->shard_cur_nb = c->shard_cur_world = 0;
-    c->shard_cur_entry = -1;
+    c->shard_costs[entry].valid = true;
+    c->shard_costs[entry].pending = false;
+    c->shard_last = entry;
     return VAG_OK;
 }
 
 int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_table, double* d_cost) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     const int per = world > 0 ? (nb_all + world - 1) / world : 0;
-    if (nb_all <= 0 || world <= 0 || c->d_shard_table.cap < sizeof(int) * (size_t)world * per)
+    const int ld = c->shard_last_dealt;
+    if (nb_all <= 0 || world <= 0 || ld < 0 || c->shard_costs[ld].nb != nb_all || c->shard_costs[ld].world != world ||
+        c->shard_costs[ld].table.cap < sizeof(int) * (size_t)world * per)
         return set_err(VAG_E_INVALID, "no deal of %d walkers over %d ranks on this context", nb_all, world);
     HIPCHK(hipSetDevice(c->device));
     if (d_table)
-        HIPCHK(hipMemcpyAsync(d_table, c->d_shard_table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_table, c->shard_costs[ld].table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
     if (d_cost) {
         if (c->shard_last < 0 || !c->shard_costs[c->shard_last].valid || c->shard_costs[c->shard_last].nb != nb_all || c->shard_costs[c->shard_last].world != world)
             return set_err(VAG_E_INVALID, "no finished sharded call of %d walkers over %d ranks on this context", nb_all, world);
@@ -3001,6 +3156,7 @@ int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_ta
 }
 
 int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     HIPCHK(hipSetDevice(c->device));
@@ -3015,6 +3171,179 @@ int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta,
     (void)collect_times(c);
     return VAG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Coalescer (ABI v11, opt-in): the reference's own calling pattern is a thread pool with one Model per thread and the GIL released
+// inside the compute methods (pybind/pybind.cpp:424-448; VegasAfterglow/fitting/samplers.py:59-70 maps eval_one over a
+// ThreadPoolExecutor).  Serialised on one GPU context that pattern runs at one light curve per call latency.  The *_coalesced entry
+// points take ONE model each, block the calling thread, and gather the calls that are waiting at the same time -- same request
+// (method, times, frequencies / band) -- into one batch call of the ordinary entry point; every caller gets its own model's slice.
+// Group commit: the first caller to find no batch forming becomes the leader, waits up to co_wait_us for company (none needed while
+// the GPU is busy: whoever arrives during a batch call is queued for the next one), runs the batch under the context lock, hands
+// the results out and promotes the next leader.  A batch that fails as a whole (one member's grid over capacity, say) is repeated
+// member by member, so a caller only ever sees the error of its own model.
+// ------------------------------------------------------------------------------------------------
+struct CoalesceRequest {
+    int kind;  // 0 grid, 1 series, 2 band; +4: components form (out4) instead of the total (out)
+    const vag_model_params* p;
+    const double *t, *nu;
+    int nt, nnu;  // series: nnu == nt
+    double nu_min, nu_max;
+    int num_nu;
+    double* out;
+    double* const* out4;
+    int rc = VAG_OK;
+    std::string err;
+    bool done = false, promoted = false;
+    bool same_request(const CoalesceRequest& o) const {
+        if (kind != o.kind || nt != o.nt || nnu != o.nnu) return false;
+        if ((kind & 3) == 2) return nu_min == o.nu_min && nu_max == o.nu_max && num_nu == o.num_nu && (t == o.t || !std::memcmp(t, o.t, sizeof(double) * nt));
+        return (t == o.t || !std::memcmp(t, o.t, sizeof(double) * nt)) && (nu == o.nu || !std::memcmp(nu, o.nu, sizeof(double) * nnu));
+    }
+    size_t out_len() const { return (kind & 3) == 0 ? (size_t)nt * nnu : (size_t)nt; }
+};
+
+static int coalesce_run_one(vag_ctx* c, CoalesceRequest& r, const vag_model_params* params, int nb, double* out, double* const* out4) {
+    switch (r.kind) {
+        case 0: return vag_flux_density_grid_batch(c, params, nb, r.t, r.nt, r.nu, r.nnu, out);
+        case 4: return vag_flux_density_grid_components4_batch(c, params, nb, r.t, r.nt, r.nu, r.nnu, out4);
+        case 1: return vag_flux_density_batch(c, params, nb, r.t, r.nu, r.nt, out);
+        case 5: return vag_flux_density_components4_batch(c, params, nb, r.t, r.nu, r.nt, out4);
+        case 2: return vag_flux_batch(c, params, nb, r.t, r.nt, r.nu_min, r.nu_max, r.num_nu, out);
+        default: return vag_flux_components4_batch(c, params, nb, r.t, r.nt, r.nu_min, r.nu_max, r.num_nu, out4);
+    }
+}
+
+static void coalesce_serve(vag_ctx* c, std::vector<CoalesceRequest*>& batch) {
+    const int nb = (int)batch.size();
+    CoalesceRequest& lead = *batch[0];
+    const size_t len = lead.out_len();
+    bool ok = false;
+    if (nb > 1) {
+        std::vector<vag_model_params> params(nb);
+        for (int i = 0; i < nb; ++i) params[i] = *batch[i]->p;
+        const bool comps = (lead.kind & 4) != 0;
+        bool want[4] = {!comps, false, false, false};
+        if (comps)
+            for (int q = 0; q < 4; ++q)
+                for (int i = 0; i < nb; ++i) want[q] = want[q] || batch[i]->out4[q] != nullptr;
+        std::vector<double> buf[4];
+        double* o4[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int q = 0; q < 4; ++q)
+            if (want[q]) {
+                buf[q].resize((size_t)nb * len);
+                o4[q] = buf[q].data();
+            }
+        const int rc = coalesce_run_one(c, lead, params.data(), nb, o4[0], o4);
+        if (rc == VAG_OK) {
+            for (int i = 0; i < nb; ++i) {
+                if (comps) {
+                    for (int q = 0; q < 4; ++q)
+                        if (batch[i]->out4[q]) std::memcpy(batch[i]->out4[q], o4[q] + (size_t)i * len, sizeof(double) * len);
+                } else {
+                    std::memcpy(batch[i]->out, o4[0] + (size_t)i * len, sizeof(double) * len);
+                }
+                batch[i]->rc = VAG_OK;
+            }
+            ok = true;
+        }
+    }
+    if (!ok)  // alone, or the batch failed as a whole: every member on its own, with its own error
+        for (int i = 0; i < nb; ++i) {
+            CoalesceRequest& r = *batch[i];
+            r.rc = coalesce_run_one(c, r, r.p, 1, r.out, r.out4);
+            if (r.rc) r.err = g_err;
+        }
+}
+
+static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
+    std::unique_lock<std::mutex> lk(c->co_mutex);
+    c->co_queue.push_back(&req);
+    ++c->co_calls;
+    bool leader = false;
+    if (!c->co_leader) {
+        c->co_leader = leader = true;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c->co_wait_us);
+        while ((int)c->co_queue.size() < c->co_max_batch && c->co_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
+    } else {
+        c->co_cv.notify_all();  // (the leader counts the queue)
+        c->co_cv.wait(lk, [&] { return req.done || req.promoted; });
+        if (req.done) {
+            if (req.rc) g_err = req.err;
+            return req.rc;
+        }
+        leader = true;  // promoted: this request heads the next batch, no waiting for company (the queue filled during the last call)
+    }
+    // the leader's batch: its own request and every queued one that asks the same thing, in arrival order
+    std::vector<CoalesceRequest*> batch{&req};
+    std::vector<CoalesceRequest*> rest;
+    for (CoalesceRequest* r : c->co_queue) {
+        if (r == &req) continue;
+        if ((int)batch.size() < c->co_max_batch && r->same_request(req))
+            batch.push_back(r);
+        else
+            rest.push_back(r);
+    }
+    c->co_queue.swap(rest);
+    ++c->co_batches;
+    lk.unlock();
+    coalesce_serve(c, batch);  // (takes the context lock inside the entry points)
+    lk.lock();
+    for (CoalesceRequest* r : batch)
+        if (r != &req) r->done = true;
+    if (!c->co_queue.empty())
+        c->co_queue.front()->promoted = true;  // stays the leader-in-waiting: co_leader remains set
+    else
+        c->co_leader = false;
+    c->co_cv.notify_all();
+    lk.unlock();
+    if (req.rc) g_err = req.err;
+    (void)leader;
+    return req.rc;
+}
+
+int vag_ctx_coalesce(vag_ctx* c, int max_batch, int wait_us) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (max_batch < 1 || wait_us < 0) return set_err(VAG_E_INVALID, "max_batch must be >= 1 and wait_us >= 0");
+    std::lock_guard<std::mutex> lk(c->co_mutex);
+    c->co_max_batch = max_batch;
+    c->co_wait_us = wait_us;
+    return VAG_OK;
+}
+
+int vag_ctx_coalesce_stats(vag_ctx* c, long long* calls, long long* batches) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(c->co_mutex);
+    if (calls) *calls = c->co_calls;
+    if (batches) *batches = c->co_batches;
+    return VAG_OK;
+}
+
+int vag_flux_density_grid_coalesced(vag_ctx* c, const vag_model_params* p, const double* t, int nt, const double* nu, int nnu, double* out,
+                                    double* const* out4) {
+    if (!c || !p || !t || !nu || (!out && !out4)) return set_err(VAG_E_INVALID, "null context, model or buffer");
+    if (nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "time and frequency arrays must be non-empty");
+    CoalesceRequest r{out4 ? 4 : 0, p, t, nu, nt, nnu, 0, 0, 0, out, out4};
+    return coalesce_submit(c, r);
+}
+
+int vag_flux_density_coalesced(vag_ctx* c, const vag_model_params* p, const double* t, const double* nu, int n, double* out,
+                               double* const* out4) {
+    if (!c || !p || !t || !nu || (!out && !out4)) return set_err(VAG_E_INVALID, "null context, model or buffer");
+    if (n <= 0) return set_err(VAG_E_INVALID, "time array must be non-empty");
+    CoalesceRequest r{out4 ? 5 : 1, p, t, nu, n, n, 0, 0, 0, out, out4};
+    return coalesce_submit(c, r);
+}
+
+int vag_flux_coalesced(vag_ctx* c, const vag_model_params* p, const double* t, int nt, double nu_min, double nu_max, int num_nu, double* out,
+                       double* const* out4) {
+    if (!c || !p || !t || (!out && !out4)) return set_err(VAG_E_INVALID, "null context, model or buffer");
+    if (nt <= 0) return set_err(VAG_E_INVALID, "time array must be non-empty");
+    CoalesceRequest r{out4 ? 6 : 2, p, t, nullptr, nt, 0, nu_min, nu_max, num_nu, out, out4};
+    return coalesce_submit(c, r);
+}
+
 
 static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                         const vag_details_out* out, bool want_rvs) {
@@ -3076,10 +3405,12 @@ static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min
 
 int vag_details(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                 const vag_details_out* out) {
+    ApiLock api_lock(c);
     return details_impl(c, params, t_min, t_max, shape, out, false);
 }
 
 int vag_profile_eval(vag_ctx* c, const vag_model_params* params, int kind, const double* x, int n, double* out) {
+    ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (kind < 0 || kind > 2) return set_err(VAG_E_INVALID, "profile kind must be 0 (E_iso), 1 (Gamma0) or 2 (rho)");
     if (n <= 0 || !x || !out) return set_err(VAG_E_INVALID, "empty abscissa array");
@@ -3106,6 +3437,7 @@ int vag_profile_eval(vag_ctx* c, const vag_model_params* params, int kind, const
 
 int vag_details_eat(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int* n_phi_eff, double* t_obs,
                     double* doppler) {
+    ApiLock api_lock(c);
     vag_details_shape sh;
     int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, false);
     if (rc) return rc;
@@ -3135,6 +3467,7 @@ int vag_details_eat(vag_ctx* c, const vag_model_params* params, double t_min, do
 }
 
 int vag_details_radiation(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int rvs, double* const* arrays) {
+    ApiLock api_lock(c);
     vag_details_shape sh;
     int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, rvs != 0);  // runs the stages with the electron arrays kept
     if (rc) return rc;
@@ -3171,6 +3504,7 @@ int vag_details_radiation(vag_ctx* c, const vag_model_params* params, double t_m
 
 int vag_details_rvs(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                     const vag_details_out* out) {
+    ApiLock api_lock(c);
     return details_impl(c, params, t_min, t_max, shape, out, true);
 }
 

@@ -143,9 +143,12 @@ VAG_DEV void lds_store_ordered(int* p, int v) {
 
 // The flat attempt loop of one wavefront (lane = row).  Returns the lane's solver status (0 ok, 1 step underflow,
 // 2 step cap).
-template <class Eq>
+// TALLY (vag_ctx_count_work, untimed passes): *n_rhs = right-hand sides this lane's row evaluated.  Everything the tally adds is
+// compiled out of the product instantiation: an extra counter and reference parameter cost the latency-bound loop 0.14 ms per
+// 1024-walker step when they were tried unconditionally (r05).
+template <class Eq, bool TALLY = false>
 VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double t_last, bool active, LdsTab lg, DynRing& ring,
-                          int lane) {
+                          int lane, int* n_rhs = nullptr) {
     constexpr int N = 5;
     constexpr double a21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40;
     constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
@@ -157,6 +160,7 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
     double dx[N];
     double t = t0, dt = 0.01 * t0;
     int fails = 0, steps = 0, status = 0, head = 0, tail_seen = 0;
+    [[maybe_unused]] int n_rej = 0;
     bool done = !active;
     if (active) {
         eq(x, dx);
@@ -214,6 +218,7 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
             const double fac = 0.9 * exp2_ode(lg_e * (reject ? -1.0 / 3 : -1.0 / 5));
             dt = h * (reject ? vmax(fac, 0.2) : (err < 0.5 ? fac : 1.0));
             if (reject) {
+                if constexpr (TALLY) ++n_rej;
                 if (++fails >= 500) {
                     status = 1;
                     done = true;
@@ -295,6 +300,7 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
         }
     }
     lds_store_release(&ring.fin, 1);
+    if constexpr (TALLY) *n_rhs = active ? 1 + 6 * (steps + n_rej) : 0;  // FSAL: six new evaluations per attempt, one at the start
 #ifdef VAG_DYN_STAMPS
     if (blockIdx.x == 0 && lane == 0)
         printf("fast dyn wave 0: attempts %d, lane 0 steps %d; cycles total %lld, attempt bodies %lld, waiting for the saver %lld (%d spins)\n",

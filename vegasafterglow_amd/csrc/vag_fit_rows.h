@@ -88,7 +88,9 @@ struct FitRowsLds {
 };
 
 // One work item of the fit: segment(s) wseg (of W) of the lattice walk of block vb (64 rows) of model m, by one wavefront.
-template <int MODE, int NBMAX, bool SPREAD>
+// COUNT: the item also tallies its work in the path's units -- a spectrum evaluation per (row, node whose boundary values
+// are formed, band), an interpolation per (row, data point inside the row's lattice) -- into a.tally; untimed passes only.
+template <int MODE, int NBMAX, bool SPREAD, bool COUNT = false>
 VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int vb, int wseg, int W, int lane) {
     const VagGridMeta* Mp = a.meta + m;
     const int n_pairs = Mp->n_theta * Mp->n_phi_eff;
@@ -243,9 +245,11 @@ VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int 
     double Bprev[NBMAX], Bcur[NBMAX];
 #pragma unroll
     for (int b = 0; b < NBMAX; ++b) Bprev[b] = Bcur[b] = 0;
+    long long n_ev = 0, n_in = 0;  // COUNT
     {
         const bool need0 = p < n && s_tp[p] <= lt_b;  // the first interval holds a point: node k_first is one of its ends
         if (__ballot(need0) != 0 && need0) boundary(k_first, dop_a, lr2_a, ldo_a, Bprev);
+        if (COUNT && need0) n_ev += NB;
     }
     while (cut(seg + 1) <= k_first) flush(seg++);  // leading segments without an interval
     VAG_FR_MARK(c_pro);
@@ -275,6 +279,7 @@ VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int 
         }
         const bool need = pe > p || t_next <= lt_c;
         VAG_FR_MARK(c_scan);
+        if (COUNT) n_ev += need ? NB : 0, n_in += pe - p;
         if (__ballot(need) != 0) {
             if (need) boundary(k, dop_b, lr2_b, ldo_b, Bcur);
 #ifdef VAG_SERIES_STAMPS
@@ -313,6 +318,12 @@ VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int 
     if constexpr (MODE == FLUX_SSC) {
         if (breach) atomicOr(a.ic_status + m, ic_breach_status(breach));
     }
+    if constexpr (COUNT) {
+        if (valid && a.tally) {
+            atomicAdd(a.tally, (unsigned long long)n_ev);
+            atomicAdd(a.tally + 1, (unsigned long long)n_in);
+        }
+    }
 #ifdef VAG_SERIES_STAMPS
     if (m == 0 && vb == 0 && lane == 0 && wseg == 0)
         printf("fit rows wave 0: K %d  cycles: prologue %lld  nodes %lld  scan %lld  boundary %lld (%d steps)  interp %lld\n", K, c_pro, c_node,
@@ -328,7 +339,7 @@ VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int 
 // registers per node.
 // SPREAD: a spreading jet's polar angle evolves along the lattice, so the viewing cosine and the solid angle are per node
 // (calc_t_obs + calc_solid_angle, observer.cpp:51-141; a.cellgeo holds cos theta, sin theta, log2|dcos| per cell).
-template <int MODE, int NBMAX, bool SPREAD = false>
+template <int MODE, int NBMAX, bool SPREAD = false, bool COUNT = false>
 __global__ void __launch_bounds__(SERIES_THREADS * FITROWS_WAVES, VAG_ROWS_MIN_WG)  // 168 VGPRs: three wavefronts per SIMD (170 would leave two)
 vag_flux_fit_rows_kernel(SeriesArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -368,7 +379,7 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
                 hi = mid;
         }
         m_lo = lo;
-        fit_rows_item<MODE, NBMAX, SPREAD>(a, L, lo, blk - blk_off[lo], wseg, W, lane);
+        fit_rows_item<MODE, NBMAX, SPREAD, COUNT>(a, L, lo, blk - blk_off[lo], wseg, W, lane);
         if (total_items <= n_waves) break;
         if (lane == 0) item = n_waves + __hip_atomic_fetch_add(a.work, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         item = __builtin_amdgcn_readfirstlane(item);

@@ -463,7 +463,7 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
                 double* __restrict__ g_rowgeo /* [nb][VAG_ROWGEO_HDR + 2 SH::max_phi + 4 SH::max_theta]: the same geometry as records */) {
     const int m = blockIdx.x;
     const int lane = threadIdx.x;
-    if (m == 0 && lane < 4) fail[lane] = 0;
+    if (m == 0 && lane < 8) fail[lane] = 0;  // (ODE row tallies, vag_capi.hip: d_fail)
     const vag_model_params P = params[m];
     const double t_min_s = tminmax[0], t_max_s = tminmax[1];
     if (!params_valid(P)) {  // the reference raises ValueError; batched walkers get status != 0 (-> NaN / -inf)

@@ -272,4 +272,28 @@ VAG_DEV void compton_correction_pair_lg2(double lg2_nu, const double* __restrict
     lg2_corr = lut[KN_LUT_N + idx] + (lut[KN_LUT_N + idx + 1] - lut[KN_LUT_N + idx]) * frac;
 }
 
+// The same function for a wavefront that holds nodes of all three ranges (vag_ic_photon_kernel's lattice fill): straight-line, the
+// table words requested first (two 16-byte gathers) and the two closed-form tails formed while they are in flight, then selected.
+// `x` = 2^lg2_x comes from the caller (the product of an electron and a seed lattice node it already holds), so that neither tail
+// pays an exp2; 1/x is a reciprocal estimate + two Newton steps.
+typedef double vdouble2_u8 __attribute__((ext_vector_type(2), aligned(8)));
+VAG_DEV void compton_correction_pair_node(double lg2_x, double x, const double* __restrict__ lut, double& corr, double& lg2_corr) {
+    constexpr double inv_step = 1.0 / ((KN_LG2_XMAX - KN_LG2_XMIN) / (double)(KN_LUT_N - 1));
+    const bool below = !(lg2_x > KN_LG2_XMIN), above = lg2_x >= KN_LG2_XMAX;  // NaN: below, and then x > 0 fails
+    const double pos = __builtin_fmin(__builtin_fmax((lg2_x - KN_LG2_XMIN) * inv_step, 0.0), (double)(KN_LUT_N - 1));
+    const int idx = min((int)pos, KN_LUT_N - 2);
+    const double frac = pos - (double)idx;
+    const vdouble2_u8 r = *reinterpret_cast<const vdouble2_u8*>(lut + idx);
+    const vdouble2_u8 l = *reinterpret_cast<const vdouble2_u8*>(lut + KN_LUT_N + idx);
+    // x >= 1e2: sigma / sigma_T = 3/8 (ln 2x + 1/2) / x   (a = 2 for the lanes of the other ranges: log2_fast's library path stays shut)
+    const double a = above ? 0.375 * ((lg2_x + 1.0) * LN2 + 0.5) : 2.0;
+    const double c_hi = a * rcp_fast(above ? x : 1.0), l_hi = log2_fast(a) - lg2_x;
+    // x <= 1e-2: 1 - 2x and its logarithm's series
+    const bool pos_x = x > 0;
+    const double c_lo = pos_x ? 1 - 2 * x : 0.0, l_lo = pos_x ? -(2 * x + 2 * x * x) * 1.4426950408889634 : -INFINITY;
+    const double c_in = r.x + (r.y - r.x) * frac, l_in = l.x + (l.y - l.x) * frac;
+    corr = below ? c_lo : (above ? c_hi : c_in);
+    lg2_corr = below ? l_lo : (above ? l_hi : l_in);
+}
+
 }  // namespace vag

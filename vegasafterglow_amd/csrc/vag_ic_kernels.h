@@ -1,5 +1,6 @@
 // vag_ic_kernels.h -- kernels of the SSC / inverse-Compton tier.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "vag_ic.h"
@@ -29,8 +30,11 @@ constexpr int IC_MAX_OUT = 192;  // three output nodes per lane; an unclamped ta
 // the 512-model configs[2] batch).  The offsets are handed out by vag_ic_plan_kernel (one atomic reservation per workgroup).
 constexpr int IC_HDR = 8;
 enum { ICH_N = 0, ICH_FIRST, ICH_LAST, ICH_TMIN, ICH_TMAX, ICH_OFF };
-constexpr int IC_PLAN = 16;  // per-cell lattice plan between vag_ic_plan_kernel and vag_ic_photon_kernel (ICP_* words)
-constexpr int IC_MAX_NU = 128, IC_MAX_G = 64, IC_MAX_LAT = (IC_MAX_G - 1) + (IC_MAX_NU - 1) + 1;
+constexpr int IC_PLAN = 24;  // per-cell record between vag_ic_plan_kernel and vag_ic_photon_kernel (ICP_* words): everything the wavefront needs of its cell but the 46 spectrum constants
+#ifndef VAG_IC_MAX_NU
+#define VAG_IC_MAX_NU 128  // (developer builds: 96 makes a cell's LDS 7.75 KB, i.e. five wavefronts per SIMD)
+#endif
+constexpr int IC_MAX_NU = VAG_IC_MAX_NU, IC_MAX_G = 64, IC_MAX_LAT = (IC_MAX_G - 1) + (IC_MAX_NU - 1) + 1;
 static_assert(VAG_NQ == FLUX_NQ && IC_HDR == FLUX_IC_HDR, "keep vag_kernels.h forward constants in sync");
 constexpr double IC_Q = 3.321928094887362 / 8;  // lattice_quantum
 constexpr double IC_X0 = 0.47140452079103166;
@@ -230,8 +234,10 @@ VAG_DEV double ic_thin_correction(const IcQ& q, double lg2_nu, Tab sp) {
 // IC-corrected synchrotron spectrum (compute_log2_spectrum, smooth-power-law-syn.cpp:80-92) given the thin-branch correction.
 // STRAIGHT: the +-20 softplus shortcuts as selects (sp_fast_sel) -- same values; for a caller whose table sits in global memory, so
 // that the three independent table reads of an evaluation are in flight together instead of one per branch.
-template <bool STRAIGHT = false, class P1, class Tab>
-VAG_DEV double log2_I_nu_ic_core(const P1 c, int st, bool corrected, const IcQ& q, const SpecConst& sc, double lg2_nu, Tab sp) {
+// HAVE_NU: the caller holds nu = 2^lg2_nu already (a lattice node of vag_ic_photon_kernel) and the cut-off term takes it as it is.
+template <bool STRAIGHT = false, bool HAVE_NU = false, class P1, class Tab>
+VAG_DEV double log2_I_nu_ic_core(const P1 c, int st, bool corrected, const IcQ& q, const SpecConst& sc, double lg2_nu, Tab sp,
+                                 double nu_val = 0.0) {
     auto sp_ = [&](double z) { return STRAIGHT ? sp_fast_sel(z, sp) : sp_fast(z, sp); };
     const double l_lo = c[VP_LG2_LO * st], l_hi = c[VP_LG2_HI * st];
     double thin = (lg2_nu - l_lo) * (1.0 / 3.0) - sp_(c[VP_DLO * st] * (lg2_nu - l_lo)) * c[VP_INV_SLO * st] -
@@ -251,6 +257,7 @@ VAG_DEV double log2_I_nu_ic_core(const P1 c, int st, bool corrected, const IcQ& 
     const double lb = thick + c[VP_TNORM * st];
     const double smooth_one = thin - sp_(c[VP_SAB * st] * (thin - lb)) * c[VP_INV_SAB * st];
     const double spec = c[VP_LG2_I * st] + (c[VP_INV_SLO * st] + smooth_one);
+    if (HAVE_NU) return (lg2_nu - c[VP_LG2_NUMAX * st] < -20) ? spec : spec - c[VP_INV_NUMAX * st] * nu_val;
     if (lg2_nu - c[VP_LG2_NUMAX * st] < -20) return spec;
     return spec - c[VP_INV_NUMAX * st] * exp2_fast(lg2_nu);
 }
@@ -475,6 +482,9 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 #ifndef VAG_IC_WAVES
 #define VAG_IC_WAVES 4
 #endif
+#ifndef VAG_IC_PERSISTENT
+#define VAG_IC_PERSISTENT 0  // (developer builds: 1 = persistent wavefronts with the next records / constants prefetched, see the kernel's end)
+#endif
 #ifndef VAG_IC_ONE_NODE_MAX
 #define VAG_IC_ONE_NODE_MAX 64  // seed lattices up to this size take one node per lane (developer builds: 0 = always two)
 #endif
@@ -485,9 +495,14 @@ VAG_DEV double read_lane(double v, int src) {  // src uniform across the wave
 // block (the order of the blocks in the pool follows the scheduler; the values in them do not depend on it).  Cells that get no
 // table (failed model, degenerate or over-capacity lattice: n = 0 and the theoretical range; a cell no row queries: n = -1) are
 // finished here.
-enum { ICP_RUN = 0, ICP_MODEL, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX,
+enum { ICP_CELL = 0 /* the cell this record belongs to: records are stored compacted, runnable cells only */, ICP_NU_SIZE, ICP_G_SIZE, ICP_N_LO, ICP_LG2_NU0, ICP_LG2_G0, ICP_LG2_GM, ICP_INV_GM, ICP_INV_GMAX,
        ICP_SMOOTH_THICK, ICP_LOG2_X_FAR /* SpecConst of the model's p: a division and a library log2 per wavefront otherwise */,
-       ICP_PHASE, ICP_N };
+       ICP_PHASE,
+       // r05: what the spectrum kernel used to fetch through its model (params, meta, cell offsets: two further dependent round trips
+       // per cell) and from the detail arrays -- the record is now the ONLY thing a wavefront needs before it can request the cell's
+       // spectrum constants, so that a persistent wavefront can have both in flight one and two cells ahead
+       ICP_ROW0 /* first cell of the cell's representative row */, ICP_NT, ICP_K, ICP_GAMMA_M, ICP_GAMMA_C, ICP_COLUMN_DEN, ICP_YC,
+       ICP_REGIME, ICP_P, ICP_KN, ICP_N_IC, ICP_OFF /* = the header's n and offset */, ICP_N };
 static_assert(ICP_N <= IC_PLAN, "plan row");
 // output lattice node q of a table: phase + IC_Q (idx0 + 2 q), idx0 + 2 q an integer far below 2^53 formed in double -- exactly the
 // value the reference converts from its integer (log2_nu_IC, inverse-compton.h:595-606)
@@ -495,19 +510,19 @@ VAG_DEV double ic_out_node(double phase, double idx0, int q) { return phase + IC
 __global__ void __launch_bounds__(256)
 vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
-                   double* __restrict__ ichdr /* [cells][IC_HDR] */, double* __restrict__ icplan /* [cells][IC_PLAN] */,
-                   unsigned long long* __restrict__ pool_used /* doubles handed out so far (starts at 2: slot 0 serves the empty tables) */,
+                   double* __restrict__ ichdr /* [cells][IC_HDR] */, double* __restrict__ icplan /* [runnable cells][IC_PLAN], compacted */,
+                   unsigned long long* __restrict__ pool_used /* [0] doubles handed out so far (starts at 2: slot 0 serves the empty tables),
+                                                                 [1] records written so far (starts at 0) */,
                    int* __restrict__ ic_status,
                    unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
                    int band_stride, const unsigned char* __restrict__ need /* [cells] or nullptr (vag_ic_band_kernel) */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = c < n_cells && c < lay.cell_off[nb];  // n_cells is the arrays' stride (>= the batch's cell count)
     double* hdr = ichdr + (size_t)(live ? c : 0) * IC_HDR;
-    double* plan = icplan + (size_t)(live ? c : 0) * IC_PLAN;
+    double plan[IC_PLAN];  // the cell's record: written out below, at the place the workgroup reserves for it among the runnable cells
     // the cell's plan; returns the length of its table (0: none)
     auto plan_cell = [&]() -> int {
         const int m = cell_model(lay.cell_off, nb, c);
-        plan[ICP_RUN] = 0;
         hdr[ICH_N] = 0;
         hdr[ICH_OFF] = 0;
         const int nt = meta[m].n_t;
@@ -564,8 +579,18 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         hdr[ICH_FIRST] = ic_out_node(phase, (double)(n_lo * 2), 0);         // first and last node of the output lattice: what the flux
         hdr[ICH_LAST] = ic_out_node(phase, (double)(n_lo * 2), n_ic - 1);   // passes' evaluator needs of it (ic_table_eval_hdr)
         plan[ICP_PHASE] = phase;
-        plan[ICP_RUN] = 1;
-        plan[ICP_MODEL] = (double)m;
+        plan[ICP_CELL] = (double)c;  // < 2^53: exact
+        plan[ICP_ROW0] = (double)(c - k);  // < 2^53: exact
+        plan[ICP_NT] = (double)nt;
+        plan[ICP_K] = (double)k;
+        plan[ICP_GAMMA_M] = gamma_m;
+        plan[ICP_GAMMA_C] = gamma_c;
+        plan[ICP_COLUMN_DEN] = det[VD_COLUMN_DEN * n_cells + c];
+        plan[ICP_YC] = det[VD_YC * n_cells + c];
+        plan[ICP_REGIME] = det[VD_REGIME * n_cells + c];
+        plan[ICP_P] = params[m].p;
+        plan[ICP_KN] = (params[m].flags & VAG_FLAG_KN) ? 1.0 : 0.0;
+        plan[ICP_N_IC] = (double)n_ic;
         plan[ICP_NU_SIZE] = (double)nu_size;
         plan[ICP_G_SIZE] = (double)g_size;
         plan[ICP_N_LO] = (double)n_lo;
@@ -581,37 +606,78 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         return n_ic;
     };
     const int len = live ? plan_cell() : 0;
-    // place of the table: exclusive sum over the workgroup's lanes + the workgroup's reservation
-    __shared__ unsigned long long s_base;
-    __shared__ int s_wave[4];
+    // place of the table in the pool and of the record among the runnable cells: exclusive sums over the workgroup's lanes + the
+    // workgroup's two reservations
+    __shared__ unsigned long long s_base, s_base_run;
+    __shared__ int s_wave[4], s_wave_run[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int incl = len;
+    int incl = len, incl_run = len > 0 ? 1 : 0;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+        const int t = __shfl_up(incl, off, 64), tr = __shfl_up(incl_run, off, 64);
+        if (lane >= off) incl += t, incl_run += tr;
     }
-    if (lane == 63) s_wave[w] = incl;
+    if (lane == 63) s_wave[w] = incl, s_wave_run[w] = incl_run;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const int total_run = s_wave_run[0] + s_wave_run[1] + s_wave_run[2] + s_wave_run[3];
         s_base = total > 0 ? atomicAdd(pool_used, (unsigned long long)total) : 0ull;
+        s_base_run = total_run > 0 ? atomicAdd(pool_used + 1, (unsigned long long)total_run) : 0ull;
     }
     __syncthreads();
     if (len > 0) {
-        int before = incl - len;
-        for (int q = 0; q < w; ++q) before += s_wave[q];
+        int before = incl - len, before_run = incl_run - 1;
+        for (int q = 0; q < w; ++q) before += s_wave[q], before_run += s_wave_run[q];
         hdr[ICH_OFF] = (double)(s_base + (unsigned long long)before);  // < 2^53: exact
+        plan[ICP_OFF] = hdr[ICH_OFF];
+        double* dst = icplan + (size_t)(s_base_run + (unsigned long long)before_run) * IC_PLAN;
+#pragma unroll
+        for (int q = 0; q < ICP_N; ++q) dst[q] = plan[q];
     }
 }
 
+// r05: PERSISTENT wavefronts.  One wavefront per cell spent a fifth of its life (7 k of 36 k cycles, -DVAG_IC_STAMPS) in its prologue:
+// plan row -> model -> params / meta / cell offsets -> the 46 spectrum constants, three dependent round trips to HBM that four resident
+// wavefronts per SIMD cannot hide (VALU 78 % busy with every instruction counter well below its pipe's limit).  Now the launch is as
+// many wavefronts as the device holds (4 per SIMD) and each takes the cells c = w, w + G, w + 2 G, ...; the plan record of cell c + 2 G and
+// the constants of cell c + G (whose record arrived an iteration ago) are requested before cell c is worked on, so a cell starts with its
+// constants in a register and its record in L2 (read again through the scalar cache: the record is wave-uniform).
+// The spectrum kernel's workgroup is ONE wavefront: its lanes run in lockstep and the LDS serves a wavefront's instructions in order, so
+// what __syncthreads() has to provide between its phases is only that the compiler keeps the memory accesses on their side of the line --
+// not the s_waitcnt vmcnt(0) it also emits, which in the persistent loop would make every phase wait for the next cells' prefetches and
+// every cell for its own table stores to land in HBM.
+// (wave_sync() of vag_kernels.h: a wavefront-scope fence and a compiler barrier, no instruction)
+struct IcPhotonArgs {
+    long long n_run;    // records (= runnable cells) vag_ic_plan_kernel wrote ...
+    const unsigned long long* n_run_dev;  // ... or, when the host did not wait for that count (likelihood calls), where it stands in HBM
+    long long n_cells;  // stride of the SoA arrays (>= the batch's cell count)
+    const double *icy, *cellpar, *cellq, *sp_table, *kn_lut, *icplan;
+    double* icpool;
+};
+// The kernel's arguments read again from the kernel-argument segment (scalar loads through a pointer the optimiser cannot see through,
+// as load_series_args of vag_grid_rows.h): the persistent loop keeps its cell number and two prefetched registers alive, not nine pointers.
+typedef const IcPhotonArgs __attribute__((address_space(4))) KernargIcPhotonArgs;
+VAG_DEV IcPhotonArgs load_ic_photon_args() {
+    KernargIcPhotonArgs* p = (KernargIcPhotonArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    IcPhotonArgs a;
+    __builtin_memcpy(&a, p, sizeof(IcPhotonArgs));
+    return a;
+}
 __global__ void __launch_bounds__(64, VAG_IC_WAVES)
-vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta, Layout lay,
-                     long long n_cells, const double* __restrict__ det, const double* __restrict__ icy,
-                     const double* __restrict__ cellpar, const double* __restrict__ cellq,
-                     const double* __restrict__ sp_table, const double* __restrict__ kn_lut, const double* __restrict__ ichdr,
-                     const double* __restrict__ icplan, double* __restrict__ icpool) {
-    const long long c = blockIdx.x;
+vag_ic_photon_kernel(IcPhotonArgs args_unused_directly) {
+    const int lane = threadIdx.x;
+    __shared__ IcShared sh;
+    constexpr int CST_Q = VAG_NPAR, CST_Y = VAG_NPAR + VAG_NQ, CST_N = VAG_NPAR + VAG_NQ + VAG_NICY;
+    static_assert(CST_N <= 64, "one constant per lane");
+    static_assert(IC_PLAN <= 64, "one record word per lane");
+    // `prefetch` requests the next cells' record / constants; a cell calls it once, where its own register demand is lowest
+    auto cell = [&](const long long c, const double my_cst, auto prefetch) {
+    // (the lane number made opaque per cell: what a cell derives from it -- LDS addresses, masks -- is formed inside the turn instead
+    // of being hoisted out of the persistent loop and held in registers across it)
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
 #ifdef VAG_IC_STAMPS  // developer aid: cycles of a wavefront per section
     long long c_t[10];
     int c_n = 0;
@@ -620,57 +686,41 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #else
 #define VAG_IC_MARK() do { } while (0)
 #endif
-    if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
-    const int lane = threadIdx.x;
-    __shared__ IcShared sh;
-    const double* plan = icplan + (size_t)c * IC_PLAN;
-    if (plan[ICP_RUN] == 0) return;  // vag_ic_plan_kernel finished this cell (uniform)
-    const double* hdr = ichdr + (size_t)c * IC_HDR;
-    double* tab = icpool + (unsigned long long)hdr[ICH_OFF];  // this cell's table in the pool
-    const int m = (int)plan[ICP_MODEL];
+    const IcPhotonArgs A = load_ic_photon_args();
+    const double* __restrict__ sp_table = A.sp_table;
+    const double* __restrict__ kn_lut = A.kn_lut;
+    double* __restrict__ icpool = A.icpool;
+    // wave-uniform and never written while this kernel runs: read through the constant address space, i.e. by scalar loads (a pointer
+    // that arrives through the opaque argument block carries no such promise and would be read by vector loads + v_readfirstlane)
+    typedef const double __attribute__((address_space(4))) ConstDouble;
+    ConstDouble* plan = (ConstDouble*)(unsigned long long)(A.icplan + (size_t)c * IC_PLAN);
+    double* tab = icpool + (unsigned long long)plan[ICP_OFF];  // this cell's table in the pool
     int nu_size = (int)plan[ICP_NU_SIZE], g_size = (int)plan[ICP_G_SIZE];
     const long n_lo = (long)plan[ICP_N_LO];
     const double lg2_nu0 = plan[ICP_LG2_NU0], lg2_g0 = plan[ICP_LG2_G0];
     const double lg2_gm = plan[ICP_LG2_GM], inv_gm = plan[ICP_INV_GM], inv_gM = plan[ICP_INV_GMAX];
-    const int n_ic = (int)hdr[ICH_N];
+    const int n_ic = (int)plan[ICP_N_IC];
     const double phase = plan[ICP_PHASE];
     const long idx0 = n_lo * 2;
     const double step = 2 * IC_Q;
-    const int nt = meta[m].n_t;
-    const long long local = c - lay.cell_off[m];
-    const int r = (int)(local / nt), k = (int)(local % nt);
-    const vag_model_params P = params[m];
-    const bool KN = (P.flags & VAG_FLAG_KN) != 0;
-    const double gamma_m = det[VD_GAMMA_M * n_cells + c], gamma_c = det[VD_GAMMA_C * n_cells + c];
-    const double column_den = det[VD_COLUMN_DEN * n_cells + c];
-    const double Y_c = det[VD_YC * n_cells + c];
-    const int regime = (int)det[VD_REGIME * n_cells + c];
-    // Every constant of the cell the two sampling loops below use, requested HERE by ONE vector load (lane l fetches constant l)
-    // and handed round through LDS: left to the evaluators they are fetched where they are used -- behind lane-divergent
-    // branches, i.e. as vector loads, one memory round trip after the other inside the loops (a dozen per pass; the loops then
-    // took 40 % of this kernel's time); as scalar loads up front they overflow the scalar registers.
-    constexpr int CST_Q = VAG_NPAR, CST_Y = VAG_NPAR + VAG_NQ, CST_N = VAG_NPAR + VAG_NQ + VAG_NICY;
-    static_assert(CST_N <= 64, "one constant per lane");
-    double my_cst;
-    {
-        const long long row0 = lay.cell_off[m] + (long long)r * nt;
-        const double* src = cellpar + row0 * VAG_NPAR + k;  // lanes past the list re-read the first word
-        if (lane < CST_Q)
-            src += (long long)lane * nt;
-        else if (lane < CST_Y)
-            src = cellq + row0 * VAG_NQ + k + (long long)(lane - CST_Q) * nt;
-        else if (lane < CST_N)
-            src = icy + c + (long long)(lane - CST_Y) * n_cells;
-        my_cst = *src;
-    }
-    __syncthreads();
+    struct { double p; } P{plan[ICP_P]};
+    const bool KN = plan[ICP_KN] != 0;
+    const double gamma_m = plan[ICP_GAMMA_M], gamma_c = plan[ICP_GAMMA_C];
+    const double column_den = plan[ICP_COLUMN_DEN];
+    const double Y_c = plan[ICP_YC];
+    const int regime = (int)plan[ICP_REGIME];
+    // Every constant of the cell the two sampling loops below use arrives as ONE vector register (lane l holds constant l, requested
+    // while the previous cell was worked on) and is handed round through LDS: left to the evaluators they are fetched where they are
+    // used -- behind lane-divergent branches, i.e. as vector loads, one memory round trip after the other inside the loops (a dozen
+    // per pass; the loops then took 40 % of this kernel's time); as scalar loads up front they overflow the scalar registers.
+    wave_sync();
     for (int j = lane; j < nu_size; j += 64) {
         sh.lg2nu[j] = lg2_nu0 + step * (double)j;
         sh.nu[j] = exp2_sat(sh.lg2nu[j]);
     }
     for (int i = lane; i < g_size; i += 64) sh.gam[i] = exp2_sat(lg2_g0 + step * (double)i);
     sh.ex[lane] = my_cst;  // `ex` is not written before the Thomson CDF
-    __syncthreads();
+    wave_sync();
     double cp[VAG_NPAR];
     for (int q : {VP_LG2_LO, VP_LG2_HI, VP_DLO, VP_INV_SLO, VP_DHI, VP_INV_SHI, VP_LG2_NUM, VP_TNORM, VP_SAB, VP_INV_SAB, VP_LG2_I,
                   VP_LG2_NUMAX, VP_INV_NUMAX})
@@ -684,7 +734,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
     const double yL2 = sh.ex[CST_Y + VY_L2], yS2 = sh.ex[CST_Y + VY_S2], yC2 = sh.ex[CST_Y + VY_C2];
     VAG_IC_MARK();  // 1: prologue
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 4) return;  // prologue only: loads, lattice parameters, lattice nodes
+    if (VAG_IC_ABLATE >= 4) { prefetch(); return; }  // prologue only: loads, lattice parameters, lattice nodes
 #endif
     // sample_distributions, inverse-compton.h:371-399
     SpecConst sc;
@@ -720,15 +770,15 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
 #endif
     for (int j = lane; j < nu_size; j += 64) {  // f = I_seed / nu^2 and its logarithm, from the logarithm
         const double x = sh.lg2nu[j];
-        const double lf = log2_I_nu_ic_core<true>(cp, 1, icq.applies(x), icq, sc, x, sp_table) - 2 * x;
+        const double lf = log2_I_nu_ic_core<true, true>(cp, 1, icq.applies(x), icq, sc, x, sp_table, sh.nu[j]) - 2 * x;
         const double f = exp2_sat(lf);
         sh.fv_th[j] = f;
         sh.lg2fv[j] = f > 0 ? lf : -INFINITY;
     }
-    __syncthreads();
+    wave_sync();
     VAG_IC_MARK();  // 2: sampled distributions
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 3) return;  // ... + the sampled electron and seed distributions
+    if (VAG_IC_ABLATE >= 3) { prefetch(); return; }  // ... + the sampled electron and seed distributions
 #endif
     const int nu_last = nu_size - 1;
     for (int j = lane; j < nu_last; j += 64) {
@@ -736,7 +786,7 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         sh.lg2r[j] = sh.lg2nu[j + 1] - sh.lg2nu[j];
         sh.inv_lg2r[j] = sh.lg2r[j] != 0 ? 1 / sh.lg2r[j] : 0;
     }
-    __syncthreads();
+    wave_sync();
     // build_cdf_thomson, inverse-compton.h:415-430
     for (int j = lane; j < nu_last; j += 64) {
         const double trap = 0.5 * (sh.fv_th[j] + sh.fv_th[j + 1]) * sh.dnu[j];
@@ -745,10 +795,10 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         sh.ex[j] = exact;
         sh.ratio_th[j] = trap > 0 ? exact / trap : 1;
     }
-    __syncthreads();
+    wave_sync();
     VAG_IC_MARK();  // 3: Thomson CDF
 #ifdef VAG_IC_ABLATE
-    if (VAG_IC_ABLATE >= 2) return;
+    if (VAG_IC_ABLATE >= 2) { prefetch(); return; }
 #endif
     // accumulate over electron energies (accumulate_IC, inverse-compton.h:483-527; build_cdf_KN, :432-481).  For electron
     // energy i the reference forms the scattering CDF over the seed bins, c_j(i) = sum_{m >= j} ex_m(i), and output node kk
@@ -821,33 +871,63 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         const int i_tail0 = (lane >> lgW) * T;
         Bin bt = bm;
         if (n_tail > 0) bt = bin_constants(MAIN + (lane & (W - 1)));
-        __syncthreads();  // every setup array has been read: from here on their memory holds D / E / lat / dNe_i / split_i
-        for (int q = lane; q < IC_MAX_DIAG; q += 64) sh.D[q] = 0.0, sh.E[q] = 0.0;
-        if (KN) {  // one KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by
-                   // two quanta, so only the even nodes of the reference's lattice are ever read: node q here is its node 2 q.
-                   // (The nodes below min_i (i + split(i)) - 1, a third of them, are never read; skipping them was measured and
-                   // costs more -- a wave-wide minimum and two barriers before the fill -- than the partial second pass it saves.)
-            const int n_lat = (g_size - 1) + (nu_size - 1) + 1;
-            const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
-            for (int q = lane; q < n_lat; q += 64) {
-                double cq, lq;
-                compton_correction_pair_lg2(lg2_base + step * (double)q, kn_lut, cq, lq);
-                sh.lat[q] = vdouble2{cq, lq};
-            }
-        }
         int my_split = nu_size;  // Thomson: no bin lies at or above the split
-        if (KN && lane < g_size) {
-            const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / my_gam;
-            // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
-            const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
-            int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) / step);
-            js = js < 0 ? 0 : (js > nu_last ? nu_last : js);
-            while (js > 0 && sh.nu[js - 1] >= nu_split) --js;
-            while (js < nu_last && sh.nu[js] < nu_split) ++js;
-            my_split = js;
+        // KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574.  Both lattices step by two quanta, so only
+        // the even nodes of the reference's lattice are ever read: node q here is its node 2 q.  And only the nodes from the Klein-
+        // Nishina split upwards: energy i reads the nodes i + j, i + j + 1 of the bins j >= split(i) - 1 (see `pair`), i.e. nothing
+        // below min_i (i + split(i)).  split(i) is the first seed node with gamma_i nu_j >= the split constant, clamped to the seed
+        // lattice -- a function of i + j up to the rounding of the stored nodes (~1e-14 in log2) -- so i + split(i) >= split(0) - 1
+        // for every i: the fill starts at q_min = split(0) - 2 (one node to spare; the nodes below it hold NaN, never read).  That is
+        // a third of the lattice on the configs[2] cells and what makes the fill ONE pass of the wavefront instead of two (r05).
+        int q_min = 0;
+        double kx0 = 0;  // h nu gamma / (m_e c^2) at lattice node q_min + lane: the product of two stored nodes, no exp2
+        const int n_lat = (g_size - 1) + (nu_size - 1) + 1;
+        if constexpr (WITH_KN) {
+            if (lane < g_size) {
+                const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) * rcp_fast(my_gam);  // (<= 1 ulp; the nodes themselves are exp2_sat values)
+                // first node with nu >= nu_split (the reference scans from 0): lattice guess, then settle on the stored nodes
+                const double lg2_split0 = log2(1e-4 * (C_ME * C_C2 / C_H)) - lg2_g0;
+                int js = (int)ceil((lg2_split0 - step * (double)lane - lg2_nu0) * (1.0 / (2 * IC_Q)));  // (a guess: the loops below settle it)
+                js = js < 0 ? 0 : (js > nu_last ? nu_last : js);
+                while (js > 0 && sh.nu[js - 1] >= nu_split) --js;
+                while (js < nu_last && sh.nu[js] < nu_split) ++js;
+                my_split = js;
+            }
+            q_min = __builtin_amdgcn_readfirstlane(my_split) - 2;  // lane 0 = energy 0 (g_size >= 2)
+            q_min = q_min < 0 ? 0 : q_min;
+#ifdef VAG_IC_FULL_LATTICE
+            q_min = 0;  // developer builds: every node, as before r05
+#endif
+            const int q = q_min + lane, jq = q < nu_last ? q : nu_last;
+            int iq = q - jq;
+            iq = iq < g_size ? iq : g_size - 1;  // lanes past the lattice: any stored node
+            kx0 = sh.gam[iq] * sh.nu[jq] * (C_H / (C_ME * C_C2));
+        }
+        wave_sync();  // every setup array has been read: from here on their memory holds D / E / lat / dNe_i / split_i
+        {   // D and E, contiguous: 512 doubles = four 16-byte stores per lane
+            static_assert(offsetof(IcShared, E) == offsetof(IcShared, D) + sizeof(double) * IC_MAX_DIAG && IC_MAX_DIAG == 256, "D | E");
+            vdouble2* z = reinterpret_cast<vdouble2*>(sh.D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[lane + 64 * q] = vdouble2{0.0, 0.0};
+        }
+        if constexpr (WITH_KN) {
+            const double lg2_base = lg2_g0 + lg2nu_first;  // log2 of the first electron node times the first seed node
+            for (int q0 = q_min; q0 < n_lat; q0 += 64) {
+                const int q = q0 + lane;
+                const double lg2_x = (lg2_base + step * (double)q) + log2(C_H / (C_ME * C_C2));
+                const double x = q0 == q_min ? kx0 : exp2_sat(lg2_x);  // (a second pass: lattices with > 64 used nodes, rare)
+                double cq, lq;
+                compton_correction_pair_node(lg2_x, x, kn_lut, cq, lq);
+                if (q < n_lat) sh.lat[q] = vdouble2{cq, lq};
+            }
+            for (int q = lane; q < q_min; q += 64) sh.lat[q] = vdouble2{__builtin_nan(""), __builtin_nan("")};
         }
         if (n_tail > 0) sh.dNe_i[lane] = my_dNe, sh.split_i[lane] = my_split;
-        __syncthreads();
+        wave_sync();
+        // HERE: behind the cell's last global read (the KN table words above) and ahead of the walk's ~18 k cycles of LDS and VALU
+        // work.  Memory returns in order, so any later read of THIS cell would wait for the next cells' words as well; and the
+        // sampling loops' ~70 registers of cell constants are dead.
+        prefetch();
         VAG_IC_MARK();  // 4: KN lattice, split indices
         int g_run = g_size;
 #ifdef VAG_IC_ABLATE
@@ -869,10 +949,12 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
                     if (__builtin_expect(b.pos, 1)) {
                         asm volatile("");
                         const double s1 = fma(nd1.y - nd0.y, b.ilr, b.s_th);
-                        ve = u * b.Lr;
                         if (__builtin_expect(fabs(s1) > 1e-3, 1)) {  // 1e-3 < |s1| < inf: one Newton step (2e-15) is enough for a term of a sum
                             asm volatile("");
                             ve = fma(b.AN, cN, -u) * rcp_ode(s1);
+                        } else {
+                            asm volatile("");
+                            ve = u * b.Lr;
                         }
                     } else
                         ve = fma(b.AN, cN, u);
@@ -892,19 +974,28 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         // much as by the VALU -- profiles/micro/valu_throughput.hip: a ds_add_f64 or a two-word read holds it for 8 cycles -- so
         // the words are not re-read.)  Every lane reads, used or not: an LDS instruction costs the same under any mask; garbage
         // where the cell has no lattice or the index runs past it (still inside this wavefront's LDS), and those lanes never use it.
-        constexpr int R = 3;
+#ifndef VAG_IC_RING
+#define VAG_IC_RING 3  // slots of the node ring: a node is read VAG_IC_RING - 2 energies ahead of its first use
+#endif
+        constexpr int R = VAG_IC_RING, D = R - 2;
+        static_assert(R >= 3 && 64 + D + 64 < IC_MAX_LAT, "ring");
         vdouble2 ring[R];
-        if constexpr (WITH_KN) ring[0] = sh.lat[lane], ring[1] = sh.lat[lane + 1];
+        if constexpr (WITH_KN) {
+#pragma unroll
+            for (int q = 0; q <= D; ++q) ring[q] = sh.lat[lane + q];
+        }
+        const unsigned long long live_i = __ballot(my_dNe > 0);  // energies with electrons: a scalar bit test per energy
         for (int i0 = 0; i0 < g_run; i0 += R) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int i = i0 + u;
-                if constexpr (WITH_KN) ring[(u + 2) % R] = sh.lat[i + 2 + lane];  // for energy i + 1
+                if constexpr (WITH_KN) ring[(u + 1 + D) % R] = sh.lat[i + 1 + D + lane];  // the upper node of energy i + D
                 if (i < g_run) {
-                    const double dNe = read_lane(my_dNe, i);
-                    if (dNe > 0)  // uniform
+                    if ((live_i >> i) & 1) {  // uniform
+                        const double dNe = read_lane(my_dNe, i);
                         pair(i, dNe, WITH_KN ? __builtin_amdgcn_readlane(my_split, __builtin_amdgcn_readfirstlane(i)) : 0, bm, ring[u % R],
                              ring[(u + 1) % R]);
+                    }
                 }
             }
         }
@@ -925,9 +1016,9 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         energies(std::true_type{});
     else
         energies(std::false_type{});
-    __syncthreads();
+    wave_sync();
     suffix_scan4(sh.D, lane);  // D[d] <- sum_{d' >= d} D[d']
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
         const int kk = lane + 64 * s3;
@@ -939,19 +1030,89 @@ vag_ic_photon_kernel(const vag_model_params* __restrict__ params, int nb, const 
         }
     }
     VAG_IC_MARK();  // 5: energy loop
-#ifdef VAG_IC_STAMPS
-    if (lane == 0 && (c % 70001) == 0)
-        printf("ic cell %lld: g %d nu %d out %d  cycles: prologue %lld  constants %lld  electrons %lld  seeds %lld  thomson cdf %lld  kn lattice %lld  energies %lld\n",
-               c, g_size, nu_size, n_ic, c_t[1] - c_t[0], c_t[2] - c_t[1], c_t[3] - c_t[2], c_t[4] - c_t[3], c_t[5] - c_t[4], c_t[6] - c_t[5],
-               c_t[7] - c_t[6]);
-#endif
     // log2 table on the output lattice, inverse-compton.h:595-606
     const double lg2_scale = log2(0.25 * C_SIGMAT);
+    // vmcnt(0) stated before the table stores (the prefetched words arrived during the walk: no wait in practice): behind this line only
+    // stores are in flight, so the next cell's first use of its prefetched constants needs no wait -- left to the compiler, the loop's
+    // back edge gets a vmcnt(0) that makes every cell wait for its own stores to reach HBM
+#if VAG_IC_PERSISTENT
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int kk = lane + 64 * s;
         if (kk < n_ic) tab[kk] = log2_fast(I_acc[s]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
     }
+#ifdef VAG_IC_STAMPS
+    c_t[c_n++] = __builtin_readcyclecounter();  // (no wait for the stores)
+    if (lane == 0 && (c % 70001) == 0)
+        printf("ic record %lld: g %d nu %d out %d  cycles: prologue %lld  constants %lld  electrons %lld  seeds %lld  thomson cdf %lld  kn lattice %lld  energies %lld  output %lld  total %lld\n",
+               c, g_size, nu_size, n_ic, c_t[1] - c_t[0], c_t[2] - c_t[1], c_t[3] - c_t[2], c_t[4] - c_t[3], c_t[5] - c_t[4], c_t[6] - c_t[5],
+               c_t[7] - c_t[6], c_t[8] - c_t[7], c_t[8] - c_t[0]);
+#endif
+    };  // cell()
+
+    long long n_tot;
+    {
+        const IcPhotonArgs A = load_ic_photon_args();
+        n_tot = A.n_run_dev ? (long long)*A.n_run_dev : A.n_run;
+    }
+    // lane l < CST_N: constant l of a cell (18 of the synchrotron block, 14 IC extras, 14 words of Y(gamma)), placed by its record's words
+    auto constants = [&](long long cell_c, long long row0, int nt, int k) -> double {
+        const IcPhotonArgs A = load_ic_photon_args();
+        const double* src = A.cellpar + row0 * VAG_NPAR + k;  // lanes past the list re-read the first word
+        if (lane < CST_Q)
+            src += (long long)lane * nt;
+        else if (lane < CST_Y)
+            src = A.cellq + row0 * VAG_NQ + k + (long long)(lane - CST_Q) * nt;
+        else if (lane < CST_N)
+            src = A.icy + cell_c + (long long)(lane - CST_Y) * A.n_cells;
+        return *src;
+    };
+#if !VAG_IC_PERSISTENT
+    // One wavefront per record.  Its prologue is two dependent round trips -- the record (scalar loads), then the constants -- where the
+    // per-cell plan of r04 needed three (plan -> model -> params / meta / offsets -> constants).
+    const long long c = blockIdx.x;
+    if (c >= n_tot) return;
+    typedef const double __attribute__((address_space(4))) ConstDouble;
+    ConstDouble* rec = (ConstDouble*)(unsigned long long)(load_ic_photon_args().icplan + (size_t)c * IC_PLAN);
+    cell(c, constants((long long)rec[ICP_CELL], (long long)rec[ICP_ROW0], (int)rec[ICP_NT], (int)rec[ICP_K]), []() {});
+#else
+    // Persistent wavefronts (developer build, measured and rejected in r05 -- DESIGN 4i): the launch is as many wavefronts as the device
+    // holds, each takes the records w, w + G, ...; the record of c + 2 G and the constants of c + G are requested before the walk of
+    // record c, so that a cell starts with its constants in a register and its record in L2.
+    const long long G = gridDim.x;
+    long long c = blockIdx.x;
+    // lane l < IC_PLAN: word l of a record
+    auto record = [&](long long cc) -> double {
+        const IcPhotonArgs A = load_ic_photon_args();
+        return cc < n_tot ? A.icplan[(size_t)cc * IC_PLAN + (lane < IC_PLAN ? lane : 0)] : 0.0;
+    };
+    auto constants_of = [&](long long cc, double rec) -> double {
+        if (cc >= n_tot) return 0.0;  // uniform: past the last record
+        return constants((long long)read_lane(rec, ICP_CELL), (long long)read_lane(rec, ICP_ROW0), (int)read_lane(rec, ICP_NT),
+                         (int)read_lane(rec, ICP_K));
+    };
+    double rec1 = record(c);
+    double cst0 = constants_of(c, rec1);
+    rec1 = record(c + G);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (as inside the loop: no read in flight on either way into a cell)
+    for (; c < n_tot; c += G) {
+        double rec2, cst1;
+        cell(c, cst0, [&]() {
+            // vmcnt(0) stated HERE, where it costs nothing (the cell's reads have been consumed; what may still be in flight is the previous
+            // cell's table stores, ~20 k cycles old): the compiler's wait bookkeeping then knows that only the two requests below are
+            // outstanding, and does not put a conservative vmcnt(0) -- i.e. a wait for them -- in front of the walk's first LDS reads
+            // (registers that earlier global reads of this cell had as their destination).
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+            cst1 = constants_of(c + G, rec1);  // (first: rec1's last use, so that rec2 may take its register without a wait)
+            rec2 = record(c + 2 * G);
+        });
+        cst0 = cst1;
+        rec1 = rec2;
+        wave_sync();  // the cell's histograms have been read: the next cell may overwrite them
+    }
+#endif
 }
 
 // ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table: the cell's header {n, first node, last node, log2 of the

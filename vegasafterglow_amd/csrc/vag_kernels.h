@@ -232,15 +232,17 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
 // output at the lattice nodes) -- coupled by an LDS ring.  Writes the interpolated state only: slot VS_GAMMA_TH holds U2_th
 // and slot VS_NP holds m2 until vag_cells_kernel(raw_shock) finishes them (Gamma_th, B, N_p of save_fwd_shock_state).
 // ------------------------------------------------------------------------------------------------
+template <bool TALLY>
 __global__ void __launch_bounds__(128)
 vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
                          const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
                          long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave,
-                         int* __restrict__ fail) {
+                         int* __restrict__ fail /* TALLY (vag_ctx_count_work): right-hand sides of the batch -> fail[4] */) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
     __shared__ DynRing ring;
     __shared__ int s_status[64];
+    [[maybe_unused]] __shared__ int s_rhs[TALLY ? 64 : 1];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0 integrates, role 1 saves
     for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 128) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
     if (threadIdx.x == 0) ring.head = ring.tail = ring.fin = 0;
@@ -322,16 +324,18 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
 #endif
     if (role == 0) {
         int status;
+        [[maybe_unused]] int n_rhs = 0;
         const bool go = active && !stopped;
         if (__any(go && eq.A != 0)) {
-            status = fs_integrator(eq, s, t0, rtol, t_last, go, eq.lg, ring, lane);
+            status = fs_integrator<FsRhs<true>, TALLY>(eq, s, t0, rtol, t_last, go, eq.lg, ring, lane, &n_rhs);
         } else {  // every row of this wavefront sits in a uniform medium
             FsRhs<false> ei;
             ei.m_jet0 = eq.m_jet0, ei.gm_coeff = eq.gm_coeff, ei.inv_gc2 = eq.inv_gc2, ei.eps_e = eq.eps_e, ei.pm2 = eq.pm2;
             ei.rho_ism = eq.rho_ism, ei.A = 0, ei.r02 = 0, ei.lg = eq.lg;
-            status = fs_integrator(ei, s, t0, rtol, t_last, go, eq.lg, ring, lane);
+            status = fs_integrator<FsRhs<false>, TALLY>(ei, s, t0, rtol, t_last, go, eq.lg, ring, lane, &n_rhs);
         }
         s_status[lane] = status;
+        if constexpr (TALLY) s_rhs[lane] = n_rhs;
     } else {
         int k = 0;
         if (active && stopped) {  // raw form of the stopped shock: m2 = 0 finishes to Gamma_th = 1, B = N_p = 0
@@ -363,6 +367,9 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
         const int status = stopped ? 0 : s_status[lane];
         row_status[row] = status;
         if (status > 0 && status < 4) atomicAdd(fail + status, 1);
+        if constexpr (TALLY) {
+            if (!stopped) atomicAdd(fail + 4, s_rhs[lane]);
+        }
     }
 }
 
@@ -1371,6 +1378,8 @@ struct SeriesArgs {
     // (the reduction kernel behind the launch resets it); the items' model offsets are lay.row_off[nb + 1 ...] (the grid kernel's plan scan)
     int nb;
     int* work;
+    // vag_ctx_count_work (the tallying instantiation of vag_flux_fit_rows_kernel only): [0] boundary-spectrum evaluations, [1] interpolations
+    unsigned long long* tally;
 };
 
 // Series kernels: k with s_t[k] < t <= s_t[k+1] (t == s_t[0] -> 0), grown outwards from `hint` (the interval of the same

@@ -133,11 +133,14 @@ class WalkerSharder:
         out = torch.empty((nb,), dtype=torch.float64, device=self.device)
         self._shape = (nb, world, d.per)
         if self.native is not None:
-            # the deal table of the call lives on the (per-device, shared) engine context between shard and finish: the context's
-            # lock is held across the three steps so that another sharder on this device cannot deal in between
+            # The context's lock is held inside shard() and inside finish(), NOT across the collective: a process-local lock held
+            # while waiting for other ranks can deadlock two sharders that take it in different orders on different ranks.  The
+            # engine keeps the deal of a call in flight per (batch size, world, spec), so another sharder of this process may deal
+            # on the same context in between (ABI v11).
             with self.native.lock:
                 self.native.shard(theta.contiguous(), nb, rank, world, d.block)
-                dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
+            dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
+            with self.native.lock:
                 self.native.finish(d.gathered, nb, world, out)
             return out
         if self._costs is None or self._costs.shape[0] != nb:

@@ -536,7 +536,7 @@ class Fitter:
                 _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_state_dev(h, nb, world, tab.data_ptr(), cost.data_ptr())))
                 return tab.cpu().numpy().astype(np.int64).reshape(world, per), cost.cpu().numpy()
 
-        _Native.lock = lock  # dist.WalkerSharder holds it across shard -> all-gather -> finish: the deal table lives on the context
+        _Native.lock = lock  # dist.WalkerSharder takes it around shard() and around finish() (not across the all-gather between them)
         eval_dev.native = _Native
         return eval_dev
 

@@ -283,6 +283,35 @@ def get_context(device=0):
         return _ctx[device]
 
 
+_coalescing = {}  # device -> True while concurrent single-model calls are gathered into batch calls
+
+
+def set_coalescing(enabled=True, max_batch=64, wait_us=50, device=0):
+    """Serve concurrent ``Model.flux_density_grid / flux_density / flux`` calls of a thread pool as batch calls (opt-in).
+
+    The reference's samplers map ``eval_one`` over a ``ThreadPoolExecutor`` with one Model per thread and the GIL released inside the
+    compute methods (pybind.cpp:424-448, fitting/samplers.py:59-70).  On one GPU context such calls are served one after the other, at
+    one call latency each.  With coalescing on, a call blocks in the engine (GIL released) and the calls that wait at the same time with
+    the same request -- times, frequencies / band -- run as ONE batch call (``vag_*_coalesced``, at most ``max_batch`` members; the first
+    caller waits ``wait_us`` for company, later ones queue up while the GPU is busy).  Each caller gets its own model's result and its own
+    model's error.  ``flux_density`` / ``flux`` results are the bits of an uncoalesced call; ``flux_density_grid`` may differ in the last
+    bits (its sums are laid out per batch).  Returns the previous setting."""
+    h, _ = get_context(device)
+    prev = _coalescing.get(device, False)
+    if enabled:
+        _lib.check(_lib.load().vag_ctx_coalesce(h, int(max_batch), int(wait_us)))
+    _coalescing[device] = bool(enabled)
+    return prev
+
+
+def coalescing_stats(device=0):
+    """(calls served, batch calls issued) by the coalescer of this device's context so far."""
+    h, _ = get_context(device)
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    _lib.check(_lib.load().vag_ctx_coalesce_stats(h, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def _as_f64(a, name):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     _req(a.ndim == 1, f"{name} must be one-dimensional")
@@ -377,6 +406,12 @@ class Model:
         _req(nu.size > 0, "frequency array must be non-empty")
         out = np.empty((nu.size, t.size))
         h, lock = get_context(self._device)
+        if _coalescing.get(self._device):  # no Python-side lock: the call blocks in the engine while its batch forms
+            comps, arr = self._component_buffers((nu.size, t.size)) if self._has_components() else (None, None)
+            _lib.check(_lib.load().vag_flux_density_grid_coalesced(
+                h, C.byref(self.params), t.ctypes.data_as(_dp), t.size, nu.ctypes.data_as(_dp), nu.size,
+                None if comps else out.ctypes.data_as(_dp), arr))
+            return FluxDict(*comps) if comps else FluxDict(out)
         if self._has_components():
             comps, arr = self._component_buffers((nu.size, t.size))
             with lock:
@@ -398,6 +433,12 @@ class Model:
                                 "output, use the generic `flux_density_grid` instead")
         out = np.empty(t.size)
         h, lock = get_context(self._device)
+        if _coalescing.get(self._device):
+            comps, arr = self._component_buffers((t.size,)) if self._has_components() else (None, None)
+            _lib.check(_lib.load().vag_flux_density_coalesced(
+                h, C.byref(self.params), t.ctypes.data_as(_dp), nu.ctypes.data_as(_dp), t.size,
+                None if comps else out.ctypes.data_as(_dp), arr))
+            return FluxDict(*comps) if comps else FluxDict(out)
         if self._has_components():
             comps, arr = self._component_buffers((t.size,))
             with lock:
@@ -416,6 +457,12 @@ class Model:
         _req(t.size > 0, "time array must be non-empty")
         out = np.empty(t.size)
         h, lock = get_context(self._device)
+        if _coalescing.get(self._device):
+            comps, arr = self._component_buffers((t.size,)) if self._has_components() else (None, None)
+            _lib.check(_lib.load().vag_flux_coalesced(
+                h, C.byref(self.params), t.ctypes.data_as(_dp), t.size, float(nu_min), float(nu_max), int(num_nu),
+                None if comps else out.ctypes.data_as(_dp), arr))
+            return FluxDict(*comps) if comps else FluxDict(out)
         if self._has_components():
             comps, arr = self._component_buffers((t.size,))
             with lock:
