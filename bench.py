@@ -530,6 +530,56 @@ def walker_cpu_baseline(lib, h, _lib, budget_s=5.0):
     return one, allc
 
 
+def threadpool_bench(lib, h, _lib, n_threads=32, n_walkers=1024, rounds=3, wait_us=50):
+    """The reference's own calling pattern, unmodified (fitting/samplers.py:59-91): eval_one per walker mapped over a
+    ThreadPoolExecutor -- a Model per walker (Fitter._build_model), Model.flux_density at the C4 data's 60 (t, nu) points with the GIL
+    released inside the engine, chi^2 in numpy -- on ONE per-device context.  Serialised (every call its own launch chain) against
+    va.set_coalescing(True): the engine gathers the calls that wait at the same time into batch calls."""
+    from concurrent.futures import ThreadPoolExecutor
+    import _abi
+    import configs
+    import vegasafterglow_amd as va
+    fit, defs, (t, nu, f_obs) = c4_fitter(lib, h, _lib)
+    _, lo, hi = fit.build_spec(defs)
+    theta = lo + (hi - lo) * np.random.default_rng(0).random((n_walkers, len(defs)))
+    prms = []
+    for s in theta:
+        kw = dict(configs.C4_TRUTH)
+        for (name, lg, _, _), v in zip(configs.C4_FREE, s):
+            kw[{"theta_v": "theta_obs"}.get(name, name)] = 10 ** v if lg else v
+        prms.append(_abi.make_params(**kw))
+    order = np.argsort(t)
+    ts, nus, fo = np.ascontiguousarray(t[order]), np.ascontiguousarray(nu[order]), f_obs[order]
+    ln_fo, sig = np.log(fo), 0.1
+
+    def eval_one(p):
+        try:
+            F = va.Model.from_params(p).flux_density(ts, nus).total
+        except Exception:  # noqa: BLE001  (samplers.py:61-70: any failure scores -inf)
+            return -np.inf
+        r = (ln_fo - np.log(np.maximum(F, 1e-300))) / sig
+        return -0.5 * float(np.dot(r, r))
+
+    out = {"threads": n_threads, "walkers": n_walkers, "data_points": int(ts.size),
+           "what": "eval_one (Model.from_params + flux_density + chi^2) over ThreadPoolExecutor(%d), the reference samplers' loop" % n_threads}
+    for label, on in (("serialised", False), ("coalesced", True)):
+        va.set_coalescing(on, max_batch=64, wait_us=wait_us)
+        c0, b0 = va.coalescing_stats()
+        with ThreadPoolExecutor(n_threads) as ex:
+            list(ex.map(eval_one, prms[:64]))  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                ll = list(ex.map(eval_one, prms))
+            dt = (time.perf_counter() - t0) / rounds
+        c1, b1 = va.coalescing_stats()
+        out[label] = {"walker_steps_per_s": n_walkers / dt, "ms_per_1024_walkers": 1e3 * dt, "finite_walkers": int(np.isfinite(ll).sum())}
+        if on:
+            out[label]["mean_batch"] = (c1 - c0) / max(b1 - b0, 1)
+    va.set_coalescing(False)
+    out["coalesced_over_serialised"] = out["coalesced"]["walker_steps_per_s"] / out["serialised"]["walker_steps_per_s"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -657,6 +707,7 @@ def main():
     with_cpu = not args.no_cpu_baseline and world == 1
     tophat = tophat_sweep(lib, h, _lib, dev, with_cpu) if (extra and world == 1) else None
     ensembles = ensemble_bench(lib, h, _lib, dev, with_cpu) if (extra and world == 1) else None
+    threadpool = threadpool_bench(lib, h, _lib) if (extra and world == 1) else None
     single = None
     if extra and world == 1:  # the metric reads "light-curves/sec (single model)": one model per call for configs[1] / [2] / [4]
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -752,6 +803,8 @@ def main():
                               f"{c1a['single_call_vs_1_core']:.2f}x one core"}
         if ensembles:
             out["ensembles_config2_config4"] = ensembles
+        if threadpool:
+            out["walker_steps_threadpool_32"] = threadpool
         if single:
             out["single_model_latency"] = single
         if with_cpu:

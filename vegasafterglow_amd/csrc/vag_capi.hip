@@ -3260,12 +3260,8 @@ static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
     std::unique_lock<std::mutex> lk(c->co_mutex);
     c->co_queue.push_back(&req);
     ++c->co_calls;
-    bool leader = false;
     if (!c->co_leader) {
-        c->co_leader = leader = true;
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c->co_wait_us);
-        while ((int)c->co_queue.size() < c->co_max_batch && c->co_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
-        }
+        c->co_leader = true;
     } else {
         c->co_cv.notify_all();  // (the leader counts the queue)
         c->co_cv.wait(lk, [&] { return req.done || req.promoted; });
@@ -3273,7 +3269,12 @@ static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
             if (req.rc) g_err = req.err;
             return req.rc;
         }
-        leader = true;  // promoted: this request heads the next batch, no waiting for company (the queue filled during the last call)
+        // promoted: this request heads the next batch
+    }
+    {   // the leader waits up to co_wait_us for company (callers of a pool arrive one interpreter hand-off apart)
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c->co_wait_us);
+        while ((int)c->co_queue.size() < c->co_max_batch && c->co_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
     }
     // the leader's batch: its own request and every queued one that asks the same thing, in arrival order
     std::vector<CoalesceRequest*> batch{&req};
@@ -3299,7 +3300,6 @@ static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
     c->co_cv.notify_all();
     lk.unlock();
     if (req.rc) g_err = req.err;
-    (void)leader;
     return req.rc;
 }
 
