@@ -401,6 +401,9 @@ int vag_details_rvs(vag_ctx* ctx, const vag_model_params* params, double t_min, 
  * NULL entries are skipped.  With Radiation(ssc=True) these are the inverse-Compton-cooled values. */
 int vag_details_radiation(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int rvs,
                           double* const* arrays);
+/* ABI v11: SynElectrons::regime of every (theta, t) cell -- determine_regime (src/radiation/synchrotron.cpp:45-60): 1 ... 6 by the
+ * ordering of gamma_a, gamma_c, gamma_m, 0 = none -- regime[n_theta][n_t] (shape as vag_details reports it). */
+int vag_details_regime(vag_ctx* ctx, const vag_model_params* params, double t_min, double t_max, int rvs, int32_t* regime);
 /* ShockDetails.t_obs [s] and .Doppler of every (phi, theta, k) cell (pybind/pymodel.cpp:296-298; shared by the forward
  * and the reverse shock, which ride the same contact discontinuity): [n_phi_eff][n_theta][n_t] with the shape
  * vag_details reports and n_phi_eff = Observer::eff_phi_grid (1 for an on-axis axisymmetric model).  Call with

@@ -45,11 +45,12 @@ full, ref = flux_ms(t, nu)
 print(f"full {t.size} x {nu.size}: flux {full:.2f} ms")
 total = 0.0
 worst = 0.0
-for t0 in range(0, t.size, 100):
-    for n0 in range(0, nu.size, 4):
-        ms, o = flux_ms(t[t0:t0 + 100], nu[n0:n0 + 4])
+TC, NC = int(os.environ.get("T_CHUNK", "100")), int(os.environ.get("NU_CHUNK", "4"))  # (T_CHUNK=200 NU_CHUNK=2: frequency chunks only, r05)
+for t0 in range(0, t.size, TC):
+    for n0 in range(0, nu.size, NC):
+        ms, o = flux_ms(t[t0:t0 + TC], nu[n0:n0 + NC])
         total += ms
-        r = ref[:, n0:n0 + 4, t0:t0 + 100]
+        r = ref[:, n0:n0 + NC, t0:t0 + TC]
         worst = max(worst, float(np.max(np.abs(o - r) / np.where(r > 0, r, 1))))
-        print(f"  t[{t0}:{t0 + 100}] nu[{n0}:{n0 + 4}]: flux {ms:.2f} ms")
+        print(f"  t[{t0}:{t0 + TC}] nu[{n0}:{n0 + NC}]: flux {ms:.2f} ms")
 print(f"sum of sub-requests {total:.2f} ms   max rel difference from the full request {worst:.2e}")

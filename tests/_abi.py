@@ -199,6 +199,16 @@ class CpuLib:
         self._check(fn(C.byref(prm), kind, _p(x), x.size, _p(out)))
         return out
 
+    def grid_shape(self, prm, t_min, t_max):
+        """(n_phi, n_theta, n_t, n_reps, symmetry, phi_mirrored) of the adaptive grid: the shape-only form of details()."""
+        fn = getattr(self.lib, self.prefix + "_details")
+        fn.argtypes = [C.POINTER(ModelParams), C.c_double, C.c_double, C.POINTER(DetailsShape),
+                       C.POINTER(DetailsOut), C.POINTER(_dp), C.c_int, C.POINTER(C.c_int), _dp, C.c_int]
+        fn.restype = C.c_int
+        sh, npe = DetailsShape(), C.c_int(0)
+        self._check(fn(C.byref(prm), t_min, t_max, C.byref(sh), None, None, 0, C.byref(npe), None, 0))
+        return (sh.n_phi, sh.n_theta, sh.n_t, sh.n_reps, sh.symmetry, sh.phi_mirrored)
+
     EXTRA_NAMES = ["gamma_m", "gamma_c", "gamma_a", "gamma_M", "N_e", "column_den", "nu_m", "nu_c", "nu_a",
                    "nu_M", "I_nu_max", "lg2_t", "lg2_doppler", "lg2_geom", "lg2_I_probe", "injection_idx"]
 

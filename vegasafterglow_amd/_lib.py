@@ -110,7 +110,7 @@ EXPORTS = [
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_regime", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
     "vag_ctx_coalesce", "vag_ctx_coalesce_stats", "vag_flux_density_grid_coalesced", "vag_flux_density_coalesced", "vag_flux_coalesced",
 ]
 
@@ -176,6 +176,7 @@ def load():
     lib.vag_details.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_rvs.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(DetailsShape), C.POINTER(DetailsOut)]
     lib.vag_details_radiation.argtypes = [v, _pp, C.c_double, C.c_double, C.c_int, C.POINTER(_dp)]
+    lib.vag_details_regime.argtypes = [v, _pp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int32)]
     lib.vag_details_eat.argtypes = [v, _pp, C.c_double, C.c_double, C.POINTER(C.c_int), _dp, _dp]
     lib.vag_profile_eval.argtypes = [v, _pp, C.c_int, _dp, C.c_int, _dp]
     lib.vag_last_stage_times.argtypes = [v, C.POINTER(StageTimes)]

@@ -3502,6 +3502,44 @@ int vag_details_radiation(vag_ctx* c, const vag_model_params* params, double t_m
     return VAG_OK;
 }
 
+// SynElectrons::regime of every (theta, t) cell (determine_regime, synchrotron.cpp:45-60: the ordering of gamma_a, gamma_c, gamma_m,
+// 1 ... 6, 0 = none), an integer the reference's parity contract covers exactly: from the electron rows the stages left -- and, where
+// the SSC stages ran, checked against the tag vag_photons_ic_kernel stored for its IC kernels (VD_REGIME).
+int vag_details_regime(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, int rvs, int32_t* regime) {
+    ApiLock api_lock(c);
+    vag_details_shape sh;
+    int rc = details_impl(c, params, t_min, t_max, &sh, nullptr, rvs != 0);
+    if (rc) return rc;
+    if (!regime) return set_err(VAG_E_INVALID, "regime must not be null");
+    const int nth = sh.n_theta, nt = sh.n_t;
+    const long long cells = c->n_cells;
+    std::vector<double> buf((size_t)cells * VAG_NDET);
+    std::vector<int> rep_of(nth);
+    const DevBuf& det = rvs ? c->d_celldet_r : c->d_celldet;
+    HIPCHK(hipMemcpy(buf.data(), det.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rep_of.data(), c->d_rep_of.p, sizeof(int) * nth, hipMemcpyDeviceToHost));
+    const bool ssc = rvs ? (params->flags & VAG_FLAG_RVS_SSC) != 0 : (params->flags & VAG_FLAG_SSC) != 0;
+    auto order = [](double a, double cc, double m) {  // determine_regime
+        if (a <= m && m <= cc) return 1;
+        if (m <= a && a <= cc) return 2;
+        if (a <= cc && cc <= m) return 3;
+        if (cc <= a && a <= m) return 4;
+        if (m <= cc && cc <= a) return 5;
+        if (cc <= m && m <= a) return 6;
+        return 0;
+    };
+    for (int j = 0; j < nth; ++j)
+        for (int k = 0; k < nt; ++k) {
+            const size_t q = (size_t)rep_of[j] * nt + k;
+            const int tag = order(buf[(size_t)VD_GAMMA_A * cells + q], buf[(size_t)VD_GAMMA_C * cells + q], buf[(size_t)VD_GAMMA_M * cells + q]);
+            if (ssc && tag != (int)buf[(size_t)VD_REGIME * cells + q])
+                return set_err(VAG_E_INTERNAL, "cell (%d, %d): the regime tag of the IC kernels (%d) is not the ordering of the stored electrons (%d)",
+                               j, k, (int)buf[(size_t)VD_REGIME * cells + q], tag);
+            regime[(size_t)j * nt + k] = tag;
+        }
+    return VAG_OK;
+}
+
 int vag_details_rvs(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                     const vag_details_out* out) {
     ApiLock api_lock(c);

@@ -22,7 +22,10 @@ namespace vag {
 #endif
 constexpr int GRIDROWS_WAVES = VAG_GRIDROWS_WAVES;
 constexpr int GRIDROWS_BANDS = 4;     // frequencies
-constexpr int GRIDROWS_MAX_NT = 128;  // requested times
+#ifndef VAG_GRIDROWS_MAX_NT
+#define VAG_GRIDROWS_MAX_NT 128
+#endif
+constexpr int GRIDROWS_MAX_NT = VAG_GRIDROWS_MAX_NT;  // requested times
 constexpr int GRIDROWS_MAX_SLOTS = 512;
 
 // (Build option VAG_ROWS_RING=1, measured slower and off by default -- DESIGN.md 4h.)  With it the interpolation work of a wavefront
