@@ -357,17 +357,29 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
     }
     for (int i = lane; i < stripes * NS; i += SERIES_THREADS) s_acc[i] = 0;
     __syncthreads();  // the only workgroup-wide barrier
-    const FitRowsLds L{s_sp, s_tp, s_band_of, s_band + wave * SERIES_MAX_BANDS, s_acc};
-    const int W = a.grid_nt, nb = a.nb;
-    const int* __restrict__ blk_off = a.lay.row_off + nb + 1;  // [nb + 1] first block of every model (vag_grid_kernel's plan scan)
-    const int total_items = blk_off[nb] * W;
     int m_lo = 0;  // a wavefront's items ascend
     // the first item of a wavefront is its own number, the later ones come from the counter (one device-wide atomic per item: ~7 ns
     // each on one address, so the 3072 simultaneous first fetches of a launch were 25 us of a 128-walker call); a launch with no more
     // items than wavefronts never touches it
-    const int n_waves = (int)gridDim.x * FITROWS_WAVES;
     int item = (int)blockIdx.x * FITROWS_WAVES + wave;
     for (;; ) {
+        // (r05, as vag_flux_grid_rows_kernel<0>: a turn re-reads the arguments through an opaque kernel-argument pointer and makes the
+        // lane / wavefront numbers opaque, so that the loop keeps the item number alive and not forty scalars)
+#if !defined(VAG_HOST_DEBUG) && !defined(VAG_FIT_NO_REREAD)
+        const SeriesArgs A = load_series_args();
+        int lane_i = threadIdx.x & 63, wave_i = threadIdx.x >> 6;
+        asm volatile("" : "+v"(lane_i), "+v"(wave_i));
+        wave_i = __builtin_amdgcn_readfirstlane(wave_i);
+#else
+        const SeriesArgs& A = a;
+        const int lane_i = lane, wave_i = wave;
+#endif
+        const FitRowsLds L{s_sp, s_tp, s_band_of, s_band + wave_i * SERIES_MAX_BANDS,
+                           s_band + FITROWS_WAVES * SERIES_MAX_BANDS + (size_t)wave_i * stripes * NS};
+        const int W = A.grid_nt, nb = A.nb;
+        const int* __restrict__ blk_off = A.lay.row_off + nb + 1;  // [nb + 1] first block of every model (vag_grid_kernel's plan scan)
+        const int total_items = blk_off[nb] * W;
+        const int n_waves = (int)gridDim.x * FITROWS_WAVES;
         if (item >= total_items) break;
         const int blk = item / W, wseg = item - blk * W;
         int lo = m_lo, hi = nb;  // blk_off[lo] <= blk < blk_off[hi]: the model is the last one that starts at or before the block
@@ -379,9 +391,9 @@ vag_flux_fit_rows_kernel(SeriesArgs a) {
                 hi = mid;
         }
         m_lo = lo;
-        fit_rows_item<MODE, NBMAX, SPREAD, COUNT>(a, L, lo, blk - blk_off[lo], wseg, W, lane);
+        fit_rows_item<MODE, NBMAX, SPREAD, COUNT>(A, L, lo, blk - blk_off[lo], wseg, W, lane_i);
         if (total_items <= n_waves) break;
-        if (lane == 0) item = n_waves + __hip_atomic_fetch_add(a.work, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane_i == 0) item = n_waves + __hip_atomic_fetch_add(A.work, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         item = __builtin_amdgcn_readfirstlane(item);
     }
     // (the counter is put back to zero by the reduction kernel that follows every launch of this one)

@@ -343,20 +343,6 @@ VAG_DEV void grid_rows_item(const SeriesArgs& a, const GridRowsLds& L, int m, in
     }
 }
 
-// The kernel's arguments read again from the kernel-argument segment (constant address space: scalar loads), the pointer hidden from
-// the optimiser first: a loop that calls this per turn re-reads the arguments per turn instead of keeping all of them in scalar
-// registers across the loop (where they overflow into VGPR lanes, and those into scratch).
-#ifndef VAG_HOST_DEBUG
-typedef const SeriesArgs __attribute__((address_space(4))) KernargSeriesArgs;
-VAG_DEV SeriesArgs load_series_args() {
-    KernargSeriesArgs* p = (KernargSeriesArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    SeriesArgs a;
-    __builtin_memcpy(&a, p, sizeof(SeriesArgs));
-    return a;
-}
-#endif
-
 // a.n = nt * nnu slots ([l][idx], nu outer), a.grid_nt = nt, a.n_bands = nnu; partial sums [nb][max_chunks][slots], one per block of
 // 64 rows.  MODE as in vag_flux_grid_kernel (FLUX_SYN / FLUX_SYN_IC / FLUX_SSC).
 // FLUX_SYN is a PERSISTENT launch like vag_flux_fit_rows_kernel (the launch fills the GPU once, every wavefront takes blocks -- its own

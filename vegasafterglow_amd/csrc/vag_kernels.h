@@ -1382,6 +1382,21 @@ struct SeriesArgs {
     unsigned long long* tally;
 };
 
+// The kernel's arguments read again from the kernel-argument segment (constant address space: scalar loads), the pointer hidden from
+// the optimiser first: a loop that calls this per turn re-reads the arguments per turn instead of keeping all of them in scalar
+// registers across the loop (where they overflow into VGPR lanes, and those into scratch).
+#ifndef VAG_HOST_DEBUG
+typedef const SeriesArgs __attribute__((address_space(4))) KernargSeriesArgs;
+VAG_DEV SeriesArgs load_series_args() {
+    KernargSeriesArgs* p = (KernargSeriesArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    SeriesArgs a;
+    __builtin_memcpy(&a, p, sizeof(SeriesArgs));
+    return a;
+}
+#endif
+
+
 // Series kernels: k with s_t[k] < t <= s_t[k+1] (t == s_t[0] -> 0), grown outwards from `hint` (the interval of the same
 // point in the previous row) and then bisected.  Requires s_t[0] <= t <= s_t[K-1].
 VAG_DEV int series_bracket(const double* __restrict__ s_t, int K, double t, int hint) {
