@@ -396,6 +396,139 @@ struct Dopri5 {
     }
 };
 
+// DOPRI5 for a FLAT attempt loop (r05; the form vag_dyn_fast.h gave the forward shock in r02): attempt() makes ONE step attempt from
+// (x, dx, t) with the step dt and leaves the candidate (xn, k3 .. k7, h) beside the untouched state; the caller accepts or rejects it
+// per lane and commit()s.  Dopri5::step (vag_device.h) repeats its attempt inside the call until it is accepted, so a wavefront of 64
+// rows repeats while ANY row rejects -- with ~7 % of a row's attempts rejected nearly every trip of the old loop paid for two.  Same
+// arithmetic per attempt, same controller (controlled_runge_kutta.hpp:752-782), same dense output (runge_kutta_dopri5.hpp:238-258).
+// The stage derivatives k2 .. k6 of the last attempt live where KStore puts them: in registers (KRegs) or in LDS (KLds: 5 x 11 doubles per
+// lane that the 256 + 254 registers of the retry-loop form shuffled between VGPRs and AGPRs -- two moves per double each way -- are
+// one ds_write / ds_read each, requested in batches a stage ahead of their use).
+template <int N>
+struct KRegs {
+    double k[5][N];
+    VAG_DEV void put(int s, int i, double v) { k[s][i] = v; }
+    VAG_DEV double get(int s, int i) const { return k[s][i]; }
+};
+template <int N>
+struct KLds {  // [5][N][64] doubles of the wavefront's LDS, this lane's column
+    volatile double* base;  // (volatile: the values must go through LDS, not be forwarded in registers)
+    VAG_DEV void put(int s, int i, double v) { base[(s * N + i) * 64] = v; }
+    VAG_DEV double get(int s, int i) const { return base[(s * N + i) * 64]; }
+};
+template <int N, class KStore = KRegs<N>>
+struct Dopri5Flat {
+    double x[N], dx[N];  // state / derivative at t (FSAL)
+    double xn[N], k7[N];  // the last attempt: candidate state at t + h and its derivative
+    KStore ks;            // k2 .. k6 of the last attempt (index 0 .. 4)
+    double t, dt, h, eps;
+
+    template <class F>
+    VAG_DEV void init(const double* x0, double t0, double dt0, double tol, F& f) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = x0[i];
+        t = t0;
+        dt = dt0;
+        eps = tol;
+        f(x, dx, t);
+    }
+    // one attempt; true = accepted (dt is then the controller's proposal for the NEXT step), false = rejected (dt is the retry's step)
+    template <class F>
+    VAG_DEV bool attempt(F& f) {
+        constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+        constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40;
+        constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
+        constexpr double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729;
+        constexpr double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+        constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+        constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
+                         dc5 = c5 - -92097.0 / 339200, dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+        double xt[N], kr[N];
+        h = dt;
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b21) * dx[i];
+        f(xt, kr, t + h * a2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) ks.put(0, i, kr[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b31) * dx[i] + (h * b32) * kr[i];
+        f(xt, kr, t + h * a3);
+#pragma unroll
+        for (int i = 0; i < N; ++i) ks.put(1, i, kr[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b41) * dx[i] + (h * b42) * ks.get(0, i) + (h * b43) * kr[i];
+        f(xt, kr, t + h * a4);
+#pragma unroll
+        for (int i = 0; i < N; ++i) ks.put(2, i, kr[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b51) * dx[i] + (h * b52) * ks.get(0, i) + (h * b53) * ks.get(1, i) + (h * b54) * kr[i];
+        f(xt, kr, t + h * a5);
+#pragma unroll
+        for (int i = 0; i < N; ++i) ks.put(3, i, kr[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            xt[i] = x[i] + (h * b61) * dx[i] + (h * b62) * ks.get(0, i) + (h * b63) * ks.get(1, i) + (h * b64) * ks.get(2, i) + (h * b65) * kr[i];
+        f(xt, kr, t + h);
+#pragma unroll
+        for (int i = 0; i < N; ++i) ks.put(4, i, kr[i]);
+        double k3[N], k4[N], k5[N];  // (read once for the candidate and the error estimate)
+#pragma unroll
+        for (int i = 0; i < N; ++i) k3[i] = ks.get(1, i), k4[i] = ks.get(2, i), k5[i] = ks.get(3, i);
+        const double* k6 = kr;
+        double xe[N];  // the error estimate up to its last term (the sum is formed left to right: same roundings as in one expression)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            xn[i] = x[i] + (h * c1) * dx[i] + (h * c3) * k3[i] + (h * c4) * k4[i] + (h * c5) * k5[i] + (h * c6) * k6[i];
+            xe[i] = (h * dc1) * dx[i] + (h * dc3) * k3[i] + (h * dc4) * k4[i] + (h * dc5) * k5[i] + (h * dc6) * k6[i];
+        }
+        f(xn, k7, t + h);
+        double err = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            err = dmax(err, fabs(xe[i] + (h * dc7) * k7[i]) * rcp_fast(eps + eps * (fabs(x[i]) + fabs(h) * fabs(dx[i]))));
+        if (err > 1.0) {
+            dt = h * dmax(9.0 / 10.0 * exp2_sat(log2_fast(err) * (-1.0 / 3)), 1.0 / 5.0);
+            return false;
+        }
+        if (err < 0.5) {
+            err = dmax(3.2e-4, err);  // 5^-5
+            dt = h * (9.0 / 10.0 * exp2_fast(log2_fast(err) * (-1.0 / 5)));
+        }
+        return true;
+    }
+    VAG_DEV void commit() {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            x[i] = xn[i];
+            dx[i] = k7[i];
+        }
+        t = t + h;
+    }
+    // dense output of the last attempt at tq in (t, t + h], BEFORE commit()
+    VAG_DEV void interp(double tq, double* out) const {
+        constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+        const double hh = (t + h) - t;  // (the committed form measures t_new - t_old)
+        const double th = (tq - t) * rcp_fast(hh);
+        const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) * (1.0 / 11282082432.0);
+        const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) * (1.0 / 32700410799.0);
+        const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) * (1.0 / 1880347072.0);
+        const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) * (1.0 / 199316789632.0);
+        const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) * (1.0 / 822651844.0);
+        const double X7 = 10.0 * (7414447.0 - 829305.0 * th) * (1.0 / 29380423.0);
+        const double thm1 = th - 1.0, th2 = th * th;
+        const double A = th2 * (3.0 - 2.0 * th);
+        const double B = th2 * thm1;
+        const double C = th2 * thm1 * thm1;
+        const double D = th * thm1 * thm1;
+        const double w1 = hh * (A * b1 - C * X1 + D), w3 = hh * (A * b3 + C * X3), w4 = hh * (A * b4 - C * X4),
+                     w5 = hh * (A * b5 + C * X5), w6 = hh * (A * b6 - C * X6), w7 = hh * (B + C * X7);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            out[i] = x[i] + w1 * dx[i] + w3 * ks.get(1, i) + w4 * ks.get(2, i) + w5 * ks.get(3, i) + w6 * ks.get(4, i) + w7 * k7[i];
+    }
+};
+
+
 // ---- deceleration time estimate: src/core/grid-refinement.h:402-453 ----
 VAG_DEV double estimate_t_dec(const Jet& jet, const Medium& med, double theta) {
     const double gamma = jet_Gamma0(jet, theta);

@@ -162,9 +162,12 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
     // Shock ctor defaults for nodes never reached (shock.cpp:12-24)
     int k = 0;
     double t_k = t_first;
-    Dopri5<NS> st;
+    // Flat attempt loop (Dopri5Flat, r05): a trip of the wavefront is one attempt of every unfinished row; the saves of the lattice nodes
+    // an accepted step passed read the candidate before it is committed.  (Until r04 Dopri5::step repeated its attempt inside the call:
+    // a wavefront repeated while ANY of its rows rejected.)
+    Dopri5Flat<NS> st;
     st.init(s, t0, 0.01 * t0, P.rtol, eq);
-    int status = 0;
+    int status = 0, fails = 0, steps = 0;
 #ifdef VAG_DYN_STAMPS  // developer aid: cycles of row 0 spent stepping / saving
     long long c_step = 0, c_save = 0, c_mark = __builtin_readcyclecounter();
     const long long c_begin = c_mark;
@@ -173,38 +176,48 @@ vag_dynamics_kernel(const vag_model_params* __restrict__ params, int nb, const V
 #else
 #define VAG_DYN_MARK(acc) do { } while (0)
 #endif
-    for (int steps = 0; st.t <= t_last;) {
-        if (!st.step(eq)) {
-            status = 1;
-            break;
+    bool done = !(st.t <= t_last);
+    while (__any(!done)) {
+        if (done) continue;
+        if (!st.attempt(eq)) {
+            if (++fails >= 500) {  // max_step_checker.hpp:92
+                status = 1;
+                done = true;
+            }
+            continue;
         }
+        fails = 0;
         VAG_DYN_MARK(c_step);
 #ifdef VAG_DYN_STAMPS
         ++n_steps;
 #endif
+        const double tn = st.t + st.h;
         if (++steps > 100000) {
             status = 2;
-            break;
+            done = true;
+        } else {
+            while (k < nt && tn > t_k) {
+                double q[NS];
+                st.interp(t_k, q);
+                if constexpr (SPREAD) o_th[k] = q[5];
+                // save_fwd_shock_state
+                const double comp = compression_fwd(q[0]);
+                const double rho = medium_rho(eq.med, q[3]);
+                const double Gth = (q[1] == 0) ? 1 : q[2] * rcp_fast(q[1] * C_C2) + 1;
+                const double e_th = (Gth - 1) * (rho * comp) * C_C2;
+                o_teng[k] = t_k;
+                o_tcomv[k] = q[4];
+                o_r[k] = q[3];
+                o_G[k] = q[0];
+                o_Gth[k] = Gth;
+                o_B[k] = sqrt_fast(8 * C_PI * P.eps_B * e_th);
+                o_Np[k] = q[1] / C_MP;
+                ++k;
+                if (k < nt) t_k = node(k);
+            }
         }
-        while (k < nt && st.t > t_k) {
-            double q[NS];
-            st.interp(t_k, q);
-            if constexpr (SPREAD) o_th[k] = q[5];
-            // save_fwd_shock_state
-            const double comp = compression_fwd(q[0]);
-            const double rho = medium_rho(eq.med, q[3]);
-            const double Gth = (q[1] == 0) ? 1 : q[2] * rcp_fast(q[1] * C_C2) + 1;
-            const double e_th = (Gth - 1) * (rho * comp) * C_C2;
-            o_teng[k] = t_k;
-            o_tcomv[k] = q[4];
-            o_r[k] = q[3];
-            o_G[k] = q[0];
-            o_Gth[k] = Gth;
-            o_B[k] = sqrt_fast(8 * C_PI * P.eps_B * e_th);
-            o_Np[k] = q[1] / C_MP;
-            ++k;
-            if (k < nt) t_k = node(k);
-        }
+        st.commit();
+        if (!(st.t <= t_last)) done = true;
         VAG_DYN_MARK(c_save);
     }
 #ifdef VAG_DYN_STAMPS
