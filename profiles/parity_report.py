@@ -70,7 +70,7 @@ for name, (kw, t, nu) in tiers.items():
     O, G = orc.flux_components4(prm, t, nu), gpu_comp4(prm, t, nu)
     print(f"{name:28s} " + " ".join(f"{rel(g, o, 1e-12):10.2e}" if o.max() > 0 else f"{'-':>10s}" for g, o in zip(G, O)))
 
-print("\nall 13 golden baselines of the reference test-suite (contract: |d| <= 2e-3 |ref| + 1e-2 max|ref| per component)")
+print("\nall 12 golden baselines of the reference test-suite (contract: |d| <= 2e-3 |ref| + 1e-2 max|ref| per component)")
 import glob
 for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))):
     name = os.path.basename(path)[:-4]

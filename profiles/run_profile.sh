@@ -3,7 +3,7 @@
 # (`python3 bench.py --gpus 1 --steps 20 --warmup 5`) and, in SEPARATE passes, SQ / TCC counters of the headline workload alone (--pmc is never combined with sys/hip/hsa traces;
 # every kernel runs serialised under --pmc, so the secondary legs are left out there).  Usage: profiles/run_profile.sh <tag>
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r05}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
