@@ -67,6 +67,24 @@ def test_defaults_and_validation_through_the_c_abi(lib):
     assert b"eps_e" in lib.vag_last_error()
 
 
+def test_thread_pool_entry_points_reject_bad_arguments_without_touching_a_device(lib):
+    """ABI v11: the coalesced single-model entry points and their configuration validate before they queue anything (no GPU here: a
+    null context / buffer is VAG_E_INVALID with a message, never a crash), and the Python switch is off by default."""
+    dp = C.POINTER(C.c_double)
+    p = _lib.ModelParams()
+    lib.vag_params_default(C.byref(p))
+    t = np.array([1e3, 1e4])
+    out = np.empty(2)
+    assert lib.vag_flux_density_coalesced(None, C.byref(p), t.ctypes.data_as(dp), t.ctypes.data_as(dp), 2, out.ctypes.data_as(dp), None) == _lib.VAG_E_INVALID
+    assert b"null" in lib.vag_last_error()
+    assert lib.vag_flux_density_grid_coalesced(None, C.byref(p), t.ctypes.data_as(dp), 2, t.ctypes.data_as(dp), 2, out.ctypes.data_as(dp), None) == _lib.VAG_E_INVALID
+    assert lib.vag_flux_coalesced(None, C.byref(p), t.ctypes.data_as(dp), 2, 1e14, 1e15, 4, out.ctypes.data_as(dp), None) == _lib.VAG_E_INVALID
+    assert lib.vag_ctx_coalesce(None, 64, 50) == _lib.VAG_E_INVALID
+    assert lib.vag_ctx_coalesce_stats(None, None, None) == _lib.VAG_E_INVALID
+    from vegasafterglow_amd import model
+    assert not any(model._coalescing.values())
+
+
 def test_no_cpu_fallback_without_a_device(lib):
     if lib.vag_device_count() > 0:
         pytest.skip("a HIP device is present")
