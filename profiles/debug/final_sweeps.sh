@@ -1,5 +1,5 @@
-# Developer aid (GPU box): the randomised checks with the round's final library, into gpurun_out/r04_sweep_final.txt
-exec > gpurun_out/r04_sweep_final3.txt 2>&1
+# Developer aid (GPU box): the randomised checks with the round's final library, into gpurun_out/r05_sweep_final.txt
+exec > gpurun_out/r05_sweep_final.txt 2>&1
 echo "## rows_stress.py (row-per-lane kernels against the row-per-wavefront / workgroup kernels on random models)"
 timeout 900 python profiles/debug/rows_stress.py 2>&1 | grep -v amdgpu | tail -25
 echo "## prior_sweep.py 256 (C4 prior box, series + grid forms, against the checker)"
