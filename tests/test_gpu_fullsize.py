@@ -501,6 +501,59 @@ def test_two_fitters_alternating_on_one_context_keep_their_own_cost_ranking(eng,
         _lib.check(lib.vag_ctx_set_stream(h, None))
 
 
+def test_two_sharded_calls_in_flight_on_one_context_finish_with_their_own_deals(eng, oracle):
+    """ABI v11: the deal of a call in flight is kept per (batch size, world, spec), so another sharder of the same process may deal on
+    the shared context between a call's shard and its finish (the Python side no longer holds the context lock across the all-gather:
+    a process-local lock held while waiting for other ranks can deadlock).  Two fitters, same batch shape: A deals, B deals, A
+    finishes, B finishes -- and the other way round -- each ln L vector the bits of its plain call; finishes of equal shape are served in
+    the order the calls were dealt."""
+    import torch
+    lib, h = eng
+    fa, defs = _c4_fitter(oracle)
+    t, nu = configs.c4_mock_data()
+    tb = t * (t / t.min()) ** 0.7
+    truth = oracle.flux_density(_abi.make_params(**configs.C4_TRUTH), tb, nu)
+    fb = fitting.Fitter(z=configs.C4_TRUTH["z"], lumi_dist=configs.C4_TRUTH["lumi_dist"], jet="gaussian", medium="ism")
+    for b in configs.C4_BANDS:
+        sel = nu == b
+        fb.add_flux_density(b, tb[sel], truth[sel], 0.1 * truth[sel])
+    sa, lo, hi = fa.build_spec(defs)
+    sb, _, _ = fb.build_spec(defs)
+    nb, ndim, world = 80, len(defs), 2
+    per = nb // world
+    samples = lo + (hi - lo) * np.random.default_rng(34).random((nb, ndim))
+    want = {"a": fa.loglike_batch(samples, defs), "b": fb.loglike_batch(samples, defs)}
+    assert not np.array_equal(want["a"], want["b"])
+    dev = torch.device("cuda", 0)
+    d_theta = torch.from_numpy(samples).to(dev)
+    _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+
+    def shard(spec):
+        blocks = []
+        for rank in range(world):
+            blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_dev(h, C.byref(spec), d_theta.data_ptr(), nb, ndim, rank, world, blk.data_ptr()))
+            blocks.append(blk)
+        return torch.cat(blocks, 0).contiguous()
+
+    def finish(gathered):
+        out = torch.empty((nb,), dtype=torch.float64, device=dev)
+        _lib.check(lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr()))
+        return out.cpu().numpy()
+
+    try:
+        for first, second in (("a", "b"), ("b", "a"), ("a", "b")):
+            specs = {"a": sa, "b": sb}
+            g1 = shard(specs[first])
+            g2 = shard(specs[second])  # deals on the same context while the first call waits for its "all-gather"
+            assert np.array_equal(finish(g1), want[first])
+            assert np.array_equal(finish(g2), want[second])
+        assert lib.vag_loglike_shard_finish_dev(h, g1.data_ptr(), nb, world, torch.empty((nb,), dtype=torch.float64, device=dev).data_ptr()) == _lib.VAG_E_INVALID
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_ctx_set_stream(h, None))
+
+
 def test_context_buffers_are_ordered_across_a_change_of_stream(eng, oracle):
     """vag_ctx_set_stream chains the streams (event at the tail of the one it leaves, waited for by the one it takes): a
     likelihood call queued on a torch side stream through the shared context and a grid request right behind it on the
