@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 11  /* v11: vag_plan.ode_rhs; a likelihood call's work tallies under vag_ctx_count_work (v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream) */
+#define VAG_ABI_VERSION 12  /* v12: vag_plan.n_ssc_slow_cells; v11: vag_plan.ode_rhs; a likelihood call's work tallies under vag_ctx_count_work (v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream) */
 
 /* error codes */
 #define VAG_OK 0
@@ -478,6 +478,10 @@ typedef struct vag_plan {
      * spreading, injection).  In the same mode a likelihood call's spec_evals / interps are tallied by the flux kernel itself
      * (boundary-spectrum evaluations actually formed, data points inside a row's lattice) instead of the 2 / 1 per (row, point) bound. */
     int64_t ode_rhs;
+    /* ABI v12: SSC cells of the last call whose lattices exceed the wavefront-per-cell kernel's on-chip layout (more than 128 seed
+     * frequencies, 64 electron energies or 192 output nodes) and took the general kernel with its arrays in HBM -- same algorithm, same
+     * table.  A likelihood call does not wait for the count: vag_last_plan reads it then, for the call's last table build only */
+    int64_t n_ssc_slow_cells;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

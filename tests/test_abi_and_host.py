@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert lib.vag_abi_version() == 11
+    assert lib.vag_abi_version() == 12
     assert b"gfx950" in lib.vag_version()
 
 
@@ -50,10 +50,11 @@ def test_struct_layouts_match_the_header():
     v6 = 272 + 4 + 64 + 64 + 8 + 5 * 8 + 4 + 8 + 8 + 8 + 8  # ... + ext_kernel, a_v_fixed, n_bands+pad, bands
     assert _lib.FitSpec.use_priors.offset == v6  # ABI v7 appends: use_priors+pad, lower, upper, prior_kind, prior_a, prior_b
     assert C.sizeof(_lib.FitSpec) == v6 + 8 + 128 + 128 + 64 + 128 + 128
-    # ABI v8 appends n_models_ssc_rebuilt + pad (v11: the pad is n_ssc_all_cell_fallbacks), v10 ic_pool_bytes, v11 ode_rhs
-    assert C.sizeof(_lib.Plan) == 4 + 4 + 5 * 8 + 6 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8
+    # ABI v8 appends n_models_ssc_rebuilt + pad (v11: the pad is n_ssc_all_cell_fallbacks), v10 ic_pool_bytes, v11 ode_rhs, v12 n_ssc_slow_cells
+    assert C.sizeof(_lib.Plan) == 4 + 4 + 5 * 8 + 6 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 8
     assert _lib.Plan.n_ssc_all_cell_fallbacks.offset == _lib.Plan.n_models_ssc_rebuilt.offset + 4
     assert _lib.Plan.ode_rhs.offset == _lib.Plan.ic_pool_bytes.offset + 8
+    assert _lib.Plan.n_ssc_slow_cells.offset == _lib.Plan.ode_rhs.offset + 8
 
 
 def test_defaults_and_validation_through_the_c_abi(lib):

@@ -1145,6 +1145,99 @@ def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
     assert plan.n_ssc_all_cell_fallbacks == 0
 
 
+@pytest.mark.parametrize("case", ["kn_rvs_wind", "thomson_ism", "kn_ism_offaxis"])
+def test_ssc_cells_beyond_the_on_chip_lattice_limits_take_the_general_kernel(eng, oracle, case):
+    """The reference sizes an SSC cell's lattices per cell (ICPhoton::initialize_grids, inverse-compton.h:340-369); the wavefront-per-cell
+    kernel holds at most 128 seed frequencies, 64 electron energies and 192 output nodes on chip.  A cell beyond that takes
+    vag_ic_photon_slow_kernel -- ICPhoton::generate_spectrum in the reference's own CDF form, arrays in HBM -- instead of
+    VAG_E_CAPACITY.  No cell of the reference's configurations is that long, so VAG_DEBUG_IC_FAST_NU_MAX lowers the fast kernel's limit:
+    0 sends EVERY cell through the general kernel (which makes this also a check of the fast kernel's diagonal-histogram form against a
+    second, reference-shaped restatement on the device), a limit inside the batch's range mixes the two.  Same components to 1e-11,
+    the count is reported in vag_plan.n_ssc_slow_cells, and the all-slow run is compared with the CPU checker as well."""
+    lib, h = eng
+    kw = {"kn_rvs_wind": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.3, duration=50.0, ssc=True, kn=True,
+                              rvs=dict(eps_e=0.1, eps_B=0.01, p=2.3, ssc=True, kn=True)),
+          "thomson_ism": dict(jet="TophatJet", theta_obs=0.0, ssc=True, kn=False),
+          "kn_ism_offaxis": dict(jet="GaussianJet", theta_obs=0.25, ssc=True, kn=True, eps_B=1e-4)}[case]
+    prm = _abi.make_params(**kw)
+    t, nu = np.logspace(2.5, 7, 20), np.array([1e9, 1e14, 1e17, 1e20, 1e23, 1e26])
+
+    def run(limit):
+        if limit is not None:
+            os.environ["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
+        try:
+            comps = gpu_components4(eng, prm, t, nu)
+        finally:
+            os.environ.pop("VAG_DEBUG_IC_FAST_NU_MAX", None)
+        pl = _lib.Plan()
+        lib.vag_last_plan(h, C.byref(pl))
+        return comps, pl.n_ssc_slow_cells
+    want, n0 = run(None)
+    assert n0 == 0 and want[1].max() > 0
+    got, n_all = run(0)
+    assert n_all > 20
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g, w, rtol=1e-11, atol=0)
+    # a limit that splits the cells: walk down from the fast kernel's own until some, not all, cells are over it
+    n_mix = 0
+    for limit in range(120, 8, -8):
+        mixed, n_mix = run(limit)
+        if 0 < n_mix < n_all:
+            break
+    assert 0 < n_mix < n_all
+    for g, w in zip(mixed, want):
+        np.testing.assert_allclose(g, w, rtol=1e-11, atol=0)
+    # and against the CPU checker, like any other SSC result
+    ref = oracle.flux_components4(prm, t, nu)  # [4 comps][nu][t]
+    for g, r in zip(got, ref):
+        assert _within_golden_contract(g[0], np.asarray(r))
+
+
+def test_ssc_loglike_with_cells_on_the_general_kernel(eng, oracle):
+    """A likelihood call never waits for the table build's counters: the general kernel is launched over a list it reads from HBM and
+    its cells draw on a fixed reserve of the pool (64 MB).  With some cells over the (lowered) limit the walkers score what they score
+    otherwise; with EVERY cell over it the reserve runs out and the walkers concerned score -inf, counted as SSC failures -- loud, not
+    wrong."""
+    rng = np.random.default_rng(17)
+    t = np.sort(10 ** rng.uniform(3.0, 6.0, 40))
+    nu = 10 ** rng.choice([14.7, 17.5, 23.0], size=t.size)
+    f = fitting.Fitter(z=1.0, lumi_dist=1e28, jet="gaussian", medium="ism", fwd_ssc=True, kn=True)
+    truth = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True)
+    f_obs = oracle.flux_density(truth, t, nu) * (1 + 0.05 * rng.standard_normal(t.size))
+    f.add_flux_density(nu, t, f_obs, 0.05 * f_obs)
+    P, S = fitting.ParamDef, fitting.Scale
+    defs = [P("E_iso", 1e51, 1e53, S.log), P("Gamma0", 100, 500, S.log), P("theta_c", 0.05, 0.2, S.linear),
+            P("theta_v", 0.0, 0.4, S.linear), P("n_ism", 0.1, 10, S.log), P("p", 2.1, 2.6, S.linear),
+            P("eps_e", 0.03, 0.3, S.log), P("eps_B", 1e-3, 1e-1, S.log), P("xi_e", 1.0, 1.0, S.fixed, 1.0)]
+    lo = np.array([51, 2.0, 0.05, 0.0, -1, 2.1, np.log10(0.03), -3])
+    hi = np.array([53, np.log10(500), 0.2, 0.4, 1, 2.6, np.log10(0.3), -1])
+    theta = lo + (hi - lo) * rng.random((8, 8))
+    want = f.loglike_batch(theta, defs)
+    assert np.all(np.isfinite(want)) and f.last_plan.n_ssc_slow_cells == 0
+
+    def run(limit):
+        os.environ["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
+        try:
+            ll = f.loglike_batch(theta, defs)
+        finally:
+            os.environ.pop("VAG_DEBUG_IC_FAST_NU_MAX")
+        return ll, f.last_plan
+    n_slow = 0
+    for limit in range(120, 8, -4):  # the highest limit that leaves some cells over it: a handful of them
+        ll, plan = run(limit)
+        n_slow = plan.n_ssc_slow_cells
+        if n_slow > 0:
+            break
+    assert 0 < n_slow < 3000 and plan.n_walkers_ssc_failed == 0
+    np.testing.assert_allclose(ll, want, rtol=1e-10, atol=0)
+    ll, plan = run(0)  # every cell: far beyond the reserve
+    assert plan.n_walkers_ssc_failed >= 1 and plan.n_walkers_rejected == plan.n_walkers_ssc_failed
+    assert np.sum(np.isneginf(ll)) == plan.n_walkers_ssc_failed
+    ok = np.isfinite(ll)
+    np.testing.assert_allclose(ll[ok], want[ok], rtol=1e-10, atol=0)
+    assert np.array_equal(f.loglike_batch(theta, defs), want)  # and the context is in order afterwards
+
+
 @pytest.mark.parametrize("case", ["grid", "series", "fused"])
 def test_ssc_band_breach_rebuilds_the_tables_unclamped(eng, case):
     """ICPhoton::compute_log2_I_nu drops a cell's band clamp and rebuilds its spectrum when a query falls outside the clamped

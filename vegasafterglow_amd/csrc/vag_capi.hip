@@ -335,7 +335,7 @@ struct vag_ctx {
     DevBuf d_sptab, d_workcount, d_knlut, d_icy, d_cellq, d_band, d_icstatus, d_icunclamp, d_ssc;
     // SSC tables: a header per cell, the lattice plan between the plan and the spectrum kernel, and the pool of tables (each as long
     // as its own output lattice; offsets handed out by vag_ic_plan_kernel, d_icused counts the doubles in use)
-    DevBuf d_ichdr, d_icplan, d_icpool, d_icused;
+    DevBuf d_ichdr, d_icplan, d_icpool, d_icused, d_icslow /* records of the cells on the spectrum kernel's slow path */;
     DevBuf d_icneed;  // [cells] bytes: 1 = some (theta, phi) row's observation window touches the cell (vag_ic_band_kernel)
     bool count_work = false;
     bool ic_all_cells = false;    // this request's SSC tables are built for every cell (the lazy selection was caught with a hole, see check_ic_status)
@@ -392,6 +392,7 @@ struct vag_ctx {
     bool fit_stats_pending = false;  // d_fitstat of the last likelihood call not read back yet
     bool ic_need_reset = true;       // first SSC table build of a pass clears d_icstatus
     bool ic_soft_fail = false;       // likelihood calls: SSC table failures invalidate the walker instead of raising
+    bool ic_slow_unread = false;     // the last table build did not wait for its counters: vag_last_plan reads the slow path's from HBM
     // plan of the last grid pass
     int nb = 0, n_rows = 0, max_k = 0, max_pairs = 0;
     long long n_cells = 0, total_pairs = 0, eat_cells = 0;
@@ -587,7 +588,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused,
+    for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused, &c->d_icslow,
                       &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
@@ -683,6 +684,13 @@ static int read_row_failures(vag_ctx* c) {
         c->plan.n_walkers_rejected = fs[0];
         c->plan.n_walkers_ssc_failed = fs[1];
         c->fit_stats_pending = false;
+    }
+    if (c->ic_slow_unread && c->d_icused.p) {  // a likelihood call's LAST table build (the builds before it reused the counters)
+        unsigned long long n = 0;
+        HIPCHK(hipMemcpyAsync(&n, c->d_icused.as<unsigned long long>() + 3, sizeof n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->plan.n_ssc_slow_cells += (long long)n;
+        c->ic_slow_unread = false;
     }
     return VAG_OK;
 }
@@ -977,6 +985,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->n_ok = n_ok;
     c->plan = vag_plan{};
     c->fit_stats_pending = false;
+    c->ic_slow_unread = false;
     c->plan.n_models_ok = n_ok;
     c->plan.n_rows = rows;
     c->plan.n_cells = cells;
@@ -1328,7 +1337,9 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     if (c->d_band.ensure(sizeof(double) * (size_t)nb * 2 * band_stride)) return VAG_E_HIP;
     if (c->d_ichdr.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_HDR)) return VAG_E_HIP;
     if (c->d_icplan.ensure(sizeof(double) * (size_t)std::max<long long>(c->n_cells, 1) * IC_PLAN)) return VAG_E_HIP;
-    if (c->d_icused.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
+    constexpr int IC_SLOW_LIST = 1 << 18;  // cells of one table build that may take the slow path (more: VAG_E_CAPACITY)
+    if (c->d_icused.ensure(4 * sizeof(unsigned long long))) return VAG_E_HIP;
+    if (c->d_icslow.ensure(sizeof(int) * (size_t)IC_SLOW_LIST)) return VAG_E_HIP;
     if (c->d_icpool.ensure(sizeof(double) * 1024)) return VAG_E_HIP;  // (never null: the empty tables point at its first words)
     if (c->d_icstatus.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
     if (c->d_icunclamp.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
@@ -1368,31 +1379,41 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icwork.p, 0, 2 * sizeof(unsigned long long), st));
         }
-        // {doubles of the pool in use: its first two words serve the gathers of the cells without a table; plan records written}
-        static const unsigned long long ic_counters_start[2] = {2, 0};
+        // {doubles of the pool in use: its first two words serve the gathers of the cells without a table; plan records written; doubles
+        // and records of the cells on the slow path}
+        static const unsigned long long ic_counters_start[4] = {2, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(c->d_icused.p, ic_counters_start, sizeof ic_counters_start, hipMemcpyHostToDevice, st));
+        // The pool grows to what the plan handed out (grow-only: in a sampler's loop it stops growing after a few calls).  The host has
+        // to see the total before the spectrum kernel may write: one 32-byte copy and a wait per table build (~20 us against the
+        // milliseconds of the build; a grid / series SSC pass ends with such a wait anyway, check_ic_status).  A LIKELIHOOD call has no
+        // host wait anywhere in its SSC stage (its table status folds into the walker's score on the device), so it does not get one
+        // here either: the pool is sized for the worst case -- every cell a table of IC_MAX_OUT nodes, plus a fixed reserve for the
+        // cells of the slow path -- once, the launch covers every cell and the kernels read the record counts from HBM.  (Beyond 32 GB
+        // of worst case the wait is taken after all.)
+        constexpr unsigned long long SLOW_RESERVE_NO_WAIT = 8ull << 20;  // doubles (64 MB): ~2000 cells of twice the fast kernel's lattices
+        const unsigned long long worst = (unsigned long long)std::max<long long>(c->n_cells, 1) * IC_MAX_OUT + 1024 + SLOW_RESERVE_NO_WAIT;
+        const bool no_wait = c->ic_soft_fail && worst * sizeof(double) <= (32ull << 30) && !std::getenv("VAG_IC_POOL_READBACK");
+        int fast_nu_max = IC_MAX_NU;  // test hook: VAG_DEBUG_IC_FAST_NU_MAX=<n> sends the cells with longer seed lattices through the slow path (0: all)
+        if (const char* e = std::getenv("VAG_DEBUG_IC_FAST_NU_MAX")) fast_nu_max = std::min(std::atoi(e), IC_MAX_NU);
         hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
                            c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icused.as<unsigned long long>(),
-                           c->d_icstatus.as<int>(), c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need);
+                           c->d_icstatus.as<int>(), c->count_work ? c->d_icwork.as<unsigned long long>() : nullptr, band_stride, d_need,
+                           fast_nu_max, no_wait ? SLOW_RESERVE_NO_WAIT : ~0ull >> 1, c->d_icslow.as<int>(), IC_SLOW_LIST);
         HIPCHK(hipGetLastError());
-        // The pool grows to what the plan handed out (grow-only: in a sampler's loop it stops growing after a few calls).  The host has
-        // to see the total before the spectrum kernel may write: one 16-byte copy and a wait per table build (~20 us against the
-        // milliseconds of the build; a grid / series SSC pass ends with such a wait anyway, check_ic_status).  A LIKELIHOOD call has no
-        // host wait anywhere in its SSC stage (its table status folds into the walker's score on the device), so it does not get one
-        // here either: the pool is sized for the worst case -- every cell a table of IC_MAX_OUT nodes -- once, the launch covers every
-        // cell and the kernel reads the record count from HBM.  (Beyond 32 GB of worst case the wait is taken after all.)
-        const unsigned long long worst = (unsigned long long)std::max<long long>(c->n_cells, 1) * IC_MAX_OUT + 1024;
-        const bool no_wait = c->ic_soft_fail && worst * sizeof(double) <= (32ull << 30) && !std::getenv("VAG_IC_POOL_READBACK");
         long long n_run = c->n_cells;  // launch size (an upper bound when the host has not seen the count)
+        long long n_slow = -1;         // records on the slow path (-1: not seen)
+        c->ic_slow_unread = no_wait;
         if (no_wait) {
             if (c->d_icpool.ensure(sizeof(double) * (size_t)worst)) return VAG_E_HIP;
         } else {
-            unsigned long long ic_counters[2] = {0, 0};
+            unsigned long long ic_counters[4] = {0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(ic_counters, c->d_icused.p, sizeof ic_counters, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             const unsigned long long pool_used = ic_counters[0];
             n_run = (long long)ic_counters[1];  // cells that get a table: one plan record each
+            n_slow = (long long)std::min<unsigned long long>(ic_counters[3], IC_SLOW_LIST);
+            c->plan.n_ssc_slow_cells += n_slow;
             if (c->d_icpool.ensure(sizeof(double) * (size_t)(pool_used + pool_used / 16 + 1024))) return VAG_E_HIP;
             c->plan.ic_pool_bytes = std::max<long long>(c->plan.ic_pool_bytes, (long long)(sizeof(double) * pool_used));
         }
@@ -1409,6 +1430,15 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
                                         c->d_cellpar.as<double>(), c->d_cellq.as<double>(), c->d_sptab.as<double>(), c->d_knlut.as<double>(),
                                         c->d_icplan.as<double>(), c->d_icpool.as<double>()});
         HIPCHK(hipGetLastError());
+        // the cells beyond the fast kernel's on-chip layout: one wavefront per listed record (a call that did not wait for the count
+        // launches a small fixed grid that finds the list empty)
+        if (n_slow != 0) {
+            const IcPhotonArgs a{n_run, nullptr, c->n_cells, c->d_icy.as<double>(), c->d_cellpar.as<double>(), c->d_cellq.as<double>(),
+                                 c->d_sptab.as<double>(), c->d_knlut.as<double>(), c->d_icplan.as<double>(), c->d_icpool.as<double>()};
+            hipLaunchKernelGGL(vag_ic_photon_slow_kernel, dim3((unsigned)(n_slow > 0 ? std::min<long long>(n_slow, 8192) : 128)), dim3(64), 0, st,
+                               a, c->d_icslow.as<int>(), c->d_icused.as<unsigned long long>() + 3, IC_SLOW_LIST);
+            HIPCHK(hipGetLastError());
+        }
         if (c->count_work) {
             unsigned long long h[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(h, c->d_icwork.p, sizeof h, hipMemcpyDeviceToHost, st));

@@ -504,6 +504,23 @@ enum { ICP_CELL = 0 /* the cell this record belongs to: records are stored compa
        ICP_ROW0 /* first cell of the cell's representative row */, ICP_NT, ICP_K, ICP_GAMMA_M, ICP_GAMMA_C, ICP_COLUMN_DEN, ICP_YC,
        ICP_REGIME, ICP_P, ICP_KN, ICP_N_IC, ICP_OFF /* = the header's n and offset */, ICP_N };
 static_assert(ICP_N <= IC_PLAN, "plan row");
+// ------------------------------------------------------------------------------------------------
+// Cells whose lattices do not fit vag_ic_photon_kernel's LDS layout (more than IC_MAX_NU seed nodes, IC_MAX_G electron energies or
+// IC_MAX_OUT output nodes: the reference sizes its arrays per cell and has no such limit).  The plan kernel marks their records (bit 1
+// of ICP_KN), reserves the working arrays behind the cell's table in the pool and lists the records; one wavefront per listed record
+// then runs ICPhoton::generate_spectrum in the reference's own form -- the scattering CDF per electron energy (build_cdf_thomson /
+// build_cdf_KN, inverse-compton.h:415-481) and the walk over the output nodes (accumulate_IC, :483-527) -- with every array in HBM
+// and the wavefront's lanes striding over the seed bins / output nodes.  Rare by construction (no cell of BASELINE's configs or of the
+// prior boxes takes it), so it is written for plainness: __syncthreads() between its phases, no LDS beyond the cell's constants.
+// It is also an independent restatement on the device of what the fast kernel computes through its diagonal histograms: the test
+// that sends EVERY cell through it (VAG_DEBUG_IC_FAST_NU_MAX=0) compares the two.
+// ------------------------------------------------------------------------------------------------
+constexpr int IC_SLOW_MAX_NU = 2048, IC_SLOW_MAX_G = 2048, IC_SLOW_MAX_OUT = 4096;
+constexpr int IC_SLOW_NU_ARRAYS = 15;
+// doubles of working memory behind the table of a cell of the slow path
+VAG_DEV int ic_slow_scratch(int nu_size, int g_size, int n_ic) {
+    return IC_SLOW_NU_ARRAYS * nu_size + 2 * g_size + 2 * (g_size + nu_size - 1) + n_ic;
+}
 // output lattice node q of a table: phase + IC_Q (idx0 + 2 q), idx0 + 2 q an integer far below 2^53 formed in double -- exactly the
 // value the reference converts from its integer (log2_nu_IC, inverse-compton.h:595-606)
 VAG_DEV double ic_out_node(double phase, double idx0, int q) { return phase + IC_Q * (idx0 + 2.0 * (double)q); }
@@ -512,15 +529,21 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
                    long long n_cells, const double* __restrict__ det, const double* __restrict__ band,
                    double* __restrict__ ichdr /* [cells][IC_HDR] */, double* __restrict__ icplan /* [runnable cells][IC_PLAN], compacted */,
                    unsigned long long* __restrict__ pool_used /* [0] doubles handed out so far (starts at 2: slot 0 serves the empty tables),
-                                                                 [1] records written so far (starts at 0) */,
+                                                                 [1] records written so far, [2] doubles handed to cells of the slow path,
+                                                                 [3] records of the slow path (all three start at 0) */,
                    int* __restrict__ ic_status,
                    unsigned long long* __restrict__ work /* optional [2]: (electron energy, seed frequency) terms / lattice nodes */,
-                   int band_stride, const unsigned char* __restrict__ need /* [cells] or nullptr (vag_ic_band_kernel) */) {
+                   int band_stride, const unsigned char* __restrict__ need /* [cells] or nullptr (vag_ic_band_kernel) */,
+                   int fast_nu_max /* IC_MAX_NU, or a test's smaller limit: longer seed lattices take the slow path */,
+                   unsigned long long slow_reserve /* doubles the slow path's cells may take from the pool altogether */,
+                   int* __restrict__ slow_list /* [slow_cap] records of the slow path */, int slow_cap) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = c < n_cells && c < lay.cell_off[nb];  // n_cells is the arrays' stride (>= the batch's cell count)
     double* hdr = ichdr + (size_t)(live ? c : 0) * IC_HDR;
     double plan[IC_PLAN];  // the cell's record: written out below, at the place the workgroup reserves for it among the runnable cells
-    // the cell's plan; returns the length of its table (0: none)
+    bool slow_cell = false;
+    int model = 0;
+    // the cell's plan; returns the doubles it takes from the pool (0: no table)
     auto plan_cell = [&]() -> int {
         const int m = cell_model(lay.cell_off, nb, c);
         hdr[ICH_N] = 0;
@@ -567,9 +590,17 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         const long n_hi = (long)ceil((log2(nu_IC_max) - phase) / step);
         const long span = n_hi - n_lo;
         const int n_ic = (int)(span > 1 ? span : 1) + 1;
-        if (nu_size > IC_MAX_NU || g_size > IC_MAX_G || n_ic > IC_MAX_OUT) {
-            atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
-            return 0;
+        // lattices beyond the fast kernel's LDS layout: vag_ic_photon_slow_kernel, whose working arrays follow the table in the pool
+        slow_cell = nu_size > fast_nu_max || g_size > IC_MAX_G || n_ic > IC_MAX_OUT;
+        int len = n_ic;
+        if (slow_cell) {
+            len += ic_slow_scratch(nu_size, g_size, n_ic);
+            bool fits = nu_size <= IC_SLOW_MAX_NU && g_size <= IC_SLOW_MAX_G && n_ic <= IC_SLOW_MAX_OUT;
+            if (fits) fits = atomicAdd(pool_used + 2, (unsigned long long)len) + (unsigned long long)len <= slow_reserve;
+            if (!fits) {
+                atomicOr(ic_status + m, 1);  // capacity: reported loudly by the host
+                return 0;
+            }
         }
         if (work) {  // instrumentation: the unit of vag_ic_photon_kernel's work model (bench.py)
             atomicAdd(work, (unsigned long long)g_size * (unsigned long long)nu_size);
@@ -589,7 +620,7 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         plan[ICP_YC] = det[VD_YC * n_cells + c];
         plan[ICP_REGIME] = det[VD_REGIME * n_cells + c];
         plan[ICP_P] = params[m].p;
-        plan[ICP_KN] = (params[m].flags & VAG_FLAG_KN) ? 1.0 : 0.0;
+        plan[ICP_KN] = ((params[m].flags & VAG_FLAG_KN) ? 1.0 : 0.0) + (slow_cell ? 2.0 : 0.0);  // bit 0: Klein-Nishina, bit 1: slow path
         plan[ICP_N_IC] = (double)n_ic;
         plan[ICP_NU_SIZE] = (double)nu_size;
         plan[ICP_G_SIZE] = (double)g_size;
@@ -603,7 +634,8 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         sc.init(params[m].p);
         plan[ICP_SMOOTH_THICK] = sc.smooth_thick;
         plan[ICP_LOG2_X_FAR] = sc.log2_x_far;
-        return n_ic;
+        model = m;
+        return len;
     };
     const int len = live ? plan_cell() : 0;
     // place of the table in the pool and of the record among the runnable cells: exclusive sums over the workgroup's lanes + the
@@ -631,9 +663,17 @@ vag_ic_plan_kernel(const vag_model_params* __restrict__ params, int nb, const Va
         for (int q = 0; q < w; ++q) before += s_wave[q], before_run += s_wave_run[q];
         hdr[ICH_OFF] = (double)(s_base + (unsigned long long)before);  // < 2^53: exact
         plan[ICP_OFF] = hdr[ICH_OFF];
-        double* dst = icplan + (size_t)(s_base_run + (unsigned long long)before_run) * IC_PLAN;
+        const unsigned long long rec = s_base_run + (unsigned long long)before_run;
+        double* dst = icplan + (size_t)rec * IC_PLAN;
 #pragma unroll
         for (int q = 0; q < ICP_N; ++q) dst[q] = plan[q];
+        if (slow_cell) {
+            const unsigned long long at = atomicAdd(pool_used + 3, 1ull);
+            if (at < (unsigned long long)slow_cap)
+                slow_list[at] = (int)rec;
+            else
+                atomicOr(ic_status + model, 1);  // (a batch with more cells on the slow path than its list holds: capacity)
+        }
     }
 }
 
@@ -694,6 +734,12 @@ vag_ic_photon_kernel(IcPhotonArgs args_unused_directly) {
     // that arrives through the opaque argument block carries no such promise and would be read by vector loads + v_readfirstlane)
     typedef const double __attribute__((address_space(4))) ConstDouble;
     ConstDouble* plan = (ConstDouble*)(unsigned long long)(A.icplan + (size_t)c * IC_PLAN);
+#if VAG_IC_PERSISTENT
+    if ((int)plan[ICP_KN] & 2) {  // a cell of the slow path (vag_ic_photon_slow_kernel)
+        prefetch();
+        return;
+    }
+#endif
     double* tab = icpool + (unsigned long long)plan[ICP_OFF];  // this cell's table in the pool
     int nu_size = (int)plan[ICP_NU_SIZE], g_size = (int)plan[ICP_G_SIZE];
     const long n_lo = (long)plan[ICP_N_LO];
@@ -704,7 +750,7 @@ vag_ic_photon_kernel(IcPhotonArgs args_unused_directly) {
     const long idx0 = n_lo * 2;
     const double step = 2 * IC_Q;
     struct { double p; } P{plan[ICP_P]};
-    const bool KN = plan[ICP_KN] != 0;
+    const bool KN = ((int)plan[ICP_KN] & 1) != 0;
     const double gamma_m = plan[ICP_GAMMA_M], gamma_c = plan[ICP_GAMMA_C];
     const double column_den = plan[ICP_COLUMN_DEN];
     const double Y_c = plan[ICP_YC];
@@ -1076,6 +1122,7 @@ vag_ic_photon_kernel(IcPhotonArgs args_unused_directly) {
     if (c >= n_tot) return;
     typedef const double __attribute__((address_space(4))) ConstDouble;
     ConstDouble* rec = (ConstDouble*)(unsigned long long)(load_ic_photon_args().icplan + (size_t)c * IC_PLAN);
+    if ((int)rec[ICP_KN] & 2) return;  // a cell of the slow path (vag_ic_photon_slow_kernel)
     cell(c, constants((long long)rec[ICP_CELL], (long long)rec[ICP_ROW0], (int)rec[ICP_NT], (int)rec[ICP_K]), []() {});
 #else
     // Persistent wavefronts (developer build, measured and rejected in r05 -- DESIGN 4i): the launch is as many wavefronts as the device
@@ -1113,6 +1160,197 @@ vag_ic_photon_kernel(IcPhotonArgs args_unused_directly) {
         wave_sync();  // the cell's histograms have been read: the next cell may overwrite them
     }
 #endif
+}
+
+__global__ void __launch_bounds__(64)
+vag_ic_photon_slow_kernel(IcPhotonArgs A, const int* __restrict__ slow_list, const unsigned long long* __restrict__ n_slow_dev,
+                          int list_cap) {
+    const int lane = threadIdx.x;
+    constexpr int CST_Q = VAG_NPAR, CST_Y = VAG_NPAR + VAG_NQ, CST_N = VAG_NPAR + VAG_NQ + VAG_NICY;
+    __shared__ double s_c[64];
+    const long long n_slow = min((long long)*n_slow_dev, (long long)list_cap);
+    // suffix sums over the bins [j_lo, j_hi): cdf[j] = sum_{j <= m < j_hi} ex[m], 64 bins per trip from the top
+    auto suffix_sums = [&](const double* ex, double* cdf, int j_lo, int j_hi) {
+        double carry = 0;
+        for (int top = j_hi; top > j_lo; top -= 64) {
+            const int j = top - 1 - lane;  // lane 0: the highest bin of the trip
+            double v = j >= j_lo ? ex[j] : 0.0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double t = __shfl_up(v, off, 64);
+                if (lane >= off) v += t;
+            }
+            v += carry;
+            if (j >= j_lo) cdf[j] = v;
+            carry = __shfl(v, 63, 64);
+        }
+    };
+    for (long long s = blockIdx.x; s < n_slow; s += gridDim.x) {
+        const double* plan = A.icplan + (size_t)slow_list[s] * IC_PLAN;
+        const int nu_size = (int)plan[ICP_NU_SIZE], g_size = (int)plan[ICP_G_SIZE], n_ic = (int)plan[ICP_N_IC];
+        const long n_lo = (long)plan[ICP_N_LO];
+        const double lg2_nu0 = plan[ICP_LG2_NU0], lg2_g0 = plan[ICP_LG2_G0];
+        const double lg2_gm = plan[ICP_LG2_GM], inv_gm = plan[ICP_INV_GM], inv_gM = plan[ICP_INV_GMAX];
+        const double phase = plan[ICP_PHASE], p = plan[ICP_P];
+        const bool KN = ((int)plan[ICP_KN] & 1) != 0;
+        const double gamma_m = plan[ICP_GAMMA_M], gamma_c = plan[ICP_GAMMA_C], column_den = plan[ICP_COLUMN_DEN], Y_c = plan[ICP_YC];
+        const int regime = (int)plan[ICP_REGIME];
+        const long long cell_c = (long long)plan[ICP_CELL], row0 = (long long)plan[ICP_ROW0];
+        const int nt = (int)plan[ICP_NT], k = (int)plan[ICP_K];
+        const double step = 2 * IC_Q;
+        const int nu_last = nu_size - 1, n_lat = (g_size - 1) + (nu_size - 1) + 1;
+        double* tab = A.icpool + (unsigned long long)plan[ICP_OFF];
+        double* w = tab + n_ic;  // the working arrays
+        double *nu = w, *lg2nu = nu + nu_size, *dnu = lg2nu + nu_size, *lg2r = dnu + nu_size, *inv_lg2r = lg2r + nu_size;
+        double *fv_th = inv_lg2r + nu_size, *lg2fv = fv_th + nu_size, *ex_th = lg2fv + nu_size, *ratio_th = ex_th + nu_size;
+        double *cdf_th = ratio_th + nu_size, *fv_buf = cdf_th + nu_size, *lg2f_buf = fv_buf + nu_size, *ex_buf = lg2f_buf + nu_size;
+        double *ratio_buf = ex_buf + nu_size, *cdf_buf = ratio_buf + nu_size;
+        double *gam = cdf_buf + nu_size, *dNe = gam + g_size, *corr = dNe + g_size, *lcorr = corr + n_lat, *I_buf = lcorr + n_lat;
+        __syncthreads();  // (the previous cell's readers of s_c)
+        {   // lane l < CST_N: constant l of the cell (as vag_ic_photon_kernel)
+            const double* src = A.cellpar + row0 * VAG_NPAR + k;
+            if (lane < CST_Q)
+                src += (long long)lane * nt;
+            else if (lane < CST_Y)
+                src = A.cellq + row0 * VAG_NQ + k + (long long)(lane - CST_Q) * nt;
+            else if (lane < CST_N)
+                src = A.icy + cell_c + (long long)(lane - CST_Y) * A.n_cells;
+            s_c[lane] = *src;
+        }
+        for (int j = lane; j < nu_size; j += 64) {
+            const double x = lg2_nu0 + step * (double)j;
+            lg2nu[j] = x;
+            nu[j] = exp2_sat(x);
+        }
+        for (int i = lane; i < g_size; i += 64) gam[i] = exp2_sat(lg2_g0 + step * (double)i);
+        for (int q = lane; q < n_ic; q += 64) I_buf[q] = 0;
+        __syncthreads();
+        double cp[VAG_NPAR];
+        for (int q = 0; q < VAG_NPAR; ++q) cp[q] = s_c[q];
+        IcQ icq;
+        icq.head(s_c + CST_Q, 1);
+        icq.rest(s_c + CST_Q, 1);
+        const bool y_any = s_c[CST_Y + VY_NSEG] != 0;
+        const double yS0 = s_c[CST_Y + VY_S0], yC0 = s_c[CST_Y + VY_C0];
+        const double yL1 = s_c[CST_Y + VY_L1], yS1 = s_c[CST_Y + VY_S1], yC1 = s_c[CST_Y + VY_C1];
+        const double yL2 = s_c[CST_Y + VY_L2], yS2 = s_c[CST_Y + VY_S2], yC2 = s_c[CST_Y + VY_C2];
+        // sample_distributions, inverse-compton.h:371-399 (the same expressions as vag_ic_photon_kernel: the two paths must hand the
+        // accumulation identical samples)
+        SpecConst sc;
+        sc.smooth_thick = plan[ICP_SMOOTH_THICK], sc.log2_x_far = plan[ICP_LOG2_X_FAR];
+        const bool slow_c = regime == 1 || regime == 2 || regime == 5, fast_c = regime == 3 || regime == 4 || regime == 6;
+        for (int i = lane; i < g_size; i += 64) {
+            constexpr double LOG2E_ = 1.4426950408889634;
+            const double gi = gam[i], rg = rcp_fast(gi), lg = lg2_g0 + step * (double)i;
+            const double dgi = 0.5 * ((i + 1 < g_size ? gam[i + 1] : gi) - (i > 0 ? gam[i - 1] : gi));
+            double spec = 0;
+            if (slow_c)
+                spec = (p - 1) * inv_gm * exp2_sat((-gi * inv_gM - gamma_m * rg) * LOG2E_ - p * (lg - lg2_gm)) * gamma_c *
+                       rcp_fast(gi + gamma_c);
+            else if (fast_c)
+                spec = exp2_sat((-gi * inv_gM - gamma_c * rg) * LOG2E_) * gamma_c * rg * rg *
+                       rcp_fast(1.0 + exp2_sat(dmin((p - 1) * (lg - lg2_gm), 1000.0)));
+            double den = column_den * spec;
+            if (gi > gamma_c) {
+                double z = fma(yS0, lg, yC0);
+                z = lg >= yL1 ? fma(yS1, lg, yC1) : z;
+                z = lg >= yL2 ? fma(yS2, lg, yC2) : z;
+                den = den * (1 + Y_c) * rcp_fast(1 + (y_any ? exp2_sat(z) : 0.0));
+            }
+            dNe[i] = den * rg * rg * dgi;
+        }
+        for (int j = lane; j < nu_size; j += 64) {
+            const double x = lg2nu[j];
+            const double lf = log2_I_nu_ic_core<true, true>(cp, 1, icq.applies(x), icq, sc, x, A.sp_table, nu[j]) - 2 * x;
+            const double f = exp2_sat(lf);
+            fv_th[j] = f;
+            lg2fv[j] = f > 0 ? lf : -INFINITY;
+        }
+        for (int j = lane; j < nu_last; j += 64) {
+            dnu[j] = nu[j + 1] - nu[j];
+            lg2r[j] = lg2nu[j + 1] - lg2nu[j];
+            inv_lg2r[j] = lg2r[j] != 0 ? 1 / lg2r[j] : 0;
+        }
+        __syncthreads();
+        // build_cdf_thomson, inverse-compton.h:415-430
+        for (int j = lane; j < nu_last; j += 64) {
+            const double trap = 0.5 * (fv_th[j] + fv_th[j + 1]) * dnu[j];
+            const double exact = power_law_bin_integral(fv_th[j], fv_th[j + 1], nu[j], nu[j + 1], lg2fv[j], lg2fv[j + 1], lg2r[j],
+                                                        inv_lg2r[j], trap);
+            ex_th[j] = exact;
+            ratio_th[j] = trap > 0 ? exact / trap : 1;
+        }
+        if (lane == 0) cdf_th[nu_last] = 0;
+        if (KN) {  // the KN correction per node of the shared gamma-nu lattice, inverse-compton.h:566-574 (its even nodes: see the fast kernel)
+            const double lg2_base = lg2_g0 + lg2_nu0;
+            for (int q = lane; q < n_lat; q += 64) {
+                double cq, lq;
+                compton_correction_pair_lg2(lg2_base + step * (double)q, A.kn_lut, cq, lq);
+                corr[q] = cq;
+                lcorr[q] = lq;
+            }
+        }
+        __syncthreads();
+        suffix_sums(ex_th, cdf_th, 0, nu_last);
+        __syncthreads();
+        for (int i = 0; i < g_size; ++i) {  // compute_IC_spectrum's loop over the electron energies, :576-592 (all of it wave-uniform)
+            const double dNe_i = dNe[i];
+            if (!(dNe_i > 0)) continue;
+            const double *fv = fv_th, *cdf = cdf_th, *ratio = ratio_th;
+            if (KN) {  // build_cdf_KN, :432-481
+                const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / gam[i];
+                int below = 0;  // seed nodes short of the last one below the split = the index of the first one at or above it
+                for (int j = lane; j < nu_last; j += 64) below += nu[j] < nu_split ? 1 : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+                const int j_split = below;
+                for (int j = j_split + lane; j <= nu_last; j += 64) {
+                    fv_buf[j] = fv_th[j] * corr[i + j];
+                    lg2f_buf[j] = lg2fv[j] + lcorr[i + j];
+                }
+                if (lane == 0) cdf_buf[nu_last] = 0;
+                __syncthreads();
+                for (int j = j_split + lane; j < nu_last; j += 64) {
+                    const double trap = 0.5 * (fv_buf[j] + fv_buf[j + 1]) * dnu[j];
+                    const double exact = power_law_bin_integral(fv_buf[j], fv_buf[j + 1], nu[j], nu[j + 1], lg2f_buf[j], lg2f_buf[j + 1],
+                                                                lg2r[j], inv_lg2r[j], trap);
+                    ex_buf[j] = exact;
+                    ratio_buf[j] = trap > 0 ? exact / trap : 1;
+                }
+                __syncthreads();
+                suffix_sums(ex_buf, cdf_buf, j_split, nu_last);
+                __syncthreads();
+                if (j_split > 0) {
+                    const double delta = cdf_buf[j_split] - cdf_th[j_split];
+                    __syncthreads();  // (every lane has read cdf_buf[j_split])
+                    for (int j = lane; j < j_split; j += 64) {
+                        fv_buf[j] = fv_th[j];
+                        ratio_buf[j] = ratio_th[j];
+                        cdf_buf[j] = cdf_th[j] + delta;
+                    }
+                }
+                __syncthreads();
+                fv = fv_buf, cdf = cdf_buf, ratio = ratio_buf;
+            }
+            // accumulate_IC, :483-527: output node kk sits at seed node j = n_lo - 2 i + kk (both lattices step by two quanta, so the
+            // in-bin offset is always zero: frac = 0, rem = 1, f_seed = f_lo)
+            const double cdf0 = cdf[0];
+            if (cdf0 > 0) {
+                for (int kk = lane; kk < n_ic; kk += 64) {
+                    const long j = n_lo - 2L * i + kk;
+                    if (j < 0)
+                        I_buf[kk] += dNe_i * cdf0;
+                    else if (j < nu_last)
+                        I_buf[kk] += dNe_i * (cdf[j + 1] + 0.5 * (fv[j] + fv[j + 1]) * dnu[j] * ratio[j]);
+                }
+            }
+            __syncthreads();  // the buffers are rewritten by the next energy
+        }
+        // log2 table on the output lattice, :595-606
+        const double lg2_scale = log2(0.25 * C_SIGMAT);
+        const long idx0 = n_lo * 2;
+        for (int kk = lane; kk < n_ic; kk += 64) tab[kk] = log2_fast(I_buf[kk]) + (phase + IC_Q * (double)(idx0 + 2L * kk)) + lg2_scale;
+    }
 }
 
 // ICPhoton::compute_log2_I_nu (inverse-compton.h:614-652) on a stored table: the cell's header {n, first node, last node, log2 of the
