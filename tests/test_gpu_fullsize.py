@@ -682,3 +682,67 @@ def test_coalesced_thread_pool_calls_are_served_as_batches_with_each_callers_own
             assert np.array_equal(r, want[im][1][0])
     finally:
         va.set_coalescing(prev)
+
+
+def test_a_long_mixed_loop_neither_grows_device_memory_nor_the_process(eng, oracle):
+    """A sampler runs for hours on one context: grid, series and band requests of mixed models, likelihood calls of varying batch size,
+    SSC tables (pooled), reverse shocks, a thread pool with coalescing -- 120 rounds of all of it.  The context's buffers are grow-only and
+    must stop growing once the largest request has been seen: after the first rounds neither the device's free memory nor the
+    process's resident set moves (to within 16 MB / 64 MB: allocator slack, numpy temporaries).  And a context that is destroyed gives
+    its device memory back: 20 create / use / destroy cycles leave free memory where it was."""
+    import psutil
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    lib, h = eng
+    proc = psutil.Process()
+    models = _mixed_models(32)
+    f, defs = _c4_fitter(oracle)
+    rng = np.random.default_rng(3)
+    lo = np.array([l for _, _, l, _ in configs.C4_FREE])
+    hi = np.array([u for _, _, _, u in configs.C4_FREE])
+    t, nu = np.logspace(3, 7, 24), np.array([1e9, 4.84e14, 1e18])
+    ts, nus = np.repeat(t, nu.size), np.tile(nu, t.size)
+
+    def one_round(r):
+        for m in models[(r % 4)::4]:
+            m.flux_density_grid(t, nu)
+            m.flux_density(ts, nus)
+            m.flux(t, 1e17, 1e18, 5)
+        for nb in (1024, 37, 512):
+            theta = lo + (hi - lo) * rng.random((nb, len(defs)))
+            f.loglike_batch(theta, defs)
+        va.set_coalescing(True, max_batch=64, wait_us=100)
+        try:
+            with ThreadPoolExecutor(16) as ex:
+                list(ex.map(lambda m: m.flux_density(ts, nus).total, models))
+        finally:
+            va.set_coalescing(False)
+
+    def free_mb():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0] / 2 ** 20
+    for r in range(6):  # every request shape has been seen: buffers at their final size
+        one_round(r)
+    free0, rss0 = free_mb(), proc.memory_info().rss / 2 ** 20
+    for r in range(6, 120):
+        one_round(r)
+    free1, rss1 = free_mb(), proc.memory_info().rss / 2 ** 20
+    assert free0 - free1 < 16.0, (free0, free1)
+    assert rss1 - rss0 < 64.0, (rss0, rss1)
+    # contexts give their memory back
+    prm = _abi.make_params(jet="GaussianJet", theta_obs=0.2, ssc=True, kn=True)
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    out = np.empty((1, nu.size, t.size))
+
+    def cycle():
+        hh = C.c_void_p()
+        _lib.check(lib.vag_ctx_create(0, C.byref(hh)))
+        _lib.check(lib.vag_flux_density_grid_batch(hh, arr, 1, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size,
+                                                   out.ctypes.data_as(dp)))
+        lib.vag_ctx_destroy(hh)
+    cycle()
+    free2 = free_mb()
+    for _ in range(20):
+        cycle()
+    assert free2 - free_mb() < 16.0
+    assert np.all(np.isfinite(out)) and out.max() > 0
