@@ -75,6 +75,25 @@ __host__ __device__ inline size_t fit_rows_lds_bytes(int n) {
 }
 
 
+// A frequency far beyond the synchrotron spectrum's exponential cut-off (SmoothPowerLawSyn::compute_log2_I_nu subtracts
+// log2(e) nu' / nu_M, smooth-power-law-syn.cpp:159-167): at nu' > 2^10.5 nu_M that term alone is below -2089 while everything else of
+// log2 I' + the geometry stays within a few hundred (a double's smallest denormal is 2^-1074), so 2^(...) is an exact zero in the
+// reference's sum whatever the interval's other end holds (nu_M in the comoving frame is the burn-off limit, ~2.4e22 Hz / (1 + Y): it does not jump between lattice nodes).  When
+// EVERY lane of the wavefront that needs the node is that far out, the evaluation is skipped and the value is -inf -- the interval's
+// slope is then not finite and the interval adds nothing (observer.h:422-426), i.e. the same exact zero.  This is the TeV band of an
+// SSC request (BASELINE configs[2] / [4]: 2.4e26 Hz), a quarter of the synchrotron pass's evaluations there.
+// Returns true (and sets `value`) when the calling lanes may skip the band.  Used by the row-per-lane GRID kernel (vag_grid_rows.h).
+constexpr double FLUX_DEAD_LG2 = 10.5;
+VAG_DEV bool band_is_dead(double lg2_nu_comoving, double lg2_nu_max, double& value) {
+#ifdef VAG_NO_DEAD_BANDS  // developer builds: evaluate everything
+    return false;
+#else
+    if (__ballot(lg2_nu_comoving - lg2_nu_max < FLUX_DEAD_LG2) != 0) return false;  // (a NaN counts as dead: non-finite either way)
+    value = -INFINITY;
+    return true;
+#endif
+}
+
 #ifndef VAG_ROWS_MIN_WG
 #define VAG_ROWS_MIN_WG 3  // workgroups per CU the row-per-lane kernels are compiled for (developer builds: 4 = 128 VGPRs)
 #endif
@@ -202,7 +221,7 @@ VAG_DEV void fit_rows_item(const SeriesArgs& a, const FitRowsLds& L, int m, int 
                     if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(s_band[b] - dop), q, sc, s_band[b] - dop, sp_tab) + geom;
             } else {
 #pragma unroll
-                for (int b = 0; b < NBMAX; ++b)
+                for (int b = 0; b < NBMAX; ++b)  // (no band_is_dead here: its test costs the walker kernel 2.6 % and a fit's bands hold data)
                     if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, s_band[b] - dop, sp_tab) + geom;
             }
         }

@@ -145,11 +145,13 @@ VAG_DEV void grid_rows_item(const SeriesArgs& a, const GridRowsLds& L, int m, in
                 if (any) q.rest(cq, K);
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b)
-                    if (b < NB) B[b] = log2_I_nu_ic_core(regs, 1, q.applies(nu_b[b] - dop), q, sc, nu_b[b] - dop, sp_tab) + geom;
+                    if (b < NB && !band_is_dead(nu_b[b] - dop, regs[VP_LG2_NUMAX], B[b]))
+                        B[b] = log2_I_nu_ic_core(regs, 1, q.applies(nu_b[b] - dop), q, sc, nu_b[b] - dop, sp_tab) + geom;
             } else {
 #pragma unroll
                 for (int b = 0; b < GRIDROWS_BANDS; ++b)
-                    if (b < NB) B[b] = log2_I_nu_fast(regs, 1, sc, nu_b[b] - dop, sp_tab) + geom;
+                    if (b < NB && !band_is_dead(nu_b[b] - dop, regs[VP_LG2_NUMAX], B[b]))
+                        B[b] = log2_I_nu_fast(regs, 1, sc, nu_b[b] - dop, sp_tab) + geom;
             }
         }
     };
