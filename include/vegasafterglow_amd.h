@@ -150,6 +150,11 @@ int vag_abi_version(void);
 /* Number of visible HIP devices (0 when none / runtime missing). */
 int vag_device_count(void);
 
+/* ABI v12: bytes of device memory the library holds in this process, over all contexts.  A context's buffers only grow, to what the
+ * largest request so far needed (+25 %), and are freed by vag_ctx_destroy: in a sampler's loop the figure stops moving after the first
+ * calls (tests/test_gpu_fullsize.py holds it to that). */
+long long vag_device_bytes_in_use(void);
+
 /* ---- engine context: one per (process, device); owns stream + workspace in HBM ---- */
 typedef struct vag_ctx vag_ctx;
 

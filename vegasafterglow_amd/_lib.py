@@ -106,7 +106,7 @@ class Limits(C.Structure):
 
 EXPORTS = [
     "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
-    "vag_device_count", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_get_stream", "vag_ctx_synchronize",
+    "vag_device_count", "vag_device_bytes_in_use", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_get_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
@@ -142,6 +142,7 @@ def load():
     lib.vag_params_default.argtypes = [_pp]
     lib.vag_params_default.restype = None
     lib.vag_params_validate.argtypes = [_pp]
+    lib.vag_device_bytes_in_use.restype = C.c_longlong
     lib.vag_ctx_create.argtypes = [C.c_int, C.POINTER(v)]
     lib.vag_ctx_destroy.argtypes = [v]
     lib.vag_ctx_destroy.restype = None

@@ -51,21 +51,26 @@ static int rowgeo_stride(bool large) {  // doubles per model of the row-geometry
     return VAG_ROWGEO_HDR + 2 * (large ? VAG_MAX_PHI : VAG_GRID_PHI) + 4 * (large ? VAG_MAX_THETA : VAG_GRID_THETA);
 }
 
+// device memory this library holds in this process, all contexts (vag_device_bytes_in_use): every buffer in HBM is a DevBuf
+static std::atomic<long long> g_device_bytes{0};
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) HIPCHK(hipFree(p));
+        g_device_bytes -= (long long)cap;
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 256;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
+        g_device_bytes += (long long)cap;
         return 0;
     }
     void release() {
         if (p) (void)hipFree(p);
+        g_device_bytes -= (long long)cap;
         p = nullptr;
         cap = 0;
     }
@@ -480,6 +485,8 @@ int vag_device_count(void) {
     return n;
 }
 
+long long vag_device_bytes_in_use(void) { return g_device_bytes.load(); }
+
 void vag_get_limits(vag_limits* out) {
     out->max_theta = VAG_MAX_THETA;
     out->max_phi = VAG_MAX_PHI;
@@ -589,7 +596,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused, &c->d_icslow,
-                      &c->d_icstatus, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
+                      &c->d_icstatus, &c->d_icunclamp, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
                       &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
