@@ -794,7 +794,8 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
         StageScope ps(c, PS_SYN_ELECTRONS);
         hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
-                           want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr);
+                           want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr,
+                           want_details || std::getenv("VAG_CELLS_WRITE_BACK") != nullptr);
     }
     HIPCHK(hipGetLastError());
     if (ssc) {  // cool the electrons row by row, then rebuild the photons

@@ -445,7 +445,9 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
                  const double* shock, long long n_cells, double* __restrict__ cellpar,
                  double* __restrict__ cell_details /* optional [11][n_cells] */,
                  const int* __restrict__ inj_idx /* optional, per row: reverse shock's injection cutoff */,
-                 double* raw_shock /* = shock when vag_dynamics_fast_kernel left (U2_th, m2) to be finished */) {
+                 double* raw_shock /* = shock when vag_dynamics_fast_kernel left (U2_th, m2) to be finished */,
+                 bool write_back /* raw_shock: store the finished Gamma_th, B, N_p (read again by the IC cooling pass and by vag_details;
+                                    a plain synchrotron call reads them nowhere else -- this kernel is bound by HBM, 28 doubles per cell with them) */) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells || c >= lay.cell_off[nb]) return;  // n_cells is the arrays' stride (>= the batch's cell count)
     const int m = cell_model(lay.cell_off, nb, c);
@@ -455,9 +457,11 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
     const long long local = c - lay.cell_off[m];
     const int r = (int)(local / nt), k = (int)(local % nt);
     const vag_model_params P = params[m];
-    double c_Gth = shock[VS_GAMMA_TH * n_cells + c], c_B = shock[VS_B * n_cells + c], c_Np = shock[VS_NP * n_cells + c];
-    if (raw_shock) {  // save_fwd_shock_state (forward-shock.tpp:151-173) on the interpolated state of this cell
-        const double m2 = c_Np, U = c_Gth;
+    double c_Gth, c_B, c_Np;
+    if (!raw_shock) {
+        c_Gth = shock[VS_GAMMA_TH * n_cells + c], c_B = shock[VS_B * n_cells + c], c_Np = shock[VS_NP * n_cells + c];
+    } else {  // save_fwd_shock_state (forward-shock.tpp:151-173) on the interpolated state of this cell
+        const double m2 = shock[VS_NP * n_cells + c], U = shock[VS_GAMMA_TH * n_cells + c];
         c_Gth = 1, c_B = 0, c_Np = 0;
         if (m2 != 0) {
             Medium med;
@@ -469,9 +473,11 @@ vag_cells_kernel(const vag_model_params* __restrict__ params, int nb, const VagG
             c_B = sqrt_fast(8 * C_PI * P.eps_B * e_th);
             c_Np = m2 / C_MP;
         }
-        raw_shock[VS_GAMMA_TH * n_cells + c] = c_Gth;
-        raw_shock[VS_B * n_cells + c] = c_B;
-        raw_shock[VS_NP * n_cells + c] = c_Np;
+        if (write_back) {
+            raw_shock[VS_GAMMA_TH * n_cells + c] = c_Gth;
+            raw_shock[VS_B * n_cells + c] = c_B;
+            raw_shock[VS_NP * n_cells + c] = c_Np;
+        }
     }
     CellOut o;
     ElecBasic inj{0, 1, 0};
