@@ -614,3 +614,16 @@ def test_every_device_buffer_of_a_context_is_released_by_destroy():
     released = set(re.findall(r"(?:c->|\.)(\w+)", src[d0:src.index("delete c;", d0)]))
     assert len(members) > 60
     assert not (members - released), sorted(members - released)
+
+
+def test_null_arguments_without_a_device_are_error_codes(lib):
+    """The entry points reject null pointers before they touch the device (the GPU suite covers the rest with a live context)."""
+    assert lib.vag_params_validate(None) == _lib.VAG_E_INVALID
+    assert lib.vag_ctx_create(0, None) == _lib.VAG_E_INVALID
+    assert lib.vag_ctx_synchronize(None) == _lib.VAG_E_INVALID
+    assert lib.vag_ctx_count_work(None, 1) == _lib.VAG_E_INVALID
+    assert lib.vag_last_plan(None, C.byref(_lib.Plan())) == _lib.VAG_E_INVALID
+    assert lib.vag_flux_density_grid_batch(None, None, 1, None, 1, None, 1, None) == _lib.VAG_E_INVALID
+    assert lib.vag_loglike_batch(None, None, None, 1, 1, None) == _lib.VAG_E_INVALID
+    lib.vag_params_default(None)
+    assert lib.vag_device_bytes_in_use() == 0 or lib.vag_device_count() > 0

@@ -2151,3 +2151,56 @@ def test_regime_tags_match_the_checker_exactly(eng, oracle, name):
     assert set(np.unique(want)) <= {0, 1, 2, 3, 4, 5, 6}
     assert np.array_equal(got[~tie], want[~tie]), f"{int(np.sum(got[~tie] != want[~tie]))} of {int(np.sum(~tie))} cells differ"
     assert tie.mean() < 0.01, (int(tie.sum()), tie.size)
+
+
+def test_null_and_empty_arguments_are_error_codes_not_crashes(eng):
+    """The C-ABI is called by hand-written bindings: a null pointer or an empty array is VAG_E_INVALID with a
+    message, never a fault, on every family of entry points; and the context works afterwards."""
+    lib, h = eng
+    prm = _abi.make_params()
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    t, nu, out = np.logspace(2, 6, 8), np.array([1e9, 1e15]), np.empty((1, 2, 8))
+    T, N, O = t.ctypes.data_as(dp), nu.ctypes.data_as(dp), out.ctypes.data_as(dp)
+    null, nullp = C.cast(None, dp), C.cast(None, C.POINTER(_lib.ModelParams))
+    tt, nn, so = np.repeat(t, 2), np.tile(nu, 8), np.empty((1, 16))
+    TT, NN, SO = tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), so.ctypes.data_as(dp)
+    o4 = (dp * 4)(O, null, null, null)
+    bad = {
+        "grid: null ctx": lambda: lib.vag_flux_density_grid_batch(None, arr, 1, T, 8, N, 2, O),
+        "grid: null models": lambda: lib.vag_flux_density_grid_batch(h, nullp, 1, T, 8, N, 2, O),
+        "grid: null t": lambda: lib.vag_flux_density_grid_batch(h, arr, 1, null, 8, N, 2, O),
+        "grid: null nu": lambda: lib.vag_flux_density_grid_batch(h, arr, 1, T, 8, null, 2, O),
+        "grid: null out": lambda: lib.vag_flux_density_grid_batch(h, arr, 1, T, 8, N, 2, null),
+        "grid: nb 0": lambda: lib.vag_flux_density_grid_batch(h, arr, 0, T, 8, N, 2, O),
+        "grid: nb < 0": lambda: lib.vag_flux_density_grid_batch(h, arr, -1, T, 8, N, 2, O),
+        "grid: nt 0": lambda: lib.vag_flux_density_grid_batch(h, arr, 1, T, 0, N, 2, O),
+        "grid: nnu 0": lambda: lib.vag_flux_density_grid_batch(h, arr, 1, T, 8, N, 0, O),
+        "grid4: null nu": lambda: lib.vag_flux_density_grid_components4_batch(h, arr, 1, T, 8, null, 2, o4),
+        "grid4: null out4": lambda: lib.vag_flux_density_grid_components4_batch(h, arr, 1, T, 8, N, 2, None),
+        "series: null t": lambda: lib.vag_flux_density_batch(h, arr, 1, null, NN, 16, SO),
+        "series: null nu": lambda: lib.vag_flux_density_batch(h, arr, 1, TT, null, 16, SO),
+        "series: null out": lambda: lib.vag_flux_density_batch(h, arr, 1, TT, NN, 16, null),
+        "series: n 0": lambda: lib.vag_flux_density_batch(h, arr, 1, TT, NN, 0, SO),
+        "band: null out": lambda: lib.vag_flux_batch(h, arr, 1, T, 8, C.c_double(1e17), C.c_double(1e18), 5, null),
+        "band: null t": lambda: lib.vag_flux_batch(h, arr, 1, null, 8, C.c_double(1e17), C.c_double(1e18), 5, SO),
+        "grid_dev: null": lambda: lib.vag_flux_density_grid_batch_dev(h, None, 1, None, 8, None, 2, None),
+        "series_dev: null": lambda: lib.vag_flux_density_batch_dev(h, None, 1, None, None, 16, None),
+        "loglike: null spec": lambda: lib.vag_loglike_batch(h, None, T, 1, 8, O),
+        "loglike_dev: null": lambda: lib.vag_loglike_batch_dev(h, None, None, 1, 8, None),
+        "last_plan: null out": lambda: lib.vag_last_plan(h, None),
+        "last_plan: null ctx": lambda: lib.vag_last_plan(None, C.byref(_lib.Plan())),
+        "synchronize: null ctx": lambda: lib.vag_ctx_synchronize(None),
+        "count_work: null ctx": lambda: lib.vag_ctx_count_work(None, 1),
+        "set_stream: null ctx": lambda: lib.vag_ctx_set_stream(None, None),
+        "coalesce: null ctx": lambda: lib.vag_ctx_coalesce(None, 8, 50),
+        "details: null model": lambda: lib.vag_details(h, None, C.c_double(1e2), C.c_double(1e6), None, None),
+        "validate: null model": lambda: lib.vag_params_validate(None),
+        "ctx_create: null out": lambda: lib.vag_ctx_create(0, None),
+    }
+    for name, call in bad.items():
+        rc = call()
+        assert rc == _lib.VAG_E_INVALID, (name, rc)
+        assert lib.vag_last_error(), name
+    lib.vag_params_default(None)  # (returns nothing; must not fault)
+    _lib.check(lib.vag_flux_density_grid_batch(h, arr, 1, T, 8, N, 2, O))
+    assert np.all(np.isfinite(out)) and out.max() > 0

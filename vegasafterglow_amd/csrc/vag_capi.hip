@@ -444,6 +444,7 @@ const char* vag_version(void) { return "vegasafterglow_amd 0.1 (gfx950)"; }
 int vag_abi_version(void) { return VAG_ABI_VERSION; }
 
 void vag_params_default(vag_model_params* p) {
+    if (!p) return;
     std::memset(p, 0, sizeof *p);
     p->jet_type = VAG_JET_TOPHAT;
     p->medium_type = VAG_MEDIUM_ISM;
@@ -475,6 +476,7 @@ void vag_params_default(vag_model_params* p) {
 }
 
 int vag_params_validate(const vag_model_params* p) {
+    if (!p) return set_err(VAG_E_INVALID, "null model");
     const char* msg = validate_msg(p);
     return msg ? set_err(VAG_E_INVALID, "%s", msg) : VAG_OK;
 }
@@ -575,6 +577,7 @@ ApiLock::ApiLock(vag_ctx* c) : m(c ? &c->api_mutex : nullptr) {
 }
 
 int vag_ctx_create(int device, vag_ctx** out) {
+    if (!out) return set_err(VAG_E_INVALID, "null output pointer");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return set_err(VAG_E_NO_DEVICE, "no HIP device available: the engine has no CPU path");
@@ -671,6 +674,7 @@ int vag_ctx_get_stream(vag_ctx* c, void** out) {
 
 int vag_ctx_count_work(vag_ctx* c, int enable) {
     ApiLock api_lock(c);
+    if (!c) return set_err(VAG_E_INVALID, "null context");
     c->count_work = enable != 0;
     return VAG_OK;
 }
@@ -704,6 +708,7 @@ static int read_row_failures(vag_ctx* c) {
 
 int vag_last_plan(vag_ctx* c, vag_plan* out) {
     ApiLock api_lock(c);
+    if (!c || !out) return set_err(VAG_E_INVALID, "null context or output");
     const int rc = read_row_failures(c);
     *out = c->plan;
     return rc;
@@ -711,6 +716,7 @@ int vag_last_plan(vag_ctx* c, vag_plan* out) {
 
 int vag_ctx_synchronize(vag_ctx* c) {
     ApiLock api_lock(c);
+    if (!c) return set_err(VAG_E_INVALID, "null context");
     HIPCHK(hipStreamSynchronize(c->stream));
     return VAG_OK;
 }
@@ -745,6 +751,7 @@ int vag_last_profile(vag_ctx* c, vag_profile* out) {
 
 int vag_last_stage_times(vag_ctx* c, vag_stage_times* out) {
     ApiLock api_lock(c);
+    if (!c || !out) return set_err(VAG_E_INVALID, "null context or output");
     // measured with HIP events recorded on the context stream around each kernel of the last batch call
     const int rc = collect_times_fwd(c);
     *out = c->times;
@@ -2028,6 +2035,7 @@ int prep_times(vag_ctx* c, const double* d_t, int nt, const double* d_nu, int nn
 }
 
 int check_host_inputs(const vag_model_params* params, int nb, const double* t, int nt) {
+    if (!params || !t) return set_err(VAG_E_INVALID, "null model or time array");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     if (nt <= 0) return set_err(VAG_E_INVALID, "time array must be non-empty");
     for (int i = 0; i < nt; ++i)
@@ -2255,6 +2263,7 @@ int vag_flux_density_grid_batch_dev(vag_ctx* c, const vag_model_params* d_params
     ApiLock api_lock(c);
     HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!d_params || !d_t || !d_nu || !d_out) return set_err(VAG_E_INVALID, "null device pointer");
     if (nb <= 0 || nt <= 0 || nnu <= 0) return set_err(VAG_E_INVALID, "empty batch, time or frequency array");
     HIPCHK(hipSetDevice(c->device));
     c->mixed_flags_seen = false;
@@ -2318,6 +2327,7 @@ int vag_flux_density_batch_dev(vag_ctx* c, const vag_model_params* d_params, int
     ApiLock api_lock(c);
     HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!d_params || !d_t || !d_nu || !d_out) return set_err(VAG_E_INVALID, "null device pointer");
     if (nb <= 0 || n <= 0) return set_err(VAG_E_INVALID, "empty batch or data array");
     HIPCHK(hipSetDevice(c->device));
     const int n_bands = c->pending_bands;  // only the host-pointer wrapper below knows the frequencies
@@ -2335,6 +2345,7 @@ int vag_flux_density_grid_batch(vag_ctx* c, const vag_model_params* params, int 
                                 const double* nu, int nnu, double* out) {
     ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!nu || !out) return set_err(VAG_E_INVALID, "null frequency or output array");
     if (nnu <= 0) return set_err(VAG_E_INVALID, "frequency array must be non-empty");
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
@@ -2409,6 +2420,7 @@ int vag_flux_density_grid_components4_batch(vag_ctx* c, const vag_model_params* 
                                             const double* nu, int nnu, double* const* out4) {
     ApiLock api_lock(c);
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
+    if (!nu) return set_err(VAG_E_INVALID, "null frequency array");
     return grid_components_impl(c, params, nb, t, nt, nu, nnu, out4);
 }
 
@@ -2416,6 +2428,7 @@ int vag_flux_density_batch(vag_ctx* c, const vag_model_params* params, int nb, c
                            double* out) {
     ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!nu || !out) return set_err(VAG_E_INVALID, "null frequency or output array");
     int rc = check_host_inputs(params, nb, t, n);
     if (rc) return rc;
     if (!uniform_flags(params, nb))
@@ -2448,6 +2461,7 @@ int vag_flux_density_components4_batch(vag_ctx* c, const vag_model_params* param
     ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
     if (!out4) return set_err(VAG_E_INVALID, "out4 must not be null");
+    if (!nu) return set_err(VAG_E_INVALID, "null frequency array");
     int rc = check_host_inputs(params, nb, t, n);
     if (rc) return rc;
     if (!uniform_flags(params, nb))
@@ -2568,6 +2582,7 @@ static int band_request_dev(vag_ctx* c, const vag_model_params* d_params, int nb
 static int flux_band_impl(vag_ctx* c, const vag_model_params* params, int nb, const double* t, int nt, double nu_min,
                           double nu_max, int num_nu, double* out_total, double* const* out4) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!out_total && !out4) return set_err(VAG_E_INVALID, "null output array");
     int rc = check_host_inputs(params, nb, t, nt);
     if (rc) return rc;
     if (!uniform_flags(params, nb)) {
@@ -2981,6 +2996,7 @@ int vag_loglike_batch_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     ApiLock api_lock(c);
     HandoffScope handoff(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!spec || !d_theta || !d_out) return set_err(VAG_E_INVALID, "null spec or device pointer");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     HIPCHK(hipSetDevice(c->device));
     int rc = upload_fit_spec(c, spec, ndim);
@@ -3196,6 +3212,7 @@ int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_ta
 int vag_loglike_batch(vag_ctx* c, const vag_fit_spec* spec, const double* theta, int nb, int ndim, double* out) {
     ApiLock api_lock(c);
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!spec || !theta || !out || ndim <= 0) return set_err(VAG_E_INVALID, "null spec, sample or output array");
     if (nb <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     HIPCHK(hipSetDevice(c->device));
     if (c->d_theta_in.ensure(sizeof(double) * (size_t)nb * (ndim + 1))) return VAG_E_HIP;
@@ -3386,6 +3403,7 @@ int vag_flux_coalesced(vag_ctx* c, const vag_model_params* p, const double* t, i
 static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min, double t_max, vag_details_shape* shape,
                         const vag_details_out* out, bool want_rvs) {
     if (!c) return set_err(VAG_E_INVALID, "null context");
+    if (!params || !shape) return set_err(VAG_E_INVALID, "null model or shape");
     if (want_rvs && !(params->flags & VAG_FLAG_RVS)) return set_err(VAG_E_INVALID, "model has no reverse shock");
     const char* msg = validate_msg(params);
     if (msg) return set_err(VAG_E_INVALID, "%s", msg);
