@@ -292,7 +292,7 @@ struct vag_ctx {
     std::recursive_mutex api_mutex;
     // Concurrent single-model calls gathered into batch calls (vag_*_coalesced, opt-in): see the coalescer below
     std::mutex co_mutex;
-    std::condition_variable co_cv;
+    std::condition_variable co_cv;  // the leader's: arrivals wake the leader alone (a waiting member sleeps on its own request's)
     std::vector<CoalesceRequest*> co_queue;
     bool co_leader = false;
     int co_max_batch = 64, co_wait_us = 50;
@@ -3250,6 +3250,9 @@ struct CoalesceRequest {
     int rc = VAG_OK;
     std::string err;
     bool done = false, promoted = false;
+    std::condition_variable cv;  // this member's own wake-up (done / promoted): an arrival or a finished batch wakes who it concerns,
+                                 // not every sleeping thread of the pool (r05: one shared condition variable with notify_all made
+                                 // each arrival wake ~20 sleepers, each of which took the mutex to find nothing for it)
     bool same_request(const CoalesceRequest& o) const {
         if (kind != o.kind || nt != o.nt || nnu != o.nnu) return false;
         if ((kind & 3) == 2) return nu_min == o.nu_min && nu_max == o.nu_max && num_nu == o.num_nu && (t == o.t || !std::memcmp(t, o.t, sizeof(double) * nt));
@@ -3318,8 +3321,8 @@ static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
     if (!c->co_leader) {
         c->co_leader = true;
     } else {
-        c->co_cv.notify_all();  // (the leader counts the queue)
-        c->co_cv.wait(lk, [&] { return req.done || req.promoted; });
+        c->co_cv.notify_one();  // (the leader counts the queue)
+        req.cv.wait(lk, [&] { return req.done || req.promoted; });
         if (req.done) {
             if (req.rc) g_err = req.err;
             return req.rc;
@@ -3347,12 +3350,16 @@ static int coalesce_submit(vag_ctx* c, CoalesceRequest& req) {
     coalesce_serve(c, batch);  // (takes the context lock inside the entry points)
     lk.lock();
     for (CoalesceRequest* r : batch)
-        if (r != &req) r->done = true;
-    if (!c->co_queue.empty())
+        if (r != &req) {
+            r->done = true;
+            r->cv.notify_one();  // (under the mutex: the member cannot return -- and its request leave the stack -- before this)
+        }
+    if (!c->co_queue.empty()) {
         c->co_queue.front()->promoted = true;  // stays the leader-in-waiting: co_leader remains set
-    else
+        c->co_queue.front()->cv.notify_one();
+    } else {
         c->co_leader = false;
-    c->co_cv.notify_all();
+    }
     lk.unlock();
     if (req.rc) g_err = req.err;
     return req.rc;
