@@ -25,7 +25,9 @@ The same JSON line carries what BASELINE.json's north_star asks for, each next t
                     driver's N = 1, 2, 4, 8 lines give each curve its origin;
   single_model_latency   one model per call (the reference's own protocol) for configs[1] / [2] / [4] beside the reference's
                     one-core time.
-Prints ONE JSON line (see DESIGN.md for the roofline conventions).
+Prints ONE JSON line of < 4 KB on stdout: the driver's contract keys + a flat `extra` of headline scalars (`compact_line`); every leg's
+full record goes to stderr and to the side file the line names (`bench_detail.json`, `bench_detail_nN.json` under torchrun).  See
+DESIGN.md for the roofline conventions.
 """
 import argparse
 import ctypes as C
@@ -238,8 +240,7 @@ def ensemble_bench(lib, h, _lib, dev, with_cpu=True, c3_models=512):
     kernels' own work tallies (one extra untimed pass with vag_ctx_count_work): spectrum evaluations x 210 (synchrotron) or
     x 30 (tabulated SSC spectrum) + interpolations x 26, over the flux stage's HIP-event time."""
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "profiles"))
-    from ssc_ensemble import c3_batch, c5_batch
+    from configs import c3_batch, c5_batch
     t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
     out = {}
     for name, prms in (("C3_fs_rs_ssc_kn", c3_batch(c3_models)), ("C5_two_component_ssc", c5_batch(1024))):
@@ -368,8 +369,7 @@ def ensemble_c5_sharded(lib, h, _lib, dev, world, n_members=4096, steps=3):
     ranks by dist.sharded_flux_density_grid, with and without the all-gather of the fluxes; at N = 1 also the 512-member share
     ONE rank of an 8-GPU run evaluates, timed alone, and the strong-scaling ratio it implies."""
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "profiles"))
-    from ssc_ensemble import c5_batch
+    from configs import c5_batch
     t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
     members = resident_members(c5_batch(n_members), dev)  # seeded: every rank builds the same ensemble
     ev = grid_evaluator(lib, h, _lib, dev, t, nu)
@@ -580,6 +580,130 @@ def threadpool_bench(lib, h, _lib, n_threads=32, n_walkers=1024, rounds=3, wait_
     return out
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+LINE_LIMIT = 4096  # the driver's parser gave up on the 21 KB line of round 5: the line is now short BY CONSTRUCTION
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _sig(x, n=5):
+    """Numbers of the line at n significant digits (the side file keeps full precision)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{n}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_line(detail, detail_file=None):
+    """The ONE line of stdout: exactly the driver's contract keys plus a flat `extra` of scalars; everything else bench.py measures
+    lives in `detail` (stderr + the side file whose name the line carries).  Pure function of `detail`, so a CPU test can hold it to
+    the length limit and to the contract keys on a recorded run (tests/test_abi_and_host.py)."""
+    rf = detail.get("roofline") or {}
+    cb = detail.get("cpu_baseline")
+    line = {k: detail.get(k) for k in CONTRACT_KEYS if k not in ("config", "roofline", "cpu_baseline")}
+    line["value"], line["ms_per_step"] = _sig(line.get("value"), 7), _sig(line.get("ms_per_step"), 6)
+    cfg = detail.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:400], **{k: v for k, v in cfg.items() if k != "workload"}}
+    line["roofline"] = {k: _sig(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch", "valu_busy")}
+    line["roofline"]["traffic"] = rf.get("traffic")
+    line["cpu_baseline"] = None if not cb else {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:160]}
+    ens = detail.get("ensembles_config2_config4") or {}
+    c3, c5 = ens.get("C3_fs_rs_ssc_kn") or {}, ens.get("C5_two_component_ssc") or {}
+    extra = {
+        "hbm_GBps": _dig(detail, "roofline_hbm", "achieved"), "hbm_frac": _dig(detail, "roofline_hbm", "frac"),
+        "cpu_all_cores_lc_per_s": _dig(detail, "cpu_baseline_all_cores", "value"), "cpu_all_cores_threads": _dig(detail, "cpu_baseline_all_cores", "cores"),
+        "vs_reference_1_core": detail.get("vs_reference_1_core_same_box"), "vs_reference_all_cores": detail.get("vs_reference_all_cores_same_box"),
+        "walker_steps_per_s": _dig(detail, "walker_steps", "value"), "walker_steps_fp64_frac": _dig(detail, "walker_steps", "roofline_fp64", "frac"),
+        "walker_steps_8192_per_s": _dig(detail, "walker_steps_8192_total", "value"),
+        "walker_cpu_1_core_per_s": _dig(detail, "walker_steps", "cpu_baseline", "value"),
+        "c1a_batched_vs_all_cores": _dig(detail, "tophat_config0", "C1a_onaxis", "speedup_vs_reference", "batched_vs_all_cores"),
+        "c1a_single_call_vs_1_core": _dig(detail, "tophat_config0", "C1a_onaxis", "speedup_vs_reference", "single_call_vs_1_core"),
+        "c1a_single_call_ms": _dig(detail, "tophat_config0", "C1a_onaxis", "batch_1", "ms_per_call"),
+        "c3_lc_per_s": c3.get("light_curves_per_s"), "c3_flux_frac": _dig(c3, "roofline_fp64_flux_passes", "frac"),
+        "c3_table_frac": _dig(c3, "roofline_fp64_ic_photons", "frac"),
+        "c5_lc_per_s": c5.get("light_curves_per_s"), "c5_flux_frac": _dig(c5, "roofline_fp64_flux_passes", "frac"),
+        "c5_table_frac": _dig(c5, "roofline_fp64_ic_photons", "frac"),
+        "implied_8gpu_ensemble_c5": _dig(detail, "ensemble_c5_4096", "implied_8gpu_speedup_over_1gpu"),
+        "implied_8gpu_walkers_8192": _dig(detail, "walker_steps_per_rank_share_of_8gpu", "implied_8gpu_speedup_8192_walkers"),
+        "implied_8gpu_walkers_1024": _dig(detail, "walker_steps_per_rank_share_of_8gpu", "implied_8gpu_speedup_over_1gpu"),
+        "rank_share_128_walkers_ms": _dig(detail, "walker_steps_per_rank_share_of_8gpu", "128_walkers_per_rank", "ms_per_step"),
+        "rccl_world": detail.get("rccl_world"),
+    }
+    line["extra"] = {k: _sig(v) for k, v in extra.items() if v is not None}
+    line["detail"] = detail_file
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) >= LINE_LIMIT and line["extra"]:  # cannot happen with the keys above; the limit holds whatever a leg returns
+        line["extra"].popitem()
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:
+        line["config"]["workload"] = line["config"]["workload"][:120]
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(detail, real_stdout, world):
+    """Detail -> stderr and the side file; the compact contract line -> the real stdout (rank 0 only calls this)."""
+    name = os.environ.get("VAG_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json" if world == 1 else f"bench_detail_n{world}.json")
+    try:
+        with open(name, "w") as f:
+            json.dump(detail, f, indent=1)
+        shown = os.path.relpath(name, ROOT)
+    except OSError as e:  # a read-only tree must not cost the line
+        shown = f"(not written: {e})"
+    sys.stderr.write("[bench detail] " + json.dumps(detail) + "\n")
+    sys.stderr.flush()
+    os.write(real_stdout, (compact_line(detail, shown) + "\n").encode())
+
+
+def headline_record(world, rccl_world, nb, steps, warmup, elapsed, st, plan, nnu, nt):
+    """The contract part of the record (same keys at every N; rank 0 prints it).  `st` = mean stage times of the timed steps
+    (grid, dynamics, cells, flux, reduce, total; HIP events on the kernels' own stream), `plan` = the tallied plan of one launch."""
+    flux_s = st[3] * 1e-3
+    # algorithmic work of ONE flux-kernel launch (DESIGN.md "Roofline accounting")
+    alg_bytes = plan.n_cells * 18 * 8 + nb * nnu * nt * 8 + nb * (64 + 64) * 8
+    alg_flops = plan.spec_evals * F_SPEC + plan.interps * F_INTERP
+    return {
+        "metric": "light-curves/sec (single model) and MCMC walker-steps/sec at 1/2/4/8 MI355X",
+        "value": world * nb * steps / elapsed,
+        "unit": "light-curves/s",
+        "n_gpus": world, "rccl_world": rccl_world,  # the second is the RCCL group's own rank count (dist.get_world_size())
+        "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: GaussianJet off-axis (theta_obs=0.3) + ISM, synchrotron+SSA, "
+                               "resolutions (0.355,0.31,20.5) -> ~64x64x199 cells/model, 200 time bins x 10 bands; "
+                               "every physical parameter jittered +-10 % log-uniformly (ragged batch)",
+                   "models_per_gpu_per_step": nb, "global_batch": world * nb, "parallelism": f"walker-shard x{world}"},
+        # the kernel's bound is the FP64 vector ALU (SURVEY 8d, DESIGN 5): flop-equivalents of ONE launch (210 per spectrum evaluation,
+        # 26 per interpolation, tallied by the kernel in an untimed pass) over its HIP-event time; `traffic` = its HBM bytes by counters
+        "roofline": {"bound": "fp64_valu", "kernel": "vag_flux_grid_kernel",
+                     "achieved": alg_flops / flux_s / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": alg_flops / flux_s / 1e12 / PEAK_FP64_TFLOPS, "traffic": None,
+                     "spec_evals_per_launch": plan.spec_evals, "interps_per_launch": plan.interps,
+                     "flop_eq_per_launch": alg_flops, "ms_per_launch": st[3]},
+        # BASELINE.json asks for HBM GB/s vs peak as well: the same launch's algorithmic bytes -- reported, not the bound
+        "roofline_hbm": {"bound": "hbm (reported because BASELINE.json names it; the kernel is FP64-VALU bound)", "kernel": "vag_flux_grid_kernel",
+                         "achieved": alg_bytes / flux_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / flux_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "bytes_per_launch": alg_bytes, "ms_per_launch": st[3]},
+        "stage_ms": {"grid": st[0], "dynamics": st[1], "syn_cells": st[2], "sync_flux": st[3], "reduce": st[4],
+                     "total_device": st[5]},
+        "plan": {"ode_rows": plan.n_rows, "cells": plan.n_cells, "theta_phi_rows": plan.total_pairs,
+                 "flux_workgroups": plan.flux_blocks, "rows_per_workgroup": plan.pairs_per_block},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -710,8 +834,7 @@ def main():
     threadpool = threadpool_bench(lib, h, _lib) if (extra and world == 1) else None
     single = None
     if extra and world == 1:  # the metric reads "light-curves/sec (single model)": one model per call for configs[1] / [2] / [4]
-        sys.path.insert(0, os.path.join(ROOT, "profiles"))
-        from ssc_ensemble import c3_batch, c5_batch
+        from configs import c3_batch, c5_batch
         t_e, nu_e = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
         ref = lambda k: (ensembles or {}).get(k, {}).get("cpu_baseline", {}).get("value")
         single = single_model_latency(lib, h, _lib, dev, {
@@ -720,40 +843,8 @@ def main():
             "C5_two_component_ssc": (c5_batch(1)[0], t_e, nu_e, ref("C5_two_component_ssc"))})
 
     if rank == 0:
-        st = np.mean(np.array(flux_ms), axis=0)
-        flux_s = st[3] * 1e-3
-        # algorithmic work of ONE flux-kernel launch (DESIGN.md "Roofline accounting")
-        alg_bytes = plan.n_cells * 18 * 8 + nb * nnu * nt * 8 + nb * (64 + 64) * 8
-        alg_flops = plan.spec_evals * F_SPEC + plan.interps * F_INTERP
-        out = {
-            "metric": "light-curves/sec (single model) and MCMC walker-steps/sec at 1/2/4/8 MI355X",
-            "value": world * nb * args.steps / elapsed,
-            "unit": "light-curves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: GaussianJet off-axis (theta_obs=0.3) + ISM, synchrotron+SSA, "
-                                   "resolutions (0.355,0.31,20.5) -> ~64x64x199 cells/model, 200 time bins x 10 bands; "
-                                   "every physical parameter jittered +-10 % log-uniformly (ragged batch)",
-                       "models_per_gpu_per_step": nb, "global_batch": world * nb, "parallelism": f"walker-shard x{world}"},
-            # the kernel's bound is the FP64 vector ALU: flop-equivalents of ONE launch (210 per spectrum evaluation,
-            # 26 per interpolation, tallied by the kernel in an untimed pass) over its HIP-event time; `traffic` = its HBM bytes by counters
-            "roofline": {"bound": "fp64_valu", "kernel": "vag_flux_grid_kernel",
-                         "achieved": alg_flops / flux_s / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": alg_flops / flux_s / 1e12 / PEAK_FP64_TFLOPS, "traffic": None,
-                         "spec_evals_per_launch": plan.spec_evals, "interps_per_launch": plan.interps,
-                         "flop_eq_per_launch": alg_flops, "ms_per_launch": st[3]},
-            # BASELINE.json asks for HBM GB/s vs peak as well: the same launch's algorithmic bytes -- reported, not the bound
-            "roofline_hbm": {"bound": "hbm (reported because BASELINE.json names it; the kernel is FP64-VALU bound)", "kernel": "vag_flux_grid_kernel",
-                             "achieved": alg_bytes / flux_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": alg_bytes / flux_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                             "bytes_per_launch": alg_bytes, "ms_per_launch": st[3]},
-            "stage_ms": {"grid": st[0], "dynamics": st[1], "syn_cells": st[2], "sync_flux": st[3], "reduce": st[4],
-                         "total_device": st[5]},
-            "plan": {"ode_rows": plan.n_rows, "cells": plan.n_cells, "theta_phi_rows": plan.total_pairs,
-                     "flux_workgroups": plan.flux_blocks, "rows_per_workgroup": plan.pairs_per_block},
-        }
+        out = headline_record(world, dist.get_world_size() if world > 1 else 1, nb, args.steps, args.warmup, elapsed,
+                              np.mean(np.array(flux_ms), axis=0), plan, nnu, nt)
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh; FETCH_SIZE x2 per the gfx950 note, calibrated on a kernel with known bytes)
         for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -826,7 +917,7 @@ def main():
                 out["walker_steps"]["cpu_baseline_all_cores"] = wall
                 out["walker_steps"]["speedup_vs_reference_1_core"] = walkers["value"] / wc["value"]
                 out["walker_steps"]["speedup_vs_reference_all_cores"] = walkers["value"] / wall["value"]
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out, real_stdout, world)
     lib.vag_ctx_destroy(h)
     if world > 1:
         dist.destroy_process_group()

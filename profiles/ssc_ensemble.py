@@ -12,30 +12,7 @@ from vegasafterglow_amd import _lib
 from vegasafterglow_amd.model import get_context
 
 
-def c5_batch(nb, seed=1):
-    rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(nb):
-        out.append(_abi.make_params(jet="TwoComponentJet", theta_c=rng.uniform(0.03, 0.1), E_iso=10 ** rng.uniform(51, 53),
-                                    Gamma0=rng.uniform(100, 500), theta_w=rng.uniform(0.2, 0.5),
-                                    E_iso_w=10 ** rng.uniform(49, 51), Gamma0_w=rng.uniform(20, 100), n_ism=1.0,
-                                    lumi_dist=1e28, z=1.0, theta_obs=0.15, eps_e=0.1, eps_B=0.01, p=2.3, ssc=True,
-                                    resolutions=(0.59, 0.98, 12.0)))
-    return out
-
-
-def c3_batch(nb, seed=3):
-    import configs
-    rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(nb):
-        kw = dict(configs.C3)
-        j = lambda: float(np.exp(rng.uniform(np.log(0.9), np.log(1.1))))
-        kw.update(theta_c=kw["theta_c"] * j(), E_iso=kw["E_iso"] * j(), Gamma0=kw["Gamma0"] * j(), A_star=kw["A_star"] * j(),
-                  eps_e=kw["eps_e"] * j(), eps_B=kw["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
-        kw["rvs"] = dict(kw["rvs"], eps_B=kw["rvs"]["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
-        out.append(_abi.make_params(**kw))
-    return out
+from configs import c3_batch, c5_batch  # the workloads live in tests/configs.py (round 6)
 
 
 if __name__ == "__main__":

@@ -121,3 +121,34 @@ NONAXI_CASES = {
     "powerlaw_wind_one_phi_3d": dict(jet="PowerLawJet", medium="Wind", A_star=0.1, n_ism=0.0, theta_obs=0.02,
                                      resolutions=(0.005, 0.5, 5.0), axisymmetric=False),
 }
+
+
+# The timed ensemble workloads of bench.py (BASELINE configs[2] / configs[4]); also what the full-size parity tests and the
+# reference-spread fixtures (tests/golden/make_spread_fixture.py) evaluate.  Seeded: every caller, and every rank, builds the same models.
+def c5_batch(nb, seed=1):
+    """BASELINE configs[4]: prior-predictive sweep of two-component jets, SSC on, resolutions (0.59, 0.98, 12) -> ~128 x 128 x 111 cells."""
+    import _abi
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nb):
+        out.append(_abi.make_params(jet="TwoComponentJet", theta_c=rng.uniform(0.03, 0.1), E_iso=10 ** rng.uniform(51, 53),
+                                    Gamma0=rng.uniform(100, 500), theta_w=rng.uniform(0.2, 0.5),
+                                    E_iso_w=10 ** rng.uniform(49, 51), Gamma0_w=rng.uniform(20, 100), n_ism=1.0,
+                                    lumi_dist=1e28, z=1.0, theta_obs=0.15, eps_e=0.1, eps_B=0.01, p=2.3, ssc=True,
+                                    resolutions=(0.59, 0.98, 12.0)))
+    return out
+
+
+def c3_batch(nb, seed=3):
+    """BASELINE configs[2] (C3 above) with +-10 % log-uniform jitter on the jet and microphysics parameters of both shocks."""
+    import _abi
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nb):
+        kw = dict(C3)
+        j = lambda: float(np.exp(rng.uniform(np.log(0.9), np.log(1.1))))
+        kw.update(theta_c=kw["theta_c"] * j(), E_iso=kw["E_iso"] * j(), Gamma0=kw["Gamma0"] * j(), A_star=kw["A_star"] * j(),
+                  eps_e=kw["eps_e"] * j(), eps_B=kw["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
+        kw["rvs"] = dict(kw["rvs"], eps_B=kw["rvs"]["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
+        out.append(_abi.make_params(**kw))
+    return out

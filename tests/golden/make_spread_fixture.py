@@ -1,6 +1,6 @@
 """Both builds of the REAL reference (oracle/_ref/libvag_ref.so: the reference's own flags, -O3 -ffp-contract=fast; and
 libvag_ref_strict.so: -O2 -ffp-contract=off) on the ensemble members the full-size GPU tests sample: the members of the configs[4]
-draw (profiles/ssc_ensemble.py c5_batch) that tests/test_gpu_fullsize.py checks, and 16 members of the jittered configs[2] batch
+draw (tests/configs.py c5_batch) that tests/test_gpu_fullsize.py checks, and 16 members of the jittered configs[2] batch
 (c3_batch(128)) the bench times.  The spread between the two builds is the reference's own compile-flag sensitivity on that input.
 Its conditioning is measured as well: the strict build is re-run with theta_obs and Gamma0 moved by ONE ulp either way (`*_ulp`: the
 largest relative change of the fluxes) -- on member 192 of the configs[4] draw, a two-component jet whose adaptive theta grid sits on the
@@ -17,9 +17,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(ROOT, "profiles"))
 import _abi  # noqa: E402
-from ssc_ensemble import c3_batch, c5_batch  # noqa: E402
+from configs import c3_batch, c5_batch  # noqa: E402
 
 C5_MEMBERS = [3, 77, 192, 200, 311, 480, 4000, 4095]
 C3_MEMBERS = list(range(0, 128, 8))

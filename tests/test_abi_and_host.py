@@ -627,3 +627,44 @@ def test_null_arguments_without_a_device_are_error_codes(lib):
     assert lib.vag_loglike_batch(None, None, None, 1, 1, None) == _lib.VAG_E_INVALID
     lib.vag_params_default(None)
     assert lib.vag_device_bytes_in_use() == 0 or lib.vag_device_count() > 0
+
+
+def test_bench_line_is_short_and_complete_by_construction():
+    """The driver parses ONE JSON line of stdout.  Round 5's line had grown to 21 KB and was not parsed (BENCH_r05.json: parsed null);
+    bench.compact_line now makes the line from the full record: < 4 KB, a JSON round trip, every contract key, roofline and
+    cpu_baseline with their members -- checked here on a recorded full run (tests/golden/bench_detail_recorded.json = round 5's record)
+    and on the same record with every leg blown up or missing."""
+    import json
+    import sys
+    sys.path.insert(0, _abi.ROOT)
+    import bench
+    detail = json.load(open(os.path.join(_abi.ROOT, "tests", "golden", "bench_detail_recorded.json")))
+    assert len(json.dumps(detail)) > 15000  # the record itself is what no longer fitted
+    for variant in ("recorded", "bloated", "headline_only"):
+        d = json.loads(json.dumps(detail))
+        if variant == "bloated":
+            d["config"]["workload"] = d["config"]["workload"] * 40
+            d["cpu_baseline"]["sample"] = "x" * 5000
+            for k in list(d):
+                if isinstance(d[k], dict) and k not in bench.CONTRACT_KEYS:
+                    d[k]["note"] = "y" * 20000
+        if variant == "headline_only":  # --no-walkers --no-cpu-baseline, or any N > 1 rank-0 record
+            d = {k: d[k] for k in bench.CONTRACT_KEYS if k != "cpu_baseline"}
+        text = bench.compact_line(d, "bench_detail.json")
+        assert "\n" not in text and len(text) < bench.LINE_LIMIT
+        line = json.loads(text)
+        assert all(k in line for k in bench.CONTRACT_KEYS)
+        assert line["value"] == pytest.approx(detail["value"], rel=1e-6) and line["ms_per_step"] == pytest.approx(detail["ms_per_step"], rel=1e-5)
+        assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None and line["dtype"] == "f64"
+        assert set(line["roofline"]) == {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch", "valu_busy"}
+        assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-3)
+        assert line["config"]["workload"].startswith("BASELINE configs[1]") and "model" not in line["config"]
+        if variant == "headline_only":
+            assert line["cpu_baseline"] is None and line["extra"] == {}
+        else:
+            assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline"]["kind"] == "reference"
+            assert all(isinstance(v, (int, float)) for v in line["extra"].values())  # scalars only
+            for k in ("walker_steps_per_s", "walker_steps_fp64_frac", "c1a_batched_vs_all_cores", "c1a_single_call_vs_1_core", "c3_lc_per_s",
+                      "c5_lc_per_s", "c3_table_frac", "implied_8gpu_walkers_8192", "implied_8gpu_walkers_1024", "implied_8gpu_ensemble_c5"):
+                assert k in line["extra"], k
+        assert line["detail"] == "bench_detail.json"

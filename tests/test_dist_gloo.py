@@ -252,7 +252,19 @@ def _bench_logic_worker(rank, world, port, q):
 
     sync, barrier, max_over_ranks = bench._dist_helpers(world, dev)
     elapsed = bench.timed_steps(step, 5, 2, world, sync, barrier, max_over_ranks)
-    q.put((rank, elapsed, dict(counted), gathered.numpy().copy()))
+    line = None
+    if rank == 0:  # what rank 0 of `torchrun --nproc-per-node N bench.py --gpus N` writes: the same compact line as at N = 1
+        import types
+        plan = types.SimpleNamespace(n_cells=1000, spec_evals=10 ** 6, interps=10 ** 6, n_rows=10, total_pairs=100, flux_blocks=4, pairs_per_block=25)
+        rec = bench.headline_record(world, dist.get_world_size(), 512, 5, 2, elapsed, np.array([0.1, 0.2, 0.1, 9.0, 0.05, 9.5]), plan, 10, 200)
+        r, w = os.pipe()
+        os.environ["VAG_BENCH_DETAIL"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vag_bench_detail_test_{os.getpid()}.json")
+        bench.emit(rec, w, world)
+        os.close(w)
+        line = os.read(r, 1 << 16).decode()
+        os.close(r)
+        os.remove(os.environ["VAG_BENCH_DETAIL"])
+    q.put((rank, elapsed, dict(counted), gathered.numpy().copy(), line))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -268,7 +280,13 @@ def test_bench_multi_rank_timing_contract_under_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, e0, c0, g0), (r1, e1, c1, g1) = results
+    (r0, e0, c0, g0, line), (r1, e1, c1, g1, none) = results
+    assert none is None and line.endswith("\n") and line.count("\n") == 1 and len(line) < 4096  # rank 0 only, ONE short line
+    import json
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["extra"]["rccl_world"] == 2 and rec["scaling"] == "weak"
+    assert rec["value"] == pytest.approx(2 * 512 * 5 / e0, rel=1e-5)  # whole-job aggregate over the MAX-over-ranks time
+    assert rec["config"]["global_batch"] == 1024 and rec["roofline"]["ms_per_launch"] == 9.0 and rec["cpu_baseline"] is None
     assert c0 == c1 == {"steps": 7, "recorded": 5}  # 2 warm-up + exactly 5 timed
     assert e0 == e1 and e0 >= 5 * 0.02  # the MAX over ranks (the slow rank's 5 x 20 ms), identical on both
     np.testing.assert_array_equal(g0, [0, 0, 0, 0, 1, 1, 1, 1])

@@ -16,7 +16,6 @@ from vegasafterglow_amd import _lib, fitting
 
 pytestmark = pytest.mark.gpu
 dp = C.POINTER(C.c_double)
-sys.path.insert(0, os.path.join(_abi.ROOT, "profiles"))
 
 
 def gpu_series(eng, prms, t, nu):
@@ -188,7 +187,7 @@ def test_row_per_lane_grid_kernel_agrees_with_the_workgroup_kernel(eng, case):
     LDS atomics in lane order); VAG_GRID_ROW_PER_WORKGROUP=1 keeps them on vag_flux_grid_kernel.  Same boundary values, same
     interpolation arithmetic, another summation order: every component agrees to rounding, and the row-per-lane result is the
     same bits from run to run."""
-    from ssc_ensemble import c3_batch, c5_batch
+    from configs import c3_batch, c5_batch
     lib, h = eng
     if case == "two_component_ssc":
         prms = c5_batch(32)
@@ -232,7 +231,7 @@ def test_config4_two_component_ssc_ensemble_512_members(eng, oracle):
     """configs[4]: 512 members of the prior-predictive two-component SSC sweep (128 x 128 grids, 100 t x 4 nu incl. 2.4e26 Hz) in
     one call: sub-sample against the oracle per member, run-to-run determinism (bitwise), batch == sub-batch to rounding, exact
     1/d_L^2 scaling."""
-    from ssc_ensemble import c5_batch
+    from configs import c5_batch
     lib, h = eng
     prms = c5_batch(512)
     t, nu = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
@@ -271,7 +270,7 @@ def test_config4_at_the_full_4096_members(eng, oracle):
     """configs[4] at the size BASELINE.json names: 4096 members of the two-component SSC sweep in one call (0.9 M SSC tables, 67 M
     (theta, phi) rows).  Size-independent properties: every flux finite and non-negative, the first 64 members equal a 64-member
     call to summation rounding, members at the far end of the batch against the oracle."""
-    from ssc_ensemble import c5_batch
+    from configs import c5_batch
     lib, h = eng
     n = 4096
     prms = c5_batch(n)
@@ -318,7 +317,7 @@ def test_config2_jittered_ensemble_members_against_both_reference_builds(eng):
     parameters) against the reference itself, per FluxDict component, on 16 of its members: each within max(2e-6, the reference's
     own sensitivity on that member and component: the spread between its two builds, 1e-11 ... 1.3e-6 here, and its response to a
     one-ulp change of theta_obs / Gamma0, up to 4.6e-4 in the reverse-shock components of single members)."""
-    from ssc_ensemble import c3_batch
+    from configs import c3_batch
     lib, h = eng
     prms = c3_batch(128)
     fx = np.load(os.path.join(_abi.ROOT, "tests", "golden", "reference_spread.npz"))

@@ -557,8 +557,7 @@ def test_oracle_equals_the_strict_reference_build_on_sampled_ensemble_members(or
     The oracle is the strict build bit for bit -- also on member 192 of the configs[4] draw, where the reference's two builds are
     1.7e-5 apart -- and within that member's spread of the -O3 build."""
     import sys
-    sys.path.insert(0, os.path.join(_abi.ROOT, "profiles"))
-    from ssc_ensemble import c3_batch, c5_batch
+    from configs import c3_batch, c5_batch
     fx = np.load(os.path.join(_abi.ROOT, "tests", "golden", "reference_spread.npz"))
     t, nu = fx["t"], fx["nu"]
     c5 = c5_batch(512)
