@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAG_ABI_VERSION 12  /* v12: vag_plan.n_ssc_slow_cells; v11: vag_plan.ode_rhs; a likelihood call's work tallies under vag_ctx_count_work (v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream) */
+#define VAG_ABI_VERSION 13  /* v13: ticketed sharded calls (vag_loglike_shard_begin_dev / _end_dev); v12: vag_plan.n_ssc_slow_cells; v11: vag_plan.ode_rhs; a likelihood call's work tallies under vag_ctx_count_work (v10: VAG_E_INTERNAL; vag_ctx_set_stream orders the context's buffers across a change of stream) */
 
 /* error codes */
 #define VAG_OK 0
@@ -145,6 +145,11 @@ int vag_params_validate(const vag_model_params* p);
 
 const char* vag_last_error(void);
 const char* vag_version(void);
+/* Developer / test hooks are VAG_* environment variables (DESIGN.md names them).  The library reads the process environment once, inside
+ * the first API call, and never on a call path afterwards (ABI v13; a thread pool may drive one context while another thread calls
+ * setenv).  A process that changes such a variable later -- the test-suite does -- calls this to have it read again; not to be called
+ * while another thread is inside the library. */
+void vag_reload_env_hooks(void);
 int vag_abi_version(void);
 
 /* Number of visible HIP devices (0 when none / runtime missing). */
@@ -361,12 +366,21 @@ int vag_last_model_costs_dev(vag_ctx* ctx, int nb, double* d_cost);
  * The deal is a function of the gathered costs only, so all ranks compute the same one without talking.  Stream-ordered on the
  * context stream like vag_loglike_batch_dev; rank / world are the caller's (no communicator is touched here).
  * ABI v11: the deal of a call in flight is kept per (nb_all, world, spec content), so other sharded calls may run on the context between
- * a call's two halves (up to four in flight; calls of equal shape finish in the order they were dealt) -- a caller need not, and should
- * not, hold a process-local lock across its collective.
+ * a call's two halves -- a caller need not, and should not, hold a process-local lock across its collective.
+ * ABI v13: a call in flight is NAMED.  vag_loglike_shard_begin_dev is vag_loglike_shard_dev plus a ticket (never 0), and
+ * vag_loglike_shard_end_dev finishes exactly that call: calls of equal shape may finish in any order, and several calls of the SAME
+ * fit may be in flight (each holds its own deal; up to eight in flight on a context, of up to four different (fit, nb_all, world) keys).
+ * vag_loglike_shard_end_dev(ctx, ticket, NULL, nb_all, world, NULL) abandons a call (the caller's collective failed): its slot is
+ * released and the fit's costs stay as they were.  The unticketed pair stays: its finish takes the OLDEST call in flight of that
+ * shape, which is right only while calls of equal shape finish in the order they were dealt, and an unticketed deal of a fit that
+ * already has one in flight replaces it.
  */
 int vag_loglike_shard_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank,
                           int world, double* d_block);
 int vag_loglike_shard_finish_dev(vag_ctx* ctx, const double* d_gathered, int nb_all, int world, double* d_out);
+int vag_loglike_shard_begin_dev(vag_ctx* ctx, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank,
+                                int world, double* d_block, uint64_t* ticket);
+int vag_loglike_shard_end_dev(vag_ctx* ctx, uint64_t ticket, const double* d_gathered, int nb_all, int world, double* d_out);
 /* For inspection (either pointer may be NULL): d_table[world * per] = walker of every (rank, slot) in the last deal, -1 = padding;
  * d_cost[nb_all] = the gathered costs the NEXT deal will rank by (after a finished call). */
 int vag_loglike_shard_state_dev(vag_ctx* ctx, int nb_all, int world, int32_t* d_table, double* d_cost);

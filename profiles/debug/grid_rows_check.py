@@ -26,9 +26,9 @@ for name, prms in (("C5", c5_batch(256)), ("C3", c3_batch(128))):
     res = {}
     for mode in ("rows", "workgroup"):
         if mode == "workgroup":
-            os.environ["VAG_GRID_ROW_PER_WORKGROUP"] = "1"
+            _lib.hooks["VAG_GRID_ROW_PER_WORKGROUP"] = "1"
         else:
-            os.environ.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
+            _lib.hooks.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
         out = np.empty((nb, nu.size, t.size))
         for rep in range(3):
             t0 = time.time()
@@ -38,7 +38,7 @@ for name, prms in (("C5", c5_batch(256)), ("C3", c3_batch(128))):
         st = _lib.StageTimes()
         lib.vag_last_stage_times(h, C.byref(st))
         res[mode] = (out, dt, st.flux_ms)
-    os.environ.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
+    _lib.hooks.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
     a, b = res["rows"][0], res["workgroup"][0]
     m = b > 1e-12 * b.max(axis=(1, 2), keepdims=True)
     print(name, "max rel diff", np.max(np.abs(a - b)[m] / b[m]), "finite", np.isfinite(a).all(),

@@ -37,11 +37,11 @@ for seed in [int(a) for a in sys.argv[1:]] or [1]:
         got, pl = run(t, series)
         fallbacks += pl.n_ssc_all_cell_fallbacks
         lazy_bytes += pl.ic_pool_bytes
-        os.environ["VAG_IC_ALL_CELLS"] = "1"
+        _lib.hooks["VAG_IC_ALL_CELLS"] = "1"
         try:
             want, pl = run(t, series)
         finally:
-            os.environ.pop("VAG_IC_ALL_CELLS")
+            _lib.hooks.pop("VAG_IC_ALL_CELLS")
         all_bytes += pl.ic_pool_bytes
         for c, (g, x) in enumerate(zip(got, want)):
             bad = [i for i in range(n) if not np.array_equal(g[i], x[i], equal_nan=True)]

@@ -14,19 +14,19 @@ lib = _lib.load(); h, lock = va.get_context(0); dp = C.POINTER(C.c_double)
 t, nu = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
 arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
 def run(tag, **env):
-    for k, v in env.items(): os.environ[k] = v
+    for k, v in env.items(): _lib.hooks[k] = v
     s, c = np.empty((1, nu.size, t.size)), np.empty((1, nu.size, t.size))
     try:
         _lib.check(lib.vag_flux_density_grid_components_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, s.ctypes.data_as(dp), c.ctypes.data_as(dp)))
         print(tag, "ok", s.sum(), c.sum())
     except RuntimeError as e:
         print(tag, "FAILED:", str(e)[-80:])
-    for k in env: os.environ.pop(k)
+    for k in env: _lib.hooks.pop(k)
     return s, c
 run("default")
 run("all cells", VAG_IC_ALL_CELLS="1")
 run("no fused", VAG_NO_FUSED="1")
-os.environ["VAG_IC_ALL_CELLS"] = "1"
+_lib.hooks["VAG_IC_ALL_CELLS"] = "1"
 m = va.Model.from_params(prm)
 d = m.details(t.min(), t.max())
 t_obs = d.fwd.t_obs

@@ -27,7 +27,7 @@ prms = prms[:30] if KN else prms[30:]
 lib = _lib.load(); h, lock = va.get_context(0); dp = C.POINTER(C.c_double)
 t, nu = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
 def run(tag, idx, **env):
-    for k, v in env.items(): os.environ[k] = v
+    for k, v in env.items(): _lib.hooks[k] = v
     n = len(idx)
     arr = (_lib.ModelParams * n)(*[_lib.ModelParams.from_buffer_copy(bytes(prms[i])) for i in idx])
     s, c = np.empty((n, nu.size, t.size)), np.empty((n, nu.size, t.size))
@@ -38,7 +38,7 @@ def run(tag, idx, **env):
     except RuntimeError as e:
         print(tag, "FAILED:", str(e)[-90:], flush=True)
         ok = False
-    for k in env: os.environ.pop(k)
+    for k in env: _lib.hooks.pop(k)
     return ok
 run("all 30", list(range(30)))
 run("all 30 again", list(range(30)))

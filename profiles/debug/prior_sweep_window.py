@@ -41,7 +41,7 @@ for w in range(nw):
     try:
         got = run(t, series)
         pl = _lib.Plan(); lib.vag_last_plan(h, C.byref(pl)); pool_lazy += pl.ic_pool_bytes
-        os.environ["VAG_IC_ALL_CELLS"] = "1"
+        _lib.hooks["VAG_IC_ALL_CELLS"] = "1"
         want = run(t, series)
         lib.vag_last_plan(h, C.byref(pl)); pool_all += pl.ic_pool_bytes
     except RuntimeError as e:
@@ -49,7 +49,7 @@ for w in range(nw):
         bad += 1
         continue
     finally:
-        os.environ.pop("VAG_IC_ALL_CELLS", None)
+        _lib.hooks.pop("VAG_IC_ALL_CELLS", None)
     for c, (g, x) in enumerate(zip(got, want)):
         same = np.array_equal(g, x, equal_nan=True)
         if not same:

@@ -25,11 +25,11 @@ _, lo, hi = fit.build_spec(defs)
 worst = 0.0
 for seed in range(4):
     theta = lo + (hi - lo) * np.random.default_rng(100 + seed).random((2048, len(defs)))
-    os.environ.pop("VAG_SERIES_ROW_PER_WAVE", None)
+    _lib.hooks.pop("VAG_SERIES_ROW_PER_WAVE", None)
     a = fit.loglike_batch(theta, defs)
-    os.environ["VAG_SERIES_ROW_PER_WAVE"] = "1"
+    _lib.hooks["VAG_SERIES_ROW_PER_WAVE"] = "1"
     b = fit.loglike_batch(theta, defs)
-    os.environ.pop("VAG_SERIES_ROW_PER_WAVE", None)
+    _lib.hooks.pop("VAG_SERIES_ROW_PER_WAVE", None)
     assert np.array_equal(np.isfinite(a), np.isfinite(b)), seed
     f = np.isfinite(b)
     worst = max(worst, float(np.max(np.abs(a[f] - b[f]) / np.maximum(np.abs(b[f]), 1e-300))))
@@ -41,10 +41,10 @@ for name, prms in (("C5", c5_batch(64, seed=7)), ("C5b", c5_batch(64, seed=8)), 
     res = []
     for mode in (None, "1"):
         if mode:
-            os.environ["VAG_GRID_ROW_PER_WORKGROUP"] = mode
+            _lib.hooks["VAG_GRID_ROW_PER_WORKGROUP"] = mode
         out = np.empty((nb, nu.size, t.size))
         _lib.check(lib.vag_flux_density_grid_batch(h, arr, nb, t.ctypes.data_as(dp), t.size, nu.ctypes.data_as(dp), nu.size, out.ctypes.data_as(dp)))
-        os.environ.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
+        _lib.hooks.pop("VAG_GRID_ROW_PER_WORKGROUP", None)
         res.append(out)
     a, b = res
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vegasafterglow_amd.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
-    assert lib.vag_abi_version() == 12
+    assert lib.vag_abi_version() == 13
     assert b"gfx950" in lib.vag_version()
 
 

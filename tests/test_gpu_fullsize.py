@@ -103,14 +103,14 @@ def test_fit_kernel_partial_sums_do_not_depend_on_the_launch_shape(eng, oracle):
     base = f.loglike_batch(samples, defs)
     try:
         for w in ("1", "2", "4"):
-            os.environ["VAG_FIT_WAVES_PER_BLOCK"] = w
+            _lib.hooks["VAG_FIT_WAVES_PER_BLOCK"] = w
             assert np.array_equal(f.loglike_batch(samples, defs), base), w
-        os.environ.pop("VAG_FIT_WAVES_PER_BLOCK")
-        os.environ["VAG_SERIES_ROW_PER_WAVE"] = "1"
+        _lib.hooks.pop("VAG_FIT_WAVES_PER_BLOCK")
+        _lib.hooks["VAG_SERIES_ROW_PER_WAVE"] = "1"
         other = f.loglike_batch(samples, defs)
     finally:
-        os.environ.pop("VAG_FIT_WAVES_PER_BLOCK", None)
-        os.environ.pop("VAG_SERIES_ROW_PER_WAVE", None)
+        _lib.hooks.pop("VAG_FIT_WAVES_PER_BLOCK", None)
+        _lib.hooks.pop("VAG_SERIES_ROW_PER_WAVE", None)
     ok = np.isfinite(base)
     assert np.array_equal(np.isfinite(other), ok) and ok.sum() > 150
     np.testing.assert_allclose(base[ok], other[ok], rtol=1e-13)
@@ -144,11 +144,11 @@ def test_cost_ordering_of_the_walkers_changes_no_bit(eng, oracle):
     rng = np.random.default_rng(23)
     a = lo + (hi - lo) * rng.random((512, len(defs)))
     b = lo + (hi - lo) * rng.random((512, len(defs)))
-    os.environ["VAG_NO_ORDER"] = "1"
+    _lib.hooks["VAG_NO_ORDER"] = "1"
     try:
         want_a, want_b = f.loglike_batch(a, defs), f.loglike_batch(b, defs)
     finally:
-        os.environ.pop("VAG_NO_ORDER")
+        _lib.hooks.pop("VAG_NO_ORDER")
     assert np.isfinite(want_a).sum() > 400
     for _ in range(2):  # first call of a batch size, then ranked by the other batch's costs, then by its own
         assert np.array_equal(f.loglike_batch(a, defs), want_a)
@@ -169,11 +169,11 @@ def test_fit_kernel_with_300_points_in_six_bands(eng, oracle):
     got = gpu_series(eng, prms, t, nu)
     again = gpu_series(eng, prms, t, nu)
     assert np.array_equal(got, again) and np.all(np.isfinite(got)) and got.max() > 0
-    os.environ["VAG_SERIES_ROW_PER_WAVE"] = "1"
+    _lib.hooks["VAG_SERIES_ROW_PER_WAVE"] = "1"
     try:
         other = gpu_series(eng, prms, t, nu)
     finally:
-        del os.environ["VAG_SERIES_ROW_PER_WAVE"]
+        del _lib.hooks["VAG_SERIES_ROW_PER_WAVE"]
     np.testing.assert_allclose(got, other, rtol=1e-12, atol=1e-300)
     for i in (0, 47):
         want = oracle.flux_density(prms[i], t, nu)
@@ -210,11 +210,11 @@ def test_row_per_lane_grid_kernel_agrees_with_the_workgroup_kernel(eng, case):
     rows, pairs, ppb = run()
     assert pairs >= 4096 * 64 and ppb == 64  # the batch is large enough for the row-per-lane kernel (vag_capi.hip: run_flux_grid)
     again, _, _ = run()
-    os.environ["VAG_GRID_ROW_PER_WORKGROUP"] = "1"
+    _lib.hooks["VAG_GRID_ROW_PER_WORKGROUP"] = "1"
     try:
         wg, _, _ = run()
     finally:
-        del os.environ["VAG_GRID_ROW_PER_WORKGROUP"]
+        del _lib.hooks["VAG_GRID_ROW_PER_WORKGROUP"]
     for a, a2, b in zip(rows, again, wg):
         assert np.array_equal(a, a2)
         assert np.all(np.isfinite(a))
@@ -552,6 +552,94 @@ def test_two_sharded_calls_in_flight_on_one_context_finish_with_their_own_deals(
             assert np.array_equal(finish(g1), want[first])
             assert np.array_equal(finish(g2), want[second])
         assert lib.vag_loglike_shard_finish_dev(h, g1.data_ptr(), nb, world, torch.empty((nb,), dtype=torch.float64, device=dev).data_ptr()) == _lib.VAG_E_INVALID
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_ctx_set_stream(h, None))
+
+
+def test_ticketed_sharded_calls_finish_in_any_order_and_twice_for_one_fit(eng, oracle):
+    """ABI v13: a call in flight is named by the ticket vag_loglike_shard_begin_dev returns.  Two fits of EQUAL shape dealt A,
+    B and finished B, A -- the order the unticketed finish ("oldest deal of this shape") gets wrong: it would apply B's deal to A's
+    block --; two calls of the SAME fit in flight at once (different samples), both finished, second first; a ticket finished twice, a
+    ticket with the wrong shape and an abandoned ticket are handled; after all of it the fit's cost cache ranks the next deal."""
+    import torch
+    lib, h = eng
+    fa, defs = _c4_fitter(oracle)
+    t, nu = configs.c4_mock_data()
+    tb = t * (t / t.min()) ** 0.7
+    truth = oracle.flux_density(_abi.make_params(**configs.C4_TRUTH), tb, nu)
+    fb = fitting.Fitter(z=configs.C4_TRUTH["z"], lumi_dist=configs.C4_TRUTH["lumi_dist"], jet="gaussian", medium="ism")
+    for b in configs.C4_BANDS:
+        sel = nu == b
+        fb.add_flux_density(b, tb[sel], truth[sel], 0.1 * truth[sel])
+    sa, lo, hi = fa.build_spec(defs)
+    sb, _, _ = fb.build_spec(defs)
+    nb, ndim, world = 96, len(defs), 3
+    per = nb // world
+    rng = np.random.default_rng(77)
+    s1, s2 = (lo + (hi - lo) * rng.random((nb, ndim)) for _ in range(2))
+    want = {("a", 1): fa.loglike_batch(s1, defs), ("b", 1): fb.loglike_batch(s1, defs), ("a", 2): fa.loglike_batch(s2, defs)}
+    dev = torch.device("cuda", 0)
+    d1, d2 = torch.from_numpy(s1).to(dev), torch.from_numpy(s2).to(dev)
+    _lib.check(lib.vag_ctx_set_stream(h, _lib.torch_stream_handle(torch.cuda.current_stream(dev))))
+    out = torch.empty((nb,), dtype=torch.float64, device=dev)
+
+    def begin(spec, d_theta):
+        """One call as `world` simulated ranks on this GPU; rank 0's ticket names the call, the others' are abandoned (on their own
+        GPUs each rank would hold one)."""
+        blocks, tickets = [], []
+        for rank in range(world):
+            blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+            tk = C.c_uint64(0)
+            _lib.check(lib.vag_loglike_shard_begin_dev(h, C.byref(spec), d_theta.data_ptr(), nb, ndim, rank, world, blk.data_ptr(), C.byref(tk)))
+            assert tk.value != 0 and tk.value not in tickets
+            blocks.append(blk)
+            tickets.append(tk.value)
+        for tk in tickets[1:]:
+            _lib.check(lib.vag_loglike_shard_end_dev(h, tk, None, nb, world, None))
+        return tickets[0], torch.cat(blocks, 0).contiguous()
+
+    def end(ticket, gathered):
+        _lib.check(lib.vag_loglike_shard_end_dev(h, ticket, gathered.data_ptr(), nb, world, out.data_ptr()))
+        return out.cpu().numpy()
+
+    try:
+        for _ in range(2):  # the second round is dealt by the costs the first one gathered: A's and B's tables then differ
+            ta, ga = begin(sa, d1)
+            tb_, gb = begin(sb, d1)
+            assert np.array_equal(end(tb_, gb), want[("b", 1)])  # B first: the opposite order to the deals
+            assert np.array_equal(end(ta, ga), want[("a", 1)])
+        # the same fit twice in flight, finished in the opposite order
+        t1, g1 = begin(sa, d1)
+        t2, g2 = begin(sa, d2)
+        assert np.array_equal(end(t2, g2), want[("a", 2)])
+        assert np.array_equal(end(t1, g1), want[("a", 1)])
+        # a ticket serves once; the shape is part of the call; ticket 0 names nothing
+        assert lib.vag_loglike_shard_end_dev(h, t1, g1.data_ptr(), nb, world, out.data_ptr()) == _lib.VAG_E_INVALID
+        t3, g3 = begin(sa, d1)
+        assert lib.vag_loglike_shard_end_dev(h, t3, g3.data_ptr(), nb + 1, world, out.data_ptr()) == _lib.VAG_E_INVALID
+        assert lib.vag_loglike_shard_end_dev(h, 0, g3.data_ptr(), nb, world, out.data_ptr()) == _lib.VAG_E_INVALID
+        assert np.array_equal(end(t3, g3), want[("a", 1)])
+        # nine calls in flight exceed the context's eight slots: refused, and the eight still finish
+        held = []
+        for i in range(8):
+            tk = C.c_uint64(0)
+            blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_begin_dev(h, C.byref(sa), d1.data_ptr(), nb, ndim, 0, world, blk.data_ptr(), C.byref(tk)))
+            held.append(tk.value)
+        tk = C.c_uint64(0)
+        assert lib.vag_loglike_shard_begin_dev(h, C.byref(sa), d1.data_ptr(), nb, ndim, 0, world, blk.data_ptr(), C.byref(tk)) == _lib.VAG_E_INVALID
+        for tk in held:
+            _lib.check(lib.vag_loglike_shard_end_dev(h, tk, None, nb, world, None))
+        # the unticketed pair still serves (oldest deal of the shape; a second deal of the fit replaces the first)
+        blocks = []
+        for rank in range(world):
+            blk = torch.empty((per, 2), dtype=torch.float64, device=dev)
+            _lib.check(lib.vag_loglike_shard_dev(h, C.byref(sa), d2.data_ptr(), nb, ndim, rank, world, blk.data_ptr()))
+            blocks.append(blk)
+        _lib.check(lib.vag_loglike_shard_finish_dev(h, torch.cat(blocks, 0).contiguous().data_ptr(), nb, world, out.data_ptr()))
+        assert np.array_equal(out.cpu().numpy(), want[("a", 2)])
+        assert lib.vag_loglike_shard_finish_dev(h, g1.data_ptr(), nb, world, out.data_ptr()) == _lib.VAG_E_INVALID  # nothing left in flight
     finally:
         torch.cuda.synchronize()
         _lib.check(lib.vag_ctx_set_stream(h, None))

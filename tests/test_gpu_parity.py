@@ -901,19 +901,19 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     prm = _abi.make_params(**kw)
     t, nu = configs.C3_T[::4], configs.C3_NU
     fused = gpu_components4(eng, prm, t, nu)
-    os.environ["VAG_NO_FUSED"] = "1"
+    _lib.hooks["VAG_NO_FUSED"] = "1"
     try:
         two_pass = gpu_components4(eng, prm, t, nu)
     finally:
-        del os.environ["VAG_NO_FUSED"]
+        del _lib.hooks["VAG_NO_FUSED"]
     for a, b in zip(fused, two_pass):
         assert np.array_equal(a, b, equal_nan=True)
     assert fused[1].max() > 0
-    os.environ["VAG_GRID_ROWWISE"] = "1"  # the wavefront-per-row kernel on the same small grid (measured slower: not the default)
+    _lib.hooks["VAG_GRID_ROWWISE"] = "1"  # the wavefront-per-row kernel on the same small grid (measured slower: not the default)
     try:
         rowwise = gpu_components4(eng, prm, t, nu)  # same algorithm, another summation order
     finally:
-        del os.environ["VAG_GRID_ROWWISE"]
+        del _lib.hooks["VAG_GRID_ROWWISE"]
     for a, b in zip(rowwise, two_pass):
         m = b > 1e-12 * b.max() if b.max() > 0 else np.zeros_like(b, dtype=bool)
         assert np.all(np.abs(a - b)[m] <= 1e-11 * b[m]) and np.all(a[~m] <= 1e-11 * max(b.max(), 1e-300))
@@ -921,12 +921,12 @@ def test_fused_sync_and_ssc_pass_is_bitwise_the_two_pass_form(eng, case):
     band_f = np.empty((1, t.size))
     arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
     _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e17, 1e19, 7, band_f.ctypes.data_as(dp)))
-    os.environ["VAG_NO_FUSED"] = "1"
+    _lib.hooks["VAG_NO_FUSED"] = "1"
     try:
         band_t = np.empty((1, t.size))
         _lib.check(lib.vag_flux_batch(h, arr, 1, t.ctypes.data_as(dp), t.size, 1e17, 1e19, 7, band_t.ctypes.data_as(dp)))
     finally:
-        del os.environ["VAG_NO_FUSED"]
+        del _lib.hooks["VAG_NO_FUSED"]
     assert np.array_equal(band_f, band_t)
 
 
@@ -985,11 +985,11 @@ def test_fast_and_general_ode_kernels_agree_on_random_walkers(eng):
                       n_ism=10 ** rng.uniform(-4, 1), p=rng.uniform(2.05, 2.8), eps_e=10 ** rng.uniform(-3, -0.5), eps_B=10 ** rng.uniform(-5, -1))
             prms.append(_abi.make_params(**kw))
         fast = gpu_grid(eng, prms, t, nu)
-        os.environ["VAG_DYN_GENERAL"] = "1"
+        _lib.hooks["VAG_DYN_GENERAL"] = "1"
         try:
             general = gpu_grid(eng, prms, t, nu)
         finally:
-            os.environ.pop("VAG_DYN_GENERAL")
+            _lib.hooks.pop("VAG_DYN_GENERAL")
         assert np.all(np.isfinite(fast)) and np.all(np.isfinite(general))
         sel = fast > 1e-3 * fast.max(axis=(1, 2), keepdims=True)
         assert np.max(np.abs(fast - general)[sel] / fast[sel]) <= 1e-10, n
@@ -1022,11 +1022,11 @@ def test_the_grid_kernels_two_layouts_give_the_same_bits(eng):
 
     for series in (False, True):
         small = run(series)
-        os.environ["VAG_GRID_FORCE_LARGE"] = "1"
+        _lib.hooks["VAG_GRID_FORCE_LARGE"] = "1"
         try:
             large = run(series)
         finally:
-            os.environ.pop("VAG_GRID_FORCE_LARGE")
+            _lib.hooks.pop("VAG_GRID_FORCE_LARGE")
         for c, (a, b) in enumerate(zip(small, large)):
             bad = [i for i in range(n) if not np.array_equal(a[i], b[i], equal_nan=True)]
             assert not bad, (series, c, [tags[i] for i in bad[:4]])
@@ -1069,11 +1069,11 @@ def test_lazily_built_ssc_tables_are_the_bits_of_every_table_on_random_narrow_wi
         pl = _lib.Plan()
         lib.vag_last_plan(h, C.byref(pl))
         lazy_bytes += pl.ic_pool_bytes
-        os.environ["VAG_IC_ALL_CELLS"] = "1"
+        _lib.hooks["VAG_IC_ALL_CELLS"] = "1"
         try:
             want = run(t, series)
         finally:
-            os.environ.pop("VAG_IC_ALL_CELLS")
+            _lib.hooks.pop("VAG_IC_ALL_CELLS")
         lib.vag_last_plan(h, C.byref(pl))
         all_bytes += pl.ic_pool_bytes
         for c, (g, x) in enumerate(zip(got, want)):
@@ -1107,24 +1107,24 @@ def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
             _lib.check(lib.vag_flux_density_components4_batch(h, arr, len(prms), tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
             return comps
         if case == "grid":
-            os.environ["VAG_NO_FUSED"] = "1"
+            _lib.hooks["VAG_NO_FUSED"] = "1"
         try:
             return gpu_components4(eng, prms, t, nu)
         finally:
-            os.environ.pop("VAG_NO_FUSED", None)
+            _lib.hooks.pop("VAG_NO_FUSED", None)
 
     got = run()
-    os.environ["VAG_IC_ALL_CELLS"] = "1"
+    _lib.hooks["VAG_IC_ALL_CELLS"] = "1"
     try:
         want = run()
     finally:
-        os.environ.pop("VAG_IC_ALL_CELLS")
+        _lib.hooks.pop("VAG_IC_ALL_CELLS")
     assert want[1].max() > 0 and want[3].max() > 0
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     # (2) a hole in the selection: the pass is repeated with every cell's table -- the reference's answer, bit for bit -- and counted;
     #     with the fallback switched off the fault is loud (what a second miss, on the all-cells pass, would raise)
-    os.environ["VAG_DEBUG_IC_NEED_SHRINK"] = "1e-2"
+    _lib.hooks["VAG_DEBUG_IC_NEED_SHRINK"] = "1e-2"
     try:
         got_fb = run()
         plan = _lib.Plan()
@@ -1132,12 +1132,12 @@ def test_ssc_tables_only_for_the_cells_a_request_queries(eng, case):
         assert plan.n_ssc_all_cell_fallbacks >= 1
         for g, w in zip(got_fb, want):
             assert np.array_equal(g, w)
-        os.environ["VAG_DEBUG_IC_NO_FALLBACK"] = "1"
+        _lib.hooks["VAG_DEBUG_IC_NO_FALLBACK"] = "1"
         with pytest.raises(RuntimeError, match="queried an SSC cell that was given no table"):
             run()
     finally:
-        os.environ.pop("VAG_DEBUG_IC_NEED_SHRINK")
-        os.environ.pop("VAG_DEBUG_IC_NO_FALLBACK", None)
+        _lib.hooks.pop("VAG_DEBUG_IC_NEED_SHRINK")
+        _lib.hooks.pop("VAG_DEBUG_IC_NO_FALLBACK", None)
     for g, w in zip(run(), want):  # and the context is in order afterwards
         assert np.array_equal(g, w)
     plan = _lib.Plan()
@@ -1164,11 +1164,11 @@ def test_ssc_cells_beyond_the_on_chip_lattice_limits_take_the_general_kernel(eng
 
     def run(limit):
         if limit is not None:
-            os.environ["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
+            _lib.hooks["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
         try:
             comps = gpu_components4(eng, prm, t, nu)
         finally:
-            os.environ.pop("VAG_DEBUG_IC_FAST_NU_MAX", None)
+            _lib.hooks.pop("VAG_DEBUG_IC_FAST_NU_MAX", None)
         pl = _lib.Plan()
         lib.vag_last_plan(h, C.byref(pl))
         return comps, pl.n_ssc_slow_cells
@@ -1216,11 +1216,11 @@ def test_ssc_loglike_with_cells_on_the_general_kernel(eng, oracle):
     assert np.all(np.isfinite(want)) and f.last_plan.n_ssc_slow_cells == 0
 
     def run(limit):
-        os.environ["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
+        _lib.hooks["VAG_DEBUG_IC_FAST_NU_MAX"] = str(limit)
         try:
             ll = f.loglike_batch(theta, defs)
         finally:
-            os.environ.pop("VAG_DEBUG_IC_FAST_NU_MAX")
+            _lib.hooks.pop("VAG_DEBUG_IC_FAST_NU_MAX")
         return ll, f.last_plan
     n_slow = 0
     for limit in range(120, 8, -4):  # the highest limit that leaves some cells over it: a handful of them
@@ -1258,21 +1258,21 @@ def test_ssc_band_breach_rebuilds_the_tables_unclamped(eng, case):
             _lib.check(lib.vag_flux_density_components4_batch(h, arr, 1, tt.ctypes.data_as(dp), nn.ctypes.data_as(dp), tt.size, out4))
         else:
             if case == "grid":
-                os.environ["VAG_NO_FUSED"] = "1"
+                _lib.hooks["VAG_NO_FUSED"] = "1"
             try:
                 comps = gpu_components4(eng, prm, t, nu)
             finally:
-                os.environ.pop("VAG_NO_FUSED", None)
+                _lib.hooks.pop("VAG_NO_FUSED", None)
         pl = _lib.Plan()
         lib.vag_last_plan(h, C.byref(pl))
         return comps, pl.n_models_ssc_rebuilt
     want, rebuilt0 = run()
     assert rebuilt0 == 0 and want[1].max() > 0
-    os.environ["VAG_DEBUG_IC_NARROW"] = "1e-9"
+    _lib.hooks["VAG_DEBUG_IC_NARROW"] = "1e-9"
     try:
         got, rebuilt = run()
     finally:
-        del os.environ["VAG_DEBUG_IC_NARROW"]
+        del _lib.hooks["VAG_DEBUG_IC_NARROW"]
     assert rebuilt >= 1
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
@@ -1303,11 +1303,11 @@ def test_lattices_longer_than_the_staged_row_are_taken_in_pieces(eng, case):
         return grid, series, band, pl.n_cells // max(pl.n_rows, 1)
     g1, s1, b1, k_nodes = run()
     assert k_nodes > 40  # several pieces of 12
-    os.environ["VAG_FLUX_K_CAP"] = "12"
+    _lib.hooks["VAG_FLUX_K_CAP"] = "12"
     try:
         g2, s2, b2, _ = run()
     finally:
-        del os.environ["VAG_FLUX_K_CAP"]
+        del _lib.hooks["VAG_FLUX_K_CAP"]
     for a, b in zip(g2 + [s2, b2], g1 + [s1, b1]):
         assert np.all(np.isfinite(a))
         np.testing.assert_allclose(a, b, rtol=2e-13, atol=1e-300)
@@ -1777,11 +1777,11 @@ def test_profile_data_uses_the_reference_stage_names(eng):
     try:
         want = plain.flux_density_grid(t, nu).total
         p0 = va.Model.profile_data()
-        os.environ["VAG_NO_FUSED"] = "1"  # the fused synchrotron + SSC pass is booked under sync_flux: ask for separate passes
+        _lib.hooks["VAG_NO_FUSED"] = "1"  # the fused synchrotron + SSC pass is booked under sync_flux: ask for separate passes
         full.flux_density_grid(t, nu)
         p1 = va.Model.profile_data()
     finally:
-        os.environ.pop("VAG_NO_FUSED", None)
+        _lib.hooks.pop("VAG_NO_FUSED", None)
         va.Model.profile_enable(False)
     assert set(p0) == names == set(p1)
     assert all(v >= 0 for v in p0.values()) and all(v >= 0 for v in p1.values())

@@ -105,12 +105,12 @@ class Limits(C.Structure):
 
 
 EXPORTS = [
-    "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version",
+    "vag_params_default", "vag_params_validate", "vag_last_error", "vag_version", "vag_abi_version", "vag_reload_env_hooks",
     "vag_device_count", "vag_device_bytes_in_use", "vag_ctx_create", "vag_ctx_destroy", "vag_ctx_set_stream", "vag_ctx_get_stream", "vag_ctx_synchronize",
     "vag_get_limits", "vag_flux_density_grid_batch", "vag_flux_density_grid_components_batch", "vag_flux_components_batch",
     "vag_flux_density_grid_components4_batch", "vag_flux_components4_batch", "vag_flux_density_batch", "vag_flux_batch",
     "vag_flux_density_components4_batch", "vag_flux_density_grid_batch_dev", "vag_flux_density_batch_dev", "vag_loglike_batch", "vag_loglike_batch_dev",
-    "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_regime", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
+    "vag_last_model_costs_dev", "vag_loglike_shard_dev", "vag_loglike_shard_finish_dev", "vag_loglike_shard_begin_dev", "vag_loglike_shard_end_dev", "vag_loglike_shard_state_dev", "vag_ctx_profile", "vag_last_profile", "vag_details", "vag_details_rvs", "vag_details_radiation", "vag_details_regime", "vag_details_eat", "vag_profile_eval", "vag_last_stage_times", "vag_last_plan", "vag_ctx_count_work",
     "vag_ctx_coalesce", "vag_ctx_coalesce_stats", "vag_flux_density_grid_coalesced", "vag_flux_density_coalesced", "vag_flux_coalesced",
 ]
 
@@ -139,6 +139,7 @@ def load():
     v = C.c_void_p
     lib.vag_last_error.restype = C.c_char_p
     lib.vag_version.restype = C.c_char_p
+    lib.vag_reload_env_hooks.restype = None
     lib.vag_params_default.argtypes = [_pp]
     lib.vag_params_default.restype = None
     lib.vag_params_validate.argtypes = [_pp]
@@ -171,6 +172,8 @@ def load():
     lib.vag_last_model_costs_dev.argtypes = [v, C.c_int, v]
     lib.vag_loglike_shard_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, C.c_int, C.c_int, v]
     lib.vag_loglike_shard_finish_dev.argtypes = [v, v, C.c_int, C.c_int, v]
+    lib.vag_loglike_shard_begin_dev.argtypes = [v, C.POINTER(FitSpec), v, C.c_int, C.c_int, C.c_int, C.c_int, v, C.POINTER(C.c_uint64)]
+    lib.vag_loglike_shard_end_dev.argtypes = [v, C.c_uint64, v, C.c_int, C.c_int, v]
     lib.vag_loglike_shard_state_dev.argtypes = [v, C.c_int, C.c_int, v, v]
     lib.vag_ctx_profile.argtypes = [v, C.c_int]
     lib.vag_last_profile.argtypes = [v, C.POINTER(Profile)]
@@ -216,3 +219,37 @@ def check(rc):
     if rc == VAG_E_INTERNAL:
         raise RuntimeError("vegasafterglow_amd internal error (please report): " + msg)
     raise RuntimeError(f"vegasafterglow_amd error {rc}: {msg}")
+
+
+class _Hooks:
+    """The engine's developer / test switches are VAG_* environment variables which the library reads ONCE (inside its first call) --
+    never on a call path, where getenv would race with another thread's setenv.  A process that flips one later does it through this
+    mapping: the variable is set (or removed) in os.environ and the library is told to read its environment again.  Not for use while
+    another thread is inside the engine."""
+
+    @staticmethod
+    def _reload():
+        if os.path.exists(LIB_PATH):
+            load().vag_reload_env_hooks()
+
+    def __setitem__(self, name, value):
+        os.environ[name] = value
+        self._reload()
+
+    def __delitem__(self, name):
+        del os.environ[name]
+        self._reload()
+
+    def pop(self, name, *default):
+        value = os.environ.pop(name, *default)
+        self._reload()
+        return value
+
+    def get(self, name, default=None):
+        return os.environ.get(name, default)
+
+    def __contains__(self, name):
+        return name in os.environ
+
+
+hooks = _Hooks()

@@ -15,7 +15,9 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
+#include <shared_mutex>
 
 #include "vag_ic_kernels.h"
 #include "vag_kernels.h"
@@ -38,6 +40,46 @@ int set_err(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+
+
+// Developer / test hooks (VAG_* environment variables).  The process environment is read ONCE -- when the first hook is asked for, i.e.
+// inside the first API call -- and again only by vag_reload_env_hooks(): no getenv on any call path afterwards (getenv races with
+// setenv / putenv of other threads, and a thread pool drives one context from many threads).  A value's storage stays where
+// it is until the next reload.
+extern "C" char** environ;
+struct EnvHooks {
+    std::shared_mutex mu;
+    std::map<std::string, std::string> kv;
+    bool loaded = false;
+    void load_locked() {
+        kv.clear();
+        for (char** e = environ; e && *e; ++e) {
+            if (std::strncmp(*e, "VAG_", 4) != 0) continue;
+            const char* eq = std::strchr(*e, '=');
+            if (eq) kv.emplace(std::string(*e, eq - *e), std::string(eq + 1));
+        }
+        loaded = true;
+    }
+    const char* get(const char* name) {
+        {
+            std::shared_lock<std::shared_mutex> rd(mu);
+            if (loaded) {
+                auto it = kv.find(name);
+                return it == kv.end() ? nullptr : it->second.c_str();
+            }
+        }
+        std::unique_lock<std::shared_mutex> wr(mu);
+        if (!loaded) load_locked();
+        auto it = kv.find(name);
+        return it == kv.end() ? nullptr : it->second.c_str();
+    }
+    void reload() {
+        std::unique_lock<std::shared_mutex> wr(mu);
+        load_locked();
+    }
+};
+EnvHooks g_hooks;
+inline const char* vag_hook(const char* name) { return g_hooks.get(name); }
 
 #define HIPCHK(call)                                                                                  \
     do {                                                                                              \
@@ -309,20 +351,27 @@ struct vag_ctx {
     // other's walkers, so a few of them are kept (least recently used is replaced), keyed by the fit spec's content hash.
     struct ShardCosts {
         DevBuf cost;
-        DevBuf table;           // the deal of this key's call in flight (between vag_loglike_shard_dev and its finish), kept afterwards for inspection
         uint64_t hash = 0;
         int nb = 0, world = 0;
         bool valid = false;     // a call of this key has finished: `cost` holds its gathered costs
-        bool pending = false;   // a call of this key waits for its finish
-        unsigned long long used = 0, dealt = 0;  // clock of the last use / of the pending deal
+        int in_flight = 0;      // calls of this key that wait for their finish (the entry is not replaced meanwhile)
+        unsigned long long used = 0;  // clock of the last use
     };
-    // Deals are kept per key (batch size, world, spec hash), so that other sharded calls on this context between one call's
-    // vag_loglike_shard_dev and its finish -- another sharder of the same process, around ITS all-gather -- leave that call's table
-    // alone (ABI v11; until v10 there was one table per context and the Python side held the context lock across the collective).
+    // A call in flight (between its deal and its finish) owns ONE flight slot: the deal's table and the ticket that names it (ABI v13).
+    // Until v12 the table hung on the key and a finish took "the oldest pending deal of this shape": two calls of equal shape that
+    // finished in the opposite order to their deals applied each other's tables, and two calls of the SAME key could not both finish.
+    struct ShardFlight {
+        DevBuf table;           // walker of every (rank, slot); kept after the finish for inspection until the slot is dealt again
+        uint64_t ticket = 0;    // the deal's clock value: unique per context, never 0
+        int key = -1, nb = 0, world = 0;
+        bool in_use = false;
+        bool unticketed = false;  // opened by vag_loglike_shard_dev: a new deal of the same key replaces it (the v9 behaviour)
+    };
     ShardCosts shard_costs[4];
+    ShardFlight shard_flights[8];
     unsigned long long shard_clock = 0;
-    int shard_last = -1;                    // entry of the last finished call (vag_loglike_shard_state_dev reports it)
-    int shard_last_dealt = -1;              // entry of the last deal
+    int shard_last = -1;                    // key entry of the last finished call (vag_loglike_shard_state_dev reports its costs)
+    int shard_last_dealt = -1;              // flight slot of the last deal (... and its table)
     DevBuf d_shard_theta, d_shard_ll;
     // device-resident batches whose models differ in their Radiation / shock flags: regrouped by flags (flux_dev_by_flags)
     bool mixed_flags_seen = false;  // the last grid pass stopped on such a batch
@@ -358,6 +407,7 @@ struct vag_ctx {
     hipEvent_t ev[8] = {};
     hipEvent_t ev_handoff = nullptr;  // orders the context's buffers across a change of stream (vag_ctx_set_stream)
     bool handoff_ready = false;       // ev_handoff marks the tail of the work queued on the current (caller-owned) stream
+    bool handoff_dirty = false;       // a compute call has queued work since the event was last recorded (ApiLock records it on the way out)
     // inputs
     DevBuf d_params, d_t, d_nu, d_lg2t, d_lg2nu, d_tminmax, d_bandw, d_out;
     // grid results
@@ -434,13 +484,13 @@ extern "C" {
 const char* vag_last_error(void) { return g_err.c_str(); }
 struct ApiLock {  // (a null context is rejected by the entry point itself)
     std::recursive_mutex* m;
+    vag_ctx* ctx;
     explicit ApiLock(vag_ctx* c);
-    ~ApiLock() {
-        if (m) m->unlock();
-    }
+    ~ApiLock();
     ApiLock(const ApiLock&) = delete;
 };
 const char* vag_version(void) { return "vegasafterglow_amd 0.1 (gfx950)"; }
+void vag_reload_env_hooks(void) { g_hooks.reload(); }
 int vag_abi_version(void) { return VAG_ABI_VERSION; }
 
 void vag_params_default(vag_model_params* p) {
@@ -572,8 +622,20 @@ static int ctx_init(vag_ctx* c) {
 
 extern "C" {
 
-ApiLock::ApiLock(vag_ctx* c) : m(c ? &c->api_mutex : nullptr) {
+ApiLock::ApiLock(vag_ctx* c) : m(c ? &c->api_mutex : nullptr), ctx(c) {
     if (m) m->lock();
+}
+// EVERY entry point leaves the hand-off event at the tail of a caller-owned stream, whichever way it returns (only the
+// device-pointer forms did, so a host-buffer call that failed with kernels still queued left `handoff_ready` stale and the next
+// vag_ctx_set_stream ordered the new stream behind an older event -- scratch buffers could be reused while the old stream wrote them).
+// (Only on the way out of a call that queued work -- `handoff_dirty`, set where a call's model stage starts: the getters may be called
+// after the caller destroyed its stream and must not touch it.)
+ApiLock::~ApiLock() {
+    if (ctx && ctx->handoff_dirty && ctx->stream != nullptr && ctx->stream != ctx->own_stream && ctx->ev_handoff) {
+        ctx->handoff_ready = hipEventRecord(ctx->ev_handoff, ctx->stream) == hipSuccess;
+        ctx->handoff_dirty = false;
+    }
+    if (m) m->unlock();
 }
 
 int vag_ctx_create(int device, vag_ctx** out) {
@@ -613,7 +675,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     c->d_icwork.release();
     c->h_fit.release();
     c->d_fitstat.release();
-    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->shard_costs[0].table, &c->shard_costs[1].table, &c->shard_costs[2].table, &c->shard_costs[3].table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo, &c->d_icneed})
+    for (DevBuf* b : {&c->d_mix_flags, &c->d_mix_perm, &c->d_mix_params, &c->d_mix_out, &c->shard_costs[0].cost, &c->shard_costs[1].cost, &c->shard_costs[2].cost, &c->shard_costs[3].cost, &c->shard_flights[0].table, &c->shard_flights[1].table, &c->shard_flights[2].table, &c->shard_flights[3].table, &c->shard_flights[4].table, &c->shard_flights[5].table, &c->shard_flights[6].table, &c->shard_flights[7].table, &c->d_shard_theta, &c->d_shard_ll, &c->d_order[0], &c->d_order[1], &c->d_cost_f, &c->d_rowgeo, &c->d_icneed})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -802,7 +864,7 @@ int run_radiation(vag_ctx* c, const vag_model_params* d_rad_params, int nb, cons
         hipLaunchKernelGGL(vag_cells_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, d_rad_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->d_shock.as<double>(), cells, c->d_cellpar.as<double>(),
                            want_details ? c->d_celldet.as<double>() : nullptr, d_inj, raw_shock ? c->d_shock.as<double>() : nullptr,
-                           want_details || std::getenv("VAG_CELLS_WRITE_BACK") != nullptr);
+                           want_details || vag_hook("VAG_CELLS_WRITE_BACK") != nullptr);
     }
     HIPCHK(hipGetLastError());
     if (ssc) {  // cool the electrons row by row, then rebuild the photons
@@ -850,7 +912,7 @@ int wait_plan(vag_ctx* c) {
 // lanes rejects) and one wavefront fills a SIMD (256 VGPRs): fewer rows per wavefront mean fewer repeated attempts and -- while the
 // batch has fewer wavefronts than the chip has SIMDs -- more SIMDs at work.  VAG_PAIR_RPW overrides (tuning).
 int pair_rows_per_wave(int rows, const char* env = "VAG_PAIR_RPW") {
-    if (const char* e = std::getenv(env)) {
+    if (const char* e = vag_hook(env)) {
         const int v = std::atoi(e);
         if (v > 0) return std::min(v, 64);
     }
@@ -865,7 +927,7 @@ int pair_rows_per_wave(int rows, const char* env = "VAG_PAIR_RPW") {
 }
 int dyn_rows_per_wave(int rows) {
     (void)rows;
-    if (const char* e = std::getenv("VAG_DYN_RPW")) {
+    if (const char* e = vag_hook("VAG_DYN_RPW")) {
         const int v = std::atoi(e);
         if (v > 0) return std::min(v, 64);
     }
@@ -875,6 +937,7 @@ int dyn_rows_per_wave(int rows) {
 // Stage 1-3: adaptive grid -> blast-wave dynamics -> per-cell radiation, for nb models whose
 // parameters are already in HBM.  d_tminmax holds the observer-time extrema [s].
 int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool want_details) {
+    c->handoff_dirty = true;  // work is about to be queued on the context stream (ApiLock::~ApiLock)
     c->order_active = c->order_next;  // only a likelihood call that permuted its walkers sets order_next (vag_ctx::d_order)
     c->order_next = false;
     hipStream_t st = c->stream;
@@ -889,7 +952,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * ps) || c->d_rep_of.ensure(sizeof(int) * (size_t)nb * ts) ||
                c->d_rep_start.ensure(sizeof(int) * (size_t)nb * ts) || c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(large));
     };
-    if (std::getenv("VAG_GRID_FORCE_LARGE")) c->grid_large = true, c->grid_large_idle = 0;  // test hook: the large layout for batches that fit the small one
+    if (vag_hook("VAG_GRID_FORCE_LARGE")) c->grid_large = true, c->grid_large_idle = 0;  // test hook: the large layout for batches that fit the small one
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
@@ -902,7 +965,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     // (finish_speculation): no host wait in the middle of the pipeline at all.  Measured equal within 3 % in a sampler loop
     // (0.716 vs 0.715 ms per 128-walker call) and slower when calls are queued back to back without reading ln L
     // (0.775 vs 0.693 ms), because its flux launches are sized for the margin -- so waiting is the default.
-    static const bool plan_ahead = std::getenv("VAG_PLAN_AHEAD") != nullptr;
+    static const bool plan_ahead = vag_hook("VAG_PLAN_AHEAD") != nullptr;
     const bool spec = plan_ahead && c->allow_spec && !want_details && c->hint_valid && c->hint_nb == nb;
     int cap_rows = INT32_MAX, cap_k = INT32_MAX, cap_pairs = INT32_MAX;
     long long cap_cells = INT64_MAX;
@@ -960,7 +1023,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             c->grid_large = true;
             HIPCHK(hipStreamSynchronize(st));  // (the arrays are about to be re-allocated at the large stride; nothing may still write them)
             if (ensure_angular(true)) return VAG_E_HIP;
-            if (std::getenv("VAG_DEBUG_LAUNCH"))
+            if (vag_hook("VAG_DEBUG_LAUNCH"))
                 std::fprintf(stderr, "[vag] grid: %d of %d models over the small layout's capacity, laying the batch out again\n", hp->n_capacity, nb);
             launch_grid(true);
             HIPCHK(hipGetLastError());
@@ -1033,7 +1096,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), c->d_shock_r.as<double>(), cells,
                            c->d_inj.as<int>(), c->d_row_status.as<int>(), c->d_fail.as<int>(), c->d_phi.as<double>(),
                            c->d_tminmax.as<double>(), prw);
-    } else if (dyn_class == 0 && !std::getenv("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
+    } else if (dyn_class == 0 && !vag_hook("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
         const int rpw = dyn_rows_per_wave(rows);
         hipLaunchKernelGGL(c->count_work ? vag_dynamics_fast_kernel<true> : vag_dynamics_fast_kernel<false>, dim3((rows + rpw - 1) / rpw),
@@ -1075,7 +1138,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
 }
 
 int choose_pairs_per_block(const vag_ctx* c) {
-    if (const char* e = std::getenv("VAG_PAIRS_PER_BLOCK")) {  // tuning/debug override
+    if (const char* e = vag_hook("VAG_PAIRS_PER_BLOCK")) {  // tuning/debug override
         const int v = std::atoi(e);
         if (v > 0) return std::min(v, std::max(1, c->max_pairs));
     }
@@ -1094,7 +1157,7 @@ int choose_pairs_per_block(const vag_ctx* c) {
 // inside the kernels; VAG_FLUX_K_CAP is a test hook that makes ordinary models take that path.
 static int flux_ks(const vag_ctx* c) {
     int cap = 512;
-    if (const char* e = std::getenv("VAG_FLUX_K_CAP")) cap = std::max(4, std::atoi(e));
+    if (const char* e = vag_hook("VAG_FLUX_K_CAP")) cap = std::max(4, std::atoi(e));
     return std::max(2, std::min(c->max_k, cap));
 }
 
@@ -1141,7 +1204,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
     // MEASURED SLOWER on every such shape (C5 2.2 k vs 4.5 k light curves/s, C3 1.27 k vs 1.79 k, C1a 1.28 M vs 2.58 M: eight
     // points per lane cost the occupancy, and every lane walks its own bracket searches), so the workgroup kernel stays.
     if (slots <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !d_bandw && mode != FLUX_FUSED && !c->count_work &&
-        std::getenv("VAG_GRID_ROWWISE") && !(c->batch_flags & VAG_FLAG_SPREADING))
+        vag_hook("VAG_GRID_ROWWISE") && !(c->batch_flags & VAG_FLAG_SPREADING))
         return run_flux_series(c, d_params, nb, d_lg2t, d_lg2nu, slots, d_out, mode, nnu, nt);
     if (slots > FLUX_MAX_SLOTS)
         return set_err(VAG_E_CAPACITY, "nt*nnu = %d exceeds %d per launch", slots, FLUX_MAX_SLOTS);
@@ -1152,7 +1215,7 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
         if (mode != FLUX_FUSED && !(c->batch_flags & VAG_FLAG_SPREADING) && !c->count_work && slots <= GRIDROWS_MAX_SLOTS &&
             nnu <= GRIDROWS_BANDS && nt <= GRIDROWS_MAX_NT && blocks >= 4096 && c->total_pairs >= 128LL * nb && c->n_rows > 0 &&
-            !std::getenv("VAG_GRID_ROW_PER_WORKGROUP")) {
+            !vag_hook("VAG_GRID_ROW_PER_WORKGROUP")) {
             const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
             if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * slots)) return VAG_E_HIP;
             SeriesArgs a{};
@@ -1257,8 +1320,8 @@ int run_flux_grid(vag_ctx* c, const vag_model_params* d_params, int nb, const do
         // requests with few (nu, t) slots and short rows keep less than half of a 512-lane workgroup busy: use 256 lanes
         // (+47 % on the C5 / C1b shapes; a 128-lane variant measured slower)
         const bool small = !spreading && !a.work_count && (long long)nt * nnu <= 512 && (long long)ks * ((nnu + 1) / 2) <= 512 &&
-                           !std::getenv("VAG_FLUX_WIDE");
-        if (std::getenv("VAG_DEBUG_LAUNCH")) {
+                           !vag_hook("VAG_FLUX_WIDE");
+        if (vag_hook("VAG_DEBUG_LAUNCH")) {
             int occ = -1;
             if (small && mode == FLUX_SSC)
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_grid_kernel<false, FLUX_SSC, false, 256>, 256, lds);
@@ -1370,16 +1433,16 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
     if (c->n_rows > 0) {
         Layout lay{c->d_row_off.as<int>(), c->d_cell_off.as<long long>()};
         double narrow = 1.0;  // test hook: VAG_DEBUG_IC_NARROW=<factor> shrinks the clamp so that the flux pass breaches it
-        if (const char* e = std::getenv("VAG_DEBUG_IC_NARROW")) narrow = std::atof(e);
+        if (const char* e = vag_hook("VAG_DEBUG_IC_NARROW")) narrow = std::atof(e);
         // tables only for the cells some row's observation window touches (the reference builds a cell's spectrum on its first
         // query); VAG_IC_ALL_CELLS=1 builds every cell's table (developer aid: A/B timing, and the loud-fault test)
         unsigned char* d_need = nullptr;
         double need_shrink = 1.0;  // test hook: VAG_DEBUG_IC_NEED_SHRINK=<factor> cuts the window short, so that a flux pass meets a skipped cell
-        if (const char* e = std::getenv("VAG_DEBUG_IC_NEED_SHRINK")) need_shrink = std::atof(e);
+        if (const char* e = vag_hook("VAG_DEBUG_IC_NEED_SHRINK")) need_shrink = std::atof(e);
         // (A likelihood call keeps every table: there a model's SSC status folds into the walker's score -- ic_soft_fail, -inf -- so a cell
         // wrongly left without a table would be a silent wrong answer instead of VAG_E_INTERNAL; round 4's sweeps found two such holes
         // in the range test, both on grid requests, both loud.)
-        if (!std::getenv("VAG_IC_ALL_CELLS") && !c->ic_all_cells && c->d_tminmax.p && !c->ic_soft_fail) {
+        if (!vag_hook("VAG_IC_ALL_CELLS") && !c->ic_all_cells && c->d_tminmax.p && !c->ic_soft_fail) {
             if (c->d_icneed.ensure((size_t)std::max<long long>(c->n_cells, 1))) return VAG_E_HIP;
             HIPCHK(hipMemsetAsync(c->d_icneed.p, 0, (size_t)std::max<long long>(c->n_cells, 1), st));
             d_need = c->d_icneed.as<unsigned char>();
@@ -1403,13 +1466,15 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         // milliseconds of the build; a grid / series SSC pass ends with such a wait anyway, check_ic_status).  A LIKELIHOOD call has no
         // host wait anywhere in its SSC stage (its table status folds into the walker's score on the device), so it does not get one
         // here either: the pool is sized for the worst case -- every cell a table of IC_MAX_OUT nodes, plus a fixed reserve for the
-        // cells of the slow path -- once, the launch covers every cell and the kernels read the record counts from HBM.  (Beyond 32 GB
-        // of worst case the wait is taken after all.)
+        // cells of the slow path -- once, the launch covers every cell and the kernels read the record counts from HBM.  That worst case
+        // is ~1.5 KB per cell where the tables use ~0.5 KB, and the pool is grow-only and per context: beyond 4 GB of worst case (~2.7 M
+        // cells, e.g. 1500 walkers of the configs[3] grid) the wait is taken after all and the pool sized by what the plan handed out
+        // (32 GB until round 5 -- several contexts, or torch allocations next to one, could run out of HBM to save 20 us).
         constexpr unsigned long long SLOW_RESERVE_NO_WAIT = 8ull << 20;  // doubles (64 MB): ~2000 cells of twice the fast kernel's lattices
         const unsigned long long worst = (unsigned long long)std::max<long long>(c->n_cells, 1) * IC_MAX_OUT + 1024 + SLOW_RESERVE_NO_WAIT;
-        const bool no_wait = c->ic_soft_fail && worst * sizeof(double) <= (32ull << 30) && !std::getenv("VAG_IC_POOL_READBACK");
+        const bool no_wait = c->ic_soft_fail && worst * sizeof(double) <= (4ull << 30) && !vag_hook("VAG_IC_POOL_READBACK");
         int fast_nu_max = IC_MAX_NU;  // test hook: VAG_DEBUG_IC_FAST_NU_MAX=<n> sends the cells with longer seed lattices through the slow path (0: all)
-        if (const char* e = std::getenv("VAG_DEBUG_IC_FAST_NU_MAX")) fast_nu_max = std::min(std::atoi(e), IC_MAX_NU);
+        if (const char* e = vag_hook("VAG_DEBUG_IC_FAST_NU_MAX")) fast_nu_max = std::min(std::atoi(e), IC_MAX_NU);
         hipLaunchKernelGGL(vag_ic_plan_kernel, dim3((unsigned)((c->n_cells + 255) / 256)), dim3(256), 0, st, d_params, nb,
                            c->d_meta.as<VagGridMeta>(), lay, c->n_cells, c->d_celldet.as<double>(), c->d_band.as<double>(),
                            c->d_ichdr.as<double>(), c->d_icplan.as<double>(), c->d_icused.as<unsigned long long>(),
@@ -1437,7 +1502,7 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
         long long ic_waves = n_run;
 #if VAG_IC_PERSISTENT
         ic_waves = (long long)c->n_cus * 4 * VAG_IC_WAVES;
-        if (const char* e = std::getenv("VAG_IC_GRID")) ic_waves = std::max(1, std::atoi(e));  // developer aid
+        if (const char* e = vag_hook("VAG_IC_GRID")) ic_waves = std::max(1, std::atoi(e));  // developer aid
 #endif
         if (n_run > 0)
         hipLaunchKernelGGL(vag_ic_photon_kernel, dim3((unsigned)std::min<long long>(n_run, ic_waves)), dim3(64), 0, st,
@@ -1488,7 +1553,7 @@ int check_ic_status(vag_ctx* c, int nb) {
     }
     if (hole) {
         ++c->plan.n_ssc_all_cell_fallbacks;
-        if (std::getenv("VAG_DEBUG_IC_NO_FALLBACK"))  // test hook: the loud answer itself
+        if (vag_hook("VAG_DEBUG_IC_NO_FALLBACK"))  // test hook: the loud answer itself
             return set_err(VAG_E_INTERNAL, "a flux pass queried an SSC cell that was given no table (fallback disabled)");
         return VAG_IC_REBUILD_ALL;
     }
@@ -1540,14 +1605,14 @@ int run_flux_ssc(vag_ctx* c, const vag_model_params* d_params, int nb, const dou
 // spectra ride the same EAT logs, bracket search and barriers (the two-pass form pays that row skeleton twice -- 35-45 %
 // of a pass on the C5 / C3 shapes).  Falls back to two passes when the doubled buffers would not fit in LDS twice.
 static bool fused_fits(vag_ctx* c, int nt, int nnu) {
-    if (std::getenv("VAG_NO_FUSED")) return false;
-    if (std::getenv("VAG_GRID_ROWWISE") && nt * nnu <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !c->count_work)
+    if (vag_hook("VAG_NO_FUSED")) return false;
+    if (vag_hook("VAG_GRID_ROWWISE") && nt * nnu <= SERIES_THREADS * SERIES_MAX_SLOTS && nnu <= SERIES_MAX_BANDS && !c->count_work)
         return false;  // experiment switch of run_flux_grid: two passes of the wavefront-per-row kernel
     // the second set of buffers must not cost a resident workgroup: on the C5 / C3 shapes it does (63 vs 51 KB: two
     // workgroups per CU instead of three) and the fused pass measured 18 % SLOWER than two passes there
     const size_t cu = 160 * 1024, fused = flux_grid_lds_bytes(FLUX_FUSED, flux_ks(c), nt, nnu),
                  two = flux_grid_lds_bytes(FLUX_SYN_IC, flux_ks(c), nt, nnu);
-    if (std::getenv("VAG_FORCE_FUSED")) return fused <= cu;
+    if (vag_hook("VAG_FORCE_FUSED")) return fused <= cu;
     return fused <= cu && std::min<size_t>(cu / fused, 4) >= std::min<size_t>(cu / two, 4);
 }
 int run_flux_fused(vag_ctx* c, const vag_model_params* d_params, int nb, const double* d_lg2t, int nt, const double* d_lg2nu,
@@ -1752,7 +1817,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         return set_err(VAG_E_CAPACITY, "series length %d exceeds %d", n, SERIES_THREADS * SERIES_MAX_SLOTS);
     // A fit's shape (plain synchrotron, <= 64 points in a few bands): the row-per-lane kernel (vag_fit_rows.h)
     if (mode != FLUX_FUSED && grid_nt == 0 && n <= FITROWS_MAX_POINTS && n_bands > 0 &&
-        n_bands <= FITROWS_BANDS && !std::getenv("VAG_SERIES_ROW_PER_WAVE")) {
+        n_bands <= FITROWS_BANDS && !vag_hook("VAG_SERIES_ROW_PER_WAVE")) {
         const int max_blocks = std::max(1, (c->max_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS);
         if (c->d_partial.ensure(sizeof(double) * (size_t)nb * max_blocks * FITROWS_SEGS * n)) return VAG_E_HIP;
         SeriesArgs a{};
@@ -1779,8 +1844,10 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         a.ichdr = c->d_ichdr.as<double>();
         a.icpool = c->d_icpool.as<double>();
         a.ic_status = c->d_icstatus.as<int>();
-        c->plan.spec_evals = 2 * c->total_pairs * (long long)n;
-        c->plan.interps = c->total_pairs * (long long)n;
+        // (+=: a call with several series passes or chunks reports all of them; the plan is reset by the model stage of the call)
+        const long long upper_evals = 2 * c->total_pairs * (long long)n, upper_interps = c->total_pairs * (long long)n;
+        c->plan.spec_evals += upper_evals;
+        c->plan.interps += upper_interps;
         c->plan.flux_blocks = max_blocks * nb;
         c->plan.pairs_per_block = FITROWS_ROWS;
         if (c->n_rows > 0) {
@@ -1788,7 +1855,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
             // one when there are blocks enough to fill it (one prologue per block).  The partial sums are the same either way.
             const long long blocks = (c->total_pairs + FITROWS_ROWS - 1) / FITROWS_ROWS;
             int wpb = blocks <= 1024 ? 4 : (blocks <= 4608 ? 2 : 1);  // measured (persistent launch, 4 / 2 / 1): 0.8 k blocks 0.072 / 0.088 / 0.140 ms, 1.6 k 0.115 / 0.105 / 0.142, 6.2 k 0.333 / 0.267 / 0.269
-            if (const char* e = std::getenv("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
+            if (const char* e = vag_hook("VAG_FIT_WAVES_PER_BLOCK")) wpb = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 2 ? 2 : 1);
             a.grid_nt = wpb;
             a.nb = nb;
             a.work = work_counters(c);
@@ -1810,8 +1877,8 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
                 unsigned long long hcount[2] = {0, 0};
                 HIPCHK(hipMemcpyAsync(hcount, c->d_workcount.p, sizeof hcount, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                c->plan.spec_evals = (long long)hcount[0];
-                c->plan.interps = (long long)hcount[1];
+                c->plan.spec_evals += (long long)hcount[0] - upper_evals;  // the tallied counts replace this pass's upper bounds
+                c->plan.interps += (long long)hcount[1] - upper_interps;
             } else
 #define VAG_FIT_LAUNCH(M_)                                                                      \
     do {                                                                                        \
@@ -1847,7 +1914,7 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
     // scores the same bits alone, in a block of 64, or among 1024).
     long long ppb = std::max<long long>(SERIES_CHUNK, (c->total_pairs + 32767) / 32768);
     ppb = (ppb + SERIES_CHUNK - 1) / SERIES_CHUNK * SERIES_CHUNK;
-    if (const char* e = std::getenv("VAG_SERIES_PPB")) ppb = std::max(1, std::atoi(e)) * SERIES_CHUNK;  // tuning override (in chunks)
+    if (const char* e = vag_hook("VAG_SERIES_PPB")) ppb = std::max(1, std::atoi(e)) * SERIES_CHUNK;  // tuning override (in chunks)
     const int max_blocks = std::max(1, (int)((c->max_pairs + ppb - 1) / ppb));
     // a small (nu, t) grid served by this kernel keeps one partial per wavefront (its 128 x 128 rows would need thousands of
     // 8-row chunks per model); a grid request makes no batch-independence promise, as the workgroup kernel does not either
@@ -1869,11 +1936,11 @@ int run_flux_series(vag_ctx* c, const vag_model_params* d_params, int nb, const 
         const int resident = std::min(series_wg_per_cu(c, w, lds_for(w)) * w, 16);
         if (resident >= best) best = resident, waves = w;
     }
-    if (const char* e = std::getenv("VAG_SERIES_WAVES")) waves = std::max(1, std::min(SERIES_WAVES, std::atoi(e)));
+    if (const char* e = vag_hook("VAG_SERIES_WAVES")) waves = std::max(1, std::min(SERIES_WAVES, std::atoi(e)));
     const size_t lds = lds_for(waves);
     if (lds > 160 * 1024) return set_err(VAG_E_CAPACITY, "LDS request %zu B exceeds 160 KiB (n_t=%d)", lds, ks);
     const dim3 sgrid((max_blocks + waves - 1) / waves, nb), sblock(SERIES_THREADS * waves);
-    if (std::getenv("VAG_DEBUG_LAUNCH")) {
+    if (vag_hook("VAG_DEBUG_LAUNCH")) {
         int occ = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vag_flux_series_kernel<FLUX_SYN, false, 1>, SERIES_THREADS * waves, lds);
         std::fprintf(stderr, "[vag] series launch: n=%d bands=%d max_k=%d rows/wave=%lld waves/wg=%d lds=%zu B grid=(%u,%u) wg/CU=%d\n", n,
@@ -2070,7 +2137,7 @@ int finish_speculation(vag_ctx* c) {
     if (int rcw = wait_plan(c)) return rcw;  // the grid stage finished long ago: the later stages keep running behind this check
     const int flags = hp->flags_first < 0 ? 0 : hp->flags_first, hflags = c->hint.flags_first < 0 ? 0 : c->hint.flags_first;
     if (hp->overflow || hp->flags_mixed || (hp->n_ok > 0 && (flags != hflags || hp->dyn_class != c->hint.dyn_class))) {
-        if (std::getenv("VAG_DEBUG_SPEC"))
+        if (vag_hook("VAG_DEBUG_SPEC"))
             std::fprintf(stderr, "[vag] planned-ahead call repeated: overflow %d mixed %d flags %d/%d dyn %d/%d rows %d cells %lld max_k %d (cap %d) max_pairs %d; hint rows %d cells %lld max_k %d max_pairs %d\n",
                          hp->overflow, hp->flags_mixed, flags, hflags, hp->dyn_class, c->hint.dyn_class, hp->rows, (long long)hp->cells,
                          hp->max_k, c->spec_cap_k, hp->max_pairs, c->hint.rows, (long long)c->hint.cells, c->hint.max_k, c->hint.max_pairs);
@@ -2249,7 +2316,7 @@ static int grid_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb, c
             if (!c->spec_pending) return rc;
             c->spec_pending = false;  // an error while planning from stale sizes is not the caller's: repeat on the waiting path
             c->hint_valid = false;
-            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead grid call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            if (vag_hook("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead grid call failed (%d: %s): repeating\n", rc, g_err.c_str());
             continue;
         }
         rc = finish_speculation(c);
@@ -2313,7 +2380,7 @@ static int series_dev_body(vag_ctx* c, const vag_model_params* d_params, int nb,
             if (!c->spec_pending) return rc;
             c->spec_pending = false;
             c->hint_valid = false;
-            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead series call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            if (vag_hook("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead series call failed (%d: %s): repeating\n", rc, g_err.c_str());
             continue;
         }
         rc = finish_speculation(c);
@@ -2913,7 +2980,7 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
     const double* d_prior = d + c->fit_prior_off;
     vag_model_params* d_params = c->d_params.as<vag_model_params>();
     // evaluation order: by the costs of the previous call with this batch size (see vag_ctx::d_order)
-    const bool can_order = nb >= 64 && nb <= 8192 && !std::getenv("VAG_NO_ORDER");
+    const bool can_order = nb >= 64 && nb <= 8192 && !vag_hook("VAG_NO_ORDER");
     const int* d_order = (can_order && c->order_nb == nb) ? c->d_order[c->order_cur].as<int>() : nullptr;
     hipLaunchKernelGGL(vag_fit_front_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, spec->base, d_theta, nb, ndim, d_prior,
                        spec->use_priors, spec->a_v_fixed, d_params, d_av, d_lp, c->d_fitstat.as<int>(), d, n, d + n,
@@ -2962,7 +3029,7 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
             n_cap = std::max(n_cap, c->plan.n_models_capacity);
             n_inv = std::max(n_inv, c->plan.n_models_invalid);
         } else if (c->spec_pending) {  // an error while planning from stale sizes: repeat the call on the waiting path
-            if (std::getenv("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead likelihood call failed (%d: %s): repeating\n", rc, g_err.c_str());
+            if (vag_hook("VAG_DEBUG_SPEC")) std::fprintf(stderr, "[vag] planned-ahead likelihood call failed (%d: %s): repeating\n", rc, g_err.c_str());
             c->spec_pending = false;
             c->hint_valid = false;
             rc = VAG_RETRY;
@@ -3098,10 +3165,8 @@ vag_shard_finish_kernel(const double* __restrict__ gathered, const int* __restri
     }
 }
 
-int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
-                          double* d_block) {
-    ApiLock api_lock(c);
-    HandoffScope handoff(c);
+static int shard_begin(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
+                       double* d_block, uint64_t* ticket) {
     if (!c || !spec || !d_theta_all || !d_block) return set_err(VAG_E_INVALID, "null context, spec or buffer");
     if (nb_all <= 0) return set_err(VAG_E_INVALID, "batch must be non-empty");
     if (world <= 0 || rank < 0 || rank >= world) return set_err(VAG_E_INVALID, "rank %d outside a world of %d", rank, world);
@@ -3125,11 +3190,18 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     for (int i = 0; i < 4; ++i) {
         const vag_ctx::ShardCosts& e = c->shard_costs[i];
         if (e.nb == nb_all && e.world == world && e.hash == c->fit_hash) entry = i;
-        if (!e.pending && (victim < 0 || e.used < c->shard_costs[victim].used)) victim = i;
+        if (e.in_flight == 0 && (victim < 0 || e.used < c->shard_costs[victim].used)) victim = i;
     }
-    // (a key that is dealt again before its finish is simply dealt anew: the earlier block never went through a finish)
+    int slot = -1;  // a free flight slot, the least recently dealt one
+    for (int i = 0; i < 8; ++i)
+        if (!c->shard_flights[i].in_use && (slot < 0 || c->shard_flights[i].ticket < c->shard_flights[slot].ticket)) slot = i;
+    // the unticketed form deals a key anew when it is dealt again before its finish (the earlier block never goes through a finish)
+    bool replaces = false;
+    for (int i = 0; i < 8 && !ticket && entry >= 0; ++i)
+        if (c->shard_flights[i].in_use && c->shard_flights[i].unticketed && c->shard_flights[i].key == entry) slot = i, replaces = true;
+    if (slot < 0) return set_err(VAG_E_INVALID, "eight sharded calls wait for their finish on this context");
     if (entry < 0) {
-        if (victim < 0) return set_err(VAG_E_INVALID, "four sharded calls wait for their finish on this context");
+        if (victim < 0) return set_err(VAG_E_INVALID, "sharded calls of four other fits wait for their finish on this context");
         entry = victim;
         c->shard_costs[entry].nb = nb_all;
         c->shard_costs[entry].world = world;
@@ -3140,21 +3212,24 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     // ranking by counting is O(nb_all^2 / 64) per call: beyond 16384 walkers the deal stays by position (equal counts)
     const bool ranked = c->shard_costs[entry].valid && nb_all <= 16384;
     c->shard_costs[entry].used = ++c->shard_clock;
+    vag_ctx::ShardFlight& fl = c->shard_flights[slot];
     if (c->shard_costs[entry].cost.ensure(sizeof(double) * (size_t)nb_all)) return VAG_E_HIP;
-    if (c->shard_costs[entry].table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
+    if (fl.table.ensure(sizeof(int) * (size_t)world * per)) return VAG_E_HIP;
     hipLaunchKernelGGL(vag_shard_deal_kernel, dim3((world * per + 3) / 4), dim3(256), 0, c->stream,
                        ranked ? c->shard_costs[entry].cost.as<double>() : nullptr, d_theta_all, nb_all, ndim, rank, world, per,
-                       c->shard_costs[entry].table.as<int>(), c->d_shard_theta.as<double>());
+                       fl.table.as<int>(), c->d_shard_theta.as<double>());
     HIPCHK(hipGetLastError());
-    c->shard_costs[entry].pending = true;
-    c->shard_costs[entry].dealt = c->shard_clock;
-    c->shard_last_dealt = entry;
+    fl.ticket = c->shard_clock;
+    fl.key = entry;
+    fl.nb = nb_all;
+    fl.world = world;
+    c->shard_last_dealt = slot;  // (kept for inspection even if the evaluation below fails)
     const int* d_order = nullptr;
     if (n_mine > 0) {
         int rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), !c->count_work);
         if (rc == VAG_RETRY) rc = loglike_body(c, spec, c->d_shard_theta.as<double>(), n_mine, ndim, c->d_shard_ll.as<double>(), false);
-        if (rc) {
-            c->shard_costs[entry].pending = false;  // (no block went out: there is nothing to finish)
+        if (rc) {  // (no block went out: there is nothing to finish, the slot is free)
+            if (replaces) fl.in_use = false, --c->shard_costs[entry].in_flight;
             return rc;
         }
         d_order = c->order_active ? c->last_order : nullptr;
@@ -3162,31 +3237,77 @@ int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_
     hipLaunchKernelGGL(vag_shard_pack_kernel, dim3((per + 127) / 128), dim3(128), 0, c->stream, c->d_shard_ll.as<double>(),
                        c->d_meta.as<VagGridMeta>(), d_order, n_mine, per, d_block);
     HIPCHK(hipGetLastError());
+    fl.in_use = true;
+    fl.unticketed = !ticket;
+    if (!replaces) ++c->shard_costs[entry].in_flight;
+    if (ticket) *ticket = fl.ticket;
     return VAG_OK;
+}
+
+// ticket 0: the oldest call in flight of this shape (the v9 form; right when calls of equal shape finish in the order of their deals)
+static int shard_end(vag_ctx* c, uint64_t ticket, const double* d_gathered, int nb_all, int world, double* d_out) {
+    if (!c) return set_err(VAG_E_INVALID, "null context");
+    const bool abandon = ticket && !d_gathered && !d_out;  // the caller's collective failed: release the call, keep the costs as they are
+    if (!abandon && (!d_gathered || !d_out)) return set_err(VAG_E_INVALID, "null context or buffer");
+    int slot = -1;
+    for (int i = 0; i < 8 && nb_all > 0; ++i) {
+        const vag_ctx::ShardFlight& f = c->shard_flights[i];
+        if (!f.in_use) continue;
+        if (ticket ? f.ticket == ticket : (f.nb == nb_all && f.world == world && (slot < 0 || f.ticket < c->shard_flights[slot].ticket))) slot = i;
+    }
+    if (slot < 0) {
+        if (ticket) return set_err(VAG_E_INVALID, "no sharded call with ticket %llu is waiting for its finish", (unsigned long long)ticket);
+        return set_err(VAG_E_INVALID, "no vag_loglike_shard_dev call of %d walkers over %d ranks is waiting for its finish", nb_all, world);
+    }
+    vag_ctx::ShardFlight& fl = c->shard_flights[slot];
+    if (fl.nb != nb_all || fl.world != world)
+        return set_err(VAG_E_INVALID, "ticket %llu was dealt for %d walkers over %d ranks, not %d over %d", (unsigned long long)ticket, fl.nb, fl.world,
+                       nb_all, world);
+    vag_ctx::ShardCosts& key = c->shard_costs[fl.key];
+    if (abandon) {
+        --key.in_flight;
+        fl.in_use = false;
+        return VAG_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int per = (nb_all + world - 1) / world;
+    hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, fl.table.as<int>(), world * per, d_out,
+                       key.cost.as<double>());
+    HIPCHK(hipGetLastError());
+    key.valid = true;
+    --key.in_flight;
+    fl.in_use = false;
+    c->shard_last = fl.key;
+    return VAG_OK;
+}
+
+int vag_loglike_shard_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
+                          double* d_block) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
+    return shard_begin(c, spec, d_theta_all, nb_all, ndim, rank, world, d_block, nullptr);
 }
 
 int vag_loglike_shard_finish_dev(vag_ctx* c, const double* d_gathered, int nb_all, int world, double* d_out) {
     ApiLock api_lock(c);
     HandoffScope handoff(c);
-    if (!c || !d_gathered || !d_out) return set_err(VAG_E_INVALID, "null context or buffer");
-    // the oldest pending deal of this shape: calls of equal shape finish in the order they were dealt (their all-gathers must run in one
-    // order on every rank anyway)
-    int entry = -1;
-    for (int i = 0; i < 4 && nb_all > 0; ++i) {
-        const vag_ctx::ShardCosts& e = c->shard_costs[i];
-        if (e.pending && e.nb == nb_all && e.world == world && (entry < 0 || e.dealt < c->shard_costs[entry].dealt)) entry = i;
-    }
-    if (entry < 0)
-        return set_err(VAG_E_INVALID, "no vag_loglike_shard_dev call of %d walkers over %d ranks is waiting for its finish", nb_all, world);
-    HIPCHK(hipSetDevice(c->device));
-    const int per = (nb_all + world - 1) / world;
-    hipLaunchKernelGGL(vag_shard_finish_kernel, dim3(1), dim3(1024), 0, c->stream, d_gathered, c->shard_costs[entry].table.as<int>(), world * per,
-                       d_out, c->shard_costs[entry].cost.as<double>());
-    HIPCHK(hipGetLastError());
-    c->shard_costs[entry].valid = true;
-    c->shard_costs[entry].pending = false;
-    c->shard_last = entry;
-    return VAG_OK;
+    return shard_end(c, 0, d_gathered, nb_all, world, d_out);
+}
+
+int vag_loglike_shard_begin_dev(vag_ctx* c, const vag_fit_spec* spec, const double* d_theta_all, int nb_all, int ndim, int rank, int world,
+                                double* d_block, uint64_t* ticket) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
+    if (!ticket) return set_err(VAG_E_INVALID, "null ticket");
+    *ticket = 0;
+    return shard_begin(c, spec, d_theta_all, nb_all, ndim, rank, world, d_block, ticket);
+}
+
+int vag_loglike_shard_end_dev(vag_ctx* c, uint64_t ticket, const double* d_gathered, int nb_all, int world, double* d_out) {
+    ApiLock api_lock(c);
+    HandoffScope handoff(c);
+    if (!ticket) return set_err(VAG_E_INVALID, "ticket 0 names no call");
+    return shard_end(c, ticket, d_gathered, nb_all, world, d_out);
 }
 
 int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_table, double* d_cost) {
@@ -3195,12 +3316,12 @@ int vag_loglike_shard_state_dev(vag_ctx* c, int nb_all, int world, int32_t* d_ta
     if (!c) return set_err(VAG_E_INVALID, "null context");
     const int per = world > 0 ? (nb_all + world - 1) / world : 0;
     const int ld = c->shard_last_dealt;
-    if (nb_all <= 0 || world <= 0 || ld < 0 || c->shard_costs[ld].nb != nb_all || c->shard_costs[ld].world != world ||
-        c->shard_costs[ld].table.cap < sizeof(int) * (size_t)world * per)
+    if (nb_all <= 0 || world <= 0 || ld < 0 || c->shard_flights[ld].nb != nb_all || c->shard_flights[ld].world != world ||
+        c->shard_flights[ld].table.cap < sizeof(int) * (size_t)world * per)
         return set_err(VAG_E_INVALID, "no deal of %d walkers over %d ranks on this context", nb_all, world);
     HIPCHK(hipSetDevice(c->device));
     if (d_table)
-        HIPCHK(hipMemcpyAsync(d_table, c->shard_costs[ld].table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_table, c->shard_flights[ld].table.p, sizeof(int) * (size_t)world * per, hipMemcpyDeviceToDevice, c->stream));
     if (d_cost) {
         if (c->shard_last < 0 || !c->shard_costs[c->shard_last].valid || c->shard_costs[c->shard_last].nb != nb_all || c->shard_costs[c->shard_last].world != world)
             return set_err(VAG_E_INVALID, "no finished sharded call of %d walkers over %d ranks on this context", nb_all, world);
@@ -3277,7 +3398,7 @@ static void coalesce_serve(vag_ctx* c, std::vector<CoalesceRequest*>& batch) {
     CoalesceRequest& lead = *batch[0];
     const size_t len = lead.out_len();
     bool ok = false;
-    if (nb > 1) {
+    if (nb > 1) try {
         std::vector<vag_model_params> params(nb);
         for (int i = 0; i < nb; ++i) params[i] = *batch[i]->p;
         const bool comps = (lead.kind & 4) != 0;
@@ -3305,6 +3426,10 @@ static void coalesce_serve(vag_ctx* c, std::vector<CoalesceRequest*>& batch) {
             }
             ok = true;
         }
+    } catch (const std::exception&) {
+        // the staging buffers could not be allocated: no exception crosses the C ABI -- the members are served one by one below,
+        // straight into their own buffers (that path allocates nothing on the host)
+        ok = false;
     }
     if (!ok)  // alone, or the batch failed as a whole: every member on its own, with its own error
         for (int i = 0; i < nb; ++i) {
@@ -3436,7 +3561,7 @@ static int details_impl(vag_ctx* c, const vag_model_params* params, double t_min
     shape->phi_mirrored = M.phi_mirrored;
     if (!out) return VAG_OK;
     const int nth = M.n_theta, nt = M.n_t;
-    if (std::getenv("VAG_DEBUG_ROWS")) {  // developer aid: ODE status (and injection cutoff) per representative row
+    if (vag_hook("VAG_DEBUG_ROWS")) {  // developer aid: ODE status (and injection cutoff) per representative row
         std::vector<int> st(c->n_rows), inj(c->n_rows, -1);
         HIPCHK(hipMemcpy(st.data(), c->d_row_status.p, sizeof(int) * c->n_rows, hipMemcpyDeviceToHost));
         if (params->flags & VAG_FLAG_RVS) HIPCHK(hipMemcpy(inj.data(), c->d_inj.p, sizeof(int) * c->n_rows, hipMemcpyDeviceToHost));

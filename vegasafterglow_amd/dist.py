@@ -135,13 +135,13 @@ class WalkerSharder:
         if self.native is not None:
             # The context's lock is held inside shard() and inside finish(), NOT across the collective: a process-local lock held
             # while waiting for other ranks can deadlock two sharders that take it in different orders on different ranks.  The
-            # engine keeps the deal of a call in flight per (batch size, world, spec), so another sharder of this process may deal
-            # on the same context in between (ABI v11).
+            # engine keeps the deal of every call in flight under a ticket (ABI v13), so another sharder of this process may deal --
+            # and finish, in any order -- on the same context in between.
             with self.native.lock:
-                self.native.shard(theta.contiguous(), nb, rank, world, d.block)
+                ticket = self.native.shard(theta.contiguous(), nb, rank, world, d.block)
             dist.all_gather_into_tensor(d.gathered, d.block, group=self.group)  # the path's only collective: 16 B per walker
             with self.native.lock:
-                self.native.finish(d.gathered, nb, world, out)
+                self.native.finish(ticket, d.gathered, nb, world, out)
             return out
         if self._costs is None or self._costs.shape[0] != nb:
             self._costs = torch.ones((nb,), dtype=torch.float64, device=self.device)

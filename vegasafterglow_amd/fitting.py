@@ -516,18 +516,21 @@ class Fitter:
 
         class _Native:
             """The engine's own sharded call for dist.WalkerSharder: deal + this rank's block, then the scatter after the
-            all-gather (vag_loglike_shard_dev / vag_loglike_shard_finish_dev); no host work besides the launches."""
+            all-gather (vag_loglike_shard_begin_dev / vag_loglike_shard_end_dev); no host work besides the launches."""
             parts = (lib, h, lock, keep)
             check = staticmethod(_lib.check)
 
             @staticmethod
             def shard(theta_all, nb, rank, world, block):
-                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_dev(
-                    h, C.byref(keep[0]), theta_all.data_ptr(), nb, keep[0].ndim, rank, world, block.data_ptr())))
+                """Returns the ticket that names this call in flight; finish() takes it (ABI v13)."""
+                ticket = C.c_uint64(0)
+                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_begin_dev(
+                    h, C.byref(keep[0]), theta_all.data_ptr(), nb, keep[0].ndim, rank, world, block.data_ptr(), C.byref(ticket))))
+                return ticket.value
 
             @staticmethod
-            def finish(gathered, nb, world, out):
-                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_finish_dev(h, gathered.data_ptr(), nb, world, out.data_ptr())))
+            def finish(ticket, gathered, nb, world, out):
+                _on_current_stream(lambda: _lib.check(lib.vag_loglike_shard_end_dev(h, ticket, gathered.data_ptr(), nb, world, out.data_ptr())))
 
             @staticmethod
             def state(nb, world, per):
