@@ -489,6 +489,9 @@ def walker_bench(lib, h, _lib, dev, rank, world, steps=10, nwalkers=1024, sharde
         res["roofline_fp64"] = {
             "bound": "fp64_valu", "unit": "TFLOP/s", "peak": PEAK_FP64_TFLOPS,
             "spec_evals": plan.spec_evals, "interps": plan.interps, "ode_rhs": plan.ode_rhs, "ode_rows": plan.n_rows,
+            # live lanes over the ODE solver's step attempts / the lane slots those attempts occupied (a wavefront of the plain kernel runs
+            # until its slowest row is done; the refill kernel of large batches takes new rows into finished lanes)
+            "ode_lane_utilisation": plan.ode_lane_attempts / max(plan.ode_lane_slots, 1),
             "flop_eq_per_walker": (f_flux + f_ode) / nwalkers,
             "achieved": tf(f_flux + f_ode, 1e3 * dt / steps), "frac": tf(f_flux + f_ode, 1e3 * dt / steps) / PEAK_FP64_TFLOPS,
             "note": "whole step (grid, ODE, cells, flux, chi^2 and the host's read of ln L) against the flux + ODE work",
@@ -625,6 +628,8 @@ def compact_line(detail, detail_file=None):
         "vs_reference_1_core": detail.get("vs_reference_1_core_same_box"), "vs_reference_all_cores": detail.get("vs_reference_all_cores_same_box"),
         "walker_steps_per_s": _dig(detail, "walker_steps", "value"), "walker_steps_fp64_frac": _dig(detail, "walker_steps", "roofline_fp64", "frac"),
         "walker_steps_8192_per_s": _dig(detail, "walker_steps_8192_total", "value"),
+        "walker_8192_ode_ms": _dig(detail, "walker_steps_8192_total", "rank0_stage_ms", "dynamics"),
+        "walker_8192_ode_lane_util": _dig(detail, "walker_steps_8192_total", "roofline_fp64", "ode_lane_utilisation"),
         "walker_cpu_1_core_per_s": _dig(detail, "walker_steps", "cpu_baseline", "value"),
         "c1a_batched_vs_all_cores": _dig(detail, "tophat_config0", "C1a_onaxis", "speedup_vs_reference", "batched_vs_all_cores"),
         "c1a_single_call_vs_1_core": _dig(detail, "tophat_config0", "C1a_onaxis", "speedup_vs_reference", "single_call_vs_1_core"),
@@ -783,7 +788,7 @@ def main():
     # 8192-walker ensemble over all ranks (what a nested sampler's live-point pool or a large emcee ensemble hands over)
     # Both run at EVERY N, N = 1 included: the driver computes scaling from the per-N lines, so each curve needs its origin.
     walkers_weak = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=1024 * world) if extra else None
-    walkers_8192 = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=8192, steps=5) if extra else None
+    walkers_8192 = walker_bench(lib, h, _lib, dev, rank, world, nwalkers=8192, steps=5, tally=True) if extra else None
     # configs[4] ("sharded 8xMI355X") at its full 4096 members through dist.sharded_flux_density_grid, at every N as well
     ensemble_c5 = ensemble_c5_sharded(lib, h, _lib, dev, world) if extra else None
     shares = sharded1 = None

@@ -501,6 +501,10 @@ typedef struct vag_plan {
      * frequencies, 64 electron energies or 192 output nodes) and took the general kernel with its arrays in HBM -- same algorithm, same
      * table.  A likelihood call does not wait for the count: vag_last_plan reads it then, for the call's last table build only */
     int64_t n_ssc_slow_cells;
+    /* ABI v13, with vag_ctx_count_work(1): lane utilisation of the forward-shock solver's attempt loop -- live lanes summed over the
+     * step attempts of every wavefront / lane slots those attempts occupied (64 per attempt).  A wavefront runs until its slowest row
+     * is done (forward-shock.tpp:194-207 loops over rows one by one); the persistent kernel refills finished lanes from a row queue. */
+    int64_t ode_lane_attempts, ode_lane_slots;
 } vag_plan;
 int vag_last_plan(vag_ctx* ctx, vag_plan* out); /* synchronises the stream to read the ODE row counters */
 /* Instrumentation: when enabled, grid-flux launches tally the exact spec_evals / interps (window-clamped) with

@@ -50,8 +50,10 @@ def test_struct_layouts_match_the_header():
     v6 = 272 + 4 + 64 + 64 + 8 + 5 * 8 + 4 + 8 + 8 + 8 + 8  # ... + ext_kernel, a_v_fixed, n_bands+pad, bands
     assert _lib.FitSpec.use_priors.offset == v6  # ABI v7 appends: use_priors+pad, lower, upper, prior_kind, prior_a, prior_b
     assert C.sizeof(_lib.FitSpec) == v6 + 8 + 128 + 128 + 64 + 128 + 128
-    # ABI v8 appends n_models_ssc_rebuilt + pad (v11: the pad is n_ssc_all_cell_fallbacks), v10 ic_pool_bytes, v11 ode_rhs, v12 n_ssc_slow_cells
-    assert C.sizeof(_lib.Plan) == 4 + 4 + 5 * 8 + 6 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 8
+    # ABI v8 appends n_models_ssc_rebuilt + pad (v11: the pad is n_ssc_all_cell_fallbacks), v10 ic_pool_bytes, v11 ode_rhs, v12 n_ssc_slow_cells,
+    # v13 ode_lane_attempts + ode_lane_slots
+    assert C.sizeof(_lib.Plan) == 4 + 4 + 5 * 8 + 6 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 8 + 16
+    assert _lib.Plan.ode_lane_slots.offset == _lib.Plan.n_ssc_slow_cells.offset + 16
     assert _lib.Plan.n_ssc_all_cell_fallbacks.offset == _lib.Plan.n_models_ssc_rebuilt.offset + 4
     assert _lib.Plan.ode_rhs.offset == _lib.Plan.ic_pool_bytes.offset + 8
     assert _lib.Plan.n_ssc_slow_cells.offset == _lib.Plan.ode_rhs.offset + 8

@@ -995,6 +995,77 @@ def test_fast_and_general_ode_kernels_agree_on_random_walkers(eng):
         assert np.max(np.abs(fast - general)[sel] / fast[sel]) <= 1e-10, n
 
 
+def test_lane_refill_ode_kernel_gives_the_bits_of_the_plain_kernel(eng):
+    """Round 6 ("persistent-lane work queue"): batches that fill the GPU's integrator slots twice over are integrated by
+    vag_dynamics_refill_kernel -- persistent wavefronts whose finished lanes take the next row from a device counter and which evaluate the
+    dense output inline (two integrators per SIMD instead of an integrator and its saver), every row's start prepared beforehand by
+    vag_dyn_prep_kernel -- instead of one wavefront per 64 rows that runs until its slowest row is done.  Rows are
+    independent and the arithmetic is the plain kernel's, expression for expression: the fluxes of 300 random walkers (ISM and wind
+    media mixed in one batch, narrow jets whose wings stop, one invalid model) are the SAME BITS whichever kernel runs and however
+    many finished lanes a wavefront collects before it refills (1, 8, 64); the solver's own tallies agree too (right-hand sides equal,
+    row failures equal), and the refill kernel's lanes are busier."""
+    rng = np.random.default_rng(66)
+    t, nu = np.logspace(4.0, 8, 40), np.array([3e9, 5.06e14, 2.41e17])
+    prms = []
+    for i in range(300):
+        kw = dict(configs.C4_TRUTH, jet="GaussianJet" if i % 3 else "PowerLawJet")
+        kw.update(E_iso=10 ** rng.uniform(50, 54), Gamma0=10 ** rng.uniform(0.5 if i % 3 == 0 else 1.5, 3), theta_c=rng.uniform(0.02, 0.3),
+                  theta_obs=rng.uniform(0, 0.8), p=rng.uniform(2.05, 2.8), eps_e=10 ** rng.uniform(-3, -0.5), eps_B=10 ** rng.uniform(-5, -1))
+        if i % 4 == 1:
+            kw.update(medium="Wind", A_star=10 ** rng.uniform(-2, 0.5), n_ism=0.0)
+        else:
+            kw.update(n_ism=10 ** rng.uniform(-4, 1))
+        if i % 7 == 3:
+            kw["radiative_fireball"] = False
+        prms.append(_abi.make_params(**kw))
+    prms[17].eps_e = 2.0  # rejected by validation: its rows do not exist
+    lib, h = eng
+    import torch
+    dev = torch.device("cuda", 0)
+    arr = (_lib.ModelParams * len(prms))(*[_lib.ModelParams.from_buffer_copy(bytes(p)) for p in prms])
+    d_p = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    d_t, d_nu = torch.from_numpy(t).to(dev), torch.from_numpy(nu).to(dev)
+
+    def gpu_grid_dev():  # (the device-pointer form reports an invalid model as a NaN row instead of failing the call)
+        d_o = torch.full((len(prms), nu.size, t.size), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(lib.vag_flux_density_grid_batch_dev(h, d_p.data_ptr(), len(prms), d_t.data_ptr(), t.size, d_nu.data_ptr(), nu.size, d_o.data_ptr()))
+        _lib.check(lib.vag_ctx_synchronize(h))
+        return d_o.cpu().numpy()
+
+    def run(refill, refill_min=None):
+        _lib.hooks["VAG_DYN_REFILL"] = refill
+        if refill_min is not None:
+            _lib.hooks["VAG_DYN_REFILL_MIN"] = str(refill_min)
+            _lib.hooks["VAG_DYN_REFILL_WGS"] = "24"  # 24 persistent wavefronts for ~16 k rows: every lane refills ~10 times
+        try:
+            flux = gpu_grid_dev()
+            _lib.check(lib.vag_ctx_count_work(h, 1))
+            flux_tallied = gpu_grid_dev()
+            plan = _lib.Plan()
+            _lib.check(lib.vag_last_plan(h, C.byref(plan)))
+        finally:
+            _lib.check(lib.vag_ctx_count_work(h, 0))
+            _lib.hooks.pop("VAG_DYN_REFILL")
+            _lib.hooks.pop("VAG_DYN_REFILL_MIN", None)
+            _lib.hooks.pop("VAG_DYN_REFILL_WGS", None)
+        assert np.array_equal(flux, flux_tallied, equal_nan=True)  # the tallying instantiation changes no bit either
+        return flux, plan
+
+    plain, p0 = run("0")
+    ok = np.isfinite(plain).all(axis=(1, 2))
+    assert ok.sum() == 299 and not ok[17] and plain[ok].max() > 0
+    assert p0.ode_rhs > 0 and 0 < p0.ode_lane_attempts < p0.ode_lane_slots
+    busy = {}
+    for refill_min in (1, 8, 64):
+        got, p1 = run("1", refill_min)
+        assert np.array_equal(got, plain, equal_nan=True), refill_min
+        assert (p1.n_rows, p1.ode_rhs, p1.n_rows_failed, p1.n_rows_gave_up) == (p0.n_rows, p0.ode_rhs, p0.n_rows_failed, p0.n_rows_gave_up)
+        assert p1.ode_lane_attempts == p0.ode_lane_attempts  # the same attempts of the same rows ...
+        busy[refill_min] = p1.ode_lane_attempts / p1.ode_lane_slots  # ... packed into fewer wavefront trips
+    assert busy[1] >= busy[8] >= busy[64] - 1e-12 and busy[1] > p0.ode_lane_attempts / p0.ode_lane_slots
+
+
 def test_the_grid_kernels_two_layouts_give_the_same_bits(eng):
     """vag_grid_kernel has a small LDS layout (256 theta / 208 phi nodes, eight models per CU) and a large one (1280 / 2560, one per CU); a
     batch in which some model outgrows the small one is laid out again with the large one, and every array downstream is strided by the

@@ -97,7 +97,8 @@ class Plan(C.Structure):
                 ("n_rows_failed", C.c_int32), ("n_rows_gave_up", C.c_int32),
                 ("n_walkers_rejected", C.c_int32), ("n_walkers_ssc_failed", C.c_int32),
                 ("ic_terms", C.c_int64), ("ic_nodes", C.c_int64), ("n_models_ssc_rebuilt", C.c_int32), ("n_ssc_all_cell_fallbacks", C.c_int32),
-                ("ic_pool_bytes", C.c_int64), ("ode_rhs", C.c_int64), ("n_ssc_slow_cells", C.c_int64)]
+                ("ic_pool_bytes", C.c_int64), ("ode_rhs", C.c_int64), ("n_ssc_slow_cells", C.c_int64),
+                ("ode_lane_attempts", C.c_int64), ("ode_lane_slots", C.c_int64)]
 
 
 class Limits(C.Structure):

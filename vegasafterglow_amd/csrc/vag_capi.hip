@@ -397,7 +397,10 @@ struct vag_ctx {
     // reverse shock (VAG_FLAG_RVS): its own shock / electron / photon arrays and radiation parameters.  The radiation and
     // flux passes always read d_shock, d_cellpar, ...; select_emitter() swaps the reverse shock's buffers in and out.
     DevBuf d_shock_r, d_cellpar_r, d_celldet_r, d_icy_r, d_cellq_r, d_params_rvs, d_inj, d_comp;
-    DevBuf d_fail;     // int[8]: ODE rows per status (1 step underflow, 2 step cap, 3 stalled), [4] right-hand sides evaluated (vag_ctx_count_work), reset per batch
+    DevBuf d_fail;     // int[16], reset per batch by the grid kernel: ODE rows per status ([1] step underflow, [2] step cap, [3] stalled); three 64-bit tallies at
+                       // [8..13] (vag_ctx_count_work: right-hand sides, live lanes over the attempts, lane slots of the attempts); [14] the row queue of the refill kernel
+    DevBuf d_dynrec;   // [rows][DYN_ROWREC] start records of vag_dynamics_refill_kernel (vag_dyn_prep_kernel)
+    int dyn_refill_wg_per_cu = 0;  // resident wavefronts of that kernel per CU (occupancy query, once)
     DevBuf d_cellgeo;  // spreading jets (VAG_FLAG_SPREADING): per-cell cos/sin(theta), log2|dcos|, shared by both shocks
     int cur_emitter = 0;                            // 0 forward, 1 reverse
     bool cur_ssc = false;                           // SSC switch of the selected emitter
@@ -662,7 +665,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused, &c->d_icslow,
                       &c->d_icstatus, &c->d_icunclamp, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
-                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_dynrec, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_valid, &c->d_series_flux})
@@ -742,14 +745,20 @@ int vag_ctx_count_work(vag_ctx* c, int enable) {
 }
 
 static int read_row_failures(vag_ctx* c) {
-    int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int f[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (c->d_fail.p && c->n_rows > 0) {
         HIPCHK(hipMemcpyAsync(f, c->d_fail.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     c->plan.n_rows_failed = f[1];
     c->plan.n_rows_gave_up = f[2] + f[3];
-    c->plan.ode_rhs = f[4];
+    {   // 64-bit tallies (vag_ctx_count_work; ADVICE r05: the int32 counter wrapped beyond ~3 M rows)
+        unsigned long long t64[3];
+        std::memcpy(t64, f + 8, sizeof t64);
+        c->plan.ode_rhs = (long long)t64[0];
+        c->plan.ode_lane_attempts = (long long)t64[1];
+        c->plan.ode_lane_slots = (long long)t64[2];
+    }
     if (c->fit_stats_pending && c->d_fitstat.p) {  // the last likelihood call's tallies over ALL of its passes
         int fs[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(fs, c->d_fitstat.p, sizeof fs, hipMemcpyDeviceToHost, c->stream));
@@ -956,7 +965,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
-    if (c->d_fail.ensure(sizeof(int) * 8)) return VAG_E_HIP;
+    if (c->d_fail.ensure(sizeof(int) * 16)) return VAG_E_HIP;
 
     // Grid shapes decide the compact layout and the launch geometry of everything downstream.  The last wavefront of
     // vag_grid_kernel scans them on the device and publishes an 80-byte summary in pinned host memory; the host spins on its
@@ -1098,11 +1107,38 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
                            c->d_tminmax.as<double>(), prw);
     } else if (dyn_class == 0 && !vag_hook("VAG_DYN_GENERAL")) {  // the common case: flat attempt loop, raw saves
         raw_shock = true;
+        // Batches beyond one and a half rounds of the plain kernel's integrator slots (four two-wavefront workgroups per CU) take the
+        // persistent kernel whose lanes refill from a row queue and save inline (two integrators per SIMD instead of one integrator and
+        // its saver); smaller ones keep the plain kernel, which is built for the latency of one row (no preparation pass on the chain).
+        // Measured (profiles/r06_refill_probe.txt, C4 walkers, ODE stage plain / refill): 53.9 k rows 0.37 / 0.41 ms, 108.6 k rows
+        // 0.74 / 0.65, 433.8 k rows 2.28 / 1.86.  VAG_DYN_REFILL=0 / 1 forces either; same bits (tests/test_gpu_parity.py).
+        bool refill = rows >= 96 * 4LL * c->n_cus;
+        if (const char* e = vag_hook("VAG_DYN_REFILL")) refill = std::atoi(e) != 0;
+        if (refill) {
+            int refill_min = 8;  // finished lanes a wavefront collects before it takes new rows (a refill is ~200 instructions for the whole wavefront)
+            if (const char* e = vag_hook("VAG_DYN_REFILL_MIN")) refill_min = std::max(1, std::min(64, std::atoi(e)));
+            if (c->d_dynrec.ensure(sizeof(double) * (size_t)rows * DYN_ROWREC)) return VAG_E_HIP;
+            hipLaunchKernelGGL(vag_dyn_prep_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
+                               c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells,
+                               c->d_row_status.as<int>(), c->d_dynrec.as<double>());
+            auto kern = c->count_work ? vag_dynamics_refill_kernel<true> : vag_dynamics_refill_kernel<false>;
+            if (c->dyn_refill_wg_per_cu <= 0) {  // what the registers allow (two wavefronts per SIMD at <= 256 VGPRs)
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vag_dynamics_refill_kernel<false>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+                c->dyn_refill_wg_per_cu = per_cu;
+            }
+            long long slots = (long long)c->dyn_refill_wg_per_cu * c->n_cus;
+            if (const char* e = vag_hook("VAG_DYN_REFILL_WGS")) slots = std::max(1, std::atoi(e));
+            const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>((rows + 63) / 64, slots));
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(64), 0, st, c->d_dynrec.as<double>(), rows, c->d_shock.as<double>(), cells,
+                               c->d_row_status.as<int>(), c->d_sptab.as<double>(), refill_min, c->d_fail.as<int>());
+        } else {
         const int rpw = dyn_rows_per_wave(rows);
         hipLaunchKernelGGL(c->count_work ? vag_dynamics_fast_kernel<true> : vag_dynamics_fast_kernel<false>, dim3((rows + rpw - 1) / rpw),
                            dim3(128), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(), c->d_theta.as<double>(), c->d_rep_start.as<int>(),
                            c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells, c->d_row_status.as<int>(),
                            c->d_sptab.as<double>(), rpw, c->d_fail.as<int>());
+        }
     } else {
         const bool inject = (c->batch_flags & VAG_FLAG_MAGNETAR) != 0;
         auto kern = spreading ? (inject ? vag_dynamics_kernel<true, true> : vag_dynamics_kernel<true, false>)

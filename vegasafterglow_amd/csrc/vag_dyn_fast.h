@@ -143,12 +143,14 @@ VAG_DEV void lds_store_ordered(int* p, int v) {
 
 // The flat attempt loop of one wavefront (lane = row).  Returns the lane's solver status (0 ok, 1 step underflow,
 // 2 step cap).
-// TALLY (vag_ctx_count_work, untimed passes): *n_rhs = right-hand sides this lane's row evaluated.  Everything the tally adds is
+// TALLY (vag_ctx_count_work, untimed passes): the right-hand sides of the rows and the loop's lane utilisation.  Everything the tally adds is
 // compiled out of the product instantiation: an extra counter and reference parameter cost the latency-bound loop 0.14 ms per
 // 1024-walker step when they were tried unconditionally (r05).
+// tally[0] += right-hand sides, tally[1] += live lanes summed over the wavefront's attempts, tally[2] += attempts x 64 (the lane slots they
+// occupied): tally[1] / tally[2] is the lane utilisation of the attempt loop.
 template <class Eq, bool TALLY = false>
 VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double t_last, bool active, LdsTab lg, DynRing& ring,
-                          int lane, int* n_rhs = nullptr) {
+                          int lane, unsigned long long* tally = nullptr) {
     constexpr int N = 5;
     constexpr double a21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40;
     constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
@@ -161,6 +163,7 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
     double t = t0, dt = 0.01 * t0;
     int fails = 0, steps = 0, status = 0, head = 0, tail_seen = 0;
     [[maybe_unused]] int n_rej = 0;
+    [[maybe_unused]] unsigned long long live_sum = 0, wave_attempts = 0;
     bool done = !active;
     if (active) {
         eq(x, dx);
@@ -180,6 +183,10 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
         bool accepted = false, commit = false;
         double xn[N], k3[N], k4[N], k5[N], k6[N], k7[N];
         double tn = t;
+        if constexpr (TALLY) {
+            live_sum += (unsigned long long)__popcll(__ballot(!done));
+            wave_attempts += 1;
+        }
         if (!done) {
             const double h = dt;
             double xt[N], k2[N];
@@ -300,7 +307,13 @@ VAG_DEV int fs_integrator(const Eq& eq, double* x, double t0, double eps, double
         }
     }
     lds_store_release(&ring.fin, 1);
-    if constexpr (TALLY) *n_rhs = active ? 1 + 6 * (steps + n_rej) : 0;  // FSAL: six new evaluations per attempt, one at the start
+    if constexpr (TALLY) {
+        if (active) atomicAdd(tally, (unsigned long long)(1 + 6 * (steps + n_rej)));  // FSAL: six new evaluations per attempt, one at the start
+        if (lane == 0) {
+            atomicAdd(tally + 1, live_sum);
+            atomicAdd(tally + 2, 64ull * wave_attempts);
+        }
+    }
 #ifdef VAG_DYN_STAMPS
     if (blockIdx.x == 0 && lane == 0)
         printf("fast dyn wave 0: attempts %d, lane 0 steps %d; cycles total %lld, attempt bodies %lld, waiting for the saver %lld (%d spins)\n",
@@ -411,6 +424,227 @@ VAG_DEV int fs_saver(DynRing& ring, int lane, bool active, int nt, Node& node, d
         printf("  saver: slots %d, polls %d, busy cycles %lld (max per slot %lld), lane 0 nodes %d\n", its, s_polls, s_busy, s_max, k);
 #endif
     return k;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Throughput form of the same solve (round 6): LANE REFILL, saves inline.  The kernel above is built for the latency of ONE row: a
+// wavefront of 64 rows runs until its slowest row is done (rows take 60 ... 130 attempts: a quarter of the lane-attempts of a large
+// batch are finished lanes waiting, vag_plan.ode_lane_attempts / ode_lane_slots), and the saver wavefront with its 39 KB ring keeps a CU
+// at four integrators -- ONE per SIMD, and a wavefront issues at most one instruction per four cycles whatever its kind, so the FP64 pipe
+// of a full GPU idles 45 % of the time (profiles/r06_pmc_dyn.txt: 0.55 VALU busy at 1.7 wavefronts per SIMD).  For batches that fill
+// the GPU several times over the workgroups are PERSISTENT single wavefronts: a lane whose row is finished takes the next row from a
+// device counter and goes on in place (rows are independent: same bits), and the dense output is evaluated inline by the lanes whose
+// step passed a lattice node -- no saver, no ring, no LDS beyond the logarithm table, so two integrators share every SIMD and fill each
+// other's issue slots.  What a lane needs to start a row is prepared beforehand, one lane per row, by vag_dyn_prep_kernel (the
+// start-up of a row is ~3 k instructions of branchy code -- library logarithms of the lattice, the enclosed mass and energy -- which a
+// refill inside the attempt loop would make the whole wavefront wait for): a 160-byte record per row and the row's node times, which
+// are an output anyway (VS_TENG).  ("persistent-lane work queue"; forward-shock.tpp:194-207 is the loop over rows.)
+// ------------------------------------------------------------------------------------------------
+constexpr int DYN_ROWREC = 20;  // doubles per row record
+enum {
+    DR_X = 0,       // Gamma, m2, U, r, t_comv at t0 (set_init_state)
+    DR_T0 = 5,
+    DR_TLAST = 6,
+    DR_RTOL = 7,
+    DR_EQ = 8,      // m_jet0, gm_coeff, inv_gc2, eps_e, pm2, rho_ism, A, r02
+    DR_NT = 16,     // (n_t of the row, state: 0 integrate, 2 nothing to do -- not evaluated, or a stopped shock the preparation wrote)
+    DR_C0 = 17,     // first cell of the row in the shock arrays (the bits of a long long)
+};
+
+template <bool TALLY>
+VAG_DEV void fs_solver_refill(const double* __restrict__ rowrec, int n_rows, unsigned* __restrict__ queue, int refill_min, LdsTab lg, int lane,
+                              double* __restrict__ shock, long long n_cells, int* __restrict__ row_status, int* __restrict__ fail,
+                              unsigned long long* __restrict__ tally) {
+    constexpr int N = 5;
+    constexpr double a21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40;
+    constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
+    constexpr double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729;
+    constexpr double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+    constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
+                     dc5 = c5 - -92097.0 / 339200, dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+    constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+    // the Wind form serves every row: with A = 0 its density term is fma(0, finite, rho_ism) = rho_ism, the uniform-medium bits
+    FsRhs<true> eq;
+    eq.lg = lg;
+    eq.m_jet0 = eq.gm_coeff = eq.inv_gc2 = eq.eps_e = eq.pm2 = eq.rho_ism = 1;
+    eq.A = eq.r02 = 0;
+    double x[N] = {2.0, 1.0, 1.0, 1.0, 1.0}, dx[N] = {0, 0, 0, 0, 0};
+    double t = 1, dt = 0.01, t_last = 0, eps = 1e-6;
+    int fails = 0, steps = 0, status = 0, row = -1;
+    // the row's lattice: next node k of nt, its time and the one after it (requested a node ahead: a load is a microsecond)
+    int k = 0, nt = 0;
+    double t_k = 0, t_k1 = 0;
+    double* o = shock;  // &shock[VS_TENG][c0]
+    [[maybe_unused]] int n_rej = 0;
+    [[maybe_unused]] unsigned long long live_sum = 0, wave_attempts = 0, rhs_sum = 0;
+    bool done = true, drained = false;
+    auto retire = [&]() {  // unreached nodes keep the Shock constructor's defaults (shock.cpp:12-24); their times are written already
+        for (; k < nt; ++k) {
+            o[VS_TCOMV * n_cells + k] = 0;
+            o[VS_R * n_cells + k] = 0;
+            o[VS_GAMMA * n_cells + k] = 1;
+            o[VS_GAMMA_TH * n_cells + k] = 0;
+            o[VS_B * n_cells + k] = 0;
+            o[VS_NP * n_cells + k] = 0;
+        }
+        row_status[row] = status;
+        if (status > 0 && status < 4) atomicAdd(fail + status, 1);
+        if constexpr (TALLY) rhs_sum += (unsigned long long)(1 + 6 * (steps + n_rej));
+        row = -1;
+    };
+    for (;;) {
+        const unsigned long long mdone = __ballot(done);
+        const int n_done = __popcll(mdone);
+        if (!drained && n_done >= refill_min) {
+            if (done && row >= 0) retire();
+            const int first = __ffsll((long long)mdone) - 1;
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(queue, (unsigned)n_done);
+            base = (unsigned)__shfl((int)base, first);
+            if (base + (unsigned)n_done >= (unsigned)n_rows) drained = true;
+            const long long mine = done ? (long long)base + __popcll(mdone & ((1ull << lane) - 1ull)) : -1;
+            if (mine >= 0 && mine < n_rows) {
+                const double* r = rowrec + (size_t)mine * DYN_ROWREC;
+                const int state = __double2hiint(r[DR_NT]);
+                if (state == 0) {
+                    row = (int)mine;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) x[i] = r[DR_X + i];
+                    t = r[DR_T0], t_last = r[DR_TLAST], eps = r[DR_RTOL];
+                    eq.m_jet0 = r[DR_EQ + 0], eq.gm_coeff = r[DR_EQ + 1], eq.inv_gc2 = r[DR_EQ + 2], eq.eps_e = r[DR_EQ + 3];
+                    eq.pm2 = r[DR_EQ + 4], eq.rho_ism = r[DR_EQ + 5], eq.A = r[DR_EQ + 6], eq.r02 = r[DR_EQ + 7];
+                    nt = __double2loint(r[DR_NT]);
+                    o = shock + __double_as_longlong(r[DR_C0]);
+                    k = 0;
+                    t_k = o[0];
+                    t_k1 = nt > 1 ? o[1] : 0.0;
+                    dt = 0.01 * t;
+                    fails = steps = status = 0;
+                    if constexpr (TALLY) n_rej = 0;
+                    eq(x, dx);
+                    done = !(t <= t_last);
+                }
+            }
+            continue;
+        }
+        if (n_done == 64) break;  // nothing live and nothing left to take
+        if constexpr (TALLY) {
+            live_sum += (unsigned long long)(64 - n_done);
+            wave_attempts += 1;
+        }
+        // ---- one step attempt of every live lane: the arithmetic of fs_integrator, expression for expression ----
+        bool accepted = false, commit = false;
+        double xn[N], k3[N], k4[N], k5[N], k6[N], k7[N];
+        double tn = t;
+        if (!done) {
+            const double h = dt;
+            double xt[N], k2[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * a21) * dx[i];
+            eq(xt, k2);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b31) * dx[i] + (h * b32) * k2[i];
+            eq(xt, k3);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xt[i] = x[i] + (h * b41) * dx[i] + (h * b42) * k2[i] + (h * b43) * k3[i];
+            eq(xt, k4);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xt[i] = x[i] + (h * b51) * dx[i] + (h * b52) * k2[i] + (h * b53) * k3[i] + (h * b54) * k4[i];
+            eq(xt, k5);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xt[i] = x[i] + (h * b61) * dx[i] + (h * b62) * k2[i] + (h * b63) * k3[i] + (h * b64) * k4[i] + (h * b65) * k5[i];
+            eq(xt, k6);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                xn[i] = x[i] + (h * c1) * dx[i] + (h * c3) * k3[i] + (h * c4) * k4[i] + (h * c5) * k5[i] + (h * c6) * k6[i];
+            eq(xn, k7);
+            double err = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double xe = (h * dc1) * dx[i] + (h * dc3) * k3[i] + (h * dc4) * k4[i] + (h * dc5) * k5[i] +
+                                  (h * dc6) * k6[i] + (h * dc7) * k7[i];
+                err = vmax(err, fabs(xe) * rcp_ode(fma(eps, fma(fabs(h), fabs(dx[i]), fabs(x[i])), eps)));
+            }
+            const bool reject = err > 1.0;
+            const double lg_e = log2_tab_nb(vmin(vmax(err, 3.2e-4), 1e300), lg);
+            const double fac = 0.9 * exp2_ode(lg_e * (reject ? -1.0 / 3 : -1.0 / 5));
+            dt = h * (reject ? vmax(fac, 0.2) : (err < 0.5 ? fac : 1.0));
+            if (reject) {
+                if constexpr (TALLY) ++n_rej;
+                if (++fails >= 500) {
+                    status = 1;
+                    done = true;
+                }
+            } else {
+                fails = 0;
+                commit = true;
+                tn = t + h;
+                if (++steps > 100000) {
+                    status = 2;
+                    done = true;
+                } else {
+                    accepted = true;
+                    done = !(tn <= t_last);
+                }
+            }
+        }
+        // ---- dense output (runge_kutta_dopri5.hpp:238-258) at the lattice nodes the accepted step passed: fs_saver's expressions ----
+        const bool saves = accepted && k < nt && tn > t_k;
+        if (__any(saves)) {
+            if (saves) {
+                const double hh = tn - t;
+                const double inv_hh = rcp_fast(hh);
+                do {
+                    const double th = (t_k - t) * inv_hh;
+                    const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) * (1.0 / 11282082432.0);
+                    const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) * (1.0 / 32700410799.0);
+                    const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) * (1.0 / 1880347072.0);
+                    const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) * (1.0 / 199316789632.0);
+                    const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) * (1.0 / 822651844.0);
+                    const double X7 = 10.0 * (7414447.0 - 829305.0 * th) * (1.0 / 29380423.0);
+                    const double thm1 = th - 1.0, th2 = th * th;
+                    const double A_ = th2 * (3.0 - 2.0 * th);
+                    const double B_ = th2 * thm1;
+                    const double C_ = th2 * thm1 * thm1;
+                    const double D_ = th * thm1 * thm1;
+                    const double w1 = hh * (A_ * B1 - C_ * X1 + D_), w3 = hh * (A_ * B3 + C_ * X3), w4 = hh * (A_ * B4 - C_ * X4),
+                                 w5 = hh * (A_ * B5 + C_ * X5), w6 = hh * (A_ * B6 - C_ * X6), w7 = hh * (B_ + C_ * X7);
+                    double q[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        q[i] = x[i] + w1 * dx[i] + w3 * k3[i] + w4 * k4[i] + w5 * k5[i] + w6 * k6[i] + w7 * k7[i];
+                    o[VS_GAMMA * n_cells + k] = q[0];
+                    o[VS_NP * n_cells + k] = q[1];
+                    o[VS_GAMMA_TH * n_cells + k] = q[2];
+                    o[VS_R * n_cells + k] = q[3];
+                    o[VS_TCOMV * n_cells + k] = q[4];
+                    ++k;
+                    t_k = t_k1;
+                    if (k + 1 < nt) t_k1 = o[k + 1];
+                } while (k < nt && tn > t_k);
+            }
+        }
+        if (commit) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x[i] = xn[i];
+                dx[i] = k7[i];
+            }
+            t = tn;
+        }
+    }
+    if (row >= 0) retire();  // rows that finished after the queue ran dry
+    if constexpr (TALLY) {
+        if (rhs_sum) atomicAdd(tally, rhs_sum);
+        if (lane == 0) {
+            atomicAdd(tally + 1, live_sum);
+            atomicAdd(tally + 2, 64ull * wave_attempts);
+        }
+    }
 }
 
 }  // namespace vag

@@ -459,11 +459,11 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
                 double* __restrict__ g_geo_th /* [nb][3][VAG_MAX_THETA]: cos, sin, log2|dcos| */,
                 double* __restrict__ g_geo_ph /* [nb][2][VAG_MAX_PHI]: cos(phi), log2(dphi) */,
-                int* __restrict__ fail /* [4] ODE-row failure counters of the dynamics stage, reset here */,
+                int* __restrict__ fail /* [16] ODE-row failure counters, work tallies and row queue of the dynamics stage, reset here */,
                 double* __restrict__ g_rowgeo /* [nb][VAG_ROWGEO_HDR + 2 SH::max_phi + 4 SH::max_theta]: the same geometry as records */) {
     const int m = blockIdx.x;
     const int lane = threadIdx.x;
-    if (m == 0 && lane < 8) fail[lane] = 0;  // (ODE row tallies, vag_capi.hip: d_fail)
+    if (m == 0 && lane < 16) fail[lane] = 0;  // (ODE row tallies and the refill kernel's row queue, vag_capi.hip: d_fail)
     const vag_model_params P = params[m];
     const double t_min_s = tminmax[0], t_max_s = tminmax[1];
     if (!params_valid(P)) {  // the reference raises ValueError; batched walkers get status != 0 (-> NaN / -inf)

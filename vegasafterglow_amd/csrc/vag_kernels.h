@@ -251,11 +251,10 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
                          const double* __restrict__ g_theta, const int* __restrict__ g_rep_start,
                          const double* __restrict__ g_tdec, Layout lay, int n_rows, double* __restrict__ shock,
                          long long n_cells, int* __restrict__ row_status, const double* __restrict__ sp_table, int rows_per_wave,
-                         int* __restrict__ fail /* TALLY (vag_ctx_count_work): right-hand sides of the batch -> fail[4] */) {
+                         int* __restrict__ fail /* [16]: TALLY (vag_ctx_count_work) adds to the three 64-bit counters at fail + 8 */) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
     __shared__ DynRing ring;
     __shared__ int s_status[64];
-    [[maybe_unused]] __shared__ int s_rhs[TALLY ? 64 : 1];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0 integrates, role 1 saves
     for (int i = threadIdx.x; i < LOG_TAB_DOUBLES; i += 128) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
     if (threadIdx.x == 0) ring.head = ring.tail = ring.fin = 0;
@@ -337,18 +336,17 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
 #endif
     if (role == 0) {
         int status;
-        [[maybe_unused]] int n_rhs = 0;
+        unsigned long long* tally = reinterpret_cast<unsigned long long*>(fail + 8);
         const bool go = active && !stopped;
         if (__any(go && eq.A != 0)) {
-            status = fs_integrator<FsRhs<true>, TALLY>(eq, s, t0, rtol, t_last, go, eq.lg, ring, lane, &n_rhs);
+            status = fs_integrator<FsRhs<true>, TALLY>(eq, s, t0, rtol, t_last, go, eq.lg, ring, lane, tally);
         } else {  // every row of this wavefront sits in a uniform medium
             FsRhs<false> ei;
             ei.m_jet0 = eq.m_jet0, ei.gm_coeff = eq.gm_coeff, ei.inv_gc2 = eq.inv_gc2, ei.eps_e = eq.eps_e, ei.pm2 = eq.pm2;
             ei.rho_ism = eq.rho_ism, ei.A = 0, ei.r02 = 0, ei.lg = eq.lg;
-            status = fs_integrator<FsRhs<false>, TALLY>(ei, s, t0, rtol, t_last, go, eq.lg, ring, lane, &n_rhs);
+            status = fs_integrator<FsRhs<false>, TALLY>(ei, s, t0, rtol, t_last, go, eq.lg, ring, lane, tally);
         }
         s_status[lane] = status;
-        if constexpr (TALLY) s_rhs[lane] = n_rhs;
     } else {
         int k = 0;
         if (active && stopped) {  // raw form of the stopped shock: m2 = 0 finishes to Gamma_th = 1, B = N_p = 0
@@ -380,10 +378,114 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
         const int status = stopped ? 0 : s_status[lane];
         row_status[row] = status;
         if (status > 0 && status < 4) atomicAdd(fail + status, 1);
-        if constexpr (TALLY) {
-            if (!stopped) atomicAdd(fail + 4, s_rhs[lane]);
-        }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same solve for batches that fill the GPU several times over: persistent single-wavefront workgroups whose lanes take rows from a
+// device counter and save inline (vag_dyn_fast.h, "lane refill").  vag_dyn_prep_kernel prepares every row's start -- one lane per row,
+// the expressions of the kernel above -- as a 160-byte record, writes the row's node times (an output of the stage) and finishes the
+// rows that need no solve (a stopped shock); vag_dynamics_refill_kernel integrates and saves.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vag_dyn_prep_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                    const double* __restrict__ g_theta, const int* __restrict__ g_rep_start, const double* __restrict__ g_tdec,
+                    Layout lay, int n_rows, double* __restrict__ shock, long long n_cells, int* __restrict__ row_status,
+                    double* __restrict__ rowrec) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double* rec = rowrec + (size_t)row * DYN_ROWREC;
+    if (row >= lay.row_off[nb]) {
+        rec[DR_NT] = __hiloint2double(2, 0);
+        return;
+    }
+    const int m = find_model(lay.row_off, nb, row);
+    const VagGridMeta M = meta[m];
+    if (M.status != 0) {
+        rec[DR_NT] = __hiloint2double(2, 0);
+        return;
+    }
+    const int nt = M.n_t;
+    const int r = row - lay.row_off[m];
+    const int j = g_rep_start[(size_t)m * M.th_stride + r];
+    const vag_model_params P = params[m];
+    Jet jet;
+    jet_init(jet, P);
+    Medium med;
+    medium_init(med, P);
+    const double theta0 = g_theta[(size_t)m * M.th_stride + j];
+    const double t_dec = g_tdec[((size_t)m * 3 + 0) * M.th_stride + j];
+    const double t_start_row = g_tdec[((size_t)m * 3 + 1) * M.th_stride + j];
+    const double t_early_row = g_tdec[((size_t)m * 3 + 2) * M.th_stride + j];
+    const long long c0 = lay.cell_off[m] + (long long)r * nt;
+    TimeLattice lat;
+    lat.init(t_start_row, M.t_end, t_dec, M.t_num_tot);
+    const double Gamma4 = jet_Gamma0(jet, theta0);
+    rec[DR_EQ + 0] = jet_eps_k(jet, theta0) / Gamma4 / C_C2 / (1 + jet.sigma0);
+    rec[DR_EQ + 1] = (P.p - 2) / (P.p - 1) * P.eps_e * C_MP / C_ME / P.xi_e;
+    rec[DR_EQ + 2] = 2 / (6 * C_PI * C_ME * C_C / C_SIGMAT / (8 * C_PI * P.eps_B));
+    rec[DR_EQ + 3] = P.radiative_fireball ? P.eps_e : 0;
+    rec[DR_EQ + 4] = P.p > 2 ? P.p - 2 : 0.0;
+    rec[DR_EQ + 5] = med.rho_ism;
+    rec[DR_EQ + 6] = med.type == VAG_MEDIUM_ISM ? 0.0 : med.A;
+    rec[DR_EQ + 7] = med.type == VAG_MEDIUM_ISM ? 0.0 : med.r02;
+    auto node = [&](int k) -> double { return M.has_early ? (k == 0 ? t_early_row : lat.node(k - 1)) : lat.node(k); };
+    const double t_first = node(0);
+    const double t_last = node(nt - 1);
+    const double t0 = dmin(t_first, dmin(0.1 * U_SEC, 0.1 * t_dec));
+    // set_init_state, forward-shock.tpp:120-149
+    double s[5];
+    const double beta4 = gamma_to_beta(Gamma4);
+    s[3] = beta4 * C_C * t0 * Gamma4 * Gamma4 * (1 + beta4);
+    s[4] = s[3] / sqrt((Gamma4 - 1) * (Gamma4 + 1)) / C_C;
+    s[0] = Gamma4;
+    s[1] = medium_mass(med, s[3]);
+    s[2] = enclosed_thermal_energy(med, s[3], s[0], adiabatic_idx(s[0]), P.radiative_fireball ? P.eps_e : 0.0);
+    const bool stopped = s[0] <= GAMMA_CUT;  // set_stopping_shock, shock-physics.h:388-397
+#pragma unroll
+    for (int i = 0; i < 5; ++i) rec[DR_X + i] = s[i];
+    rec[DR_T0] = t0;
+    rec[DR_TLAST] = t_last;
+    rec[DR_RTOL] = P.rtol;
+    rec[DR_NT] = __hiloint2double(stopped ? 2 : 0, nt);
+    rec[DR_C0] = __longlong_as_double(c0);
+    double* o = shock + c0;
+    for (int k = 0; k < nt; ++k) o[VS_TENG * n_cells + k] = node(k);
+    if (stopped) {  // raw form of the stopped shock: m2 = 0 finishes to Gamma_th = 1, B = N_p = 0
+        for (int k = 0; k < nt; ++k) {
+            o[VS_TCOMV * n_cells + k] = s[4];
+            o[VS_R * n_cells + k] = s[3];
+            o[VS_GAMMA * n_cells + k] = 1;
+            o[VS_GAMMA_TH * n_cells + k] = 0;
+            o[VS_B * n_cells + k] = 0;
+            o[VS_NP * n_cells + k] = 0;
+        }
+        row_status[row] = 0;
+    }
+}
+
+#ifndef VAG_DYN_REFILL_WAVES
+#define VAG_DYN_REFILL_WAVES 2  // wavefronts per SIMD the register allocation aims at
+#endif
+template <bool TALLY>
+__global__ void __launch_bounds__(64, VAG_DYN_REFILL_WAVES)
+vag_dynamics_refill_kernel(const double* __restrict__ rowrec, int n_rows, double* __restrict__ shock, long long n_cells,
+                           int* __restrict__ row_status, const double* __restrict__ sp_table, int refill_min,
+                           int* __restrict__ fail /* [16]: [1..3] failures, 64-bit tallies at fail + 8, the row queue at fail + 14 */) {
+    __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
+    __syncthreads();
+#ifdef VAG_DYN_PLACEMENT  // developer aid: where the dispatcher put the persistent wavefronts
+    if (lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);  // HW_REG_XCC_ID
+        printf("P %d %d xcc %u se %u sh %u cu %u simd %u wave %u\n", (int)blockIdx.x, 0, xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15,
+               (hw >> 4) & 3, hw & 15);
+    }
+#endif
+    fs_solver_refill<TALLY>(rowrec, n_rows, reinterpret_cast<unsigned*>(fail + 14), refill_min, lds_tab(s_lg), lane, shock, n_cells, row_status,
+                            fail, reinterpret_cast<unsigned long long*>(fail + 8));
 }
 
 // ------------------------------------------------------------------------------------------------
