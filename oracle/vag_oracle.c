@@ -2636,6 +2636,17 @@ static int build_lattice(double lg2_lo, double lg2_hi, double step, double** gri
     return (int)n;
 }
 
+/* Instrumentation of generate_spectrum (round 6): with `on` set, every table build also counts the unit of work of the device's
+ * spectrum kernel -- (electron energy i, seed bin m) terms dN_e(i) x (bin integral of m at energy i) -- and how many of them are NOT
+ * NEEDED: the bin lies above every output node of the clamped table, or the term is below 2^-bits of the final value of the SMALLEST
+ * output node it enters (a bin enters every node below it; the output falls with frequency).  `energies_dead` counts the (cell,
+ * energy) walks in which every bin is such a term: what a wavefront could skip as a whole.  Not part of any checked result. */
+static struct {
+    int on;
+    double bits;
+    long long cells, terms, terms_negligible, energies, energies_dead;
+} g_ic_tally = {0, 60.0, 0, 0, 0, 0, 0};
+
 /* generate_spectrum: compute_grid_params + initialize_grids + sample_distributions + compute_IC_spectrum */
 static void icphoton_generate(icphoton_t* ic) {
     icphoton_free(ic);
@@ -2794,6 +2805,56 @@ static void icphoton_generate(icphoton_t* ic) {
             ACCUMULATE_IC_(dN_e_boost[i], ic->ic_idx0 - 2 * (long)IC_GAMMA_MULT * i, fv_th);
         }
     }
+    if (g_ic_tally.on) { /* second walk against the finished I_buf */
+        const double thr = exp2(-g_ic_tally.bits);
+        g_ic_tally.cells += 1;
+        if (!ic->KN) BUILD_CDF_TH_(cdf_buf, ratio_buf);
+        for (int i = 0; i < g_size; ++i) {
+            if (dN_e_boost[i] <= 0) continue;
+            if (ic->KN) { /* the energy's own CDF: the KN-corrected bins above the split, the Thomson ones below (build_cdf_KN) */
+                const size_t n_lat_unused = 0;
+                (void)n_lat_unused;
+                const double lg2_base = log2(gamma[0]) + lg2_nu_seed[0];
+                const size_t i_gamma = IC_GAMMA_MULT * (size_t)i;
+                const double nu_split = 1e-4 * (C_ME * C_C2 / C_H) / gamma[i];
+                int j_split = 0;
+                while (j_split < nu_last && nu_seed[j_split] < nu_split) ++j_split;
+                double corr, lg2_corr;
+                compton_correction_pair(exp2(lg2_base + IC_Q * (double)(i_gamma + IC_NU_MULT * (size_t)nu_last)), &corr, &lg2_corr);
+                fv_buf[nu_last] = fv_th[nu_last] * corr;
+                double lg2f_hi = lg2fv_th[nu_last] + lg2_corr;
+                cdf_buf[nu_last] = 0;
+                for (int j = nu_last - 1; j >= j_split; --j) {
+                    compton_correction_pair(exp2(lg2_base + IC_Q * (double)(i_gamma + IC_NU_MULT * (size_t)j)), &corr, &lg2_corr);
+                    fv_buf[j] = fv_th[j] * corr;
+                    const double lg2f_lo = lg2fv_th[j] + lg2_corr;
+                    const double trap = 0.5 * (fv_buf[j] + fv_buf[j + 1]) * dnu_seed[j];
+                    cdf_buf[j] = cdf_buf[j + 1] + power_law_bin_integral(fv_buf[j], fv_buf[j + 1], nu_seed[j], nu_seed[j + 1], lg2f_lo, lg2f_hi,
+                                                                         lg2r[j], inv_lg2r[j], trap);
+                    lg2f_hi = lg2f_lo;
+                }
+                if (j_split > 0) {
+                    const double delta = cdf_buf[j_split] - cdf_th[j_split];
+                    for (int j = j_split - 1; j >= 0; --j) cdf_buf[j] = cdf_th[j] + delta;
+                }
+            }
+            const long n_off = ic->ic_idx0 - 2 * (long)IC_GAMMA_MULT * i;
+            int all_dead = 1;
+            for (int m = 0; m < nu_last; ++m) {
+                const double term = dN_e_boost[i] * (cdf_buf[m] - cdf_buf[m + 1]);
+                /* the last output node whose lattice position nn = n_off + IC_IC_MULT kk falls into bin m or below it */
+                long kk_max = ((long)m * IC_NU_MULT + (IC_NU_MULT - 1) - n_off) / (long)IC_IC_MULT;
+                if ((long)m * IC_NU_MULT + (IC_NU_MULT - 1) - n_off < 0) kk_max = -1;
+                if (kk_max > n_ic - 1) kk_max = n_ic - 1;
+                const int dead = kk_max < 0 || !(term >= thr * I_buf[kk_max]);
+                g_ic_tally.terms += 1;
+                g_ic_tally.terms_negligible += dead;
+                all_dead &= dead;
+            }
+            g_ic_tally.energies += 1;
+            g_ic_tally.energies_dead += all_dead;
+        }
+    }
 #undef BUILD_CDF_TH_
 #undef ACCUMULATE_IC_
     const double log2_scale = log2(0.25 * C_SIGMAT);
@@ -2856,6 +2917,16 @@ static double eval_ic_cell(void* grid, int j, int k, int t_grid, double log2_nu)
     return icphoton_log2_I_nu((icphoton_t*)grid + (size_t)j * t_grid + k, log2_nu);
 }
 
+/* Instrumentation of specific_flux (round 6): with a reference F of the same request (code units, as specific_flux returns
+ * it) set, the pass counts the boundary evaluations B[l][k] of every row's window (the flux kernels' unit of work: n_evals) and those
+ * among them that are NOT NEEDED -- every interpolated term they enter lies below 2^-bits of the final flux of its (nu, t) bin, or they
+ * serve no requested time at all -- and the same for the interpolated terms themselves.  Not part of any checked result. */
+static struct {
+    const double* F_ref;
+    double bits;
+    long long n_evals, n_evals_negligible, n_interps, n_interps_negligible;
+} g_flux_tally = {NULL, 60.0, 0, 0, 0, 0};
+
 /* F[nnu][nt] in code units */
 static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const double* t_obs, int nt_obs, const double* nu_obs,
                           int nnu, double* F) {
@@ -2869,6 +2940,8 @@ static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const d
     double* slope = calloc(nnu, sizeof(double));
     double* lo = calloc(nnu, sizeof(double));
     double* col = calloc((size_t)nnu * nt_obs, sizeof(double));
+    unsigned char* needed = g_flux_tally.F_ref ? calloc((size_t)t_grid * nnu, 1) : NULL;
+    const double tally_norm = o->one_plus_z / (o->lumi_dist * o->lumi_dist);
 
     for (int i = 0; i < o->n_phi_eff; ++i) {
         for (int j = 0; j < o->n_theta; ++j) {
@@ -2902,7 +2975,23 @@ static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const d
                     const double dlg2_t = lg2_t_obs[idx] - t_lo_val;
                     for (int l = 0; l < nnu; ++l) col[(size_t)l * nt_obs + idx] = lo[l] + dlg2_t * slope[l];
                 }
+                if (needed)
+                    for (int idx = idx_start; idx < t_idx; ++idx)
+                        for (int l = 0; l < nnu; ++l) {
+                            const double thr = log2(g_flux_tally.F_ref[(size_t)l * nt_obs + idx] / tally_norm) - g_flux_tally.bits;
+                            const int counts = col[(size_t)l * nt_obs + idx] >= thr;
+                            g_flux_tally.n_interps += 1;
+                            g_flux_tally.n_interps_negligible += !counts;
+                            if (counts) needed[(size_t)k * nnu + l] = needed[(size_t)(k + 1) * nnu + l] = 1;
+                        }
             }
+            if (needed)
+                for (int k = k_lo; k <= k_hi; ++k)
+                    for (int l = 0; l < nnu; ++l) {
+                        g_flux_tally.n_evals += 1;
+                        g_flux_tally.n_evals_negligible += !needed[(size_t)k * nnu + l];
+                        needed[(size_t)k * nnu + l] = 0;
+                    }
             for (int l = 0; l < nnu; ++l)
                 for (int idx = col_first; idx < t_idx; ++idx)
                     F[(size_t)l * nt_obs + idx] += exp2(col[(size_t)l * nt_obs + idx]);
@@ -2910,6 +2999,7 @@ static void specific_flux(const eat_t* o, cell_eval_fn eval, void* grid, const d
     }
     const double norm = o->one_plus_z / (o->lumi_dist * o->lumi_dist);
     for (size_t q = 0; q < (size_t)nnu * nt_obs; ++q) F[q] *= norm;
+    free(needed);
     free(lg2_t_obs);
     free(lg2_nu_src);
     free(boundary);
@@ -3284,6 +3374,51 @@ int vag_oracle_flux_density_grid_components(const vag_model_params* p, const dou
                                             double* out, double* out_ssc) {
     double* out4[4] = {out, out_ssc, NULL, NULL};
     return vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, out4);
+}
+
+/* Instrumentation (g_flux_tally above): counts[4] = {boundary evaluations, of which not needed at 2^-bits, interpolated terms, of which
+ * below 2^-bits of their bin's final flux} for a forward-shock synchrotron grid request.  Not thread-safe; used by
+ * profiles/debug/negligible_work.py only. */
+int vag_oracle_flux_tally(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu, double bits, long long* counts) {
+    if (p->flags & (VAG_FLAG_SSC | VAG_FLAG_RVS)) return VAG_E_INVALID;
+    const size_t n = (size_t)nnu * nt;
+    double* ref = malloc(sizeof(double) * n);
+    double* again = malloc(sizeof(double) * n);
+    double* out4[4] = {ref, NULL, NULL, NULL};
+    int rc = vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, out4);
+    if (rc == 0) {
+        for (size_t q = 0; q < n; ++q) ref[q] *= U_FLUX_DEN_CGS; /* back to what specific_flux returns */
+        g_flux_tally.F_ref = ref;
+        g_flux_tally.bits = bits;
+        g_flux_tally.n_evals = g_flux_tally.n_evals_negligible = g_flux_tally.n_interps = g_flux_tally.n_interps_negligible = 0;
+        out4[0] = again;
+        rc = vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, out4);
+        g_flux_tally.F_ref = NULL;
+        counts[0] = g_flux_tally.n_evals, counts[1] = g_flux_tally.n_evals_negligible;
+        counts[2] = g_flux_tally.n_interps, counts[3] = g_flux_tally.n_interps_negligible;
+    }
+    free(ref);
+    free(again);
+    return rc;
+}
+
+/* Instrumentation (g_ic_tally above): counts[5] = {cells with a table, (energy, seed bin) terms, of which not needed at 2^-bits, (cell,
+ * energy) walks, of which every term is not needed} over all SSC table builds of one grid request.  Used by
+ * profiles/debug/negligible_work.py only. */
+int vag_oracle_ssc_tally(const vag_model_params* p, const double* t, int nt, const double* nu, int nnu, double bits, long long* counts) {
+    const size_t n = (size_t)nnu * nt;
+    double* buf = malloc(sizeof(double) * n * 4);
+    double* out4[4] = {buf, buf + n, (p->flags & VAG_FLAG_RVS) ? buf + 2 * n : NULL,
+                       ((p->flags & VAG_FLAG_RVS) && (p->flags & VAG_FLAG_RVS_SSC)) ? buf + 3 * n : NULL};
+    g_ic_tally.on = 1;
+    g_ic_tally.bits = bits;
+    g_ic_tally.cells = g_ic_tally.terms = g_ic_tally.terms_negligible = g_ic_tally.energies = g_ic_tally.energies_dead = 0;
+    const int rc = vag_oracle_flux_density_grid_components4(p, t, nt, nu, nnu, out4);
+    g_ic_tally.on = 0;
+    counts[0] = g_ic_tally.cells, counts[1] = g_ic_tally.terms, counts[2] = g_ic_tally.terms_negligible;
+    counts[3] = g_ic_tally.energies, counts[4] = g_ic_tally.energies_dead;
+    free(buf);
+    return rc;
 }
 
 /* Model.flux_density_grid: total = fwd.sync + fwd.ssc (PyFlux::calc_total, pymodel.cpp:350-364) */
