@@ -15,10 +15,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 lib = _lib.load(); h, lock = va.get_context(0); orc = _abi.load_oracle(); dp = C.POINTER(C.c_double)
 rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", 4242)))
 t, nu = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22, 1e26])
-worst = {"sync": (0.0, -1), "ssc": (0.0, -1)}
-bad = 0
-outside = []  # draws outside the reference's golden contract
 for kn in (True, False):
+    worst = {"sync": (0.0, -1), "ssc": (0.0, -1)}  # per pass (until round 5 the Thomson line repeated the Klein-Nishina maximum: VERDICT r05)
+    bad = 0
+    outside = []  # draws outside the reference's golden contract
     prms = []
     for i in range(n):
         jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]

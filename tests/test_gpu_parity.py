@@ -2067,13 +2067,15 @@ def _theta_nodes(eng, oracle, prm, t):
     return th, oracle.details(prm, t_min, t_max)["theta"]
 
 
-def _assert_same_grid_shapes(eng, oracle, draws, t, what, max_duplicate_draws=2):
+def _assert_same_grid_shapes(eng, oracle, draws, t, what, known_duplicate_draws=()):
     """Every draw: the six grid integers equal to the checker's.  ONE difference is legitimate and is checked for what it is: the
     reference's theta grid can carry a node one ulp away from its neighbour -- merge_grids keeps values that are not bit-equal
     (grid-refinement.h:362-393), and the last quantile of inverse_CFD_sampling, interpolated towards pow(10, log10(theta_max)), need not
     land on theta_max itself (:138-189) -- a zero-width bin that the engine's own last-bit arithmetic may or may not reproduce.  Such a
     draw must agree in every other integer and in the node count once nodes closer than 1e-12 (relative) to their neighbour are
-    counted once; the draws it happens on are few and are named in the assertion message if they are not."""
+    counted once.  The draws it is KNOWN to happen on are named by the caller (one in all the sweeps: draw 3 of the Klein-Nishina sweep, 38
+    nodes against 37); at most one draw beyond them may show it -- a library rebuilt with other last bits can move the coincidence to
+    another draw -- and the message names every draw that did."""
     dup = []
     for i, p in enumerate(draws):
         got, want = _grid_shapes(eng, oracle, p, t)
@@ -2088,7 +2090,9 @@ def _assert_same_grid_shapes(eng, oracle, draws, t, what, max_duplicate_draws=2)
         assert g["n_theta"] - distinct(th_g) + w["n_theta"] - distinct(th_w) == abs(g["n_theta"] - w["n_theta"]), msg
         assert g["n_reps"] - w["n_reps"] in (0, g["n_theta"] - w["n_theta"]), msg  # (representative rows: one per theta node, or unaffected)
         dup.append(i)
-    assert len(dup) <= max(max_duplicate_draws, len(draws) // 3), f"{what}: duplicate-node differences on draws {dup}"
+    new = sorted(set(dup) - set(known_duplicate_draws))
+    assert len(new) <= 1 and len(dup) <= len(known_duplicate_draws) + 1, \
+        f"{what}: duplicate-node differences on draws {dup} (known: {list(known_duplicate_draws)}, not known: {new})"
 
 
 @pytest.mark.parametrize("kn", [True, False], ids=["klein_nishina", "thomson"])
@@ -2096,7 +2100,7 @@ def test_random_forward_shock_ssc_draws_match_the_checker(eng, oracle, kn):
     import sweeps
     prms = sweeps.ssc_draws(16, kn)
     gate = _sweep_gate("sweep_ssc")
-    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "ssc " + ("kn" if kn else "thomson"))
+    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "ssc " + ("kn" if kn else "thomson"), known_duplicate_draws=(3,) if kn else ())
     sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
     report = []
     for i, p in enumerate(prms):
