@@ -152,3 +152,16 @@ def c3_batch(nb, seed=3):
         kw["rvs"] = dict(kw["rvs"], eps_B=kw["rvs"]["eps_B"] * j(), p=2.3 + rng.uniform(-0.1, 0.1))
         out.append(_abi.make_params(**kw))
     return out
+
+
+# Grids beyond what the grid kernel's two LDS layouts hold (round 6): the reference sizes its grids freely (grid-refinement.h:639-706).
+# tests/golden/make_big_grid_fixture.py runs the reference itself on them; the third needs ~2 minutes of CPU, hence a fixture.
+BIG_GRID_T = np.logspace(3, 7, 6)
+BIG_GRID_NU = np.array([1e9, 1e15])
+BIG_GRID_CASES = {
+    "theta_2000": dict(jet="GaussianJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, theta_obs=0.0, resolutions=(0.1, 25.0, 5.0)),
+    "time_10000": dict(C1A, resolutions=(0.1, 0.5, 1600.0)),
+    "theta_2000_time_10000": dict(jet="GaussianJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, theta_obs=0.0,
+                                  resolutions=(0.1, 25.0, 1600.0)),
+    "phi_3000_offaxis": dict(jet="GaussianJet", theta_c=0.1, E_iso=1e52, Gamma0=300.0, medium="ISM", n_ism=1.0, theta_obs=0.3, resolutions=(17.0, 0.31, 5.0)),
+}

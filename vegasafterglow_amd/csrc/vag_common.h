@@ -6,13 +6,16 @@
 
 // Static per-model capacities of the adaptive grid (src/core/grid-refinement.h:639-706 decides
 // the actual sizes at run time; these bound them).
-#define VAG_MAX_THETA 1280  // theta nodes per model (the large layout of the grid kernel; VagGridMeta::th_stride is the HBM stride of a batch)
-#define VAG_MAX_PHI 2560    // phi nodes per model
+#define VAG_MAX_THETA 1280  // theta nodes per model in the LARGE LDS layout of the grid kernel (VagGridMeta::th_stride is the HBM stride of a batch)
+#define VAG_MAX_PHI 2560    // phi nodes per model in that layout
+#define VAG_HUGE_THETA 16384  // the third layout (round 6): the grid kernel's scratch arrays in HBM instead of LDS, for models whose angular grids
+#define VAG_HUGE_PHI 32768    //   outgrow the large one (the reference sizes its grids freely, grid-refinement.h:639-706); node indices stay below 2^15
 #define VAG_GRID_THETA 256  // what the grid kernel's small (default) LDS layout holds; a batch that needs more is laid out again
 #define VAG_GRID_PHI 208    //   with the large layout (vag_grid_kernel<true>).  256 / 208 is 20 420 B of LDS: eight models per CU, as many
                             //   as the kernel's 206 VGPRs allow (320 / 640 was 27 KB: five; the configs' ensembles reach 177 / 191)
 #define VAG_ROWGEO_HDR 4    // doubles ahead of a model's row-geometry records (vag_grid_kernel.h writes them, the flux grid kernel reads them)
-#define VAG_MAX_TIME 8192   // time-lattice nodes per row (the flux kernels stage at most 512 at a time and take longer lattices in pieces)
+#define VAG_MAX_TIME (1 << 20)  // time-lattice nodes per row: no kernel holds a row at once (the flux kernels stage at most 512 nodes at a time and take
+                                // longer lattices in pieces), so this is a sanity bound on memory, not a layout limit (8192 until round 5)
 #define VAG_MAX_NU 64       // frequencies per grid call
 #define VAG_MAX_JUMPS 16
 

@@ -1097,8 +1097,12 @@ grid_model(SH& sh, const vag_model_params* __restrict__ params, int nb, const do
 // Two wavefronts per SIMD (second launch bound): left alone the compiler allocates 208 VGPRs + 49 AGPRs = 257 registers -- ONE more than
 // two resident wavefronts allow -- and a batch larger than the chip's 1024 SIMDs then runs its models one per SIMD, round after round
 // (4096 top-hat models: 0.52 ms of grid stage at 0.87 resident wavefronts per SIMD, profiles/debug/grid_occupancy.sh).
-template <bool LARGE>
-__global__ void __launch_bounds__(WAVE, LARGE ? 1 : 2)
+// LEVEL 0 / 1: the small / large scratch layout in LDS.  LEVEL 2 (round 6): the same wavefront program with its scratch arrays in HBM
+// (`scratch`, one GridSharedT<VAG_HUGE_THETA, VAG_HUGE_PHI> per model) -- for a batch in which some model outgrew the large layout; the
+// barriers between the program's phases order global memory within the workgroup as they order LDS.
+using GridSharedHuge = GridSharedT<VAG_HUGE_THETA, VAG_HUGE_PHI>;
+template <int LEVEL>
+__global__ void __launch_bounds__(WAVE, LEVEL == 0 ? 2 : 1)
 vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const double* __restrict__ tminmax,
                 VagGridMeta* meta, double* __restrict__ g_phi, double* __restrict__ g_theta,
                 int* __restrict__ g_rep_of, int* __restrict__ g_rep_start, double* __restrict__ g_tdec,
@@ -1106,11 +1110,17 @@ vag_grid_kernel(const vag_model_params* __restrict__ params, int nb, const doubl
                 int* __restrict__ done_counter /* zero between launches */, int* __restrict__ row_off,
                 long long* __restrict__ cell_off, VagDevPlan* __restrict__ plan, VagDevPlan* host_plan, int seq, int cap_rows,
                 long long cap_cells, int cap_k, int cap_pairs, int expect_flags, int expect_dyn, float* __restrict__ cost,
-                double* __restrict__ g_rowgeo) {
-    using Shared = typename std::conditional<LARGE, GridSharedT<VAG_MAX_THETA, VAG_MAX_PHI>, GridSharedT<VAG_GRID_THETA, VAG_GRID_PHI>>::type;
-    __shared__ Shared sh;  // declared here, not in grid_model: LDS of a device function is charged to every kernel of the module
-    if ((int)blockIdx.x < nb)
-        grid_model<Shared>(sh, params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail, g_rowgeo);
+                double* __restrict__ g_rowgeo, GridSharedHuge* scratch /* LEVEL 2: [nb] */) {
+    if constexpr (LEVEL == 2) {
+        if ((int)blockIdx.x < nb)
+            grid_model<GridSharedHuge>(scratch[blockIdx.x], params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph,
+                                       fail, g_rowgeo);
+    } else {
+        using Shared = typename std::conditional<LEVEL == 1, GridSharedT<VAG_MAX_THETA, VAG_MAX_PHI>, GridSharedT<VAG_GRID_THETA, VAG_GRID_PHI>>::type;
+        __shared__ Shared sh;  // declared here, not in grid_model: LDS of a device function is charged to every kernel of the module
+        if ((int)blockIdx.x < nb)
+            grid_model<Shared>(sh, params, nb, tminmax, meta, g_phi, g_theta, g_rep_of, g_rep_start, g_tdec, g_geo_th, g_geo_ph, fail, g_rowgeo);
+    }
     __shared__ int s_last;
     __threadfence();  // this model's results are visible device-wide before the ticket is taken
     __syncthreads();

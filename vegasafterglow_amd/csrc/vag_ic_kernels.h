@@ -296,6 +296,9 @@ VAG_DEV void log2_I_nu_ic_pair(const P1 c, int st, const P2 qv, int qst, const S
 // Doppler factor over all (phi, theta) rows.  D^-1 = Gamma - u cos_v is monotone in cos_v, so the extrema over phi
 // come from the extrema of cos_v per theta row.  One wavefront per model.
 // ------------------------------------------------------------------------------------------------
+// HUGE: a batch laid out with the grid kernel's third layout (more theta nodes than the LDS arrays below hold): the rows' extreme viewing
+// cosines go through `cv_scratch` [nb][2][th_stride] in HBM instead.
+template <bool HUGE>
 __global__ void __launch_bounds__(64)
 vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMeta* __restrict__ meta,
                    const double* __restrict__ geo_th, const double* __restrict__ geo_ph, const int* __restrict__ g_rep_of,
@@ -307,7 +310,8 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
                    int band_stride /* >= the longest lattice of the batch */,
                    const double* __restrict__ tminmax /* [2] extrema of the requested observer times [s] */,
                    unsigned char* __restrict__ need /* [cells], cleared by the caller, or nullptr: every cell gets a table */,
-                   double debug_need_shrink /* 1, or a test's factor on the window's upper end (forces a query of a skipped cell) */) {
+                   double debug_need_shrink /* 1, or a test's factor on the window's upper end (forces a query of a skipped cell) */,
+                   double* __restrict__ cv_scratch) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const VagGridMeta M = meta[m];
     if (M.status != 0) return;
@@ -328,7 +332,13 @@ vag_ic_band_kernel(const vag_model_params* __restrict__ params, const VagGridMet
         for (long long q = cell_off[m] + lane; q < cell_off[m + 1]; q += 64) need[q] = 1;
         need = nullptr;
     }
-    __shared__ double s_cvmin[VAG_MAX_THETA], s_cvmax[VAG_MAX_THETA];
+    __shared__ double s_cvmin_lds[HUGE ? 1 : VAG_MAX_THETA], s_cvmax_lds[HUGE ? 1 : VAG_MAX_THETA];
+    double* s_cvmin = s_cvmin_lds;
+    double* s_cvmax = s_cvmax_lds;
+    if constexpr (HUGE) {
+        s_cvmin = cv_scratch + (size_t)m * 2 * M.th_stride;
+        s_cvmax = s_cvmin + M.th_stride;
+    }
     const vag_model_params P = params[m];
     const double cos_obs = cos(P.theta_obs), sin_obs = sin(P.theta_obs);
     const double* gth = geo_th + (size_t)m * 3 * M.th_stride;
