@@ -852,7 +852,7 @@ def main():
                               np.mean(np.array(flux_ms), axis=0), plan, nnu, nt)
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh; FETCH_SIZE x2 per the gfx950 note, calibrated on a kernel with known bytes)
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tp) and nb == 512 and world == 1:
                 out["roofline"]["traffic"] = out["roofline_hbm"]["traffic"] = json.load(open(tp))["traffic_bytes_per_launch"]
@@ -861,7 +861,7 @@ def main():
                 break
         # VALU-pipe busy fractions of the kernels the rooflines name, from committed rocprofv3 --pmc passes (SQ_INSTS_VALU x 4 /
         # (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)): the machine's own view next to the convention-based `frac`s
-        for name in ("r05_valu_busy.json", "r04_valu_busy.json", "r03_valu_busy.json"):
+        for name in ("r06_valu_busy.json", "r05_valu_busy.json", "r04_valu_busy.json", "r03_valu_busy.json"):
             vp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(vp):
                 vb = json.load(open(vp))
