@@ -1120,16 +1120,28 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
         // persistent kernel whose lanes refill from a row queue and save inline (two integrators per SIMD instead of one integrator and
         // its saver); smaller ones keep the plain kernel, which is built for the latency of one row (no preparation pass on the chain).
         // Measured (profiles/r06_refill_probe.txt, C4 walkers, ODE stage plain / refill): 53.9 k rows 0.37 / 0.41 ms, 108.6 k rows
-        // 0.74 / 0.65, 433.8 k rows 2.28 / 1.86.  VAG_DYN_REFILL=0 / 1 forces either; same bits (tests/test_gpu_parity.py).
+        // 0.72 / 0.62, 218 k rows 1.22 / 0.89, 433.8 k rows 2.28 / 1.73.  The rows are queued longest first (vag_dyn_fast.h: a row's step
+        // count is predictable from its start record), by a counting sort of three small kernels.  VAG_DYN_REFILL=0 / 1 forces either; same bits (tests/test_gpu_parity.py).
         bool refill = rows >= 96 * 4LL * c->n_cus;
         if (const char* e = vag_hook("VAG_DYN_REFILL")) refill = std::atoi(e) != 0;
         if (refill) {
-            int refill_min = 8;  // finished lanes a wavefront collects before it takes new rows (a refill is ~200 instructions for the whole wavefront)
+            int refill_min = 16;  // finished lanes a wavefront collects before it takes new rows (a refill is ~200 instructions for the whole wavefront; 1 / 4 / 8 / 16: 1.97 / 1.80 / 1.80 / 1.73 ms per 8192 walkers)
             if (const char* e = vag_hook("VAG_DYN_REFILL_MIN")) refill_min = std::max(1, std::min(64, std::atoi(e)));
-            if (c->d_dynrec.ensure(sizeof(double) * (size_t)rows * DYN_ROWREC)) return VAG_E_HIP;
-            hipLaunchKernelGGL(vag_dyn_prep_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
+            // records | the sorted queue (rows ints) | the queue's two counters | histogram / offsets [DYN_BUCKETS][chunks] | length class per row
+            const size_t n_chunks = ((size_t)rows + DYN_CHUNK - 1) / DYN_CHUNK;
+            const size_t rec_bytes = sizeof(double) * (size_t)rows * DYN_ROWREC, ord_bytes = sizeof(int) * (((size_t)rows + 1) & ~(size_t)1);
+            const size_t hist_bytes = sizeof(unsigned) * DYN_BUCKETS * n_chunks;
+            if (c->d_dynrec.ensure(rec_bytes + ord_bytes + 16 + hist_bytes + (size_t)rows)) return VAG_E_HIP;
+            char* dyn_base = static_cast<char*>(c->d_dynrec.p);
+            int* d_dynorder = reinterpret_cast<int*>(dyn_base + rec_bytes);
+            unsigned* d_queue = reinterpret_cast<unsigned*>(dyn_base + rec_bytes + ord_bytes);
+            unsigned* d_hist = d_queue + 4;
+            signed char* d_cls = reinterpret_cast<signed char*>(dyn_base + rec_bytes + ord_bytes + 16 + hist_bytes);
+            hipLaunchKernelGGL(vag_dyn_prep_kernel, dim3((unsigned)n_chunks), dim3(DYN_CHUNK), 0, st, d_params, nb, c->d_meta.as<VagGridMeta>(),
                                c->d_theta.as<double>(), c->d_rep_start.as<int>(), c->d_tdec.as<double>(), lay, rows, c->d_shock.as<double>(), cells,
-                               c->d_row_status.as<int>(), c->d_dynrec.as<double>());
+                               c->d_row_status.as<int>(), c->d_dynrec.as<double>(), d_cls, d_hist);
+            hipLaunchKernelGGL(vag_dyn_scan_kernel, dim3(1), dim3(1024), 0, st, d_hist, (int)n_chunks, d_queue);
+            hipLaunchKernelGGL(vag_dyn_file_kernel, dim3((unsigned)n_chunks), dim3(DYN_CHUNK), 0, st, d_cls, d_hist, rows, d_dynorder);
             auto kern = c->count_work ? vag_dynamics_refill_kernel<true> : vag_dynamics_refill_kernel<false>;
             if (c->dyn_refill_wg_per_cu <= 0) {  // what the registers allow (two wavefronts per SIMD at <= 256 VGPRs)
                 int per_cu = 0;
@@ -1140,7 +1152,7 @@ int run_model_stages(vag_ctx* c, const vag_model_params* d_params, int nb, bool 
             if (const char* e = vag_hook("VAG_DYN_REFILL_WGS")) slots = std::max(1, std::atoi(e));
             const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>((rows + 63) / 64, slots));
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(64), 0, st, c->d_dynrec.as<double>(), rows, c->d_shock.as<double>(), cells,
-                               c->d_row_status.as<int>(), c->d_sptab.as<double>(), refill_min, c->d_fail.as<int>());
+                               c->d_row_status.as<int>(), c->d_sptab.as<double>(), refill_min, c->d_fail.as<int>(), d_queue, d_dynorder);
         } else {
         const int rpw = dyn_rows_per_wave(rows);
         hipLaunchKernelGGL(c->count_work ? vag_dynamics_fast_kernel<true> : vag_dynamics_fast_kernel<false>, dim3((rows + rpw - 1) / rpw),

@@ -442,6 +442,26 @@ VAG_DEV int fs_saver(DynRing& ring, int lane, bool active, int nt, Node& node, d
 // are an output anyway (VS_TENG).  ("persistent-lane work queue"; forward-shock.tpp:194-207 is the loop over rows.)
 // ------------------------------------------------------------------------------------------------
 constexpr int DYN_ROWREC = 20;  // doubles per row record
+// The row queue is ordered: longest rows first.  A row's step count is predictable from its start record -- on 7111 rows of an
+// 8192-walker configs[3] step (18 ... 134 steps, standard deviation 27) a linear form in ln Gamma0, ln(Gamma0 - 1), ln rho and ln m_jet
+// leaves a residual of 1.1 steps (profiles/r06_row_attempts.txt) -- so vag_dyn_prep_kernel files every row under its predicted length
+// (DYN_BUCKETS lists of 8 steps each) and the wavefronts empty the lists from the longest down: a wavefront's 64 rows are of one
+// length (few lanes wait for a straggler), and what is still running when the lists are empty are the SHORT rows (LPT scheduling).
+// The prediction only orders work: a poor one costs time, never a bit.
+// The queue is ONE array in that order, made by a counting sort that keeps neighbours together (vag_dyn_prep_kernel: histogram per chunk of
+// 256 rows in LDS; vag_dyn_scan_kernel: offsets, longest class first, chunks in order inside a class; vag_dyn_file_kernel: scatter), so
+// the 64 rows a wavefront holds come from a window of a few thousand rows of the batch.  Two simpler forms lost: sixteen lists filled
+// by atomics (arrival order: a wavefront's lanes then saved into 64 unrelated places of seven 135 MB arrays, the kernel ran at 11 % of
+// the VALU issue slots, and 433 k insertions on sixteen counters cost another 0.8 ms: 6.0 against 1.86 ms per 8192 walkers), and lists
+// per chunk walked by the wavefronts (2.95 ms with 4096-row chunks, 18.7 with 256-row ones: finding the next non-empty list is a chain
+// of dependent loads).
+constexpr int DYN_BUCKETS = 16;
+constexpr int DYN_CHUNK = 256;  // rows per chunk = the preparation kernel's workgroup
+VAG_DEV int dyn_row_bucket(double Gamma0, double rho, double m_jet) {
+    const double pred = 101.1 + 7.43 * log(Gamma0) + 3.04 * log(fmax(Gamma0 - 1, 1e-12)) + 1.81 * (log(rho) - log(m_jet));
+    const int b = (int)(pred * 0.125);
+    return pred == pred ? (b < 0 ? 0 : (b > DYN_BUCKETS - 1 ? DYN_BUCKETS - 1 : b)) : DYN_BUCKETS - 1;
+}
 enum {
     DR_X = 0,       // Gamma, m2, U, r, t_comv at t0 (set_init_state)
     DR_T0 = 5,
@@ -453,7 +473,9 @@ enum {
 };
 
 template <bool TALLY>
-VAG_DEV void fs_solver_refill(const double* __restrict__ rowrec, int n_rows, unsigned* __restrict__ queue, int refill_min, LdsTab lg, int lane,
+VAG_DEV void fs_solver_refill(const double* __restrict__ rowrec, int n_rows,
+                              unsigned* __restrict__ queue /* [0] rows in the sorted queue, [1] rows taken */,
+                              const int* __restrict__ order /* the queue: rows, longest predicted first */, int refill_min, LdsTab lg, int lane,
                               double* __restrict__ shock, long long n_cells, int* __restrict__ row_status, int* __restrict__ fail,
                               unsigned long long* __restrict__ tally) {
     constexpr int N = 5;
@@ -492,6 +514,13 @@ VAG_DEV void fs_solver_refill(const double* __restrict__ rowrec, int n_rows, uns
         row_status[row] = status;
         if (status > 0 && status < 4) atomicAdd(fail + status, 1);
         if constexpr (TALLY) rhs_sum += (unsigned long long)(1 + 6 * (steps + n_rej));
+#ifdef VAG_DYN_ROWSTATS  // developer aid: what predicts a row's attempt count? (profiles/debug/row_attempts.py)
+        if (row % 61 == 0) {
+            const double* r = rowrec + (size_t)row * DYN_ROWREC;
+            printf("R %d steps %d G0 %.6e t0 %.6e tlast %.6e mjet %.6e rho %.6e A %.6e nt %d\n", row, steps, r[DR_X], r[DR_T0], r[DR_TLAST], r[DR_EQ], r[DR_EQ + 5],
+                   r[DR_EQ + 6], nt);
+        }
+#endif
         row = -1;
     };
     for (;;) {
@@ -500,11 +529,16 @@ VAG_DEV void fs_solver_refill(const double* __restrict__ rowrec, int n_rows, uns
         if (!drained && n_done >= refill_min) {
             if (done && row >= 0) retire();
             const int first = __ffsll((long long)mdone) - 1;
-            unsigned base = 0;
-            if (lane == first) base = atomicAdd(queue, (unsigned)n_done);
+            unsigned base = 0, filed = 0;
+            if (lane == first) {
+                base = atomicAdd(queue + 1, (unsigned)n_done);
+                filed = queue[0];
+            }
             base = (unsigned)__shfl((int)base, first);
-            if (base + (unsigned)n_done >= (unsigned)n_rows) drained = true;
-            const long long mine = done ? (long long)base + __popcll(mdone & ((1ull << lane) - 1ull)) : -1;
+            filed = (unsigned)__shfl((int)filed, first);
+            if (base + (unsigned)n_done >= filed) drained = true;
+            const unsigned slot = base + (unsigned)__popcll(mdone & ((1ull << lane) - 1ull));
+            const long long mine = done && slot < filed ? order[slot] : -1;
             if (mine >= 0 && mine < n_rows) {
                 const double* r = rowrec + (size_t)mine * DYN_ROWREC;
                 const int state = __double2hiint(r[DR_NT]);

@@ -385,25 +385,26 @@ vag_dynamics_fast_kernel(const vag_model_params* __restrict__ params, int nb, co
 // The same solve for batches that fill the GPU several times over: persistent single-wavefront workgroups whose lanes take rows from a
 // device counter and save inline (vag_dyn_fast.h, "lane refill").  vag_dyn_prep_kernel prepares every row's start -- one lane per row,
 // the expressions of the kernel above -- as a 160-byte record, writes the row's node times (an output of the stage) and finishes the
-// rows that need no solve (a stopped shock); vag_dynamics_refill_kernel integrates and saves.
+// rows that need no solve (a stopped shock); vag_dyn_scan_kernel / vag_dyn_file_kernel order the row queue by predicted length (counting
+// sort over the preparation's per-chunk histograms); vag_dynamics_refill_kernel integrates and saves.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-vag_dyn_prep_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
-                    const double* __restrict__ g_theta, const int* __restrict__ g_rep_start, const double* __restrict__ g_tdec,
-                    Layout lay, int n_rows, double* __restrict__ shock, long long n_cells, int* __restrict__ row_status,
-                    double* __restrict__ rowrec) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+// one row's start record, node times and -- for a stopped shock -- its whole output; returns the row's length class, or -1 for a row
+// the solver has nothing to do for
+VAG_DEV int dyn_prep_row(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                         const double* __restrict__ g_theta, const int* __restrict__ g_rep_start, const double* __restrict__ g_tdec,
+                         Layout lay, int n_rows, double* __restrict__ shock, long long n_cells, int* __restrict__ row_status,
+                         double* __restrict__ rowrec, int row) {
+    if (row >= n_rows) return -1;
     double* rec = rowrec + (size_t)row * DYN_ROWREC;
     if (row >= lay.row_off[nb]) {
         rec[DR_NT] = __hiloint2double(2, 0);
-        return;
+        return -1;
     }
     const int m = find_model(lay.row_off, nb, row);
     const VagGridMeta M = meta[m];
     if (M.status != 0) {
         rec[DR_NT] = __hiloint2double(2, 0);
-        return;
+        return -1;
     }
     const int nt = M.n_t;
     const int r = row - lay.row_off[m];
@@ -461,7 +462,65 @@ vag_dyn_prep_kernel(const vag_model_params* __restrict__ params, int nb, const V
             o[VS_NP * n_cells + k] = 0;
         }
         row_status[row] = 0;
+        return -1;
     }
+    return dyn_row_bucket(Gamma4, fma(rec[DR_EQ + 6], 1.0 / fma(s[3], s[3], rec[DR_EQ + 7]), med.rho_ism), rec[DR_EQ + 0]);
+}
+
+__global__ void __launch_bounds__(DYN_CHUNK)
+vag_dyn_prep_kernel(const vag_model_params* __restrict__ params, int nb, const VagGridMeta* __restrict__ meta,
+                    const double* __restrict__ g_theta, const int* __restrict__ g_rep_start, const double* __restrict__ g_tdec,
+                    Layout lay, int n_rows, double* __restrict__ shock, long long n_cells, int* __restrict__ row_status,
+                    double* __restrict__ rowrec, signed char* __restrict__ cls /* [rows] length class of the row, -1: not in the queue */,
+                    unsigned* __restrict__ hist /* [DYN_BUCKETS][chunks] rows of the class in the chunk */) {
+    __shared__ unsigned s_hist[DYN_BUCKETS];
+    if (threadIdx.x < DYN_BUCKETS) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int row = blockIdx.x * DYN_CHUNK + threadIdx.x;
+    const int bucket = dyn_prep_row(params, nb, meta, g_theta, g_rep_start, g_tdec, lay, n_rows, shock, n_cells, row_status, rowrec, row);
+    if (row < n_rows) cls[row] = (signed char)bucket;
+    if (bucket >= 0) atomicAdd(&s_hist[bucket], 1u);
+    __syncthreads();
+    if (threadIdx.x < DYN_BUCKETS) hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// exclusive offsets of the (class, chunk) groups in queue order -- longest class first, chunks ascending inside a class -- in place;
+// queue[0] = rows in the queue, queue[1] = 0 (rows taken).  One workgroup: the histogram is 16 x (rows / 256) counts.
+__global__ void __launch_bounds__(1024)
+vag_dyn_scan_kernel(unsigned* __restrict__ hist, int n_chunks, unsigned* __restrict__ queue) {
+    __shared__ unsigned s_part[1024];
+    const int n = DYN_BUCKETS * n_chunks, tid = threadIdx.x;
+    // element e of the scan = (class DYN_BUCKETS - 1 - e / n_chunks, chunk e % n_chunks); a thread owns a contiguous run of elements
+    const int per = (n + 1023) / 1024, e0 = tid * per, e1 = min(n, e0 + per);
+    auto at = [&](int e) -> unsigned& { return hist[(size_t)(DYN_BUCKETS - 1 - e / n_chunks) * n_chunks + e % n_chunks]; };
+    unsigned sum = 0;
+    for (int e = e0; e < e1; ++e) sum += at(e);
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele over the 1024 partial sums
+        const unsigned v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;  // exclusive
+    for (int e = e0; e < e1; ++e) {
+        const unsigned c = at(e);
+        at(e) = run;
+        run += c;
+    }
+    if (tid == 1023) queue[0] = s_part[1023], queue[1] = 0;
+}
+
+__global__ void __launch_bounds__(DYN_CHUNK)
+vag_dyn_file_kernel(const signed char* __restrict__ cls, const unsigned* __restrict__ offs /* [DYN_BUCKETS][chunks] */, int n_rows,
+                    int* __restrict__ order) {
+    __shared__ unsigned s_next[DYN_BUCKETS];
+    if (threadIdx.x < DYN_BUCKETS) s_next[threadIdx.x] = offs[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * DYN_CHUNK + threadIdx.x;
+    const int b = row < n_rows ? cls[row] : -1;
+    if (b >= 0) order[atomicAdd(&s_next[b], 1u)] = row;  // (the order inside a (class, chunk) group is the atomics': rows are independent)
 }
 
 #ifndef VAG_DYN_REFILL_WAVES
@@ -471,7 +530,8 @@ template <bool TALLY>
 __global__ void __launch_bounds__(64, VAG_DYN_REFILL_WAVES)
 vag_dynamics_refill_kernel(const double* __restrict__ rowrec, int n_rows, double* __restrict__ shock, long long n_cells,
                            int* __restrict__ row_status, const double* __restrict__ sp_table, int refill_min,
-                           int* __restrict__ fail /* [16]: [1..3] failures, 64-bit tallies at fail + 8, the row queue at fail + 14 */) {
+                           int* __restrict__ fail /* [16]: [1..3] failures, 64-bit tallies at fail + 8 */,
+                           unsigned* __restrict__ queue, const int* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) double s_lg[LOG_TAB_DOUBLES];
     const int lane = threadIdx.x;
     for (int i = lane; i < LOG_TAB_DOUBLES; i += 64) s_lg[i] = sp_table[SP_TABLE_DOUBLES + i];
@@ -484,8 +544,8 @@ vag_dynamics_refill_kernel(const double* __restrict__ rowrec, int n_rows, double
                (hw >> 4) & 3, hw & 15);
     }
 #endif
-    fs_solver_refill<TALLY>(rowrec, n_rows, reinterpret_cast<unsigned*>(fail + 14), refill_min, lds_tab(s_lg), lane, shock, n_cells, row_status,
-                            fail, reinterpret_cast<unsigned long long*>(fail + 8));
+    fs_solver_refill<TALLY>(rowrec, n_rows, queue, order, refill_min, lds_tab(s_lg), lane, shock, n_cells, row_status, fail,
+                            reinterpret_cast<unsigned long long*>(fail + 8));
 }
 
 // ------------------------------------------------------------------------------------------------
