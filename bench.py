@@ -496,9 +496,11 @@ def walker_bench(lib, h, _lib, dev, rank, world, steps=10, nwalkers=1024, sharde
             "achieved": tf(f_flux + f_ode, 1e3 * dt / steps), "frac": tf(f_flux + f_ode, 1e3 * dt / steps) / PEAK_FP64_TFLOPS,
             "note": "whole step (grid, ODE, cells, flux, chi^2 and the host's read of ln L) against the flux + ODE work",
             "vag_flux_fit_rows_kernel": {"ms": st.flux_ms, "achieved": tf(f_flux, st.flux_ms), "frac": tf(f_flux, st.flux_ms) / PEAK_FP64_TFLOPS},
-            "vag_dynamics_fast_kernel": {"ms": st.dynamics_ms, "achieved": tf(f_ode, st.dynamics_ms), "frac": tf(f_ode, st.dynamics_ms) / PEAK_FP64_TFLOPS,
-                                         "note": "a latency chain (one lane per row, ~110 dependent steps): the fraction says how little of the "
-                                                 "chip a 1024-walker batch's ODE rows can occupy, not how the kernel issues"}}
+            # the ODE stage: vag_dynamics_fast_kernel (a latency chain: one lane per row, ~110 dependent steps -- on a 1024-walker batch the
+            # fraction says how little of the chip 53.9 k rows can occupy, not how the kernel issues), or from 98 k rows on the persistent
+            # lane-refill kernel with its preparation and queue-sorting launches
+            "ode_stage": {"kernel": "vag_dynamics_refill_kernel (+ prep / scan / file)" if plan.n_rows >= 96 * 4 * 256 else "vag_dynamics_fast_kernel",
+                          "ms": st.dynamics_ms, "achieved": tf(f_ode, st.dynamics_ms), "frac": tf(f_ode, st.dynamics_ms) / PEAK_FP64_TFLOPS}}
     return res
 
 
