@@ -9,9 +9,9 @@ SSC_T, SSC_NU = np.logspace(1.5, 7.5, 30), np.array([1e9, 4.84e14, 1e18, 2.4e22,
 RS_T, RS_NU = np.logspace(1.5, 7.5, 36), np.array([1e9, 4.84e14, 1e18, 2.4e24])
 
 
-def ssc_draws(n, kn):
+def ssc_draws(n, kn, seed=4242):
     """Forward shock with SSC: the n Klein-Nishina draws (kn=True) or the n Thomson draws that follow them in the stream."""
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(seed)
     sets = {}
     for flag in (True, False):
         prms = []
@@ -31,9 +31,9 @@ def ssc_draws(n, kn):
     return sets[bool(kn)]
 
 
-def rs_ssc_draws(n):
+def rs_ssc_draws(n, seed=777):
     """Forward + reverse shock, SSC with Klein-Nishina on both."""
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(seed)
     prms = []
     for i in range(n):
         jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]
@@ -50,10 +50,10 @@ def rs_ssc_draws(n):
 NONAXI_T, NONAXI_NU = np.logspace(2.5, 7.5, 28), np.array([1e9, 4.84e14, 1e18])
 
 
-def nonaxi_spread_draws(n):
+def nonaxi_spread_draws(n, seed=2024):
     """Model(axisymmetric=False) with a spreading jet -- one lattice and one blast-wave solve per (phi, theta) node -- over the jet
     profiles; every fourth draw carries a reverse shock."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     prms = []
     for i in range(n):
         jet = ["TophatJet", "GaussianJet", "PowerLawJet", "TwoComponentJet"][i % 4]
@@ -71,11 +71,11 @@ def nonaxi_spread_draws(n):
     return prms
 
 
-def spread_ssc_draws(n):
+def spread_ssc_draws(n, seed=4242):
     """Axisymmetric jets with lateral spreading and SSC (Klein-Nishina) over all six jet profiles: the first n draws of
     `SWEEP_MODE=spread python profiles/debug/prior_sweep_ssc.py n` (draw 13 of the 30-draw stream is the Gaussian jet in a dense wind
     whose rows arrive earlier from later nodes: tests/test_gpu_parity.py pins it by name as well)."""
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(seed)
     prms = []
     for i in range(n):
         jet = ["TophatJet", "GaussianJet", "PowerLawJet"][i % 3]

@@ -2210,6 +2210,70 @@ def test_random_forward_shock_ssc_draws_match_the_checker(eng, oracle, kn):
     assert np.median([r[1] for r in report]) < 1e-8  # the bulk agrees far below the gate
 
 
+@pytest.mark.parametrize("seed", [60001, 60002, 60003])
+def test_fresh_seed_draws_of_every_sweep_stay_inside_the_reference_contract(eng, oracle, seed):
+    """The sweeps above are held to what the reference demonstrates on their sixteen named draws (a fixture from its own builds).  Here:
+    three further seeds of each of the four generators -- 24 Klein-Nishina + 24 Thomson forward-shock SSC draws, 12 forward + reverse
+    shock draws with SSC + KN on both, 12 spreading SSC draws over all six jets, 6 (phi, theta) pair-row draws: 234 models no earlier test
+    or recorded sweep has seen -- against the checker under the reference's own golden contract, every component finite, the grid
+    integers equal (up to the one-ulp twin node of top-hat jets: distinct theta nodes equal), and the forward-shock synchrotron
+    component of the 144 non-spreading forward-shock draws to max(1e-6, 3 x what the REFERENCE demonstrates on that draw) over the bins
+    above 1e-3 of the peak (tests/golden/fresh_seed_sensitivity.json from its own two builds: build spread and one-ulp response; 138 of
+    the 144 demonstrate < 1e-7, a top hat seen from inside its cone 1.3e-4 -- the engine is at 3.1e-4 there), the median below 1e-8."""
+    import json
+    import sweeps
+    errs = []
+    dem = json.load(open(os.path.join(_abi.ROOT, "tests", "golden", "fresh_seed_sensitivity.json")))["demonstrated"]
+
+    def check(name, got, want, tight):
+        assert np.all(np.isfinite(got)), name
+        if want.max() <= 0:
+            assert got.max() <= 0, name
+            return
+        assert _within_golden_contract(got, want), name
+        m = want > 1e-3 * want.max()
+        e = float(np.max(np.abs(got - want)[m] / want[m]))
+        if tight is not None:
+            assert e <= max(1e-6, 3 * dem[tight]), (name, e, dem[tight])
+            errs.append(e)
+
+    def shapes(prm, t, name):
+        g, w = _grid_shapes(eng, oracle, prm, t)
+        if g != w:  # the twin node (see _assert_same_grid_shapes)
+            th_g, th_w = _theta_nodes(eng, oracle, prm, t)
+            distinct = lambda th: 1 + int(np.sum(np.diff(th) > 1e-12 * th[1:]))
+            assert distinct(th_g) == distinct(th_w) and g[0] == w[0] and g[2] == w[2] and g[4:] == w[4:], (name, g, w)
+
+    for kn in (True, False):
+        prms = sweeps.ssc_draws(24, kn, seed=seed)
+        sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
+        for i, p in enumerate(prms):
+            want = oracle.flux_components(p, sweeps.SSC_T, sweeps.SSC_NU)
+            check(f"ssc kn={kn} #{i} sync", sync[i], want[0], f"{seed}_{'kn' if kn else 'thomson'}_{i}")
+            check(f"ssc kn={kn} #{i} ssc", ssc[i], want[1], None)
+            shapes(p, sweeps.SSC_T, f"ssc kn={kn} #{i}")
+    prms = sweeps.rs_ssc_draws(12, seed=seed)
+    comps = gpu_components4(eng, prms, sweeps.RS_T, sweeps.RS_NU)
+    for i, p in enumerate(prms):
+        want = oracle.flux_components4(p, sweeps.RS_T, sweeps.RS_NU)
+        for c, name in enumerate(("fwd.sync", "fwd.ssc", "rvs.sync", "rvs.ssc")):
+            check(f"rs #{i} {name}", comps[c][i], want[c], None)
+        shapes(p, sweeps.RS_T, f"rs #{i}")
+    prms = sweeps.spread_ssc_draws(12, seed=seed)
+    sync, ssc = gpu_components(eng, prms, sweeps.SSC_T, sweeps.SSC_NU)
+    for i, p in enumerate(prms):
+        want = oracle.flux_components(p, sweeps.SSC_T, sweeps.SSC_NU)
+        check(f"spread #{i} sync", sync[i], want[0], None)
+        check(f"spread #{i} ssc", ssc[i], want[1], None)
+    prms = sweeps.nonaxi_spread_draws(6, seed=seed)
+    comps = gpu_components4(eng, prms, sweeps.NONAXI_T, sweeps.NONAXI_NU)
+    for i, p in enumerate(prms):
+        want = oracle.flux_components4(p, sweeps.NONAXI_T, sweeps.NONAXI_NU)
+        for c in range(4):
+            check(f"nonaxi #{i} component {c}", comps[c][i], want[c], None)
+    assert len(errs) == 48 and np.median(errs) < 1e-8
+
+
 def test_random_forward_reverse_shock_ssc_draws_match_the_checker(eng, oracle):
     import sweeps
     prms = sweeps.rs_ssc_draws(16)
