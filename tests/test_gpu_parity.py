@@ -1472,7 +1472,9 @@ def test_grids_beyond_the_lds_layouts_match_the_reference(eng, oracle, case):
 
 def test_the_grid_kernels_third_layout_gives_the_bits_of_the_lds_layouts(eng):
     """The grid kernel's scratch arrays in HBM (VAG_GRID_FORCE_LARGE=2) instead of LDS: the same program, the same numbers -- every
-    grid array and the fluxes of a mixed batch (all six jets, on and off axis, a reverse shock, SSC) bit for bit."""
+    grid array and the fluxes of a mixed batch (all six jets, on and off axis) bit for bit; and, downstream of it, everything that is
+    strided by the layout: an SSC + Klein-Nishina batch with a reverse shock (the SSC band kernel then keeps its per-theta extrema in
+    HBM) and a spreading SSC jet."""
     rng = np.random.default_rng(8)
     t, nu = np.logspace(3, 7, 10), np.array([1e9, 1e15])
     prms = []
@@ -1481,20 +1483,27 @@ def test_the_grid_kernels_third_layout_gives_the_bits_of_the_lds_layouts(eng):
         if jet in ("TwoComponentJet", "StepPowerLawJet", "PowerLawWing"):
             kw.update(theta_w=kw["theta_c"] * 2.5, E_iso_w=kw["E_iso"] * 0.05, Gamma0_w=30.0)
         prms.append(_abi.make_params(**kw))
-    small = gpu_grid(eng, prms, t, nu)
-    shapes = [_grid_arrays(eng, p, t) for p in prms]
+    ssc = [_abi.make_params(**dict(configs.C3, theta_obs=0.1 * k)) for k in range(3)]
+    spread = [_abi.make_params(jet="GaussianJet", theta_obs=0.15, spreading=True, ssc=True)]
+
+    def everything():
+        out = [gpu_grid(eng, prms, t, nu)]
+        out += list(gpu_components4(eng, ssc, configs.C3_T[::5], configs.C3_NU))
+        out += list(gpu_components(eng, spread, t, nu))
+        out += [a for p in prms for a in _grid_arrays(eng, p, t)]
+        return out
+
+    small = everything()
     _lib.hooks["VAG_GRID_FORCE_LARGE"] = "2"
     try:
-        huge = gpu_grid(eng, prms, t, nu)
-        shapes_huge = [_grid_arrays(eng, p, t) for p in prms]
+        huge = everything()
     finally:
         _lib.hooks.pop("VAG_GRID_FORCE_LARGE")
         for _ in range(9):
             gpu_grid(eng, prms[0], t, nu)  # back to the small layout
-    assert np.array_equal(small, huge)
-    for a, b in zip(shapes, shapes_huge):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
+    assert len(small) == len(huge) and small[1].max() > 0 and small[2].max() > 0 and small[4].max() > 0
+    for a, b in zip(small, huge):
+        assert np.array_equal(a, b, equal_nan=True)
 
 
 def _engine_shape(eng, prm, t):
