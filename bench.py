@@ -190,7 +190,7 @@ def tophat_sweep(lib, h, _lib, dev, with_cpu):
     import configs
     out = {}
     t, nu = configs.C1_T, configs.C1_NU
-    for name, kw, batches in (("C1a_onaxis", configs.C1A, (1, 64, 1024, 4096)), ("C1b_theta_obs_0.05", configs.C1B, (1, 64, 1024))):
+    for name, kw, batches in (("C1a_onaxis", configs.C1A, (1, 64, 1024, 4096, 16384)), ("C1b_theta_obs_0.05", configs.C1B, (1, 64, 1024))):
         res = {}
         for nb in batches:
             rng = np.random.default_rng(1)
