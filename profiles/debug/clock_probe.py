@@ -61,6 +61,31 @@ clk = [c for c, _ in out if isinstance(c, int)]
 pw = [p for _, p in out if isinstance(p, float)]
 print(f"headline (512 configs[1] models per call): {n} calls, {1e3 * dt:.3f} ms per call; sclk samples {len(clk)}: mean {np.mean(clk):.0f} MHz min {min(clk)}; power mean {np.mean(pw):.0f} W max {max(pw):.0f}", flush=True)
 
+def sampled_loop(label, fn, seconds=4.0):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    stop, out = threading.Event(), []
+    th = threading.Thread(target=sample, args=(stop, out))
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        fn()
+        torch.cuda.synchronize()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    stop.set()
+    th.join()
+    clk = [c for c, _ in out if isinstance(c, int)]
+    pw = [p for _, p in out if isinstance(p, float)]
+    print(f"{label}: {n} calls, {1e3 * dt:.3f} ms per call; sclk samples {len(clk)}: mean {np.mean(clk):.0f} MHz min {min(clk)}; power mean {np.mean(pw):.0f} W max {max(pw):.0f}", flush=True)
+
+
+if nw >= 8192:  # the SSC ensembles of the bench as well
+    t_e, nu_e = np.logspace(2, 8, 100), np.array([1e9, 4.84e14, 1e18, 2.4e26])
+    sampled_loop("configs[2] (512 models per call)", bench._grid_call(lib, h, _lib, dev, configs.c3_batch(512), t_e, nu_e))
+    sampled_loop("configs[4] (1024 members per call)", bench._grid_call(lib, h, _lib, dev, configs.c5_batch(1024), t_e, nu_e))
+
 for mode in ("0", "1", "0", "1"):
     _lib.hooks["VAG_DYN_REFILL"] = mode
     for _ in range(3):
