@@ -2899,22 +2899,6 @@ static int upload_fit_spec(vag_ctx* c, const vag_fit_spec* spec, int ndim) {
 // The front of a likelihood call, one launch: bounds mask and ln prior (log_prob_batch, fitting/samplers.py:72-91), the
 // transformer of fitting/utils.py:110-135 (theta[nb][ndim] -> params[nb], 10^theta for log-scale parameters), A_V per walker,
 // and -- block 0 -- log2 of the point data's times / frequencies and their time extrema for the grid stage.
-// order_out[rank] = walker, ranks by descending cost of the walker in THIS call (cost[] is in evaluation-slot order: order_in maps
-// a slot back to its walker; null = identity).  Ranking by counting, one wavefront per slot: the lanes compare it with all others.
-__global__ void __launch_bounds__(256)
-vag_order_kernel(const float* __restrict__ cost, const int* __restrict__ order_in, int nb, int* __restrict__ order_out) {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= nb) return;
-    const float mine = cost[m];
-    int rank = 0;
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-        const int i = i0 + lane;
-        const float c = i < nb ? cost[i] : -1.0f;
-        rank += __popcll(__ballot(c > mine || (c == mine && i < m)));
-    }
-    if (lane == 0) order_out[rank] = order_in ? order_in[m] : m;
-}
-
 __global__ void __launch_bounds__(128)
 vag_fit_front_kernel(vag_model_params base, const double* __restrict__ theta, int nb, int ndim, const double* __restrict__ prior,
                      int use_priors, double a_v_fixed, vag_model_params* __restrict__ out, double* __restrict__ a_v,
@@ -2987,8 +2971,23 @@ vag_fit_back_kernel(const double* __restrict__ flux /* [nb][n] */, int n, const 
                     const int* __restrict__ row_off, const int* __restrict__ ic_status /* or null */, double* __restrict__ chi2,
                     int* __restrict__ valid, const double* __restrict__ ln_prior, int first, int last, double* __restrict__ out,
                     int* __restrict__ fitstat /* [0] walkers scored -inf, [1] of those: SSC table failures */,
-                    const int* __restrict__ order /* evaluation slot -> walker, or null */) {
+                    const int* __restrict__ order /* evaluation slot -> walker, or null */,
+                    const float* __restrict__ cost /* with next_order: the slots' costs of THIS call (the grid kernel's plan scan leaves them) */,
+                    int nb, int* __restrict__ next_order /* or null: [rank] = walker, descending cost */) {
     const int m = blockIdx.x, lane = threadIdx.x;
+    // next_order[rank] = walker, ranks by descending cost of the slot in THIS call (cost[] is in evaluation-slot order: `order` maps a slot
+    // back to its walker; null = identity).  Ranking by counting: the lanes compare this wavefront's slot with all others.  (Until round 5
+    // a launch of its own, vag_order_kernel, behind this kernel.)
+    if (next_order) {
+        const float mine = cost[m];
+        int rank = 0;
+        for (int i0 = 0; i0 < nb; i0 += 64) {
+            const int i = i0 + lane;
+            const float c = i < nb ? cost[i] : -1.0f;
+            rank += __popcll(__ballot(c > mine || (c == mine && i < m)));
+        }
+        if (lane == 0) next_order[rank] = order ? order[m] : m;
+    }
     const double av = (ext != nullptr) ? a_v[m] : 0.0;
     const bool grid_ok = meta[m].status == 0;
     double s = 0;
@@ -3046,14 +3045,14 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
                        c->d_lg2t.as<double>(), c->d_lg2nu.as<double>(), c->d_tminmax.as<double>(), d_order);
     HIPCHK(hipGetLastError());
     bool order_made = false;
-    auto make_order = [&]() -> int {  // once per call, from the first pass's grids: the order the NEXT call evaluates in
-        if (!can_order || order_made) return VAG_OK;
-        order_made = true;
+    // once per call, from the first pass's grids: the order the NEXT call evaluates in -- made by the first back kernel (its wavefronts are
+    // one per evaluation slot: no launch of its own on the call's critical path since round 6)
+    auto next_order = [&]() -> int* {
+        if (!can_order || order_made) return nullptr;
         DevBuf& nxt = c->d_order[c->order_cur ^ 1];
-        if (nxt.ensure(sizeof(int) * (size_t)nb)) return VAG_E_HIP;
-        hipLaunchKernelGGL(vag_order_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, c->d_cost_f.as<float>(), d_order, nb, nxt.as<int>());
-        HIPCHK(hipGetLastError());
-        return VAG_OK;
+        if (nxt.ensure(sizeof(int) * (size_t)nb)) return nullptr;
+        order_made = true;
+        return nxt.as<int>();
     };
     const int n_pass = (n > 0 ? 1 : 0) + spec->n_bands;
     int pass = 0, n_cap = 0, n_inv = 0;  // per-pass rejection counts: the call reports the worst pass
@@ -3063,9 +3062,9 @@ static int loglike_body(vag_ctx* c, const vag_fit_spec* spec, const double* d_th
         hipLaunchKernelGGL(vag_fit_back_kernel, dim3(nb), dim3(64), 0, st, flux, npts, lnf, lne, w, ext, d_av,
                            c->d_meta.as<VagGridMeta>(), c->d_row_status.as<int>(), c->d_row_off.as<int>(),
                            (ssc && c->d_icstatus.p) ? c->d_icstatus.as<int>() : nullptr, d_chi2, c->d_valid.as<int>(), d_lp,
-                           pass == 0 ? 1 : 0, pass == n_pass - 1 ? 1 : 0, d_out, c->d_fitstat.as<int>(), d_order);
+                           pass == 0 ? 1 : 0, pass == n_pass - 1 ? 1 : 0, d_out, c->d_fitstat.as<int>(), d_order, c->d_cost_f.as<float>(), nb,
+                           next_order());
         HIPCHK(hipGetLastError());
-        if (int rco = make_order()) return rco;
         ++pass;
         n_cap = std::max(n_cap, c->plan.n_models_capacity);
         n_inv = std::max(n_inv, c->plan.n_models_invalid);

@@ -125,8 +125,8 @@ class WalkerSharder:
         if theta.dim() != 2:
             raise ValueError("theta must be [nb, ndim]")
         nb = theta.shape[0]
-        if not (dist.is_available() and dist.is_initialized()):
-            values, _ = self.eval_dev(theta)
+        if not (dist.is_available() and dist.is_initialized()):  # one process: nothing to deal, so no cost report is asked for
+            values, _ = self.eval_dev(theta, want_costs=False) if getattr(self.eval_dev, "optional_costs", False) else self.eval_dev(theta)
             return values
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         d = self._deal(nb, world, rank)

@@ -502,17 +502,19 @@ class Fitter:
                 finally:
                     lib.vag_ctx_set_stream(h, prev)
 
-        def eval_dev(theta):
+        def eval_dev(theta, want_costs=True):
             theta = theta.contiguous()
             k = theta.shape[0]
             values = torch.empty((k,), dtype=torch.float64, device=dev)
-            costs = torch.empty((k,), dtype=torch.float64, device=dev)
+            costs = torch.empty((k,), dtype=torch.float64, device=dev) if want_costs else None
 
             def run():
                 _lib.check(lib.vag_loglike_batch_dev(h, C.byref(keep[0]), theta.data_ptr(), k, keep[0].ndim, values.data_ptr()))
-                _lib.check(lib.vag_last_model_costs_dev(h, k, costs.data_ptr()))
+                if want_costs:  # (one more launch: only a sharder that deals by cost asks for it)
+                    _lib.check(lib.vag_last_model_costs_dev(h, k, costs.data_ptr()))
             _on_current_stream(run)
             return values, costs
+        eval_dev.optional_costs = True
 
         class _Native:
             """The engine's own sharded call for dist.WalkerSharder: deal + this rank's block, then the scatter after the
