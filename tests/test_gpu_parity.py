@@ -1470,6 +1470,37 @@ def test_grids_beyond_the_lds_layouts_match_the_reference(eng, oracle, case):
     np.testing.assert_allclose(alone, got[1], rtol=1e-12)
 
 
+def test_a_fit_whose_walkers_need_the_third_grid_layout_scores_them(eng, oracle):
+    """Until round 5 a walker whose adaptive grid outgrew the grid kernel's LDS layouts scored -inf (VAG_E_CAPACITY inside a fit).  A
+    Fitter at resolution (0.06, 17, 6) gives every Gaussian-jet walker ~1400 theta nodes: the likelihood call lays the batch out with
+    the third layout itself (scratch in HBM) and every walker gets ln L -- the fitter's formula on the checker's fluxes."""
+    t, nu = configs.c4_mock_data()
+    truth = oracle.flux_density(_abi.make_params(**configs.C4_TRUTH), t, nu)
+    f = fitting.Fitter(z=configs.C4_TRUTH["z"], lumi_dist=configs.C4_TRUTH["lumi_dist"], jet="gaussian", medium="ism", resolution=(0.06, 17.0, 6.0))
+    for b in configs.C4_BANDS:
+        sel = nu == b
+        f.add_flux_density(b, t[sel], truth[sel], 0.1 * truth[sel])
+    defs = [fitting.ParamDef(n, 10.0 ** lo if lg else lo, 10.0 ** hi if lg else hi,
+                             fitting.Scale.log if lg else fitting.Scale.linear) for n, lg, lo, hi in configs.C4_FREE]
+    _, lo, hi = f.build_spec(defs)
+    samples = lo + (hi - lo) * np.random.default_rng(3).random((6, len(defs)))
+    got = f.loglike_batch(samples, defs)
+    lib, h = eng
+    pl = _lib.Plan()
+    lib.vag_last_plan(h, C.byref(pl))
+    assert pl.n_models_capacity == 0 and pl.n_models_ok == 6 and pl.n_rows > 6 * 1280 and np.all(np.isfinite(got))
+    f._consolidate_data()
+    for i, s in enumerate(samples):
+        kw = dict(configs.C4_TRUTH, resolutions=(0.06, 17.0, 6.0))
+        for (name, lg, _, _), v in zip(configs.C4_FREE, s):
+            kw[{"theta_v": "theta_obs"}.get(name, name)] = 10 ** v if lg else v
+        F = oracle.flux_density(_abi.make_params(**kw), f._all_t, f._all_nu)
+        want = -0.5 * np.sum(f._all_weights * ((f._all_log_flux - np.log(np.maximum(F, 1e-300))) / f._all_log_err) ** 2)
+        assert abs(got[i] - want) <= 1e-5 * max(1.0, abs(want)), (i, got[i], want)
+    for _ in range(9):  # (back to the small layout)
+        gpu_grid(eng, _abi.make_params(**configs.C1A), configs.C1_T, configs.C1_NU)
+
+
 def test_the_grid_kernels_third_layout_gives_the_bits_of_the_lds_layouts(eng):
     """The grid kernel's scratch arrays in HBM (VAG_GRID_FORCE_LARGE=2) instead of LDS: the same program, the same numbers -- every
     grid array and the fluxes of a mixed batch (all six jets, on and off axis) bit for bit; and, downstream of it, everything that is
